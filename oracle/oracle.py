@@ -1,0 +1,259 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes front-end of oracle/liboracle.so.
+
+CPU restatement of the reference hot path (see the headers under oracle/ for file:line citations).
+PARITY UNPINNED: /root/reference holds no golden vectors for this path (test/runtests.jl:1-5) and cannot
+run here (no Julia toolchain, third-party packages absent).  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module; the product path never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+c_fp = C.POINTER(C.c_float)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".hpp"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.po_create.restype = C.c_void_p
+        _LIB.po_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
+        _LIB.po_step_batch.restype = C.c_double
+    return _LIB
+
+
+def _d(a):
+    return a.ctypes.data_as(c_dp)
+
+
+def _arr(x, n=None):
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    if n is not None:
+        assert a.size == n, (a.size, n)
+    return a
+
+
+class Oracle:
+    """One coupled MPC problem family (N_short, N_long, dt's) on one trajectory."""
+
+    def __init__(self, N_short=10, N_long=20, dt_short=0.01, dt_long=0.2, use_correction_step=True, rk4_substeps=10):
+        self.L = lib()
+        self.h = C.c_void_p(self.L.po_create(N_short, N_long, dt_short, dt_long, int(use_correction_step), rk4_substeps))
+        self.Ns, self.Nl = N_short, N_long
+        self.N = N_short + N_long
+        self.Nn = self.N + 1
+        veh = np.zeros(22); cp = np.zeros(16); un = np.zeros(2)
+        self.L.po_get_params(self.h, _d(veh), _d(cp), _d(un))
+        self.veh, self.cp, self.u_norm = veh, cp, un
+        n = C.c_int(); m = C.c_int(); nnz = C.c_int()
+        self.L.po_qp_dims(self.h, C.byref(n), C.byref(m), C.byref(nnz))
+        self.n, self.m, self.nnz = n.value, m.value, nnz.value
+        self.sd_len = self.L.po_sd_len(self.h)
+
+    def __del__(self):
+        try:
+            self.L.po_destroy(self.h)
+        except Exception:
+            pass
+
+    VEH_FIELDS = ["G", "m", "Izz", "L", "a", "b", "h", "mu", "Caf", "Car", "Cd0", "Cd1", "Cd2", "fwd_frac", "rwd_frac", "fwb_frac",
+                  "rwb_frac", "Fx_max", "Fx_min", "Px_max", "delta_max", "kappa_max"]
+    CP_FIELDS = ["V_min", "V_max", "k_V", "k_s", "deltadot_max", "Q_ds", "Q_dpsi", "Q_e", "W_beta", "W_r", "W_HJI", "N_HJI", "R_delta",
+                 "R_ddelta", "R_Fx", "R_dFx"]
+
+    def vehicle(self):
+        return dict(zip(self.VEH_FIELDS, self.veh))
+
+    def control_params(self):
+        return dict(zip(self.CP_FIELDS, self.cp))
+
+    def set_control_params(self, **kw):
+        for k, v in kw.items():
+            self.cp[self.CP_FIELDS.index(k)] = v
+        self.L.po_set_control_params(self.h, _d(self.cp))
+
+    def set_hji_eps(self, eps):
+        self.L.po_set_hji_eps(self.h, C.c_double(eps))
+
+    # ---- data ----
+    def set_trajectory(self, traj12):
+        a = _arr(traj12)
+        assert a.ndim == 2 and a.shape[0] == 12
+        self.traj = a
+        self.L.po_set_trajectory(self.h, a.shape[1], _d(a))
+
+    def set_hji_grid(self, knots, V, gradV):
+        dims = np.array([len(k) for k in knots], dtype=np.int32)
+        kc = np.ascontiguousarray(np.concatenate(knots), dtype=np.float32)
+        Vf = np.ascontiguousarray(V, dtype=np.float32); gf = np.ascontiguousarray(gradV, dtype=np.float32)
+        assert Vf.size == int(np.prod(dims)) and gf.size == 7 * Vf.size
+        self.L.po_set_hji_grid(self.h, dims.ctypes.data_as(c_ip), kc.ctypes.data_as(c_fp), Vf.ctypes.data_as(c_fp), gf.ctypes.data_as(c_fp))
+
+    # ---- pieces ----
+    def time_steps(self, t0):
+        ts = np.zeros(self.Nn); dt = np.zeros(self.N)
+        self.L.po_time_steps(self.h, C.c_double(t0), _d(ts), _d(dt))
+        return ts, dt
+
+    def path_coordinates(self, E, N):
+        out = np.zeros(3); im = C.c_int()
+        self.L.po_path_coordinates(self.h, C.c_double(E), C.c_double(N), _d(out), C.byref(im))
+        return out[0], out[1], out[2], im.value
+
+    def traj_at_time(self, t):
+        o = np.zeros(12); self.L.po_traj_at_time(self.h, C.c_double(t), _d(o)); return o
+
+    def traj_at_s(self, s):
+        o = np.zeros(12); self.L.po_traj_at_s(self.h, C.c_double(s), _d(o)); return o
+
+    def tracking_dynamics(self, q, u, p):
+        o = np.zeros(6); self.L.po_tracking_dynamics(self.h, _d(_arr(q, 6)), _d(_arr(u, 2)), _d(_arr(p, 4)), _d(o)); return o
+
+    def world_dynamics(self, q, u):
+        o = np.zeros(6); self.L.po_world_dynamics(self.h, _d(_arr(q, 6)), _d(_arr(u, 2)), _d(o)); return o
+
+    def stable_limits(self, Ux, Fxf, Fxr):
+        o = np.zeros(14); self.L.po_stable_limits(self.h, C.c_double(Ux), C.c_double(Fxf), C.c_double(Fxr), _d(o))
+        return o[0], o[1], o[2:10].reshape(4, 2), o[10:14]
+
+    def steady_state(self, V, A_tan, kappa, num_iters=4, r=None, beta0=0.0, delta0=0.0, Fyf0=0.0):
+        o = np.zeros(8)
+        r = V * kappa if r is None else r
+        self.L.po_steady_state(self.h, C.c_double(V), C.c_double(A_tan), C.c_double(kappa), num_iters, C.c_double(r), C.c_double(beta0),
+                               C.c_double(delta0), C.c_double(Fyf0), _d(o))
+        return dict(zip(["beta", "Ux", "Uy", "r", "A", "delta", "Fxf", "Fxr"], o))
+
+    def linearize_interval(self, q, u0, p0, uf, pf, dt, ramp):
+        A = np.zeros((6, 6)); B0 = np.zeros((6, 2)); Bf = np.zeros((6, 2)); c = np.zeros(6)
+        self.L.po_linearize_interval(self.h, _d(_arr(q, 6)), _d(_arr(u0, 2)), _d(_arr(p0, 4)), _d(_arr(uf, 2)), _d(_arr(pf, 4)), C.c_double(dt),
+                                     int(ramp), _d(A), _d(B0), _d(Bf), _d(c))
+        return A, B0, Bf, c
+
+    def propagate_tracking(self, q, u0, p0, uf, pf, dt, ramp):
+        x = _arr(q, 6).copy()
+        self.L.po_propagate_tracking(self.h, _d(x), _d(_arr(u0, 2)), _d(_arr(p0, 4)), _d(_arr(uf, 2)), _d(_arr(pf, 4)), C.c_double(dt), int(ramp))
+        return x
+
+    def plant_step(self, q6, u3, dt):
+        x = _arr(q6, 6).copy(); self.L.po_plant_step(self.h, _d(x), _d(_arr(u3, 3)), C.c_double(dt)); return x
+
+    def next_control(self, u2n):
+        o = np.zeros(3); self.L.po_next_control(self.h, _d(_arr(u2n, 2)), _d(o)); return o
+
+    def hji_relative_state(self, us6, them4):
+        o = np.zeros(7); self.L.po_hji_relative_state(_d(_arr(us6, 6)), _d(_arr(them4, 4)), _d(o)); return o
+
+    def hji_lookup(self, x7):
+        V = C.c_double(); g = np.zeros(7)
+        inb = self.L.po_hji_lookup(self.h, _d(_arr(x7, 7)), C.byref(V), _d(g))
+        return V.value, g, bool(inb)
+
+    def hji_constraint(self, state6, other4, control3):
+        M = np.zeros(2); b = C.c_double(); V = C.c_double()
+        self.L.po_hji_constraint(self.h, _d(_arr(state6, 6)), _d(_arr(other4, 4)), _d(_arr(control3, 3)), _d(M), C.byref(b), C.byref(V))
+        return M, b.value, V.value
+
+    def nodes(self, state6, control3, ts, dt, time_offset=float("nan"), solved=False, prev_ts=None, prev_q=None, prev_u=None):
+        qs = np.zeros((self.Nn, 6)); us = np.zeros((self.Nn, 2)); ps = np.zeros((self.Nn, 4))
+        pt = _arr(prev_ts, self.Nn) if prev_ts is not None else None
+        pq = _arr(prev_q, 6 * self.Nn) if prev_q is not None else None
+        pu = _arr(prev_u, 2 * self.Nn) if prev_u is not None else None
+        self.L.po_nodes(self.h, _d(_arr(state6, 6)), _d(_arr(control3, 3)), C.c_double(time_offset), int(solved), _d(_arr(ts, self.Nn)),
+                        _d(_arr(dt, self.N)), _d(pt) if pt is not None else None, _d(pq) if pq is not None else None,
+                        _d(pu) if pu is not None else None, _d(qs), _d(us), _d(ps))
+        return qs, us, ps
+
+    def update_qp(self, qs, us, ps, dt, state6, control3, other4=(0, 0, 0, 0)):
+        sd = np.zeros(self.sd_len); V = C.c_double()
+        self.L.po_update_qp(self.h, _d(_arr(qs, 6 * self.Nn)), _d(_arr(us, 2 * self.Nn)), _d(_arr(ps, 4 * self.Nn)), _d(_arr(dt, self.N)),
+                            _d(_arr(state6, 6)), _d(_arr(control3, 3)), _d(_arr(other4, 4)), _d(sd), C.byref(V))
+        return sd
+
+    def unpack_sd(self, sd):
+        N = self.N; o = 0; out = {}
+        for name, sz, shp in [("A", 36, (N, 6, 6)), ("B0", 12, (N, 6, 2)), ("Bf", 12, (N, 6, 2)), ("c", 6, (N, 6)), ("H", 8, (N, 4, 2)), ("G", 4, (N, 4)),
+                              ("dmin", 1, (N,)), ("dmax", 1, (N,)), ("fxmax", 1, (N,)), ("ddmin", 1, (N,)), ("ddmax", 1, (N,)), ("dt", 1, (N,))]:
+            out[name] = sd[o:o + sz * N].reshape(shp); o += sz * N
+        out["q_curr"] = sd[o:o + 6]; o += 6; out["u_curr"] = sd[o:o + 2]; o += 2; out["M_hji"] = sd[o:o + 2]; o += 2; out["b_hji"] = sd[o]
+        return out
+
+    def pack_sd(self, d):
+        return np.concatenate([np.ravel(d[k]) for k in ["A", "B0", "Bf", "c", "H", "G", "dmin", "dmax", "fxmax", "ddmin", "ddmax", "dt", "q_curr", "u_curr",
+                                                        "M_hji"]] + [np.atleast_1d(d["b_hji"])]).astype(np.float64)
+
+    def assemble_qp(self, sd):
+        Pd = np.zeros(self.n); q = np.zeros(self.n); Ap = np.zeros(self.n + 1, dtype=np.int32); Ai = np.zeros(self.nnz, dtype=np.int32)
+        Ax = np.zeros(self.nnz); l = np.zeros(self.m); u = np.zeros(self.m)
+        self.L.po_assemble_qp(self.h, _d(_arr(sd, self.sd_len)), _d(Pd), _d(q), Ap.ctypes.data_as(c_ip), Ai.ctypes.data_as(c_ip), _d(Ax), _d(l), _d(u))
+        return dict(Pd=Pd, q=q, Ap=Ap, Ai=Ai, Ax=Ax, l=l, u=u)
+
+    def solve_exact(self, sd):
+        x = np.zeros(self.n); y = np.zeros(self.m); info = np.zeros(5)
+        st = self.L.po_solve_exact(self.h, _d(_arr(sd, self.sd_len)), _d(x), _d(y), _d(info))
+        return x, y, dict(iters=int(info[0]), status=int(info[1]), res_pri=info[2], res_dua=info[3], gap=info[4])
+
+    def osqp_settings(self, rho=0.1, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_iter=4000, scaling=10, check_termination=25,
+                      adaptive_rho=1, adaptive_rho_interval=25, warm_start=1):
+        self.L.po_osqp_settings(self.h, C.c_double(rho), C.c_double(sigma), C.c_double(alpha), C.c_double(eps_abs), C.c_double(eps_rel), max_iter,
+                                scaling, check_termination, adaptive_rho, adaptive_rho_interval, warm_start)
+
+    def osqp_solve(self, sd, inst=0):
+        x = np.zeros(self.n); y = np.zeros(self.m); info = np.zeros(6)
+        st = self.L.po_osqp_solve(self.h, inst, _d(_arr(sd, self.sd_len)), _d(x), _d(y), _d(info))
+        return x, y, dict(iters=int(info[0]), status=int(info[1]), res_pri=info[2], res_dua=info[3], rho=info[4], n_refactor=int(info[5]))
+
+    def reset_instance(self, inst):
+        self.L.po_reset_instance(self.h, inst)
+
+    def split_x(self, x):
+        Nn, N, Ns = self.Nn, self.N, self.Ns
+        o = 0; q = x[o:o + 6 * Nn].reshape(Nn, 6); o += 6 * Nn
+        u = x[o:o + 2 * Nn].reshape(Nn, 2); o += 2 * Nn
+        sg = x[o:o + 2 * N].reshape(N, 2); o += 2 * N
+        sh = x[o:o + Ns]; o += Ns
+        dd = x[o:o + N]; o += N
+        df = x[o:o + N]
+        return dict(q=q, u=u, sigma=sg, sigma_hji=sh, ddelta=dd, dFx=df)
+
+    def step_batch(self, states6, controls3, t0, others4=None, time_offsets=None, solver=0, nthreads=1, want_sol=False):
+        B = len(t0)
+        s = _arr(states6, 6 * B); c = _arr(controls3, 3 * B); t = _arr(t0, B)
+        o = _arr(others4, 4 * B) if others4 is not None else None
+        to = _arr(time_offsets, B) if time_offsets is not None else None
+        u = np.zeros((B, 3)); sol = np.zeros((B, 8 * self.Nn)) if want_sol else None
+        it = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32)
+        secs = self.L.po_step_batch(self.h, B, _d(s), _d(c), _d(t), _d(o) if o is not None else None, _d(to) if to is not None else None, solver, nthreads,
+                                    _d(u), _d(sol) if sol is not None else None, it.ctypes.data_as(c_ip), st.ctypes.data_as(c_ip))
+        return u, sol, it, st, secs
+
+
+def active_set(qp, x, y, tol=1e-7):
+    """Index list of active inequality rows from an (x, y) pair of the canonical QP: +(i+1) upper-active, -(i+1) lower-active.
+    Equality rows (l == u) are excluded.  A row is active when its multiplier exceeds `tol` in magnitude."""
+    out = []
+    for i in range(len(y)):
+        if qp["l"][i] == qp["u"][i]:
+            continue
+        if y[i] > tol:
+            out.append(i + 1)
+        elif y[i] < -tol:
+            out.append(-(i + 1))
+    return out

@@ -1,0 +1,511 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. Not part of the shipped product path.
+// (1) Canonical assembly of the coupled tracking QP exactly as construct_coupled_tracking_QP states it
+//     (/root/reference/src/coupled_lat_long.jl:233-309): variable order = Variable creation order
+//     (q 6x(N+1) column-major, u 2x(N+1), sigma 2xN, sigma_HJI Ns, d_delta N, d_Fx N), row order = order of
+//     the @constraint statements (C1..C13 of SURVEY.md section 8a).  OSQP form: min 1/2 x'Px + q'x, l <= Ax <= u.
+// (2) A static-pattern sparse LDL' (own code) used by both solvers below.
+// (3) `OSQPPort`: restatement of the ADMM algorithm of OSQP (the solver behind solve!,
+//     model_predictive_control.jl:76 -> Parametron 0.4.0 -> OSQP.jl 0.4.0 -> libosqp; third-party, absent from
+//     /root/reference; algorithm as published in Stellato et al., "OSQP: an operator splitting solver for
+//     quadratic programs", with the library defaults named in SURVEY.md 8c).  This is the CPU baseline
+//     ("kind": "port").  Deliberate deviation: adaptive-rho runs on a fixed iteration cadence
+//     (adaptive_rho_interval, default 25 = check_termination) instead of OSQP's wall-clock-derived interval.
+// (4) `solve_exact`: a primal-dual interior-point method on the same canonical (P,q,A,l,u) that returns the
+//     optimum to ~1e-10; it is the parity target for the GPU path ("exact optimum of the same QP data").
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <set>
+#include <vector>
+#include "mpc_coupled.hpp"
+
+namespace po {
+
+static const double QP_INF = 1e20;    // OSQP_INFTY of the 0.4.x library
+
+struct QP {
+    int n = 0, m = 0;
+    std::vector<double> Pd, q;         // P is diagonal (coupled_lat_long.jl:301-308)
+    std::vector<int> Ap, Ai;           // CSC
+    std::vector<double> Ax, l, u;
+};
+
+struct CoupledQPLayout {
+    int Ns = 0, Nl = 0, N = 0, n = 0, m = 0;
+    int o_q, o_u, o_s, o_sh, o_dd, o_df;                 // variable offsets
+    int r_C1, r_C2, r_C3, r_C4, r_C5, r_C6, r_C7, r_C8, r_C9, r_C10, r_C11, r_C12, r_C13;   // row offsets
+    std::vector<int> Ap, Ai, pos;                         // pos[e] = CSC slot of the e-th emitted coefficient
+    std::vector<std::pair<int, int>> emitted;
+
+    int vq(int i, int t) const { return o_q + 6 * t + i; }
+    int vu(int i, int t) const { return o_u + 2 * t + i; }
+    int vs(int i, int k) const { return o_s + 2 * k + i; }
+
+    template <class F> void walk(const StageData* sd, F emit) const {
+        // C1, C2
+        for (int j = 0; j < 2 * N; j++) emit(r_C1 + j, o_s + j, 1.0);
+        for (int t = 0; t < Ns; t++) emit(r_C2 + t, o_sh + t, 1.0);
+        // C3, C4: diff(delta) == d_delta, diff(Fx) == d_Fx
+        for (int k = 0; k < N; k++) { emit(r_C3 + k, vu(0, k + 1), 1.0); emit(r_C3 + k, vu(0, k), -1.0); emit(r_C3 + k, o_dd + k, -1.0); }
+        for (int k = 0; k < N; k++) { emit(r_C4 + k, vu(1, k + 1), 1.0); emit(r_C4 + k, vu(1, k), -1.0); emit(r_C4 + k, o_df + k, -1.0); }
+        // C5, C6, C7
+        for (int t = 0; t <= N; t++) emit(r_C5 + t, vq(1, t), 1.0);
+        for (int t = 0; t <= N; t++) emit(r_C6 + t, vq(1, t), 1.0);
+        for (int t = 0; t <= N; t++) emit(r_C7 + t, vu(1, t), 1.0);
+        // C8, C9
+        for (int i = 0; i < 6; i++) emit(r_C8 + i, vq(i, 0), 1.0);
+        for (int i = 0; i < 2; i++) emit(r_C9 + i, vu(i, 0), 1.0);
+        // C10: A q_t + B u_t + c == q_{t+1}   (dense parameter matrices => all 36+12 entries structural)
+        for (int t = 0; t < Ns; t++) for (int i = 0; i < 6; i++) {
+            int r = r_C10 + 6 * t + i;
+            for (int j = 0; j < 6; j++) emit(r, vq(j, t), sd ? sd->A[36 * t + 6 * i + j] : 1.0);
+            for (int j = 0; j < 2; j++) emit(r, vu(j, t), sd ? sd->B0[12 * t + 2 * i + j] : 1.0);
+            emit(r, vq(i, t + 1), -1.0);
+        }
+        // C11: M u_t + b + sigma_HJI_t >= 0
+        for (int t = 0; t < Ns; t++) { for (int j = 0; j < 2; j++) emit(r_C11 + t, vu(j, t), sd ? sd->M_hji[j] : 1.0); emit(r_C11 + t, o_sh + t, 1.0); }
+        // C12
+        for (int t = Ns; t < N; t++) for (int i = 0; i < 6; i++) {
+            int r = r_C12 + 6 * (t - Ns) + i;
+            for (int j = 0; j < 6; j++) emit(r, vq(j, t), sd ? sd->A[36 * t + 6 * i + j] : 1.0);
+            for (int j = 0; j < 2; j++) emit(r, vu(j, t), sd ? sd->B0[12 * t + 2 * i + j] : 1.0);
+            for (int j = 0; j < 2; j++) emit(r, vu(j, t + 1), sd ? sd->Bf[12 * t + 2 * i + j] : 1.0);
+            emit(r, vq(i, t + 1), -1.0);
+        }
+        // C13
+        for (int t = 0; t < N; t++) {
+            int r = r_C13 + 9 * t;
+            emit(r + 0, vu(0, t + 1), 1.0);
+            emit(r + 1, vu(0, t + 1), 1.0);
+            emit(r + 2, vu(1, t + 1), 1.0);
+            for (int i = 0; i < 4; i++) {
+                emit(r + 3 + i, vq(2, t + 1), sd ? sd->H[8 * t + 2 * i] : 1.0);
+                emit(r + 3 + i, vq(3, t + 1), sd ? sd->H[8 * t + 2 * i + 1] : 1.0);
+                emit(r + 3 + i, vs(i / 2, t), -1.0);
+            }
+            emit(r + 7, o_dd + t, 1.0);
+            emit(r + 8, o_dd + t, 1.0);
+        }
+    }
+
+    void build(int ns, int nl) {
+        Ns = ns; Nl = nl; N = ns + nl;
+        o_q = 0; o_u = 6 * (N + 1); o_s = 8 * (N + 1); o_sh = o_s + 2 * N; o_dd = o_sh + Ns; o_df = o_dd + N; n = o_df + N;
+        r_C1 = 0; r_C2 = r_C1 + 2 * N; r_C3 = r_C2 + Ns; r_C4 = r_C3 + N; r_C5 = r_C4 + N; r_C6 = r_C5 + N + 1; r_C7 = r_C6 + N + 1;
+        r_C8 = r_C7 + N + 1; r_C9 = r_C8 + 6; r_C10 = r_C9 + 2; r_C11 = r_C10 + 6 * Ns; r_C12 = r_C11 + Ns; r_C13 = r_C12 + 6 * Nl; m = r_C13 + 9 * N;
+        emitted.clear();
+        walk(nullptr, [&](int r, int c, double) { emitted.push_back({r, c}); });
+        int nnz = (int)emitted.size();
+        std::vector<int> order(nnz);
+        for (int e = 0; e < nnz; e++) order[e] = e;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return emitted[a].second != emitted[b].second ? emitted[a].second < emitted[b].second : emitted[a].first < emitted[b].first; });
+        Ap.assign(n + 1, 0); Ai.resize(nnz); pos.resize(nnz);
+        for (int k = 0; k < nnz; k++) { int e = order[k]; Ai[k] = emitted[e].first; Ap[emitted[e].second + 1]++; pos[e] = k; }
+        for (int j = 0; j < n; j++) Ap[j + 1] += Ap[j];
+    }
+
+    void fill(const StageData& sd, const CoupledControlParams& cp, const VehicleParams& veh, const double u_norm[2], QP& qp) const {
+        qp.n = n; qp.m = m; qp.Ap = Ap; qp.Ai = Ai; qp.Ax.assign(Ai.size(), 0.0);
+        int e = 0;
+        walk(&sd, [&](int, int, double v) { qp.Ax[pos[e++]] = v; });
+        qp.Pd.assign(n, 0.0); qp.q.assign(n, 0.0); qp.l.assign(m, -QP_INF); qp.u.assign(m, QP_INF);
+        // objective (:294-309, no 1/2 => P = 2 diag)
+        for (int k = 0; k < N; k++) {
+            double dt = sd.dt[k];
+            qp.Pd[vq(0, k + 1)] = 2 * cp.Q_ds * dt; qp.Pd[vq(4, k + 1)] = 2 * cp.Q_dpsi * dt; qp.Pd[vq(5, k + 1)] = 2 * cp.Q_e * dt;
+            qp.Pd[vu(0, k + 1)] = 2 * cp.R_delta * dt; qp.Pd[vu(1, k + 1)] = 2 * cp.R_Fx * dt;
+            qp.Pd[o_dd + k] = 2 * cp.R_ddelta / dt; qp.Pd[o_df + k] = 2 * cp.R_dFx / dt;
+            qp.q[vs(0, k)] = cp.W_beta * dt; qp.q[vs(1, k)] = cp.W_r * dt;
+        }
+        for (int t = 0; t < Ns; t++) qp.q[o_sh + t] = (t < cp.N_HJI) ? cp.W_HJI : 0.0;      // :344
+        // bounds
+        for (int j = 0; j < 2 * N; j++) qp.l[r_C1 + j] = 0;
+        for (int t = 0; t < Ns; t++) qp.l[r_C2 + t] = 0;
+        for (int k = 0; k < N; k++) { qp.l[r_C3 + k] = qp.u[r_C3 + k] = 0; qp.l[r_C4 + k] = qp.u[r_C4 + k] = 0; }
+        for (int t = 0; t <= N; t++) { qp.l[r_C5 + t] = cp.V_min; qp.u[r_C6 + t] = cp.V_max; qp.l[r_C7 + t] = veh.Fx_min / u_norm[1]; }
+        for (int i = 0; i < 6; i++) qp.l[r_C8 + i] = qp.u[r_C8 + i] = sd.q_curr[i];
+        for (int i = 0; i < 2; i++) qp.l[r_C9 + i] = qp.u[r_C9 + i] = sd.u_curr[i];
+        for (int t = 0; t < Ns; t++) for (int i = 0; i < 6; i++) qp.l[r_C10 + 6 * t + i] = qp.u[r_C10 + 6 * t + i] = -sd.c[6 * t + i];
+        for (int t = 0; t < Ns; t++) qp.l[r_C11 + t] = -sd.b_hji;
+        for (int t = Ns; t < N; t++) for (int i = 0; i < 6; i++) qp.l[r_C12 + 6 * (t - Ns) + i] = qp.u[r_C12 + 6 * (t - Ns) + i] = -sd.c[6 * t + i];
+        for (int t = 0; t < N; t++) {
+            int r = r_C13 + 9 * t;
+            qp.u[r + 0] = sd.dmax[t]; qp.l[r + 1] = sd.dmin[t]; qp.u[r + 2] = sd.fxmax[t];
+            for (int i = 0; i < 4; i++) qp.u[r + 3 + i] = sd.G[4 * t + i];
+            qp.u[r + 7] = sd.ddmax[t]; qp.l[r + 8] = sd.ddmin[t];
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// Static-pattern sparse LDL' for symmetric quasi-definite matrices.
+struct LDLSymbolic {
+    int n = 0;
+    std::vector<int> perm, iperm;                 // perm[new] = old
+    std::vector<int> Lp, Li;                      // strictly-lower pattern of L, CSC, sorted rows
+    std::vector<int> up, ui;                      // per column: target slots of the rank-1 update (see numeric)
+    std::vector<int> ent_slot;                    // for each input entry: >=0 -> Lx slot, <0 -> diagonal -(k+1)
+    // entries: list of (i,j) of the symmetric matrix (either triangle, each off-diagonal pair once), all diagonals present
+    void analyse(int n_, const std::vector<std::pair<int, int>>& entries) {
+        n = n_;
+        std::vector<std::set<int>> adj(n);
+        for (auto& e : entries) if (e.first != e.second) { adj[e.first].insert(e.second); adj[e.second].insert(e.first); }
+        // minimum-degree ordering by explicit elimination
+        perm.assign(n, 0); iperm.assign(n, -1);
+        std::vector<char> done(n, 0);
+        {
+            std::vector<std::set<int>> g = adj;
+            for (int k = 0; k < n; k++) {
+                int best = -1; size_t bd = (size_t)-1;
+                for (int v = 0; v < n; v++) if (!done[v] && g[v].size() < bd) { bd = g[v].size(); best = v; }
+                perm[k] = best; iperm[best] = k; done[best] = 1;
+                std::vector<int> nb(g[best].begin(), g[best].end());
+                for (int a : nb) g[a].erase(best);
+                for (size_t x = 0; x < nb.size(); x++) for (size_t y = x + 1; y < nb.size(); y++) { g[nb[x]].insert(nb[y]); g[nb[y]].insert(nb[x]); }
+                g[best].clear();
+            }
+        }
+        // symbolic factorisation on the permuted pattern
+        std::vector<std::set<int>> col(n);
+        for (auto& e : entries) if (e.first != e.second) { int a = iperm[e.first], b = iperm[e.second]; col[std::min(a, b)].insert(std::max(a, b)); }
+        for (int j = 0; j < n; j++) {
+            if (col[j].empty()) continue;
+            int parent = *col[j].begin();
+            for (int r : col[j]) if (r != parent) col[parent].insert(r);
+        }
+        Lp.assign(n + 1, 0);
+        for (int j = 0; j < n; j++) Lp[j + 1] = Lp[j] + (int)col[j].size();
+        Li.resize(Lp[n]);
+        for (int j = 0; j < n; j++) { int p = Lp[j]; for (int r : col[j]) Li[p++] = r; }
+        auto slot = [&](int r, int c) { const int* b = &Li[Lp[c]]; const int* e = &Li[Lp[c + 1]]; const int* it = std::lower_bound(b, e, r); return (int)(it - &Li[0]); };
+        up.assign(n + 1, 0);
+        for (int j = 0; j < n; j++) { int cnt = Lp[j + 1] - Lp[j]; up[j + 1] = up[j] + cnt * (cnt - 1) / 2; }
+        ui.resize(up[n]);
+        for (int j = 0; j < n; j++) {
+            int w = up[j];
+            for (int a = Lp[j]; a < Lp[j + 1]; a++) for (int b = Lp[j]; b < a; b++) ui[w++] = slot(Li[a], Li[b]);
+        }
+        ent_slot.resize(entries.size());
+        for (size_t e = 0; e < entries.size(); e++) {
+            int a = iperm[entries[e].first], b = iperm[entries[e].second];
+            if (a == b) ent_slot[e] = -(a + 1);
+            else ent_slot[e] = slot(std::max(a, b), std::min(a, b));
+        }
+    }
+};
+
+struct LDLNumeric {
+    const LDLSymbolic* S = nullptr;
+    std::vector<double> Lx, D, w;
+    void init(const LDLSymbolic* s) { S = s; Lx.assign(s->Li.size(), 0); D.assign(s->n, 0); w.assign(s->n, 0); }
+    // vals aligned with the `entries` list given to analyse()
+    bool factor(const double* vals, size_t nvals) {
+        std::fill(Lx.begin(), Lx.end(), 0.0); std::fill(D.begin(), D.end(), 0.0);
+        for (size_t e = 0; e < nvals; e++) { int s = S->ent_slot[e]; if (s < 0) D[-s - 1] += vals[e]; else Lx[s] += vals[e]; }
+        const int n = S->n; const int *Lp = S->Lp.data(), *Li = S->Li.data(), *up = S->up.data(), *ui = S->ui.data();
+        for (int j = 0; j < n; j++) {
+            double d = D[j];
+            if (d == 0.0 || std::isnan(d)) return false;
+            double inv = 1.0 / d;
+            int w0 = up[j];
+            for (int a = Lp[j]; a < Lp[j + 1]; a++) {
+                double la = Lx[a] * inv;
+                for (int b = Lp[j]; b < a; b++) Lx[ui[w0++]] -= la * Lx[b];     // (row_a, row_b) -= L_a d L_b, Lx[b] still unscaled
+                D[Li[a]] -= la * Lx[a];
+            }
+            for (int a = Lp[j]; a < Lp[j + 1]; a++) Lx[a] *= inv;
+        }
+        return true;
+    }
+    void solve(double* b) {     // in place, b in ORIGINAL ordering
+        const int n = S->n; const int *Lp = S->Lp.data(), *Li = S->Li.data();
+        for (int k = 0; k < n; k++) w[k] = b[S->perm[k]];
+        for (int j = 0; j < n; j++) { double y = w[j]; for (int a = Lp[j]; a < Lp[j + 1]; a++) w[Li[a]] -= Lx[a] * y; }
+        for (int j = 0; j < n; j++) w[j] /= D[j];
+        for (int j = n - 1; j >= 0; j--) { double y = w[j]; for (int a = Lp[j]; a < Lp[j + 1]; a++) y -= Lx[a] * w[Li[a]]; w[j] = y; }
+        for (int k = 0; k < n; k++) b[S->perm[k]] = w[k];
+    }
+};
+
+// KKT pattern [[P+sI, A'],[A, -D]] for a QP pattern; entries: n+m diagonals first, then A's nnz in CSC order.
+struct KKTPattern {
+    LDLSymbolic sym;
+    int n = 0, m = 0, nnzA = 0;
+    void build(int n_, int m_, const std::vector<int>& Ap, const std::vector<int>& Ai) {
+        n = n_; m = m_; nnzA = (int)Ai.size();
+        std::vector<std::pair<int, int>> ent;
+        for (int i = 0; i < n + m; i++) ent.push_back({i, i});
+        for (int j = 0; j < n; j++) for (int p = Ap[j]; p < Ap[j + 1]; p++) ent.push_back({n + Ai[p], j});
+        sym.analyse(n + m, ent);
+    }
+};
+
+inline double vnorm_inf(const double* v, int n) { double r = 0; for (int i = 0; i < n; i++) r = std::max(r, std::fabs(v[i])); return r; }
+inline void A_mul(const QP& qp, const double* Ax, const double* x, double* out) {
+    for (int i = 0; i < qp.m; i++) out[i] = 0;
+    for (int j = 0; j < qp.n; j++) { double xj = x[j]; for (int p = qp.Ap[j]; p < qp.Ap[j + 1]; p++) out[qp.Ai[p]] += Ax[p] * xj; }
+}
+inline void At_mul(const QP& qp, const double* Ax, const double* y, double* out) {
+    for (int j = 0; j < qp.n; j++) { double s = 0; for (int p = qp.Ap[j]; p < qp.Ap[j + 1]; p++) s += Ax[p] * y[qp.Ai[p]]; out[j] = s; }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+struct OSQPSettings {
+    double rho = 0.1, sigma = 1e-6, alpha = 1.6, eps_abs = 1e-3, eps_rel = 1e-3;
+    int max_iter = 4000, scaling = 10, check_termination = 25, adaptive_rho = 1, adaptive_rho_interval = 25;
+    double adaptive_rho_tolerance = 5.0;
+    int warm_start = 1;
+};
+
+struct OSQPPort {
+    const KKTPattern* K = nullptr;
+    OSQPSettings st;
+    LDLNumeric ldl;
+    double rho;                                   // persists across solves like work->settings->rho
+    std::vector<double> x, y, z;                  // UNSCALED warm-start iterates (x, y) kept between solves
+    bool have_warm = false;
+    int last_iters = 0, last_status = 0, n_refactor = 0;
+    double last_pri = 0, last_dua = 0;
+    // scaled problem
+    std::vector<double> D, E, Pd, q, Ax, l, u, rho_vec, kkt_vals;
+    double c = 1;
+
+    void init(const KKTPattern* k, const OSQPSettings& s) { K = k; st = s; ldl.init(&k->sym); rho = s.rho; have_warm = false; }
+    void reset() { rho = st.rho; have_warm = false; }    // Parametron.initialize! (Pigeon.jl:45-46, ros_integration.jl:146)
+
+    static double lim(double v) { const double MINS = 1e-4, MAXS = 1e4; return v < MINS ? 1.0 : (v > MAXS ? MAXS : v); }
+
+    void scale(const QP& qp) {
+        int n = qp.n, m = qp.m;
+        D.assign(n, 1.0); E.assign(m, 1.0); c = 1.0;
+        Pd = qp.Pd; q = qp.q; Ax = qp.Ax; l = qp.l; u = qp.u;
+        std::vector<double> dn(n), en(m);
+        for (int it = 0; it < st.scaling; it++) {
+            for (int j = 0; j < n; j++) dn[j] = std::fabs(Pd[j]);
+            for (int i = 0; i < m; i++) en[i] = 0;
+            for (int j = 0; j < n; j++) for (int p = qp.Ap[j]; p < qp.Ap[j + 1]; p++) { double a = std::fabs(Ax[p]); dn[j] = std::max(dn[j], a); en[qp.Ai[p]] = std::max(en[qp.Ai[p]], a); }
+            for (int j = 0; j < n; j++) dn[j] = 1.0 / std::sqrt(lim(dn[j]));
+            for (int i = 0; i < m; i++) en[i] = 1.0 / std::sqrt(lim(en[i]));
+            for (int j = 0; j < n; j++) { Pd[j] *= dn[j] * dn[j]; q[j] *= dn[j]; for (int p = qp.Ap[j]; p < qp.Ap[j + 1]; p++) Ax[p] *= dn[j] * en[qp.Ai[p]]; D[j] *= dn[j]; }
+            for (int i = 0; i < m; i++) E[i] *= en[i];
+            double avg = 0; for (int j = 0; j < n; j++) avg += std::fabs(Pd[j]); avg /= n;
+            double qn = vnorm_inf(q.data(), n);
+            double ct = 1.0 / lim(std::max(avg, lim(qn)));     // cost scaling: max(mean column norm of P, limited |q|_inf), limited, inverted
+            for (int j = 0; j < n; j++) { Pd[j] *= ct; q[j] *= ct; }
+            c *= ct;
+        }
+        for (int i = 0; i < m; i++) { l[i] = qp.l[i] <= -QP_INF ? -QP_INF : qp.l[i] * E[i]; u[i] = qp.u[i] >= QP_INF ? QP_INF : qp.u[i] * E[i]; }
+    }
+    void set_rho_vec(const QP& qp) {
+        rho_vec.resize(qp.m);
+        for (int i = 0; i < qp.m; i++) {
+            if (l[i] <= -QP_INF * 1e-4 && u[i] >= QP_INF * 1e-4) rho_vec[i] = 1e-6;
+            else if (std::fabs(u[i] - l[i]) < 1e-4) rho_vec[i] = 1e3 * rho;
+            else rho_vec[i] = rho;
+        }
+    }
+    bool refactor(const QP& qp) {
+        int n = qp.n, m = qp.m;
+        kkt_vals.resize(n + m + Ax.size());
+        for (int j = 0; j < n; j++) kkt_vals[j] = Pd[j] + st.sigma;
+        for (int i = 0; i < m; i++) kkt_vals[n + i] = -1.0 / rho_vec[i];
+        for (size_t p = 0; p < Ax.size(); p++) kkt_vals[n + m + p] = Ax[p];
+        n_refactor++;
+        return ldl.factor(kkt_vals.data(), kkt_vals.size());
+    }
+
+    // returns status: 1 solved, -2 max iterations, -10 numerical failure
+    int solve(const QP& qp) {
+        const int n = qp.n, m = qp.m;
+        scale(qp);
+        set_rho_vec(qp);
+        if (!refactor(qp)) return last_status = -10;
+        std::vector<double> xs(n, 0.0), zs(m, 0.0), ys(m, 0.0), xp(n), zp(m), rhs(n + m), tmpm(m), tmpn(n), tmpn2(n);
+        if (st.warm_start && have_warm) {
+            for (int j = 0; j < n; j++) xs[j] = x[j] / D[j];
+            for (int i = 0; i < m; i++) ys[i] = y[i] * c / E[i];
+            A_mul(qp, Ax.data(), xs.data(), zs.data());
+        }
+        int iter = 0, status = -2;
+        auto residuals = [&](double& pri, double& dua, double& eps_pri, double& eps_dua, double& rho_est) {
+            A_mul(qp, Ax.data(), xs.data(), tmpm.data());                 // A x (scaled)
+            double pri_s = 0, nAx_s = 0, nz_s = 0, pri_u = 0, nAx_u = 0, nz_u = 0;
+            for (int i = 0; i < m; i++) {
+                double r = tmpm[i] - zs[i];
+                pri_s = std::max(pri_s, std::fabs(r)); nAx_s = std::max(nAx_s, std::fabs(tmpm[i])); nz_s = std::max(nz_s, std::fabs(zs[i]));
+                pri_u = std::max(pri_u, std::fabs(r / E[i])); nAx_u = std::max(nAx_u, std::fabs(tmpm[i] / E[i])); nz_u = std::max(nz_u, std::fabs(zs[i] / E[i]));
+            }
+            At_mul(qp, Ax.data(), ys.data(), tmpn.data());                // A' y (scaled)
+            double dua_s = 0, nPx_s = 0, nAty_s = 0, nq_s = 0, dua_u = 0, nPx_u = 0, nAty_u = 0, nq_u = 0;
+            for (int j = 0; j < n; j++) {
+                double Px = Pd[j] * xs[j];
+                double r = Px + q[j] + tmpn[j];
+                dua_s = std::max(dua_s, std::fabs(r)); nPx_s = std::max(nPx_s, std::fabs(Px)); nAty_s = std::max(nAty_s, std::fabs(tmpn[j])); nq_s = std::max(nq_s, std::fabs(q[j]));
+                dua_u = std::max(dua_u, std::fabs(r / D[j])); nPx_u = std::max(nPx_u, std::fabs(Px / D[j])); nAty_u = std::max(nAty_u, std::fabs(tmpn[j] / D[j])); nq_u = std::max(nq_u, std::fabs(q[j] / D[j]));
+            }
+            pri = pri_u; dua = dua_u / c;
+            eps_pri = st.eps_abs + st.eps_rel * std::max(nAx_u, nz_u);
+            eps_dua = st.eps_abs + st.eps_rel * std::max(std::max(nPx_u, nAty_u), nq_u) / c;
+            double pn = pri_s / (std::max(nAx_s, nz_s) + 1e-10);
+            double dn_ = dua_s / (std::max(std::max(nPx_s, nAty_s), nq_s) + 1e-10);
+            rho_est = rho * std::sqrt(pn / (dn_ + 1e-10));
+            rho_est = std::min(std::max(rho_est, 1e-6), 1e6);
+        };
+        double pri = 0, dua = 0, ep = 0, ed = 0, rest = rho;
+        for (iter = 1; iter <= st.max_iter; iter++) {
+            xp = xs; zp = zs;
+            for (int j = 0; j < n; j++) rhs[j] = st.sigma * xp[j] - q[j];
+            for (int i = 0; i < m; i++) rhs[n + i] = zp[i] - ys[i] / rho_vec[i];
+            ldl.solve(rhs.data());
+            for (int j = 0; j < n; j++) xs[j] = st.alpha * rhs[j] + (1 - st.alpha) * xp[j];
+            for (int i = 0; i < m; i++) {
+                double zt = zp[i] + (rhs[n + i] - ys[i]) / rho_vec[i];
+                double zr = st.alpha * zt + (1 - st.alpha) * zp[i];
+                double zn = std::min(std::max(zr + ys[i] / rho_vec[i], l[i]), u[i]);
+                ys[i] += rho_vec[i] * (zr - zn);
+                zs[i] = zn;
+            }
+            bool checked = false;
+            if (st.check_termination && iter % st.check_termination == 0) {
+                residuals(pri, dua, ep, ed, rest); checked = true;
+                if (pri <= ep && dua <= ed) { status = 1; break; }
+            }
+            if (st.adaptive_rho && st.adaptive_rho_interval && iter % st.adaptive_rho_interval == 0) {
+                if (!checked) residuals(pri, dua, ep, ed, rest);
+                if (rest > rho * st.adaptive_rho_tolerance || rest < rho / st.adaptive_rho_tolerance) {
+                    rho = rest; set_rho_vec(qp);
+                    if (!refactor(qp)) { status = -10; break; }
+                }
+            }
+        }
+        if (iter > st.max_iter) { iter = st.max_iter; residuals(pri, dua, ep, ed, rest); if (pri <= ep && dua <= ed) status = 1; }
+        x.resize(n); y.resize(m); z.resize(m);
+        for (int j = 0; j < n; j++) x[j] = xs[j] * D[j];
+        for (int i = 0; i < m; i++) { y[i] = ys[i] * E[i] / c; z[i] = zs[i] / E[i]; }
+        have_warm = true; last_iters = iter; last_status = status; last_pri = pri; last_dua = dua;
+        return status;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// High-accuracy reference solve (Mehrotra predictor-corrector on the canonical form).  y uses OSQP's sign
+// convention (y_i < 0 active lower bound, y_i > 0 active upper bound) so that P x + q + A'y = 0.
+struct ExactResult { std::vector<double> x, y; int iters = 0; int status = 0; double res_pri = 0, res_dua = 0, gap = 0; };
+
+inline int solve_exact(const QP& qp, const KKTPattern& K, LDLNumeric& ldl, ExactResult& R, int max_iter = 80, double tol = 1e-10) {
+    const int n = qp.n, m = qp.m;
+    const double delta = 1e-10, eps_eq = 1e-10;
+    // row classes: 0 eq, 1 lower-only, 2 upper-only, 3 free
+    std::vector<int> cls(m);
+    std::vector<double> bnd(m, 0.0);
+    for (int i = 0; i < m; i++) {
+        bool hl = qp.l[i] > -QP_INF, hu = qp.u[i] < QP_INF;
+        if (hl && hu) { if (qp.u[i] - qp.l[i] > 1e-12) { std::fprintf(stderr, "solve_exact: two-sided row %d unsupported\n", i); return R.status = -20; } cls[i] = 0; bnd[i] = qp.l[i]; }
+        else if (hl) { cls[i] = 1; bnd[i] = qp.l[i]; }
+        else if (hu) { cls[i] = 2; bnd[i] = qp.u[i]; }
+        else cls[i] = 3;
+    }
+    std::vector<double> x(n, 0.0), y(m, 0.0), t(m, 1.0), lam(m, 1.0), Dg(m), vals(n + m + qp.Ax.size()), rhs(n + m), sol(n + m), res(n + m);
+    std::vector<double> Axv(m), Aty(n), rx(n), rp(m), rc(m), dt_aff(m), dl_aff(m), dx(n), dy(m), dtv(m), dl(m);
+    for (size_t p = 0; p < qp.Ax.size(); p++) vals[n + m + p] = qp.Ax[p];
+    auto factor = [&]() {
+        for (int j = 0; j < n; j++) vals[j] = qp.Pd[j] + delta;
+        for (int i = 0; i < m; i++) vals[n + i] = -Dg[i];
+        return ldl.factor(vals.data(), vals.size());
+    };
+    auto kkt_solve = [&](std::vector<double>& b) {     // solves with 3 refinement steps against the regularised matrix itself
+        sol = b; ldl.solve(sol.data());
+        for (int it = 0; it < 3; it++) {
+            // res = b - K sol
+            A_mul(qp, qp.Ax.data(), sol.data(), Axv.data()); At_mul(qp, qp.Ax.data(), sol.data() + n, Aty.data());
+            for (int j = 0; j < n; j++) res[j] = b[j] - ((qp.Pd[j] + delta) * sol[j] + Aty[j]);
+            for (int i = 0; i < m; i++) res[n + i] = b[n + i] - (Axv[i] - Dg[i] * sol[n + i]);
+            ldl.solve(res.data());
+            for (int k = 0; k < n + m; k++) sol[k] += res[k];
+        }
+    };
+    // initial point: least-squares style start with unit weights
+    for (int i = 0; i < m; i++) Dg[i] = (cls[i] == 0) ? eps_eq : (cls[i] == 3 ? 1e12 : 1.0);
+    if (!factor()) return R.status = -10;
+    for (int j = 0; j < n; j++) rhs[j] = -qp.q[j];
+    for (int i = 0; i < m; i++) rhs[n + i] = bnd[i];
+    kkt_solve(rhs);
+    for (int j = 0; j < n; j++) x[j] = sol[j];
+    A_mul(qp, qp.Ax.data(), x.data(), Axv.data());
+    {
+        double tmin = 1e300, lmin = 1e300;
+        for (int i = 0; i < m; i++) {
+            y[i] = (cls[i] == 0) ? sol[n + i] : 0.0;
+            if (cls[i] == 1) { t[i] = Axv[i] - bnd[i]; lam[i] = -sol[n + i]; }
+            else if (cls[i] == 2) { t[i] = bnd[i] - Axv[i]; lam[i] = sol[n + i]; }
+            else continue;
+            tmin = std::min(tmin, t[i]); lmin = std::min(lmin, lam[i]);
+        }
+        double st_ = tmin < 1e-2 ? 1.0 - tmin : 0.0, sl_ = lmin < 1e-2 ? 1.0 - lmin : 0.0;
+        for (int i = 0; i < m; i++) if (cls[i] == 1 || cls[i] == 2) { t[i] += st_; lam[i] += sl_; }
+    }
+    int nineq = 0; for (int i = 0; i < m; i++) if (cls[i] == 1 || cls[i] == 2) nineq++;
+    double nq = vnorm_inf(qp.q.data(), n), nb = vnorm_inf(bnd.data(), m);
+    int it; int status = -2;
+    for (it = 0; it < max_iter; it++) {
+        for (int i = 0; i < m; i++) y[i] = cls[i] == 1 ? -lam[i] : (cls[i] == 2 ? lam[i] : (cls[i] == 0 ? y[i] : 0.0));
+        A_mul(qp, qp.Ax.data(), x.data(), Axv.data()); At_mul(qp, qp.Ax.data(), y.data(), Aty.data());
+        double mu = 0, rpn = 0, rdn = 0;
+        for (int j = 0; j < n; j++) { rx[j] = -(qp.Pd[j] * x[j] + qp.q[j] + Aty[j]); rdn = std::max(rdn, std::fabs(rx[j])); }
+        for (int i = 0; i < m; i++) {
+            if (cls[i] == 0) rp[i] = bnd[i] - Axv[i];
+            else if (cls[i] == 1) rp[i] = bnd[i] - Axv[i] + t[i];       // a dx - dt = rp
+            else if (cls[i] == 2) rp[i] = bnd[i] - Axv[i] - t[i];       // a dx + dt = rp
+            else rp[i] = 0;
+            if (cls[i] != 3) rpn = std::max(rpn, std::fabs(rp[i]));
+            if (cls[i] == 1 || cls[i] == 2) mu += t[i] * lam[i];
+        }
+        mu /= std::max(nineq, 1);
+        R.res_pri = rpn; R.res_dua = rdn; R.gap = mu;
+        if (rpn <= tol * (1 + nb) && rdn <= tol * (1 + nq) && mu <= tol) { status = 1; break; }
+        for (int i = 0; i < m; i++) Dg[i] = (cls[i] == 0) ? eps_eq : (cls[i] == 3 ? 1e12 : t[i] / lam[i]);
+        if (!factor()) { status = -10; break; }
+        auto direction = [&](const std::vector<double>& rcv, std::vector<double>& odx, std::vector<double>& ody, std::vector<double>& odt, std::vector<double>& odl) {
+            for (int j = 0; j < n; j++) rhs[j] = rx[j];
+            for (int i = 0; i < m; i++) {
+                if (cls[i] == 1) rhs[n + i] = rp[i] + rcv[i] / lam[i];
+                else if (cls[i] == 2) rhs[n + i] = rp[i] - rcv[i] / lam[i];
+                else rhs[n + i] = rp[i];
+            }
+            kkt_solve(rhs);
+            for (int j = 0; j < n; j++) odx[j] = sol[j];
+            for (int i = 0; i < m; i++) {
+                ody[i] = sol[n + i];
+                if (cls[i] == 1) { odl[i] = -ody[i]; odt[i] = (rcv[i] - t[i] * odl[i]) / lam[i]; }
+                else if (cls[i] == 2) { odl[i] = ody[i]; odt[i] = (rcv[i] - t[i] * odl[i]) / lam[i]; }
+                else { odl[i] = 0; odt[i] = 0; }
+            }
+        };
+        auto steplen = [&](const std::vector<double>& odt, const std::vector<double>& odl) {
+            double a = 1.0;
+            for (int i = 0; i < m; i++) if (cls[i] == 1 || cls[i] == 2) {
+                if (odt[i] < 0) a = std::min(a, -t[i] / odt[i]);
+                if (odl[i] < 0) a = std::min(a, -lam[i] / odl[i]);
+            }
+            return a;
+        };
+        for (int i = 0; i < m; i++) rc[i] = -t[i] * lam[i];
+        direction(rc, dx, dy, dt_aff, dl_aff);
+        double aaff = steplen(dt_aff, dl_aff);
+        double mu_aff = 0;
+        for (int i = 0; i < m; i++) if (cls[i] == 1 || cls[i] == 2) mu_aff += (t[i] + aaff * dt_aff[i]) * (lam[i] + aaff * dl_aff[i]);
+        mu_aff /= std::max(nineq, 1);
+        double sig = std::pow(mu_aff / mu, 3.0);
+        for (int i = 0; i < m; i++) rc[i] = sig * mu - t[i] * lam[i] - dt_aff[i] * dl_aff[i];
+        direction(rc, dx, dy, dtv, dl);
+        double a = std::min(1.0, 0.995 * steplen(dtv, dl));
+        for (int j = 0; j < n; j++) x[j] += a * dx[j];
+        for (int i = 0; i < m; i++) { if (cls[i] == 0) y[i] += a * dy[i]; else if (cls[i] != 3) { t[i] += a * dtv[i]; lam[i] += a * dl[i]; } }
+    }
+    for (int i = 0; i < m; i++) y[i] = cls[i] == 1 ? -lam[i] : (cls[i] == 2 ? lam[i] : (cls[i] == 0 ? y[i] : 0.0));
+    R.x = x; R.y = y; R.iters = it; R.status = status;
+    return status;
+}
+
+}  // namespace po
