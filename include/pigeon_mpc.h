@@ -1,0 +1,160 @@
+/*
+ * pigeon_mpc.h — C ABI of the MI355X-native batched MPC hot path (libpigeon_hip.so).
+ *
+ * The reference (StanfordASL/Pigeon.jl) has NO FFI for this path; its seam is a Julia call convention: five generic
+ * functions applied in fixed order to a mutable TrajectoryTrackingMPC
+ *   compute_time_steps!(mpc, t)          src/model_predictive_control.jl:70   (-> :17-30)
+ *   compute_linearization_nodes!(mpc)    src/model_predictive_control.jl:72   (-> src/coupled_lat_long.jl:62-142)
+ *   update_QP!(mpc)                      src/model_predictive_control.jl:74   (-> src/coupled_lat_long.jl:315-368)
+ *   solve!(mpc)                          src/model_predictive_control.jl:76   (-> Parametron -> OSQP, third-party)
+ *   get_next_control(mpc)                src/model_predictive_control.jl:78   (-> src/coupled_lat_long.jl:370-374)
+ * called from src/ros_integration.jl:96-99,124 and src/model_predictive_control.jl:90-95.  Each entry point below names
+ * the reference interface it replaces.  A batch of B independent MPC instances shares one handle (one vehicle, one
+ * set of control parameters, one reference trajectory, one HJI grid); per-instance persistent state (solved flag,
+ * previous time grid, previous primal solution) lives in device memory inside the handle.
+ *
+ * Conventions: every function returns 0 on success or a negative pg_status; no exceptions cross the ABI; all
+ * arrays are instance-major ("array of structs": state[b*6 + k]) in double precision; pointers are HOST pointers
+ * unless the parameter name ends in _dev.  One handle per host thread and device.
+ */
+#ifndef PIGEON_MPC_H
+#define PIGEON_MPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pg_handle pg_handle;
+
+enum pg_status {
+    PG_OK = 0,
+    PG_ERR_NO_DEVICE = -1,      /* HIP runtime found no usable gfx950 device: the product path NEVER falls back to a CPU */
+    PG_ERR_INVALID = -2,        /* bad argument (null pointer, B > capacity, L < 2, ...) */
+    PG_ERR_HIP = -3,            /* a HIP call failed; pg_last_error() has the text */
+    PG_ERR_STATE = -4           /* call order violated (e.g. no trajectory installed) */
+};
+
+/* per-instance solver status words written by pg_solve (the reference never inspects OSQP's status,
+ * src/ros_integration.jl:127 "TODO"; the NaN fallback of :134-147 is reproduced by the caller from these) */
+enum pg_solve_status {
+    PG_SOLVED = 1,
+    PG_MAX_ITER = 2,            /* iteration cap reached before the tolerances were met */
+    PG_NUMERICAL = 3,           /* NaN/Inf met in the data or the iterates (e.g. the H4 hazard: other-car speed 0) */
+    PG_INFEASIBLE_X0 = 4        /* a hard bound on the fixed first node is violated (Ux_1 outside [V_min,V_max], Fx_1 < Fx_min) */
+};
+
+/* vehicle dictionary: src/vehicles.jl:1-59; field sets of src/vehicle_dynamics.jl:7-29,272-292 */
+typedef struct pg_vehicle {
+    double G, m, Izz, L, a, b, h, mu, Caf, Car, Cd0, Cd1, Cd2;
+    double fwd_frac, rwd_frac, fwb_frac, rwb_frac;
+    double Fx_max, Fx_min, Px_max, delta_max, kappa_max;
+} pg_vehicle;
+
+/* CoupledControlParams: src/coupled_lat_long.jl:1-40 */
+typedef struct pg_control_params {
+    double V_min, V_max, k_V, k_s, deltadot_max;
+    double Q_ds, Q_dpsi, Q_e, W_beta, W_r, W_HJI;
+    double R_delta, R_ddelta, R_Fx, R_dFx;
+    int32_t N_HJI;
+    int32_t _pad;
+} pg_control_params;
+
+/* keyword arguments of CoupledTrajectoryTrackingMPC (src/coupled_lat_long.jl:42-43) + build-defined knobs */
+typedef struct pg_config {
+    pg_vehicle vehicle;
+    pg_control_params control;
+    int32_t N_short, N_long;        /* default 10, 20 */
+    double dt_short, dt_long;       /* default 0.01, 0.2 */
+    int32_t use_correction_step;    /* default 1 */
+    int32_t rk4_substeps;           /* sub-steps of the RK4 `propagate` inside linearize (third-party default 10) */
+    double hji_eps;                 /* HJI_eps, src/model_predictive_control.jl:67 (0.05) */
+    int32_t batch_capacity;         /* maximum B */
+    int32_t device;                 /* HIP device ordinal */
+    int32_t ipm_max_iter;           /* interior-point iteration cap (default 40) */
+    int32_t _pad;
+    double ipm_tol;                 /* complementarity / infeasibility tolerance (default 1e-13) */
+    double ipm_mu0;                 /* initial barrier parameter (default 100) */
+} pg_config;
+
+/* X1() and the default keyword values of the reference constructors */
+int pg_default_config(pg_config* cfg);
+
+/* CoupledTrajectoryTrackingMPC(vehicle, trajectory; ...)  src/coupled_lat_long.jl:42-60 (trajectory installed separately) */
+int pg_create(const pg_config* cfg, pg_handle** out);
+int pg_destroy(pg_handle* h);
+const char* pg_last_error(const pg_handle* h);
+int pg_get_config(const pg_handle* h, pg_config* out);
+/* u_normalization, src/coupled_lat_long.jl:199 */
+int pg_get_u_normalization(const pg_handle* h, double out[2]);
+
+/* mpc.trajectory = TrajectoryTube(t,s,V,A,E,N,psi,kappa,theta,phi,edge_L,edge_R)  src/trajectories.jl:8-44; src/ros_integration.jl:53 */
+int pg_set_trajectory(pg_handle* h, int32_t L, const double* t, const double* s, const double* V, const double* A, const double* E,
+                      const double* N, const double* psi, const double* kappa, const double* theta, const double* phi,
+                      const double* edge_L, const double* edge_R);
+
+/* mpc.HJI_cache = HJICache(grid_knots, V_raw, gradV_raw)  src/HJI_computation.jl:26-57.  V is column-major (dim 1 fastest),
+ * gradV is 7 floats per node in the same node order.  Without a grid the safety row is inactive (M = 0, b = 1). */
+int pg_set_hji_grid(pg_handle* h, const int32_t dims[7], const float* knots_concat, const float* V, const float* gradV);
+int pg_clear_hji_grid(pg_handle* h);
+
+/* mpc.solved = false (src/ros_integration.jl:34,41,147): mask[b] != 0 resets instance b; mask == NULL resets all */
+int pg_reset(pg_handle* h, const uint8_t* mask);
+
+/* mpc.current_state / current_control / other_car_state / time_offset (src/ros_integration.jl:50-53,76-78,155):
+ * state [B][6] (E,N,psi,Ux,Uy,r), control [B][3] (delta,Fxf,Fxr), t0 [B], other_car [B][4] (E,N,psi,V) or NULL (zeros),
+ * time_offset [B] (NaN = path-tracking mode) or NULL (all NaN).  Copies host -> device. */
+int pg_set_inputs(pg_handle* h, int32_t B, const double* state, const double* control, const double* t0, const double* other_car,
+                  const double* time_offset);
+/* same, inputs already resident in device memory (HBM) */
+int pg_set_inputs_dev(pg_handle* h, int32_t B, const double* state_dev, const double* control_dev, const double* t0_dev,
+                      const double* other_car_dev, const double* time_offset_dev);
+
+/* the five reference calls, each over the whole batch, device-resident intermediates */
+int pg_compute_time_steps(pg_handle* h);              /* compute_time_steps!           model_predictive_control.jl:17-30 */
+int pg_compute_linearization_nodes(pg_handle* h);     /* compute_linearization_nodes!  coupled_lat_long.jl:62-142 */
+int pg_update_qp(pg_handle* h);                       /* update_QP!                    coupled_lat_long.jl:315-368 (+ HJI_computation.jl:160-170) */
+int pg_solve(pg_handle* h);                           /* solve!                        model_predictive_control.jl:76 */
+int pg_get_next_control(pg_handle* h, double* u_out); /* get_next_control              coupled_lat_long.jl:370-374; u_out [B][3] (delta,Fxf,Fxr), host */
+int pg_get_next_control_dev(pg_handle* h, double* u_out_dev);
+
+/* all five for every instance: host buffers in, host buffers out (status/iters may be NULL) */
+int pg_step(pg_handle* h, int32_t B, const double* state, const double* control, const double* t0, const double* other_car,
+            const double* time_offset, double* u_out, int32_t* status, int32_t* iters);
+/* the four compute phases + control extraction on the inputs last installed; nothing crosses PCIe.  u_out_dev may be NULL. */
+int pg_step_dev(pg_handle* h, double* u_out_dev);
+
+/* stream to launch on (hipStream_t as void*); NULL = the null stream */
+int pg_set_stream(pg_handle* h, void* hip_stream);
+int pg_synchronize(pg_handle* h);
+
+/* ---- read-backs for parity tests and logging (host pointers, any may be NULL) ---------------------------------- */
+/* ts [B][N+1], dt [B][N], prev_ts [B][N+1] */
+int pg_get_time_steps(pg_handle* h, double* ts, double* dt, double* prev_ts);
+/* qs [B][N+1][6], us [B][N+1][2] (delta, Fx in physical units), ps [B][N+1][4] (V, kappa, 0, 0) */
+int pg_get_nodes(pg_handle* h, double* qs, double* us, double* ps);
+/* path_coordinates of the current states: sep [B][3] = (s, e, t)   src/trajectories.jl:71-94 */
+int pg_get_path_coordinates(pg_handle* h, double* sep);
+/* refreshed QP data of instances [b0, b0+n): n blocks of pg_qp_len() doubles laid out as
+ * A[N][6][6] B0[N][6][2] Bf[N][6][2] c[N][6] H[N][4][2] G[N][4] dmin[N] dmax[N] fxmax[N] ddmin[N] ddmax[N] dt[N] q_curr[6] u_curr[2] M_hji[2] b_hji
+ * (the numeric content update_QP! writes into the Parametron parameters, coupled_lat_long.jl:323-366; B's scaled by u_normalization) */
+int pg_qp_len(const pg_handle* h);
+int pg_get_qp(pg_handle* h, int32_t b0, int32_t n, double* out);
+/* primal solution: x [B][N+1][8] = (q (6), normalised u (2)) per node; sigma [B][N][3] = (sigma1, sigma2, sigma_HJI of node k+1) */
+int pg_get_solution(pg_handle* h, double* x, double* sigma);
+/* status [B] (pg_solve_status), iters [B], active [B][N] bit masks over the 16 stage rows (row order in DESIGN.md), mu [B] final gap */
+int pg_get_solve_info(pg_handle* h, int32_t* status, int32_t* iters, uint16_t* active, double* mu);
+/* milliseconds of the last pg_step_dev per phase: time_steps+nodes, update_qp (linearize, limits, HJI), solve (+extract); HIP events */
+int pg_get_phase_ms(pg_handle* h, float out3[3]);
+
+/* cache[x] for a batch of relative states: HJI_computation.jl:66-72.  x7 [B][7] host; V [B], gradV [B][7] host.  Out of bounds => V=+Inf, gradV=0 */
+int pg_hji_lookup(pg_handle* h, int32_t B, const double* x7, double* V, double* gradV);
+int pg_hji_lookup_dev(pg_handle* h, int32_t B, const double* x7_dev, double* V_dev, double* gradV_dev);
+/* compute_reachability_constraint for the installed inputs: M [B][2] (already multiplied by u_normalization), b [B], V [B] */
+int pg_get_hji_constraint(pg_handle* h, double* M, double* b, double* V);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

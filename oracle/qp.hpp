@@ -393,7 +393,7 @@ struct OSQPPort {
 // convention (y_i < 0 active lower bound, y_i > 0 active upper bound) so that P x + q + A'y = 0.
 struct ExactResult { std::vector<double> x, y; int iters = 0; int status = 0; double res_pri = 0, res_dua = 0, gap = 0; };
 
-inline int solve_exact(const QP& qp, const KKTPattern& K, LDLNumeric& ldl, ExactResult& R, int max_iter = 80, double tol = 1e-10) {
+inline int solve_exact(const QP& qp, const KKTPattern& K, LDLNumeric& ldl, ExactResult& R, int max_iter = 80, double tol = 1e-10, double tol_gap = 1e-14) {
     const int n = qp.n, m = qp.m;
     const double delta = 1e-10, eps_eq = 1e-10;
     // row classes: 0 eq, 1 lower-only, 2 upper-only, 3 free
@@ -463,7 +463,7 @@ inline int solve_exact(const QP& qp, const KKTPattern& K, LDLNumeric& ldl, Exact
         }
         mu /= std::max(nineq, 1);
         R.res_pri = rpn; R.res_dua = rdn; R.gap = mu;
-        if (rpn <= tol * (1 + nb) && rdn <= tol * (1 + nq) && mu <= tol) { status = 1; break; }
+        if (rpn <= tol * (1 + nb) && rdn <= tol * (1 + nq) && mu <= tol_gap) { status = 1; break; }
         for (int i = 0; i < m; i++) Dg[i] = (cls[i] == 0) ? eps_eq : (cls[i] == 3 ? 1e12 : t[i] / lam[i]);
         if (!factor()) { status = -10; break; }
         auto direction = [&](const std::vector<double>& rcv, std::vector<double>& odx, std::vector<double>& ody, std::vector<double>& odt, std::vector<double>& odl) {

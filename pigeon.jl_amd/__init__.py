@@ -1,0 +1,9 @@
+"""MI355X-native batched MPC hot path of StanfordASL/Pigeon.jl (coupled lat/long tracking QP + HJI lookup).
+
+Host mirror of the reference's call convention over the C ABI in include/pigeon_mpc.h; all compute is HIP on gfx950.
+"""
+from ._lib import PigeonError, load_library, LIB_PATH, SYMBOLS  # noqa: F401
+from .mpc import BatchedTrajectoryTrackingMPC, CoupledTrajectoryTrackingMPC, simulate, SOLVED, MAX_ITER, NUMERICAL, INFEASIBLE_X0  # noqa: F401
+from .trajectories import TrajectoryTube, straight_trajectory, load_path_fixture, invcumtrapz  # noqa: F401
+from .vehicles import X1, CoupledControlParams  # noqa: F401
+from . import synthetic  # noqa: F401

@@ -1,0 +1,62 @@
+"""ctypes binding of libpigeon_hip.so (C ABI: include/pigeon_mpc.h).  No CPU fallback: a missing library or GPU raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpigeon_hip.so")
+_lib = None
+
+
+class PigeonError(RuntimeError):
+    pass
+
+
+class pg_vehicle(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ["G", "m", "Izz", "L", "a", "b", "h", "mu", "Caf", "Car", "Cd0", "Cd1", "Cd2", "fwd_frac", "rwd_frac",
+                                          "fwb_frac", "rwb_frac", "Fx_max", "Fx_min", "Px_max", "delta_max", "kappa_max"]]
+
+
+class pg_control_params(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ["V_min", "V_max", "k_V", "k_s", "deltadot_max", "Q_ds", "Q_dpsi", "Q_e", "W_beta", "W_r", "W_HJI",
+                                          "R_delta", "R_ddelta", "R_Fx", "R_dFx"]] + [("N_HJI", C.c_int32), ("_pad", C.c_int32)]
+
+
+class pg_config(C.Structure):
+    _fields_ = [("vehicle", pg_vehicle), ("control", pg_control_params), ("N_short", C.c_int32), ("N_long", C.c_int32), ("dt_short", C.c_double),
+                ("dt_long", C.c_double), ("use_correction_step", C.c_int32), ("rk4_substeps", C.c_int32), ("hji_eps", C.c_double),
+                ("batch_capacity", C.c_int32), ("device", C.c_int32), ("ipm_max_iter", C.c_int32), ("_pad", C.c_int32), ("ipm_tol", C.c_double),
+                ("ipm_mu0", C.c_double)]
+
+
+# every symbol include/pigeon_mpc.h declares (tests check that the built library exports each one)
+SYMBOLS = ["pg_default_config", "pg_create", "pg_destroy", "pg_last_error", "pg_get_config", "pg_get_u_normalization", "pg_set_trajectory",
+           "pg_set_hji_grid", "pg_clear_hji_grid", "pg_reset", "pg_set_inputs", "pg_set_inputs_dev", "pg_compute_time_steps",
+           "pg_compute_linearization_nodes", "pg_update_qp", "pg_solve", "pg_get_next_control", "pg_get_next_control_dev", "pg_step", "pg_step_dev",
+           "pg_set_stream", "pg_synchronize", "pg_get_time_steps", "pg_get_nodes", "pg_get_path_coordinates", "pg_qp_len", "pg_get_qp", "pg_get_solution",
+           "pg_get_solve_info", "pg_get_phase_ms", "pg_hji_lookup", "pg_hji_lookup_dev", "pg_get_hji_constraint"]
+
+
+def load_library():
+    """Loads the HIP library.  PyTorch-ROCm is imported first so that both share ONE HIP runtime in this process."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PigeonError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)")
+    try:
+        import torch  # noqa: F401  (plumbing: device memory / streams / torch.distributed live in the same HIP runtime)
+    except Exception:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    lib.pg_last_error.restype = C.c_char_p
+    lib.pg_last_error.argtypes = [C.c_void_p]
+    for s in SYMBOLS:
+        getattr(lib, s)
+    _lib = lib
+    return lib
+
+
+def check(lib, h, rc, what):
+    if rc != 0:
+        msg = lib.pg_last_error(h)
+        raise PigeonError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")

@@ -1,0 +1,431 @@
+// C ABI of libpigeon_hip.so (declared in include/pigeon_mpc.h).  Host-side handle, device buffers, kernel launches.
+// The product path has NO CPU fallback: without a HIP device pg_create fails with PG_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "pg_kernels.hip"
+
+using namespace pg;
+
+struct pg_handle {
+    pg_config cfg;
+    DevCfg dc;
+    int B = 0;                       // current batch
+    hipStream_t stream = nullptr;
+    std::string err;
+    // device buffers
+    double *d_traj = nullptr; int traj_L = 0;
+    double *d_state = nullptr, *d_control = nullptr, *d_t0 = nullptr, *d_other = nullptr, *d_toff = nullptr;
+    int* d_solved = nullptr;
+    double *d_ts = nullptr, *d_dt = nullptr, *d_prev_ts = nullptr, *d_sep = nullptr, *d_nodes = nullptr, *d_qp = nullptr;
+    double *d_x7 = nullptr, *d_vg8 = nullptr, *d_Mb = nullptr;
+    double *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
+    int *d_status = nullptr, *d_iters = nullptr; uint16_t* d_active = nullptr;
+    // HJI grid
+    HjiView hv; float *d_knots = nullptr, *d_hnodes = nullptr; bool has_hji = false;
+    hipEvent_t ev[4]; bool ev_ok = false; float phase_ms[3] = {0, 0, 0}; bool timing_valid = false;
+    size_t solve_lds = 0;
+};
+
+#define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return PG_ERR_HIP; } } while (0)
+#define REQUIRE(h, cond, msg) do { if (!(cond)) { if (h) (h)->err = (msg); return PG_ERR_INVALID; } } while (0)
+
+static std::string g_create_error;
+
+extern "C" {
+
+int pg_default_config(pg_config* c) {
+    if (!c) return PG_ERR_INVALID;
+    memset(c, 0, sizeof(*c));
+    pg_vehicle& P = c->vehicle;                      // vehicles.jl:1-59
+    P.G = 9.80665;
+    double mfl = 484, mfr = 455, mrl = 521, mrr = 504;
+    P.m = mfl + mfr + mrl + mrr; P.Izz = 2900; P.L = 2.87;
+    P.a = (mrl + mrr) / P.m * P.L; P.b = (mfl + mfr) / P.m * P.L;
+    P.h = 0.1 * P.b / P.L + 0.1 * P.a / P.L + 0.37;
+    P.mu = 0.92; P.Caf = 150e3; P.Car = 220e3; P.Fx_max = 5600; P.Px_max = 75e3; P.Cd0 = 241.0; P.Cd1 = 25.1; P.Cd2 = 0.0;
+    P.fwd_frac = 0.0; P.rwd_frac = 1.0 - P.fwd_frac; P.fwb_frac = 0.6; P.rwb_frac = 1.0 - P.fwb_frac;
+    double f1 = -P.m * P.G * P.a * P.mu / (P.L * P.rwb_frac + P.mu * P.h), f2 = -P.m * P.G * P.b * P.mu / (P.L * P.fwb_frac - P.mu * P.h);
+    P.Fx_min = f1 > f2 ? f1 : f2;
+    P.delta_max = 18 * M_PI / 180; P.kappa_max = tan(P.delta_max) / P.L;
+    pg_control_params& U = c->control;               // coupled_lat_long.jl:23-38
+    U.V_min = 1.0; U.V_max = 15.0; U.k_V = 10.0 / 4 / 100; U.k_s = 10.0 / 4 / 10000; U.deltadot_max = 0.344;
+    U.Q_ds = 1.0; U.Q_dpsi = 1.0; U.Q_e = 1.0; U.W_beta = 50 / (10 * M_PI / 180); U.W_r = 50.0; U.W_HJI = 500.0; U.N_HJI = 3;
+    U.R_delta = 0.0; U.R_ddelta = 0.1; U.R_Fx = 0.0; U.R_dFx = 0.5;
+    c->N_short = 10; c->N_long = 20; c->dt_short = 0.01; c->dt_long = 0.2; c->use_correction_step = 1;   // coupled_lat_long.jl:42-43
+    c->rk4_substeps = 10; c->hji_eps = 0.05; c->batch_capacity = 4096; c->device = 0;
+    c->ipm_max_iter = 40; c->ipm_tol = 1e-13; c->ipm_mu0 = 100.0;
+    return PG_OK;
+}
+
+static void free_all(pg_handle* h) {
+    void* ptrs[] = {h->d_traj, h->d_state, h->d_control, h->d_t0, h->d_other, h->d_toff, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (h->ev_ok) for (int i = 0; i < 4; i++) (void)hipEventDestroy(h->ev[i]);
+}
+
+const char* pg_last_error(const pg_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int pg_create(const pg_config* cfg, pg_handle** out) {
+    if (!cfg || !out) return PG_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { g_create_error = "no HIP device available (this library has no CPU path)"; return PG_ERR_NO_DEVICE; }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "device ordinal out of range"; return PG_ERR_INVALID; }
+    if (cfg->N_short < 1 || cfg->N_long < 0 || cfg->N_short + cfg->N_long + 1 > 64 || cfg->batch_capacity < 1 || cfg->rk4_substeps < 1) {
+        g_create_error = "invalid horizon / capacity (need 1 <= N_short, N_short+N_long+1 <= 64)"; return PG_ERR_INVALID;
+    }
+    if (hipSetDevice(cfg->device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return PG_ERR_HIP; }
+    pg_handle* h = new pg_handle();
+    h->cfg = *cfg;
+    DevCfg& C = h->dc; memset(&C, 0, sizeof(C));
+    C.veh = cfg->vehicle; C.cp = cfg->control; C.Ns = cfg->N_short; C.Nl = cfg->N_long; C.N = C.Ns + C.Nl; C.NN = C.N + 1;
+    C.dt_short = cfg->dt_short; C.dt_long = cfg->dt_long; C.use_correction_step = cfg->use_correction_step; C.nsub = cfg->rk4_substeps;
+    C.alias_prev_ts = 1; C.has_hji = 0; C.hji_eps = cfg->hji_eps;
+    C.un0 = cfg->vehicle.delta_max; C.un1 = fmax(-cfg->vehicle.Fx_min, cfg->vehicle.Fx_max);      // coupled_lat_long.jl:199
+    C.fxmin_n = cfg->vehicle.Fx_min / C.un1;
+    C.qp_len = 84 * C.N + 11;
+    C.ipm_max_iter = cfg->ipm_max_iter; C.ipm_tol = cfg->ipm_tol; C.ipm_mu0 = cfg->ipm_mu0;
+    const size_t cap = (size_t)cfg->batch_capacity; const int N = C.N, NN = C.NN;
+#define ALLOC(ptr, count, type) do { if (hipMalloc((void**)&(ptr), (size_t)(count) * sizeof(type)) != hipSuccess) { g_create_error = "hipMalloc failed for " #ptr; free_all(h); delete h; return PG_ERR_HIP; } } while (0)
+    ALLOC(h->d_state, cap * 6, double); ALLOC(h->d_control, cap * 3, double); ALLOC(h->d_t0, cap, double); ALLOC(h->d_other, cap * 4, double); ALLOC(h->d_toff, cap, double);
+    ALLOC(h->d_solved, cap, int); ALLOC(h->d_ts, cap * NN, double); ALLOC(h->d_dt, cap * N, double); ALLOC(h->d_prev_ts, cap * NN, double);
+    ALLOC(h->d_sep, cap * 4, double); ALLOC(h->d_nodes, cap * NN * 10, double); ALLOC(h->d_qp, cap * C.qp_len, double);
+    ALLOC(h->d_x7, cap * 7, double); ALLOC(h->d_vg8, cap * 8, double); ALLOC(h->d_Mb, cap * 4, double);
+    ALLOC(h->d_solx, cap * NN * 8, double); ALLOC(h->d_sigma, cap * N * 3, double); ALLOC(h->d_u, cap * 3, double); ALLOC(h->d_mu, cap, double);
+    ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_active, cap * N, uint16_t);
+#undef ALLOC
+    // initial ts = 1..NN (model_predictive_control.jl:13), solved = false
+    {
+        std::vector<double> ts(cap * NN), dt(cap * N, 1.0);
+        for (size_t b = 0; b < cap; b++) for (int i = 0; i < NN; i++) ts[b * NN + i] = i + 1;
+        (void)hipMemcpy(h->d_ts, ts.data(), ts.size() * 8, hipMemcpyHostToDevice);
+        (void)hipMemcpy(h->d_prev_ts, ts.data(), ts.size() * 8, hipMemcpyHostToDevice);
+        (void)hipMemcpy(h->d_dt, dt.data(), dt.size() * 8, hipMemcpyHostToDevice);
+        (void)hipMemset(h->d_solved, 0, cap * sizeof(int));
+        (void)hipMemset(h->d_other, 0, cap * 4 * 8);
+        (void)hipMemset(h->d_solx, 0, cap * NN * 8 * 8);
+    }
+    for (int i = 0; i < 4; i++) if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_create_error = "hipEventCreate failed"; free_all(h); delete h; return PG_ERR_HIP; }
+    h->ev_ok = true;
+    h->solve_lds = (size_t)(66 * N + 14 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 64 + 64 + 16 + 16 + 8 + 8) * sizeof(double);
+    if (h->solve_lds > 160 * 1024) { g_create_error = "horizon too long for LDS staging"; free_all(h); delete h; return PG_ERR_INVALID; }
+    if (h->solve_lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+    *out = h;
+    return PG_OK;
+}
+
+int pg_destroy(pg_handle* h) { if (!h) return PG_ERR_INVALID; (void)hipSetDevice(h->cfg.device); free_all(h); delete h; return PG_OK; }
+int pg_get_config(const pg_handle* h, pg_config* out) { if (!h || !out) return PG_ERR_INVALID; *out = h->cfg; return PG_OK; }
+int pg_get_u_normalization(const pg_handle* h, double out[2]) { if (!h || !out) return PG_ERR_INVALID; out[0] = h->dc.un0; out[1] = h->dc.un1; return PG_OK; }
+int pg_qp_len(const pg_handle* h) { return h ? h->dc.qp_len : PG_ERR_INVALID; }
+int pg_set_stream(pg_handle* h, void* s) { if (!h) return PG_ERR_INVALID; h->stream = (hipStream_t)s; return PG_OK; }
+int pg_synchronize(pg_handle* h) { if (!h) return PG_ERR_INVALID; HIPCHK(h, hipStreamSynchronize(h->stream)); return PG_OK; }
+
+int pg_set_trajectory(pg_handle* h, int32_t L, const double* t, const double* s, const double* V, const double* A, const double* E, const double* N,
+                      const double* psi, const double* kappa, const double* theta, const double* phi, const double* edge_L, const double* edge_R) {
+    if (!h) return PG_ERR_INVALID;
+    REQUIRE(h, L >= 2 && t && s && V && A && E && N && psi && kappa, "pg_set_trajectory: need L >= 2 and the eight read channels");
+    (void)theta; (void)phi; (void)edge_L; (void)edge_R;   // carried by TrajectoryTube (trajectories.jl:17-20) but read by nothing on this path
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->d_traj) { (void)hipFree(h->d_traj); h->d_traj = nullptr; }
+    HIPCHK(h, hipMalloc((void**)&h->d_traj, (size_t)8 * L * sizeof(double)));
+    const double* src[8] = {t, s, V, A, E, N, psi, kappa};
+    for (int k = 0; k < 8; k++) HIPCHK(h, hipMemcpy(h->d_traj + (size_t)k * L, src[k], (size_t)L * 8, hipMemcpyHostToDevice));
+    TrajView& T = h->dc.traj; T.L = L;
+    T.t = h->d_traj; T.s = h->d_traj + L; T.V = h->d_traj + 2 * (size_t)L; T.A = h->d_traj + 3 * (size_t)L; T.E = h->d_traj + 4 * (size_t)L;
+    T.N = h->d_traj + 5 * (size_t)L; T.psi = h->d_traj + 6 * (size_t)L; T.kappa = h->d_traj + 7 * (size_t)L;
+    h->traj_L = L;
+    return PG_OK;
+}
+
+int pg_clear_hji_grid(pg_handle* h) {
+    if (!h) return PG_ERR_INVALID;
+    (void)hipStreamSynchronize(h->stream);
+    if (h->d_knots) (void)hipFree(h->d_knots);
+    if (h->d_hnodes) (void)hipFree(h->d_hnodes);
+    h->d_knots = nullptr; h->d_hnodes = nullptr; h->has_hji = false; h->dc.has_hji = 0;
+    return PG_OK;
+}
+
+int pg_set_hji_grid(pg_handle* h, const int32_t dims[7], const float* knots_concat, const float* V, const float* gradV) {
+    if (!h) return PG_ERR_INVALID;
+    REQUIRE(h, dims && knots_concat && V && gradV, "pg_set_hji_grid: null argument");
+    size_t n = 1; int nk = 0;
+    for (int d = 0; d < 7; d++) { REQUIRE(h, dims[d] >= 2, "pg_set_hji_grid: every dimension needs >= 2 knots"); n *= dims[d]; nk += dims[d]; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    pg_clear_hji_grid(h);
+    // interleave (V, gradV[7]) into 8-float node records: one 32 B aligned read per corner instead of a 4 B + a 28 B unaligned one
+    std::vector<float> rec(n * 8);
+    for (size_t i = 0; i < n; i++) { rec[8 * i] = V[i]; for (int k = 0; k < 7; k++) rec[8 * i + 1 + k] = gradV[7 * i + k]; }
+    HIPCHK(h, hipMalloc((void**)&h->d_hnodes, rec.size() * sizeof(float)));
+    HIPCHK(h, hipMalloc((void**)&h->d_knots, (size_t)nk * sizeof(float)));
+    HIPCHK(h, hipMemcpy(h->d_hnodes, rec.data(), rec.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_knots, knots_concat, (size_t)nk * sizeof(float), hipMemcpyHostToDevice));
+    long st = 1; int ko = 0;
+    for (int d = 0; d < 7; d++) { h->hv.dims[d] = dims[d]; h->hv.koff[d] = ko; h->hv.stride[d] = st; st *= dims[d]; ko += dims[d]; }
+    h->hv.knots = h->d_knots; h->hv.nodes = h->d_hnodes;
+    h->has_hji = true; h->dc.has_hji = 1;
+    return PG_OK;
+}
+
+__global__ void k_reset(int B, const uint8_t* mask, int* solved) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && (!mask || mask[b])) solved[b] = 0;
+}
+
+int pg_reset(pg_handle* h, const uint8_t* mask) {
+    if (!h) return PG_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int cap = h->cfg.batch_capacity;
+    if (!mask) { HIPCHK(h, hipMemsetAsync(h->d_solved, 0, (size_t)cap * sizeof(int), h->stream)); return PG_OK; }
+    REQUIRE(h, h->B > 0, "pg_reset with a mask needs inputs installed (B known)");
+    uint8_t* dm = nullptr;
+    HIPCHK(h, hipMalloc((void**)&dm, h->B));
+    HIPCHK(h, hipMemcpy(dm, mask, h->B, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_reset, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, h->B, dm, h->d_solved);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(dm);
+    return PG_OK;
+}
+
+static int set_inputs(pg_handle* h, int32_t B, const double* state, const double* control, const double* t0, const double* other, const double* toff, hipMemcpyKind kind) {
+    if (!h) return PG_ERR_INVALID;
+    REQUIRE(h, B >= 1 && B <= h->cfg.batch_capacity, "batch size outside [1, batch_capacity]");
+    REQUIRE(h, state && control && t0, "state, control and t0 are required");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    h->B = B;
+    HIPCHK(h, hipMemcpyAsync(h->d_state, state, (size_t)B * 6 * 8, kind, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_control, control, (size_t)B * 3 * 8, kind, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_t0, t0, (size_t)B * 8, kind, h->stream));
+    if (other) HIPCHK(h, hipMemcpyAsync(h->d_other, other, (size_t)B * 4 * 8, kind, h->stream));
+    else HIPCHK(h, hipMemsetAsync(h->d_other, 0, (size_t)B * 4 * 8, h->stream));
+    if (toff) HIPCHK(h, hipMemcpyAsync(h->d_toff, toff, (size_t)B * 8, kind, h->stream));
+    else HIPCHK(h, hipMemsetAsync(h->d_toff, 0xFF, (size_t)B * 8, h->stream));      // all-ones bit pattern is a NaN: path-tracking mode
+    if (kind == hipMemcpyHostToDevice) HIPCHK(h, hipStreamSynchronize(h->stream));  // host buffers may be reused by the caller
+    return PG_OK;
+}
+int pg_set_inputs(pg_handle* h, int32_t B, const double* state, const double* control, const double* t0, const double* other, const double* toff) {
+    return set_inputs(h, B, state, control, t0, other, toff, hipMemcpyHostToDevice);
+}
+int pg_set_inputs_dev(pg_handle* h, int32_t B, const double* state, const double* control, const double* t0, const double* other, const double* toff) {
+    return set_inputs(h, B, state, control, t0, other, toff, hipMemcpyDeviceToDevice);
+}
+
+static int check_ready(pg_handle* h) {
+    if (!h) return PG_ERR_INVALID;
+    if (h->B <= 0) { h->err = "no inputs installed (call pg_set_inputs first)"; return PG_ERR_STATE; }
+    if (!h->d_traj) { h->err = "no trajectory installed (call pg_set_trajectory first)"; return PG_ERR_STATE; }
+    if (hipSetDevice(h->cfg.device) != hipSuccess) { h->err = "hipSetDevice failed"; return PG_ERR_HIP; }
+    return PG_OK;
+}
+#define LAUNCH_CHECK(h) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { (h)->err = std::string("kernel launch: ") + hipGetErrorString(e_); return PG_ERR_HIP; } } while (0)
+
+int pg_compute_time_steps(pg_handle* h) {
+    int rc = check_ready(h); if (rc) return rc;
+    const int B = h->B;
+    hipLaunchKernelGGL(k_time_steps, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, h->d_t0, h->d_ts, h->d_dt, h->d_prev_ts);
+    LAUNCH_CHECK(h);
+    return PG_OK;
+}
+int pg_compute_linearization_nodes(pg_handle* h) {
+    int rc = check_ready(h); if (rc) return rc;
+    const int B = h->B;
+    hipLaunchKernelGGL(k_project, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep);
+    LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(k_nodes, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
+                       h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes);
+    LAUNCH_CHECK(h);
+    return PG_OK;
+}
+static int launch_hji_lookup(pg_handle* h, int B, const double* x7_dev, double* out8_dev) {
+    hipLaunchKernelGGL(k_hji_lookup, dim3(((size_t)B * 64 + 255) / 256), dim3(256), 0, h->stream, h->hv, B, x7_dev, out8_dev);
+    LAUNCH_CHECK(h);
+    return PG_OK;
+}
+int pg_update_qp(pg_handle* h) {
+    int rc = check_ready(h); if (rc) return rc;
+    const int B = h->B; const DevCfg& C = h->dc;
+    if (h->has_hji) {
+        hipLaunchKernelGGL(k_hji_relstate, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, h->d_state, h->d_other, h->d_x7);
+        LAUNCH_CHECK(h);
+        rc = launch_hji_lookup(h, B, h->d_x7, h->d_vg8); if (rc) return rc;
+        hipLaunchKernelGGL(k_hji_constraint, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, h->d_x7, h->d_vg8, h->d_control, h->d_Mb);
+        LAUNCH_CHECK(h);
+    }
+    long nl = (long)B * C.N * 5;
+    hipLaunchKernelGGL(k_linearize, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_qp);
+    LAUNCH_CHECK(h);
+    long nt = (long)B * C.N;
+    hipLaunchKernelGGL(k_limits, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp);
+    LAUNCH_CHECK(h);
+    return PG_OK;
+}
+int pg_solve(pg_handle* h) {
+    int rc = check_ready(h); if (rc) return rc;
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved};
+    hipLaunchKernelGGL(k_solve, dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, O);
+    LAUNCH_CHECK(h);
+    return PG_OK;
+}
+int pg_get_next_control_dev(pg_handle* h, double* u_out_dev) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (u_out_dev) HIPCHK(h, hipMemcpyAsync(u_out_dev, h->d_u, (size_t)h->B * 3 * 8, hipMemcpyDeviceToDevice, h->stream));
+    return PG_OK;
+}
+int pg_get_next_control(pg_handle* h, double* u_out) {
+    int rc = check_ready(h); if (rc) return rc;
+    REQUIRE(h, u_out, "u_out is null");
+    HIPCHK(h, hipMemcpyAsync(u_out, h->d_u, (size_t)h->B * 3 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PG_OK;
+}
+int pg_step_dev(pg_handle* h, double* u_out_dev) {
+    int rc = check_ready(h); if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    if ((rc = pg_compute_time_steps(h))) return rc;
+    if ((rc = pg_compute_linearization_nodes(h))) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    if ((rc = pg_update_qp(h))) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+    if ((rc = pg_solve(h))) return rc;
+    if ((rc = pg_get_next_control_dev(h, u_out_dev))) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+    h->timing_valid = true;
+    return PG_OK;
+}
+int pg_get_phase_ms(pg_handle* h, float out3[3]) {
+    if (!h || !out3) return PG_ERR_INVALID;
+    if (!h->timing_valid) { h->err = "no pg_step_dev recorded yet"; return PG_ERR_STATE; }
+    HIPCHK(h, hipEventSynchronize(h->ev[3]));
+    for (int i = 0; i < 3; i++) HIPCHK(h, hipEventElapsedTime(&out3[i], h->ev[i], h->ev[i + 1]));
+    return PG_OK;
+}
+int pg_step(pg_handle* h, int32_t B, const double* state, const double* control, const double* t0, const double* other, const double* toff,
+            double* u_out, int32_t* status, int32_t* iters) {
+    int rc = pg_set_inputs(h, B, state, control, t0, other, toff); if (rc) return rc;
+    if ((rc = pg_step_dev(h, nullptr))) return rc;
+    if (u_out && (rc = pg_get_next_control(h, u_out))) return rc;
+    if (status) HIPCHK(h, hipMemcpy(status, h->d_status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost));
+    if (iters) HIPCHK(h, hipMemcpy(iters, h->d_iters, (size_t)B * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PG_OK;
+}
+
+// ---- read-backs --------------------------------------------------------------------------------------------------
+static int d2h(pg_handle* h, void* dst, const void* src, size_t bytes) {
+    if (!dst) return PG_OK;
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    return PG_OK;
+}
+int pg_get_time_steps(pg_handle* h, double* ts, double* dt, double* prev_ts) {
+    int rc = check_ready(h); if (rc) return rc;
+    const size_t B = h->B; const DevCfg& C = h->dc;
+    if ((rc = d2h(h, ts, h->d_ts, B * C.NN * 8)) || (rc = d2h(h, dt, h->d_dt, B * C.N * 8)) || (rc = d2h(h, prev_ts, h->d_prev_ts, B * C.NN * 8))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PG_OK;
+}
+int pg_get_nodes(pg_handle* h, double* qs, double* us, double* ps) {
+    int rc = check_ready(h); if (rc) return rc;
+    const size_t B = h->B; const DevCfg& C = h->dc;
+    std::vector<double> nd(B * C.NN * 10);
+    HIPCHK(h, hipMemcpyAsync(nd.data(), h->d_nodes, nd.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < B * C.NN; i++) {
+        const double* r = &nd[i * 10];
+        if (qs) for (int k = 0; k < 6; k++) qs[i * 6 + k] = r[k];
+        if (us) { us[i * 2] = r[6]; us[i * 2 + 1] = r[7]; }
+        if (ps) { ps[i * 4] = r[8]; ps[i * 4 + 1] = r[9]; ps[i * 4 + 2] = 0.0; ps[i * 4 + 3] = 0.0; }
+    }
+    return PG_OK;
+}
+int pg_get_path_coordinates(pg_handle* h, double* sep) {
+    int rc = check_ready(h); if (rc) return rc;
+    REQUIRE(h, sep, "sep is null");
+    const size_t B = h->B;
+    std::vector<double> s4(B * 4);
+    HIPCHK(h, hipMemcpyAsync(s4.data(), h->d_sep, s4.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (size_t b = 0; b < B; b++) for (int k = 0; k < 3; k++) sep[b * 3 + k] = s4[b * 4 + k];
+    return PG_OK;
+}
+int pg_get_qp(pg_handle* h, int32_t b0, int32_t n, double* out) {
+    int rc = check_ready(h); if (rc) return rc;
+    REQUIRE(h, out && b0 >= 0 && n >= 1 && b0 + n <= h->B, "pg_get_qp: range outside the batch");
+    HIPCHK(h, hipMemcpyAsync(out, h->d_qp + (size_t)b0 * h->dc.qp_len, (size_t)n * h->dc.qp_len * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PG_OK;
+}
+int pg_get_solution(pg_handle* h, double* x, double* sigma) {
+    int rc = check_ready(h); if (rc) return rc;
+    const size_t B = h->B; const DevCfg& C = h->dc;
+    if ((rc = d2h(h, x, h->d_solx, B * C.NN * 8 * 8)) || (rc = d2h(h, sigma, h->d_sigma, B * C.N * 3 * 8))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PG_OK;
+}
+int pg_get_solve_info(pg_handle* h, int32_t* status, int32_t* iters, uint16_t* active, double* mu) {
+    int rc = check_ready(h); if (rc) return rc;
+    const size_t B = h->B; const DevCfg& C = h->dc;
+    if ((rc = d2h(h, status, h->d_status, B * 4)) || (rc = d2h(h, iters, h->d_iters, B * 4)) || (rc = d2h(h, active, h->d_active, B * C.N * 2)) ||
+        (rc = d2h(h, mu, h->d_mu, B * 8))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PG_OK;
+}
+int pg_get_hji_constraint(pg_handle* h, double* M, double* b, double* V) {
+    int rc = check_ready(h); if (rc) return rc;
+    const size_t B = h->B;
+    std::vector<double> mb(B * 4);
+    if (h->has_hji) { HIPCHK(h, hipMemcpyAsync(mb.data(), h->d_Mb, mb.size() * 8, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream)); }
+    for (size_t i = 0; i < B; i++) {
+        if (!h->has_hji) { mb[4 * i] = 0; mb[4 * i + 1] = 0; mb[4 * i + 2] = 1; mb[4 * i + 3] = INFINITY; }
+        if (M) { M[2 * i] = mb[4 * i]; M[2 * i + 1] = mb[4 * i + 1]; }
+        if (b) b[i] = mb[4 * i + 2];
+        if (V) V[i] = mb[4 * i + 3];
+    }
+    return PG_OK;
+}
+
+int pg_hji_lookup_dev(pg_handle* h, int32_t B, const double* x7_dev, double* V_dev, double* gradV_dev) {
+    if (!h) return PG_ERR_INVALID;
+    REQUIRE(h, h->has_hji, "no HJI grid installed");
+    REQUIRE(h, B >= 1 && x7_dev, "pg_hji_lookup_dev: bad arguments");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    double* out8 = nullptr;
+    HIPCHK(h, hipMalloc((void**)&out8, (size_t)B * 8 * 8));
+    int rc = launch_hji_lookup(h, B, x7_dev, out8);
+    if (!rc) {
+        if (V_dev) HIPCHK(h, hipMemcpy2DAsync(V_dev, 8, out8, 64, 8, B, hipMemcpyDeviceToDevice, h->stream));
+        if (gradV_dev) HIPCHK(h, hipMemcpy2DAsync(gradV_dev, 56, out8 + 1, 64, 56, B, hipMemcpyDeviceToDevice, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(out8);
+    return rc;
+}
+int pg_hji_lookup(pg_handle* h, int32_t B, const double* x7, double* V, double* gradV) {
+    if (!h) return PG_ERR_INVALID;
+    REQUIRE(h, h->has_hji, "no HJI grid installed");
+    REQUIRE(h, B >= 1 && x7, "pg_hji_lookup: bad arguments");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    double *dx = nullptr, *dout = nullptr;
+    HIPCHK(h, hipMalloc((void**)&dx, (size_t)B * 7 * 8));
+    HIPCHK(h, hipMalloc((void**)&dout, (size_t)B * 8 * 8));
+    HIPCHK(h, hipMemcpyAsync(dx, x7, (size_t)B * 7 * 8, hipMemcpyHostToDevice, h->stream));
+    int rc = launch_hji_lookup(h, B, dx, dout);
+    std::vector<double> out((size_t)B * 8);
+    if (!rc) {
+        HIPCHK(h, hipMemcpyAsync(out.data(), dout, out.size() * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (int i = 0; i < B; i++) { if (V) V[i] = out[8 * (size_t)i]; if (gradV) for (int k = 0; k < 7; k++) gradV[7 * (size_t)i + k] = out[8 * (size_t)i + 1 + k]; }
+    }
+    (void)hipFree(dx); (void)hipFree(dout);
+    return rc;
+}
+
+}  // extern "C"

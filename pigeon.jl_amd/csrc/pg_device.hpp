@@ -1,0 +1,264 @@
+// Device-side vehicle physics and trajectory lookups for the MI355X MPC hot path (gfx950, fp64).
+// Written from the reference's equations (file:line cited per function, relative to /root/reference/src);
+// independent of oracle/ (the oracle is test infrastructure and is never included here).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/pigeon_mpc.h"
+
+#define PG_DEV __device__ __forceinline__
+
+namespace pg {
+
+// ---- two-tangent forward-mode number (stands in for ForwardDiff.Dual inside `linearize` and HJI_computation.jl:167) ----
+struct D2 {
+    double v, a, b;
+    PG_DEV D2() {}
+    PG_DEV D2(double x) : v(x), a(0.0), b(0.0) {}
+    PG_DEV D2(double x, double da, double db) : v(x), a(da), b(db) {}
+};
+PG_DEV D2 operator+(D2 x, D2 y) { return D2(x.v + y.v, x.a + y.a, x.b + y.b); }
+PG_DEV D2 operator-(D2 x, D2 y) { return D2(x.v - y.v, x.a - y.a, x.b - y.b); }
+PG_DEV D2 operator-(D2 x) { return D2(-x.v, -x.a, -x.b); }
+PG_DEV D2 operator*(D2 x, D2 y) { return D2(x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b); }
+PG_DEV D2 operator/(D2 x, D2 y) { double inv = 1.0 / y.v, q = x.v * inv; return D2(q, (x.a - q * y.a) * inv, (x.b - q * y.b) * inv); }
+PG_DEV D2 operator+(D2 x, double y) { return D2(x.v + y, x.a, x.b); }
+PG_DEV D2 operator+(double y, D2 x) { return D2(x.v + y, x.a, x.b); }
+PG_DEV D2 operator-(D2 x, double y) { return D2(x.v - y, x.a, x.b); }
+PG_DEV D2 operator-(double y, D2 x) { return D2(y - x.v, -x.a, -x.b); }
+PG_DEV D2 operator*(D2 x, double y) { return D2(x.v * y, x.a * y, x.b * y); }
+PG_DEV D2 operator*(double y, D2 x) { return D2(x.v * y, x.a * y, x.b * y); }
+PG_DEV D2 operator/(D2 x, double y) { double inv = 1.0 / y; return D2(x.v * inv, x.a * inv, x.b * inv); }
+PG_DEV D2 operator/(double x, D2 y) { double inv = 1.0 / y.v, q = x * inv; return D2(q, -q * y.a * inv, -q * y.b * inv); }
+
+PG_DEV double val(double x) { return x; }
+PG_DEV double val(D2 x) { return x.v; }
+PG_DEV D2 chain(D2 x, double f, double df) { return D2(f, df * x.a, df * x.b); }
+
+PG_DEV void sincos_(double x, double& s, double& c) { sincos(x, &s, &c); }
+PG_DEV void sincos_(D2 x, D2& s, D2& c) { double sv, cv; sincos(x.v, &sv, &cv); s = chain(x, sv, cv); c = chain(x, cv, -sv); }
+PG_DEV double tan_(double x) { return tan(x); }
+PG_DEV D2 tan_(D2 x) { double t = tan(x.v); return chain(x, t, 1.0 + t * t); }
+PG_DEV double sqrt_(double x) { return sqrt(x); }
+PG_DEV D2 sqrt_(D2 x) { double s = sqrt(x.v); return chain(x, s, 0.5 / s); }
+PG_DEV double atan2_(double y, double x) { return atan2(y, x); }
+PG_DEV D2 atan2_(D2 y, D2 x) { double inv = 1.0 / (x.v * x.v + y.v * y.v); return D2(atan2(y.v, x.v), (x.v * y.a - y.v * x.a) * inv, (x.v * y.b - y.v * x.b) * inv); }
+PG_DEV double abs_(double x) { return fabs(x); }
+PG_DEV D2 abs_(D2 x) { return x.v < 0.0 ? -x : x; }
+PG_DEV double sgn(double x) { return (double)((x > 0.0) - (x < 0.0)); }
+template <class T> PG_DEV T cst(double x);
+template <> PG_DEV double cst<double>(double x) { return x; }
+template <> PG_DEV D2 cst<D2>(double x) { return D2(x); }
+
+// Julia min/max propagate NaN
+PG_DEV double jmin(double a, double b) { return (a != a || b != b) ? NAN : (b < a ? b : a); }
+PG_DEV double jmax(double a, double b) { return (a != a || b != b) ? NAN : (b > a ? b : a); }
+PG_DEV double clampd(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
+
+// ---- tire model: vehicle_dynamics.jl:35-48 ----
+template <class T>
+PG_DEV T fiala(T alpha, double Ca, double mu, T Fx, T Fz) {
+    T Fmax = mu * Fz;
+    if (abs_(val(Fx)) >= val(Fmax)) return cst<T>(0.0);
+    T Fy_max = sqrt_(Fmax * Fmax - Fx * Fx);
+    T tana = tan_(alpha);
+    T slide = (3.0 / Ca) * Fy_max;
+    T ratio = abs_(tana / slide);
+    if (val(ratio) <= 1.0) return -(Ca * tana) * (1.0 - ratio + ratio * ratio * (1.0 / 3.0));
+    return -Fy_max * sgn(val(tana));
+}
+// vehicle_dynamics.jl:56-62 (returns tan(alpha))
+PG_DEV double inv_fiala_tan(double Fy, double Ca, double Fy_max) {
+    if (fabs(Fy) >= Fy_max) return -(3.0 * Fy_max / Ca) * sgn(Fy);
+    return -(1.0 + cbrt(fabs(Fy) / Fy_max - 1.0)) * sgn(Fy);
+}
+// vehicle_dynamics.jl:64-76: 3-iteration front-axle load-transfer fixed point, then rear
+template <class T>
+PG_DEV void lateral_forces(const pg_vehicle& P, T af, T ar, T Fxf, T Fxr, T sd, T cd, T& Fyf, T& Fyr) {
+    const double W_b = P.m * P.G * P.b, W_a = P.m * P.G * P.a, invL = 1.0 / P.L;
+    Fyf = cst<T>(0.0);
+    T Fx = Fxf * cd + Fxr;
+#pragma unroll 1
+    for (int i = 0; i < 3; i++) {
+        T Fzf = (W_b - P.h * Fx) * invL;
+        Fyf = fiala<T>(af, P.Caf, P.mu, Fxf, Fzf);
+        Fx = Fxf * cd - Fyf * sd + Fxr;
+    }
+    T Fzr = (W_a + P.h * Fx) * invL;
+    Fyr = fiala<T>(ar, P.Car, P.mu, Fxr, Fzr);
+}
+
+// apply_control_limits (vehicle_dynamics.jl:293-298; Ux by value) followed by longitudinal_tire_forces (:279-283)
+template <class T>
+PG_DEV void actuate(const pg_vehicle& P, T delta, T Fx, double Ux, T& d_out, T& Fxf, T& Fxr) {
+    double dv = val(delta);
+    d_out = dv > P.delta_max ? cst<T>(P.delta_max) : (dv < -P.delta_max ? cst<T>(-P.delta_max) : delta);
+    double cap = jmin(P.Fx_max, P.Px_max / Ux);
+    T f = Fx;
+    if (cap < val(f)) f = cst<T>(cap);
+    if (P.Fx_min > val(f)) f = cst<T>(P.Fx_min);
+    if (val(f) > 0.0) { Fxf = f * P.fwd_frac; Fxr = f * P.rwd_frac; }
+    else              { Fxf = f * P.fwb_frac; Fxr = f * P.rwb_frac; }
+}
+
+// body-frame accelerations common to BicycleModel (:114-133) and TrackingBicycleModel (:162-178)
+template <class T>
+PG_DEV void body_accel(const pg_vehicle& P, T Ux, T Uy, T r, T delta, T Fxf, T Fxr, T& dUx, T& dUy, T& dr) {
+    T sd, cd; sincos_(delta, sd, cd);
+    T af = atan2_(Uy + P.a * r, Ux) - delta;
+    T ar = atan2_(Uy - P.b * r, Ux);
+    T Fyf, Fyr;
+    lateral_forces<T>(P, af, ar, Fxf, Fxr, sd, cd, Fyf, Fyr);
+    T Fx_drag = -P.Cd0 - Ux * (P.Cd1 + P.Cd2 * Ux);
+    T Fxf_t = Fxf * cd - Fyf * sd;
+    T Fyf_t = Fyf * cd + Fxf * sd;
+    const double invm = 1.0 / P.m, invI = 1.0 / P.Izz;
+    dUx = (Fxf_t + Fxr + Fx_drag) * invm + r * Uy;
+    dUy = (Fyf_t + Fyr) * invm - r * Ux;
+    dr = (P.a * Fyf_t - P.b * Fyr) * invI;
+}
+
+// VehicleModel{TrackingBicycleModel}: vehicle_dynamics.jl:310-315 over :159-183.  q=(ds,Ux,Uy,r,dpsi,e), u=(delta,Fx), p=(V,kappa)
+template <class T>
+PG_DEV void tracking_rhs(const pg_vehicle& P, const T q[6], T u0, T u1, double pV, double pK, T out[6]) {
+    T d, Fxf, Fxr;
+    actuate<T>(P, u0, u1, val(q[1]), d, Fxf, Fxr);
+    T s, c; sincos_(q[4], s, c);
+    T vs = q[1] * c - q[2] * s;
+    out[0] = vs - pV;
+    body_accel<T>(P, q[1], q[2], q[3], d, Fxf, Fxr, out[1], out[2], out[3]);
+    out[4] = q[3] - vs * pK;
+    out[5] = q[1] * s + q[2] * c;
+}
+// VehicleModel{BicycleModel}: vehicle_dynamics.jl:310-314 over :111-135; only the components the hot path reads (dUx,dUy,dr)
+template <class T>
+PG_DEV void world_body_rhs(const pg_vehicle& P, double Ux, double Uy, double r, T u0, T u1, T& dUx, T& dUy, T& dr) {
+    T d, Fxf, Fxr;
+    actuate<T>(P, u0, u1, Ux, d, Fxf, Fxr);
+    body_accel<T>(P, cst<T>(Ux), cst<T>(Uy), cst<T>(r), d, Fxf, Fxr, dUx, dUy, dr);
+}
+
+// stable_limits: vehicle_dynamics.jl:227-263
+struct Envelope { double dmin, dmax, H[4][2], G[4]; };
+PG_DEV Envelope stable_limits(const pg_vehicle& B, double Ux, double Fxf, double Fxr) {
+    double Fx = Fxf + Fxr;
+    double Fzf = (B.m * B.G * B.b - B.h * Fx) / B.L, Fzr = (B.m * B.G * B.a + B.h * Fx) / B.L;
+    double Ffm = B.mu * Fzf, Frm = B.mu * Fzr;
+    double Fyf_max = fabs(Fxf) > Ffm ? 0.0 : sqrt(Ffm * Ffm - Fxf * Fxf);
+    double Fyr_max = fabs(Fxr) > Frm ? 0.0 : sqrt(Frm * Frm - Fxr * Fxr);
+    double tf = 3.0 * Fyf_max / B.Caf, tr = 3.0 * Fyr_max / B.Car;
+    double af = atan(tf), ar = atan(tr);
+    Envelope o;
+    double muG = B.mu * B.G, Ux2 = Ux * Ux;
+    o.dmax = atan(B.L * muG / Ux2 - tr) + af;
+    o.dmin = atan(-B.L * muG / Ux2 + tr) - af;
+    double rC = muG / Ux, UyC = -Ux * tr + B.b * rC;
+    double rD = Ux / B.L * (tan(af + o.dmax) - tr), UyD = Ux * tr + B.b * rD;
+    double mCD = (rD - rC) / (UyD - UyC);
+    double rE = Ux / B.L * (tan(-af + o.dmin) + tr), UyE = -Ux * tr + B.b * rE;
+    double rF = -muG / Ux, UyF = Ux * tr + B.b * rF;
+    double mEF = (rF - rE) / (UyF - UyE);
+    o.H[0][0] = 1.0 / Ux;  o.H[0][1] = -B.b / Ux;
+    o.H[1][0] = -1.0 / Ux; o.H[1][1] = B.b / Ux;
+    o.H[2][0] = -mCD;      o.H[2][1] = 1.0;
+    o.H[3][0] = mEF;       o.H[3][1] = -1.0;
+    o.G[0] = ar; o.G[1] = ar; o.G[2] = rC - UyC * mCD; o.G[3] = -rF + UyF * mEF;
+    return o;
+}
+
+// steady_state_estimates: vehicle_dynamics.jl:319-390
+struct Steady { double beta, Ux, Uy, r, A, delta, Fx; };
+PG_DEV Steady steady_state(const pg_vehicle& P, double V, double A_tan, double kappa, int num_iters, double r, double beta, double delta, double Fyf) {
+    double A_rad = V * V * kappa;
+    double A_max = P.mu * P.G;
+    if (hypot(A_tan, A_rad) > A_max) {
+        if (fabs(A_rad) > A_max) { A_rad = A_max * sgn(A_rad); A_tan = 0.0; }
+        else A_tan = sqrt(A_max * A_max - A_rad * A_rad) * sgn(A_tan);
+    }
+    double rdot = A_tan * kappa;
+    double Fxr = 0.0, Fxf = 0.0, A_out = A_tan;
+#pragma unroll 1
+    for (int i = 1;; i++) {
+        double sb, cb, sd, cd; sincos(beta, &sb, &cb); sincos(delta, &sd, &cd);
+        double Ux = V * cb, Uy = V * sb;
+        double Fx_drag = -P.Cd0 - Ux * (P.Cd1 + P.Cd2 * Ux);
+        double Ax = A_tan * cb - A_rad * sb, Ay = A_tan * sb + A_rad * cb;
+        double Fx = Ax * P.m - Fx_drag;
+        Fx = jmin(Fx, jmin(P.Fx_max, P.Px_max / Ux) * (P.rwd_frac + P.fwd_frac * cd) - Fyf * sd);
+        double Fzr = (P.m * P.G * P.a + P.h * Fx) / P.L, Fzf = (P.m * P.G * P.b - P.h * Fx) / P.L;
+        double Frm = P.mu * Fzr, Ffm = P.mu * Fzf;
+        double frac = Fx > 0.0 ? P.rwd_frac / (P.rwd_frac + P.fwd_frac * cd) : P.rwb_frac / (P.rwb_frac + P.fwb_frac * cd);
+        Fxr = clampd((Fx + Fyf * sd) * frac, -Frm, Frm);
+        double Fyr_max = sqrt(Frm * Frm - Fxr * Fxr);
+        double Fyr = clampd((Ay * P.m - rdot * P.Izz / P.a) / (1.0 + P.b / P.a), -Fyr_max, Fyr_max);
+        double tanar = inv_fiala_tan(Fyr, P.Car, Fyr_max);
+        double Fxf_t = clampd(Fx - Fxr, -Ffm, Ffm);
+        double Fyf_tmax = sqrt(Ffm * Ffm - Fxf_t * Fxf_t);
+        double Fyf_t = clampd((P.b * Fyr + rdot * P.Izz) / P.a, -Fyf_tmax, Fyf_tmax);
+        Fxf = Fxf_t * cd + Fyf_t * sd;
+        Fyf = Fyf_t * cd - Fxf_t * sd;
+        double Fyf_max = sqrt(Ffm * Ffm - Fxf * Fxf);
+        double af = atan(inv_fiala_tan(Fyf, P.Caf, Fyf_max));
+        delta = atan2(Uy + P.a * r, Ux) - af;
+        if (i == num_iters) {
+            double Ax2 = (Fxf * cd - Fyf * sd + Fxr + Fx_drag) / P.m;
+            double Ay2 = (Fyf * cd + Fxf * sd + Fyr) / P.m;
+            A_out = Ax2 * cb + Ay2 * sb;
+            break;
+        }
+        beta = atan(tanar + P.b * r / Ux);
+    }
+    Steady o;
+    double sb, cb; sincos(beta, &sb, &cb);
+    o.beta = beta; o.Ux = V * cb; o.Uy = V * sb; o.r = r; o.A = A_out; o.delta = delta; o.Fx = Fxf + Fxr;
+    return o;
+}
+
+// ---- trajectory (trajectories.jl) ----
+struct TrajView {
+    int L;
+    const double *t, *s, *V, *A, *E, *N, *psi, *kappa;   // theta, phi, edges are carried by the tube but read by nothing on this path
+};
+// count of elements < x  (Julia searchsortedfirst - 1)
+PG_DEV int count_less(const double* v, int n, double x) {
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (v[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+// count of elements <= x (Julia searchsortedlast)
+PG_DEV int count_leq(const double* v, int n, double x) {
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (v[mid] <= x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+PG_DEV int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// traj(t).s : trajectories.jl:47-54 (only the arclength is read by the hot path, coupled_lat_long.jl:77,96,114)
+PG_DEV double traj_s_at_time(const TrajView& T, double tq) {
+    int i = clampi(count_less(T.t, T.L, tq), 1, T.L - 1) - 1;
+    double Ai = (T.V[i + 1] - T.V[i]) / (T.t[i + 1] - T.t[i]);
+    double dt = tq - T.t[i];
+    return T.s[i] + T.V[i] * dt + Ai * dt * dt * 0.5;
+}
+// traj[s] : trajectories.jl:55-68 -> (V, A, psi, kappa)
+struct TrajS { double V, A, psi, kappa; };
+PG_DEV TrajS traj_at_s(const TrajView& T, double sq) {
+    int i = clampi(count_less(T.s, T.L, sq), 1, T.L - 1) - 1;
+    double Ai = (T.V[i + 1] - T.V[i]) / (T.t[i + 1] - T.t[i]);
+    double ds = sq - T.s[i], dt;
+    if (fabs(Ai) < 1e-3 || sq > T.s[T.L - 1]) dt = ds / T.V[i];
+    else dt = (sqrt(2.0 * Ai * ds + T.V[i] * T.V[i]) - T.V[i]) / Ai;
+    TrajS o; o.V = T.V[i] + Ai * dt; o.A = Ai;
+    int j = clampi(count_leq(T.s, T.L, sq), 1, T.L - 1) - 1;          // interp_by_s: Gridded(Linear()) + Line() (trajectories.jl:32-35)
+    double w = (sq - T.s[j]) / (T.s[j + 1] - T.s[j]);
+    o.psi = T.psi[j] + w * (T.psi[j + 1] - T.psi[j]);
+    o.kappa = T.kappa[j] + w * (T.kappa[j + 1] - T.kappa[j]);
+    return o;
+}
+// adiff: DifferentialDynamicsModels (absent); semantics restated at PigeonViz.jl:24-28
+PG_DEV double adiff(double x, double y) {
+    const double twopi = 6.283185307179586476925286766559;
+    double d = fmod(x - y, twopi);
+    if (d < 0.0) d += twopi;
+    return d <= 3.14159265358979323846 ? d : d - twopi;
+}
+
+}  // namespace pg

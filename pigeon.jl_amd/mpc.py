@@ -1,0 +1,276 @@
+"""Host-side mirror of the reference's MPC call convention for a BATCH of independent instances.
+
+Reference seam (relative to /root/reference/src): the five generic functions of model_predictive_control.jl:70-78
+applied to a mutable TrajectoryTrackingMPC (:32-68), called in this order by ros_integration.jl:96-99,124 and by
+simulate (:80-100).  Julia's `f!(mpc)` spelling becomes `f_(mpc)` here; argument meaning and order are unchanged.
+Everything numerical happens in libpigeon_hip.so (HIP, gfx950); this module only marshals arrays.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from .trajectories import TrajectoryTube
+from .vehicles import X1, CoupledControlParams
+
+c_dp = C.POINTER(C.c_double)
+
+SOLVED, MAX_ITER, NUMERICAL, INFEASIBLE_X0 = 1, 2, 3, 4
+
+
+def _p(a, ctype=c_dp):
+    return None if a is None else a.ctypes.data_as(ctype)
+
+
+def _f64(x, shape=None):
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class BatchedTrajectoryTrackingMPC:
+    """B copies of CoupledTrajectoryTrackingMPC(vehicle, trajectory; ...) (coupled_lat_long.jl:42-60) on one MI355X."""
+
+    def __init__(self, trajectory, batch_capacity, vehicle=None, control_params=None, N_short=10, N_long=20, dt_short=0.01, dt_long=0.2,
+                 use_correction_step=True, rk4_substeps=10, device=0, ipm_max_iter=40, ipm_tol=1e-13, ipm_mu0=100.0, hji_eps=0.05):
+        self.lib = _lib.load_library()
+        cfg = _lib.pg_config()
+        self.lib.pg_default_config(C.byref(cfg))
+        self.vehicle = X1() if vehicle is None else dict(vehicle)
+        self.control_params = CoupledControlParams() if control_params is None else dict(control_params)
+        for name, _ in _lib.pg_vehicle._fields_:
+            setattr(cfg.vehicle, name, float(self.vehicle[name]))
+        for name, _ in _lib.pg_control_params._fields_:
+            if name == "_pad":
+                continue
+            setattr(cfg.control, name, int(self.control_params[name]) if name == "N_HJI" else float(self.control_params[name]))
+        cfg.N_short, cfg.N_long, cfg.dt_short, cfg.dt_long = N_short, N_long, dt_short, dt_long
+        cfg.use_correction_step, cfg.rk4_substeps, cfg.batch_capacity, cfg.device = int(use_correction_step), rk4_substeps, batch_capacity, device
+        cfg.ipm_max_iter, cfg.ipm_tol, cfg.ipm_mu0, cfg.hji_eps = ipm_max_iter, ipm_tol, ipm_mu0, hji_eps
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        rc = self.lib.pg_create(C.byref(cfg), C.byref(self.h))
+        if rc != 0:
+            raise _lib.PigeonError(f"pg_create failed with status {rc}: {self.lib.pg_last_error(None).decode()}")
+        self.N_short, self.N_long = N_short, N_long
+        self.N = N_short + N_long
+        self.NN = self.N + 1
+        self.capacity = batch_capacity
+        self.B = 0
+        un = np.zeros(2)
+        self._chk(self.lib.pg_get_u_normalization(self.h, _p(un)), "pg_get_u_normalization")
+        self.u_normalization = un
+        self.qp_len = self.lib.pg_qp_len(self.h)
+        self.trajectory = None
+        if trajectory is not None:
+            self.set_trajectory(trajectory)
+
+    def _chk(self, rc, what):
+        _lib.check(self.lib, self.h, rc, what)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.pg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- mpc.trajectory = ... (ros_integration.jl:53) ----
+    def set_trajectory(self, traj: TrajectoryTube):
+        self.trajectory = traj
+        cols = [np.ascontiguousarray(traj.data[i]) for i in range(12)]
+        self._chk(self.lib.pg_set_trajectory(self.h, len(traj), *[_p(c) for c in cols]), "pg_set_trajectory")
+
+    # ---- mpc.HJI_cache = HJICache(...) (Pigeon.jl:40) ----
+    def set_hji_cache(self, grid_knots, V_raw, gradV_raw):
+        dims = np.array([len(k) for k in grid_knots], dtype=np.int32)
+        kc = np.ascontiguousarray(np.concatenate([np.asarray(k, dtype=np.float32) for k in grid_knots]))
+        V = np.ascontiguousarray(V_raw, dtype=np.float32).reshape(-1)
+        g = np.ascontiguousarray(gradV_raw, dtype=np.float32).reshape(-1)
+        assert V.size == int(np.prod(dims.astype(np.int64))) and g.size == 7 * V.size
+        self._chk(self.lib.pg_set_hji_grid(self.h, _p(dims, C.POINTER(C.c_int32)), _p(kc, C.POINTER(C.c_float)), _p(V, C.POINTER(C.c_float)),
+                                           _p(g, C.POINTER(C.c_float))), "pg_set_hji_grid")
+
+    def clear_hji_cache(self):
+        self._chk(self.lib.pg_clear_hji_grid(self.h), "pg_clear_hji_grid")
+
+    # ---- mpc.solved = false (ros_integration.jl:34,41,147) ----
+    def reset(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self._chk(self.lib.pg_reset(self.h, _p(m, C.POINTER(C.c_uint8))), "pg_reset")
+
+    # ---- mpc.current_state / current_control / other_car_state / time_offset + the time argument of compute_time_steps! ----
+    def set_inputs(self, current_state, current_control, t, other_car_state=None, time_offset=None):
+        s = _f64(current_state).reshape(-1, 6)
+        B = s.shape[0]
+        c = _f64(current_control, (B, 3)); t0 = _f64(t, (B,))
+        o = None if other_car_state is None else _f64(other_car_state, (B, 4))
+        to = None if time_offset is None else _f64(time_offset, (B,))
+        self._chk(self.lib.pg_set_inputs(self.h, B, _p(s), _p(c), _p(t0), _p(o), _p(to)), "pg_set_inputs")
+        self.B = B
+
+    def set_inputs_dev(self, B, state_ptr, control_ptr, t0_ptr, other_ptr=None, toff_ptr=None):
+        """Inputs already resident in HBM (raw device addresses, e.g. torch.Tensor.data_ptr())."""
+        vp = lambda a: C.c_void_p(a) if a else None
+        self._chk(self.lib.pg_set_inputs_dev(self.h, B, vp(state_ptr), vp(control_ptr), vp(t0_ptr), vp(other_ptr), vp(toff_ptr)), "pg_set_inputs_dev")
+        self.B = B
+
+    # ---- the five reference calls ----
+    def compute_time_steps_(self, t0=None):
+        """compute_time_steps!(mpc, t0): model_predictive_control.jl:70.  t0 (array of B) may also come from set_inputs."""
+        if t0 is not None:
+            raise ValueError("pass t through set_inputs(state, control, t, ...): the batch keeps its inputs in device memory")
+        self._chk(self.lib.pg_compute_time_steps(self.h), "pg_compute_time_steps")
+
+    def compute_linearization_nodes_(self):
+        self._chk(self.lib.pg_compute_linearization_nodes(self.h), "pg_compute_linearization_nodes")
+
+    def update_QP_(self):
+        self._chk(self.lib.pg_update_qp(self.h), "pg_update_qp")
+
+    def solve_(self):
+        self._chk(self.lib.pg_solve(self.h), "pg_solve")
+
+    def get_next_control(self):
+        """BicycleControl (delta, Fxf, Fxr) per instance: coupled_lat_long.jl:370-374."""
+        u = np.zeros((self.B, 3))
+        self._chk(self.lib.pg_get_next_control(self.h, _p(u)), "pg_get_next_control")
+        return u
+
+    def step_(self, current_state, current_control, t, other_car_state=None, time_offset=None):
+        """The whole callback body of ros_integration.jl:94-99,124 for every instance; returns (u, status, iters)."""
+        s = _f64(current_state).reshape(-1, 6); B = s.shape[0]
+        c = _f64(current_control, (B, 3)); t0 = _f64(t, (B,))
+        o = None if other_car_state is None else _f64(other_car_state, (B, 4))
+        to = None if time_offset is None else _f64(time_offset, (B,))
+        u = np.zeros((B, 3)); st = np.zeros(B, dtype=np.int32); it = np.zeros(B, dtype=np.int32)
+        self._chk(self.lib.pg_step(self.h, B, _p(s), _p(c), _p(t0), _p(o), _p(to), _p(u), _p(st, C.POINTER(C.c_int32)), _p(it, C.POINTER(C.c_int32))), "pg_step")
+        self.B = B
+        return u, st, it
+
+    MPC_ = step_      # the convenience names BASELINE.json's north star uses
+
+    def step_dev(self, u_out_ptr=None):
+        self._chk(self.lib.pg_step_dev(self.h, C.c_void_p(u_out_ptr) if u_out_ptr else None), "pg_step_dev")
+
+    def synchronize(self):
+        self._chk(self.lib.pg_synchronize(self.h), "pg_synchronize")
+
+    def set_stream(self, hip_stream):
+        self._chk(self.lib.pg_set_stream(self.h, C.c_void_p(hip_stream)), "pg_set_stream")
+
+    def phase_ms(self):
+        out = (C.c_float * 3)()
+        self._chk(self.lib.pg_get_phase_ms(self.h, out), "pg_get_phase_ms")
+        return [out[i] for i in range(3)]
+
+    # ---- read-backs ----
+    def time_steps(self):
+        ts = np.zeros((self.B, self.NN)); dt = np.zeros((self.B, self.N)); pts = np.zeros((self.B, self.NN))
+        self._chk(self.lib.pg_get_time_steps(self.h, _p(ts), _p(dt), _p(pts)), "pg_get_time_steps")
+        return ts, dt, pts
+
+    def nodes(self):
+        qs = np.zeros((self.B, self.NN, 6)); us = np.zeros((self.B, self.NN, 2)); ps = np.zeros((self.B, self.NN, 4))
+        self._chk(self.lib.pg_get_nodes(self.h, _p(qs), _p(us), _p(ps)), "pg_get_nodes")
+        return qs, us, ps
+
+    def path_coordinates(self):
+        sep = np.zeros((self.B, 3))
+        self._chk(self.lib.pg_get_path_coordinates(self.h, _p(sep)), "pg_get_path_coordinates")
+        return sep
+
+    def qp_data(self, b0=0, n=None):
+        n = self.B - b0 if n is None else n
+        out = np.zeros((n, self.qp_len))
+        self._chk(self.lib.pg_get_qp(self.h, b0, n, _p(out)), "pg_get_qp")
+        return out
+
+    def solution(self):
+        x = np.zeros((self.B, self.NN, 8)); sg = np.zeros((self.B, self.N, 3))
+        self._chk(self.lib.pg_get_solution(self.h, _p(x), _p(sg)), "pg_get_solution")
+        return x, sg
+
+    def solve_info(self):
+        st = np.zeros(self.B, dtype=np.int32); it = np.zeros(self.B, dtype=np.int32); act = np.zeros((self.B, self.N), dtype=np.uint16); mu = np.zeros(self.B)
+        self._chk(self.lib.pg_get_solve_info(self.h, _p(st, C.POINTER(C.c_int32)), _p(it, C.POINTER(C.c_int32)), _p(act, C.POINTER(C.c_uint16)), _p(mu)),
+                  "pg_get_solve_info")
+        return st, it, act, mu
+
+    def hji_constraint(self):
+        M = np.zeros((self.B, 2)); b = np.zeros(self.B); V = np.zeros(self.B)
+        self._chk(self.lib.pg_get_hji_constraint(self.h, _p(M), _p(b), _p(V)), "pg_get_hji_constraint")
+        return M, b, V
+
+    def hji_lookup(self, x7):
+        """cache[x] for a batch of HJIRelativeState rows: HJI_computation.jl:66-72."""
+        x = _f64(x7).reshape(-1, 7); B = x.shape[0]
+        V = np.zeros(B); g = np.zeros((B, 7))
+        self._chk(self.lib.pg_hji_lookup(self.h, B, _p(x), _p(V), _p(g)), "pg_hji_lookup")
+        return V, g
+
+    # ---- canonical active-set indices (row numbering of the reference's QP) ----
+    def canonical_active_set(self, b, act_masks, qp_row):
+        """Signed 1-based row indices of the reference QP that are active for instance b: +i upper bound, -i lower bound.
+        act_masks: [N] uint16 from solve_info(); qp_row: this instance's pg_get_qp block (for the fixed first node)."""
+        N, Ns = self.N, self.N_short
+        cp = self.control_params
+        r_C1 = 0; r_C2 = r_C1 + 2 * N; r_C3 = r_C2 + Ns; r_C4 = r_C3 + N; r_C5 = r_C4 + N; r_C6 = r_C5 + N + 1; r_C7 = r_C6 + N + 1
+        r_C8 = r_C7 + N + 1; r_C9 = r_C8 + 6; r_C10 = r_C9 + 2; r_C11 = r_C10 + 6 * Ns; r_C12 = r_C11 + Ns; r_C13 = r_C12 + 6 * self.N_long
+        out = []
+        nh = min(int(cp["N_HJI"]), Ns)
+        # node 1 (fixed): sigma_HJI_1 = max(0, -(M u_1 + b)); its two rows are decided in closed form
+        M = qp_row[-3:-1]; bh = qp_row[-1]; u1 = qp_row[-5:-3]
+        if nh >= 1 and cp["W_HJI"] > 0:
+            if M @ u1 + bh < 0:
+                out.append(-(r_C11 + 0 + 1))
+            else:
+                out.append(-(r_C2 + 0 + 1))
+        for k in range(N):
+            m = int(act_masks[k]); node = k + 1
+            bit = lambda j: (m >> j) & 1
+            if bit(0): out.append(-(r_C5 + node + 1))
+            if bit(1): out.append(+(r_C6 + node + 1))
+            if bit(2): out.append(-(r_C7 + node + 1))
+            base = r_C13 + 9 * k
+            if bit(3): out.append(+(base + 0 + 1))
+            if bit(4): out.append(-(base + 1 + 1))
+            if bit(5): out.append(+(base + 2 + 1))
+            for i in range(4):
+                if bit(6 + i): out.append(+(base + 3 + i + 1))
+            if bit(10): out.append(-(r_C1 + 2 * k + 0 + 1))
+            if bit(11): out.append(-(r_C1 + 2 * k + 1 + 1))
+            if bit(12): out.append(+(base + 7 + 1))
+            if bit(13): out.append(-(base + 8 + 1))
+            if node < nh:
+                if bit(14): out.append(-(r_C11 + node + 1))
+                if bit(15): out.append(-(r_C2 + node + 1))
+        return sorted(out, key=abs)
+
+
+def CoupledTrajectoryTrackingMPC(vehicle, trajectory, batch_capacity=1, **kw):
+    """Name of the reference constructor (coupled_lat_long.jl:42); returns the batched type."""
+    return BatchedTrajectoryTrackingMPC(trajectory, batch_capacity, vehicle=vehicle, **kw)
+
+
+def simulate(mpc: BatchedTrajectoryTrackingMPC, plant_step, q0, u0, steps, dt=0.01, t_start=None, time_offset=None):
+    """Closed-loop harness with the semantics of simulate (model_predictive_control.jl:80-100): the state is advanced with the
+    OLD control, then the control is replaced (one-step actuation delay).  `plant_step(q[B,6], u[B,3], dt) -> q` is supplied by
+    the caller (the nonlinear plant is not part of the GPU hot path)."""
+    q = _f64(q0).reshape(-1, 6).copy(); u = _f64(u0, q.shape[:1] + (3,)).copy()
+    t = np.zeros(q.shape[0]) if t_start is None else _f64(t_start, (q.shape[0],)).copy()
+    hist = []
+    for _ in range(steps):
+        hist.append((q.copy(), u.copy()))
+        mpc.set_inputs(q, u, t, time_offset=time_offset)
+        mpc.compute_time_steps_(); mpc.compute_linearization_nodes_(); mpc.update_QP_(); mpc.solve_()
+        q = plant_step(q, u, dt)
+        u = mpc.get_next_control()
+        t = t + dt
+    return hist

@@ -1,0 +1,123 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Tolerances (fp64 path): intermediates 1e-9 relative-inf (different summation orders / libm vs ocml transcendental functions);
+optimal controls 1e-6 relative-inf on NORMALISED controls against the oracle's exact optimum of the SAME QP data (north star);
+active-set index lists identical.
+"""
+import numpy as np
+import pytest
+
+from conftest import make_oracle
+
+pytestmark = pytest.mark.gpu
+
+B_SMALL = 96
+
+
+def rel_inf(a, b, floor=1.0):
+    a = np.asarray(a); b = np.asarray(b)
+    return float(np.max(np.abs(a - b)) / max(floor, float(np.max(np.abs(b)))))
+
+
+@pytest.fixture(scope="module")
+def setup(pkg, oracle_mod, skidpad):
+    mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, B_SMALL)
+    orc = make_oracle(oracle_mod, skidpad)
+    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B_SMALL, seed=12345)
+    return mpc, orc, state, control, t0, toff
+
+
+def oracle_pipeline(orc, state, control, t0, toff, b, other=(0, 0, 0, 0)):
+    ts, dt = orc.time_steps(t0[b])
+    qs, us, ps = orc.nodes(state[b], control[b], ts, dt, time_offset=toff[b])
+    sd = orc.update_qp(qs, us, ps, dt, state[b], control[b], other)
+    return ts, dt, qs, us, ps, sd
+
+
+def test_time_steps_and_projection(setup):
+    mpc, orc, state, control, t0, toff = setup
+    mpc.set_inputs(state, control, t0, time_offset=toff)
+    mpc.compute_time_steps_()
+    mpc.compute_linearization_nodes_()
+    ts, dt, pts = mpc.time_steps()
+    sep = mpc.path_coordinates()
+    for b in range(B_SMALL):
+        ots, odt = orc.time_steps(t0[b])
+        assert np.array_equal(ts[b], ots) and np.array_equal(dt[b], odt)
+        assert np.array_equal(pts[b], ts[b])          # prev_ts aliases ts in the reference (model_predictive_control.jl:15)
+        s, e, t, _ = orc.path_coordinates(state[b, 0], state[b, 1])
+        assert abs(sep[b, 0] - s) <= 1e-9 * max(1, abs(s)) and abs(sep[b, 1] - e) <= 1e-9 and abs(sep[b, 2] - t) <= 1e-9 * max(1, abs(t))
+
+
+def test_cold_nodes(setup):
+    mpc, orc, state, control, t0, toff = setup
+    mpc.reset()
+    mpc.set_inputs(state, control, t0, time_offset=toff)
+    mpc.compute_time_steps_(); mpc.compute_linearization_nodes_()
+    qs, us, ps = mpc.nodes()
+    for b in range(B_SMALL):
+        _, _, oq, ou, op, _ = oracle_pipeline(orc, state, control, t0, toff, b)
+        assert rel_inf(qs[b], oq) < 1e-9, b
+        assert rel_inf(us[b], ou) < 1e-9, b
+        assert rel_inf(ps[b], op) < 1e-9, b
+
+
+def test_qp_data(setup):
+    mpc, orc, state, control, t0, toff = setup
+    mpc.reset()
+    mpc.set_inputs(state, control, t0, time_offset=toff)
+    mpc.compute_time_steps_(); mpc.compute_linearization_nodes_(); mpc.update_QP_()
+    qp = mpc.qp_data()
+    assert qp.shape[1] == orc.sd_len
+    for b in range(B_SMALL):
+        sd = oracle_pipeline(orc, state, control, t0, toff, b)[5]
+        G = orc.unpack_sd(qp[b]); O = orc.unpack_sd(sd)
+        for k in O:
+            assert rel_inf(G[k], O[k]) < 1e-8, (b, k, rel_inf(G[k], O[k]))
+
+
+def test_solve_matches_exact_optimum(setup, oracle_mod):
+    mpc, orc, state, control, t0, toff = setup
+    mpc.reset()
+    u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
+    assert np.all(status == 1), status
+    qp = mpc.qp_data()
+    x, sg = mpc.solution()
+    st, it, act, mu = mpc.solve_info()
+    worst_u2 = 0.0; worst_all = 0.0
+    for b in range(B_SMALL):
+        xe, ye, info = orc.solve_exact(qp[b])            # exact optimum of the SAME QP data the GPU solved
+        assert info["status"] == 1
+        X = orc.split_x(xe)
+        worst_u2 = max(worst_u2, rel_inf(x[b, 1, 6:], X["u"][1]))
+        worst_all = max(worst_all, rel_inf(x[b, :, 6:], X["u"]), rel_inf(x[b, :, :6], X["q"]))
+        un = orc.next_control(X["u"][1])
+        assert rel_inf(u[b] / [mpc.u_normalization[0], mpc.u_normalization[1], mpc.u_normalization[1]],
+                       un / [mpc.u_normalization[0], mpc.u_normalization[1], mpc.u_normalization[1]]) < 1e-6
+        qpc = orc.assemble_qp(qp[b])
+        assert mpc.canonical_active_set(b, act[b], qp[b]) == oracle_mod.active_set(qpc, xe, ye, tol=1e-6), b
+    assert worst_u2 < 1e-6, worst_u2
+    assert worst_all < 1e-5, worst_all
+
+
+def test_warm_second_step(setup):
+    """Second consecutive step: warm branch of compute_linearization_nodes! (coupled_lat_long.jl:82-102) on both sides."""
+    mpc, orc, state, control, t0, toff = setup
+    mpc.reset()
+    u1, status, _ = mpc.step_(state, control, t0, time_offset=toff)
+    x1, _ = mpc.solution()
+    ts1, _, _ = mpc.time_steps()
+    # advance the plant with the OLD control (simulate semantics, model_predictive_control.jl:94-95) using the oracle's plant model
+    state2 = np.stack([orc.plant_step(state[b], control[b], 0.01) for b in range(B_SMALL)])
+    u2, status2, _ = mpc.step_(state2, u1, t0 + 0.01, time_offset=toff)
+    assert np.all(status2 == 1)
+    qs, us, ps = mpc.nodes()
+    qp = mpc.qp_data()
+    x2, _ = mpc.solution()
+    for b in range(0, B_SMALL, 4):
+        ts, dt = orc.time_steps(t0[b] + 0.01)
+        oq, ou, op = orc.nodes(state2[b], u1[b], ts, dt, time_offset=toff[b], solved=True, prev_ts=ts, prev_q=x1[b, :, :6], prev_u=x1[b, :, 6:])
+        assert rel_inf(qs[b], oq) < 1e-9 and rel_inf(us[b], ou) < 1e-9 and rel_inf(ps[b], op) < 1e-9
+        xe, ye, info = orc.solve_exact(qp[b])
+        X = orc.split_x(xe)
+        assert rel_inf(x2[b, 1, 6:], X["u"][1]) < 1e-6
