@@ -35,6 +35,11 @@ struct MPCTimeSteps {
     int N_short = 10, N_long = 20;
     double dt_short = 0.01, dt_long = 0.2;
     bool use_correction_step = true;
+    // The reference's constructor passes the SAME array as `ts` and `prev_ts` (model_predictive_control.jl:15,
+    // `MPCTimeSteps(ts, dt, ..., ts)`), so `TS.prev_ts .= TS.ts` (:20) is a self-copy and prev_ts always equals the
+    // CURRENT grid: the warm branch (coupled_lat_long.jl:82-102) therefore re-uses the previous solution node-for-node.
+    // alias_prev_ts = true reproduces that behaviour; false gives the (apparently intended) time-shifted interpolation.
+    bool alias_prev_ts = true;
     std::vector<double> ts, dt, prev_ts;
     void init() {
         int N = 1 + N_short + N_long;
@@ -50,6 +55,7 @@ struct MPCTimeSteps {
         for (int i = 0; i <= N_short; i++) ts[i] = t0 + dt_short * i;
         for (int i = 1; i <= N_long; i++) ts[N_short + i] = t0_long + dt_long * i;
         for (int i = 0; i < N_short + N_long; i++) dt[i] = ts[i + 1] - ts[i];
+        if (alias_prev_ts) prev_ts = ts;
     }
 };
 

@@ -241,3 +241,4 @@ double po_step_batch(void* hv, int B, const double* states6, const double* contr
 }  // extern "C"
 
 extern "C" void po_set_hji_placeholder(void* hv) { ((Handle*)hv)->mpc.hji.placeholder(); }
+extern "C" void po_set_alias_prev_ts(void* hv, int on) { ((Handle*)hv)->mpc.TS.alias_prev_ts = on != 0; }

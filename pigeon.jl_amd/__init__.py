@@ -6,4 +6,4 @@ from ._lib import PigeonError, load_library, LIB_PATH, SYMBOLS  # noqa: F401
 from .mpc import BatchedTrajectoryTrackingMPC, CoupledTrajectoryTrackingMPC, simulate, SOLVED, MAX_ITER, NUMERICAL, INFEASIBLE_X0  # noqa: F401
 from .trajectories import TrajectoryTube, straight_trajectory, load_path_fixture, invcumtrapz  # noqa: F401
 from .vehicles import X1, CoupledControlParams  # noqa: F401
-from . import synthetic  # noqa: F401
+from . import synthetic, sharding  # noqa: F401

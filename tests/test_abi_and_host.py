@@ -1,0 +1,103 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/pigeon_mpc.h declares; host-side logic."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "pigeon_mpc.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pg_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_header_symbol(pkg):
+    lib = pkg.load_library()
+    syms = header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert sorted(pkg.SYMBOLS) == syms
+
+
+def test_default_config_matches_x1(pkg):
+    from pigeon_jl_amd import _lib
+    lib = pkg.load_library()
+    cfg = _lib.pg_config()
+    assert lib.pg_default_config(C.byref(cfg)) == 0
+    X = pkg.X1()
+    for name, _ in _lib.pg_vehicle._fields_:
+        assert getattr(cfg.vehicle, name) == pytest.approx(X[name], rel=1e-15), name
+    P = pkg.CoupledControlParams()
+    for name, _ in _lib.pg_control_params._fields_:
+        if name != "_pad":
+            assert getattr(cfg.control, name) == pytest.approx(P[name], rel=1e-15), name
+    assert (cfg.N_short, cfg.N_long, cfg.dt_short, cfg.dt_long, cfg.use_correction_step) == (10, 20, 0.01, 0.2, 1)
+
+
+def test_no_gpu_fails_loudly(pkg):
+    """Without a HIP device the product path must refuse to run (no CPU fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.PigeonError) as e:
+        pkg.BatchedTrajectoryTrackingMPC(pkg.straight_trajectory(30.0, 5.0), 4)
+    assert "no HIP device" in str(e.value)
+
+
+def test_product_path_never_imports_oracle():
+    pk = os.path.join(ROOT, "pigeon.jl_amd")
+    for dirpath, _, files in os.walk(pk):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and '#include "../../oracle' not in txt and "liboracle" not in txt, f
+
+
+def test_trajectory_tube_from_path(pkg):
+    """ros_integration.jl:13-16 + math.jl:2."""
+    t = pkg.load_path_fixture("skidpadoval")
+    assert len(t) == 1000 and t.data.shape == (12, 1000)
+    assert t.t[0] == 0 and np.allclose(np.diff(t.t), np.diff(t.s) / 6.0)
+    assert np.all(t.phi == 0) and np.all(t.edge_L == 4.0)
+    vs = pkg.load_path_fixture("variable_speed")
+    assert len(vs) == 28 and np.all(np.diff(vs.t) > 0)
+    st = pkg.straight_trajectory(30.0, 5.0)
+    assert len(st) == 2 and st.t[1] == 6.0 and st.N[1] == 30.0
+
+
+def test_synthetic_inputs_are_seeded(pkg, skidpad):
+    a = pkg.synthetic.config2_inputs(skidpad, 32, seed=12345)
+    b = pkg.synthetic.config2_inputs(skidpad, 32, seed=12345)
+    c = pkg.synthetic.config2_inputs(skidpad, 32, seed=12346)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert not np.array_equal(a[0], c[0])
+    st, ctl, t0, toff = a
+    assert np.all(st[:, 3] >= 5.4 - 1e-9) and np.all(st[:, 3] <= 6.6 + 1e-9) and np.all(np.abs(ctl[:, 0]) <= 0.05)
+    assert np.all((ctl[:, 1] == 0) | (ctl[:, 1] < 0))          # drive force is rear-only, brake force 60/40 (vehicles.jl:43-46)
+
+
+def test_shard_ranges_cover_batch(pkg):
+    for B, W in [(4096, 8), (65536, 8), (10, 4), (7, 3)]:
+        r = [pkg.sharding.shard_range(B, W, k) for k in range(W)]
+        assert r[0][0] == 0 and r[-1][1] == B and all(r[k][1] == r[k + 1][0] for k in range(W - 1))
+        sizes = [b - a for a, b in r]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_canonical_active_set_mapping(pkg):
+    """Bit j of stage k -> signed 1-based row of the reference QP (row blocks C1..C13)."""
+    m = pkg.BatchedTrajectoryTrackingMPC.__new__(pkg.BatchedTrajectoryTrackingMPC)
+    m.N, m.N_short, m.N_long, m.control_params = 30, 10, 20, pkg.CoupledControlParams()
+    masks = np.zeros(30, dtype=np.uint16)
+    masks[0] = (1 << 13) | (1 << 10)          # d_delta >= ddmin, sigma1 >= 0 at transition 0
+    masks[29] = (1 << 5)                      # Fx <= fxmax at the last node
+    qp = np.zeros(2531); qp[-1] = 1.0         # b_hji = 1, M = 0 -> sigma_HJI_1 >= 0 active at the fixed node
+    got = m.canonical_active_set(0, masks, qp)
+    r_C13 = 60 + 10 + 30 + 30 + 93 + 8 + 60 + 10 + 120
+    assert got == sorted([-(0 + 1), -(60 + 1), -(r_C13 + 8 + 1), +(r_C13 + 9 * 29 + 2 + 1)], key=abs)
