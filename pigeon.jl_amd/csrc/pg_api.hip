@@ -113,10 +113,13 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     }
     for (int i = 0; i < 4; i++) if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_create_error = "hipEventCreate failed"; free_all(h); delete h; return PG_ERR_HIP; }
     h->ev_ok = true;
-    h->solve_lds = (size_t)(66 * N + 14 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 64 + 64 + 16 + 16 + 8 + 8) * sizeof(double);
+    h->solve_lds = (size_t)(66 * N + 14 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 64 + 88 + 8 + 64) * sizeof(double);
     if (h->solve_lds > 160 * 1024) { g_create_error = "horizon too long for LDS staging"; free_all(h); delete h; return PG_ERR_INVALID; }
     if (h->solve_lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+    {
+        (void)hipFuncSetAttribute((const void*)k_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+        (void)hipFuncSetAttribute((const void*)k_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+    }
     *out = h;
     return PG_OK;
 }
@@ -271,8 +274,21 @@ int pg_update_qp(pg_handle* h) {
 int pg_solve(pg_handle* h) {
     int rc = check_ready(h); if (rc) return rc;
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved};
-    hipLaunchKernelGGL(k_solve, dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, O);
+    hipLaunchKernelGGL(k_solve<false>, dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, O, (unsigned long long*)nullptr);
     LAUNCH_CHECK(h);
+    return PG_OK;
+}
+// debug (not part of the public header): per-phase shader-clock cycles of one solve launch, out [B][6] =
+// (stage assembly+step, sync, matrix pass, vector passes, forward passes, prologue); diagnostic build of the kernel, never timed
+int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
+    int rc = check_ready(h); if (rc) return rc;
+    unsigned long long* d = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d, (size_t)h->B * 6 * 8));
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved};
+    hipLaunchKernelGGL(k_solve<true>, dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, O, d);
+    LAUNCH_CHECK(h);
+    HIPCHK(h, hipMemcpy(out, d, (size_t)h->B * 6 * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
     return PG_OK;
 }
 int pg_get_next_control_dev(pg_handle* h, double* u_out_dev) {

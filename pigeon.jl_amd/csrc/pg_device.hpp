@@ -55,12 +55,14 @@ PG_DEV double jmax(double a, double b) { return (a != a || b != b) ? NAN : (b > 
 PG_DEV double clampd(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
 
 // ---- tire model: vehicle_dynamics.jl:35-48 ----
+// takes tan(alpha) directly: the slip angles of the reference are atan(...) - delta, and only their tangent is ever used
+// (vehicle_dynamics.jl:37), so tan(atan(y/x) - delta) = (y/x - tan delta)/(1 + (y/x) tan delta) replaces an atan2 + tan pair
+// (identical in exact arithmetic for Ux > 0, the only regime the MPC runs in: V_min = 1, ros_integration.jl:84-87)
 template <class T>
-PG_DEV T fiala(T alpha, double Ca, double mu, T Fx, T Fz) {
+PG_DEV T fiala(T tana, double Ca, double mu, T Fx, T Fz) {
     T Fmax = mu * Fz;
     if (abs_(val(Fx)) >= val(Fmax)) return cst<T>(0.0);
     T Fy_max = sqrt_(Fmax * Fmax - Fx * Fx);
-    T tana = tan_(alpha);
     T slide = (3.0 / Ca) * Fy_max;
     T ratio = abs_(tana / slide);
     if (val(ratio) <= 1.0) return -(Ca * tana) * (1.0 - ratio + ratio * ratio * (1.0 / 3.0));
@@ -73,7 +75,7 @@ PG_DEV double inv_fiala_tan(double Fy, double Ca, double Fy_max) {
 }
 // vehicle_dynamics.jl:64-76: 3-iteration front-axle load-transfer fixed point, then rear
 template <class T>
-PG_DEV void lateral_forces(const pg_vehicle& P, T af, T ar, T Fxf, T Fxr, T sd, T cd, T& Fyf, T& Fyr) {
+PG_DEV void lateral_forces(const pg_vehicle& P, T af, T ar, T Fxf, T Fxr, T sd, T cd, T& Fyf, T& Fyr) {   // af, ar: TANGENTS of the slip angles
     const double W_b = P.m * P.G * P.b, W_a = P.m * P.G * P.a, invL = 1.0 / P.L;
     Fyf = cst<T>(0.0);
     T Fx = Fxf * cd + Fxr;
@@ -104,10 +106,11 @@ PG_DEV void actuate(const pg_vehicle& P, T delta, T Fx, double Ux, T& d_out, T& 
 template <class T>
 PG_DEV void body_accel(const pg_vehicle& P, T Ux, T Uy, T r, T delta, T Fxf, T Fxr, T& dUx, T& dUy, T& dr) {
     T sd, cd; sincos_(delta, sd, cd);
-    T af = atan2_(Uy + P.a * r, Ux) - delta;
-    T ar = atan2_(Uy - P.b * r, Ux);
+    T tf = (Uy + P.a * r) / Ux, td = sd / cd;
+    T taf = (tf - td) / (1.0 + tf * td);          // tan(atan2(Uy + a r, Ux) - delta)   (:118)
+    T tar = (Uy - P.b * r) / Ux;                   // tan(atan2(Uy - b r, Ux))           (:119)
     T Fyf, Fyr;
-    lateral_forces<T>(P, af, ar, Fxf, Fxr, sd, cd, Fyf, Fyr);
+    lateral_forces<T>(P, taf, tar, Fxf, Fxr, sd, cd, Fyf, Fyr);
     T Fx_drag = -P.Cd0 - Ux * (P.Cd1 + P.Cd2 * Ux);
     T Fxf_t = Fxf * cd - Fyf * sd;
     T Fyf_t = Fyf * cd + Fxf * sd;

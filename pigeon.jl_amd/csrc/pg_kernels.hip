@@ -9,6 +9,7 @@
 // Data layout notes are in DESIGN.md.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "pg_device.hpp"
 
 namespace pg {
@@ -41,7 +42,8 @@ __host__ __device__ inline QpOff qp_offsets(int N) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void k_time_steps(DevCfg C, int B, const double* __restrict__ t0, double* __restrict__ ts, double* __restrict__ dt, double* __restrict__ prev_ts) {
+__global__ __launch_bounds__(64) void k_time_steps(DevCfg C, int B, const double* __restrict__ t0, double* __restrict__ ts, double* __restrict__ dt, double* __restrict__ prev_ts) {
+#pragma clang fp contract(off)   // the time grid is compared bit-for-bit with the CPU restatement: no fused multiply-add here
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     double* T = ts + (size_t)b * C.NN; double* PT = prev_ts + (size_t)b * C.NN; double* D = dt + (size_t)b * C.N;
@@ -94,7 +96,12 @@ __global__ __launch_bounds__(256) void k_project(DevCfg C, int B, const double* 
 
 // ------------------------------------------------------------------------------------------------------------------
 // nodes record per node: q[6], u[2] (physical units), V, kappa  -> 10 doubles
-__global__ void k_nodes(DevCfg C, int B, const double* __restrict__ state, const double* __restrict__ control, const double* __restrict__ toff,
+struct NodeRec { double q0, q1, q2, q3, q4, q5, u0, u1, pV, pK; };
+PG_DEV void put_node(double* __restrict__ ND, int i, const NodeRec& r) {
+    double* o = ND + i * 10;
+    o[0] = r.q0; o[1] = r.q1; o[2] = r.q2; o[3] = r.q3; o[4] = r.q4; o[5] = r.q5; o[6] = r.u0; o[7] = r.u1; o[8] = r.pV; o[9] = r.pK;
+}
+__global__ __launch_bounds__(64) void k_nodes(DevCfg C, int B, const double* __restrict__ state, const double* __restrict__ control, const double* __restrict__ toff,
                         const int* __restrict__ solved, const double* __restrict__ sep, const double* __restrict__ ts, const double* __restrict__ dt,
                         const double* __restrict__ prev_ts, const double* __restrict__ prev_x, double* __restrict__ nodes) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,68 +110,72 @@ __global__ void k_nodes(DevCfg C, int B, const double* __restrict__ state, const
     const double* q0 = state + (size_t)b * 6; const double* u0 = control + (size_t)b * 3;
     const double* TS = ts + (size_t)b * C.NN; const double* DT = dt + (size_t)b * C.N;
     double* ND = nodes + (size_t)b * C.NN * 10;
-    double s0 = sep[(size_t)b * 4], e0 = sep[(size_t)b * 4 + 1];
-    double E0 = q0[0]; (void)E0;
-    double psi0 = q0[2], Ux0 = q0[3], Uy0 = q0[4], r0 = q0[5];
+    const double s0 = sep[(size_t)b * 4], e0 = sep[(size_t)b * 4 + 1];
+    const double psi0 = q0[2], Ux0 = q0[3], Uy0 = q0[4], r0 = q0[5];
+    const double d0 = u0[0], Fxf0 = u0[1], Fxr0 = u0[2];
     TrajS tj = traj_at_s(T, s0);                                                   // :76
-    double ds = s0 - traj_s_at_time(T, TS[0]);                                     // :77
-    double dpsi = adiff(psi0, tj.psi);                                             // :78
-    double q[6] = {ds, Ux0, Uy0, r0, dpsi, e0};
-    double u[2] = {u0[0], u0[1] + u0[2]};
-    double p[2] = {tj.V, tj.kappa};
-    auto put = [&](int i) { double* o = ND + i * 10; for (int k = 0; k < 6; k++) o[k] = q[k]; o[6] = u[0]; o[7] = u[1]; o[8] = p[0]; o[9] = p[1]; };
+    const double ds0 = s0 - traj_s_at_time(T, TS[0]);                              // :77
+    const double dpsi = adiff(psi0, tj.psi);                                       // :78
+    // node 1 of the reference (index 0 here) is the measured state in both branches (:79-85, and i == 1 of the cold loop)
+    NodeRec r;
+    r.q0 = ds0; r.q1 = Ux0; r.q2 = Uy0; r.q3 = r0; r.q4 = dpsi; r.q5 = e0; r.u0 = d0; r.u1 = Fxf0 + Fxr0; r.pV = tj.V; r.pK = tj.kappa;
+    put_node(ND, 0, r);
     if (solved[b]) {                                                               // :82-102 with update_interpolations! (:189-195)
         const double* PT = prev_ts + (size_t)b * C.NN; const double* PX = prev_x + (size_t)b * C.NN * 8;
-        put(0);
-        double tlast = PT[C.NN - 1];
+        const double tlast = PT[C.NN - 1];
         for (int i = 1; i < C.NN; i++) {
             double t = TS[i];
             double tq = (t < tlast) ? t : tlast;
             int j = clampi(count_leq(PT, C.NN, tq), 1, C.NN - 1) - 1;
             double w = (tq - PT[j]) / (PT[j + 1] - PT[j]);
-            for (int k = 0; k < 6; k++) q[k] = (1.0 - w) * PX[j * 8 + k] + w * PX[(j + 1) * 8 + k];
-            u[0] = ((1.0 - w) * PX[j * 8 + 6] + w * PX[(j + 1) * 8 + 6]) * C.un0;
-            u[1] = ((1.0 - w) * PX[j * 8 + 7] + w * PX[(j + 1) * 8 + 7]) * C.un1;
-            double s = traj_s_at_time(T, t) + q[0];                                // :96
+            const double* a = PX + j * 8; const double* c = a + 8;
+            r.q0 = (1.0 - w) * a[0] + w * c[0]; r.q1 = (1.0 - w) * a[1] + w * c[1]; r.q2 = (1.0 - w) * a[2] + w * c[2];
+            r.q3 = (1.0 - w) * a[3] + w * c[3]; r.q4 = (1.0 - w) * a[4] + w * c[4]; r.q5 = (1.0 - w) * a[5] + w * c[5];
+            r.u0 = ((1.0 - w) * a[6] + w * c[6]) * C.un0; r.u1 = ((1.0 - w) * a[7] + w * c[7]) * C.un1;
+            double s = traj_s_at_time(T, t) + r.q0;                                // :96
             tj = traj_at_s(T, s);
-            p[0] = tj.V; p[1] = tj.kappa;
-            put(i);
+            r.pV = tj.V; r.pK = tj.kappa;
+            put_node(ND, i, r);
         }
         return;
     }
     // cold start :103-141
-    double s = s0, sdp, cdp; sincos(dpsi, &sdp, &cdp);
+    double sdp, cdp; sincos(dpsi, &sdp, &cdp);
     double V = Ux0 * cdp - Uy0 * sdp;
-    double beta0 = atan2(Uy0, Ux0), delta0 = u0[0];
+    const double beta0 = atan2(Uy0, Ux0);
     double Fyf0, Fyr0;
     {   // lateral_tire_forces(bicycle, q0, u0): raw (delta, Fxf, Fxr), no actuator limits (:110; vehicle_dynamics.jl:78-87)
-        double sd, cd; sincos(u0[0], &sd, &cd);
-        double af = atan2(Uy0 + P.a * r0, Ux0) - u0[0], ar = atan2(Uy0 - P.b * r0, Ux0);
-        lateral_forces<double>(P, af, ar, u0[1], u0[2], sd, cd, Fyf0, Fyr0);
+        double sd, cd; sincos(d0, &sd, &cd);
+        double af = tan(atan2(Uy0 + P.a * r0, Ux0) - d0), ar = tan(atan2(Uy0 - P.b * r0, Ux0));
+        lateral_forces<double>(P, af, ar, Fxf0, Fxr0, sd, cd, Fyf0, Fyr0);
     }
-    bool traj_mode = !(toff[b] != toff[b]);
-    for (int i = 0; i < C.NN; i++) {
+    const bool traj_mode = !(toff[b] != toff[b]);
+    // i == 1 of the reference loop: acceleration from the full nonlinear model (:117-119); its node record is already written above
+    double s = s0;
+    {
+        double tau = DT[0];
+        double dUx, dUy, dr;
+        world_body_rhs<double>(P, Ux0, Uy0, r0, d0, Fxf0 + Fxr0, dUx, dUy, dr);
+        double A = (dUx - r0 * Uy0) * cdp - (dUy + r0 * Ux0) * sdp;
+        V = V + A * tau;
+        s = s + V * tau + A * tau * tau * 0.5;
+    }
+#pragma unroll 1
+    for (int i = 1; i < C.NN; i++) {
         double tau = (i == C.NN - 1) ? DT[i - 1] : DT[i];
         tj = traj_at_s(T, s);
-        ds = s - traj_s_at_time(T, TS[i]);
+        double ds = s - traj_s_at_time(T, TS[i]);
         double A_des = tj.A + C.cp.k_V * (tj.V - V) / tau + (traj_mode ? -C.cp.k_s * ds / tau / tau : 0.0);
         A_des = jmin(jmax(A_des, (C.cp.V_min - V) / tau), (C.cp.V_max - V) / tau);
-        double A;
-        if (i == 0) {
-            double dUx, dUy, dr;
-            world_body_rhs<double>(P, Ux0, Uy0, r0, u0[0], u0[1] + u0[2], dUx, dUy, dr);        // :118
-            A = (dUx - r0 * Uy0) * cdp - (dUy + r0 * Ux0) * sdp;                                 // :119
-        } else if (i <= C.Ns) {
-            Steady est = steady_state(P, V, A_des, tj.kappa, 1, r0, beta0, delta0, Fyf0);        // :122
-            q[0] = ds; q[1] = Ux0; q[2] = Uy0; q[3] = r0; q[4] = adiff(psi0, tj.psi); q[5] = e0;
-            u[0] = est.delta; u[1] = est.Fx; p[0] = tj.V; p[1] = tj.kappa; A = est.A;
-        } else {
-            Steady est = steady_state(P, V, A_des, tj.kappa, 4, V * tj.kappa, 0.0, 0.0, 0.0);    // :128
-            q[0] = ds; q[1] = est.Ux; q[2] = est.Uy; q[3] = est.r; q[4] = -est.beta; q[5] = 0.0;
-            u[0] = est.delta; u[1] = est.Fx; p[0] = tj.V; p[1] = tj.kappa; A = est.A;
-        }
-        put(i);
-        if (i == C.NN - 1) break;
+        const bool shortp = i <= C.Ns;
+        Steady est = shortp ? steady_state(P, V, A_des, tj.kappa, 1, r0, beta0, d0, Fyf0)            // :122
+                            : steady_state(P, V, A_des, tj.kappa, 4, V * tj.kappa, 0.0, 0.0, 0.0);   // :128
+        r.q0 = ds;
+        r.q1 = shortp ? Ux0 : est.Ux; r.q2 = shortp ? Uy0 : est.Uy; r.q3 = shortp ? r0 : est.r;
+        r.q4 = shortp ? adiff(psi0, tj.psi) : -est.beta; r.q5 = shortp ? e0 : 0.0;
+        r.u0 = est.delta; r.u1 = est.Fx; r.pV = tj.V; r.pK = tj.kappa;
+        put_node(ND, i, r);
+        double A = est.A;
         V = V + A * tau;
         s = s + V * tau + A * tau * tau * 0.5;
     }
@@ -197,20 +208,22 @@ __global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const double
     };
 #pragma unroll 1
     for (int i = 0; i < nsub; i++) {
-        double t0 = i * h;
-        D2 k1[6], k2[6], xx[6], acc[6];
-        rhs(x, t0, k1);
+        const double t0 = i * h;
+        D2 kk[6], xx[6], acc[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) { xx[k] = x[k] + k1[k] * (h * 0.5); acc[k] = k1[k]; }
-        rhs(xx, t0 + h * 0.5, k2);
+        for (int k = 0; k < 6; k++) { xx[k] = x[k]; acc[k] = D2(0.0); }
+        // classical RK4 written as one rolled stage loop (one instance of the dynamics in the instruction stream, fewer live registers)
+#pragma unroll 1
+        for (int st = 0; st < 4; st++) {
+            const double cst_ = st == 0 ? 0.0 : (st == 3 ? 1.0 : 0.5);        // stage time fraction
+            const double wgt = (st == 0 || st == 3) ? 1.0 : 2.0;              // quadrature weight (x h/6)
+            const double nxt = st == 2 ? 1.0 : 0.5;                           // coefficient of k in the NEXT stage's evaluation point
+            rhs(xx, t0 + cst_ * h, kk);
 #pragma unroll
-        for (int k = 0; k < 6; k++) { xx[k] = x[k] + k2[k] * (h * 0.5); acc[k] = acc[k] + 2.0 * k2[k]; }
-        rhs(xx, t0 + h * 0.5, k1);
+            for (int k = 0; k < 6; k++) { acc[k] = acc[k] + kk[k] * wgt; xx[k] = x[k] + kk[k] * (nxt * h); }
+        }
 #pragma unroll
-        for (int k = 0; k < 6; k++) { xx[k] = x[k] + k1[k] * h; acc[k] = acc[k] + 2.0 * k1[k]; }
-        rhs(xx, t0 + h, k2);
-#pragma unroll
-        for (int k = 0; k < 6; k++) x[k] = x[k] + (acc[k] + k2[k]) * (h / 6.0);
+        for (int k = 0; k < 6; k++) x[k] = x[k] + acc[k] * (h / 6.0);
     }
     QpOff o = qp_offsets(C.N);
     double* Q = qp + (size_t)b * C.qp_len;
@@ -231,7 +244,7 @@ __global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const double
 }
 
 // finishes c = Phi - A q - B0 u0 - Bf uf, scales B by u_normalization, stability envelope + bounds (:354-367), q_curr/u_curr (:332-333), HJI row (:345-346)
-__global__ void k_limits(DevCfg C, int B, const double* __restrict__ nodes, const double* __restrict__ dt, const double* __restrict__ hji_Mb, double* __restrict__ qp) {
+__global__ __launch_bounds__(256) void k_limits(DevCfg C, int B, const double* __restrict__ nodes, const double* __restrict__ dt, const double* __restrict__ hji_Mb, double* __restrict__ qp) {
     long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)B * C.N) return;
     int b = (int)(gid / C.N), t = (int)(gid - (long)b * C.N);
@@ -273,7 +286,7 @@ __global__ void k_limits(DevCfg C, int B, const double* __restrict__ nodes, cons
 struct HjiView { int dims[7]; int koff[7]; long stride[7]; const float* knots; const float* nodes; };
 
 // HJIRelativeState(us, them): HJI_computation.jl:20-24 (cpsi = sin(-psi), spsi = cos(-psi): names swapped in the reference)
-__global__ void k_hji_relstate(int B, const double* __restrict__ state, const double* __restrict__ other, double* __restrict__ x7) {
+__global__ __launch_bounds__(256) void k_hji_relstate(int B, const double* __restrict__ state, const double* __restrict__ other, double* __restrict__ x7) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const double* us = state + (size_t)b * 6; const double* th = other + (size_t)b * 4; double* x = x7 + (size_t)b * 7;
@@ -334,7 +347,7 @@ __global__ __launch_bounds__(256) void k_hji_lookup(HjiView Hv, int B, const dou
 }
 
 // optimal_disturbance (dMode=:min) HJI_computation.jl:90-131 + compute_reachability_constraint :160-170, lane = instance
-__global__ void k_hji_constraint(DevCfg C, int B, const double* __restrict__ x7, const double* __restrict__ vg8, const double* __restrict__ control,
+__global__ __launch_bounds__(64) void k_hji_constraint(DevCfg C, int B, const double* __restrict__ x7, const double* __restrict__ vg8, const double* __restrict__ control,
                                  double* __restrict__ Mb) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -404,15 +417,33 @@ PG_DEV double wave_sum(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(64) void k_solve(DevCfg C, int B, const double* __restrict__ qp, SolveOut O) {
+// reciprocal: v_rcp_f64 seed + two Newton steps (~1 ulp; the IEEE division sequence costs ~5x more issue slots and the
+// interior-point internals only need a consistent, accurate-to-rounding scaling)
+PG_DEV double frcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0); r = fma(r, e, r);
+    e = fma(-x, r, 1.0); r = fma(r, e, r);
+    return r;
+}
+
+// broadcast of lane `src` (compile-time constant) to the whole wave through SGPRs: no LDS, no barrier
+PG_DEV double rl(double v, int src) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(64) void k_solve(DevCfg C, int B, const double* __restrict__ qp, SolveOut O, unsigned long long* __restrict__ prof) {
+    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int slot) { if (PROF) { unsigned long long now = clock64(); pc[slot] += now - tprev; tprev = now; } };
+    if (PROF) tprev = clock64();
     const int b = blockIdx.x, lane = threadIdx.x;
     const int N = C.N, NN = C.NN;
     extern __shared__ double lds[];
-    double* sA = lds;                    // [N][36]
-    double* sB0 = sA + 36 * N;           // [N][12]
-    double* sBf = sB0 + 12 * N;          // [N][12]
+    double* sAb = lds;                   // [N][6][8]  rows 0..5 of Abar_k = [A | B0+Bf]   (rows 6,7 are [0 I])
+    double* sBf = sAb + 48 * N;          // [N][6][2]  rows 0..5 of Bbar_k              (rows 6,7 are I)
     double* sc = sBf + 12 * N;           // [N][6]
-    double* sQ = sc + 6 * N;             // [NN][14]: diag[8], (yy, yr, rr), (dd, df, ff)
+    double* sQ = sc + 6 * N;             // [NN][14]: diag[8], (yy, yr, rr), (dd-df off-diagonal), -, -
     double* sq = sQ + 14 * NN;           // [NN][8]
     double* sR = sq + 8 * NN;            // [N][2]   diagonal of Rhat
     double* sr = sR + 2 * N;             // [N][2]
@@ -423,16 +454,19 @@ __global__ __launch_bounds__(64) void k_solve(DevCfg C, int B, const double* __r
     double* sx = skf + 2 * N;            // [NN][8]  Newton point
     double* sv = sx + 8 * NN;            // [N][2]
     double* sP = sv + 2 * N;             // [8][8]
-    double* sMA = sP + 64;               // [8][8]
-    double* sMB = sMA + 64;              // [8][2]
-    double* sF = sMB + 16;               // [2][8]
-    double* sp = sF + 16;                // [8]  p_{k+1}
-    double* sx0 = sp + 8;                // [8]
+    double* sMT = sP + 64;               // [11][8]  (P [Abar | Bbar | cbar]) stored column-major
+    double* sx0 = sMT + 88;              // [8]
+    double* sDum = sx0 + 8;              // [64] sink for predicated-off stores (keeps the pass loops branch-free)
 
     const QpOff o = qp_offsets(N);
     const double* Q = qp + (size_t)b * C.qp_len;
-    // ---- stage the dynamics blocks in LDS (coalesced: lanes read consecutive doubles) ----
-    for (int i = lane; i < 66 * N; i += 64) lds[i] = Q[i];          // A, B0, Bf, c are the first 66 N doubles of the block
+    // ---- stage the dynamics blocks in LDS ----
+    for (int i = lane; i < 48 * N; i += 64) {
+        int k = i / 48, r = (i - 48 * k) >> 3, j = i & 7;
+        sAb[i] = j < 6 ? Q[o.A + 36 * k + 6 * r + j] : Q[o.B0 + 12 * k + 2 * r + (j - 6)] + Q[o.Bf + 12 * k + 2 * r + (j - 6)];
+    }
+    for (int i = lane; i < 12 * N; i += 64) sBf[i] = Q[o.Bf + i];
+    for (int i = lane; i < 6 * N; i += 64) sc[i] = Q[o.c + i];
     if (lane < 8) sx0[lane] = lane < 6 ? Q[o.qcurr + lane] : Q[o.ucurr + lane - 6];
 
     // ---- per-stage constants in the registers of lane s (stage s = transition s, node s+1) ----
@@ -442,13 +476,20 @@ __global__ __launch_bounds__(64) void k_solve(DevCfg C, int B, const double* __r
     const double M0 = Q[o.M], M1 = Q[o.M + 1];
     const bool hji_on = act && (s + 1 < (C.cp.N_HJI < C.Ns ? C.cp.N_HJI : C.Ns));
     const double dts = Q[o.dt + s];
-    const double Qd0 = 2.0 * C.cp.Q_ds * dts, Qd4 = 2.0 * C.cp.Q_dpsi * dts, Qd5 = 2.0 * C.cp.Q_e * dts, Qd6 = 2.0 * C.cp.R_delta * dts, Qd7 = 2.0 * C.cp.R_Fx * dts;
     const double Rd0 = 2.0 * C.cp.R_ddelta / dts, Rd1 = 2.0 * C.cp.R_dFx / dts;
     const double wb = C.cp.W_beta * dts, wr = C.cp.W_r * dts, wh = C.cp.W_HJI;
 #pragma unroll
     for (int i = 0; i < 4; i++) { h0[i] = Q[o.H + 8 * s + 2 * i]; h1[i] = Q[o.H + 8 * s + 2 * i + 1]; bb[6 + i] = Q[o.G + 4 * s + i]; }
     bb[0] = -C.cp.V_min; bb[1] = C.cp.V_max; bb[2] = -C.fxmin_n; bb[3] = Q[o.dmax + s]; bb[4] = -Q[o.dmin + s]; bb[5] = Q[o.fxmax + s];
     bb[10] = 0.0; bb[11] = 0.0; bb[12] = Q[o.ddmax + s]; bb[13] = -Q[o.ddmin + s]; bb[14] = Q[o.b]; bb[15] = 0.0;
+    if (act) {   // entries of the stage cost that never change
+        double* Qo = sQ + 14 * (s + 1);
+        Qo[0] = 2.0 * C.cp.Q_ds * dts; Qo[2] = 0.0; Qo[3] = 0.0; Qo[4] = 2.0 * C.cp.Q_dpsi * dts; Qo[5] = 2.0 * C.cp.Q_e * dts; Qo[12] = 0.0; Qo[13] = 0.0;
+        double* qo = sq + 8 * (s + 1);
+        qo[0] = 0.0; qo[4] = 0.0; qo[5] = 0.0;
+        sR[2 * s + 1] = Rd1; sr[2 * s + 1] = 0.0;
+    }
+    const double Qd6 = 2.0 * C.cp.R_delta * dts, Qd7 = 2.0 * C.cp.R_Fx * dts;
     __syncthreads();
 
     // slack of every row at the point w = (x[8], v0, s1, s2, sh)
@@ -460,40 +501,48 @@ __global__ __launch_bounds__(64) void k_solve(DevCfg C, int B, const double* __r
         out[14] = bb[14] + M0 * x[6] + M1 * x[7] + sh; out[15] = sh;
     };
     const int nrows = hji_on ? 16 : 14;
+    const int r8 = lane & 7;             // component index for the vector passes (lanes >= 8 mirror lanes 0..7)
 
-    // forward roll-out through LDS by lanes 0..7: x_{k+1} = Abar x_k + Bbar v_k + cbar  (v from sK/skf when use_gain)
-    auto abar = [&](int k, int m, int j) -> double {   // Abar_k[m][j]
-        if (m < 6) return j < 6 ? sA[36 * k + 6 * m + j] : sB0[12 * k + 2 * m + (j - 6)] + sBf[12 * k + 2 * m + (j - 6)];
-        return m == j ? 1.0 : 0.0;
-    };
-    auto forward = [&](bool use_gain) {
-        if (lane < 8) sx[lane] = sx0[lane];
-        __syncthreads();
+    // forward roll-out: lanes r8 hold x_k[r8] in a register; broadcasts by readlane; results published to sx/sv for the stage lanes.
+    // The loop body is one basic block (predicated stores go to a dummy slot) so that all LDS reads of a stage issue back to back.
+    auto forward = [&](auto use_gain_t) {
+        constexpr bool use_gain = decltype(use_gain_t)::value;
+        double xi = sx0[r8];
+        *(lane < 8 ? sx + lane : sDum + lane) = xi;
+        const int rr = r8 < 6 ? r8 : 5;
+        const double w_lo = r8 < 6 ? 1.0 : 0.0, w_6 = r8 == 6 ? 1.0 : 0.0, w_7 = r8 == 7 ? 1.0 : 0.0;
+#pragma unroll 1
         for (int k = 0; k < N; k++) {
-            double v0 = 0.0, v1 = 0.0;
-            if (use_gain) {
-                v0 = skf[2 * k]; v1 = skf[2 * k + 1];
+            const double* Kk = sK + 16 * k; const double* Ar = sAb + 48 * k + 8 * rr;
+            double K0[8], K1[8], A8[8];
 #pragma unroll
-                for (int m = 0; m < 8; m++) { double xm = sx[8 * k + m]; v0 += sK[16 * k + m] * xm; v1 += sK[16 * k + 8 + m] * xm; }
-            }
-            if (lane < 8) {
-                double acc;
-                if (lane < 6) {
-                    acc = sc[6 * k + lane] + sBf[12 * k + 2 * lane] * v0 + sBf[12 * k + 2 * lane + 1] * v1;
+            for (int m = 0; m < 8; m++) { A8[m] = Ar[m]; K0[m] = use_gain ? Kk[m] : 0.0; K1[m] = use_gain ? Kk[8 + m] : 0.0; }
+            double kf0 = use_gain ? skf[2 * k] : 0.0, kf1 = use_gain ? skf[2 * k + 1] : 0.0;
+            double cr = sc[6 * k + rr], bf0 = sBf[12 * k + 2 * rr], bf1 = sBf[12 * k + 2 * rr + 1];
+            double xm[8];
 #pragma unroll
-                    for (int m = 0; m < 8; m++) acc += abar(k, lane, m) * sx[8 * k + m];
-                } else acc = sx[8 * k + lane] + (lane == 6 ? v0 : v1);
-                sx[8 * (k + 1) + lane] = acc;
-                if (lane == 0) { sv[2 * k] = v0; sv[2 * k + 1] = v1; }
+            for (int m = 0; m < 8; m++) xm[m] = rl(xi, m);
+            double a0 = kf0, a1 = 0.0, b0 = kf1, b1 = 0.0, e0 = cr, e1 = 0.0;
+#pragma unroll
+            for (int m = 0; m < 8; m += 2) {
+                a0 += K0[m] * xm[m]; a1 += K0[m + 1] * xm[m + 1]; b0 += K1[m] * xm[m]; b1 += K1[m + 1] * xm[m + 1];
+                e0 += A8[m] * xm[m]; e1 += A8[m + 1] * xm[m + 1];
             }
-            __syncthreads();
+            double v0 = a0 + a1, v1 = b0 + b1;
+            double xr = (e0 + e1) + (bf0 * v0 + bf1 * v1);
+            // arithmetic blend instead of ?: so that the compiler keeps the LDS reads above unconditional (a branch here serialises them)
+            double xn = w_lo * xr + w_6 * (xm[6] + v0) + w_7 * (xm[7] + v1);
+            xi = xn;
+            *(lane < 8 ? sx + 8 * (k + 1) + lane : sDum + lane) = xn;
+            *(lane < 2 ? sv + 2 * k + lane : sDum + lane) = lane == 0 ? v0 : v1;
         }
+        __syncthreads();
     };
 
     // ---- initial point: v = 0 roll-out; sigma just feasible; t = max(slack, tau); lambda = mu0 / t ----
     StageRows R;
-    double xs[8], sg1 = 0.0, sg2 = 0.0, sgh = 0.0, vcur0 = 0.0;    // current iterate of this stage: x_{s+1}, sigma, v (v1 is not constrained)
-    forward(false);
+    double xs[8], sg1 = 0.0, sg2 = 0.0, sgh = 0.0, vcur0 = 0.0;
+    forward(std::false_type{});
     double rp0 = 0.0;
     {
 #pragma unroll
@@ -511,22 +560,22 @@ __global__ __launch_bounds__(64) void k_solve(DevCfg C, int B, const double* __r
             if (on) rp0 = fmax(rp0, tj - sl[j]);
         }
     }
+    stamp(5);
     rp0 = wave_max(rp0);
     const double ntot = wave_sum(act ? (double)nrows : 0.0);
     double vcur1 = 0.0;
     double phi = 1.0, mu = 0.0;
     int it = 0, status = PG_MAX_ITER;
 
-    // assemble stage s of the Newton LQ problem from W = lam/t and ell, eliminate the slacks, publish to LDS.
-    // returns the elimination data needed to recover sigma+ (d, c, g for sigma1, sigma2, sigma_HJI)
-    double e_d1, e_c10, e_c11, e_g1, e_d2, e_c20, e_c21, e_g2, e_dh, e_ch0, e_ch1, e_gh;
+    double e_d1, e_c10, e_c11, e_g1, e_d2, e_c20, e_c21, e_g2, e_dh, e_ch0, e_ch1, e_gh;   // e_d* hold RECIPROCALS of the slack pivots
+    double it_[NROW];                    // 1 / t_j, refreshed once per interior-point iteration
     auto assemble = [&](double sigmu, bool matrices) {
         double W[NROW], ell[NROW];
 #pragma unroll
         for (int j = 0; j < NROW; j++) {
             bool on = j < nrows;
-            W[j] = on ? R.lam[j] / R.t[j] : 0.0;
-            ell[j] = on ? (sigmu - R.corr[j]) / R.t[j] + R.lam[j] - W[j] * bb[j] : 0.0;
+            W[j] = on ? R.lam[j] * it_[j] : 0.0;
+            ell[j] = on ? (sigmu - R.corr[j]) * it_[j] + R.lam[j] - W[j] * bb[j] : 0.0;
         }
         double g1 = -ell[0] + ell[1], g7 = -ell[2] + ell[5] - M1 * ell[14], g6 = ell[3] - ell[4] - M0 * ell[14];
         double g2 = 0.0, g3 = 0.0;
@@ -534,132 +583,142 @@ __global__ __launch_bounds__(64) void k_solve(DevCfg C, int B, const double* __r
         for (int i = 0; i < 4; i++) { g2 += h0[i] * ell[6 + i]; g3 += h1[i] * ell[6 + i]; }
         e_g1 = wb - ell[6] - ell[7] - ell[10]; e_g2 = wr - ell[8] - ell[9] - ell[11]; e_gh = wh - ell[14] - ell[15];
         double gv0 = ell[12] - ell[13];
-        e_d1 = W[6] + W[7] + W[10]; e_d2 = W[8] + W[9] + W[11]; e_dh = hji_on ? W[14] + W[15] : 1.0;
+        e_d1 = frcp(W[6] + W[7] + W[10]); e_d2 = frcp(W[8] + W[9] + W[11]); e_dh = hji_on ? frcp(W[14] + W[15]) : 1.0;
         e_c10 = -(W[6] * h0[0] + W[7] * h0[1]); e_c11 = -(W[6] * h1[0] + W[7] * h1[1]);
         e_c20 = -(W[8] * h0[2] + W[9] * h0[3]); e_c21 = -(W[8] * h1[2] + W[9] * h1[3]);
         e_ch0 = W[14] * M0; e_ch1 = W[14] * M1;
         if (!hji_on) e_gh = 0.0;
         if (act) {
             double* qo = sq + 8 * (s + 1);
-            qo[0] = 0.0; qo[1] = g1; qo[4] = 0.0; qo[5] = 0.0;
-            qo[2] = g2 - e_c10 * e_g1 / e_d1 - e_c20 * e_g2 / e_d2;
-            qo[3] = g3 - e_c11 * e_g1 / e_d1 - e_c21 * e_g2 / e_d2;
-            qo[6] = g6 - e_ch0 * e_gh / e_dh; qo[7] = g7 - e_ch1 * e_gh / e_dh;
-            sr[2 * s] = gv0; sr[2 * s + 1] = 0.0;
+            qo[1] = g1;
+            qo[2] = g2 - e_c10 * e_g1 * e_d1 - e_c20 * e_g2 * e_d2;
+            qo[3] = g3 - e_c11 * e_g1 * e_d1 - e_c21 * e_g2 * e_d2;
+            qo[6] = g6 - e_ch0 * e_gh * e_dh; qo[7] = g7 - e_ch1 * e_gh * e_dh;
+            sr[2 * s] = gv0;
             if (matrices) {
                 double* Qo = sQ + 14 * (s + 1);
-                Qo[0] = Qd0; Qo[1] = W[0] + W[1]; Qo[2] = 0.0; Qo[3] = 0.0; Qo[4] = Qd4; Qo[5] = Qd5;
-                Qo[6] = Qd6 + W[3] + W[4] + M0 * M0 * W[14] - e_ch0 * e_ch0 / e_dh;
-                Qo[7] = Qd7 + W[2] + W[5] + M1 * M1 * W[14] - e_ch1 * e_ch1 / e_dh;
-                Qo[13] = 0.0;   // (ff) slot unused: diag carries it
+                Qo[1] = W[0] + W[1];
+                Qo[6] = Qd6 + W[3] + W[4] + M0 * M0 * W[14] - e_ch0 * e_ch0 * e_dh;
+                Qo[7] = Qd7 + W[2] + W[5] + M1 * M1 * W[14] - e_ch1 * e_ch1 * e_dh;
                 double yy = 0.0, yr = 0.0, rr = 0.0;
 #pragma unroll
                 for (int i = 0; i < 4; i++) { yy += W[6 + i] * h0[i] * h0[i]; yr += W[6 + i] * h0[i] * h1[i]; rr += W[6 + i] * h1[i] * h1[i]; }
-                Qo[8] = yy - e_c10 * e_c10 / e_d1 - e_c20 * e_c20 / e_d2;
-                Qo[9] = yr - e_c10 * e_c11 / e_d1 - e_c20 * e_c21 / e_d2;
-                Qo[10] = rr - e_c11 * e_c11 / e_d1 - e_c21 * e_c21 / e_d2;
-                Qo[11] = M0 * M1 * W[14] - e_ch0 * e_ch1 / e_dh;      // (delta, Fx) off-diagonal
-                Qo[12] = 0.0;
-                sR[2 * s] = Rd0 + W[12] + W[13]; sR[2 * s + 1] = Rd1;
+                Qo[8] = yy - e_c10 * e_c10 * e_d1 - e_c20 * e_c20 * e_d2;
+                Qo[9] = yr - e_c10 * e_c11 * e_d1 - e_c20 * e_c21 * e_d2;
+                Qo[10] = rr - e_c11 * e_c11 * e_d1 - e_c21 * e_c21 * e_d2;
+                Qo[11] = M0 * M1 * W[14] - e_ch0 * e_ch1 * e_dh;
+                sR[2 * s] = Rd0 + W[12] + W[13];
             }
         }
     };
-    // Qhat_k[i][j] from the packed per-node record (node k >= 1; node 0 has no cost)
-    auto qhat = [&](int k, int i, int j) -> double {
-        const double* Qo = sQ + 14 * k;
-        if (i == j) return (i == 2) ? Qo[8] : (i == 3) ? Qo[10] : Qo[i];
-        if ((i == 2 && j == 3) || (i == 3 && j == 2)) return Qo[9];
-        if ((i == 6 && j == 7) || (i == 7 && j == 6)) return Qo[11];
-        return 0.0;
-    };
-
     const int li = lane >> 3, lj = lane & 7;
+    // slot of Qhat[li][lj] inside the packed 14-double node record (slot 12 is a stored zero)
+    const int qidx = (li == lj) ? (li == 2 ? 8 : (li == 3 ? 10 : li)) : (((li == 2 && lj == 3) || (li == 3 && lj == 2)) ? 9 : (((li == 6 && lj == 7) || (li == 7 && lj == 6)) ? 11 : 12));
 
-    // Riccati matrix pass (once per IPM iteration): lane (li, lj) owns P[li][lj]
+    // Riccati matrix pass (once per IPM iteration): lane (li, lj) owns P[li][lj]; two LDS round trips per stage, branch-free body
     auto riccati_matrices = [&]() {
-        double Pij = qhat(N, li, lj);
+        double Pij = sQ[14 * N + qidx];
+        double pvec = sq[8 * N + r8];                  // predictor's backward vector recursion rides along (same stage order)
+        const int ljb = lj < 2 ? lj : 0;
+#pragma unroll 1
         for (int k = N - 1; k >= 0; k--) {
+            const double* Ak = sAb + 48 * k; const double* Bk = sBf + 12 * k; const double* ck = sc + 6 * k;
             sP[lane] = Pij;
-            __syncthreads();
-            double ma = 0.0, second = 0.0;
+            // stage constants (independent of the recursion): issue their reads before the barrier
+            double acol[6], arow[6], aug6[6], bk0[6], bk1[6];
 #pragma unroll
-            for (int m = 0; m < 8; m++) {
-                double pim = sP[8 * li + m];
-                ma += pim * abar(k, m, lj);
-                double col = 0.0;
-                if (lj < 2) col = m < 6 ? sBf[12 * k + 2 * m + lj] : ((m - 6) == lj ? 1.0 : 0.0);
-                else if (lj == 2) col = m < 6 ? sc[6 * k + m] : 0.0;
-                second += pim * col;
-            }
-            sMA[lane] = ma;
-            if (lj < 2) sMB[2 * li + lj] = second;
-            if (lj == 2) sMc[8 * k + li] = second;
-            __syncthreads();
-            // F[c][lj] = Bbar' MA ; S = Rhat + Bbar' MB
-            double F0 = sMA[8 * 6 + lj], F1 = sMA[8 * 7 + lj];
-            double S00 = sR[2 * k] + sMB[2 * 6 + 0], S01 = sMB[2 * 6 + 1], S11 = sR[2 * k + 1] + sMB[2 * 7 + 1];
-            double macol[8];
+            for (int m = 0; m < 6; m++) { acol[m] = Ak[8 * m + lj]; arow[m] = Ak[8 * m + li]; aug6[m] = lj == 2 ? ck[m] : Bk[2 * m + ljb]; bk0[m] = Bk[2 * m]; bk1[m] = Bk[2 * m + 1]; }
+            double qh = sQ[14 * k + qidx], R0 = sR[2 * k], R1 = sR[2 * k + 1];
+            double a6v[6];
 #pragma unroll
-            for (int m = 0; m < 8; m++) macol[m] = sMA[8 * m + lj];
+            for (int m = 0; m < 6; m++) a6v[m] = Ak[8 * m + r8];
+            double qkv = sq[8 * k + r8], r0v = sr[2 * k], r1v = sr[2 * k + 1];
+            __syncthreads();
+            double prow[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) prow[m] = sP[8 * li + m];
+            double ma = lj == 6 ? prow[6] : (lj == 7 ? prow[7] : 0.0);
+            double aug = lj == 0 ? prow[6] : (lj == 1 ? prow[7] : 0.0);
+#pragma unroll
+            for (int m = 0; m < 6; m++) { ma += prow[m] * acol[m]; aug += prow[m] * aug6[m]; }
+            sMT[8 * lj + li] = ma;
+            *(lj < 3 ? sMT + 8 * (8 + lj) + li : sDum + lane) = aug;
+            *(lj == 2 ? sMc + 8 * k + li : sDum + lane) = aug;
+            __syncthreads();
+            double cj[8], ci[8], mb0[8], mb1[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) { cj[m] = sMT[8 * lj + m]; ci[m] = sMT[8 * li + m]; mb0[m] = sMT[64 + m]; mb1[m] = sMT[72 + m]; }
+            double Fj0 = cj[6], Fj1 = cj[7], Fi0 = ci[6], Fi1 = ci[7];
+            double S00 = R0 + mb0[6], S01 = mb1[6], S11 = R1 + mb1[7];
 #pragma unroll
             for (int m = 0; m < 6; m++) {
-                double b0 = sBf[12 * k + 2 * m], b1 = sBf[12 * k + 2 * m + 1];
-                F0 += b0 * macol[m]; F1 += b1 * macol[m];
-                S00 += b0 * sMB[2 * m]; S01 += b0 * sMB[2 * m + 1]; S11 += b1 * sMB[2 * m + 1];
+                Fj0 += bk0[m] * cj[m]; Fj1 += bk1[m] * cj[m]; Fi0 += bk0[m] * ci[m]; Fi1 += bk1[m] * ci[m];
+                S00 += bk0[m] * mb0[m]; S01 += bk0[m] * mb1[m]; S11 += bk1[m] * mb1[m];
             }
-            double det = S00 * S11 - S01 * S01, idet = 1.0 / det;
+            double idet = frcp(S00 * S11 - S01 * S01);
             double I00 = S11 * idet, I01 = -S01 * idet, I11 = S00 * idet;
-            double K0 = -(I00 * F0 + I01 * F1), K1 = -(I01 * F0 + I11 * F1);
-            if (li == 0) { sK[16 * k + lj] = K0; sK[16 * k + 8 + lj] = K1; sF[lj] = F0; sF[8 + lj] = F1; }
-            if (lane == 0) { sSi[4 * k] = I00; sSi[4 * k + 1] = I01; sSi[4 * k + 2] = I11; }
-            __syncthreads();
-            if (k > 0) {
-                double pn = qhat(k, li, lj) + sF[li] * K0 + sF[8 + li] * K1;
+            double K0 = -(I00 * Fj0 + I01 * Fj1), K1 = -(I01 * Fj0 + I11 * Fj1);
+            *(li < 2 ? sK + 16 * k + 8 * li + lj : sDum + lane) = li == 0 ? K0 : K1;
+            *(lane < 3 ? sSi + 4 * k + lane : sDum + lane) = lane == 0 ? I00 : (lane == 1 ? I01 : I11);
+            double pn = qh + Fi0 * K0 + Fi1 * K1 + (li == 6 ? cj[6] : (li == 7 ? cj[7] : 0.0));
 #pragma unroll
-                for (int m = 0; m < 8; m++) pn += abar(k, m, li) * macol[m];
-                // symmetrise through LDS
-                sP[lane] = pn;
-                __syncthreads();
-                Pij = 0.5 * (pn + sP[8 * lj + li]);
-                __syncthreads();
-            }
-        }
-    };
-    // Riccati vector pass backward (lanes 0..7): p_k = qhat_k + Abar'(y) + K' f,  y = Mc_k + p_{k+1},  f = rhat + Bbar' y,  kff = -Sinv f
-    auto riccati_vectors = [&]() {
-        if (lane < 8) sp[lane] = sq[8 * N + lane];
-        __syncthreads();
-        for (int k = N - 1; k >= 0; k--) {
+            for (int m = 0; m < 6; m++) pn += arow[m] * cj[m];
+            Pij = pn;                                        // (k == 0: never used)
+            // ---- vector recursion of the predictor: y = Mc_k + p_{k+1} (Mc_k = column 10 of the augmented product, in sMT[80..87]) ----
+            double yi = sMT[80 + r8] + pvec;
             double y[8];
 #pragma unroll
-            for (int m = 0; m < 8; m++) y[m] = sMc[8 * k + m] + sp[m];
-            double f0 = sr[2 * k] + y[6], f1 = sr[2 * k + 1] + y[7];
+            for (int m = 0; m < 8; m++) y[m] = rl(yi, m);
+            double f0 = r0v + y[6], f1 = r1v + y[7], f0b = 0.0, f1b = 0.0;
+            double acc = qkv + (r8 == 6 ? y[6] : (r8 == 7 ? y[7] : 0.0)), accb = 0.0;
 #pragma unroll
-            for (int m = 0; m < 6; m++) { f0 += sBf[12 * k + 2 * m] * y[m]; f1 += sBf[12 * k + 2 * m + 1] * y[m]; }
-            double pn = 0.0;
-            if (lane < 8 && k > 0) {
-                pn = sq[8 * k + lane] + sK[16 * k + lane] * f0 + sK[16 * k + 8 + lane] * f1;
-#pragma unroll
-                for (int m = 0; m < 8; m++) pn += abar(k, m, lane) * y[m];
+            for (int m = 0; m < 6; m += 2) {
+                f0 += bk0[m] * y[m]; f0b += bk0[m + 1] * y[m + 1]; f1 += bk1[m] * y[m]; f1b += bk1[m + 1] * y[m + 1];
+                acc += a6v[m] * y[m]; accb += a6v[m + 1] * y[m + 1];
             }
-            __syncthreads();
-            if (lane < 8) sp[lane] = pn;
-            if (lane == 0) {
-                double I00 = sSi[4 * k], I01 = sSi[4 * k + 1], I11 = sSi[4 * k + 2];
-                skf[2 * k] = -(I00 * f0 + I01 * f1); skf[2 * k + 1] = -(I01 * f0 + I11 * f1);
-            }
-            __syncthreads();
+            f0 += f0b; f1 += f1b;
+            // K[c][r8] for this lane's component: K0/K1 above are K[c][lj] and lj == r8
+            pvec = (acc + accb) + (K0 * f0 + K1 * f1);
+            *(lane < 2 ? skf + 2 * k + lane : sDum + lane) = lane == 0 ? -(I00 * f0 + I01 * f1) : -(I01 * f0 + I11 * f1);
         }
+        __syncthreads();
     };
-    // Newton point of this stage from LDS + slack recovery; computes t+ per row
+    // Riccati vector pass backward: lane r8 holds p_{k+1}[r8]; p_k = qhat_k + Abar' y + K' f, y = Mc_k + p_{k+1}, f = rhat + Bbar' y, kff = -Sinv f
+    auto riccati_vectors = [&]() {
+        double pi = sq[8 * N + r8];
+#pragma unroll 1
+        for (int k = N - 1; k >= 0; k--) {
+            const double* Ak = sAb + 48 * k; const double* Bk = sBf + 12 * k;
+            double a6[6], b0[6], b1[6];
+#pragma unroll
+            for (int m = 0; m < 6; m++) { a6[m] = Ak[8 * m + r8]; b0[m] = Bk[2 * m]; b1[m] = Bk[2 * m + 1]; }
+            double mc = sMc[8 * k + r8], qk = sq[8 * k + r8], k0 = sK[16 * k + r8], k1 = sK[16 * k + 8 + r8], r0 = sr[2 * k], r1 = sr[2 * k + 1];
+            double I00 = sSi[4 * k], I01 = sSi[4 * k + 1], I11 = sSi[4 * k + 2];
+            double yi = mc + pi;
+            double y[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) y[m] = rl(yi, m);
+            double f0 = r0 + y[6], f1 = r1 + y[7], f0b = 0.0, f1b = 0.0;
+            double acc = qk + (r8 == 6 ? y[6] : (r8 == 7 ? y[7] : 0.0)), accb = 0.0;
+#pragma unroll
+            for (int m = 0; m < 6; m += 2) {
+                f0 += b0[m] * y[m]; f0b += b0[m + 1] * y[m + 1]; f1 += b1[m] * y[m]; f1b += b1[m + 1] * y[m + 1];
+                acc += a6[m] * y[m]; accb += a6[m + 1] * y[m + 1];
+            }
+            f0 += f0b; f1 += f1b;
+            pi = (acc + accb) + (k0 * f0 + k1 * f1);          // (k == 0: never used)
+            *(lane < 2 ? skf + 2 * k + lane : sDum + lane) = lane == 0 ? -(I00 * f0 + I01 * f1) : -(I01 * f0 + I11 * f1);
+        }
+        __syncthreads();
+    };
     double xn[8], vn0, vn1, sn1, sn2, snh;
     auto newton_point = [&](double* tplus) {
 #pragma unroll
         for (int m = 0; m < 8; m++) xn[m] = sx[8 * (s + 1) + m];
         vn0 = sv[2 * s]; vn1 = sv[2 * s + 1];
-        sn1 = -(e_c10 * xn[2] + e_c11 * xn[3] + e_g1) / e_d1;
-        sn2 = -(e_c20 * xn[2] + e_c21 * xn[3] + e_g2) / e_d2;
-        snh = hji_on ? -(e_ch0 * xn[6] + e_ch1 * xn[7] + e_gh) / e_dh : 0.0;
+        sn1 = -(e_c10 * xn[2] + e_c11 * xn[3] + e_g1) * e_d1;
+        sn2 = -(e_c20 * xn[2] + e_c21 * xn[3] + e_g2) * e_d2;
+        snh = hji_on ? -(e_ch0 * xn[6] + e_ch1 * xn[7] + e_gh) * e_dh : 0.0;
         slacks(xn, vn0, sn1, sn2, snh, tplus);
     };
 
@@ -670,64 +729,77 @@ __global__ __launch_bounds__(64) void k_solve(DevCfg C, int B, const double* __r
         mu = wave_sum(musum) / ntot;
         if (!(mu == mu) || fabs(mu) > 1e300) { status = PG_NUMERICAL; break; }
         if (mu <= C.ipm_tol && phi * fmax(rp0, 1.0) <= C.ipm_tol) { status = PG_SOLVED; break; }
+        double il_[NROW];
+#pragma unroll
+        for (int j = 0; j < NROW; j++) { it_[j] = frcp(R.t[j]); il_[j] = frcp(R.lam[j]); }
 
         // ---- predictor (sigma = 0, no correction) ----
 #pragma unroll
         for (int j = 0; j < NROW; j++) R.corr[j] = 0.0;
+        stamp(0);
         assemble(0.0, true);
         __syncthreads();
-        riccati_matrices();
-        riccati_vectors();
-        forward(true);
-        double tp[NROW], dta[NROW], dla[NROW];
+        stamp(1);
+        riccati_matrices();                // matrix recursion + the predictor's vector recursion
+        stamp(2);
+        forward(std::true_type{});
+        stamp(4);
+        double tp[NROW];
         newton_point(tp);
-        double amax = 1.0;
+        // step to the boundary: alpha_max = 1 / max_j( -dt_j / t_j, -dl_j / lam_j )  (only rows that move towards the boundary are positive)
+        double rmax = 0.0;
 #pragma unroll
         for (int j = 0; j < NROW; j++) {
             bool on = act && j < nrows;
-            double W = R.lam[j] / R.t[j];
-            dta[j] = tp[j] - R.t[j];
-            dla[j] = -W * tp[j];                          // lambda+ - lambda with sigma*mu = 0, corr = 0
-            if (on && dta[j] < 0.0) amax = fmin(amax, -R.t[j] / dta[j]);
-            if (on && dla[j] < 0.0) amax = fmin(amax, -R.lam[j] / dla[j]);
+            double dt_ = tp[j] - R.t[j], dl_ = -(R.lam[j] * it_[j]) * tp[j];     // lambda+ - lambda with sigma*mu = 0, corr = 0
+            R.corr[j] = dt_ * dl_;
+            double rj = fmax(-dt_ * it_[j], -dl_ * il_[j]);
+            rmax = fmax(rmax, on ? rj : 0.0);
         }
-        double aaff = wave_min(amax);
+        rmax = wave_max(rmax);
+        double aaff = rmax > 1.0 ? 1.0 / rmax : 1.0;
         double msum = 0.0;
 #pragma unroll
-        for (int j = 0; j < NROW; j++) msum += (act && j < nrows) ? (R.t[j] + aaff * dta[j]) * (R.lam[j] + aaff * dla[j]) : 0.0;
+        for (int j = 0; j < NROW; j++) {
+            double dt_ = tp[j] - R.t[j], dl_ = -(R.lam[j] * it_[j]) * tp[j];
+            msum += (act && j < nrows) ? (R.t[j] + aaff * dt_) * (R.lam[j] + aaff * dl_) : 0.0;
+        }
         double mu_aff = wave_sum(msum) / ntot;
         double sg = mu_aff / mu; sg = sg * sg * sg;
         // ---- corrector ----
-#pragma unroll
-        for (int j = 0; j < NROW; j++) R.corr[j] = dta[j] * dla[j];
         assemble(sg * mu, false);
         __syncthreads();
+        stamp(1);
         riccati_vectors();
-        forward(true);
+        stamp(3);
+        forward(std::true_type{});
+        stamp(4);
         newton_point(tp);
-        amax = 1e300;
+        rmax = 0.0;
 #pragma unroll
         for (int j = 0; j < NROW; j++) {
             bool on = act && j < nrows;
-            double W = R.lam[j] / R.t[j];
-            dta[j] = tp[j] - R.t[j];
-            dla[j] = (sg * mu - R.corr[j]) / R.t[j] - W * tp[j];
-            if (on && dta[j] < 0.0) amax = fmin(amax, -R.t[j] / dta[j]);
-            if (on && dla[j] < 0.0) amax = fmin(amax, -R.lam[j] / dla[j]);
+            double dt_ = tp[j] - R.t[j], dl_ = (sg * mu - R.corr[j]) * it_[j] - (R.lam[j] * it_[j]) * tp[j];
+            tp[j] = dl_;                              // keep d(lambda); d(t) is recomputed from the stage point below
+            R.corr[j] = dt_;
+            double rj = fmax(-dt_ * it_[j], -dl_ * il_[j]);
+            rmax = fmax(rmax, on ? rj : 0.0);
         }
-        double alpha = fmin(1.0, 0.995 * wave_min(amax));
+        rmax = wave_max(rmax);
+        double alpha = rmax > 0.995 ? 0.995 / rmax : 1.0;
 #pragma unroll
         for (int j = 0; j < NROW; j++) {
             bool on = act && j < nrows;
-            if (on) { R.t[j] += alpha * dta[j]; R.lam[j] += alpha * dla[j]; }
+            R.t[j] += on ? alpha * R.corr[j] : 0.0; R.lam[j] += on ? alpha * tp[j] : 0.0;
         }
 #pragma unroll
         for (int m = 0; m < 8; m++) xs[m] += alpha * (xn[m] - xs[m]);
         vcur0 += alpha * (vn0 - vcur0); vcur1 += alpha * (vn1 - vcur1);
         sg1 += alpha * (sn1 - sg1); sg2 += alpha * (sn2 - sg2); sgh += alpha * (snh - sgh);
         phi *= (1.0 - alpha);
-        __syncthreads();
     }
+    stamp(0);
+    if (PROF && lane == 0) { for (int i = 0; i < 6; i++) prof[(size_t)b * 6 + i] = pc[i]; }
     if (status == PG_SOLVED) {
         double Ux0 = sx0[1], Fx0 = sx0[7];
         if (Ux0 < C.cp.V_min || Ux0 > C.cp.V_max || Fx0 < C.fxmin_n) status = PG_INFEASIBLE_X0;
