@@ -1,0 +1,86 @@
+"""GPU parity tests of the HJI lookup / safety-constraint path (HJI_computation.jl:20-24,66-131,160-170) against the CPU oracle."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import make_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def grid(pkg):
+    return pkg.synthetic.hji_grid(dims=(7, 6, 5, 4, 4, 5, 4), seed=11)
+
+
+def test_lookup_matches_oracle(pkg, oracle_mod, skidpad, grid):
+    knots, V, g = grid
+    mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, 8)
+    mpc.set_hji_cache(knots, V, g)
+    orc = make_oracle(oracle_mod, skidpad); orc.set_hji_grid(knots, V, g)
+    rng = np.random.default_rng(0)
+    n = 500
+    lo = np.array([k[0] for k in knots], dtype=np.float64); hi = np.array([k[-1] for k in knots], dtype=np.float64)
+    x = lo + (hi - lo) * rng.uniform(-0.05, 1.05, (n, 7))          # ~30 % of the points fall outside the grid
+    x[0] = lo; x[1] = hi                                            # exact corners are in bounds (:67 uses <=)
+    x[2] = [float(k[len(k) // 2]) for k in knots]                   # an interior knot point
+    Vg, Gg = mpc.hji_lookup(x)
+    nin = 0
+    for i in range(n):
+        Vo, Go, inb = orc.hji_lookup(x[i])
+        if inb:
+            nin += 1
+            assert abs(Vg[i] - Vo) <= 1e-12 * max(1.0, abs(Vo)), i
+            assert np.max(np.abs(Gg[i] - Go)) <= 1e-12, i
+        else:
+            assert math.isinf(Vg[i]) and Vg[i] > 0 and np.all(Gg[i] == 0), i
+    assert 50 < nin < n
+
+
+def test_constraint_rows_and_solve_with_hji(pkg, oracle_mod, skidpad, grid):
+    """update_QP! with an active safety row (V <= eps), then the full solve against the exact optimum of the same QP."""
+    knots, V, g = grid
+    B = 48
+    mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, B, hji_eps=10.0)            # large eps so that most rows are active
+    mpc.set_hji_cache(knots, V, g)
+    orc = make_oracle(oracle_mod, skidpad); orc.set_hji_grid(knots, V, g); orc.set_hji_eps(10.0)
+    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B, seed=21)
+    other = pkg.synthetic.other_cars(state, seed=5)
+    u, status, iters = mpc.step_(state, control, t0, other_car_state=other, time_offset=toff)
+    M, b, Vv = mpc.hji_constraint()
+    nact = 0
+    for i in range(B):
+        Mo, bo, Vo = orc.hji_constraint(state[i], other[i], control[i])
+        Mo = Mo * orc.u_norm                                                     # coupled_lat_long.jl:345
+        if math.isinf(Vo):
+            assert math.isinf(Vv[i]) and np.all(M[i] == 0) and b[i] == 1.0
+        else:
+            nact += 1
+            assert abs(Vv[i] - Vo) <= 1e-12 * max(1, abs(Vo))
+            assert np.max(np.abs(M[i] - Mo)) <= 1e-9 * max(1.0, np.max(np.abs(Mo))) and abs(b[i] - bo) <= 1e-9 * max(1.0, abs(bo)), i
+    assert nact >= B // 2
+    assert np.all(status == 1), status
+    qp = mpc.qp_data(); x, sg = mpc.solution(); st, it, act, mu = mpc.solve_info()
+    worst = 0.0
+    for i in range(B):
+        xe, ye, info = orc.solve_exact(qp[i]); X = orc.split_x(xe)
+        worst = max(worst, float(np.max(np.abs(x[i, 1, 6:] - X["u"][1]))))
+        qpc = orc.assemble_qp(qp[i])
+        assert mpc.canonical_active_set(i, act[i], qp[i]) == oracle_mod.active_set(qpc, xe, ye, tol=1e-6), i
+        # the penalised slacks of nodes 2 and 3 (sigma_HJI, N_HJI = 3) match the canonical solution
+        assert np.max(np.abs(sg[i, :2, 2] - X["sigma_hji"][1:3])) < 1e-6
+    assert worst < 1e-6, worst
+
+
+def test_nan_hazard_is_reported(pkg, skidpad, grid):
+    """other-car speed 0 inside the grid with V <= eps gives b_HJI = NaN in the reference; the kernel must flag it."""
+    knots, V, g = grid
+    mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, 4, hji_eps=10.0)
+    mpc.set_hji_cache(knots, V, g)
+    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, 4, seed=3)
+    other = pkg.synthetic.other_cars(state, seed=5)
+    other[1, 3] = 0.0
+    u, status, iters = mpc.step_(state, control, t0, other_car_state=other, time_offset=toff)
+    assert status[1] == pkg.NUMERICAL and np.all(np.isnan(u[1]))
+    assert status[0] == pkg.SOLVED and status[2] == pkg.SOLVED and np.all(np.isfinite(u[[0, 2, 3]]))
