@@ -1,0 +1,113 @@
+# PigeonMI355X.jl — the binding a Pigeon.jl maintainer would add to drive the MI355X hot path (libpigeon_hip.so) from Julia.
+#
+# NOT EXECUTED in the build container (no Julia toolchain there); the same C ABI is exercised by the Python mirror
+# (pigeon.jl_amd/mpc.py) and by tests/.  Function names and call order are the reference's own
+# (src/model_predictive_control.jl:70-78); `mpc` is a batch of B independent controllers instead of one.
+module PigeonMI355X
+
+using StaticArrays
+import Pigeon: compute_time_steps!, compute_linearization_nodes!, update_QP!, get_next_control,
+               BicycleState, BicycleControl, SimpleCarState, TrajectoryTube, CoupledControlParams, X1
+import Parametron: solve!
+
+const LIB = get(ENV, "PIGEON_HIP_LIB", joinpath(@__DIR__, "..", "pigeon.jl_amd", "csrc", "libpigeon_hip.so"))
+
+# mirrors of the C structs of include/pigeon_mpc.h (isbits, same field order)
+struct PgVehicle
+    G::Float64; m::Float64; Izz::Float64; L::Float64; a::Float64; b::Float64; h::Float64; mu::Float64; Caf::Float64; Car::Float64
+    Cd0::Float64; Cd1::Float64; Cd2::Float64; fwd_frac::Float64; rwd_frac::Float64; fwb_frac::Float64; rwb_frac::Float64
+    Fx_max::Float64; Fx_min::Float64; Px_max::Float64; delta_max::Float64; kappa_max::Float64
+end
+struct PgControlParams
+    V_min::Float64; V_max::Float64; k_V::Float64; k_s::Float64; deltadot_max::Float64
+    Q_ds::Float64; Q_dpsi::Float64; Q_e::Float64; W_beta::Float64; W_r::Float64; W_HJI::Float64
+    R_delta::Float64; R_ddelta::Float64; R_Fx::Float64; R_dFx::Float64
+    N_HJI::Int32; _pad::Int32
+end
+struct PgConfig
+    vehicle::PgVehicle; control::PgControlParams
+    N_short::Int32; N_long::Int32; dt_short::Float64; dt_long::Float64
+    use_correction_step::Int32; rk4_substeps::Int32; hji_eps::Float64
+    batch_capacity::Int32; device::Int32; ipm_max_iter::Int32; _pad::Int32; ipm_tol::Float64; ipm_mu0::Float64
+end
+
+check(h, rc, what) = rc == 0 || error("$what failed ($rc): " * unsafe_string(ccall((:pg_last_error, LIB), Cstring, (Ptr{Cvoid},), h)))
+
+"B copies of CoupledTrajectoryTrackingMPC(vehicle, trajectory; ...) (src/coupled_lat_long.jl:42-60) on one MI355X."
+mutable struct BatchedTrajectoryTrackingMPC
+    handle::Ptr{Cvoid}
+    B::Int
+    current_state::Vector{BicycleState{Float64}}        # fields the ROS callback writes (src/ros_integration.jl:50-53)
+    current_control::Vector{BicycleControl{Float64}}
+    other_car_state::Vector{SimpleCarState{Float64}}
+    time_offset::Vector{Float64}
+    t::Vector{Float64}
+end
+
+function BatchedTrajectoryTrackingMPC(vehicle::Dict{Symbol,Float64}, trajectory::TrajectoryTube{Float64}, B::Integer;
+                                      control_params=CoupledControlParams(), N_short=10, N_long=20, dt_short=0.01, dt_long=0.2,
+                                      use_correction_step=true, device=0)
+    cfg = Ref{PgConfig}()
+    ccall((:pg_default_config, LIB), Cint, (Ref{PgConfig},), cfg)
+    c = cfg[]
+    veh = PgVehicle((vehicle[k] for k in (:G, :m, :Izz, :L, :a, :b, :h, :μ, :Cαf, :Cαr, :Cd0, :Cd1, :Cd2, :fwd_frac, :rwd_frac, :fwb_frac, :rwb_frac,
+                                           :Fx_max, :Fx_min, :Px_max, :δ_max, :κ_max))...)
+    U = control_params
+    cp = PgControlParams(U.V_min, U.V_max, U.k_V, U.k_s, U.δ̇_max, U.Q_Δs, U.Q_Δψ, U.Q_e, U.W_β, U.W_r, U.W_HJI, U.R_δ, U.R_Δδ, U.R_Fx, U.R_ΔFx, U.N_HJI, 0)
+    cfg[] = PgConfig(veh, cp, N_short, N_long, dt_short, dt_long, use_correction_step, c.rk4_substeps, c.hji_eps, B, device,
+                     c.ipm_max_iter, 0, c.ipm_tol, c.ipm_mu0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:pg_create, LIB), Cint, (Ref{PgConfig}, Ref{Ptr{Cvoid}}), cfg, h)
+    rc == 0 || error("pg_create failed ($rc): " * unsafe_string(ccall((:pg_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
+    mpc = BatchedTrajectoryTrackingMPC(h[], B, zeros(BicycleState{Float64}, B), zeros(BicycleControl{Float64}, B),
+                                       zeros(SimpleCarState{Float64}, B), fill(NaN, B), zeros(B))
+    finalizer(m -> ccall((:pg_destroy, LIB), Cint, (Ptr{Cvoid},), m.handle), mpc)
+    set_trajectory!(mpc, trajectory)
+    mpc
+end
+
+"mpc.trajectory = latest_trajectory[] (src/ros_integration.jl:53)"
+function set_trajectory!(mpc::BatchedTrajectoryTrackingMPC, tj::TrajectoryTube{Float64})
+    check(mpc.handle, ccall((:pg_set_trajectory, LIB), Cint, (Ptr{Cvoid}, Int32, ntuple(_ -> Ptr{Float64}, 12)...),
+                            mpc.handle, length(tj), tj.t, tj.s, tj.V, tj.A, tj.E, tj.N, tj.ψ, tj.κ, tj.θ, tj.ϕ, tj.edge_L, tj.edge_R), "pg_set_trajectory")
+end
+
+"mpc.HJI_cache = HJICache(fname) (src/Pigeon.jl:40): hand over grid_knots, V_raw, ∇V_raw exactly as stored in the JLD2 file"
+function set_hji_cache!(mpc::BatchedTrajectoryTrackingMPC, grid_knots::NTuple{7,Vector{Float32}}, V_raw::Array{Float32,7}, ∇V_raw::Array{Float32})
+    dims = Int32[length(k) for k in grid_knots]
+    check(mpc.handle, ccall((:pg_set_hji_grid, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+                            mpc.handle, dims, vcat(grid_knots...), V_raw, ∇V_raw), "pg_set_hji_grid")
+end
+
+"mpc.solved = false (src/ros_integration.jl:34,41,147)"
+reset!(mpc::BatchedTrajectoryTrackingMPC) = check(mpc.handle, ccall((:pg_reset, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}), mpc.handle, C_NULL), "pg_reset")
+
+# ---- the five generic functions of the reference, same names, same order --------------------------------------------------------
+function compute_time_steps!(mpc::BatchedTrajectoryTrackingMPC, t0::AbstractVector{Float64})
+    mpc.t .= t0
+    # Vector{BicycleState{Float64}} is B x 6 doubles, instance-major: exactly the layout the ABI expects
+    check(mpc.handle, ccall((:pg_set_inputs, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                            mpc.handle, mpc.B, mpc.current_state, mpc.current_control, mpc.t, mpc.other_car_state, mpc.time_offset), "pg_set_inputs")
+    check(mpc.handle, ccall((:pg_compute_time_steps, LIB), Cint, (Ptr{Cvoid},), mpc.handle), "pg_compute_time_steps")
+end
+compute_linearization_nodes!(mpc::BatchedTrajectoryTrackingMPC) =
+    check(mpc.handle, ccall((:pg_compute_linearization_nodes, LIB), Cint, (Ptr{Cvoid},), mpc.handle), "pg_compute_linearization_nodes")
+update_QP!(mpc::BatchedTrajectoryTrackingMPC) = check(mpc.handle, ccall((:pg_update_qp, LIB), Cint, (Ptr{Cvoid},), mpc.handle), "pg_update_qp")
+solve!(mpc::BatchedTrajectoryTrackingMPC) = check(mpc.handle, ccall((:pg_solve, LIB), Cint, (Ptr{Cvoid},), mpc.handle), "pg_solve")
+function get_next_control(mpc::BatchedTrajectoryTrackingMPC)
+    u = Vector{BicycleControl{Float64}}(undef, mpc.B)
+    check(mpc.handle, ccall((:pg_get_next_control, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), mpc.handle, u), "pg_get_next_control")
+    u
+end
+
+"The convenience entry points named in the project brief: all five calls for every instance."
+function step!(mpc::BatchedTrajectoryTrackingMPC, t0::AbstractVector{Float64})
+    u = Vector{BicycleControl{Float64}}(undef, mpc.B); status = Vector{Int32}(undef, mpc.B); iters = Vector{Int32}(undef, mpc.B)
+    check(mpc.handle, ccall((:pg_step, LIB), Cint,
+                            (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}),
+                            mpc.handle, mpc.B, mpc.current_state, mpc.current_control, t0, mpc.other_car_state, mpc.time_offset, u, status, iters), "pg_step")
+    u, status, iters
+end
+const MPC! = step!
+
+end # module
