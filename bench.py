@@ -136,7 +136,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: Batch={B}/GPU coupled MPC, N=30 (N_short=10, N_long=20), X1, randomised x0 along skidpadoval, cold start, HJI inactive, fp64",
                        "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}, all_gather of controls" if world > 1 else "single GPU",
-                       "solver": "Mehrotra interior point on the stage-structured QP (Riccati), tol 1e-13", "accuracy": "max|u-u*| <= 1e-6 (normalised) vs exact optimum"},
+                       "solver": "Mehrotra interior point on the stage-structured QP (Riccati), tol 1e-12", "accuracy": "max|u-u*| <= 1e-6 (normalised) vs exact optimum"},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": dom_ms,
                          "note": "algorithmic HBM bytes are 112 B/solve (SURVEY 8d): the step is fp64-VALU/LDS/latency bound by construction, not HBM bound"},

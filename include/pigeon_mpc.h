@@ -74,7 +74,7 @@ typedef struct pg_config {
     int32_t device;                 /* HIP device ordinal */
     int32_t ipm_max_iter;           /* interior-point iteration cap (default 40) */
     int32_t _pad;
-    double ipm_tol;                 /* complementarity / infeasibility tolerance (default 1e-13) */
+    double ipm_tol;                 /* complementarity / infeasibility tolerance (default 1e-12; tighter values lose accuracy to rounding) */
     double ipm_mu0;                 /* initial barrier parameter (default 100) */
 } pg_config;
 

@@ -21,7 +21,7 @@ struct pg_handle {
     double *d_state = nullptr, *d_control = nullptr, *d_t0 = nullptr, *d_other = nullptr, *d_toff = nullptr;
     int* d_solved = nullptr;
     double *d_ts = nullptr, *d_dt = nullptr, *d_prev_ts = nullptr, *d_sep = nullptr, *d_nodes = nullptr, *d_qp = nullptr;
-    double *d_x7 = nullptr, *d_vg8 = nullptr, *d_Mb = nullptr;
+    double *d_x7 = nullptr, *d_vg8 = nullptr, *d_Mb = nullptr, *d_abar = nullptr;
     double *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     int *d_status = nullptr, *d_iters = nullptr; uint16_t* d_active = nullptr;
     // HJI grid
@@ -57,13 +57,13 @@ int pg_default_config(pg_config* c) {
     U.R_delta = 0.0; U.R_ddelta = 0.1; U.R_Fx = 0.0; U.R_dFx = 0.5;
     c->N_short = 10; c->N_long = 20; c->dt_short = 0.01; c->dt_long = 0.2; c->use_correction_step = 1;   // coupled_lat_long.jl:42-43
     c->rk4_substeps = 10; c->hji_eps = 0.05; c->batch_capacity = 4096; c->device = 0;
-    c->ipm_max_iter = 40; c->ipm_tol = 1e-13; c->ipm_mu0 = 100.0;
+    c->ipm_max_iter = 40; c->ipm_tol = 1e-12; c->ipm_mu0 = 100.0;
     return PG_OK;
 }
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_state, h->d_control, h->d_t0, h->d_other, h->d_toff, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_abar, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->ev_ok) for (int i = 0; i < 4; i++) (void)hipEventDestroy(h->ev[i]);
 }
@@ -96,6 +96,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_state, cap * 6, double); ALLOC(h->d_control, cap * 3, double); ALLOC(h->d_t0, cap, double); ALLOC(h->d_other, cap * 4, double); ALLOC(h->d_toff, cap, double);
     ALLOC(h->d_solved, cap, int); ALLOC(h->d_ts, cap * NN, double); ALLOC(h->d_dt, cap * N, double); ALLOC(h->d_prev_ts, cap * NN, double);
     ALLOC(h->d_sep, cap * 4, double); ALLOC(h->d_nodes, cap * NN * 10, double); ALLOC(h->d_qp, cap * C.qp_len, double);
+    ALLOC(h->d_abar, cap * N * 66, double);
     ALLOC(h->d_x7, cap * 7, double); ALLOC(h->d_vg8, cap * 8, double); ALLOC(h->d_Mb, cap * 4, double);
     ALLOC(h->d_solx, cap * NN * 8, double); ALLOC(h->d_sigma, cap * N * 3, double); ALLOC(h->d_u, cap * 3, double); ALLOC(h->d_mu, cap, double);
     ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_active, cap * N, uint16_t);
@@ -113,7 +114,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     }
     for (int i = 0; i < 4; i++) if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_create_error = "hipEventCreate failed"; free_all(h); delete h; return PG_ERR_HIP; }
     h->ev_ok = true;
-    h->solve_lds = (size_t)(66 * N + 14 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 64 + 88 + 8 + 64) * sizeof(double);
+    h->solve_lds = (size_t)(4 * 66 + 10 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 64 + 88 + 8 + 64 + 2) * sizeof(double);
     if (h->solve_lds > 160 * 1024) { g_create_error = "horizon too long for LDS staging"; free_all(h); delete h; return PG_ERR_INVALID; }
     if (h->solve_lds > 48 * 1024)
     {
@@ -267,14 +268,14 @@ int pg_update_qp(pg_handle* h) {
     hipLaunchKernelGGL(k_linearize, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_qp);
     LAUNCH_CHECK(h);
     long nt = (long)B * C.N;
-    hipLaunchKernelGGL(k_limits, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp);
+    hipLaunchKernelGGL(k_limits, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp, h->d_abar);
     LAUNCH_CHECK(h);
     return PG_OK;
 }
 int pg_solve(pg_handle* h) {
     int rc = check_ready(h); if (rc) return rc;
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved};
-    hipLaunchKernelGGL(k_solve<false>, dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, O, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_solve<false>, dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, O, (unsigned long long*)nullptr);
     LAUNCH_CHECK(h);
     return PG_OK;
 }
@@ -285,7 +286,7 @@ int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     unsigned long long* d = nullptr;
     HIPCHK(h, hipMalloc((void**)&d, (size_t)h->B * 6 * 8));
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved};
-    hipLaunchKernelGGL(k_solve<true>, dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, O, d);
+    hipLaunchKernelGGL(k_solve<true>, dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, O, d);
     LAUNCH_CHECK(h);
     HIPCHK(h, hipMemcpy(out, d, (size_t)h->B * 6 * 8, hipMemcpyDeviceToHost));
     (void)hipFree(d);

@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const double
 }
 
 // finishes c = Phi - A q - B0 u0 - Bf uf, scales B by u_normalization, stability envelope + bounds (:354-367), q_curr/u_curr (:332-333), HJI row (:345-346)
-__global__ __launch_bounds__(256) void k_limits(DevCfg C, int B, const double* __restrict__ nodes, const double* __restrict__ dt, const double* __restrict__ hji_Mb, double* __restrict__ qp) {
+__global__ __launch_bounds__(256) void k_limits(DevCfg C, int B, const double* __restrict__ nodes, const double* __restrict__ dt, const double* __restrict__ hji_Mb, double* __restrict__ qp,
+                                                double* __restrict__ abar) {
     long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)B * C.N) return;
     int b = (int)(gid / C.N), t = (int)(gid - (long)b * C.N);
@@ -261,6 +262,15 @@ __global__ __launch_bounds__(256) void k_limits(DevCfg C, int B, const double* _
         else { Bf[2 * i] = 0.0; Bf[2 * i + 1] = 0.0; }
         c[i] = ci;
         B0[2 * i] *= C.un0; B0[2 * i + 1] *= C.un1; Bf[2 * i] *= C.un0; Bf[2 * i + 1] *= C.un1;      // :338,350-351
+    }
+    {   // packed copy streamed by k_solve: rows 0..5 of Abar = [A | B0+Bf], Bbar = Bf, cbar = c  (66 doubles per stage)
+        double* P66 = abar + ((size_t)b * C.N + t) * 66;
+        for (int i = 0; i < 6; i++) {
+            for (int j = 0; j < 6; j++) P66[8 * i + j] = A[6 * i + j];
+            P66[8 * i + 6] = B0[2 * i] + Bf[2 * i]; P66[8 * i + 7] = B0[2 * i + 1] + Bf[2 * i + 1];
+            P66[48 + 2 * i] = Bf[2 * i]; P66[48 + 2 * i + 1] = Bf[2 * i + 1];
+            P66[60 + i] = c[i];
+        }
     }
     double Uxt = n1[1], Fx = n1[7];                                                                   // :357-358
     double Fxf = Fx > 0.0 ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac, Fxr = Fx > 0.0 ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
@@ -433,18 +443,18 @@ PG_DEV double rl(double v, int src) {
 }
 
 template <bool PROF>
-__global__ __launch_bounds__(64) void k_solve(DevCfg C, int B, const double* __restrict__ qp, SolveOut O, unsigned long long* __restrict__ prof) {
+__global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* __restrict__ qp, const double* __restrict__ abar, SolveOut O, unsigned long long* __restrict__ prof) {
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int slot) { if (PROF) { unsigned long long now = clock64(); pc[slot] += now - tprev; tprev = now; } };
     if (PROF) tprev = clock64();
     const int b = blockIdx.x, lane = threadIdx.x;
     const int N = C.N, NN = C.NN;
     extern __shared__ double lds[];
-    double* sAb = lds;                   // [N][6][8]  rows 0..5 of Abar_k = [A | B0+Bf]   (rows 6,7 are [0 I])
-    double* sBf = sAb + 48 * N;          // [N][6][2]  rows 0..5 of Bbar_k              (rows 6,7 are I)
-    double* sc = sBf + 12 * N;           // [N][6]
-    double* sQ = sc + 6 * N;             // [NN][14]: diag[8], (yy, yr, rr), (dd-df off-diagonal), -, -
-    double* sq = sQ + 14 * NN;           // [NN][8]
+    // The dynamics blocks are NOT resident: each pass streams them stage by stage from L2 through a 4-slot LDS ring
+    // (slot = 66 doubles: rows 0..5 of Abar_k = [A | B0+Bf] (48), rows 0..5 of Bbar_k = Bf (12), cbar_k = c (6)); rows 6,7 are [0 I] / I / 0.
+    double* sRing = lds;                 // [4][66]
+    double* sQ = sRing + 4 * 66;         // [NN][10]: diagonal[8] (with (Uy,Uy),(r,r) at 2,3), (Uy,r) off-diagonal, (delta,Fx) off-diagonal
+    double* sq = sQ + 10 * NN;           // [NN][8]
     double* sR = sq + 8 * NN;            // [N][2]   diagonal of Rhat
     double* sr = sR + 2 * N;             // [N][2]
     double* sK = sr + 2 * N;             // [N][2][8]
@@ -457,16 +467,21 @@ __global__ __launch_bounds__(64) void k_solve(DevCfg C, int B, const double* __r
     double* sMT = sP + 64;               // [11][8]  (P [Abar | Bbar | cbar]) stored column-major
     double* sx0 = sMT + 88;              // [8]
     double* sDum = sx0 + 8;              // [64] sink for predicated-off stores (keeps the pass loops branch-free)
+    double* sZero = sDum + 64;           // [2]  a stored 0.0 (off-pattern entries of Qhat)
 
     const QpOff o = qp_offsets(N);
     const double* Q = qp + (size_t)b * C.qp_len;
-    // ---- stage the dynamics blocks in LDS ----
-    for (int i = lane; i < 48 * N; i += 64) {
-        int k = i / 48, r = (i - 48 * k) >> 3, j = i & 7;
-        sAb[i] = j < 6 ? Q[o.A + 36 * k + 6 * r + j] : Q[o.B0 + 12 * k + 2 * r + (j - 6)] + Q[o.Bf + 12 * k + 2 * r + (j - 6)];
-    }
-    for (int i = lane; i < 12 * N; i += 64) sBf[i] = Q[o.Bf + i];
-    for (int i = lane; i < 6 * N; i += 64) sc[i] = Q[o.c + i];
+    // ---- LDS ring fed from L2: lane l < 33 moves 16 bytes of the 528-byte stage block; two-deep software pipeline (register, then LDS) ----
+    const double2* gA = reinterpret_cast<const double2*>(abar + (size_t)b * N * 66);
+    const int rlane = lane < 33 ? lane : 0;
+    double2 ring_pre;
+    auto ring_slot = [&](int k) -> double* { return sRing + (k & 3) * 66; };
+    auto ring_load = [&](int k) { int kk = k < 0 ? 0 : (k >= N ? N - 1 : k); ring_pre = gA[kk * 33 + rlane]; };
+    auto ring_put = [&](int k) { double2* dst = lane < 33 ? reinterpret_cast<double2*>(ring_slot(k)) + lane : reinterpret_cast<double2*>(sDum) + (lane & 31); *dst = ring_pre; };
+    // prime(k0, dir): block k0 lands in the ring, block k0+dir is in flight.  step(k, dir) at the top of stage k: block k+dir lands, k+2dir takes off.
+    auto ring_prime = [&](int k0, int dir) { ring_load(k0); ring_put(k0); ring_load(k0 + dir); };
+    auto ring_step = [&](int k, int dir) { ring_put(k + dir); ring_load(k + 2 * dir); };
+    if (lane < 2) sZero[lane] = 0.0;
     if (lane < 8) sx0[lane] = lane < 6 ? Q[o.qcurr + lane] : Q[o.ucurr + lane - 6];
 
     // ---- per-stage constants in the registers of lane s (stage s = transition s, node s+1) ----
@@ -483,8 +498,8 @@ __global__ __launch_bounds__(64) void k_solve(DevCfg C, int B, const double* __r
     bb[0] = -C.cp.V_min; bb[1] = C.cp.V_max; bb[2] = -C.fxmin_n; bb[3] = Q[o.dmax + s]; bb[4] = -Q[o.dmin + s]; bb[5] = Q[o.fxmax + s];
     bb[10] = 0.0; bb[11] = 0.0; bb[12] = Q[o.ddmax + s]; bb[13] = -Q[o.ddmin + s]; bb[14] = Q[o.b]; bb[15] = 0.0;
     if (act) {   // entries of the stage cost that never change
-        double* Qo = sQ + 14 * (s + 1);
-        Qo[0] = 2.0 * C.cp.Q_ds * dts; Qo[2] = 0.0; Qo[3] = 0.0; Qo[4] = 2.0 * C.cp.Q_dpsi * dts; Qo[5] = 2.0 * C.cp.Q_e * dts; Qo[12] = 0.0; Qo[13] = 0.0;
+        double* Qo = sQ + 10 * (s + 1);
+        Qo[0] = 2.0 * C.cp.Q_ds * dts; Qo[4] = 2.0 * C.cp.Q_dpsi * dts; Qo[5] = 2.0 * C.cp.Q_e * dts;
         double* qo = sq + 8 * (s + 1);
         qo[0] = 0.0; qo[4] = 0.0; qo[5] = 0.0;
         sR[2 * s + 1] = Rd1; sr[2 * s + 1] = 0.0;
@@ -509,16 +524,19 @@ __global__ __launch_bounds__(64) void k_solve(DevCfg C, int B, const double* __r
         constexpr bool use_gain = decltype(use_gain_t)::value;
         double xi = sx0[r8];
         *(lane < 8 ? sx + lane : sDum + lane) = xi;
+        ring_prime(0, +1);
         const int rr = r8 < 6 ? r8 : 5;
         const double w_lo = r8 < 6 ? 1.0 : 0.0, w_6 = r8 == 6 ? 1.0 : 0.0, w_7 = r8 == 7 ? 1.0 : 0.0;
 #pragma unroll 1
         for (int k = 0; k < N; k++) {
-            const double* Kk = sK + 16 * k; const double* Ar = sAb + 48 * k + 8 * rr;
+            ring_step(k, +1);
+            const double* Rk = ring_slot(k);
+            const double* Kk = sK + 16 * k; const double* Ar = Rk + 8 * rr;
             double K0[8], K1[8], A8[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) { A8[m] = Ar[m]; K0[m] = use_gain ? Kk[m] : 0.0; K1[m] = use_gain ? Kk[8 + m] : 0.0; }
             double kf0 = use_gain ? skf[2 * k] : 0.0, kf1 = use_gain ? skf[2 * k + 1] : 0.0;
-            double cr = sc[6 * k + rr], bf0 = sBf[12 * k + 2 * rr], bf1 = sBf[12 * k + 2 * rr + 1];
+            double cr = Rk[60 + rr], bf0 = Rk[48 + 2 * rr], bf1 = Rk[48 + 2 * rr + 1];
             double xm[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) xm[m] = rl(xi, m);
@@ -596,39 +614,43 @@ __global__ __launch_bounds__(64) void k_solve(DevCfg C, int B, const double* __r
             qo[6] = g6 - e_ch0 * e_gh * e_dh; qo[7] = g7 - e_ch1 * e_gh * e_dh;
             sr[2 * s] = gv0;
             if (matrices) {
-                double* Qo = sQ + 14 * (s + 1);
+                double* Qo = sQ + 10 * (s + 1);
                 Qo[1] = W[0] + W[1];
                 Qo[6] = Qd6 + W[3] + W[4] + M0 * M0 * W[14] - e_ch0 * e_ch0 * e_dh;
                 Qo[7] = Qd7 + W[2] + W[5] + M1 * M1 * W[14] - e_ch1 * e_ch1 * e_dh;
                 double yy = 0.0, yr = 0.0, rr = 0.0;
 #pragma unroll
                 for (int i = 0; i < 4; i++) { yy += W[6 + i] * h0[i] * h0[i]; yr += W[6 + i] * h0[i] * h1[i]; rr += W[6 + i] * h1[i] * h1[i]; }
-                Qo[8] = yy - e_c10 * e_c10 * e_d1 - e_c20 * e_c20 * e_d2;
-                Qo[9] = yr - e_c10 * e_c11 * e_d1 - e_c20 * e_c21 * e_d2;
-                Qo[10] = rr - e_c11 * e_c11 * e_d1 - e_c21 * e_c21 * e_d2;
-                Qo[11] = M0 * M1 * W[14] - e_ch0 * e_ch1 * e_dh;
+                Qo[2] = yy - e_c10 * e_c10 * e_d1 - e_c20 * e_c20 * e_d2;
+                Qo[8] = yr - e_c10 * e_c11 * e_d1 - e_c20 * e_c21 * e_d2;
+                Qo[3] = rr - e_c11 * e_c11 * e_d1 - e_c21 * e_c21 * e_d2;
+                Qo[9] = M0 * M1 * W[14] - e_ch0 * e_ch1 * e_dh;
                 sR[2 * s] = Rd0 + W[12] + W[13];
             }
         }
     };
     const int li = lane >> 3, lj = lane & 7;
-    // slot of Qhat[li][lj] inside the packed 14-double node record (slot 12 is a stored zero)
-    const int qidx = (li == lj) ? (li == 2 ? 8 : (li == 3 ? 10 : li)) : (((li == 2 && lj == 3) || (li == 3 && lj == 2)) ? 9 : (((li == 6 && lj == 7) || (li == 7 && lj == 6)) ? 11 : 12));
+    // slot of Qhat[li][lj] inside the packed 10-double node record; off-pattern entries read a stored zero (qmul = 0 kills the node stride)
+    const int qidx = (li == lj) ? li : (((li == 2 && lj == 3) || (li == 3 && lj == 2)) ? 8 : (((li == 6 && lj == 7) || (li == 7 && lj == 6)) ? 9 : -1));
+    const double* qbase = qidx >= 0 ? sQ + qidx : sZero;
+    const int qmul = qidx >= 0 ? 10 : 0;
 
     // Riccati matrix pass (once per IPM iteration): lane (li, lj) owns P[li][lj]; two LDS round trips per stage, branch-free body
     auto riccati_matrices = [&]() {
-        double Pij = sQ[14 * N + qidx];
+        double Pij = qbase[qmul * N];
         double pvec = sq[8 * N + r8];                  // predictor's backward vector recursion rides along (same stage order)
         const int ljb = lj < 2 ? lj : 0;
+        ring_prime(N - 1, -1);
 #pragma unroll 1
         for (int k = N - 1; k >= 0; k--) {
-            const double* Ak = sAb + 48 * k; const double* Bk = sBf + 12 * k; const double* ck = sc + 6 * k;
+            ring_step(k, -1);
+            const double* Ak = ring_slot(k); const double* Bk = Ak + 48; const double* ck = Ak + 60;
             sP[lane] = Pij;
             // stage constants (independent of the recursion): issue their reads before the barrier
             double acol[6], arow[6], aug6[6], bk0[6], bk1[6];
 #pragma unroll
             for (int m = 0; m < 6; m++) { acol[m] = Ak[8 * m + lj]; arow[m] = Ak[8 * m + li]; aug6[m] = lj == 2 ? ck[m] : Bk[2 * m + ljb]; bk0[m] = Bk[2 * m]; bk1[m] = Bk[2 * m + 1]; }
-            double qh = sQ[14 * k + qidx], R0 = sR[2 * k], R1 = sR[2 * k + 1];
+            double qh = qbase[qmul * k], R0 = sR[2 * k], R1 = sR[2 * k + 1];
             double a6v[6];
 #pragma unroll
             for (int m = 0; m < 6; m++) a6v[m] = Ak[8 * m + r8];
@@ -686,9 +708,11 @@ __global__ __launch_bounds__(64) void k_solve(DevCfg C, int B, const double* __r
     // Riccati vector pass backward: lane r8 holds p_{k+1}[r8]; p_k = qhat_k + Abar' y + K' f, y = Mc_k + p_{k+1}, f = rhat + Bbar' y, kff = -Sinv f
     auto riccati_vectors = [&]() {
         double pi = sq[8 * N + r8];
+        ring_prime(N - 1, -1);
 #pragma unroll 1
         for (int k = N - 1; k >= 0; k--) {
-            const double* Ak = sAb + 48 * k; const double* Bk = sBf + 12 * k;
+            ring_step(k, -1);
+            const double* Ak = ring_slot(k); const double* Bk = Ak + 48;
             double a6[6], b0[6], b1[6];
 #pragma unroll
             for (int m = 0; m < 6; m++) { a6[m] = Ak[8 * m + r8]; b0[m] = Bk[2 * m]; b1[m] = Bk[2 * m + 1]; }

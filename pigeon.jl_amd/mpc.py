@@ -34,7 +34,7 @@ class BatchedTrajectoryTrackingMPC:
     """B copies of CoupledTrajectoryTrackingMPC(vehicle, trajectory; ...) (coupled_lat_long.jl:42-60) on one MI355X."""
 
     def __init__(self, trajectory, batch_capacity, vehicle=None, control_params=None, N_short=10, N_long=20, dt_short=0.01, dt_long=0.2,
-                 use_correction_step=True, rk4_substeps=10, device=0, ipm_max_iter=40, ipm_tol=1e-13, ipm_mu0=100.0, hji_eps=0.05):
+                 use_correction_step=True, rk4_substeps=10, device=0, ipm_max_iter=40, ipm_tol=1e-12, ipm_mu0=100.0, hji_eps=0.05):
         self.lib = _lib.load_library()
         cfg = _lib.pg_config()
         self.lib.pg_default_config(C.byref(cfg))

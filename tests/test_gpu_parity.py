@@ -11,7 +11,7 @@ from conftest import make_oracle
 
 pytestmark = pytest.mark.gpu
 
-B_SMALL = 96
+B_SMALL = 192
 
 
 def rel_inf(a, b, floor=1.0):
