@@ -22,16 +22,28 @@ HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec (
 BYTES_PER_SOLVE_COLD_FP64 = 112           # state 6 + control 3 + t0 in, control 3 + status + iters out
 
 
+def usable_cores():
+    """Host threads this process may really use: the scheduler affinity, capped by the cgroup CPU quota (cpu.max) when one is set."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(pkg, traj, state, control, t0, toff):
     """The reference ALGORITHM (OSQP-form ADMM with sparse LDL', default settings) on the host cores: oracle 'port'.
     Only this leg and the checker may touch oracle/."""
     from oracle import oracle as orc_mod
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     orc = orc_mod.Oracle(); orc.set_trajectory(traj.data)
     n1 = 128
     _, _, it1, st1, secs1 = orc.step_batch(state[:n1], control[:n1], t0[:n1], time_offsets=toff[:n1], solver=1, nthreads=1)
     orc2 = orc_mod.Oracle(); orc2.set_trajectory(traj.data)
-    nall = min(len(t0), max(256, 64 * cores))
+    nall = min(len(t0), max(512, 128 * cores))
     _, _, it, st, secs = orc2.step_batch(state[:nall], control[:nall], t0[:nall], time_offsets=toff[:nall], solver=1, nthreads=cores)
     return {"value": nall / secs, "unit": "solves/s", "cores": cores, "kind": "port",
             "sample": f"{nall} cold instances of the same workload on {cores} host threads (OSQP-port ADMM, eps 1e-3, mean {float(np.mean(it)):.0f} iterations); "
@@ -46,6 +58,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hji", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -116,6 +129,32 @@ def main():
     st, it, act, mu = mpc.solve_info()
     ok = int((st == pkg.SOLVED).sum())
 
+    # HJI value/gradient lookup (the bandwidth-bound kernel of the path): 2^20 random in-grid relative states against the config-3 grid
+    hji = None
+    if rank == 0 and not args.no_hji:
+        import ctypes as C
+        knots, Vg, gg = pkg.synthetic.hji_grid_large()
+        mpc.set_hji_cache(knots, Vg, gg)
+        nq = 1 << 20
+        xq = torch.from_numpy(pkg.synthetic.hji_queries(knots, nq)).to(dev)
+        out8 = torch.empty(nq, 8, dtype=torch.float64, device=dev)
+        look = lambda: mpc._chk(mpc.lib.pg_hji_lookup8_dev(mpc.h, nq, C.c_void_p(xq.data_ptr()), C.c_void_p(out8.data_ptr())), "pg_hji_lookup8_dev")
+        for _ in range(3):
+            look()
+        torch.cuda.synchronize()
+        reps = 20
+        ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)     # the handle launches on torch's current stream (set_stream above)
+        ev0.record()
+        for _ in range(reps):
+            look()
+        ev1.record(); torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / reps
+        gbs = nq * 4096 / (ms * 1e-3) / 1e9
+        hji = {"lookups_per_s": nq / (ms * 1e-3), "avg_launch_ms": ms, "algorithmic_bytes_per_lookup": 4096, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": gbs / HBM_PEAK_GBS, "bound": "hbm", "grid": "13x13x9x9x9x9x9 float32 (V, gradV): 320 MB of 32 B node records", "lookups": nq,
+               "finite": bool(torch.isfinite(out8).all().item())}
+        mpc.clear_hji_cache()
+
     if rank == 0:
         total = world * B * args.steps
         value = total / elapsed
@@ -144,6 +183,8 @@ def main():
             "warm_value": world * B * args.steps / warm_elapsed,
             "solved": f"{ok}/{B}", "ipm_iters_mean": float(np.mean(it)), "ipm_iters_max": int(np.max(it)),
         }
+        if hji is not None:
+            line["hji_lookup"] = hji
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, traj, state, control, t0, toff)
         print(json.dumps(line), flush=True)

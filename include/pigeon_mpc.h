@@ -151,6 +151,8 @@ int pg_get_phase_ms(pg_handle* h, float out3[3]);
 /* cache[x] for a batch of relative states: HJI_computation.jl:66-72.  x7 [B][7] host; V [B], gradV [B][7] host.  Out of bounds => V=+Inf, gradV=0 */
 int pg_hji_lookup(pg_handle* h, int32_t B, const double* x7, double* V, double* gradV);
 int pg_hji_lookup_dev(pg_handle* h, int32_t B, const double* x7_dev, double* V_dev, double* gradV_dev);
+/* packed form, no temporaries, asynchronous on the handle's stream: out8 [B][8] = (V, gradV[0..6]) per lookup (the kernel's native output) */
+int pg_hji_lookup8_dev(pg_handle* h, int32_t B, const double* x7_dev, double* out8_dev);
 /* compute_reachability_constraint for the installed inputs: M [B][2] (already multiplied by u_normalization), b [B], V [B] */
 int pg_get_hji_constraint(pg_handle* h, double* M, double* b, double* V);
 

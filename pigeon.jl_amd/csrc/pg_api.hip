@@ -250,7 +250,7 @@ int pg_compute_linearization_nodes(pg_handle* h) {
     return PG_OK;
 }
 static int launch_hji_lookup(pg_handle* h, int B, const double* x7_dev, double* out8_dev) {
-    hipLaunchKernelGGL(k_hji_lookup, dim3(((size_t)B * 64 + 255) / 256), dim3(256), 0, h->stream, h->hv, B, x7_dev, out8_dev);
+    hipLaunchKernelGGL(k_hji_lookup, dim3((unsigned)(((size_t)B * 16 + 255) / 256)), dim3(256), 0, h->stream, h->hv, B, x7_dev, out8_dev);
     LAUNCH_CHECK(h);
     return PG_OK;
 }
@@ -424,6 +424,13 @@ int pg_hji_lookup_dev(pg_handle* h, int32_t B, const double* x7_dev, double* V_d
     HIPCHK(h, hipStreamSynchronize(h->stream));
     (void)hipFree(out8);
     return rc;
+}
+int pg_hji_lookup8_dev(pg_handle* h, int32_t B, const double* x7_dev, double* out8_dev) {
+    if (!h) return PG_ERR_INVALID;
+    REQUIRE(h, h->has_hji, "no HJI grid installed");
+    REQUIRE(h, B >= 1 && x7_dev && out8_dev, "pg_hji_lookup8_dev: bad arguments");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return launch_hji_lookup(h, B, x7_dev, out8_dev);
 }
 int pg_hji_lookup(pg_handle* h, int32_t B, const double* x7, double* V, double* gradV) {
     if (!h) return PG_ERR_INVALID;

@@ -306,54 +306,72 @@ __global__ __launch_bounds__(256) void k_hji_relstate(int B, const double* __res
     x[3] = us[3]; x[4] = us[4]; x[5] = th[3]; x[6] = us[5];
 }
 
-// cache[x]: HJI_computation.jl:66-72.  One wave per lookup; lane c (6 bits = corner bits of dims 2..7) gathers the dim-1 PAIR
-// (2 node records = 64 contiguous bytes), weights in fp64, wave reduction of the 8 channels.  out8[b] = (V, gradV[0..6]).
+// cache[x]: HJI_computation.jl:66-72.  SIXTEEN lanes per lookup (four lookups per wave): lane g of a group owns the corner bits of
+// dims 2..5 and walks the 4 corner combinations of dims 6,7; for each it gathers the dim-1 PAIR (2 node records = 64 contiguous
+// bytes: 4 x dwordx4).  Weights and sums in fp64 (Float32 grid x Float64 query); the 8 channels are reduced over
+// the 16-lane row with DPP butterflies (no LDS crossbar).  out8[b] = (V, gradV[0..6]); out of bounds => (Inf, 0) (:70).
+PG_DEV double dpp_add(double v, int ctrl_is /*0: xor1, 1: xor2, 2: half mirror, 3: row mirror*/) {
+    int lo = __double2loint(v), hi = __double2hiint(v), plo, phi;
+    if (ctrl_is == 0) { plo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true); }        // quad_perm [1,0,3,2]
+    else if (ctrl_is == 1) { plo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true); }   // quad_perm [2,3,0,1]
+    else if (ctrl_is == 2) { plo = __builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true); } // row_half_mirror
+    else { plo = __builtin_amdgcn_mov_dpp(lo, 0x140, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0x140, 0xF, 0xF, true); }                   // row_mirror
+    return v + __hiloint2double(phi, plo);
+}
 __global__ __launch_bounds__(256) void k_hji_lookup(HjiView Hv, int B, const double* __restrict__ x7, double* __restrict__ out8) {
-    int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wave >= B) return;
-    const double* x = x7 + (size_t)wave * 7;
-    // lanes 0..6: knot search for their dimension (searchsortedlast, clamp to [1, n-1]) and the in-bounds test (:67)
-    int myidx = 0; double myw = 0.0; int inb = 1;
-    if (lane < 7) {
-        const float* k = Hv.knots + Hv.koff[lane]; int n = Hv.dims[lane]; double xv = x[lane];
-        inb = ((double)k[0] <= xv) && (xv <= (double)k[n - 1]);
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = threadIdx.x & 15;
+    long look = gid >> 4;
+    const bool live = look < B;
+    if (!live) look = B - 1;                       // keep whole rows active for the DPP reduction; results of dead groups are not stored
+    const double* x = x7 + (size_t)look * 7;
+    // every lane searches all 7 dims (knot vectors are tiny and L1-resident): searchsortedlast, clamp to [1, n-1], in-bounds test (:67)
+    int idx[7]; double w[7]; bool inb = true;
+#pragma unroll
+    for (int d = 0; d < 7; d++) {
+        const float* k = Hv.knots + Hv.koff[d]; const int n = Hv.dims[d]; const double xv = x[d];
+        inb = inb && ((double)k[0] <= xv) && (xv <= (double)k[n - 1]);
         int lo = 0, hi = n;
         while (lo < hi) { int mid = (lo + hi) >> 1; if ((double)k[mid] <= xv) lo = mid + 1; else hi = mid; }
         int i = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
-        myidx = i - 1;
+        idx[d] = i - 1;
         double k0 = k[i - 1], k1 = k[i];
-        myw = (xv - k0) / (k1 - k0);
+        w[d] = (xv - k0) / (k1 - k0);
     }
-    int all_in = __all(inb);
     double acc[8];
-    if (all_in) {
-        long off = 0; double wt = 1.0; double w0 = __shfl(myw, 0); int i0 = __shfl(myidx, 0);
-        off = (long)i0 * Hv.stride[0];
 #pragma unroll
-        for (int d = 1; d < 7; d++) {
-            double wd = __shfl(myw, d); int id = __shfl(myidx, d);
-            int bit = (lane >> (d - 1)) & 1;
-            wt *= bit ? wd : (1.0 - wd);
-            off += (long)(id + bit) * Hv.stride[d];
+    for (int c = 0; c < 8; c++) acc[c] = 0.0;
+    if (inb) {
+        long base = (long)idx[0] * Hv.stride[0]; double wt = 1.0;
+#pragma unroll
+        for (int d = 1; d < 5; d++) { int bit = (g >> (d - 1)) & 1; wt *= bit ? w[d] : (1.0 - w[d]); base += (long)(idx[d] + bit) * Hv.stride[d]; }
+        float4 r[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {              // issue all 16 loads (256 B per lane) before the first use
+            long off = base + (long)(idx[5] + (c & 1)) * Hv.stride[5] + (long)(idx[6] + (c >> 1)) * Hv.stride[6];
+            const float4* p = reinterpret_cast<const float4*>(Hv.nodes + off * 8);
+            r[c][0] = p[0]; r[c][1] = p[1]; r[c][2] = p[2]; r[c][3] = p[3];
         }
-        const float4* p = reinterpret_cast<const float4*>(Hv.nodes + off * 8);
-        float4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
-        double wa = wt * (1.0 - w0), wb = wt * w0;
-        acc[0] = wa * (double)a0.x + wb * (double)b0.x; acc[1] = wa * (double)a0.y + wb * (double)b0.y;
-        acc[2] = wa * (double)a0.z + wb * (double)b0.z; acc[3] = wa * (double)a0.w + wb * (double)b0.w;
-        acc[4] = wa * (double)a1.x + wb * (double)b1.x; acc[5] = wa * (double)a1.y + wb * (double)b1.y;
-        acc[6] = wa * (double)a1.z + wb * (double)b1.z; acc[7] = wa * (double)a1.w + wb * (double)b1.w;
 #pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) acc[k] += __shfl_xor(acc[k], s);
+        for (int c = 0; c < 4; c++) {
+            double wc = wt * ((c & 1) ? w[5] : (1.0 - w[5])) * ((c >> 1) ? w[6] : (1.0 - w[6]));
+            double wa = wc * (1.0 - w[0]), wb = wc * w[0];
+            acc[0] += wa * (double)r[c][0].x + wb * (double)r[c][2].x; acc[1] += wa * (double)r[c][0].y + wb * (double)r[c][2].y;
+            acc[2] += wa * (double)r[c][0].z + wb * (double)r[c][2].z; acc[3] += wa * (double)r[c][0].w + wb * (double)r[c][2].w;
+            acc[4] += wa * (double)r[c][1].x + wb * (double)r[c][3].x; acc[5] += wa * (double)r[c][1].y + wb * (double)r[c][3].y;
+            acc[6] += wa * (double)r[c][1].z + wb * (double)r[c][3].z; acc[7] += wa * (double)r[c][1].w + wb * (double)r[c][3].w;
         }
-    } else {
-        acc[0] = INFINITY;
-#pragma unroll
-        for (int k = 1; k < 8; k++) acc[k] = 0.0;
     }
-    if (lane < 8) out8[(size_t)wave * 8 + lane] = acc[lane];
+    // reduction over the 16 lanes of the row (out-of-bounds groups reduce zeros)
+#pragma unroll
+    for (int c = 0; c < 8; c++) { double v = acc[c]; v = dpp_add(v, 0); v = dpp_add(v, 1); v = dpp_add(v, 2); v = dpp_add(v, 3); acc[c] = v; }
+    if (live && g < 8) {
+        double o = acc[0];
+#pragma unroll
+        for (int c = 1; c < 8; c++) o = (g == c) ? acc[c] : o;
+        if (!inb) o = (g == 0) ? INFINITY : 0.0;
+        out8[(size_t)look * 8 + g] = o;
+    }
 }
 
 // optimal_disturbance (dMode=:min) HJI_computation.jl:90-131 + compute_reachability_constraint :160-170, lane = instance

@@ -57,3 +57,33 @@ def hji_grid(dims=(13, 13, 9, 9, 9, 9, 9), seed=3):
     Vf = np.asarray(V, dtype=np.float32).reshape(-1, order="F")
     gf = np.stack([np.asarray(g[..., k], dtype=np.float32).reshape(-1, order="F") for k in range(7)], axis=1)
     return knots, Vf, gf
+
+
+def hji_grid_large(dims=(13, 13, 9, 9, 9, 9, 9), seed=3):
+    """BASELINE config 3 grid (~10 M nodes: V 40 MB + gradV 279 MB, larger than the 256 MiB Infinity Cache) built with float32
+    broadcasting (same analytic V as hji_grid, a few seconds instead of minutes)."""
+    rng = np.random.default_rng(seed)
+    lo = np.array([-20.0, -8.0, -np.pi, 0.5, -2.0, 0.0, -1.0]); hi = np.array([20.0, 8.0, np.pi, 14.0, 2.0, 12.0, 1.0])
+    knots = []
+    for d in range(7):
+        u = np.linspace(0, 1, dims[d])
+        u[1:-1] += rng.uniform(-0.25, 0.25, dims[d] - 2) / (dims[d] - 1)
+        knots.append((lo[d] + (hi[d] - lo[d]) * u).astype(np.float32))
+    # Fortran order (dim 1 fastest) == C order of the reversed axes
+    ax = [knots[d].astype(np.float32).reshape([-1 if k == d else 1 for k in range(6, -1, -1)]) for d in range(7)]   # axis position 6-d
+    shape = tuple(dims[::-1])
+    r = np.sqrt(ax[0] ** 2 / 4 + ax[1] ** 2 + 1.0).astype(np.float32)
+    V = np.broadcast_to(r - 3.0 + 0.05 * ax[3] - 0.02 * ax[5] + 0.1 * np.cos(ax[2]), shape).astype(np.float32).reshape(-1)
+    g = np.zeros((V.size, 7), dtype=np.float32)
+    g[:, 0] = np.broadcast_to(ax[0] / (4 * r), shape).reshape(-1)
+    g[:, 1] = np.broadcast_to(ax[1] / r, shape).reshape(-1)
+    g[:, 2] = np.broadcast_to(-0.1 * np.sin(ax[2]), shape).reshape(-1)
+    g[:, 3] = 0.05; g[:, 5] = -0.02
+    return knots, V, g
+
+
+def hji_queries(knots, n, seed=9, margin=0.0):
+    """n relative states uniformly inside the grid (margin > 0 pushes a share of them out of bounds)."""
+    rng = np.random.default_rng(seed)
+    lo = np.array([k[0] for k in knots], dtype=np.float64); hi = np.array([k[-1] for k in knots], dtype=np.float64)
+    return lo + (hi - lo) * rng.uniform(-margin, 1 + margin, (n, 7))
