@@ -151,7 +151,7 @@ def main():
         ms = ev0.elapsed_time(ev1) / reps
         gbs = nq * 4096 / (ms * 1e-3) / 1e9
         hji = {"lookups_per_s": nq / (ms * 1e-3), "avg_launch_ms": ms, "algorithmic_bytes_per_lookup": 4096, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": gbs / HBM_PEAK_GBS, "bound": "hbm", "grid": "13x13x9x9x9x9x9 float32 (V, gradV): 320 MB of 32 B node records", "lookups": nq,
+               "frac": gbs / HBM_PEAK_GBS, "bound": "hbm", "grid": "13x13x9x9x9x9x9 float32 (V, gradV), 10 M nodes; device layout: one contiguous 4 KiB cell record per lookup (41 GB table, capacity traded for line efficiency)", "lookups": nq,
                "finite": bool(torch.isfinite(out8).all().item())}
         mpc.clear_hji_cache()
 

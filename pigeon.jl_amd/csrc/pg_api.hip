@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -25,12 +26,13 @@ struct pg_handle {
     double *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     int *d_status = nullptr, *d_iters = nullptr; uint16_t* d_active = nullptr;
     // HJI grid
-    HjiView hv; float *d_knots = nullptr, *d_hnodes = nullptr; bool has_hji = false;
+    HjiView hv; float *d_knots = nullptr, *d_hnodes = nullptr, *d_hcells = nullptr; bool has_hji = false;
     hipEvent_t ev[4]; bool ev_ok = false; float phase_ms[3] = {0, 0, 0}; bool timing_valid = false;
     size_t solve_lds = 0;
 };
 
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return PG_ERR_HIP; } } while (0)
+#define LAUNCH_CHECK(h) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { (h)->err = std::string("kernel launch: ") + hipGetErrorString(e_); return PG_ERR_HIP; } } while (0)
 #define REQUIRE(h, cond, msg) do { if (!(cond)) { if (h) (h)->err = (msg); return PG_ERR_INVALID; } } while (0)
 
 static std::string g_create_error;
@@ -63,7 +65,7 @@ int pg_default_config(pg_config* c) {
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_state, h->d_control, h->d_t0, h->d_other, h->d_toff, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_abar, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_abar, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->ev_ok) for (int i = 0; i < 4; i++) (void)hipEventDestroy(h->ev[i]);
 }
@@ -155,7 +157,8 @@ int pg_clear_hji_grid(pg_handle* h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->d_knots) (void)hipFree(h->d_knots);
     if (h->d_hnodes) (void)hipFree(h->d_hnodes);
-    h->d_knots = nullptr; h->d_hnodes = nullptr; h->has_hji = false; h->dc.has_hji = 0;
+    if (h->d_hcells) (void)hipFree(h->d_hcells);
+    h->d_knots = nullptr; h->d_hnodes = nullptr; h->d_hcells = nullptr; h->has_hji = false; h->dc.has_hji = 0;
     return PG_OK;
 }
 
@@ -176,6 +179,23 @@ int pg_set_hji_grid(pg_handle* h, const int32_t dims[7], const float* knots_conc
     long st = 1; int ko = 0;
     for (int d = 0; d < 7; d++) { h->hv.dims[d] = dims[d]; h->hv.koff[d] = ko; h->hv.stride[d] = st; st *= dims[d]; ko += dims[d]; }
     h->hv.knots = h->d_knots; h->hv.nodes = h->d_hnodes;
+    // cell records (8 corners of dims 1..3 contiguous): built on the device from the compact node records, which are then released
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
+    int cd = 7; long ncell = 0;
+    if (const char* e = getenv("PG_HJI_CELL_DIMS")) { int v = atoi(e); if (v == 3 || v == 5 || v == 7) cd = v; }     // test hook: force a smaller record
+    for (;; cd -= 2) {        // largest cell record (4 KiB / 1 KiB / 256 B) whose table fits a quarter of the free HBM
+        long cs = 1; ncell = 1;
+        for (int d = 0; d < 7; d++) { int ext = d < cd ? dims[d] - 1 : dims[d]; h->hv.cstride[d] = cs; cs *= ext; ncell *= ext; }
+        if (cd == 3 || ((size_t)ncell << cd) * 32 <= free_b / 4) break;
+    }
+    h->hv.cdims = cd;
+    HIPCHK(h, hipMalloc((void**)&h->d_hcells, ((size_t)ncell << cd) * 8 * sizeof(float)));
+    h->hv.cells = h->d_hcells;
+    hipLaunchKernelGGL(k_hji_build_cells, dim3((unsigned)((((size_t)ncell << cd) + 255) / 256)), dim3(256), 0, h->stream, h->hv, ncell, h->d_hcells);
+    LAUNCH_CHECK(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(h->d_hnodes); h->d_hnodes = nullptr; h->hv.nodes = nullptr;
     h->has_hji = true; h->dc.has_hji = 1;
     return PG_OK;
 }
@@ -230,7 +250,6 @@ static int check_ready(pg_handle* h) {
     if (hipSetDevice(h->cfg.device) != hipSuccess) { h->err = "hipSetDevice failed"; return PG_ERR_HIP; }
     return PG_OK;
 }
-#define LAUNCH_CHECK(h) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { (h)->err = std::string("kernel launch: ") + hipGetErrorString(e_); return PG_ERR_HIP; } } while (0)
 
 int pg_compute_time_steps(pg_handle* h) {
     int rc = check_ready(h); if (rc) return rc;
@@ -250,7 +269,10 @@ int pg_compute_linearization_nodes(pg_handle* h) {
     return PG_OK;
 }
 static int launch_hji_lookup(pg_handle* h, int B, const double* x7_dev, double* out8_dev) {
-    hipLaunchKernelGGL(k_hji_lookup, dim3((unsigned)(((size_t)B * 16 + 255) / 256)), dim3(256), 0, h->stream, h->hv, B, x7_dev, out8_dev);
+    dim3 grid((unsigned)(((size_t)B * 16 + 255) / 256));
+    if (h->hv.cdims == 7) hipLaunchKernelGGL(k_hji_lookup<7>, grid, dim3(256), 0, h->stream, h->hv, B, x7_dev, out8_dev);
+    else if (h->hv.cdims == 5) hipLaunchKernelGGL(k_hji_lookup<5>, grid, dim3(256), 0, h->stream, h->hv, B, x7_dev, out8_dev);
+    else hipLaunchKernelGGL(k_hji_lookup<3>, grid, dim3(256), 0, h->stream, h->hv, B, x7_dev, out8_dev);
     LAUNCH_CHECK(h);
     return PG_OK;
 }

@@ -293,7 +293,31 @@ __global__ __launch_bounds__(256) void k_limits(DevCfg C, int B, const double* _
 
 // ------------------------------------------------------------------------------------------------------------------
 // HJI grid on device: node record = 8 floats (V, gradV[0..6]) -> one 32 B aligned read per corner, 64 B per dim-1 pair.
-struct HjiView { int dims[7]; int koff[7]; long stride[7]; const float* knots; const float* nodes; };
+// Lookup layout: CELL records.  A cell of the leading `cdims` dimensions stores its 2^cdims corner nodes contiguously, ordered by the
+// corner bits (b1 + 2 b2 + ...), 32 B per node.  cdims = 5: 1 KiB records, a 16-lane group reads one record as a single coalesced 1 KiB
+// access (4 records per lookup); cdims = 3: 256 B records, one per lane (16 per lookup).  Cells overlap, i.e. every node is stored up
+// to 2^cdims times (10 GB / 2.6 GB for the 10 M-node grid): on a 288 GB part HBM capacity is not the constraint, DRAM-page and line
+// efficiency of a random gather is.  pg_set_hji_grid picks the largest cdims whose table fits the memory budget.
+struct HjiView { int dims[7]; int koff[7]; long stride[7]; long cstride[7]; int cdims; const float* knots; const float* nodes; const float* cells; };
+
+// builds the cell records from the compact node records: thread = (cell, corner)
+__global__ __launch_bounds__(256) void k_hji_build_cells(HjiView Hv, long ncell, float* __restrict__ cells) {
+    long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cd = Hv.cdims;
+    if (gid >= (ncell << cd)) return;
+    long cell = gid >> cd; int corner = (int)(gid & ((1 << cd) - 1));
+    long rem = cell, node = 0;
+#pragma unroll
+    for (int d = 0; d < 7; d++) {
+        int ext = d < cd ? Hv.dims[d] - 1 : Hv.dims[d];
+        int i = (int)(rem % ext); rem /= ext;
+        if (d < cd) i += (corner >> d) & 1;
+        node += (long)i * Hv.stride[d];
+    }
+    const float4* src = reinterpret_cast<const float4*>(Hv.nodes + node * 8);
+    float4* dst = reinterpret_cast<float4*>(cells + gid * 8);
+    dst[0] = src[0]; dst[1] = src[1];
+}
 
 // HJIRelativeState(us, them): HJI_computation.jl:20-24 (cpsi = sin(-psi), spsi = cos(-psi): names swapped in the reference)
 __global__ __launch_bounds__(256) void k_hji_relstate(int B, const double* __restrict__ state, const double* __restrict__ other, double* __restrict__ x7) {
@@ -307,17 +331,19 @@ __global__ __launch_bounds__(256) void k_hji_relstate(int B, const double* __res
 }
 
 // cache[x]: HJI_computation.jl:66-72.  SIXTEEN lanes per lookup (four lookups per wave): lane g of a group owns the corner bits of
-// dims 2..5 and walks the 4 corner combinations of dims 6,7; for each it gathers the dim-1 PAIR (2 node records = 64 contiguous
-// bytes: 4 x dwordx4).  Weights and sums in fp64 (Float32 grid x Float64 query); the 8 channels are reduced over
+// dims 4..7 and gathers ONE cell record (the 8 corners of dims 1..3 = 256 contiguous, aligned bytes: 16 x dwordx4).  Weights and sums in fp64 (Float32 grid x Float64 query); the 8 channels are reduced over
 // the 16-lane row with DPP butterflies (no LDS crossbar).  out8[b] = (V, gradV[0..6]); out of bounds => (Inf, 0) (:70).
-PG_DEV double dpp_add(double v, int ctrl_is /*0: xor1, 1: xor2, 2: half mirror, 3: row mirror*/) {
+PG_DEV double dpp_add(double v, int ctrl_is /*0: xor1, 1: xor2, 2: half mirror, 3: row mirror, 4: rotate 4, 5: rotate 8*/) {
     int lo = __double2loint(v), hi = __double2hiint(v), plo, phi;
     if (ctrl_is == 0) { plo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true); }        // quad_perm [1,0,3,2]
     else if (ctrl_is == 1) { plo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true); }   // quad_perm [2,3,0,1]
     else if (ctrl_is == 2) { plo = __builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true); } // row_half_mirror
-    else { plo = __builtin_amdgcn_mov_dpp(lo, 0x140, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0x140, 0xF, 0xF, true); }                   // row_mirror
+    else if (ctrl_is == 3) { plo = __builtin_amdgcn_mov_dpp(lo, 0x140, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0x140, 0xF, 0xF, true); } // row_mirror
+    else if (ctrl_is == 4) { plo = __builtin_amdgcn_mov_dpp(lo, 0x124, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0x124, 0xF, 0xF, true); } // row_ror:4
+    else { plo = __builtin_amdgcn_mov_dpp(lo, 0x128, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0x128, 0xF, 0xF, true); }                   // row_ror:8
     return v + __hiloint2double(phi, plo);
 }
+template <int CD>
 __global__ __launch_bounds__(256) void k_hji_lookup(HjiView Hv, int B, const double* __restrict__ x7, double* __restrict__ out8) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int g = threadIdx.x & 15;
@@ -341,15 +367,51 @@ __global__ __launch_bounds__(256) void k_hji_lookup(HjiView Hv, int B, const dou
     double acc[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) acc[c] = 0.0;
-    if (inb) {
-        long base = (long)idx[0] * Hv.stride[0]; double wt = 1.0;
+    if (inb && CD == 7) {
+        // cdims = 7: ONE 4 KiB record holds all 128 corners of the lookup, ordered by the corner bits.  Lane g reads the float4s
+        // 16 j + g (j = 0..15): every load instruction of the 16-lane group covers 256 contiguous bytes.  float4 f belongs to node f/2
+        // (half f & 1), so the lane always sees the same channel half (g & 1) of nodes 8 j + (g >> 1): bits b1..b3 = g >> 1, b4..b7 = j.
+        long cell = 0;
 #pragma unroll
-        for (int d = 1; d < 5; d++) { int bit = (g >> (d - 1)) & 1; wt *= bit ? w[d] : (1.0 - w[d]); base += (long)(idx[d] + bit) * Hv.stride[d]; }
+        for (int d = 0; d < 7; d++) cell += (long)idx[d] * Hv.cstride[d];
+        const float4* p = reinterpret_cast<const float4*>(Hv.cells + cell * 1024) + g;
+        float4 r[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) r[j] = p[16 * j];
+        const int lb = g >> 1;
+        const double wlo = ((lb & 1) ? w[0] : (1.0 - w[0])) * ((lb & 2) ? w[1] : (1.0 - w[1])) * ((lb & 4) ? w[2] : (1.0 - w[2]));
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            double wj = wlo * ((j & 1) ? w[3] : (1.0 - w[3])) * ((j & 2) ? w[4] : (1.0 - w[4])) * ((j & 4) ? w[5] : (1.0 - w[5])) * ((j & 8) ? w[6] : (1.0 - w[6]));
+            acc[0] += wj * (double)r[j].x; acc[1] += wj * (double)r[j].y; acc[2] += wj * (double)r[j].z; acc[3] += wj * (double)r[j].w;
+        }
+    }
+    if (CD == 7) {
+        // sum over the 8 lanes with the same channel half (same lane parity): xor 2 inside the quad, then rotations by 4 and 8 across quads
+#pragma unroll
+        for (int c = 0; c < 4; c++) { double v = acc[c]; v = dpp_add(v, 1); v = dpp_add(v, 4); v = dpp_add(v, 5); acc[c] = v; }
+        if (live && g < 8) {      // lanes 0,2,4,6 hold channels 0..3, lanes 1,3,5,7 channels 4..7: lane g stores channel g
+            const int c = g >> 1;  // after the butterflies every even lane has the same sums, every odd lane too
+            double o = (c == 0) ? acc[0] : (c == 1 ? acc[1] : (c == 2 ? acc[2] : acc[3]));
+            // channel index = 4 * (g & 1) + (g >> 1)
+            int ch = 4 * (g & 1) + c;
+            if (!inb) o = (ch == 0) ? INFINITY : 0.0;
+            out8[(size_t)look * 8 + ch] = o;
+        }
+        return;
+    }
+    if (inb && CD == 5) {
+        // cdims = 5: lane g owns the corner bits of dims 2..5 = the 64 B chunk g (dim-1 pair) of a 1 KiB record; 4 records for dims 6,7
+        long cell = 0; double wt = 1.0;
+#pragma unroll
+        for (int d = 0; d < 5; d++) cell += (long)idx[d] * Hv.cstride[d];
+#pragma unroll
+        for (int d = 1; d < 5; d++) { int bit = (g >> (d - 1)) & 1; wt *= bit ? w[d] : (1.0 - w[d]); }
         float4 r[4][4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {              // issue all 16 loads (256 B per lane) before the first use
-            long off = base + (long)(idx[5] + (c & 1)) * Hv.stride[5] + (long)(idx[6] + (c >> 1)) * Hv.stride[6];
-            const float4* p = reinterpret_cast<const float4*>(Hv.nodes + off * 8);
+        for (int c = 0; c < 4; c++) {
+            long rec = cell + (long)(idx[5] + (c & 1)) * Hv.cstride[5] + (long)(idx[6] + (c >> 1)) * Hv.cstride[6];
+            const float4* p = reinterpret_cast<const float4*>(Hv.cells + rec * 256) + 4 * g;
             r[c][0] = p[0]; r[c][1] = p[1]; r[c][2] = p[2]; r[c][3] = p[3];
         }
 #pragma unroll
@@ -360,6 +422,23 @@ __global__ __launch_bounds__(256) void k_hji_lookup(HjiView Hv, int B, const dou
             acc[2] += wa * (double)r[c][0].z + wb * (double)r[c][2].z; acc[3] += wa * (double)r[c][0].w + wb * (double)r[c][2].w;
             acc[4] += wa * (double)r[c][1].x + wb * (double)r[c][3].x; acc[5] += wa * (double)r[c][1].y + wb * (double)r[c][3].y;
             acc[6] += wa * (double)r[c][1].z + wb * (double)r[c][3].z; acc[7] += wa * (double)r[c][1].w + wb * (double)r[c][3].w;
+        }
+    }
+    if (inb && CD == 3) {
+        // cdims = 3: this lane's cell record: cell (idx1, idx2, idx3) at the corner of dims 4..7 selected by the lane bits
+        long cell = (long)idx[0] * Hv.cstride[0] + (long)idx[1] * Hv.cstride[1] + (long)idx[2] * Hv.cstride[2];
+        double wt = 1.0;
+#pragma unroll
+        for (int d = 3; d < 7; d++) { int bit = (g >> (d - 3)) & 1; wt *= bit ? w[d] : (1.0 - w[d]); cell += (long)(idx[d] + bit) * Hv.cstride[d]; }
+        const float4* p = reinterpret_cast<const float4*>(Hv.cells + cell * 64);
+        float4 r[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) r[c] = p[c];  // 256 contiguous bytes: issue everything before the first use
+#pragma unroll
+        for (int c = 0; c < 8; c++) {              // corner c of the cell: bits (b1, b2, b3)
+            double wc = wt * ((c & 1) ? w[0] : (1.0 - w[0])) * ((c & 2) ? w[1] : (1.0 - w[1])) * ((c & 4) ? w[2] : (1.0 - w[2]));
+            acc[0] += wc * (double)r[2 * c].x; acc[1] += wc * (double)r[2 * c].y; acc[2] += wc * (double)r[2 * c].z; acc[3] += wc * (double)r[2 * c].w;
+            acc[4] += wc * (double)r[2 * c + 1].x; acc[5] += wc * (double)r[2 * c + 1].y; acc[6] += wc * (double)r[2 * c + 1].z; acc[7] += wc * (double)r[2 * c + 1].w;
         }
     }
     // reduction over the 16 lanes of the row (out-of-bounds groups reduce zeros)

@@ -14,7 +14,10 @@ def grid(pkg):
     return pkg.synthetic.hji_grid(dims=(7, 6, 5, 4, 4, 5, 4), seed=11)
 
 
-def test_lookup_matches_oracle(pkg, oracle_mod, skidpad, grid):
+@pytest.mark.parametrize("cell_dims", [7, 5, 3])
+def test_lookup_matches_oracle(pkg, oracle_mod, skidpad, grid, cell_dims, monkeypatch):
+    """All three device layouts (4 KiB / 1 KiB / 256 B cell records; chosen by free memory in production) against the oracle."""
+    monkeypatch.setenv("PG_HJI_CELL_DIMS", str(cell_dims))
     knots, V, g = grid
     mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, 8)
     mpc.set_hji_cache(knots, V, g)
