@@ -656,17 +656,25 @@ __global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* 
 
     // ---- initial point: v = 0 roll-out; sigma just feasible; t = max(slack, tau); lambda = mu0 / t ----
     StageRows R;
-    double xs[8], sg1 = 0.0, sg2 = 0.0, sgh = 0.0, vcur0 = 0.0;
+    // the damped iterate (x_{s+1}, sigma) of this stage is kept in the output buffers (read-modify-write once per iteration), not in registers
+    double* const SXs = O.sol_x + (size_t)b * NN * 8 + 8 * (s + 1);
+    double* const SGs = O.sol_sigma + ((size_t)b * N + s) * 3;
     forward(std::false_type{});
     double rp0 = 0.0;
     {
+        double xs[8];
 #pragma unroll
         for (int m = 0; m < 8; m++) xs[m] = sx[8 * (s + 1) + m];
         double sl[NROW];
         slacks(xs, 0.0, 0.0, 0.0, 0.0, sl);
         const double sig0 = 0.1, tau = 1e-4;
-        sg1 = fmax(0.0, -fmin(sl[6], sl[7])) + sig0; sg2 = fmax(0.0, -fmin(sl[8], sl[9])) + sig0; sgh = hji_on ? fmax(0.0, -sl[14]) + sig0 : 0.0;
+        double sg1 = fmax(0.0, -fmin(sl[6], sl[7])) + sig0, sg2 = fmax(0.0, -fmin(sl[8], sl[9])) + sig0, sgh = hji_on ? fmax(0.0, -sl[14]) + sig0 : 0.0;
         slacks(xs, 0.0, sg1, sg2, sgh, sl);
+        if (act) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) SXs[m] = xs[m];
+            SGs[0] = sg1; SGs[1] = sg2; SGs[2] = sgh;
+        }
 #pragma unroll
         for (int j = 0; j < NROW; j++) {
             bool on = act && j < nrows;
@@ -678,7 +686,6 @@ __global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* 
     stamp(5);
     rp0 = wave_max(rp0);
     const double ntot = wave_sum(act ? (double)nrows : 0.0);
-    double vcur1 = 0.0;
     double phi = 1.0, mu = 0.0;
     int it = 0, status = PG_MAX_ITER;
 
@@ -850,9 +857,8 @@ __global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* 
         mu = wave_sum(musum) / ntot;
         if (!(mu == mu) || fabs(mu) > 1e300) { status = PG_NUMERICAL; break; }
         if (mu <= C.ipm_tol && phi * fmax(rp0, 1.0) <= C.ipm_tol) { status = PG_SOLVED; break; }
-        double il_[NROW];
 #pragma unroll
-        for (int j = 0; j < NROW; j++) { it_[j] = frcp(R.t[j]); il_[j] = frcp(R.lam[j]); }
+        for (int j = 0; j < NROW; j++) it_[j] = frcp(R.t[j]);
 
         // ---- predictor (sigma = 0, no correction) ----
 #pragma unroll
@@ -874,7 +880,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* 
             bool on = act && j < nrows;
             double dt_ = tp[j] - R.t[j], dl_ = -(R.lam[j] * it_[j]) * tp[j];     // lambda+ - lambda with sigma*mu = 0, corr = 0
             R.corr[j] = dt_ * dl_;
-            double rj = fmax(-dt_ * it_[j], -dl_ * il_[j]);
+            double rj = fmax(-dt_ * it_[j], -dl_ * frcp(R.lam[j]));
             rmax = fmax(rmax, on ? rj : 0.0);
         }
         rmax = wave_max(rmax);
@@ -903,7 +909,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* 
             double dt_ = tp[j] - R.t[j], dl_ = (sg * mu - R.corr[j]) * it_[j] - (R.lam[j] * it_[j]) * tp[j];
             tp[j] = dl_;                              // keep d(lambda); d(t) is recomputed from the stage point below
             R.corr[j] = dt_;
-            double rj = fmax(-dt_ * it_[j], -dl_ * il_[j]);
+            double rj = fmax(-dt_ * it_[j], -dl_ * frcp(R.lam[j]));
             rmax = fmax(rmax, on ? rj : 0.0);
         }
         rmax = wave_max(rmax);
@@ -913,10 +919,12 @@ __global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* 
             bool on = act && j < nrows;
             R.t[j] += on ? alpha * R.corr[j] : 0.0; R.lam[j] += on ? alpha * tp[j] : 0.0;
         }
+        if (act) {
 #pragma unroll
-        for (int m = 0; m < 8; m++) xs[m] += alpha * (xn[m] - xs[m]);
-        vcur0 += alpha * (vn0 - vcur0); vcur1 += alpha * (vn1 - vcur1);
-        sg1 += alpha * (sn1 - sg1); sg2 += alpha * (sn2 - sg2); sgh += alpha * (snh - sgh);
+            for (int m = 0; m < 8; m++) { double c = SXs[m]; SXs[m] = c + alpha * (xn[m] - c); }
+            double c1 = SGs[0], c2 = SGs[1], c3 = SGs[2];
+            SGs[0] = c1 + alpha * (sn1 - c1); SGs[1] = c2 + alpha * (sn2 - c2); SGs[2] = c3 + alpha * (snh - c3);
+        }
         phi *= (1.0 - alpha);
     }
     stamp(0);
@@ -929,10 +937,6 @@ __global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* 
     double* SX = O.sol_x + (size_t)b * NN * 8;
     if (lane < 8) SX[lane] = sx0[lane];
     if (act) {
-#pragma unroll
-        for (int m = 0; m < 8; m++) SX[8 * (s + 1) + m] = xs[m];
-        double* SG = O.sol_sigma + ((size_t)b * N + s) * 3;
-        SG[0] = sg1; SG[1] = sg2; SG[2] = sgh;
         unsigned mask = 0;
 #pragma unroll
         for (int j = 0; j < NROW; j++) if (j < nrows && R.lam[j] > R.t[j]) mask |= (1u << j);
@@ -940,7 +944,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* 
     }
     if (lane == 0) {
         // get_next_control: coupled_lat_long.jl:370-374 (node 2 of the reference = stage lane 0's node)
-        double d = xs[6] * C.un0, Fx = xs[7] * C.un1;
+        double d = SXs[6] * C.un0, Fx = SXs[7] * C.un1;         // lane 0 is stage 0: SXs is node 2 of the reference
         double* U = O.u_out + (size_t)b * 3;
         U[0] = d; U[1] = Fx > 0.0 ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac; U[2] = Fx > 0.0 ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
         O.status[b] = status; O.iters[b] = it; O.mu[b] = mu; O.solved[b] = 1;      // model_predictive_control.jl:76: solved = true
