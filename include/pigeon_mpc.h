@@ -73,13 +73,20 @@ typedef struct pg_config {
     int32_t batch_capacity;         /* maximum B */
     int32_t device;                 /* HIP device ordinal */
     int32_t ipm_max_iter;           /* interior-point iteration cap (default 40) */
-    int32_t _pad;
+    int32_t formulation;            /* PG_COUPLED (src/coupled_lat_long.jl) or PG_DECOUPLED (src/decoupled_lat_long.jl) */
     double ipm_tol;                 /* complementarity / infeasibility tolerance (default 1e-12; tighter values lose accuracy to rounding) */
     double ipm_mu0;                 /* initial barrier parameter (default 100) */
 } pg_config;
 
-/* X1() and the default keyword values of the reference constructors */
+enum pg_formulation { PG_COUPLED = 0, PG_DECOUPLED = 1 };
+
+/* X1() and the default keyword values of the reference constructors (coupled formulation) */
 int pg_default_config(pg_config* cfg);
+/* DecoupledTrajectoryTrackingMPC(vehicle, trajectory; ...) defaults: src/decoupled_lat_long.jl:18-33.  The lateral formulation uses the
+ * fields V_min, V_max, k_V, k_s, deltadot_max, Q_dpsi, Q_e, W_beta, W_r, R_delta, R_ddelta of pg_control_params; delta is NOT normalised
+ * (pg_get_u_normalization returns (1,1)); pg_get_next_control returns delta from the QP and Fx from the seeded node 2 (:275-278).
+ * The warm branch does not exist in this formulation (:52-104 always re-seeds), and the HJI row is not part of it. */
+int pg_default_config_decoupled(pg_config* cfg);
 
 /* CoupledTrajectoryTrackingMPC(vehicle, trajectory; ...)  src/coupled_lat_long.jl:42-60 (trajectory installed separately) */
 int pg_create(const pg_config* cfg, pg_handle** out);

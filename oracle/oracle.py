@@ -257,3 +257,76 @@ def active_set(qp, x, y, tol=1e-7):
         elif y[i] < -tol:
             out.append(-(i + 1))
     return out
+
+
+class OracleDecoupled:
+    """Decoupled (lateral) formulation: /root/reference/src/decoupled_lat_long.jl.  Same caveats as Oracle (parity unpinned)."""
+
+    def __init__(self, N_short=10, N_long=20, dt_short=0.01, dt_long=0.2, use_correction_step=True):
+        self.L = lib()
+        self.L.pd_create.restype = C.c_void_p
+        self.L.pd_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
+        self.h = C.c_void_p(self.L.pd_create(N_short, N_long, dt_short, dt_long, int(use_correction_step)))
+        self.Ns, self.Nl, self.N, self.Nn = N_short, N_long, N_short + N_long, N_short + N_long + 1
+        n = C.c_int(); m = C.c_int(); nnz = C.c_int(); sl = C.c_int()
+        self.L.pd_qp_dims(self.h, C.byref(n), C.byref(m), C.byref(nnz), C.byref(sl))
+        self.n, self.m, self.nnz, self.sd_len = n.value, m.value, nnz.value, sl.value
+        cp = np.zeros(11); self.L.pd_get_control_params(self.h, _d(cp))
+        self.cp = dict(zip(["V_min", "V_max", "k_V", "k_s", "deltadot_max", "Q_dpsi", "Q_e", "W_beta", "W_r", "R_delta", "R_ddelta"], cp))
+
+    def __del__(self):
+        try:
+            self.L.pd_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_trajectory(self, traj12):
+        a = _arr(traj12); self.L.pd_set_trajectory(self.h, a.shape[1], _d(a))
+
+    def time_steps(self, t0):
+        ts = np.zeros(self.Nn); dt = np.zeros(self.N)
+        self.L.pd_time_steps(self.h, C.c_double(t0), _d(ts), _d(dt)); return ts, dt
+
+    def nodes(self, state6, control3, ts, dt, time_offset=float("nan")):
+        qs = np.zeros((self.Nn, 4)); us = np.zeros((self.Nn, 2)); ps = np.zeros((self.Nn, 4))
+        self.L.pd_nodes(self.h, _d(_arr(state6, 6)), _d(_arr(control3, 3)), C.c_double(time_offset), _d(_arr(ts, self.Nn)), _d(_arr(dt, self.N)), _d(qs), _d(us), _d(ps))
+        return qs, us, ps
+
+    def update_qp(self, qs, us, ps, dt):
+        sd = np.zeros(self.sd_len)
+        self.L.pd_update_qp(self.h, _d(_arr(qs, 4 * self.Nn)), _d(_arr(us, 2 * self.Nn)), _d(_arr(ps, 4 * self.Nn)), _d(_arr(dt, self.N)), _d(sd))
+        return sd
+
+    def unpack_sd(self, sd):
+        N = self.N; o = 0; out = {}
+        for name, sz, shp in [("A", 16, (N, 4, 4)), ("B0", 4, (N, 4)), ("Bf", 4, (N, 4)), ("c", 4, (N, 4)), ("H", 8, (N, 4, 2)), ("G", 4, (N, 4)),
+                              ("dmin", 1, (N,)), ("dmax", 1, (N,)), ("ddmin", 1, (N,)), ("ddmax", 1, (N,)), ("dt", 1, (N,))]:
+            out[name] = sd[o:o + sz * N].reshape(shp); o += sz * N
+        out["q_curr"] = sd[o:o + 4]; out["d_curr"] = sd[o + 4]
+        return out
+
+    def assemble_qp(self, sd):
+        Pd = np.zeros(self.n); q = np.zeros(self.n); Ap = np.zeros(self.n + 1, dtype=np.int32); Ai = np.zeros(self.nnz, dtype=np.int32)
+        Ax = np.zeros(self.nnz); l = np.zeros(self.m); u = np.zeros(self.m)
+        self.L.pd_assemble_qp(self.h, _d(_arr(sd, self.sd_len)), _d(Pd), _d(q), Ap.ctypes.data_as(c_ip), Ai.ctypes.data_as(c_ip), _d(Ax), _d(l), _d(u))
+        return dict(Pd=Pd, q=q, Ap=Ap, Ai=Ai, Ax=Ax, l=l, u=u)
+
+    def solve_exact(self, sd):
+        x = np.zeros(self.n); y = np.zeros(self.m); info = np.zeros(5)
+        self.L.pd_solve_exact(self.h, _d(_arr(sd, self.sd_len)), _d(x), _d(y), _d(info))
+        return x, y, dict(iters=int(info[0]), status=int(info[1]), res_pri=info[2], res_dua=info[3], gap=info[4])
+
+    def split_x(self, x):
+        Nn, N = self.Nn, self.N
+        return dict(q=x[:4 * Nn].reshape(Nn, 4), delta=x[4 * Nn:5 * Nn], sigma=x[5 * Nn:5 * Nn + 2 * N].reshape(N, 2), ddelta=x[5 * Nn + 2 * N:])
+
+    def lateral_dynamics(self, q4, u2, p4):
+        o = np.zeros(4); self.L.pd_lateral_dynamics(self.h, _d(_arr(q4, 4)), _d(_arr(u2, 2)), _d(_arr(p4, 4)), _d(o)); return o
+
+    def linearize_interval(self, q4, w0, wf, dt, ramp):
+        A = np.zeros((4, 4)); B0 = np.zeros(4); Bf = np.zeros(4); c = np.zeros(4)
+        self.L.pd_linearize_interval(self.h, _d(_arr(q4, 4)), _d(_arr(w0, 6)), _d(_arr(wf, 6)), C.c_double(dt), int(ramp), _d(A), _d(B0), _d(Bf), _d(c))
+        return A, B0, Bf, c
+
+    def next_control(self, delta, Fx_seed):
+        o = np.zeros(3); self.L.pd_next_control(self.h, C.c_double(delta), C.c_double(Fx_seed), _d(o)); return o

@@ -242,3 +242,76 @@ double po_step_batch(void* hv, int B, const double* states6, const double* contr
 
 extern "C" void po_set_hji_placeholder(void* hv) { ((Handle*)hv)->mpc.hji.placeholder(); }
 extern "C" void po_set_alias_prev_ts(void* hv, int on) { ((Handle*)hv)->mpc.TS.alias_prev_ts = on != 0; }
+
+// ---- decoupled (lateral) formulation: decoupled_lat_long.jl ------------------------------------------------------------------
+namespace {
+struct HandleDec { DecoupledMPC mpc; DecoupledQPLayout lay; KKTPattern kkt; int sd_len() const { return 45 * mpc.N() + 5; } };
+void sdd_to_flat(const StageDataDec& sd, double* f) {
+    double* p = f;
+    auto cp = [&](const std::vector<double>& v) { std::memcpy(p, v.data(), v.size() * 8); p += v.size(); };
+    cp(sd.A); cp(sd.B0); cp(sd.Bf); cp(sd.c); cp(sd.H); cp(sd.G); cp(sd.dmin); cp(sd.dmax); cp(sd.ddmin); cp(sd.ddmax); cp(sd.dt);
+    std::memcpy(p, sd.q_curr, 32); p += 4; *p++ = sd.d_curr;
+}
+void flat_to_sdd(const double* f, int Ns, int Nl, StageDataDec& sd) {
+    sd.resize(Ns, Nl); const double* p = f;
+    auto cp = [&](std::vector<double>& v) { std::memcpy(v.data(), p, v.size() * 8); p += v.size(); };
+    cp(sd.A); cp(sd.B0); cp(sd.Bf); cp(sd.c); cp(sd.H); cp(sd.G); cp(sd.dmin); cp(sd.dmax); cp(sd.ddmin); cp(sd.ddmax); cp(sd.dt);
+    std::memcpy(sd.q_curr, p, 32); p += 4; sd.d_curr = *p++;
+}
+}  // namespace
+extern "C" {
+void* pd_create(int Ns, int Nl, double dt_short, double dt_long, int corr) {
+    HandleDec* h = new HandleDec(); h->mpc.init(Ns, Nl, dt_short, dt_long, corr != 0);
+    h->lay.build(Ns, Nl); h->kkt.build(h->lay.n, h->lay.m, h->lay.Ap, h->lay.Ai);
+    return h;
+}
+void pd_destroy(void* hv) { delete (HandleDec*)hv; }
+void pd_get_control_params(void* hv, double* v11) {
+    const DecoupledControlParams& c = ((HandleDec*)hv)->mpc.cp;
+    double v[11] = {c.V_min, c.V_max, c.k_V, c.k_s, c.deltadot_max, c.Q_dpsi, c.Q_e, c.W_beta, c.W_r, c.R_delta, c.R_ddelta};
+    std::memcpy(v11, v, sizeof(v));
+}
+void pd_set_trajectory(void* hv, int L, const double* a) {
+    TrajectoryTube& T = ((HandleDec*)hv)->mpc.traj; T.L = L;
+    std::vector<double>* f[12] = {&T.t, &T.s, &T.V, &T.A, &T.E, &T.N, &T.psi, &T.kappa, &T.theta, &T.phi, &T.edge_L, &T.edge_R};
+    for (int k = 0; k < 12; k++) f[k]->assign(a + (size_t)k * L, a + (size_t)(k + 1) * L);
+}
+void pd_qp_dims(void* hv, int* n, int* m, int* nnz, int* sd_len) { HandleDec* h = (HandleDec*)hv; *n = h->lay.n; *m = h->lay.m; *nnz = (int)h->lay.Ai.size(); *sd_len = h->sd_len(); }
+void pd_time_steps(void* hv, double t0, double* ts, double* dt) {
+    MPCTimeSteps T = ((HandleDec*)hv)->mpc.TS; T.compute(t0);
+    std::memcpy(ts, T.ts.data(), T.ts.size() * 8); std::memcpy(dt, T.dt.data(), T.dt.size() * 8);
+}
+void pd_nodes(void* hv, const double* state6, const double* control3, double time_offset, const double* ts, const double* dt, double* qs, double* us, double* ps) {
+    DecoupledMPC m = ((HandleDec*)hv)->mpc; int Nn = m.N() + 1;
+    m.TS.ts.assign(ts, ts + Nn); m.TS.dt.assign(dt, dt + Nn - 1);
+    NodesDec nd; m.linearization_nodes(state6, control3, time_offset, nd);
+    std::memcpy(qs, nd.qs.data(), nd.qs.size() * 8); std::memcpy(us, nd.us.data(), nd.us.size() * 8); std::memcpy(ps, nd.ps.data(), nd.ps.size() * 8);
+}
+void pd_update_qp(void* hv, const double* qs, const double* us, const double* ps, const double* dt, double* sd_flat) {
+    DecoupledMPC m = ((HandleDec*)hv)->mpc; int Nn = m.N() + 1;
+    m.TS.dt.assign(dt, dt + Nn - 1);
+    NodesDec nd; nd.qs.assign(qs, qs + 4 * Nn); nd.us.assign(us, us + 2 * Nn); nd.ps.assign(ps, ps + 4 * Nn);
+    StageDataDec sd; m.update_qp(nd, sd); sdd_to_flat(sd, sd_flat);
+}
+void pd_assemble_qp(void* hv, const double* sd_flat, double* Pd, double* q, int* Ap, int* Ai, double* Ax, double* l, double* u) {
+    HandleDec* h = (HandleDec*)hv; StageDataDec sd; flat_to_sdd(sd_flat, h->mpc.TS.N_short, h->mpc.TS.N_long, sd);
+    QP qp; h->lay.fill(sd, h->mpc.cp, qp);
+    std::memcpy(Pd, qp.Pd.data(), qp.n * 8); std::memcpy(q, qp.q.data(), qp.n * 8);
+    std::memcpy(Ap, qp.Ap.data(), (qp.n + 1) * 4); std::memcpy(Ai, qp.Ai.data(), qp.Ai.size() * 4); std::memcpy(Ax, qp.Ax.data(), qp.Ax.size() * 8);
+    std::memcpy(l, qp.l.data(), qp.m * 8); std::memcpy(u, qp.u.data(), qp.m * 8);
+}
+int pd_solve_exact(void* hv, const double* sd_flat, double* x, double* y, double* info5) {
+    HandleDec* h = (HandleDec*)hv; StageDataDec sd; flat_to_sdd(sd_flat, h->mpc.TS.N_short, h->mpc.TS.N_long, sd);
+    QP qp; h->lay.fill(sd, h->mpc.cp, qp);
+    LDLNumeric ldl; ldl.init(&h->kkt.sym);
+    ExactResult R; int st = solve_exact_robust(qp, h->kkt, ldl, R);
+    if ((int)R.x.size() == qp.n) { std::memcpy(x, R.x.data(), qp.n * 8); std::memcpy(y, R.y.data(), qp.m * 8); }
+    info5[0] = R.iters; info5[1] = R.status; info5[2] = R.res_pri; info5[3] = R.res_dua; info5[4] = R.gap;
+    return st;
+}
+void pd_lateral_dynamics(void* hv, const double* q4, const double* u2, const double* p4, double* out4) { vehicle_lateral_dynamics<double>(((HandleDec*)hv)->mpc.veh, q4, u2, p4, out4); }
+void pd_linearize_interval(void* hv, const double* q4, const double* w0, const double* wf, double dt, int ramp, double* A16, double* B0, double* Bf, double* c) {
+    ((HandleDec*)hv)->mpc.linearize_interval(q4, w0, wf, dt, ramp != 0, A16, B0, Bf, c);
+}
+void pd_next_control(void* hv, double delta, double Fx_seed, double* out3) { ((HandleDec*)hv)->mpc.next_control(delta, Fx_seed, out3); }
+}

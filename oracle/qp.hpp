@@ -19,6 +19,7 @@
 #include <set>
 #include <vector>
 #include "mpc_coupled.hpp"
+#include "mpc_decoupled.hpp"
 
 namespace po {
 
@@ -134,6 +135,86 @@ struct CoupledQPLayout {
             qp.u[r + 0] = sd.dmax[t]; qp.l[r + 1] = sd.dmin[t]; qp.u[r + 2] = sd.fxmax[t];
             for (int i = 0; i < 4; i++) qp.u[r + 3 + i] = sd.G[4 * t + i];
             qp.u[r + 7] = sd.ddmax[t]; qp.l[r + 8] = sd.ddmin[t];
+        }
+    }
+};
+
+// Canonical lateral-tracking QP exactly as construct_lateral_tracking_QP states it (/root/reference/src/decoupled_lat_long.jl:162-223):
+// variables q 4x(N+1), delta (N+1), sigma 2xN, d_delta N; rows in @constraint order.  N = 30: n = 245, m = 455.
+struct DecoupledQPLayout {
+    int Ns = 0, Nl = 0, N = 0, n = 0, m = 0;
+    int o_q, o_d, o_s, o_dd;
+    int r_1, r_2, r_3, r_4, r_5, r_6, r_7;
+    std::vector<int> Ap, Ai, pos;
+    std::vector<std::pair<int, int>> emitted;
+    int vq(int i, int t) const { return o_q + 4 * t + i; }
+    int vd(int t) const { return o_d + t; }
+    int vs(int i, int k) const { return o_s + 2 * k + i; }
+    template <class F> void walk(const StageDataDec* sd, F emit) const {
+        for (int j = 0; j < 2 * N; j++) emit(r_1 + j, o_s + j, 1.0);                                                          // :166
+        for (int k = 0; k < N; k++) { emit(r_2 + k, vd(k + 1), 1.0); emit(r_2 + k, vd(k), -1.0); emit(r_2 + k, o_dd + k, -1.0); }   // :167
+        for (int i = 0; i < 4; i++) emit(r_3 + i, vq(i, 0), 1.0);                                                             // :169
+        emit(r_4, vd(0), 1.0);                                                                                                // :170
+        for (int t = 0; t < Ns; t++) for (int i = 0; i < 4; i++) {                                                            // :171-179
+            int r = r_5 + 4 * t + i;
+            for (int j = 0; j < 4; j++) emit(r, vq(j, t), sd ? sd->A[16 * t + 4 * i + j] : 1.0);
+            emit(r, vd(t), sd ? sd->B0[4 * t + i] : 1.0);
+            emit(r, vq(i, t + 1), -1.0);
+        }
+        for (int t = Ns; t < N; t++) for (int i = 0; i < 4; i++) {                                                            // :181-190
+            int r = r_6 + 4 * (t - Ns) + i;
+            for (int j = 0; j < 4; j++) emit(r, vq(j, t), sd ? sd->A[16 * t + 4 * i + j] : 1.0);
+            emit(r, vd(t), sd ? sd->B0[4 * t + i] : 1.0);
+            emit(r, vd(t + 1), sd ? sd->Bf[4 * t + i] : 1.0);
+            emit(r, vq(i, t + 1), -1.0);
+        }
+        for (int t = 0; t < N; t++) {                                                                                         // :193-211
+            int r = r_7 + 8 * t;
+            emit(r + 0, vd(t + 1), 1.0); emit(r + 1, vd(t + 1), 1.0);
+            for (int i = 0; i < 4; i++) {
+                emit(r + 2 + i, vq(0, t + 1), sd ? sd->H[8 * t + 2 * i] : 1.0);
+                emit(r + 2 + i, vq(1, t + 1), sd ? sd->H[8 * t + 2 * i + 1] : 1.0);
+                emit(r + 2 + i, vs(i / 2, t), -1.0);
+            }
+            emit(r + 6, o_dd + t, 1.0); emit(r + 7, o_dd + t, 1.0);
+        }
+    }
+    void build(int ns, int nl) {
+        Ns = ns; Nl = nl; N = ns + nl;
+        o_q = 0; o_d = 4 * (N + 1); o_s = 5 * (N + 1); o_dd = o_s + 2 * N; n = o_dd + N;
+        r_1 = 0; r_2 = 2 * N; r_3 = r_2 + N; r_4 = r_3 + 4; r_5 = r_4 + 1; r_6 = r_5 + 4 * Ns; r_7 = r_6 + 4 * Nl; m = r_7 + 8 * N;
+        emitted.clear();
+        walk(nullptr, [&](int r, int c, double) { emitted.push_back({r, c}); });
+        int nnz = (int)emitted.size();
+        std::vector<int> order(nnz);
+        for (int e = 0; e < nnz; e++) order[e] = e;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return emitted[a].second != emitted[b].second ? emitted[a].second < emitted[b].second : emitted[a].first < emitted[b].first; });
+        Ap.assign(n + 1, 0); Ai.resize(nnz); pos.resize(nnz);
+        for (int k = 0; k < nnz; k++) { int e = order[k]; Ai[k] = emitted[e].first; Ap[emitted[e].second + 1]++; pos[e] = k; }
+        for (int j = 0; j < n; j++) Ap[j + 1] += Ap[j];
+    }
+    void fill(const StageDataDec& sd, const DecoupledControlParams& cp, QP& qp) const {
+        qp.n = n; qp.m = m; qp.Ap = Ap; qp.Ai = Ai; qp.Ax.assign(Ai.size(), 0.0);
+        int e = 0;
+        walk(&sd, [&](int, int, double v) { qp.Ax[pos[e++]] = v; });
+        qp.Pd.assign(n, 0.0); qp.q.assign(n, 0.0); qp.l.assign(m, -QP_INF); qp.u.assign(m, QP_INF);
+        for (int k = 0; k < N; k++) {                                                                                         // :213-222
+            double dt = sd.dt[k];
+            qp.Pd[vq(2, k + 1)] = 2 * cp.Q_dpsi * dt; qp.Pd[vq(3, k + 1)] = 2 * cp.Q_e * dt; qp.Pd[vd(k + 1)] = 2 * cp.R_delta * dt;
+            qp.Pd[o_dd + k] = 2 * cp.R_ddelta / dt;
+            qp.q[vs(0, k)] = cp.W_beta * dt; qp.q[vs(1, k)] = cp.W_r * dt;
+        }
+        for (int j = 0; j < 2 * N; j++) qp.l[r_1 + j] = 0;
+        for (int k = 0; k < N; k++) qp.l[r_2 + k] = qp.u[r_2 + k] = 0;
+        for (int i = 0; i < 4; i++) qp.l[r_3 + i] = qp.u[r_3 + i] = sd.q_curr[i];
+        qp.l[r_4] = qp.u[r_4] = sd.d_curr;
+        for (int t = 0; t < Ns; t++) for (int i = 0; i < 4; i++) qp.l[r_5 + 4 * t + i] = qp.u[r_5 + 4 * t + i] = -sd.c[4 * t + i];
+        for (int t = Ns; t < N; t++) for (int i = 0; i < 4; i++) qp.l[r_6 + 4 * (t - Ns) + i] = qp.u[r_6 + 4 * (t - Ns) + i] = -sd.c[4 * t + i];
+        for (int t = 0; t < N; t++) {
+            int r = r_7 + 8 * t;
+            qp.u[r + 0] = sd.dmax[t]; qp.l[r + 1] = sd.dmin[t];
+            for (int i = 0; i < 4; i++) qp.u[r + 2 + i] = sd.G[4 * t + i];
+            qp.u[r + 6] = sd.ddmax[t]; qp.l[r + 7] = sd.ddmin[t];
         }
     }
 };
@@ -393,7 +474,7 @@ struct OSQPPort {
 // convention (y_i < 0 active lower bound, y_i > 0 active upper bound) so that P x + q + A'y = 0.
 struct ExactResult { std::vector<double> x, y; int iters = 0; int status = 0; double res_pri = 0, res_dua = 0, gap = 0; };
 
-inline int solve_exact(const QP& qp, const KKTPattern& K, LDLNumeric& ldl, ExactResult& R, int max_iter = 80, double tol = 1e-10, double tol_gap = 1e-14) {
+inline int solve_exact(const QP& qp, const KKTPattern& K, LDLNumeric& ldl, ExactResult& R, int max_iter = 120, double tol = 1e-10, double tol_gap = 1e-14) {
     const int n = qp.n, m = qp.m;
     const double delta = 1e-10, eps_eq = 1e-10;
     // row classes: 0 eq, 1 lower-only, 2 upper-only, 3 free
@@ -496,16 +577,35 @@ inline int solve_exact(const QP& qp, const KKTPattern& K, LDLNumeric& ldl, Exact
         double mu_aff = 0;
         for (int i = 0; i < m; i++) if (cls[i] == 1 || cls[i] == 2) mu_aff += (t[i] + aaff * dt_aff[i]) * (lam[i] + aaff * dl_aff[i]);
         mu_aff /= std::max(nineq, 1);
-        double sig = std::pow(mu_aff / mu, 3.0);
+        double sig = std::pow(std::min(mu_aff / mu, 1.0), 3.0);
+        // keep complementarity from collapsing ahead of feasibility (the classic failure of infeasible-start methods): while the residuals are
+        // still far above their tolerance relative to the gap, do not aim below a fifth of the current mu
+        if (rpn > tol * (1 + nb) || rdn > tol * (1 + nq)) sig = std::max(sig, 0.2);
         for (int i = 0; i < m; i++) rc[i] = sig * mu - t[i] * lam[i] - dt_aff[i] * dl_aff[i];
         direction(rc, dx, dy, dtv, dl);
         double a = std::min(1.0, 0.995 * steplen(dtv, dl));
         for (int j = 0; j < n; j++) x[j] += a * dx[j];
         for (int i = 0; i < m; i++) { if (cls[i] == 0) y[i] += a * dy[i]; else if (cls[i] != 3) { t[i] += a * dtv[i]; lam[i] += a * dl[i]; } }
     }
+    // rounding floor on ill-conditioned instances (long horizons with saturated steering): the gap stalls above tol_gap; residuals still hold
+    if (status == -2 && R.gap <= 1e-10 && R.res_pri <= tol * (1 + nb) && R.res_dua <= 1e3 * tol * (1 + nq)) status = 1;
     for (int i = 0; i < m; i++) y[i] = cls[i] == 1 ? -lam[i] : (cls[i] == 2 ? lam[i] : (cls[i] == 0 ? y[i] : 0.0));
     R.x = x; R.y = y; R.iters = it; R.status = status;
     return status;
 }
 
+}  // namespace po
+
+namespace po {
+// Robust "exact" solve used by the oracle API: interior point first; on the rare instance where the infeasible-start IPM collapses the gap
+// before the residuals (long horizons, saturated steering), fall back to the OSQP-form ADMM run to 1e-10 (slow, but it cannot collapse).
+inline int solve_exact_robust(const QP& qp, const KKTPattern& K, LDLNumeric& ldl, ExactResult& R) {
+    int st = solve_exact(qp, K, ldl, R);
+    if (st == 1) return st;
+    OSQPSettings s; s.eps_abs = 1e-10; s.eps_rel = 1e-10; s.max_iter = 400000; s.warm_start = 0;
+    OSQPPort admm; admm.init(&K, s);
+    int sa = admm.solve(qp);
+    if (sa == 1) { R.x = admm.x; R.y = admm.y; R.iters = -admm.last_iters; R.status = 1; R.res_pri = admm.last_pri; R.res_dua = admm.last_dua; R.gap = 0.0; return 1; }
+    return st;
+}
 }  // namespace po

@@ -24,12 +24,12 @@ class pg_control_params(C.Structure):
 class pg_config(C.Structure):
     _fields_ = [("vehicle", pg_vehicle), ("control", pg_control_params), ("N_short", C.c_int32), ("N_long", C.c_int32), ("dt_short", C.c_double),
                 ("dt_long", C.c_double), ("use_correction_step", C.c_int32), ("rk4_substeps", C.c_int32), ("hji_eps", C.c_double),
-                ("batch_capacity", C.c_int32), ("device", C.c_int32), ("ipm_max_iter", C.c_int32), ("_pad", C.c_int32), ("ipm_tol", C.c_double),
+                ("batch_capacity", C.c_int32), ("device", C.c_int32), ("ipm_max_iter", C.c_int32), ("formulation", C.c_int32), ("ipm_tol", C.c_double),
                 ("ipm_mu0", C.c_double)]
 
 
 # every symbol include/pigeon_mpc.h declares (tests check that the built library exports each one)
-SYMBOLS = ["pg_default_config", "pg_create", "pg_destroy", "pg_last_error", "pg_get_config", "pg_get_u_normalization", "pg_set_trajectory",
+SYMBOLS = ["pg_default_config", "pg_default_config_decoupled", "pg_create", "pg_destroy", "pg_last_error", "pg_get_config", "pg_get_u_normalization", "pg_set_trajectory",
            "pg_set_hji_grid", "pg_clear_hji_grid", "pg_reset", "pg_set_inputs", "pg_set_inputs_dev", "pg_compute_time_steps",
            "pg_compute_linearization_nodes", "pg_update_qp", "pg_solve", "pg_get_next_control", "pg_get_next_control_dev", "pg_step", "pg_step_dev",
            "pg_set_stream", "pg_synchronize", "pg_get_time_steps", "pg_get_nodes", "pg_get_path_coordinates", "pg_qp_len", "pg_get_qp", "pg_get_solution",

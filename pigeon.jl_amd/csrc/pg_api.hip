@@ -59,7 +59,17 @@ int pg_default_config(pg_config* c) {
     U.R_delta = 0.0; U.R_ddelta = 0.1; U.R_Fx = 0.0; U.R_dFx = 0.5;
     c->N_short = 10; c->N_long = 20; c->dt_short = 0.01; c->dt_long = 0.2; c->use_correction_step = 1;   // coupled_lat_long.jl:42-43
     c->rk4_substeps = 10; c->hji_eps = 0.05; c->batch_capacity = 4096; c->device = 0;
-    c->ipm_max_iter = 40; c->ipm_tol = 1e-12; c->ipm_mu0 = 100.0;
+    c->ipm_max_iter = 40; c->ipm_tol = 1e-12; c->ipm_mu0 = 100.0; c->formulation = PG_COUPLED;
+    return PG_OK;
+}
+
+int pg_default_config_decoupled(pg_config* c) {
+    int rc = pg_default_config(c); if (rc) return rc;
+    pg_control_params& U = c->control;               // decoupled_lat_long.jl:18-30
+    const double d10 = 10 * M_PI / 180;
+    U.Q_ds = 0.0; U.Q_dpsi = 1.0 / (d10 * d10); U.Q_e = 1.0; U.W_beta = 50 / d10; U.W_r = 50.0; U.W_HJI = 0.0; U.N_HJI = 0;
+    U.R_delta = 0.0; U.R_ddelta = 0.01 / (d10 * d10); U.R_Fx = 0.0; U.R_dFx = 1.0;      // R_dFx only pins the inert Fx slot of the embedding
+    c->formulation = PG_DECOUPLED;
     return PG_OK;
 }
 
@@ -79,6 +89,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) { g_create_error = "no HIP device available (this library has no CPU path)"; return PG_ERR_NO_DEVICE; }
     if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "device ordinal out of range"; return PG_ERR_INVALID; }
+    if (cfg->formulation != PG_COUPLED && cfg->formulation != PG_DECOUPLED) { g_create_error = "unknown formulation"; return PG_ERR_INVALID; }
     if (cfg->N_short < 1 || cfg->N_long < 0 || cfg->N_short + cfg->N_long + 1 > 64 || cfg->batch_capacity < 1 || cfg->rk4_substeps < 1) {
         g_create_error = "invalid horizon / capacity (need 1 <= N_short, N_short+N_long+1 <= 64)"; return PG_ERR_INVALID;
     }
@@ -91,6 +102,12 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     C.alias_prev_ts = 1; C.has_hji = 0; C.hji_eps = cfg->hji_eps;
     C.un0 = cfg->vehicle.delta_max; C.un1 = fmax(-cfg->vehicle.Fx_min, cfg->vehicle.Fx_max);      // coupled_lat_long.jl:199
     C.fxmin_n = cfg->vehicle.Fx_min / C.un1;
+    C.formulation = cfg->formulation; C.ux_dummy = 0.5 * (cfg->control.V_min + cfg->control.V_max);
+    C.dbg_instance = -1; if (const char* e = getenv("PG_DEBUG_INSTANCE")) C.dbg_instance = atoi(e);
+    if (cfg->formulation == PG_DECOUPLED) {          // no u normalisation in the lateral QP (decoupled_lat_long.jl:134-226); inert slots pinned
+        C.un0 = 1.0; C.un1 = 1.0; C.fxmin_n = -1.0;
+        C.cp.Q_ds = 0.0; C.cp.R_Fx = 0.0; C.cp.R_dFx = 1.0; C.cp.N_HJI = 0; C.cp.W_HJI = 0.0;
+    }
     C.qp_len = 84 * C.N + 11;
     C.ipm_max_iter = cfg->ipm_max_iter; C.ipm_tol = cfg->ipm_tol; C.ipm_mu0 = cfg->ipm_mu0;
     const size_t cap = (size_t)cfg->batch_capacity; const int N = C.N, NN = C.NN;
@@ -165,6 +182,7 @@ int pg_clear_hji_grid(pg_handle* h) {
 int pg_set_hji_grid(pg_handle* h, const int32_t dims[7], const float* knots_concat, const float* V, const float* gradV) {
     if (!h) return PG_ERR_INVALID;
     REQUIRE(h, dims && knots_concat && V && gradV, "pg_set_hji_grid: null argument");
+    REQUIRE(h, h->dc.formulation == PG_COUPLED, "the HJI safety row belongs to the coupled formulation only (coupled_lat_long.jl:341-346)");
     size_t n = 1; int nk = 0;
     for (int d = 0; d < 7; d++) { REQUIRE(h, dims[d] >= 2, "pg_set_hji_grid: every dimension needs >= 2 knots"); n *= dims[d]; nk += dims[d]; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -263,8 +281,11 @@ int pg_compute_linearization_nodes(pg_handle* h) {
     const int B = h->B;
     hipLaunchKernelGGL(k_project, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep);
     LAUNCH_CHECK(h);
-    hipLaunchKernelGGL(k_nodes, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
-                       h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes);
+    if (h->dc.formulation == PG_DECOUPLED)
+        hipLaunchKernelGGL(k_nodes_dec, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_sep, h->d_ts, h->d_dt, h->d_nodes);
+    else
+        hipLaunchKernelGGL(k_nodes, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
+                           h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes);
     LAUNCH_CHECK(h);
     return PG_OK;
 }
@@ -279,6 +300,12 @@ static int launch_hji_lookup(pg_handle* h, int B, const double* x7_dev, double* 
 int pg_update_qp(pg_handle* h) {
     int rc = check_ready(h); if (rc) return rc;
     const int B = h->B; const DevCfg& C = h->dc;
+    if (C.formulation == PG_DECOUPLED) {
+        long nt = (long)B * C.N;
+        hipLaunchKernelGGL(k_qp_dec, dim3((unsigned)((nt + 127) / 128)), dim3(128), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_qp, h->d_abar);
+        LAUNCH_CHECK(h);
+        return PG_OK;
+    }
     if (h->has_hji) {
         hipLaunchKernelGGL(k_hji_relstate, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, h->d_state, h->d_other, h->d_x7);
         LAUNCH_CHECK(h);
@@ -297,7 +324,7 @@ int pg_update_qp(pg_handle* h) {
 int pg_solve(pg_handle* h) {
     int rc = check_ready(h); if (rc) return rc;
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved};
-    hipLaunchKernelGGL(k_solve<false>, dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, O, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_solve<false>, dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, (unsigned long long*)nullptr);
     LAUNCH_CHECK(h);
     return PG_OK;
 }
@@ -306,11 +333,12 @@ int pg_solve(pg_handle* h) {
 int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     int rc = check_ready(h); if (rc) return rc;
     unsigned long long* d = nullptr;
-    HIPCHK(h, hipMalloc((void**)&d, (size_t)h->B * 6 * 8));
+    HIPCHK(h, hipMalloc((void**)&d, ((size_t)h->B * 6 + 1024) * 8));
+    HIPCHK(h, hipMemset(d, 0, ((size_t)h->B * 6 + 1024) * 8));
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved};
-    hipLaunchKernelGGL(k_solve<true>, dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, O, d);
+    hipLaunchKernelGGL(k_solve<true>, dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, d);
     LAUNCH_CHECK(h);
-    HIPCHK(h, hipMemcpy(out, d, (size_t)h->B * 6 * 8, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out, d, ((size_t)h->B * 6 + 1024) * 8, hipMemcpyDeviceToHost));      // out: [B][6] cycles + 1024-double trace of PG_DEBUG_INSTANCE
     (void)hipFree(d);
     return PG_OK;
 }

@@ -140,6 +140,20 @@ PG_DEV void world_body_rhs(const pg_vehicle& P, double Ux, double Uy, double r, 
     body_accel<T>(P, cst<T>(Ux), cst<T>(Uy), cst<T>(r), d, Fxf, Fxr, dUx, dUy, dr);
 }
 
+// VehicleModel{LateralTrackingBicycleModel}: vehicle_dynamics.jl:310-316 over :205-224.  q = (Uy, r, dpsi, e), u = (delta, Fx), p = (Ux, kappa)
+// Ux is a parameter here (get_Ux = p[1], :309): the actuator limits see its VALUE only (:295) while the dynamics see the full number.
+template <class T>
+PG_DEV void lateral_rhs(const pg_vehicle& P, const T q[4], T u0, T u1, T pUx, T pK, T out[4]) {
+    T d, Fxf, Fxr;
+    actuate<T>(P, u0, u1, val(pUx), d, Fxf, Fxr);
+    T s, c; sincos_(q[2], s, c);
+    T dUx_unused, dUy, dr;
+    body_accel<T>(P, pUx, q[0], q[1], d, Fxf, Fxr, dUx_unused, dUy, dr);
+    out[0] = dUy; out[1] = dr;
+    out[2] = q[1] - pUx * pK;
+    out[3] = pUx * s + q[0] * c;
+}
+
 // stable_limits: vehicle_dynamics.jl:227-263
 struct Envelope { double dmin, dmax, H[4][2], G[4]; };
 PG_DEV Envelope stable_limits(const pg_vehicle& B, double Ux, double Fxf, double Fxr) {

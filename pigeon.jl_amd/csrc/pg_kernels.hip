@@ -20,6 +20,9 @@ struct DevCfg {
     int Ns, Nl, N, NN;            // NN = N + 1 nodes
     double dt_short, dt_long;
     int use_correction_step, nsub;
+    int formulation;              // PG_COUPLED / PG_DECOUPLED
+    int dbg_instance;             // diagnostic kernel build only: instance whose interior-point trace is printed (-1 = none; env PG_DEBUG_INSTANCE)
+    double ux_dummy;              // decoupled: value of the inert Ux slot of the embedded 8-state problem (strictly inside [V_min, V_max])
     int alias_prev_ts;            // the reference's MPCTimeSteps passes `ts` as prev_ts too (model_predictive_control.jl:15): same array
     int has_hji;
     double hji_eps;
@@ -291,6 +294,164 @@ __global__ __launch_bounds__(256) void k_limits(DevCfg C, int B, const double* _
     }
 }
 
+// ==================================================================================================================
+// Decoupled (lateral) formulation: decoupled_lat_long.jl.  The lateral QP (state (Uy, r, dpsi, e), input delta) is EMBEDDED in the
+// 8-state stage structure k_solve works on: x = (0, Ux_dummy, Uy, r, dpsi, e, delta, 0) with identity dynamics, zero cost and
+// never-active bounds on the three inert slots, so the same solve kernel serves both formulations (the inert slots are exactly
+// decoupled from the rest, the optimum of the embedded problem restricted to the live slots IS the lateral optimum).
+// Node record (10 doubles): (0, Ux parameter, Uy, r, dpsi, e, delta, Fx, 0, kappa).
+__global__ __launch_bounds__(64) void k_nodes_dec(DevCfg C, int B, const double* __restrict__ state, const double* __restrict__ control, const double* __restrict__ toff,
+                                                  const double* __restrict__ sep, const double* __restrict__ ts, const double* __restrict__ dt, double* __restrict__ nodes) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const TrajView& T = C.traj; const pg_vehicle& P = C.veh;
+    const double* q0 = state + (size_t)b * 6; const double* u0 = control + (size_t)b * 3;
+    const double* TS = ts + (size_t)b * C.NN; const double* DT = dt + (size_t)b * C.N;
+    double* ND = nodes + (size_t)b * C.NN * 10;
+    double s = sep[(size_t)b * 4]; const double e0 = sep[(size_t)b * 4 + 1];           // :65
+    const double psi0 = q0[2], Ux0 = q0[3], Uy0 = q0[4], r0 = q0[5], d0 = u0[0], Fxf0 = u0[1], Fxr0 = u0[2];
+    double V = hypot(Ux0, Uy0);                                                         // :67
+    const double beta0 = atan2(Uy0, Ux0);
+    double Fyf0, Fyr0;
+    {
+        double sd, cd; sincos(d0, &sd, &cd);
+        double af = tan(atan2(Uy0 + P.a * r0, Ux0) - d0), ar = tan(atan2(Uy0 - P.b * r0, Ux0));
+        lateral_forces<double>(P, af, ar, Fxf0, Fxr0, sd, cd, Fyf0, Fyr0);               // :71
+    }
+    const bool traj_mode = !(toff[b] != toff[b]);
+#pragma unroll 1
+    for (int i = 0; i < C.NN; i++) {
+        double tau = (i == C.NN - 1) ? DT[i - 1] : DT[i];
+        TrajS tj = traj_at_s(T, s);
+        double A_des = tj.A + C.cp.k_V * (tj.V - V) / tau + (traj_mode ? C.cp.k_s * (traj_s_at_time(T, TS[i]) - s) / tau / tau : 0.0);   // :76
+        A_des = jmin(jmax(A_des, (C.cp.V_min - V) / tau), (C.cp.V_max - V) / tau);
+        NodeRec r; double A;
+        r.q0 = 0.0; r.pV = 0.0; r.pK = tj.kappa;
+        if (i == 0) {
+            r.q1 = Ux0; r.q2 = Uy0; r.q3 = r0; r.q4 = adiff(psi0, tj.psi); r.q5 = e0; r.u0 = d0; r.u1 = Fxf0 + Fxr0;      // :79-81
+            double dUx, dUy, dr;
+            world_body_rhs<double>(P, Ux0, Uy0, r0, d0, Fxf0 + Fxr0, dUx, dUy, dr);                                          // :82
+            double sb, cb; sincos(beta0, &sb, &cb);
+            A = (dUx - r0 * Uy0) * cb + (dUy + r0 * Ux0) * sb;                                                               // :83
+        } else {
+            const bool shortp = i <= C.Ns;
+            Steady est = shortp ? steady_state(P, V, A_des, tj.kappa, 1, r0, beta0, d0, Fyf0) : steady_state(P, V, A_des, tj.kappa, 4, V * tj.kappa, 0.0, 0.0, 0.0);
+            r.q1 = est.Ux;
+            r.q2 = shortp ? Uy0 : est.Uy; r.q3 = shortp ? r0 : est.r; r.q4 = shortp ? adiff(psi0, tj.psi) : -est.beta; r.q5 = shortp ? e0 : 0.0;   // :85,92
+            r.u0 = est.delta; r.u1 = est.Fx; A = est.A;
+        }
+        put_node(ND, i, r);
+        V = V + A * tau;
+        s = s + V * tau + A * tau * tau * 0.5;
+    }
+}
+
+// 4x4 helpers for the exact discretisation
+struct M4d { double a[16]; };
+PG_DEV M4d m4mul(const M4d& x, const M4d& y) { M4d r;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) { double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) s += x.a[4 * i + k] * y.a[4 * k + j];
+            r.a[4 * i + j] = s; }
+    return r; }
+
+// update_QP! of the lateral formulation (decoupled_lat_long.jl:228-273), lane = (instance, interval):
+// continuous Jacobians by forward mode (8 tangent directions: Uy, r, dpsi, e, delta, Fx, Ux, kappa), exact ZOH / FOH discretisation
+// (Ad = exp(A dt), G0 = int exp(A s) ds, G1 = (1/dt) int exp(A (dt - s)) s ds by Taylor series + scaling and squaring), envelope and bounds;
+// the result is written in the embedded coupled layout (QP block + the packed per-stage block k_solve streams).
+__global__ __launch_bounds__(128) void k_qp_dec(DevCfg C, int B, const double* __restrict__ nodes, const double* __restrict__ dt, double* __restrict__ qp, double* __restrict__ abar) {
+    long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)B * C.N) return;
+    int b = (int)(gid / C.N), t = (int)(gid - (long)b * C.N);
+    const bool ramp = t >= C.Ns;
+    const double* n0 = nodes + ((size_t)b * C.NN + t) * 10; const double* n1 = n0 + 10;
+    const double q[4] = {n0[2], n0[3], n0[4], n0[5]};
+    const double w0[4] = {n0[6], n0[7], n0[1], n0[9]}, wf[4] = {n1[6], n1[7], n1[1], n1[9]};      // (delta, Fx, Ux, kappa); theta = phi = 0 carry no derivative
+    const double T = dt[(size_t)b * C.N + t];
+    M4d A; double Bc[4][4], cc[4];
+    {
+        D2 f[4];
+        D2 x[4] = {D2(q[0], 1.0, 0.0), D2(q[1], 0.0, 1.0), D2(q[2]), D2(q[3])};
+        lateral_rhs<D2>(C.veh, x, D2(w0[0]), D2(w0[1]), D2(w0[2]), D2(w0[3]), f);
+        for (int i = 0; i < 4; i++) { A.a[4 * i] = f[i].a; A.a[4 * i + 1] = f[i].b; cc[i] = f[i].v; }
+        D2 y[4] = {D2(q[0]), D2(q[1]), D2(q[2], 1.0, 0.0), D2(q[3], 0.0, 1.0)};
+        lateral_rhs<D2>(C.veh, y, D2(w0[0]), D2(w0[1]), D2(w0[2]), D2(w0[3]), f);
+        for (int i = 0; i < 4; i++) { A.a[4 * i + 2] = f[i].a; A.a[4 * i + 3] = f[i].b; }
+        D2 z[4] = {D2(q[0]), D2(q[1]), D2(q[2]), D2(q[3])};
+        lateral_rhs<D2>(C.veh, z, D2(w0[0], 1.0, 0.0), D2(w0[1], 0.0, 1.0), D2(w0[2]), D2(w0[3]), f);
+        for (int i = 0; i < 4; i++) { Bc[i][0] = f[i].a; Bc[i][1] = f[i].b; }
+        lateral_rhs<D2>(C.veh, z, D2(w0[0]), D2(w0[1]), D2(w0[2], 1.0, 0.0), D2(w0[3], 0.0, 1.0), f);
+        for (int i = 0; i < 4; i++) { Bc[i][2] = f[i].a; Bc[i][3] = f[i].b; }
+        for (int i = 0; i < 4; i++) {
+            double ci = cc[i];
+            for (int j = 0; j < 4; j++) ci -= A.a[4 * i + j] * q[j] + Bc[i][j] * w0[j];
+            cc[i] = ci;                                                                    // c = f - A x - B w
+        }
+    }
+    // exp(A T) and its integrals
+    double nrm = 0.0;
+    for (int i = 0; i < 4; i++) { double sr = 0.0; for (int j = 0; j < 4; j++) sr += fabs(A.a[4 * i + j]); nrm = fmax(nrm, sr); }
+    int sq = 0; double h = T;
+    while (nrm * h > 0.25 && sq < 40) { h *= 0.5; sq++; }
+    M4d Ah, term, Ad, G0, G2;
+    for (int i = 0; i < 16; i++) { Ah.a[i] = A.a[i] * h; double e = (i % 5 == 0) ? 1.0 : 0.0; term.a[i] = e; Ad.a[i] = e; G0.a[i] = e * h; G2.a[i] = e * h * h * 0.5; }
+#pragma unroll 1
+    for (int k = 1; k <= 16; k++) {
+        term = m4mul(term, Ah);
+        const double ik = 1.0 / k, c0 = h / (k + 1), c2 = h * h / ((k + 1.0) * (k + 2.0));
+        for (int i = 0; i < 16; i++) { term.a[i] *= ik; Ad.a[i] += term.a[i]; G0.a[i] += term.a[i] * c0; G2.a[i] += term.a[i] * c2; }
+    }
+#pragma unroll 1
+    for (int i = 0; i < sq; i++) {
+        M4d AG2 = m4mul(Ad, G2), AG0 = m4mul(Ad, G0), AA = m4mul(Ad, Ad);
+        for (int j = 0; j < 16; j++) { G2.a[j] = G2.a[j] + h * G0.a[j] + AG2.a[j]; G0.a[j] += AG0.a[j]; Ad.a[j] = AA.a[j]; }
+        h *= 2.0;
+    }
+    double b0[4], bf[4], cd[4];
+    const double iT = 1.0 / T;
+    for (int i = 0; i < 4; i++) {
+        double s0 = 0.0, sf = 0.0, sc = 0.0;
+        for (int k = 0; k < 4; k++) {
+            double g0 = G0.a[4 * i + k], g1 = ramp ? G2.a[4 * i + k] * iT : 0.0;
+            s0 += (g0 - g1) * Bc[k][0]; sf += g1 * Bc[k][0];
+            double fold = cc[k] * g0;
+            for (int j = 1; j < 4; j++) fold += (g0 - g1) * Bc[k][j] * w0[j] + g1 * Bc[k][j] * (ramp ? wf[j] : 0.0);
+            sc += fold;
+        }
+        b0[i] = s0; bf[i] = sf; cd[i] = sc;
+    }
+    // ---- embedded coupled layout ----
+    QpOff o = qp_offsets(C.N);
+    double* Q = qp + (size_t)b * C.qp_len;
+    double* A6 = Q + o.A + 36 * t; double* B06 = Q + o.B0 + 12 * t; double* Bf6 = Q + o.Bf + 12 * t; double* c6 = Q + o.c + 6 * t;
+    double* P66 = abar + ((size_t)b * C.N + t) * 66;
+    for (int i = 0; i < 36; i++) A6[i] = 0.0;
+    for (int i = 0; i < 12; i++) { B06[i] = 0.0; Bf6[i] = 0.0; }
+    for (int i = 0; i < 66; i++) P66[i] = 0.0;
+    A6[0] = 1.0; A6[7] = 1.0; P66[0] = 1.0; P66[9] = 1.0; c6[0] = 0.0; c6[1] = 0.0;
+    for (int i = 0; i < 4; i++) {
+        for (int j = 0; j < 4; j++) { A6[6 * (2 + i) + 2 + j] = Ad.a[4 * i + j]; P66[8 * (2 + i) + 2 + j] = Ad.a[4 * i + j]; }
+        B06[2 * (2 + i)] = b0[i]; Bf6[2 * (2 + i)] = bf[i]; c6[2 + i] = cd[i];
+        P66[8 * (2 + i) + 6] = b0[i] + bf[i]; P66[48 + 2 * (2 + i)] = bf[i]; P66[60 + 2 + i] = cd[i];
+    }
+    // envelope and bounds (:262-272): Ux from the NEXT node's parameter, Fx from its seeded control; nothing is normalised here
+    double Uxt = n1[1], Fx = n1[7];
+    double Fxf = Fx > 0.0 ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac, Fxr = Fx > 0.0 ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
+    Envelope e = stable_limits(C.veh, Uxt, Fxf, Fxr);
+    for (int i = 0; i < 4; i++) { Q[o.H + 8 * t + 2 * i] = e.H[i][0]; Q[o.H + 8 * t + 2 * i + 1] = e.H[i][1]; Q[o.G + 4 * t + i] = e.G[i]; }
+    Q[o.dmin + t] = jmax(e.dmin, -C.veh.delta_max); Q[o.dmax + t] = jmin(e.dmax, C.veh.delta_max);
+    Q[o.fxmax + t] = 1.0;                                           // inert Fx slot: 0 <= 1 is never active
+    Q[o.ddmin + t] = -C.cp.deltadot_max * T; Q[o.ddmax + t] = C.cp.deltadot_max * T;
+    Q[o.dt + t] = T;
+    if (t == 0) {
+        Q[o.qcurr] = 0.0; Q[o.qcurr + 1] = C.ux_dummy; for (int k = 0; k < 4; k++) Q[o.qcurr + 2 + k] = q[k];
+        Q[o.ucurr] = n0[6]; Q[o.ucurr + 1] = 0.0; Q[o.M] = 0.0; Q[o.M + 1] = 0.0; Q[o.b] = 1.0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // HJI grid on device: node record = 8 floats (V, gradV[0..6]) -> one 32 B aligned read per corner, 64 B per dim-1 pair.
 // Lookup layout: CELL records.  A cell of the leading `cdims` dimensions stores its 2^cdims corner nodes contiguously, ordered by the
@@ -540,7 +701,7 @@ PG_DEV double rl(double v, int src) {
 }
 
 template <bool PROF>
-__global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* __restrict__ qp, const double* __restrict__ abar, SolveOut O, unsigned long long* __restrict__ prof) {
+__global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* __restrict__ qp, const double* __restrict__ abar, const double* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof) {
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int slot) { if (PROF) { unsigned long long now = clock64(); pc[slot] += now - tprev; tprev = now; } };
     if (PROF) tprev = clock64();
@@ -654,37 +815,11 @@ __global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* 
         __syncthreads();
     };
 
-    // ---- initial point: v = 0 roll-out; sigma just feasible; t = max(slack, tau); lambda = mu0 / t ----
     StageRows R;
     // the damped iterate (x_{s+1}, sigma) of this stage is kept in the output buffers (read-modify-write once per iteration), not in registers
     double* const SXs = O.sol_x + (size_t)b * NN * 8 + 8 * (s + 1);
     double* const SGs = O.sol_sigma + ((size_t)b * N + s) * 3;
-    forward(std::false_type{});
     double rp0 = 0.0;
-    {
-        double xs[8];
-#pragma unroll
-        for (int m = 0; m < 8; m++) xs[m] = sx[8 * (s + 1) + m];
-        double sl[NROW];
-        slacks(xs, 0.0, 0.0, 0.0, 0.0, sl);
-        const double sig0 = 0.1, tau = 1e-4;
-        double sg1 = fmax(0.0, -fmin(sl[6], sl[7])) + sig0, sg2 = fmax(0.0, -fmin(sl[8], sl[9])) + sig0, sgh = hji_on ? fmax(0.0, -sl[14]) + sig0 : 0.0;
-        slacks(xs, 0.0, sg1, sg2, sgh, sl);
-        if (act) {
-#pragma unroll
-            for (int m = 0; m < 8; m++) SXs[m] = xs[m];
-            SGs[0] = sg1; SGs[1] = sg2; SGs[2] = sgh;
-        }
-#pragma unroll
-        for (int j = 0; j < NROW; j++) {
-            bool on = act && j < nrows;
-            double tj = on ? fmax(sl[j], tau) : 1.0;
-            R.t[j] = tj; R.lam[j] = on ? C.ipm_mu0 / tj : 0.0; R.corr[j] = 0.0;
-            if (on) rp0 = fmax(rp0, tj - sl[j]);
-        }
-    }
-    stamp(5);
-    rp0 = wave_max(rp0);
     const double ntot = wave_sum(act ? (double)nrows : 0.0);
     double phi = 1.0, mu = 0.0;
     int it = 0, status = PG_MAX_ITER;
@@ -789,7 +924,9 @@ __global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* 
             double pn = qh + Fi0 * K0 + Fi1 * K1 + (li == 6 ? cj[6] : (li == 7 ? cj[7] : 0.0));
 #pragma unroll
             for (int m = 0; m < 6; m++) pn += arow[m] * cj[m];
-            Pij = pn;                                        // (k == 0: never used)
+            // symmetrise (lane (j,i) holds the transposed entry): without it the antisymmetric rounding error of the recursion is amplified by
+            // |eig(Abar)|^2 per stage and wrecks long horizons whose linearised dynamics are open-loop unstable (N = 50, saturated tires)
+            Pij = 0.5 * (pn + __shfl(pn, 8 * lj + li));      // (k == 0: never used)
             // ---- vector recursion of the predictor: y = Mc_k + p_{k+1} (Mc_k = column 10 of the augmented product, in sMT[80..87]) ----
             double yi = sMT[80 + r8] + pvec;
             double y[8];
@@ -850,7 +987,67 @@ __global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* 
         slacks(xn, vn0, sn1, sn2, snh, tplus);
     };
 
-    for (it = 0; it < C.ipm_max_iter; it++) {
+    int it_total = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+    rp0 = 0.0; phi = 1.0;
+    if (attempt == 0) {
+        // ---- first attempt: v = 0 roll-out (dynamics- and rate-feasible), sigma just feasible; t = max(slack, tau); lambda = mu0 / t ----
+        forward(std::false_type{});
+        double xs[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) xs[m] = sx[8 * (s + 1) + m];
+        double sl[NROW];
+        slacks(xs, 0.0, 0.0, 0.0, 0.0, sl);
+        const double sig0 = 0.1, tau = 1e-4;
+        double sg1 = fmax(0.0, -fmin(sl[6], sl[7])) + sig0, sg2 = fmax(0.0, -fmin(sl[8], sl[9])) + sig0, sgh = hji_on ? fmax(0.0, -sl[14]) + sig0 : 0.0;
+        slacks(xs, 0.0, sg1, sg2, sgh, sl);
+        if (act) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) SXs[m] = xs[m];
+            SGs[0] = sg1; SGs[1] = sg2; SGs[2] = sgh;
+        }
+#pragma unroll
+        for (int j = 0; j < NROW; j++) {
+            bool on = act && j < nrows;
+            double tj = on ? fmax(sl[j], tau) : 1.0;
+            R.t[j] = tj; R.lam[j] = on ? C.ipm_mu0 / tj : 0.0; R.corr[j] = 0.0;
+            if (on) rp0 = fmax(rp0, tj - sl[j]);
+        }
+    } else {
+        // ---- second attempt (only for instances the first start could not solve: long horizons whose linearised dynamics are open-loop
+        // unstable make the v = 0 roll-out explode, |e| ~ 500 m at N = 50): least-squares start.  One Newton solve with every row replaced
+        // by a unit-weight quadratic penalty (closed-loop roll-out, bounded), then a UNIFORM shift that makes every slack >= 1. ----
+#pragma unroll
+        for (int j = 0; j < NROW; j++) { R.t[j] = 1.0; R.lam[j] = (act && j < nrows) ? 1.0 : 0.0; R.corr[j] = 0.0; it_[j] = 1.0; }
+        assemble(0.0, true);
+        __syncthreads();
+        riccati_matrices();
+        forward(std::true_type{});
+        double tp[NROW];
+        newton_point(tp);
+        double tmin = 1e300;
+#pragma unroll
+        for (int j = 0; j < NROW; j++) tmin = fmin(tmin, (act && j < nrows) ? tp[j] : 1e300);
+        tmin = wave_min(tmin);
+        const double shift = tmin < 1.0 ? 1.0 - tmin : 0.0;
+        if (act) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) SXs[m] = xn[m];
+            SGs[0] = sn1; SGs[1] = sn2; SGs[2] = snh;
+        }
+#pragma unroll
+        for (int j = 0; j < NROW; j++) {
+            bool on = act && j < nrows;
+            double tj = on ? tp[j] + shift : 1.0;
+            R.t[j] = tj; R.lam[j] = on ? C.ipm_mu0 / tj : 0.0; R.corr[j] = 0.0;
+        }
+        rp0 = shift;
+    }
+    stamp(5);
+    rp0 = wave_max(rp0);
+    status = PG_MAX_ITER;
+    const int iter_cap = attempt == 0 ? C.ipm_max_iter : 3 * C.ipm_max_iter;
+    for (it = 0; it < iter_cap; it++) {
         double musum = 0.0;
 #pragma unroll
         for (int j = 0; j < NROW; j++) musum += (act && j < nrows) ? R.t[j] * R.lam[j] : 0.0;
@@ -885,6 +1082,9 @@ __global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* 
         }
         rmax = wave_max(rmax);
         double aaff = rmax > 1.0 ? 1.0 / rmax : 1.0;
+        // rounding floor: once mu is within 1e4x of the tolerance and the affine direction can no longer move (step to the boundary < 0.3),
+        // further iterations only add noise (observed on long, ill-conditioned horizons): accept the iterate as it stands
+        if (mu <= 1e4 * C.ipm_tol && aaff < 0.3 && phi * fmax(rp0, 1.0) <= C.ipm_tol) { status = PG_SOLVED; break; }
         double msum = 0.0;
 #pragma unroll
         for (int j = 0; j < NROW; j++) {
@@ -892,7 +1092,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* 
             msum += (act && j < nrows) ? (R.t[j] + aaff * dt_) * (R.lam[j] + aaff * dl_) : 0.0;
         }
         double mu_aff = wave_sum(msum) / ntot;
-        double sg = mu_aff / mu; sg = sg * sg * sg;
+        double sg = fmin(mu_aff / mu, 1.0); sg = sg * sg * sg;          // Mehrotra centring parameter, never above 1
         // ---- corrector ----
         assemble(sg * mu, false);
         __syncthreads();
@@ -926,7 +1126,16 @@ __global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* 
             SGs[0] = c1 + alpha * (sn1 - c1); SGs[1] = c2 + alpha * (sn2 - c2); SGs[2] = c3 + alpha * (snh - c3);
         }
         phi *= (1.0 - alpha);
+        if (PROF && b == C.dbg_instance && lane == 0 && it_total + it < 256) {      // trace region behind the [B][6] cycle counters: (mu, aaff, sigma, alpha) per iteration
+            double* tr = reinterpret_cast<double*>(prof + (size_t)B * 6) + 4 * (it_total + it);
+            tr[0] = mu; tr[1] = aaff; tr[2] = sg; tr[3] = alpha;
+        }
+        if (mu > 1e8 * C.ipm_mu0) break;          // diverging: give up on this start
     }
+    it_total += it;
+    if (status == PG_SOLVED || status == PG_NUMERICAL) break;
+    }   // attempts
+    it = it_total;
     stamp(0);
     if (PROF && lane == 0) { for (int i = 0; i < 6; i++) prof[(size_t)b * 6 + i] = pc[i]; }
     if (status == PG_SOLVED) {
@@ -945,6 +1154,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* 
     if (lane == 0) {
         // get_next_control: coupled_lat_long.jl:370-374 (node 2 of the reference = stage lane 0's node)
         double d = SXs[6] * C.un0, Fx = SXs[7] * C.un1;         // lane 0 is stage 0: SXs is node 2 of the reference
+        if (C.formulation == PG_DECOUPLED) Fx = nodes[((size_t)b * NN + 1) * 10 + 7];      // decoupled_lat_long.jl:275-278: Fx of the seeded node 2
         double* U = O.u_out + (size_t)b * 3;
         U[0] = d; U[1] = Fx > 0.0 ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac; U[2] = Fx > 0.0 ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
         O.status[b] = status; O.iters[b] = it; O.mu[b] = mu; O.solved[b] = 1;      // model_predictive_control.jl:76: solved = true

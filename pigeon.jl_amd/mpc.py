@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 from .trajectories import TrajectoryTube
-from .vehicles import X1, CoupledControlParams
+from .vehicles import X1, CoupledControlParams, DecoupledControlParams
 
 c_dp = C.POINTER(C.c_double)
 
@@ -34,16 +34,19 @@ class BatchedTrajectoryTrackingMPC:
     """B copies of CoupledTrajectoryTrackingMPC(vehicle, trajectory; ...) (coupled_lat_long.jl:42-60) on one MI355X."""
 
     def __init__(self, trajectory, batch_capacity, vehicle=None, control_params=None, N_short=10, N_long=20, dt_short=0.01, dt_long=0.2,
-                 use_correction_step=True, rk4_substeps=10, device=0, ipm_max_iter=40, ipm_tol=1e-12, ipm_mu0=100.0, hji_eps=0.05):
+                 use_correction_step=True, rk4_substeps=10, device=0, ipm_max_iter=40, ipm_tol=1e-12, ipm_mu0=100.0, hji_eps=0.05, formulation="coupled"):
         self.lib = _lib.load_library()
         cfg = _lib.pg_config()
-        self.lib.pg_default_config(C.byref(cfg))
+        assert formulation in ("coupled", "decoupled")
+        self.formulation = formulation
+        (self.lib.pg_default_config if formulation == "coupled" else self.lib.pg_default_config_decoupled)(C.byref(cfg))
         self.vehicle = X1() if vehicle is None else dict(vehicle)
-        self.control_params = CoupledControlParams() if control_params is None else dict(control_params)
+        default_cp = CoupledControlParams() if formulation == "coupled" else DecoupledControlParams()
+        self.control_params = default_cp if control_params is None else dict(control_params)
         for name, _ in _lib.pg_vehicle._fields_:
             setattr(cfg.vehicle, name, float(self.vehicle[name]))
         for name, _ in _lib.pg_control_params._fields_:
-            if name == "_pad":
+            if name == "_pad" or name not in self.control_params:      # the lateral formulation has no Q_ds / R_Fx / R_dFx / W_HJI / N_HJI
                 continue
             setattr(cfg.control, name, int(self.control_params[name]) if name == "N_HJI" else float(self.control_params[name]))
         cfg.N_short, cfg.N_long, cfg.dt_short, cfg.dt_long = N_short, N_long, dt_short, dt_long
@@ -257,6 +260,30 @@ class BatchedTrajectoryTrackingMPC:
 def CoupledTrajectoryTrackingMPC(vehicle, trajectory, batch_capacity=1, **kw):
     """Name of the reference constructor (coupled_lat_long.jl:42); returns the batched type."""
     return BatchedTrajectoryTrackingMPC(trajectory, batch_capacity, vehicle=vehicle, **kw)
+
+
+def DecoupledTrajectoryTrackingMPC(vehicle, trajectory, batch_capacity=1, **kw):
+    """Name of the reference constructor (decoupled_lat_long.jl:32); returns the batched type."""
+    return BatchedTrajectoryTrackingMPC(trajectory, batch_capacity, vehicle=vehicle, formulation="decoupled", **kw)
+
+
+def decoupled_canonical_active_set(N, N_short, act_masks):
+    """Signed 1-based active rows of the reference's LATERAL QP (decoupled_lat_long.jl:166-211 row order) from the per-stage masks."""
+    Ns, Nl = N_short, N - N_short
+    r_1 = 0; r_2 = 2 * N; r_3 = r_2 + N; r_4 = r_3 + 4; r_5 = r_4 + 1; r_6 = r_5 + 4 * Ns; r_7 = r_6 + 4 * Nl
+    out = []
+    for k in range(N):
+        m = int(act_masks[k]); base = r_7 + 8 * k
+        bit = lambda j: (m >> j) & 1
+        if bit(3): out.append(+(base + 0 + 1))
+        if bit(4): out.append(-(base + 1 + 1))
+        for i in range(4):
+            if bit(6 + i): out.append(+(base + 2 + i + 1))
+        if bit(10): out.append(-(r_1 + 2 * k + 0 + 1))
+        if bit(11): out.append(-(r_1 + 2 * k + 1 + 1))
+        if bit(12): out.append(+(base + 6 + 1))
+        if bit(13): out.append(-(base + 7 + 1))
+    return sorted(out, key=abs)
 
 
 def simulate(mpc: BatchedTrajectoryTrackingMPC, plant_step, q0, u0, steps, dt=0.01, t_start=None, time_offset=None):

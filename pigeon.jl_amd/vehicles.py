@@ -38,3 +38,15 @@ def CoupledControlParams(**kw):
             raise KeyError(k)
         p[k] = v
     return p
+
+
+def DecoupledControlParams(**kw):
+    """Keyword constructor of /root/reference/src/decoupled_lat_long.jl:18-30."""
+    d10 = 10 * math.pi / 180
+    p = dict(V_min=1.0, V_max=15.0, k_V=10 / 4 / 100, k_s=10 / 4 / 10000, deltadot_max=0.344, Q_dpsi=1 / d10 ** 2, Q_e=1.0, W_beta=50 / d10, W_r=50.0,
+             R_delta=0.0, R_ddelta=0.01 / d10 ** 2)
+    for k, v in kw.items():
+        if k not in p:
+            raise KeyError(k)
+        p[k] = v
+    return p

@@ -9,8 +9,9 @@ traj = pkg.load_path_fixture("skidpadoval")
 mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B)
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345)
 mpc.step_(state, control, t0, time_offset=toff)
-out = np.zeros((B, 6), dtype=np.uint64)
+out = np.zeros(B * 6 + 1024, dtype=np.uint64)
 rc = mpc.lib.pg_debug_solve_cycles(mpc.h, out.ctypes.data_as(C.c_void_p)); assert rc == 0
+out = out[:B * 6].reshape(B, 6)
 st, it, act, mu = mpc.solve_info()
 names = ["stage(assemble/step)", "sync", "matrix pass", "vector passes", "forward passes", "prologue"]
 tot = out.sum(1).astype(float)
