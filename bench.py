@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hji", action="store_true")
+    ap.add_argument("--no-decoupled", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -129,6 +130,24 @@ def main():
     st, it, act, mu = mpc.solve_info()
     ok = int((st == pkg.SOLVED).sum())
 
+    # BASELINE config 5: decoupled (lateral) MPC, N = 50 (N_short = 10, N_long = 40), same batch, cold every step (that formulation has no warm branch)
+    dec = None
+    if rank == 0 and not args.no_decoupled:
+        mpc_d = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, device=local)
+        mpc_d.set_stream(torch.cuda.current_stream().cuda_stream)
+        mpc_d.set_inputs_dev(B, d_state.data_ptr(), d_control.data_ptr(), d_t0.data_ptr(), None, d_toff.data_ptr())
+        for _ in range(2):
+            mpc_d.step_dev(u_out.data_ptr())
+        torch.cuda.synchronize(); td = time.perf_counter()
+        for _ in range(args.steps):
+            mpc_d.step_dev(u_out.data_ptr())
+        torch.cuda.synchronize(); td = time.perf_counter() - td
+        std, itd, _, _ = mpc_d.solve_info()
+        dec = {"workload": f"configs[4]: Batch={B} decoupled MPC, N=50 (no wall rows: not in the reference snapshot), fp64", "value": B * args.steps / td, "unit": "solves/s",
+               "ms_per_step": 1e3 * td / args.steps, "phase_ms": [float(v) for v in mpc_d.phase_ms()], "solved": f"{int((std == pkg.SOLVED).sum())}/{B}",
+               "ipm_iters_mean": float(np.mean(itd))}
+        mpc_d.close()
+
     # HJI value/gradient lookup (the bandwidth-bound kernel of the path): 2^20 random in-grid relative states against the config-3 grid
     hji = None
     if rank == 0 and not args.no_hji:
@@ -185,6 +204,8 @@ def main():
         }
         if hji is not None:
             line["hji_lookup"] = hji
+        if dec is not None:
+            line["decoupled_n50"] = dec
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, traj, state, control, t0, toff)
         print(json.dumps(line), flush=True)
