@@ -28,7 +28,7 @@ struct pg_handle {
     // HJI grid
     HjiView hv; float *d_knots = nullptr, *d_hnodes = nullptr, *d_hcells = nullptr; bool has_hji = false;
     hipEvent_t ev[4]; bool ev_ok = false; float phase_ms[3] = {0, 0, 0}; bool timing_valid = false;
-    size_t solve_lds = 0;
+    size_t solve_lds = 0; bool solve_ring = false;
 };
 
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return PG_ERR_HIP; } } while (0)
@@ -133,12 +133,16 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     }
     for (int i = 0; i < 4; i++) if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_create_error = "hipEventCreate failed"; free_all(h); delete h; return PG_ERR_HIP; }
     h->ev_ok = true;
-    h->solve_lds = (size_t)(4 * 66 + 10 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 64 + 88 + 8 + 64 + 2) * sizeof(double);
+    // horizons up to 32 intervals keep their dynamics blocks resident in LDS (one pass over the QP data); longer ones stream them through a 4-slot ring
+    h->solve_ring = N > 32;
+    h->solve_lds = (size_t)((h->solve_ring ? 4 : N) * 66 + 10 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 64 + 88 + 8 + 64 + 2) * sizeof(double);
     if (h->solve_lds > 160 * 1024) { g_create_error = "horizon too long for LDS staging"; free_all(h); delete h; return PG_ERR_INVALID; }
     if (h->solve_lds > 48 * 1024)
     {
-        (void)hipFuncSetAttribute((const void*)k_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
-        (void)hipFuncSetAttribute((const void*)k_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+        (void)hipFuncSetAttribute((const void*)k_solve<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+        (void)hipFuncSetAttribute((const void*)k_solve<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+        (void)hipFuncSetAttribute((const void*)k_solve<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+        (void)hipFuncSetAttribute((const void*)k_solve<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
     }
     *out = h;
     return PG_OK;
@@ -324,7 +328,8 @@ int pg_update_qp(pg_handle* h) {
 int pg_solve(pg_handle* h) {
     int rc = check_ready(h); if (rc) return rc;
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved};
-    hipLaunchKernelGGL(k_solve<false>, dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, (unsigned long long*)nullptr);
+    if (h->solve_ring) hipLaunchKernelGGL((k_solve<false, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, (unsigned long long*)nullptr);
+    else hipLaunchKernelGGL((k_solve<false, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, (unsigned long long*)nullptr);
     LAUNCH_CHECK(h);
     return PG_OK;
 }
@@ -336,7 +341,8 @@ int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     HIPCHK(h, hipMalloc((void**)&d, ((size_t)h->B * 6 + 1024) * 8));
     HIPCHK(h, hipMemset(d, 0, ((size_t)h->B * 6 + 1024) * 8));
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved};
-    hipLaunchKernelGGL(k_solve<true>, dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, d);
+    if (h->solve_ring) hipLaunchKernelGGL((k_solve<true, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, d);
+    else hipLaunchKernelGGL((k_solve<true, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, d);
     LAUNCH_CHECK(h);
     HIPCHK(h, hipMemcpy(out, d, ((size_t)h->B * 6 + 1024) * 8, hipMemcpyDeviceToHost));      // out: [B][6] cycles + 1024-double trace of PG_DEBUG_INSTANCE
     (void)hipFree(d);

@@ -700,8 +700,8 @@ PG_DEV double rl(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-template <bool PROF>
-__global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* __restrict__ qp, const double* __restrict__ abar, const double* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof) {
+template <bool PROF, bool RING>
+__global__ __launch_bounds__(64, RING ? 2 : 1) void k_solve(DevCfg C, int B, const double* __restrict__ qp, const double* __restrict__ abar, const double* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof) {
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int slot) { if (PROF) { unsigned long long now = clock64(); pc[slot] += now - tprev; tprev = now; } };
     if (PROF) tprev = clock64();
@@ -710,8 +710,8 @@ __global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* 
     extern __shared__ double lds[];
     // The dynamics blocks are NOT resident: each pass streams them stage by stage from L2 through a 4-slot LDS ring
     // (slot = 66 doubles: rows 0..5 of Abar_k = [A | B0+Bf] (48), rows 0..5 of Bbar_k = Bf (12), cbar_k = c (6)); rows 6,7 are [0 I] / I / 0.
-    double* sRing = lds;                 // [4][66]
-    double* sQ = sRing + 4 * 66;         // [NN][10]: diagonal[8] (with (Uy,Uy),(r,r) at 2,3), (Uy,r) off-diagonal, (delta,Fx) off-diagonal
+    double* sRing = lds;                 // RING: [4][66] slots; otherwise all N stage blocks resident: [N][66]
+    double* sQ = sRing + (RING ? 4 : N) * 66;         // [NN][10]: diagonal[8] (with (Uy,Uy),(r,r) at 2,3), (Uy,r) off-diagonal, (delta,Fx) off-diagonal
     double* sq = sQ + 10 * NN;           // [NN][8]
     double* sR = sq + 8 * NN;            // [N][2]   diagonal of Rhat
     double* sr = sR + 2 * N;             // [N][2]
@@ -733,12 +733,15 @@ __global__ __launch_bounds__(64, 2) void k_solve(DevCfg C, int B, const double* 
     const double2* gA = reinterpret_cast<const double2*>(abar + (size_t)b * N * 66);
     const int rlane = lane < 33 ? lane : 0;
     double2 ring_pre;
-    auto ring_slot = [&](int k) -> double* { return sRing + (k & 3) * 66; };
+    auto ring_slot = [&](int k) -> double* { return sRing + (RING ? (k & 3) : k) * 66; };
     auto ring_load = [&](int k) { int kk = k < 0 ? 0 : (k >= N ? N - 1 : k); ring_pre = gA[kk * 33 + rlane]; };
     auto ring_put = [&](int k) { double2* dst = lane < 33 ? reinterpret_cast<double2*>(ring_slot(k)) + lane : reinterpret_cast<double2*>(sDum) + (lane & 31); *dst = ring_pre; };
     // prime(k0, dir): block k0 lands in the ring, block k0+dir is in flight.  step(k, dir) at the top of stage k: block k+dir lands, k+2dir takes off.
-    auto ring_prime = [&](int k0, int dir) { ring_load(k0); ring_put(k0); ring_load(k0 + dir); };
-    auto ring_step = [&](int k, int dir) { ring_put(k + dir); ring_load(k + 2 * dir); };
+    auto ring_prime = [&](int k0, int dir) { if (RING) { ring_load(k0); ring_put(k0); ring_load(k0 + dir); } };
+    auto ring_step = [&](int k, int dir) { if (RING) { ring_put(k + dir); ring_load(k + 2 * dir); } };
+    if (!RING) {      // short horizons: every stage block is read from HBM exactly once and stays in LDS (66 N doubles = 15.8 KB at N = 30)
+        for (int i = lane; i < 33 * N; i += 64) reinterpret_cast<double2*>(sRing)[i] = gA[i];
+    }
     if (lane < 2) sZero[lane] = 0.0;
     if (lane < 8) sx0[lane] = lane < 6 ? Q[o.qcurr + lane] : Q[o.ucurr + lane - 6];
 
