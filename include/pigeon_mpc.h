@@ -132,6 +132,14 @@ int pg_step(pg_handle* h, int32_t B, const double* state, const double* control,
 /* the four compute phases + control extraction on the inputs last installed; nothing crosses PCIe.  u_out_dev may be NULL. */
 int pg_step_dev(pg_handle* h, double* u_out_dev);
 
+/* simulate(mpc, q0, u0, dt)  src/model_predictive_control.jl:80-100 for every instance, entirely on the device (no host round trip between
+ * steps): per step  record -> the four compute calls -> state = propagate(dynamics, state, StepControl(dt, old control)) -> control = get_next_control
+ * -> t += dt.  Starts from the inputs last installed (pg_set_inputs*: state, control, t0, time_offset) and leaves the final ones there
+ * (pg_get_state reads them).  state_hist_dev [steps][B][6] / control_hist_dev [steps][B][3] may be NULL.  Asynchronous on the handle's stream. */
+int pg_simulate_dev(pg_handle* h, int32_t steps, double dt, double* state_hist_dev, double* control_hist_dev);
+/* current device-resident inputs: state [B][6], control [B][3], t0 [B] (host pointers, any may be NULL) */
+int pg_get_state(pg_handle* h, double* state, double* control, double* t0);
+
 /* stream to launch on (hipStream_t as void*); NULL = the null stream */
 int pg_set_stream(pg_handle* h, void* hip_stream);
 int pg_synchronize(pg_handle* h);

@@ -374,6 +374,31 @@ int pg_step_dev(pg_handle* h, double* u_out_dev) {
     h->timing_valid = true;
     return PG_OK;
 }
+static int d2h(pg_handle* h, void* dst, const void* src, size_t bytes) {
+    if (!dst) return PG_OK;
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    return PG_OK;
+}
+int pg_simulate_dev(pg_handle* h, int32_t steps, double dt, double* state_hist_dev, double* control_hist_dev) {
+    int rc = check_ready(h); if (rc) return rc;
+    REQUIRE(h, steps >= 1 && dt > 0.0, "pg_simulate_dev: steps >= 1 and dt > 0 required");
+    const int B = h->B;
+    for (int k = 0; k < steps; k++) {
+        if (state_hist_dev) HIPCHK(h, hipMemcpyAsync(state_hist_dev + (size_t)k * B * 6, h->d_state, (size_t)B * 6 * 8, hipMemcpyDeviceToDevice, h->stream));      // push!(qs, state) :88
+        if (control_hist_dev) HIPCHK(h, hipMemcpyAsync(control_hist_dev + (size_t)k * B * 3, h->d_control, (size_t)B * 3 * 8, hipMemcpyDeviceToDevice, h->stream)); // push!(us, control) :89
+        if ((rc = pg_compute_time_steps(h)) || (rc = pg_compute_linearization_nodes(h)) || (rc = pg_update_qp(h)) || (rc = pg_solve(h))) return rc;          // :90-93
+        hipLaunchKernelGGL(k_advance, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, dt, h->d_state, h->d_control, h->d_u, h->d_t0);                  // :94-95
+        LAUNCH_CHECK(h);
+    }
+    return PG_OK;
+}
+int pg_get_state(pg_handle* h, double* state, double* control, double* t0) {
+    int rc = check_ready(h); if (rc) return rc;
+    const size_t B = h->B;
+    if ((rc = d2h(h, state, h->d_state, B * 6 * 8)) || (rc = d2h(h, control, h->d_control, B * 3 * 8)) || (rc = d2h(h, t0, h->d_t0, B * 8))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PG_OK;
+}
 int pg_get_phase_ms(pg_handle* h, float out3[3]) {
     if (!h || !out3) return PG_ERR_INVALID;
     if (!h->timing_valid) { h->err = "no pg_step_dev recorded yet"; return PG_ERR_STATE; }
@@ -393,11 +418,6 @@ int pg_step(pg_handle* h, int32_t B, const double* state, const double* control,
 }
 
 // ---- read-backs --------------------------------------------------------------------------------------------------
-static int d2h(pg_handle* h, void* dst, const void* src, size_t bytes) {
-    if (!dst) return PG_OK;
-    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
-    return PG_OK;
-}
 int pg_get_time_steps(pg_handle* h, double* ts, double* dt, double* prev_ts) {
     int rc = check_ready(h); if (rc) return rc;
     const size_t B = h->B; const DevCfg& C = h->dc;

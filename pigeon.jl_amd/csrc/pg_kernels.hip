@@ -294,6 +294,42 @@ __global__ __launch_bounds__(256) void k_limits(DevCfg C, int B, const double* _
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Closed-loop plant step of `simulate` (model_predictive_control.jl:94-95), lane = instance:
+//   state   <- propagate(dynamics, state, StepControl(dt, BicycleControl2(current_control)))   (RK4, nsub sub-steps, world-frame BicycleModel
+//              through the actuator limits: vehicle_dynamics.jl:111-135,293-314)
+//   control <- get_next_control(mpc)     (one-step actuation delay: the state moves with the OLD control)
+//   t       <- t + dt
+__global__ __launch_bounds__(64) void k_advance(DevCfg C, int B, double dtp, double* __restrict__ state, double* __restrict__ control, const double* __restrict__ u_next,
+                                                double* __restrict__ t0) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double* q = state + (size_t)b * 6; double* u = control + (size_t)b * 3;
+    double x[6] = {q[0], q[1], q[2], q[3], q[4], q[5]};
+    const double d = u[0], Fx = u[1] + u[2];
+    const int nsub = C.nsub; const double h = dtp / nsub;
+    auto rhs = [&](const double* y, double* o) {
+        double s, c; sincos(y[2], &s, &c);
+        o[0] = -y[3] * s - y[4] * c; o[1] = y[3] * c - y[4] * s; o[2] = y[5];          // psi measured from North (:127-129)
+        world_body_rhs<double>(C.veh, y[3], y[4], y[5], d, Fx, o[3], o[4], o[5]);
+    };
+#pragma unroll 1
+    for (int i = 0; i < nsub; i++) {
+        double k1[6], k2[6], k3[6], k4[6], y[6];
+        rhs(x, k1);
+        for (int k = 0; k < 6; k++) y[k] = x[k] + k1[k] * (h * 0.5);
+        rhs(y, k2);
+        for (int k = 0; k < 6; k++) y[k] = x[k] + k2[k] * (h * 0.5);
+        rhs(y, k3);
+        for (int k = 0; k < 6; k++) y[k] = x[k] + k3[k] * h;
+        rhs(y, k4);
+        for (int k = 0; k < 6; k++) x[k] += (k1[k] + 2.0 * k2[k] + 2.0 * k3[k] + k4[k]) * (h / 6.0);
+    }
+    for (int k = 0; k < 6; k++) q[k] = x[k];
+    u[0] = u_next[(size_t)b * 3]; u[1] = u_next[(size_t)b * 3 + 1]; u[2] = u_next[(size_t)b * 3 + 2];
+    t0[b] += dtp;
+}
+
 // ==================================================================================================================
 // Decoupled (lateral) formulation: decoupled_lat_long.jl.  The lateral QP (state (Uy, r, dpsi, e), input delta) is EMBEDDED in the
 // 8-state stage structure k_solve works on: x = (0, Ux_dummy, Uy, r, dpsi, e, delta, 0) with identity dynamics, zero cost and

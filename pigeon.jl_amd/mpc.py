@@ -162,6 +162,21 @@ class BatchedTrajectoryTrackingMPC:
     def step_dev(self, u_out_ptr=None):
         self._chk(self.lib.pg_step_dev(self.h, C.c_void_p(u_out_ptr) if u_out_ptr else None), "pg_step_dev")
 
+    def simulate_(self, steps, dt=0.01, record=False):
+        """simulate (model_predictive_control.jl:80-100) on the device from the inputs last installed; returns (state, control, t) after `steps`
+        steps and, with record=True, the histories qs [steps][B][6], us [steps][B][3] (the values pushed at :88-89)."""
+        import ctypes as C_
+        qh = uh = None; dq = du = None
+        if record:
+            import torch
+            dq = torch.empty(steps, self.B, 6, dtype=torch.float64, device=f"cuda:{self.cfg.device}"); du = torch.empty(steps, self.B, 3, dtype=torch.float64, device=f"cuda:{self.cfg.device}")
+        self._chk(self.lib.pg_simulate_dev(self.h, steps, C_.c_double(dt), C_.c_void_p(dq.data_ptr()) if record else None, C_.c_void_p(du.data_ptr()) if record else None), "pg_simulate_dev")
+        s = np.zeros((self.B, 6)); c = np.zeros((self.B, 3)); t = np.zeros(self.B)
+        self._chk(self.lib.pg_get_state(self.h, _p(s), _p(c), _p(t)), "pg_get_state")
+        if record:
+            qh = dq.cpu().numpy(); uh = du.cpu().numpy()
+        return s, c, t, qh, uh
+
     def synchronize(self):
         self._chk(self.lib.pg_synchronize(self.h), "pg_synchronize")
 

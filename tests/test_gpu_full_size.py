@@ -101,3 +101,26 @@ def test_ragged_and_tiny_batches(pkg, skidpad):
     assert np.array_equal(up, ub[:37])
     with pytest.raises(pkg.PigeonError):
         big.step_(np.zeros((71, 6)), np.zeros((71, 3)), np.zeros(71))            # B > capacity is refused, not truncated
+
+
+def test_closed_loop_on_device_matches_oracle(pkg, oracle_mod, skidpad):
+    """pg_simulate_dev (simulate, model_predictive_control.jl:80-100: warm branch, one-step actuation delay, RK4 plant) against the oracle's
+    closed loop with its exact solver, 40 steps x 24 instances; the two loops only share inputs."""
+    Bc, steps = 24, 40
+    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, Bc, seed=77, traj_mode=False)
+    mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, Bc)
+    mpc.set_inputs(state, control, t0, time_offset=toff)
+    s, c, t, qh, uh = mpc.simulate_(steps, dt=0.01, record=True)
+    orc = make_oracle(oracle_mod, skidpad)
+    q = state.copy(); u = control.copy(); tt = t0.copy()
+    un = np.array([orc.u_norm[0], orc.u_norm[1], orc.u_norm[1]])
+    for k in range(steps):
+        assert np.max(np.abs(qh[k] - q) / np.maximum(1.0, np.abs(q))) < 1e-5, k
+        assert np.max(np.abs(uh[k] - u) / un) < 1e-5, k
+        unext, _, it, st, _ = orc.step_batch(q, u, tt, time_offsets=toff, solver=0)
+        assert np.all(st == 1)
+        q = np.stack([orc.plant_step(q[b], u[b], 0.01) for b in range(Bc)])
+        u = unext; tt = tt + 0.01
+    assert np.max(np.abs(s - q) / np.maximum(1.0, np.abs(q))) < 1e-5 and np.max(np.abs(c - u) / un) < 1e-5 and np.allclose(t, tt)
+    st, it, act, mu = mpc.solve_info()
+    assert np.all(st == 1)
