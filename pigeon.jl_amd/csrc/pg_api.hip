@@ -285,11 +285,17 @@ int pg_compute_linearization_nodes(pg_handle* h) {
     const int B = h->B;
     hipLaunchKernelGGL(k_project, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep);
     LAUNCH_CHECK(h);
-    if (h->dc.formulation == PG_DECOUPLED)
-        hipLaunchKernelGGL(k_nodes_dec, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_sep, h->d_ts, h->d_dt, h->d_nodes);
-    else
-        hipLaunchKernelGGL(k_nodes, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
+    const bool staged = h->traj_L <= 2048;
+    const size_t traj_lds = staged ? (size_t)2 * h->traj_L * sizeof(double) : 0;
+    const dim3 grid((B + 63) / 64), block(64);
+    if (h->dc.formulation == PG_DECOUPLED) {
+        auto kern = staged ? k_nodes_dec<true> : k_nodes_dec<false>;
+        hipLaunchKernelGGL(kern, grid, block, traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_sep, h->d_ts, h->d_dt, h->d_nodes);
+    } else {
+        auto kern = staged ? k_nodes<true> : k_nodes<false>;
+        hipLaunchKernelGGL(kern, grid, block, traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
                            h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes);
+    }
     LAUNCH_CHECK(h);
     return PG_OK;
 }

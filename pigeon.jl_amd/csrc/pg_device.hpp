@@ -20,15 +20,22 @@ PG_DEV D2 operator+(D2 x, D2 y) { return D2(x.v + y.v, x.a + y.a, x.b + y.b); }
 PG_DEV D2 operator-(D2 x, D2 y) { return D2(x.v - y.v, x.a - y.a, x.b - y.b); }
 PG_DEV D2 operator-(D2 x) { return D2(-x.v, -x.a, -x.b); }
 PG_DEV D2 operator*(D2 x, D2 y) { return D2(x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b); }
-PG_DEV D2 operator/(D2 x, D2 y) { double inv = 1.0 / y.v, q = x.v * inv; return D2(q, (x.a - q * y.a) * inv, (x.b - q * y.b) * inv); }
+// reciprocal: v_rcp_f64 seed + two Newton steps (~1 ulp); the IEEE division sequence costs ~5x more issue slots
+PG_DEV double frcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0); r = fma(r, e, r);
+    e = fma(-x, r, 1.0); r = fma(r, e, r);
+    return r;
+}
+PG_DEV D2 operator/(D2 x, D2 y) { double inv = frcp(y.v), q = x.v * inv; return D2(q, (x.a - q * y.a) * inv, (x.b - q * y.b) * inv); }
 PG_DEV D2 operator+(D2 x, double y) { return D2(x.v + y, x.a, x.b); }
 PG_DEV D2 operator+(double y, D2 x) { return D2(x.v + y, x.a, x.b); }
 PG_DEV D2 operator-(D2 x, double y) { return D2(x.v - y, x.a, x.b); }
 PG_DEV D2 operator-(double y, D2 x) { return D2(y - x.v, -x.a, -x.b); }
 PG_DEV D2 operator*(D2 x, double y) { return D2(x.v * y, x.a * y, x.b * y); }
 PG_DEV D2 operator*(double y, D2 x) { return D2(x.v * y, x.a * y, x.b * y); }
-PG_DEV D2 operator/(D2 x, double y) { double inv = 1.0 / y; return D2(x.v * inv, x.a * inv, x.b * inv); }
-PG_DEV D2 operator/(double x, D2 y) { double inv = 1.0 / y.v, q = x * inv; return D2(q, -q * y.a * inv, -q * y.b * inv); }
+PG_DEV D2 operator/(D2 x, double y) { double inv = frcp(y); return D2(x.v * inv, x.a * inv, x.b * inv); }
+PG_DEV D2 operator/(double x, D2 y) { double inv = frcp(y.v), q = x * inv; return D2(q, -q * y.a * inv, -q * y.b * inv); }
 
 PG_DEV double val(double x) { return x; }
 PG_DEV double val(D2 x) { return x.v; }
@@ -39,7 +46,7 @@ PG_DEV void sincos_(D2 x, D2& s, D2& c) { double sv, cv; sincos(x.v, &sv, &cv); 
 PG_DEV double tan_(double x) { return tan(x); }
 PG_DEV D2 tan_(D2 x) { double t = tan(x.v); return chain(x, t, 1.0 + t * t); }
 PG_DEV double sqrt_(double x) { return sqrt(x); }
-PG_DEV D2 sqrt_(D2 x) { double s = sqrt(x.v); return chain(x, s, 0.5 / s); }
+PG_DEV D2 sqrt_(D2 x) { double s = sqrt(x.v); return chain(x, s, 0.5 * frcp(s)); }
 PG_DEV double atan2_(double y, double x) { return atan2(y, x); }
 PG_DEV D2 atan2_(D2 y, D2 x) { double inv = 1.0 / (x.v * x.v + y.v * y.v); return D2(atan2(y.v, x.v), (x.v * y.a - y.v * x.a) * inv, (x.v * y.b - y.v * x.b) * inv); }
 PG_DEV double abs_(double x) { return fabs(x); }

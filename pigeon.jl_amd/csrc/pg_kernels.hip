@@ -104,12 +104,21 @@ PG_DEV void put_node(double* __restrict__ ND, int i, const NodeRec& r) {
     double* o = ND + i * 10;
     o[0] = r.q0; o[1] = r.q1; o[2] = r.q2; o[3] = r.q3; o[4] = r.q4; o[5] = r.q5; o[6] = r.u0; o[7] = r.u1; o[8] = r.pV; o[9] = r.pK;
 }
-__global__ __launch_bounds__(64) void k_nodes(DevCfg C, int B, const double* __restrict__ state, const double* __restrict__ control, const double* __restrict__ toff,
+template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, int B, const double* __restrict__ state, const double* __restrict__ control, const double* __restrict__ toff,
                         const int* __restrict__ solved, const double* __restrict__ sep, const double* __restrict__ ts, const double* __restrict__ dt,
                         const double* __restrict__ prev_ts, const double* __restrict__ prev_x, double* __restrict__ nodes) {
+    // the two searched channels (t, s) are staged in LDS when they fit: every node costs three binary searches whose ~10 dependent probes each
+    // would otherwise pay L2 latency (the kernel is a 64-wave serial recurrence: latency, not bandwidth, is its whole cost)
+    extern __shared__ double sh_traj[];
+    TrajView T = C.traj;
+    if constexpr (STAGED) {                                 // compile-time so the searches compile to ds_read, not flat loads
+        for (int i = threadIdx.x; i < T.L; i += blockDim.x) { sh_traj[i] = C.traj.t[i]; sh_traj[T.L + i] = C.traj.s[i]; }
+        __syncthreads();
+        T.t = sh_traj; T.s = sh_traj + T.L;
+    }
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const TrajView& T = C.traj; const pg_vehicle& P = C.veh;
+    const pg_vehicle& P = C.veh;
     const double* q0 = state + (size_t)b * 6; const double* u0 = control + (size_t)b * 3;
     const double* TS = ts + (size_t)b * C.NN; const double* DT = dt + (size_t)b * C.N;
     double* ND = nodes + (size_t)b * C.NN * 10;
@@ -336,11 +345,18 @@ __global__ __launch_bounds__(64) void k_advance(DevCfg C, int B, double dtp, dou
 // never-active bounds on the three inert slots, so the same solve kernel serves both formulations (the inert slots are exactly
 // decoupled from the rest, the optimum of the embedded problem restricted to the live slots IS the lateral optimum).
 // Node record (10 doubles): (0, Ux parameter, Uy, r, dpsi, e, delta, Fx, 0, kappa).
-__global__ __launch_bounds__(64) void k_nodes_dec(DevCfg C, int B, const double* __restrict__ state, const double* __restrict__ control, const double* __restrict__ toff,
+template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg C, int B, const double* __restrict__ state, const double* __restrict__ control, const double* __restrict__ toff,
                                                   const double* __restrict__ sep, const double* __restrict__ ts, const double* __restrict__ dt, double* __restrict__ nodes) {
+    extern __shared__ double sh_traj[];
+    TrajView T = C.traj;
+    if constexpr (STAGED) {                                 // compile-time so the searches compile to ds_read, not flat loads
+        for (int i = threadIdx.x; i < T.L; i += blockDim.x) { sh_traj[i] = C.traj.t[i]; sh_traj[T.L + i] = C.traj.s[i]; }
+        __syncthreads();
+        T.t = sh_traj; T.s = sh_traj + T.L;
+    }
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const TrajView& T = C.traj; const pg_vehicle& P = C.veh;
+    const pg_vehicle& P = C.veh;
     const double* q0 = state + (size_t)b * 6; const double* u0 = control + (size_t)b * 3;
     const double* TS = ts + (size_t)b * C.NN; const double* DT = dt + (size_t)b * C.N;
     double* ND = nodes + (size_t)b * C.NN * 10;
@@ -719,15 +735,6 @@ PG_DEV double wave_sum(double v) {
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
     return v;
-}
-
-// reciprocal: v_rcp_f64 seed + two Newton steps (~1 ulp; the IEEE division sequence costs ~5x more issue slots and the
-// interior-point internals only need a consistent, accurate-to-rounding scaling)
-PG_DEV double frcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, r, 1.0); r = fma(r, e, r);
-    e = fma(-x, r, 1.0); r = fma(r, e, r);
-    return r;
 }
 
 // broadcast of lane `src` (compile-time constant) to the whole wave through SGPRs: no LDS, no barrier

@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_full_size.py -m gpu -x -q -k closed_loop 2>&1 | tail -12
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-hji --no-decoupled > gpurun_out/bench.log 2>&1
+tail -1 gpurun_out/bench.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ['value','ms_per_step','phase_ms','warm_value','solved','ipm_iters_mean']})"
