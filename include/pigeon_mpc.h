@@ -100,6 +100,15 @@ int pg_get_u_normalization(const pg_handle* h, double out[2]);
 int pg_set_trajectory(pg_handle* h, int32_t L, const double* t, const double* s, const double* V, const double* A, const double* E,
                       const double* N, const double* psi, const double* kappa, const double* theta, const double* phi,
                       const double* edge_L, const double* edge_R);
+/* Batched form of the same assignment when instances track DIFFERENT references (one controller per (x0, reference trajectory) pair,
+ * src/model_predictive_control.jl:36 `trajectory::TrajectoryTube{T}` is a per-controller field): install a library of n_traj tubes once,
+ * then select one per instance.  channels is [n_traj][10][Lmax] doubles, channel order t, s, V, A, E, N, psi, kappa, edge_L, edge_R
+ * (src/trajectories.jl:8-21); L[k] <= Lmax is the node count of trajectory k (the tail of a shorter one is ignored).
+ * pg_set_trajectory(...) == a library of one; installing a library drops any previous index. */
+int pg_set_trajectories(pg_handle* h, int32_t n_traj, int32_t Lmax, const int32_t* L, const double* channels);
+/* index[b] in [0, n_traj): the trajectory instance b tracks.  Persistent across steps until the library or the index is replaced.
+ * With n_traj > 1 the phase calls return PG_ERR_STATE until an index covering the current batch is installed. */
+int pg_set_trajectory_index(pg_handle* h, int32_t B, const int32_t* index);
 
 /* mpc.HJI_cache = HJICache(grid_knots, V_raw, gradV_raw)  src/HJI_computation.jl:26-57.  V is column-major (dim 1 fastest),
  * gradV is 7 floats per node in the same node order.  Without a grid the safety row is inactive (M = 0, b = 1). */

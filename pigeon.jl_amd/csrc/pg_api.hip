@@ -18,7 +18,7 @@ struct pg_handle {
     hipStream_t stream = nullptr;
     std::string err;
     // device buffers
-    double *d_traj = nullptr; int traj_L = 0;
+    double *d_traj = nullptr; int traj_L = 0; int *d_traj_len = nullptr, *d_traj_idx = nullptr; int traj_idx_B = 0;
     double *d_state = nullptr, *d_control = nullptr, *d_t0 = nullptr, *d_other = nullptr, *d_toff = nullptr;
     int* d_solved = nullptr;
     double *d_ts = nullptr, *d_dt = nullptr, *d_prev_ts = nullptr, *d_sep = nullptr, *d_nodes = nullptr, *d_qp = nullptr;
@@ -74,7 +74,7 @@ int pg_default_config_decoupled(pg_config* c) {
 }
 
 static void free_all(pg_handle* h) {
-    void* ptrs[] = {h->d_traj, h->d_state, h->d_control, h->d_t0, h->d_other, h->d_toff, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
+    void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_state, h->d_control, h->d_t0, h->d_other, h->d_toff, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
                     h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_abar, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->ev_ok) for (int i = 0; i < 4; i++) (void)hipEventDestroy(h->ev[i]);
@@ -155,21 +155,57 @@ int pg_qp_len(const pg_handle* h) { return h ? h->dc.qp_len : PG_ERR_INVALID; }
 int pg_set_stream(pg_handle* h, void* s) { if (!h) return PG_ERR_INVALID; h->stream = (hipStream_t)s; return PG_OK; }
 int pg_synchronize(pg_handle* h) { if (!h) return PG_ERR_INVALID; HIPCHK(h, hipStreamSynchronize(h->stream)); return PG_OK; }
 
+// install a library: channels[n_traj][10][Lmax] (t, s, V, A, E, N, psi, kappa, edge_L, edge_R), L[k] valid nodes of trajectory k
+static int install_trajectories(pg_handle* h, int n_traj, int Lmax, const int32_t* L, const double* channels) {
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->d_traj) { (void)hipFree(h->d_traj); h->d_traj = nullptr; }
+    if (h->d_traj_len) { (void)hipFree(h->d_traj_len); h->d_traj_len = nullptr; }
+    if (h->d_traj_idx) { (void)hipFree(h->d_traj_idx); h->d_traj_idx = nullptr; }
+    h->traj_idx_B = 0;
+    const size_t stride = (size_t)10 * Lmax;
+    HIPCHK(h, hipMalloc((void**)&h->d_traj, (size_t)n_traj * stride * sizeof(double)));
+    HIPCHK(h, hipMemcpy(h->d_traj, channels, (size_t)n_traj * stride * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMalloc((void**)&h->d_traj_len, (size_t)n_traj * sizeof(int)));
+    HIPCHK(h, hipMemcpy(h->d_traj_len, L, (size_t)n_traj * sizeof(int), hipMemcpyHostToDevice));
+    TrajView& T = h->dc.traj; T.L = L[0];
+    const double* p = h->d_traj; const size_t c = (size_t)Lmax;
+    T.t = p; T.s = p + c; T.V = p + 2 * c; T.A = p + 3 * c; T.E = p + 4 * c; T.N = p + 5 * c; T.psi = p + 6 * c; T.kappa = p + 7 * c; T.edge_L = p + 8 * c; T.edge_R = p + 9 * c;
+    h->dc.n_traj = n_traj; h->dc.traj_stride = (long)stride; h->dc.traj_len = h->d_traj_len; h->dc.traj_idx = nullptr;
+    h->traj_L = L[0];
+    return PG_OK;
+}
+
 int pg_set_trajectory(pg_handle* h, int32_t L, const double* t, const double* s, const double* V, const double* A, const double* E, const double* N,
                       const double* psi, const double* kappa, const double* theta, const double* phi, const double* edge_L, const double* edge_R) {
     if (!h) return PG_ERR_INVALID;
     REQUIRE(h, L >= 2 && t && s && V && A && E && N && psi && kappa, "pg_set_trajectory: need L >= 2 and the eight read channels");
-    (void)theta; (void)phi; (void)edge_L; (void)edge_R;   // carried by TrajectoryTube (trajectories.jl:17-20) but read by nothing on this path
+    (void)theta; (void)phi;                                   // carried by TrajectoryTube (trajectories.jl:17-18) but read by nothing on this path
+    std::vector<double> pack((size_t)10 * L);
+    const double* src[8] = {t, s, V, A, E, N, psi, kappa};
+    for (int k = 0; k < 8; k++) memcpy(pack.data() + (size_t)k * L, src[k], (size_t)L * 8);
+    for (int i = 0; i < L; i++) { pack[(size_t)8 * L + i] = edge_L ? edge_L[i] : 4.0; pack[(size_t)9 * L + i] = edge_R ? edge_R[i] : -4.0; }   // defaults: trajectories.jl:42
+    const int32_t Ls = L;
+    return install_trajectories(h, 1, L, &Ls, pack.data());
+}
+
+int pg_set_trajectories(pg_handle* h, int32_t n_traj, int32_t Lmax, const int32_t* L, const double* channels) {
+    if (!h) return PG_ERR_INVALID;
+    REQUIRE(h, n_traj >= 1 && Lmax >= 2 && L && channels, "pg_set_trajectories: need n_traj >= 1, Lmax >= 2, lengths and channels");
+    for (int k = 0; k < n_traj; k++) REQUIRE(h, L[k] >= 2 && L[k] <= Lmax, "pg_set_trajectories: every trajectory needs 2 <= L[k] <= Lmax");
+    return install_trajectories(h, n_traj, Lmax, L, channels);
+}
+
+int pg_set_trajectory_index(pg_handle* h, int32_t B, const int32_t* index) {
+    if (!h) return PG_ERR_INVALID;
+    REQUIRE(h, h->d_traj, "pg_set_trajectory_index: no trajectory library installed");
+    REQUIRE(h, B >= 1 && B <= h->cfg.batch_capacity && index, "pg_set_trajectory_index: need 1 <= B <= batch_capacity and an index array");
+    for (int b = 0; b < B; b++) REQUIRE(h, index[b] >= 0 && index[b] < h->dc.n_traj, "pg_set_trajectory_index: index out of range of the installed library");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->d_traj) { (void)hipFree(h->d_traj); h->d_traj = nullptr; }
-    HIPCHK(h, hipMalloc((void**)&h->d_traj, (size_t)8 * L * sizeof(double)));
-    const double* src[8] = {t, s, V, A, E, N, psi, kappa};
-    for (int k = 0; k < 8; k++) HIPCHK(h, hipMemcpy(h->d_traj + (size_t)k * L, src[k], (size_t)L * 8, hipMemcpyHostToDevice));
-    TrajView& T = h->dc.traj; T.L = L;
-    T.t = h->d_traj; T.s = h->d_traj + L; T.V = h->d_traj + 2 * (size_t)L; T.A = h->d_traj + 3 * (size_t)L; T.E = h->d_traj + 4 * (size_t)L;
-    T.N = h->d_traj + 5 * (size_t)L; T.psi = h->d_traj + 6 * (size_t)L; T.kappa = h->d_traj + 7 * (size_t)L;
-    h->traj_L = L;
+    if (!h->d_traj_idx) HIPCHK(h, hipMalloc((void**)&h->d_traj_idx, (size_t)h->cfg.batch_capacity * sizeof(int)));
+    HIPCHK(h, hipMemcpy(h->d_traj_idx, index, (size_t)B * sizeof(int), hipMemcpyHostToDevice));
+    h->dc.traj_idx = h->d_traj_idx; h->traj_idx_B = B;
     return PG_OK;
 }
 
@@ -269,6 +305,7 @@ static int check_ready(pg_handle* h) {
     if (!h) return PG_ERR_INVALID;
     if (h->B <= 0) { h->err = "no inputs installed (call pg_set_inputs first)"; return PG_ERR_STATE; }
     if (!h->d_traj) { h->err = "no trajectory installed (call pg_set_trajectory first)"; return PG_ERR_STATE; }
+    if (h->dc.n_traj > 1 && h->traj_idx_B < h->B) { h->err = "a trajectory library is installed but pg_set_trajectory_index does not cover the batch"; return PG_ERR_STATE; }
     if (hipSetDevice(h->cfg.device) != hipSuccess) { h->err = "hipSetDevice failed"; return PG_ERR_HIP; }
     return PG_OK;
 }
@@ -285,7 +322,7 @@ int pg_compute_linearization_nodes(pg_handle* h) {
     const int B = h->B;
     hipLaunchKernelGGL(k_project, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep);
     LAUNCH_CHECK(h);
-    const bool staged = h->traj_L <= 2048;
+    const bool staged = h->dc.n_traj == 1 && h->traj_L <= 2048;
     const size_t traj_lds = staged ? (size_t)2 * h->traj_L * sizeof(double) : 0;
     const dim3 grid((B + 63) / 64), block(64);
     if (h->dc.formulation == PG_DECOUPLED) {

@@ -240,7 +240,7 @@ PG_DEV Steady steady_state(const pg_vehicle& P, double V, double A_tan, double k
 // ---- trajectory (trajectories.jl) ----
 struct TrajView {
     int L;
-    const double *t, *s, *V, *A, *E, *N, *psi, *kappa;   // theta, phi, edges are carried by the tube but read by nothing on this path
+    const double *t, *s, *V, *A, *E, *N, *psi, *kappa, *edge_L, *edge_R;   // theta, phi are carried by the tube but read by nothing on this path
 };
 // count of elements < x  (Julia searchsortedfirst - 1)
 PG_DEV int count_less(const double* v, int n, double x) {

@@ -31,8 +31,22 @@ struct DevCfg {
     int qp_len;
     int ipm_max_iter;
     double ipm_tol, ipm_mu0;
-    TrajView traj;
+    TrajView traj;                // trajectory 0 of the installed library
+    int n_traj;                   // library size (1: every instance tracks `traj`)
+    long traj_stride;             // doubles between consecutive trajectories of the library ([n_traj][10][Lmax])
+    const int* traj_idx;          // [B] per-instance selection (nullptr when n_traj == 1)
+    const int* traj_len;          // [n_traj] valid nodes of each trajectory
 };
+// the reference trajectory instance b tracks (mpc.trajectory of that controller)
+PG_DEV TrajView traj_of(const DevCfg& C, int b) {
+    TrajView T = C.traj;
+    if (C.n_traj > 1) {
+        const int k = C.traj_idx[b]; const long off = (long)k * C.traj_stride;
+        T.L = C.traj_len[k];
+        T.t += off; T.s += off; T.V += off; T.A += off; T.E += off; T.N += off; T.psi += off; T.kappa += off; T.edge_L += off; T.edge_R += off;
+    }
+    return T;
+}
 
 // offsets inside one instance's QP block (doubles); same order as pg_get_qp documents
 struct QpOff { int A, B0, Bf, c, H, G, dmin, dmax, fxmax, ddmin, ddmax, dt, qcurr, ucurr, M, b; };
@@ -73,7 +87,7 @@ PG_DEV double seg_dist2(double ax, double ay, double bx, double by, double x, do
 __global__ __launch_bounds__(256) void k_project(DevCfg C, int B, const double* __restrict__ state, double* __restrict__ sep) {
     int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= B) return;
-    const TrajView& T = C.traj;
+    const TrajView T = traj_of(C, wave);
     double x = state[(size_t)wave * 6 + 0], y = state[(size_t)wave * 6 + 1];
     double best = INFINITY; int bi = 0x7fffffff;
     for (int i = lane; i < T.L - 1; i += 64) {
@@ -111,13 +125,14 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
     // would otherwise pay L2 latency (the kernel is a 64-wave serial recurrence: latency, not bandwidth, is its whole cost)
     extern __shared__ double sh_traj[];
     TrajView T = C.traj;
-    if constexpr (STAGED) {                                 // compile-time so the searches compile to ds_read, not flat loads
+    if constexpr (STAGED) {                                 // single shared trajectory; compile-time so the searches compile to ds_read, not flat loads
         for (int i = threadIdx.x; i < T.L; i += blockDim.x) { sh_traj[i] = C.traj.t[i]; sh_traj[T.L + i] = C.traj.s[i]; }
         __syncthreads();
         T.t = sh_traj; T.s = sh_traj + T.L;
     }
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    if constexpr (!STAGED) T = traj_of(C, b);
     const pg_vehicle& P = C.veh;
     const double* q0 = state + (size_t)b * 6; const double* u0 = control + (size_t)b * 3;
     const double* TS = ts + (size_t)b * C.NN; const double* DT = dt + (size_t)b * C.N;
@@ -349,13 +364,14 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg 
                                                   const double* __restrict__ sep, const double* __restrict__ ts, const double* __restrict__ dt, double* __restrict__ nodes) {
     extern __shared__ double sh_traj[];
     TrajView T = C.traj;
-    if constexpr (STAGED) {                                 // compile-time so the searches compile to ds_read, not flat loads
+    if constexpr (STAGED) {                                 // single shared trajectory; compile-time so the searches compile to ds_read, not flat loads
         for (int i = threadIdx.x; i < T.L; i += blockDim.x) { sh_traj[i] = C.traj.t[i]; sh_traj[T.L + i] = C.traj.s[i]; }
         __syncthreads();
         T.t = sh_traj; T.s = sh_traj + T.L;
     }
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    if constexpr (!STAGED) T = traj_of(C, b);
     const pg_vehicle& P = C.veh;
     const double* q0 = state + (size_t)b * 6; const double* u0 = control + (size_t)b * 3;
     const double* TS = ts + (size_t)b * C.NN; const double* DT = dt + (size_t)b * C.N;

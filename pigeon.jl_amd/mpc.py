@@ -85,10 +85,35 @@ class BatchedTrajectoryTrackingMPC:
             pass
 
     # ---- mpc.trajectory = ... (ros_integration.jl:53) ----
-    def set_trajectory(self, traj: TrajectoryTube):
+    def set_trajectory(self, traj):
+        """One TrajectoryTube for the whole batch, or a list of tubes (a library; select per instance with set_trajectory_index)."""
+        if isinstance(traj, (list, tuple)):
+            return self.set_trajectories(traj)
         self.trajectory = traj
+        self.trajectories = [traj]
         cols = [np.ascontiguousarray(traj.data[i]) for i in range(12)]
         self._chk(self.lib.pg_set_trajectory(self.h, len(traj), *[_p(c) for c in cols]), "pg_set_trajectory")
+
+    # ---- one controller per (x0, reference trajectory) pair: the batch carries a library of tubes and a per-instance selection ----
+    def set_trajectories(self, trajs, index=None):
+        trajs = list(trajs)
+        Lmax = max(len(t) for t in trajs)
+        L = np.array([len(t) for t in trajs], dtype=np.int32)
+        pack = np.zeros((len(trajs), 10, Lmax))
+        rows = [0, 1, 2, 3, 4, 5, 6, 7, 10, 11]                     # t, s, V, A, E, N, psi, kappa, edge_L, edge_R of the 12-channel tube
+        for k, t in enumerate(trajs):
+            pack[k, :, :len(t)] = t.data[rows]
+            pack[k, :, len(t):] = t.data[rows][:, -1:]              # padding is never read (L[k] bounds every search)
+        self._chk(self.lib.pg_set_trajectories(self.h, len(trajs), Lmax, _p(L, C.POINTER(C.c_int32)), _p(pack)), "pg_set_trajectories")
+        self.trajectories = trajs
+        self.trajectory = trajs[0]
+        if index is not None:
+            self.set_trajectory_index(index)
+
+    def set_trajectory_index(self, index):
+        index = np.ascontiguousarray(index, dtype=np.int32)
+        self._chk(self.lib.pg_set_trajectory_index(self.h, len(index), _p(index, C.POINTER(C.c_int32))), "pg_set_trajectory_index")
+        self.trajectory_index = index
 
     # ---- mpc.HJI_cache = HJICache(...) (Pigeon.jl:40) ----
     def set_hji_cache(self, grid_knots, V_raw, gradV_raw):

@@ -9,10 +9,12 @@ def path_pose(traj, s):
     return f(traj.E), f(traj.N), f(traj.psi), f(traj.kappa), f(traj.V), f(traj.t)
 
 
-def config2_inputs(traj, B, seed=12345, traj_mode=True):
-    """Config 2 of BASELINE.md: randomised x0 along one test path.  Returns state [B,6], control [B,3], t0 [B], time_offset [B]."""
+def config2_inputs(traj, B, seed=12345, traj_mode=True, s_range=None):
+    """Config 2 of BASELINE.md: randomised x0 along one test path.  Returns state [B,6], control [B,3], t0 [B], time_offset [B].
+    s_range overrides the arclength window (default [5, s_end - 60] m; short paths need their own)."""
     rng = np.random.default_rng(seed)
-    s = rng.uniform(5.0, traj.s[-1] - 60.0, B)
+    lo, hi = (5.0, traj.s[-1] - 60.0) if s_range is None else s_range
+    s = rng.uniform(lo, hi, B)
     E, N, psi, kappa, V, t = path_pose(traj, s)
     e = rng.uniform(-0.5, 0.5, B)
     # psi is measured from North (vehicle_dynamics.jl:127): heading (-sin psi, cos psi), left normal (-cos psi, -sin psi)
