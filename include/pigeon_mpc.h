@@ -134,6 +134,14 @@ int pg_update_qp(pg_handle* h);                       /* update_QP!             
 int pg_solve(pg_handle* h);                           /* solve!                        model_predictive_control.jl:76 */
 int pg_get_next_control(pg_handle* h, double* u_out); /* get_next_control              coupled_lat_long.jl:370-374; u_out [B][3] (delta,Fxf,Fxr), host */
 int pg_get_next_control_dev(pg_handle* h, double* u_out_dev);
+/* The control the ROS loop actually sends (src/ros_integration.jl:114-124): when the instance is in trajectory mode (time_offset not NaN),
+ * use_hji_policy is set and the looked-up value V <= HJI_eps, the HJI fallback policy optimal_control(...) (src/HJI_computation.jl:133-158:
+ * bang-bang steer + 50-point Fx line search) replaces get_next_control(mpc).  Call after pg_update_qp/pg_solve (it reuses that step's lookup).
+ * u_out [B][3] (delta,Fxf,Fxr); source [B] (may be NULL): 0 = MPC control, 1 = HJI policy, 2 = V <= eps but the policy is switched off
+ * ("with a feather", :120-123); u2_policy [B][2] (may be NULL) = (delta_opt, Fx_opt) of optimal_control regardless of the selection.
+ * Without a grid V = +Inf and the MPC control is returned.  Coupled formulation only. */
+int pg_get_next_control_hji(pg_handle* h, int32_t use_hji_policy, double* u_out, int32_t* source, double* u2_policy);
+int pg_get_next_control_hji_dev(pg_handle* h, int32_t use_hji_policy, double* u_out_dev, int32_t* source_dev);
 
 /* all five for every instance: host buffers in, host buffers out (status/iters may be NULL) */
 int pg_step(pg_handle* h, int32_t B, const double* state, const double* control, const double* t0, const double* other_car,

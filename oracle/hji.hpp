@@ -112,6 +112,24 @@ inline void optimal_disturbance(const VehicleParams& P, const double x[7], const
     uH[0] = desAy / V; uH[1] = maxAx;
 }
 
+// optimal_control (uMode = :max, N = 50): HJI_computation.jl:133-158.  Bang-bang steer from the sign of the lateral co-state, then a 50-point
+// line search over Fx in [Fx_min, Fx_max] of grad V . (forces); strict '>' keeps the FIRST maximiser; a NaN score never wins (Fx_opt stays 0).
+inline void optimal_control(const VehicleParams& P, const double x[7], const double g[7], double u2[2], int N = 50) {
+    double A = g[3] / P.m, B = g[4] / P.m + P.a * g[6] / P.Izz, C = g[4] / P.m - P.b * g[6] / P.Izz;
+    double d_opt = B >= 0 ? P.delta_max : -P.delta_max;
+    double V_opt = -INFINITY, Fx_opt = 0.0;
+    for (int n = 0; n < N; n++) {
+        double frac = (double)n / (double)(N - 1);
+        double Fx = frac * P.Fx_max + (1 - frac) * P.Fx_min;
+        double Fxf, Fxr, Fyf, Fyr;
+        longitudinal_tire_forces<double>(P, Fx, Fxf, Fxr);
+        lateral_tire_forces_q(P, x[3], x[4], x[6], d_opt, Fxf, Fxr, Fyf, Fyr);      // fake_qR = (0,0,0,Ux,Uy,r)  (:137)
+        double V = A * Fx + B * Fyf + C * Fyr;
+        if (V > V_opt) { Fx_opt = Fx; V_opt = V; }
+    }
+    u2[0] = d_opt; u2[1] = Fx_opt;
+}
+
 // compute_reachability_constraint: HJI_computation.jl:160-170 with uR_lin = BicycleControl2(current_control)
 // as passed at coupled_lat_long.jl:342.  Returns M (2), b, and the looked-up V.
 inline void reachability_constraint(const VehicleParams& P, const HJICache& cache, const double x[7], double eps,

@@ -166,6 +166,13 @@ class Oracle:
         inb = self.L.po_hji_lookup(self.h, _d(_arr(x7, 7)), C.byref(V), _d(g))
         return V.value, g, bool(inb)
 
+    def hji_optimal_control(self, state6, other4):
+        """(V, (delta_opt, Fx_opt)): optimal_control of HJI_computation.jl:133-158 at cache[relative_state].gradV"""
+        u2 = np.zeros(2)
+        self.L.po_hji_optimal_control.restype = C.c_double
+        V = self.L.po_hji_optimal_control(self.h, _d(_arr(state6, 6)), _d(_arr(other4, 4)), _d(u2))
+        return float(V), u2
+
     def hji_constraint(self, state6, other4, control3):
         M = np.zeros(2); b = C.c_double(); V = C.c_double()
         self.L.po_hji_constraint(self.h, _d(_arr(state6, 6)), _d(_arr(other4, 4)), _d(_arr(control3, 3)), _d(M), C.byref(b), C.byref(V))

@@ -122,6 +122,13 @@ void po_next_control(void* hv, const double* u2n, double* out3) { ((Handle*)hv)-
 
 void po_hji_relative_state(const double* us6, const double* them4, double* x7) { hji_relative_state(us6, them4, x7); }
 int po_hji_lookup(void* hv, const double* x7, double* V, double* g7) { return ((Handle*)hv)->mpc.hji.lookup(x7, *V, g7) ? 1 : 0; }
+// ros_integration.jl:114-124 selection input: (delta_opt, Fx_opt) of optimal_control at the looked-up gradient; returns V
+double po_hji_optimal_control(void* hv, const double* state6, const double* other4, double* u2) {
+    Handle* h = (Handle*)hv; double x7[7], g[7], V; hji_relative_state(state6, other4, x7);
+    h->mpc.hji.lookup(x7, V, g);
+    optimal_control(h->mpc.veh, x7, g, u2);
+    return V;
+}
 void po_hji_constraint(void* hv, const double* state6, const double* other4, const double* control3, double* M2, double* b, double* V) {
     Handle* h = (Handle*)hv; double x7[7]; hji_relative_state(state6, other4, x7);
     double uR[2] = {control3[0], control3[1] + control3[2]};

@@ -24,6 +24,7 @@ struct pg_handle {
     double *d_ts = nullptr, *d_dt = nullptr, *d_prev_ts = nullptr, *d_sep = nullptr, *d_nodes = nullptr, *d_qp = nullptr;
     double *d_x7 = nullptr, *d_vg8 = nullptr, *d_Mb = nullptr, *d_abar = nullptr;
     double *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
+    double *d_pol_u2 = nullptr, *d_pol_u = nullptr; int* d_pol_src = nullptr;   // HJI fallback policy (HJI_computation.jl:133-158)
     int *d_status = nullptr, *d_iters = nullptr; uint16_t* d_active = nullptr;
     // HJI grid
     HjiView hv; float *d_knots = nullptr, *d_hnodes = nullptr, *d_hcells = nullptr; bool has_hji = false;
@@ -75,7 +76,7 @@ int pg_default_config_decoupled(pg_config* c) {
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_state, h->d_control, h->d_t0, h->d_other, h->d_toff, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_abar, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_abar, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->ev_ok) for (int i = 0; i < 4; i++) (void)hipEventDestroy(h->ev[i]);
 }
@@ -119,6 +120,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_x7, cap * 7, double); ALLOC(h->d_vg8, cap * 8, double); ALLOC(h->d_Mb, cap * 4, double);
     ALLOC(h->d_solx, cap * NN * 8, double); ALLOC(h->d_sigma, cap * N * 3, double); ALLOC(h->d_u, cap * 3, double); ALLOC(h->d_mu, cap, double);
     ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_active, cap * N, uint16_t);
+    ALLOC(h->d_pol_u2, cap * 2, double); ALLOC(h->d_pol_u, cap * 3, double); ALLOC(h->d_pol_src, cap, int);
 #undef ALLOC
     // initial ts = 1..NN (model_predictive_control.jl:13), solved = false
     {
@@ -400,6 +402,37 @@ int pg_get_next_control(pg_handle* h, double* u_out) {
     int rc = check_ready(h); if (rc) return rc;
     REQUIRE(h, u_out, "u_out is null");
     HIPCHK(h, hipMemcpyAsync(u_out, h->d_u, (size_t)h->B * 3 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PG_OK;
+}
+// ros_integration.jl:114-124: the HJI fallback policy takes the wheel when the value function says the situation is unsafe
+static int launch_hji_policy(pg_handle* h, int use_policy) {
+    const int B = h->B;
+    if (h->dc.formulation != PG_COUPLED) { h->err = "the HJI policy belongs to the coupled controller (ros_integration.jl:56,114)"; return PG_ERR_STATE; }
+    if (!h->has_hji) {                      // no grid: V = +Inf everywhere, the MPC control always wins
+        HIPCHK(h, hipMemcpyAsync(h->d_pol_u, h->d_u, (size_t)B * 3 * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_pol_src, 0, (size_t)B * sizeof(int), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_pol_u2, 0, (size_t)B * 2 * 8, h->stream));
+        return PG_OK;
+    }
+    hipLaunchKernelGGL(k_hji_policy, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, use_policy, h->d_x7, h->d_vg8, h->d_toff, h->d_u, h->d_pol_u2, h->d_pol_u, h->d_pol_src);
+    LAUNCH_CHECK(h);
+    return PG_OK;
+}
+int pg_get_next_control_hji_dev(pg_handle* h, int32_t use_hji_policy, double* u_out_dev, int32_t* source_dev) {
+    int rc = check_ready(h); if (rc) return rc;
+    if ((rc = launch_hji_policy(h, use_hji_policy))) return rc;
+    if (u_out_dev) HIPCHK(h, hipMemcpyAsync(u_out_dev, h->d_pol_u, (size_t)h->B * 3 * 8, hipMemcpyDeviceToDevice, h->stream));
+    if (source_dev) HIPCHK(h, hipMemcpyAsync(source_dev, h->d_pol_src, (size_t)h->B * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    return PG_OK;
+}
+int pg_get_next_control_hji(pg_handle* h, int32_t use_hji_policy, double* u_out, int32_t* source, double* u2_policy) {
+    int rc = check_ready(h); if (rc) return rc;
+    REQUIRE(h, u_out, "u_out is null");
+    if ((rc = launch_hji_policy(h, use_hji_policy))) return rc;
+    HIPCHK(h, hipMemcpyAsync(u_out, h->d_pol_u, (size_t)h->B * 3 * 8, hipMemcpyDeviceToHost, h->stream));
+    if (source) HIPCHK(h, hipMemcpyAsync(source, h->d_pol_src, (size_t)h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (u2_policy) HIPCHK(h, hipMemcpyAsync(u2_policy, h->d_pol_u2, (size_t)h->B * 2 * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PG_OK;
 }

@@ -723,6 +723,44 @@ __global__ __launch_bounds__(64) void k_hji_constraint(DevCfg C, int B, const do
     o[2] = Hm.v - (M0 * uR0 + M1 * uR1);                                           // :168
 }
 
+// optimal_control (uMode=:max, N=50) HJI_computation.jl:133-158 and the control selection of the ROS loop (ros_integration.jl:114-124), lane = instance.
+// u2 [B][2] = (delta_opt, Fx_opt) whenever the relative state is inside the grid; u_next [B][3] = the policy's BicycleControl when it takes over
+// (traj mode, use_policy, V <= eps), else the MPC control u_mpc; source: 0 MPC, 1 HJI policy, 2 V <= eps but the policy is switched off.
+__global__ __launch_bounds__(64) void k_hji_policy(DevCfg C, int B, int use_policy, const double* __restrict__ x7, const double* __restrict__ vg8, const double* __restrict__ toff,
+                                                   const double* __restrict__ u_mpc, double* __restrict__ u2, double* __restrict__ u_next, int* __restrict__ source) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const pg_vehicle& P = C.veh;
+    const double* x = x7 + (size_t)b * 7; const double* vg = vg8 + (size_t)b * 8; const double* g = vg + 1;
+    const double Ux = x[3], Uy = x[4], r = x[6];
+    const double A = g[3] / P.m, Bc = g[4] / P.m + P.a * g[6] / P.Izz, Cc = g[4] / P.m - P.b * g[6] / P.Izz;      // :140-142
+    const double d_opt = Bc >= 0.0 ? P.delta_max : -P.delta_max;                                                   // :143
+    double sd, cd; sincos(d_opt, &sd, &cd);
+    const double tf = (Uy + P.a * r) / Ux, td = sd / cd;
+    const double taf = (tf - td) / (1.0 + tf * td), tar = (Uy - P.b * r) / Ux;       // slip-angle tangents (vehicle_dynamics.jl:84-85), Ux > 0
+    double V_opt = -INFINITY, Fx_opt = 0.0;
+#pragma unroll 1
+    for (int n = 0; n < 50; n++) {
+        double frac = (double)n / 49.0;
+        double Fx = frac * P.Fx_max + (1.0 - frac) * P.Fx_min;
+        double Fxf = Fx > 0.0 ? Fx * P.fwd_frac : Fx * P.fwb_frac, Fxr = Fx > 0.0 ? Fx * P.rwd_frac : Fx * P.rwb_frac;       // longitudinal_tire_forces, no limits (:148)
+        double Fyf, Fyr;
+        lateral_forces<double>(P, taf, tar, Fxf, Fxr, sd, cd, Fyf, Fyr);
+        double V = A * Fx + Bc * Fyf + Cc * Fyr;
+        if (V > V_opt) { Fx_opt = Fx; V_opt = V; }
+    }
+    u2[(size_t)b * 2] = d_opt; u2[(size_t)b * 2 + 1] = Fx_opt;
+    const bool traj_mode = toff[b] == toff[b];
+    const bool unsafe = traj_mode && vg[0] <= C.hji_eps;
+    int src = unsafe ? (use_policy ? 1 : 2) : 0;
+    double o0 = u_mpc[(size_t)b * 3], o1 = u_mpc[(size_t)b * 3 + 1], o2 = u_mpc[(size_t)b * 3 + 2];
+    if (src == 1) {                  // BicycleControl(longitudinal_params, BicycleControl2(delta_opt, Fx_opt))  (vehicle_dynamics.jl:284)
+        o0 = d_opt; o1 = Fx_opt > 0.0 ? Fx_opt * P.fwd_frac : Fx_opt * P.fwb_frac; o2 = Fx_opt > 0.0 ? Fx_opt * P.rwd_frac : Fx_opt * P.rwb_frac;
+    }
+    u_next[(size_t)b * 3] = o0; u_next[(size_t)b * 3 + 1] = o1; u_next[(size_t)b * 3 + 2] = o2;
+    source[b] = src;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // QP solve: one wavefront per instance.  See tools/ipm_prototype.py for the algorithm statement and DESIGN.md for the derivation.
 // State x_k = (q_k, u_k) in R^8, input v_k = u_{k+1} - u_k; 16 inequality rows per transition k (node k+1):

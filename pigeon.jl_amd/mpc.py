@@ -171,6 +171,12 @@ class BatchedTrajectoryTrackingMPC:
         self._chk(self.lib.pg_get_next_control(self.h, _p(u)), "pg_get_next_control")
         return u
 
+    def get_next_control_hji(self, use_HJI_policy=True):
+        """ros_integration.jl:114-124: (u [B,3], source [B] (0 MPC / 1 HJI policy / 2 unsafe but policy off), optimal_control (delta, Fx) [B,2])"""
+        u = np.zeros((self.B, 3)); src = np.zeros(self.B, dtype=np.int32); u2 = np.zeros((self.B, 2))
+        self._chk(self.lib.pg_get_next_control_hji(self.h, int(bool(use_HJI_policy)), _p(u), _p(src, C.POINTER(C.c_int32)), _p(u2)), "pg_get_next_control_hji")
+        return u, src, u2
+
     def step_(self, current_state, current_control, t, other_car_state=None, time_offset=None):
         """The whole callback body of ros_integration.jl:94-99,124 for every instance; returns (u, status, iters)."""
         s = _f64(current_state).reshape(-1, 6); B = s.shape[0]

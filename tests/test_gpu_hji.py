@@ -87,3 +87,42 @@ def test_nan_hazard_is_reported(pkg, skidpad, grid):
     u, status, iters = mpc.step_(state, control, t0, other_car_state=other, time_offset=toff)
     assert status[1] == pkg.NUMERICAL and np.all(np.isnan(u[1]))
     assert status[0] == pkg.SOLVED and status[2] == pkg.SOLVED and np.all(np.isfinite(u[[0, 2, 3]]))
+
+
+def test_hji_fallback_policy(pkg, oracle_mod, skidpad, grid):
+    """optimal_control (HJI_computation.jl:133-158) and the ROS loop's selection (ros_integration.jl:114-124) against the oracle:
+    bang-bang steer sign and the argmax of the 50-point Fx line search are index work (exact), the chosen forces are bit-identical grid points."""
+    knots, V, g = grid
+    B = 96
+    eps = 0.5
+    mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, B, hji_eps=eps)
+    mpc.set_hji_cache(knots, V, g)
+    orc = make_oracle(oracle_mod, skidpad); orc.set_hji_grid(knots, V, g); orc.set_hji_eps(eps)
+    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B, seed=33)
+    toff[::5] = np.nan                                               # path-tracking mode never hands over (tracking_mode != :traj)
+    other = pkg.synthetic.other_cars(state, seed=9)
+    u_mpc, status, _ = mpc.step_(state, control, t0, other_car_state=other, time_offset=toff)
+    assert np.all(status == 1)
+    u_on, src_on, u2 = mpc.get_next_control_hji(True)
+    u_off, src_off, _ = mpc.get_next_control_hji(False)
+    P = mpc.vehicle
+    fx_grid = np.array([n / 49 * P["Fx_max"] + (1 - n / 49) * P["Fx_min"] for n in range(50)])
+    seen = set()
+    for i in range(B):
+        Vo, u2o = orc.hji_optimal_control(state[i], other[i])
+        unsafe = (not math.isnan(toff[i])) and Vo <= eps
+        assert src_on[i] == (1 if unsafe else 0) and src_off[i] == (2 if unsafe else 0), i
+        seen.add(int(src_on[i]))
+        assert np.array_equal(u_off[i], u_mpc[i])
+        if not math.isinf(Vo):
+            assert u2[i, 0] == u2o[0], i                                                         # steer sign: exact
+            assert int(np.argmin(np.abs(fx_grid - u2[i, 1]))) == int(np.argmin(np.abs(fx_grid - u2o[1]))), i   # line-search index: exact
+            assert u2[i, 1] == u2o[1], i
+        if unsafe:
+            Fx = u2o[1]
+            exp = [u2o[0], Fx * (P["fwd_frac"] if Fx > 0 else P["fwb_frac"]), Fx * (P["rwd_frac"] if Fx > 0 else P["rwb_frac"])]
+            assert np.allclose(u_on[i], exp, rtol=0, atol=1e-12 * max(1.0, abs(Fx))), i
+        else:
+            assert np.array_equal(u_on[i], u_mpc[i])
+    assert seen == {0, 1}, seen                                      # both outcomes exercised
+    mpc.close()
