@@ -116,7 +116,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_state, cap * 6, double); ALLOC(h->d_control, cap * 3, double); ALLOC(h->d_t0, cap, double); ALLOC(h->d_other, cap * 4, double); ALLOC(h->d_toff, cap, double);
     ALLOC(h->d_solved, cap, int); ALLOC(h->d_ts, cap * NN, double); ALLOC(h->d_dt, cap * N, double); ALLOC(h->d_prev_ts, cap * NN, double);
     ALLOC(h->d_sep, cap * 4, double); ALLOC(h->d_nodes, cap * NN * 10, double); ALLOC(h->d_qp, cap * C.qp_len, double);
-    ALLOC(h->d_abar, cap * N * 66, double);
+    ALLOC(h->d_abar, cap * N * SB, double);
     ALLOC(h->d_x7, cap * 7, double); ALLOC(h->d_vg8, cap * 8, double); ALLOC(h->d_Mb, cap * 4, double);
     ALLOC(h->d_solx, cap * NN * 8, double); ALLOC(h->d_sigma, cap * N * 3, double); ALLOC(h->d_u, cap * 3, double); ALLOC(h->d_mu, cap, double);
     ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_active, cap * N, uint16_t);
@@ -137,7 +137,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     h->ev_ok = true;
     // horizons up to 32 intervals keep their dynamics blocks resident in LDS (one pass over the QP data); longer ones stream them through a 4-slot ring
     h->solve_ring = N > 32;
-    h->solve_lds = (size_t)((h->solve_ring ? 4 : N) * 66 + 10 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 64 + 88 + 8 + 64 + 2) * sizeof(double);
+    h->solve_lds = (size_t)((h->solve_ring ? 4 : N) * SB + 10 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 72 + 100 + 8 + 64 + 2) * sizeof(double);
     if (h->solve_lds > 160 * 1024) { g_create_error = "horizon too long for LDS staging"; free_all(h); delete h; return PG_ERR_INVALID; }
     if (h->solve_lds > 48 * 1024)
     {

@@ -48,6 +48,10 @@ PG_DEV TrajView traj_of(const DevCfg& C, int b) {
     return T;
 }
 
+// Packed stage block streamed by k_solve: rows 0..5 of Abar = [A | B0+Bf] at a row stride of 9 doubles (odd stride: the 8 rows land on distinct LDS
+// banks, so the row-indexed reads of the Riccati passes are conflict-free), then Bbar = Bf (12) at SB_B, cbar = c (6) at SB_C.
+constexpr int SB = 72, SB_ROW = 9, SB_B = 54, SB_C = 66, SB_CHUNKS = SB / 2;
+
 // offsets inside one instance's QP block (doubles); same order as pg_get_qp documents
 struct QpOff { int A, B0, Bf, c, H, G, dmin, dmax, fxmax, ddmin, ddmax, dt, qcurr, ucurr, M, b; };
 __host__ __device__ inline QpOff qp_offsets(int N) {
@@ -290,13 +294,13 @@ __global__ __launch_bounds__(256) void k_limits(DevCfg C, int B, const double* _
         c[i] = ci;
         B0[2 * i] *= C.un0; B0[2 * i + 1] *= C.un1; Bf[2 * i] *= C.un0; Bf[2 * i + 1] *= C.un1;      // :338,350-351
     }
-    {   // packed copy streamed by k_solve: rows 0..5 of Abar = [A | B0+Bf], Bbar = Bf, cbar = c  (66 doubles per stage)
-        double* P66 = abar + ((size_t)b * C.N + t) * 66;
+    {   // packed copy streamed by k_solve: rows 0..5 of Abar = [A | B0+Bf], Bbar = Bf, cbar = c  (SB doubles per stage)
+        double* P66 = abar + ((size_t)b * C.N + t) * SB;
         for (int i = 0; i < 6; i++) {
-            for (int j = 0; j < 6; j++) P66[8 * i + j] = A[6 * i + j];
-            P66[8 * i + 6] = B0[2 * i] + Bf[2 * i]; P66[8 * i + 7] = B0[2 * i + 1] + Bf[2 * i + 1];
-            P66[48 + 2 * i] = Bf[2 * i]; P66[48 + 2 * i + 1] = Bf[2 * i + 1];
-            P66[60 + i] = c[i];
+            for (int j = 0; j < 6; j++) P66[SB_ROW * i + j] = A[6 * i + j];
+            P66[SB_ROW * i + 6] = B0[2 * i] + Bf[2 * i]; P66[SB_ROW * i + 7] = B0[2 * i + 1] + Bf[2 * i + 1]; P66[SB_ROW * i + 8] = 0.0;
+            P66[SB_B + 2 * i] = Bf[2 * i]; P66[SB_B + 2 * i + 1] = Bf[2 * i + 1];
+            P66[SB_C + i] = c[i];
         }
     }
     double Uxt = n1[1], Fx = n1[7];                                                                   // :357-358
@@ -495,15 +499,15 @@ __global__ __launch_bounds__(128) void k_qp_dec(DevCfg C, int B, const double* _
     QpOff o = qp_offsets(C.N);
     double* Q = qp + (size_t)b * C.qp_len;
     double* A6 = Q + o.A + 36 * t; double* B06 = Q + o.B0 + 12 * t; double* Bf6 = Q + o.Bf + 12 * t; double* c6 = Q + o.c + 6 * t;
-    double* P66 = abar + ((size_t)b * C.N + t) * 66;
+    double* P66 = abar + ((size_t)b * C.N + t) * SB;
     for (int i = 0; i < 36; i++) A6[i] = 0.0;
     for (int i = 0; i < 12; i++) { B06[i] = 0.0; Bf6[i] = 0.0; }
-    for (int i = 0; i < 66; i++) P66[i] = 0.0;
-    A6[0] = 1.0; A6[7] = 1.0; P66[0] = 1.0; P66[9] = 1.0; c6[0] = 0.0; c6[1] = 0.0;
+    for (int i = 0; i < SB; i++) P66[i] = 0.0;
+    A6[0] = 1.0; A6[7] = 1.0; P66[0] = 1.0; P66[SB_ROW + 1] = 1.0; c6[0] = 0.0; c6[1] = 0.0;
     for (int i = 0; i < 4; i++) {
-        for (int j = 0; j < 4; j++) { A6[6 * (2 + i) + 2 + j] = Ad.a[4 * i + j]; P66[8 * (2 + i) + 2 + j] = Ad.a[4 * i + j]; }
+        for (int j = 0; j < 4; j++) { A6[6 * (2 + i) + 2 + j] = Ad.a[4 * i + j]; P66[SB_ROW * (2 + i) + 2 + j] = Ad.a[4 * i + j]; }
         B06[2 * (2 + i)] = b0[i]; Bf6[2 * (2 + i)] = bf[i]; c6[2 + i] = cd[i];
-        P66[8 * (2 + i) + 6] = b0[i] + bf[i]; P66[48 + 2 * (2 + i)] = bf[i]; P66[60 + 2 + i] = cd[i];
+        P66[SB_ROW * (2 + i) + 6] = b0[i] + bf[i]; P66[SB_B + 2 * (2 + i)] = bf[i]; P66[SB_C + 2 + i] = cd[i];
     }
     // envelope and bounds (:262-272): Ux from the NEXT node's parameter, Fx from its seeded control; nothing is normalised here
     double Uxt = n1[1], Fx = n1[7];
@@ -806,9 +810,9 @@ __global__ __launch_bounds__(64, RING ? 2 : 1) void k_solve(DevCfg C, int B, con
     const int N = C.N, NN = C.NN;
     extern __shared__ double lds[];
     // The dynamics blocks are NOT resident: each pass streams them stage by stage from L2 through a 4-slot LDS ring
-    // (slot = 66 doubles: rows 0..5 of Abar_k = [A | B0+Bf] (48), rows 0..5 of Bbar_k = Bf (12), cbar_k = c (6)); rows 6,7 are [0 I] / I / 0.
-    double* sRing = lds;                 // RING: [4][66] slots; otherwise all N stage blocks resident: [N][66]
-    double* sQ = sRing + (RING ? 4 : N) * 66;         // [NN][10]: diagonal[8] (with (Uy,Uy),(r,r) at 2,3), (Uy,r) off-diagonal, (delta,Fx) off-diagonal
+    // (slot = SB doubles: rows 0..5 of Abar_k = [A | B0+Bf] at row stride 9, rows 0..5 of Bbar_k = Bf (12), cbar_k = c (6)); rows 6,7 are [0 I] / I / 0.
+    double* sRing = lds;                 // RING: [4][SB] slots; otherwise all N stage blocks resident: [N][SB]
+    double* sQ = sRing + (RING ? 4 : N) * SB;         // [NN][10]: diagonal[8] (with (Uy,Uy),(r,r) at 2,3), (Uy,r) off-diagonal, (delta,Fx) off-diagonal
     double* sq = sQ + 10 * NN;           // [NN][8]
     double* sR = sq + 8 * NN;            // [N][2]   diagonal of Rhat
     double* sr = sR + 2 * N;             // [N][2]
@@ -818,26 +822,26 @@ __global__ __launch_bounds__(64, RING ? 2 : 1) void k_solve(DevCfg C, int B, con
     double* skf = sMc + 8 * N;           // [N][2]
     double* sx = skf + 2 * N;            // [NN][8]  Newton point
     double* sv = sx + 8 * NN;            // [N][2]
-    double* sP = sv + 2 * N;             // [8][8]
-    double* sMT = sP + 64;               // [11][8]  (P [Abar | Bbar | cbar]) stored column-major
-    double* sx0 = sMT + 88;              // [8]
+    double* sP = sv + 2 * N;             // [8][9]   (row stride 9: conflict-free row reads)
+    double* sMT = sP + 72;               // [11][9]  (P [Abar | Bbar | cbar]) stored column-major, column stride 9
+    double* sx0 = sMT + 99 + 1;              // [8]
     double* sDum = sx0 + 8;              // [64] sink for predicated-off stores (keeps the pass loops branch-free)
     double* sZero = sDum + 64;           // [2]  a stored 0.0 (off-pattern entries of Qhat)
 
     const QpOff o = qp_offsets(N);
     const double* Q = qp + (size_t)b * C.qp_len;
-    // ---- LDS ring fed from L2: lane l < 33 moves 16 bytes of the 528-byte stage block; two-deep software pipeline (register, then LDS) ----
-    const double2* gA = reinterpret_cast<const double2*>(abar + (size_t)b * N * 66);
-    const int rlane = lane < 33 ? lane : 0;
+    // ---- LDS ring fed from L2: lane l < 36 moves 16 bytes of the 576-byte stage block; two-deep software pipeline (register, then LDS) ----
+    const double2* gA = reinterpret_cast<const double2*>(abar + (size_t)b * N * SB);
+    const int rlane = lane < SB_CHUNKS ? lane : 0;
     double2 ring_pre;
-    auto ring_slot = [&](int k) -> double* { return sRing + (RING ? (k & 3) : k) * 66; };
-    auto ring_load = [&](int k) { int kk = k < 0 ? 0 : (k >= N ? N - 1 : k); ring_pre = gA[kk * 33 + rlane]; };
-    auto ring_put = [&](int k) { double2* dst = lane < 33 ? reinterpret_cast<double2*>(ring_slot(k)) + lane : reinterpret_cast<double2*>(sDum) + (lane & 31); *dst = ring_pre; };
+    auto ring_slot = [&](int k) -> double* { return sRing + (RING ? (k & 3) : k) * SB; };
+    auto ring_load = [&](int k) { int kk = k < 0 ? 0 : (k >= N ? N - 1 : k); ring_pre = gA[kk * SB_CHUNKS + rlane]; };
+    auto ring_put = [&](int k) { double2* dst = lane < SB_CHUNKS ? reinterpret_cast<double2*>(ring_slot(k)) + lane : reinterpret_cast<double2*>(sDum) + (lane & 31); *dst = ring_pre; };
     // prime(k0, dir): block k0 lands in the ring, block k0+dir is in flight.  step(k, dir) at the top of stage k: block k+dir lands, k+2dir takes off.
     auto ring_prime = [&](int k0, int dir) { if (RING) { ring_load(k0); ring_put(k0); ring_load(k0 + dir); } };
     auto ring_step = [&](int k, int dir) { if (RING) { ring_put(k + dir); ring_load(k + 2 * dir); } };
-    if (!RING) {      // short horizons: every stage block is read from HBM exactly once and stays in LDS (66 N doubles = 15.8 KB at N = 30)
-        for (int i = lane; i < 33 * N; i += 64) reinterpret_cast<double2*>(sRing)[i] = gA[i];
+    if (!RING) {      // short horizons: every stage block is read from HBM exactly once and stays in LDS (SB N doubles = 17.3 KB at N = 30)
+        for (int i = lane; i < SB_CHUNKS * N; i += 64) reinterpret_cast<double2*>(sRing)[i] = gA[i];
     }
     if (lane < 2) sZero[lane] = 0.0;
     if (lane < 8) sx0[lane] = lane < 6 ? Q[o.qcurr + lane] : Q[o.ucurr + lane - 6];
@@ -889,12 +893,12 @@ __global__ __launch_bounds__(64, RING ? 2 : 1) void k_solve(DevCfg C, int B, con
         for (int k = 0; k < N; k++) {
             ring_step(k, +1);
             const double* Rk = ring_slot(k);
-            const double* Kk = sK + 16 * k; const double* Ar = Rk + 8 * rr;
+            const double* Kk = sK + 16 * k; const double* Ar = Rk + SB_ROW * rr;
             double K0[8], K1[8], A8[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) { A8[m] = Ar[m]; K0[m] = use_gain ? Kk[m] : 0.0; K1[m] = use_gain ? Kk[8 + m] : 0.0; }
             double kf0 = use_gain ? skf[2 * k] : 0.0, kf1 = use_gain ? skf[2 * k + 1] : 0.0;
-            double cr = Rk[60 + rr], bf0 = Rk[48 + 2 * rr], bf1 = Rk[48 + 2 * rr + 1];
+            double cr = Rk[SB_C + rr], bf0 = Rk[SB_B + 2 * rr], bf1 = Rk[SB_B + 2 * rr + 1];
             double xm[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) xm[m] = rl(xi, m);
@@ -983,32 +987,32 @@ __global__ __launch_bounds__(64, RING ? 2 : 1) void k_solve(DevCfg C, int B, con
 #pragma unroll 1
         for (int k = N - 1; k >= 0; k--) {
             ring_step(k, -1);
-            const double* Ak = ring_slot(k); const double* Bk = Ak + 48; const double* ck = Ak + 60;
-            sP[lane] = Pij;
+            const double* Ak = ring_slot(k); const double* Bk = Ak + SB_B; const double* ck = Ak + SB_C;
+            sP[9 * li + lj] = Pij;
             // stage constants (independent of the recursion): issue their reads before the barrier
             double acol[6], arow[6], aug6[6], bk0[6], bk1[6];
 #pragma unroll
-            for (int m = 0; m < 6; m++) { acol[m] = Ak[8 * m + lj]; arow[m] = Ak[8 * m + li]; aug6[m] = lj == 2 ? ck[m] : Bk[2 * m + ljb]; bk0[m] = Bk[2 * m]; bk1[m] = Bk[2 * m + 1]; }
+            for (int m = 0; m < 6; m++) { acol[m] = Ak[SB_ROW * m + lj]; arow[m] = Ak[SB_ROW * m + li]; aug6[m] = lj == 2 ? ck[m] : Bk[2 * m + ljb]; bk0[m] = Bk[2 * m]; bk1[m] = Bk[2 * m + 1]; }
             double qh = qbase[qmul * k], R0 = sR[2 * k], R1 = sR[2 * k + 1];
             double a6v[6];
 #pragma unroll
-            for (int m = 0; m < 6; m++) a6v[m] = Ak[8 * m + r8];
+            for (int m = 0; m < 6; m++) a6v[m] = Ak[SB_ROW * m + r8];
             double qkv = sq[8 * k + r8], r0v = sr[2 * k], r1v = sr[2 * k + 1];
             __syncthreads();
             double prow[8];
 #pragma unroll
-            for (int m = 0; m < 8; m++) prow[m] = sP[8 * li + m];
+            for (int m = 0; m < 8; m++) prow[m] = sP[9 * li + m];
             double ma = lj == 6 ? prow[6] : (lj == 7 ? prow[7] : 0.0);
             double aug = lj == 0 ? prow[6] : (lj == 1 ? prow[7] : 0.0);
 #pragma unroll
             for (int m = 0; m < 6; m++) { ma += prow[m] * acol[m]; aug += prow[m] * aug6[m]; }
-            sMT[8 * lj + li] = ma;
-            *(lj < 3 ? sMT + 8 * (8 + lj) + li : sDum + lane) = aug;
+            sMT[9 * lj + li] = ma;
+            *(lj < 3 ? sMT + 9 * (8 + lj) + li : sDum + lane) = aug;
             *(lj == 2 ? sMc + 8 * k + li : sDum + lane) = aug;
             __syncthreads();
             double cj[8], ci[8], mb0[8], mb1[8];
 #pragma unroll
-            for (int m = 0; m < 8; m++) { cj[m] = sMT[8 * lj + m]; ci[m] = sMT[8 * li + m]; mb0[m] = sMT[64 + m]; mb1[m] = sMT[72 + m]; }
+            for (int m = 0; m < 8; m++) { cj[m] = sMT[9 * lj + m]; ci[m] = sMT[9 * li + m]; mb0[m] = sMT[72 + m]; mb1[m] = sMT[81 + m]; }
             double Fj0 = cj[6], Fj1 = cj[7], Fi0 = ci[6], Fi1 = ci[7];
             double S00 = R0 + mb0[6], S01 = mb1[6], S11 = R1 + mb1[7];
 #pragma unroll
@@ -1027,8 +1031,8 @@ __global__ __launch_bounds__(64, RING ? 2 : 1) void k_solve(DevCfg C, int B, con
             // symmetrise (lane (j,i) holds the transposed entry): without it the antisymmetric rounding error of the recursion is amplified by
             // |eig(Abar)|^2 per stage and wrecks long horizons whose linearised dynamics are open-loop unstable (N = 50, saturated tires)
             Pij = 0.5 * (pn + __shfl(pn, 8 * lj + li));      // (k == 0: never used)
-            // ---- vector recursion of the predictor: y = Mc_k + p_{k+1} (Mc_k = column 10 of the augmented product, in sMT[80..87]) ----
-            double yi = sMT[80 + r8] + pvec;
+            // ---- vector recursion of the predictor: y = Mc_k + p_{k+1} (Mc_k = column 10 of the augmented product, in sMT[90..97]) ----
+            double yi = sMT[90 + r8] + pvec;
             double y[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) y[m] = rl(yi, m);
@@ -1053,10 +1057,10 @@ __global__ __launch_bounds__(64, RING ? 2 : 1) void k_solve(DevCfg C, int B, con
 #pragma unroll 1
         for (int k = N - 1; k >= 0; k--) {
             ring_step(k, -1);
-            const double* Ak = ring_slot(k); const double* Bk = Ak + 48;
+            const double* Ak = ring_slot(k); const double* Bk = Ak + SB_B;
             double a6[6], b0[6], b1[6];
 #pragma unroll
-            for (int m = 0; m < 6; m++) { a6[m] = Ak[8 * m + r8]; b0[m] = Bk[2 * m]; b1[m] = Bk[2 * m + 1]; }
+            for (int m = 0; m < 6; m++) { a6[m] = Ak[SB_ROW * m + r8]; b0[m] = Bk[2 * m]; b1[m] = Bk[2 * m + 1]; }
             double mc = sMc[8 * k + r8], qk = sq[8 * k + r8], k0 = sK[16 * k + r8], k1 = sK[16 * k + 8 + r8], r0 = sr[2 * k], r1 = sr[2 * k + 1];
             double I00 = sSi[4 * k], I01 = sSi[4 * k + 1], I11 = sSi[4 * k + 2];
             double yi = mc + pi;
