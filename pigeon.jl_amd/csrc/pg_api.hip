@@ -30,6 +30,7 @@ struct pg_handle {
     HjiView hv; float *d_knots = nullptr, *d_hnodes = nullptr, *d_hcells = nullptr; bool has_hji = false;
     hipEvent_t ev[4]; bool ev_ok = false; float phase_ms[3] = {0, 0, 0}; bool timing_valid = false;
     size_t solve_lds = 0; bool solve_ring = false;
+    double* d_ws4 = nullptr; bool solve_quad = false; size_t solve4_lds = 0;   // k_solve4 (four instances per wavefront)
 };
 
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return PG_ERR_HIP; } } while (0)
@@ -76,7 +77,7 @@ int pg_default_config_decoupled(pg_config* c) {
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_state, h->d_control, h->d_t0, h->d_other, h->d_toff, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_abar, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_abar, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->ev_ok) for (int i = 0; i < 4; i++) (void)hipEventDestroy(h->ev[i]);
 }
@@ -120,6 +121,8 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_x7, cap * 7, double); ALLOC(h->d_vg8, cap * 8, double); ALLOC(h->d_Mb, cap * 4, double);
     ALLOC(h->d_solx, cap * NN * 8, double); ALLOC(h->d_sigma, cap * N * 3, double); ALLOC(h->d_u, cap * 3, double); ALLOC(h->d_mu, cap, double);
     ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_active, cap * N, uint16_t);
+    { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (pg_solve4.hip)
+    if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), double);
     ALLOC(h->d_pol_u2, cap * 2, double); ALLOC(h->d_pol_u, cap * 3, double); ALLOC(h->d_pol_src, cap, int);
 #undef ALLOC
     // initial ts = 1..NN (model_predictive_control.jl:13), solved = false
@@ -137,6 +140,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     h->ev_ok = true;
     // horizons up to 32 intervals keep their dynamics blocks resident in LDS (one pass over the QP data); longer ones stream them through a 4-slot ring
     h->solve_ring = N > 32;
+    h->solve4_lds = lds4_bytes(N);
     h->solve_lds = (size_t)((h->solve_ring ? 4 : N) * SB + 10 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 72 + 100 + 8 + 64 + 2) * sizeof(double);
     if (h->solve_lds > 160 * 1024) { g_create_error = "horizon too long for LDS staging"; free_all(h); delete h; return PG_ERR_INVALID; }
     if (h->solve_lds > 48 * 1024)
@@ -373,7 +377,8 @@ int pg_update_qp(pg_handle* h) {
 int pg_solve(pg_handle* h) {
     int rc = check_ready(h); if (rc) return rc;
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved};
-    if (h->solve_ring) hipLaunchKernelGGL((k_solve<false, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, (unsigned long long*)nullptr);
+    if (h->solve_quad) hipLaunchKernelGGL((k_solve4<2, false>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, h->d_ws4, O, (unsigned long long*)nullptr);
+    else if (h->solve_ring) hipLaunchKernelGGL((k_solve<false, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, (unsigned long long*)nullptr);
     else hipLaunchKernelGGL((k_solve<false, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, (unsigned long long*)nullptr);
     LAUNCH_CHECK(h);
     return PG_OK;
@@ -386,7 +391,8 @@ int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     HIPCHK(h, hipMalloc((void**)&d, ((size_t)h->B * 6 + 1024) * 8));
     HIPCHK(h, hipMemset(d, 0, ((size_t)h->B * 6 + 1024) * 8));
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved};
-    if (h->solve_ring) hipLaunchKernelGGL((k_solve<true, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, d);
+    if (h->solve_quad) hipLaunchKernelGGL((k_solve4<2, true>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, h->d_ws4, O, d);
+    else if (h->solve_ring) hipLaunchKernelGGL((k_solve<true, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, d);
     else hipLaunchKernelGGL((k_solve<true, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, d);
     LAUNCH_CHECK(h);
     HIPCHK(h, hipMemcpy(out, d, ((size_t)h->B * 6 + 1024) * 8, hipMemcpyDeviceToHost));      // out: [B][6] cycles + 1024-double trace of PG_DEBUG_INSTANCE

@@ -1265,4 +1265,6 @@ __global__ __launch_bounds__(64, RING ? 2 : 1) void k_solve(DevCfg C, int B, con
     }
 }
 
+#include "pg_solve4.hip"
+
 }  // namespace pg

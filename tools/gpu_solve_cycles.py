@@ -14,6 +14,8 @@ rc = mpc.lib.pg_debug_solve_cycles(mpc.h, out.ctypes.data_as(C.c_void_p)); asser
 out = out[:B * 6].reshape(B, 6)
 st, it, act, mu = mpc.solve_info()
 names = ["stage(assemble/step)", "sync", "matrix pass", "vector passes", "forward passes", "prologue"]
+if os.environ.get("PG_SOLVER") == "quad":
+    names = ["stage phases", "matrix pass", "vector pass", "forward passes", "initial roll-out", "-"]
 tot = out.sum(1).astype(float)
 print("iters mean", it.mean(), "cycles/solve mean", tot.mean())
 for i, n in enumerate(names):
