@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hji", action="store_true")
     ap.add_argument("--no-decoupled", action="store_true")
+    ap.add_argument("--no-f32", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -174,6 +175,39 @@ def main():
                "finite": bool(torch.isfinite(out8).all().item())}
         mpc.clear_hji_cache()
 
+    # BASELINE config 3: coupled MPC + HJI safety constraint on the precomputed 7-D grid, fp32 (libpigeon_hip_f32.so: same sources, arithmetic type swapped)
+    f32 = None
+    if rank == 0 and not args.no_f32:
+        m32 = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision="f32")
+        m32.set_stream(torch.cuda.current_stream().cuda_stream)
+        other = pkg.synthetic.other_cars(state, seed=777)
+        f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        s32, c32, o32 = f(state), f(control), f(other)
+        u32 = torch.zeros(B, 3, dtype=torch.float32, device=dev)
+
+        def run32(with_hji):
+            m32.set_inputs_dev(B, s32.data_ptr(), c32.data_ptr(), d_t0.data_ptr(), o32.data_ptr() if with_hji else None, d_toff.data_ptr())
+            for _ in range(2):
+                m32.reset(); m32.step_dev(u32.data_ptr())
+            torch.cuda.synchronize(); t_ = time.perf_counter()
+            for _ in range(args.steps):
+                m32.reset(); m32.step_dev(u32.data_ptr())
+            torch.cuda.synchronize(); t_ = time.perf_counter() - t_
+            st_, it_, _, _ = m32.solve_info()
+            return {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": [float(v) for v in m32.phase_ms()],
+                    "solved": f"{int((st_ == pkg.SOLVED).sum())}/{B}", "ipm_iters_mean": float(np.mean(it_))}
+
+        plain = run32(False)
+        f32 = {"workload": f"configs[2]: Batch={B} coupled MPC + HJI safety constraint (13x13x9x9x9x9x9 float32 grid), N=30, fp32, cold", "dtype": "f32",
+               "accuracy": "controls within 5e-3 (normalised) of the exact optimum, median 5e-5 (tests/test_gpu_f32.py)", "without_hji": plain}
+        if not args.no_hji:
+            knots, Vg, gg = pkg.synthetic.hji_grid_large()
+            m32.set_hji_cache(knots, Vg, gg)
+            f32.update(run32(True))
+            _, _, Vh = m32.hji_constraint()
+            f32["hji_rows_active"] = int(np.sum(Vh <= 0.05)); f32["hji_in_grid"] = int(np.sum(np.isfinite(Vh)))
+        m32.close()
+
     if rank == 0:
         total = world * B * args.steps
         value = total / elapsed
@@ -206,6 +240,8 @@ def main():
             line["hji_lookup"] = hji
         if dec is not None:
             line["decoupled_n50"] = dec
+        if f32 is not None:
+            line["fp32"] = f32
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, traj, state, control, t0, toff)
         print(json.dumps(line), flush=True)

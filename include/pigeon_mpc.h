@@ -16,6 +16,10 @@
  * Conventions: every function returns 0 on success or a negative pg_status; no exceptions cross the ABI; all
  * arrays are instance-major ("array of structs": state[b*6 + k]) in double precision; pointers are HOST pointers
  * unless the parameter name ends in _dev.  One handle per host thread and device.
+ *
+ * Two builds export this same ABI: libpigeon_hip.so computes the path in fp64 (the reference's type), libpigeon_hip_f32.so in fp32
+ * (BASELINE configs 3/4).  Host arrays are double in both; DEVICE arrays of path data (pg_real_dev) have the library's own element
+ * type, which pg_precision_bits() reports (64 or 32).  Absolute times (t0, time_offset, the time grid) are double in both builds.
  */
 #ifndef PIGEON_MPC_H
 #define PIGEON_MPC_H
@@ -27,6 +31,9 @@ extern "C" {
 #endif
 
 typedef struct pg_handle pg_handle;
+typedef void pg_real_dev;       /* device array of double (libpigeon_hip.so) or float (libpigeon_hip_f32.so) */
+/* 64 for libpigeon_hip.so, 32 for libpigeon_hip_f32.so */
+int pg_precision_bits(void);
 
 enum pg_status {
     PG_OK = 0,
@@ -124,8 +131,8 @@ int pg_reset(pg_handle* h, const uint8_t* mask);
 int pg_set_inputs(pg_handle* h, int32_t B, const double* state, const double* control, const double* t0, const double* other_car,
                   const double* time_offset);
 /* same, inputs already resident in device memory (HBM) */
-int pg_set_inputs_dev(pg_handle* h, int32_t B, const double* state_dev, const double* control_dev, const double* t0_dev,
-                      const double* other_car_dev, const double* time_offset_dev);
+int pg_set_inputs_dev(pg_handle* h, int32_t B, const pg_real_dev* state_dev, const pg_real_dev* control_dev, const double* t0_dev,
+                      const pg_real_dev* other_car_dev, const double* time_offset_dev);
 
 /* the five reference calls, each over the whole batch, device-resident intermediates */
 int pg_compute_time_steps(pg_handle* h);              /* compute_time_steps!           model_predictive_control.jl:17-30 */
@@ -133,7 +140,7 @@ int pg_compute_linearization_nodes(pg_handle* h);     /* compute_linearization_n
 int pg_update_qp(pg_handle* h);                       /* update_QP!                    coupled_lat_long.jl:315-368 (+ HJI_computation.jl:160-170) */
 int pg_solve(pg_handle* h);                           /* solve!                        model_predictive_control.jl:76 */
 int pg_get_next_control(pg_handle* h, double* u_out); /* get_next_control              coupled_lat_long.jl:370-374; u_out [B][3] (delta,Fxf,Fxr), host */
-int pg_get_next_control_dev(pg_handle* h, double* u_out_dev);
+int pg_get_next_control_dev(pg_handle* h, pg_real_dev* u_out_dev);
 /* The control the ROS loop actually sends (src/ros_integration.jl:114-124): when the instance is in trajectory mode (time_offset not NaN),
  * use_hji_policy is set and the looked-up value V <= HJI_eps, the HJI fallback policy optimal_control(...) (src/HJI_computation.jl:133-158:
  * bang-bang steer + 50-point Fx line search) replaces get_next_control(mpc).  Call after pg_update_qp/pg_solve (it reuses that step's lookup).
@@ -141,19 +148,19 @@ int pg_get_next_control_dev(pg_handle* h, double* u_out_dev);
  * ("with a feather", :120-123); u2_policy [B][2] (may be NULL) = (delta_opt, Fx_opt) of optimal_control regardless of the selection.
  * Without a grid V = +Inf and the MPC control is returned.  Coupled formulation only. */
 int pg_get_next_control_hji(pg_handle* h, int32_t use_hji_policy, double* u_out, int32_t* source, double* u2_policy);
-int pg_get_next_control_hji_dev(pg_handle* h, int32_t use_hji_policy, double* u_out_dev, int32_t* source_dev);
+int pg_get_next_control_hji_dev(pg_handle* h, int32_t use_hji_policy, pg_real_dev* u_out_dev, int32_t* source_dev);
 
 /* all five for every instance: host buffers in, host buffers out (status/iters may be NULL) */
 int pg_step(pg_handle* h, int32_t B, const double* state, const double* control, const double* t0, const double* other_car,
             const double* time_offset, double* u_out, int32_t* status, int32_t* iters);
 /* the four compute phases + control extraction on the inputs last installed; nothing crosses PCIe.  u_out_dev may be NULL. */
-int pg_step_dev(pg_handle* h, double* u_out_dev);
+int pg_step_dev(pg_handle* h, pg_real_dev* u_out_dev);
 
 /* simulate(mpc, q0, u0, dt)  src/model_predictive_control.jl:80-100 for every instance, entirely on the device (no host round trip between
  * steps): per step  record -> the four compute calls -> state = propagate(dynamics, state, StepControl(dt, old control)) -> control = get_next_control
  * -> t += dt.  Starts from the inputs last installed (pg_set_inputs*: state, control, t0, time_offset) and leaves the final ones there
  * (pg_get_state reads them).  state_hist_dev [steps][B][6] / control_hist_dev [steps][B][3] may be NULL.  Asynchronous on the handle's stream. */
-int pg_simulate_dev(pg_handle* h, int32_t steps, double dt, double* state_hist_dev, double* control_hist_dev);
+int pg_simulate_dev(pg_handle* h, int32_t steps, double dt, pg_real_dev* state_hist_dev, pg_real_dev* control_hist_dev);
 /* current device-resident inputs: state [B][6], control [B][3], t0 [B] (host pointers, any may be NULL) */
 int pg_get_state(pg_handle* h, double* state, double* control, double* t0);
 
@@ -182,9 +189,9 @@ int pg_get_phase_ms(pg_handle* h, float out3[3]);
 
 /* cache[x] for a batch of relative states: HJI_computation.jl:66-72.  x7 [B][7] host; V [B], gradV [B][7] host.  Out of bounds => V=+Inf, gradV=0 */
 int pg_hji_lookup(pg_handle* h, int32_t B, const double* x7, double* V, double* gradV);
-int pg_hji_lookup_dev(pg_handle* h, int32_t B, const double* x7_dev, double* V_dev, double* gradV_dev);
+int pg_hji_lookup_dev(pg_handle* h, int32_t B, const pg_real_dev* x7_dev, pg_real_dev* V_dev, pg_real_dev* gradV_dev);
 /* packed form, no temporaries, asynchronous on the handle's stream: out8 [B][8] = (V, gradV[0..6]) per lookup (the kernel's native output) */
-int pg_hji_lookup8_dev(pg_handle* h, int32_t B, const double* x7_dev, double* out8_dev);
+int pg_hji_lookup8_dev(pg_handle* h, int32_t B, const pg_real_dev* x7_dev, pg_real_dev* out8_dev);
 /* compute_reachability_constraint for the installed inputs: M [B][2] (already multiplied by u_normalization), b [B], V [B] */
 int pg_get_hji_constraint(pg_handle* h, double* M, double* b, double* V);
 

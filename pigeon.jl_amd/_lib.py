@@ -3,8 +3,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpigeon_hip.so")
-_lib = None
+LIB_PATH = os.path.join(_HERE, "csrc", "libpigeon_hip.so")             # fp64 (the reference's arithmetic type)
+LIB_PATH_F32 = os.path.join(_HERE, "csrc", "libpigeon_hip_f32.so")     # fp32 build of the same sources (BASELINE configs 3/4)
+_libs = {}
 
 
 class PigeonError(RuntimeError):
@@ -29,30 +30,32 @@ class pg_config(C.Structure):
 
 
 # every symbol include/pigeon_mpc.h declares (tests check that the built library exports each one)
-SYMBOLS = ["pg_default_config", "pg_default_config_decoupled", "pg_create", "pg_destroy", "pg_last_error", "pg_get_config", "pg_get_u_normalization", "pg_set_trajectory", "pg_set_trajectories", "pg_set_trajectory_index",
+SYMBOLS = ["pg_precision_bits", "pg_default_config", "pg_default_config_decoupled", "pg_create", "pg_destroy", "pg_last_error", "pg_get_config", "pg_get_u_normalization", "pg_set_trajectory", "pg_set_trajectories", "pg_set_trajectory_index",
            "pg_set_hji_grid", "pg_clear_hji_grid", "pg_reset", "pg_set_inputs", "pg_set_inputs_dev", "pg_compute_time_steps",
            "pg_compute_linearization_nodes", "pg_update_qp", "pg_solve", "pg_get_next_control", "pg_get_next_control_dev", "pg_get_next_control_hji", "pg_get_next_control_hji_dev", "pg_step", "pg_step_dev", "pg_simulate_dev", "pg_get_state",
            "pg_set_stream", "pg_synchronize", "pg_get_time_steps", "pg_get_nodes", "pg_get_path_coordinates", "pg_qp_len", "pg_get_qp", "pg_get_solution",
            "pg_get_solve_info", "pg_get_phase_ms", "pg_hji_lookup", "pg_hji_lookup_dev", "pg_hji_lookup8_dev", "pg_get_hji_constraint"]
 
 
-def load_library():
-    """Loads the HIP library.  PyTorch-ROCm is imported first so that both share ONE HIP runtime in this process."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise PigeonError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)")
+def load_library(precision="f64"):
+    """Loads the HIP library of the requested arithmetic type.  PyTorch-ROCm is imported first so that both share ONE HIP runtime in this process."""
+    assert precision in ("f64", "f32")
+    if precision in _libs:
+        return _libs[precision]
+    path = LIB_PATH if precision == "f64" else LIB_PATH_F32
+    if not os.path.exists(path):
+        raise PigeonError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)")
     try:
         import torch  # noqa: F401  (plumbing: device memory / streams / torch.distributed live in the same HIP runtime)
     except Exception:
         pass
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     lib.pg_last_error.restype = C.c_char_p
     lib.pg_last_error.argtypes = [C.c_void_p]
     for s in SYMBOLS:
         getattr(lib, s)
-    _lib = lib
+    assert lib.pg_precision_bits() == (64 if precision == "f64" else 32)
+    _libs[precision] = lib
     return lib
 
 

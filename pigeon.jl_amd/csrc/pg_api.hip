@@ -18,19 +18,21 @@ struct pg_handle {
     hipStream_t stream = nullptr;
     std::string err;
     // device buffers
-    double *d_traj = nullptr; int traj_L = 0; int *d_traj_len = nullptr, *d_traj_idx = nullptr; int traj_idx_B = 0;
-    double *d_state = nullptr, *d_control = nullptr, *d_t0 = nullptr, *d_other = nullptr, *d_toff = nullptr;
+    real *d_traj = nullptr; int traj_L = 0; int *d_traj_len = nullptr, *d_traj_idx = nullptr; int traj_idx_B = 0;
+    real *d_state = nullptr, *d_control = nullptr, *d_other = nullptr;
+    double *d_t0 = nullptr, *d_toff = nullptr;            // absolute time stays fp64 in both builds (tdouble)
     int* d_solved = nullptr;
-    double *d_ts = nullptr, *d_dt = nullptr, *d_prev_ts = nullptr, *d_sep = nullptr, *d_nodes = nullptr, *d_qp = nullptr;
-    double *d_x7 = nullptr, *d_vg8 = nullptr, *d_Mb = nullptr, *d_abar = nullptr;
-    double *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
-    double *d_pol_u2 = nullptr, *d_pol_u = nullptr; int* d_pol_src = nullptr;   // HJI fallback policy (HJI_computation.jl:133-158)
+    double *d_ts = nullptr, *d_dt = nullptr, *d_prev_ts = nullptr;
+    real *d_sep = nullptr, *d_nodes = nullptr, *d_qp = nullptr;
+    real *d_x7 = nullptr, *d_vg8 = nullptr, *d_Mb = nullptr, *d_abar = nullptr;
+    real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
+    real *d_pol_u2 = nullptr, *d_pol_u = nullptr; int* d_pol_src = nullptr;   // HJI fallback policy (HJI_computation.jl:133-158)
     int *d_status = nullptr, *d_iters = nullptr; uint16_t* d_active = nullptr;
     // HJI grid
     HjiView hv; float *d_knots = nullptr, *d_hnodes = nullptr, *d_hcells = nullptr; bool has_hji = false;
     hipEvent_t ev[4]; bool ev_ok = false; float phase_ms[3] = {0, 0, 0}; bool timing_valid = false;
     size_t solve_lds = 0; bool solve_ring = false;
-    double* d_ws4 = nullptr; bool solve_quad = false; size_t solve4_lds = 0;   // k_solve4 (four instances per wavefront)
+    real* d_ws4 = nullptr; bool solve_quad = false; size_t solve4_lds = 0;   // k_solve4 (four instances per wavefront)
 };
 
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return PG_ERR_HIP; } } while (0)
@@ -38,6 +40,50 @@ struct pg_handle {
 #define REQUIRE(h, cond, msg) do { if (!(cond)) { if (h) (h)->err = (msg); return PG_ERR_INVALID; } } while (0)
 
 static std::string g_create_error;
+
+// Host <-> device transfers of path data.  The ABI speaks double on the host side; device buffers are `real` (double in libpigeon_hip.so,
+// float in libpigeon_hip_f32.so).  *_dev entry points take device pointers in the library's own element type (times are always double).
+static int up(pg_handle* h, real* dst, const double* src, size_t n) {            // returns after the host buffer has been consumed
+#ifdef PG_F32
+    std::vector<float> tmp(n);
+    for (size_t i = 0; i < n; i++) tmp[i] = (float)src[i];
+    HIPCHK(h, hipMemcpyAsync(dst, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+#else
+    HIPCHK(h, hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+#endif
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PG_OK;
+}
+static int down(pg_handle* h, double* dst, const real* src, size_t n) {          // returns after the copy has completed
+    if (!dst) return PG_OK;
+#ifdef PG_F32
+    std::vector<float> tmp(n);
+    HIPCHK(h, hipMemcpyAsync(tmp.data(), src, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < n; i++) dst[i] = (double)tmp[i];
+#else
+    HIPCHK(h, hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+#endif
+    return PG_OK;
+}
+static int down_raw(pg_handle* h, void* dst, const void* src, size_t bytes) {      // integer / time buffers: same type on both sides
+    if (!dst) return PG_OK;
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PG_OK;
+}
+static void fill_dev_params(DevCfg& C, const pg_config* cfg) {
+    const pg_vehicle& v = cfg->vehicle; DevVehicle& V = C.veh;
+    V.G = (real)v.G; V.m = (real)v.m; V.Izz = (real)v.Izz; V.L = (real)v.L; V.a = (real)v.a; V.b = (real)v.b; V.h = (real)v.h; V.mu = (real)v.mu;
+    V.Caf = (real)v.Caf; V.Car = (real)v.Car; V.Cd0 = (real)v.Cd0; V.Cd1 = (real)v.Cd1; V.Cd2 = (real)v.Cd2;
+    V.fwd_frac = (real)v.fwd_frac; V.rwd_frac = (real)v.rwd_frac; V.fwb_frac = (real)v.fwb_frac; V.rwb_frac = (real)v.rwb_frac;
+    V.Fx_max = (real)v.Fx_max; V.Fx_min = (real)v.Fx_min; V.Px_max = (real)v.Px_max; V.delta_max = (real)v.delta_max; V.kappa_max = (real)v.kappa_max;
+    const pg_control_params& u = cfg->control; DevControl& U = C.cp;
+    U.V_min = (real)u.V_min; U.V_max = (real)u.V_max; U.k_V = (real)u.k_V; U.k_s = (real)u.k_s; U.deltadot_max = (real)u.deltadot_max;
+    U.Q_ds = (real)u.Q_ds; U.Q_dpsi = (real)u.Q_dpsi; U.Q_e = (real)u.Q_e; U.W_beta = (real)u.W_beta; U.W_r = (real)u.W_r; U.W_HJI = (real)u.W_HJI;
+    U.R_delta = (real)u.R_delta; U.R_ddelta = (real)u.R_ddelta; U.R_Fx = (real)u.R_Fx; U.R_dFx = (real)u.R_dFx; U.N_HJI = u.N_HJI;
+}
 
 extern "C" {
 
@@ -99,31 +145,31 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     pg_handle* h = new pg_handle();
     h->cfg = *cfg;
     DevCfg& C = h->dc; memset(&C, 0, sizeof(C));
-    C.veh = cfg->vehicle; C.cp = cfg->control; C.Ns = cfg->N_short; C.Nl = cfg->N_long; C.N = C.Ns + C.Nl; C.NN = C.N + 1;
+    fill_dev_params(C, cfg); C.Ns = cfg->N_short; C.Nl = cfg->N_long; C.N = C.Ns + C.Nl; C.NN = C.N + 1;
     C.dt_short = cfg->dt_short; C.dt_long = cfg->dt_long; C.use_correction_step = cfg->use_correction_step; C.nsub = cfg->rk4_substeps;
-    C.alias_prev_ts = 1; C.has_hji = 0; C.hji_eps = cfg->hji_eps;
-    C.un0 = cfg->vehicle.delta_max; C.un1 = fmax(-cfg->vehicle.Fx_min, cfg->vehicle.Fx_max);      // coupled_lat_long.jl:199
-    C.fxmin_n = cfg->vehicle.Fx_min / C.un1;
-    C.formulation = cfg->formulation; C.ux_dummy = 0.5 * (cfg->control.V_min + cfg->control.V_max);
+    C.alias_prev_ts = 1; C.has_hji = 0; C.hji_eps = (real)cfg->hji_eps;
+    C.un0 = (real)cfg->vehicle.delta_max; C.un1 = (real)fmax(-cfg->vehicle.Fx_min, cfg->vehicle.Fx_max);      // coupled_lat_long.jl:199
+    C.fxmin_n = (real)(cfg->vehicle.Fx_min / fmax(-cfg->vehicle.Fx_min, cfg->vehicle.Fx_max));
+    C.formulation = cfg->formulation; C.ux_dummy = (real)(0.5 * (cfg->control.V_min + cfg->control.V_max));
     C.dbg_instance = -1; if (const char* e = getenv("PG_DEBUG_INSTANCE")) C.dbg_instance = atoi(e);
     if (cfg->formulation == PG_DECOUPLED) {          // no u normalisation in the lateral QP (decoupled_lat_long.jl:134-226); inert slots pinned
         C.un0 = 1.0; C.un1 = 1.0; C.fxmin_n = -1.0;
         C.cp.Q_ds = 0.0; C.cp.R_Fx = 0.0; C.cp.R_dFx = 1.0; C.cp.N_HJI = 0; C.cp.W_HJI = 0.0;
     }
     C.qp_len = 84 * C.N + 11;
-    C.ipm_max_iter = cfg->ipm_max_iter; C.ipm_tol = cfg->ipm_tol; C.ipm_mu0 = cfg->ipm_mu0;
+    C.ipm_max_iter = cfg->ipm_max_iter; C.ipm_tol = (real)cfg->ipm_tol; C.ipm_mu0 = (real)cfg->ipm_mu0;
     const size_t cap = (size_t)cfg->batch_capacity; const int N = C.N, NN = C.NN;
 #define ALLOC(ptr, count, type) do { if (hipMalloc((void**)&(ptr), (size_t)(count) * sizeof(type)) != hipSuccess) { g_create_error = "hipMalloc failed for " #ptr; free_all(h); delete h; return PG_ERR_HIP; } } while (0)
-    ALLOC(h->d_state, cap * 6, double); ALLOC(h->d_control, cap * 3, double); ALLOC(h->d_t0, cap, double); ALLOC(h->d_other, cap * 4, double); ALLOC(h->d_toff, cap, double);
+    ALLOC(h->d_state, cap * 6, real); ALLOC(h->d_control, cap * 3, real); ALLOC(h->d_t0, cap, double); ALLOC(h->d_other, cap * 4, real); ALLOC(h->d_toff, cap, double);
     ALLOC(h->d_solved, cap, int); ALLOC(h->d_ts, cap * NN, double); ALLOC(h->d_dt, cap * N, double); ALLOC(h->d_prev_ts, cap * NN, double);
-    ALLOC(h->d_sep, cap * 4, double); ALLOC(h->d_nodes, cap * NN * 10, double); ALLOC(h->d_qp, cap * C.qp_len, double);
-    ALLOC(h->d_abar, cap * N * SB, double);
-    ALLOC(h->d_x7, cap * 7, double); ALLOC(h->d_vg8, cap * 8, double); ALLOC(h->d_Mb, cap * 4, double);
-    ALLOC(h->d_solx, cap * NN * 8, double); ALLOC(h->d_sigma, cap * N * 3, double); ALLOC(h->d_u, cap * 3, double); ALLOC(h->d_mu, cap, double);
+    ALLOC(h->d_sep, cap * 4, real); ALLOC(h->d_nodes, cap * NN * 10, real); ALLOC(h->d_qp, cap * C.qp_len, real);
+    ALLOC(h->d_abar, cap * N * SB, real);
+    ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
+    ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_u, cap * 3, real); ALLOC(h->d_mu, cap, real);
     ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_active, cap * N, uint16_t);
     { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (pg_solve4.hip)
-    if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), double);
-    ALLOC(h->d_pol_u2, cap * 2, double); ALLOC(h->d_pol_u, cap * 3, double); ALLOC(h->d_pol_src, cap, int);
+    if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), real);
+    ALLOC(h->d_pol_u2, cap * 2, real); ALLOC(h->d_pol_u, cap * 3, real); ALLOC(h->d_pol_src, cap, int);
 #undef ALLOC
     // initial ts = 1..NN (model_predictive_control.jl:13), solved = false
     {
@@ -133,15 +179,15 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         (void)hipMemcpy(h->d_prev_ts, ts.data(), ts.size() * 8, hipMemcpyHostToDevice);
         (void)hipMemcpy(h->d_dt, dt.data(), dt.size() * 8, hipMemcpyHostToDevice);
         (void)hipMemset(h->d_solved, 0, cap * sizeof(int));
-        (void)hipMemset(h->d_other, 0, cap * 4 * 8);
-        (void)hipMemset(h->d_solx, 0, cap * NN * 8 * 8);
+        (void)hipMemset(h->d_other, 0, cap * 4 * sizeof(real));
+        (void)hipMemset(h->d_solx, 0, cap * NN * 8 * sizeof(real));
     }
     for (int i = 0; i < 4; i++) if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_create_error = "hipEventCreate failed"; free_all(h); delete h; return PG_ERR_HIP; }
     h->ev_ok = true;
     // horizons up to 32 intervals keep their dynamics blocks resident in LDS (one pass over the QP data); longer ones stream them through a 4-slot ring
     h->solve_ring = N > 32;
     h->solve4_lds = lds4_bytes(N);
-    h->solve_lds = (size_t)((h->solve_ring ? 4 : N) * SB + 10 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 72 + 100 + 8 + 64 + 2) * sizeof(double);
+    h->solve_lds = (size_t)((h->solve_ring ? 4 : N) * SB + 10 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 72 + 100 + 8 + 64 + 2) * sizeof(real);
     if (h->solve_lds > 160 * 1024) { g_create_error = "horizon too long for LDS staging"; free_all(h); delete h; return PG_ERR_INVALID; }
     if (h->solve_lds > 48 * 1024)
     {
@@ -156,7 +202,13 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
 
 int pg_destroy(pg_handle* h) { if (!h) return PG_ERR_INVALID; (void)hipSetDevice(h->cfg.device); free_all(h); delete h; return PG_OK; }
 int pg_get_config(const pg_handle* h, pg_config* out) { if (!h || !out) return PG_ERR_INVALID; *out = h->cfg; return PG_OK; }
-int pg_get_u_normalization(const pg_handle* h, double out[2]) { if (!h || !out) return PG_ERR_INVALID; out[0] = h->dc.un0; out[1] = h->dc.un1; return PG_OK; }
+int pg_get_u_normalization(const pg_handle* h, double out[2]) {
+    if (!h || !out) return PG_ERR_INVALID;
+    const bool dec = h->cfg.formulation == PG_DECOUPLED;      // reported in full precision (the host de-normalises with it)
+    out[0] = dec ? 1.0 : h->cfg.vehicle.delta_max; out[1] = dec ? 1.0 : fmax(-h->cfg.vehicle.Fx_min, h->cfg.vehicle.Fx_max);
+    return PG_OK;
+}
+int pg_precision_bits(void) { return (int)(8 * sizeof(real)); }
 int pg_qp_len(const pg_handle* h) { return h ? h->dc.qp_len : PG_ERR_INVALID; }
 int pg_set_stream(pg_handle* h, void* s) { if (!h) return PG_ERR_INVALID; h->stream = (hipStream_t)s; return PG_OK; }
 int pg_synchronize(pg_handle* h) { if (!h) return PG_ERR_INVALID; HIPCHK(h, hipStreamSynchronize(h->stream)); return PG_OK; }
@@ -170,12 +222,12 @@ static int install_trajectories(pg_handle* h, int n_traj, int Lmax, const int32_
     if (h->d_traj_idx) { (void)hipFree(h->d_traj_idx); h->d_traj_idx = nullptr; }
     h->traj_idx_B = 0;
     const size_t stride = (size_t)10 * Lmax;
-    HIPCHK(h, hipMalloc((void**)&h->d_traj, (size_t)n_traj * stride * sizeof(double)));
-    HIPCHK(h, hipMemcpy(h->d_traj, channels, (size_t)n_traj * stride * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMalloc((void**)&h->d_traj, (size_t)n_traj * stride * sizeof(real)));
+    { int rc = up(h, h->d_traj, channels, (size_t)n_traj * stride); if (rc) return rc; }
     HIPCHK(h, hipMalloc((void**)&h->d_traj_len, (size_t)n_traj * sizeof(int)));
     HIPCHK(h, hipMemcpy(h->d_traj_len, L, (size_t)n_traj * sizeof(int), hipMemcpyHostToDevice));
     TrajView& T = h->dc.traj; T.L = L[0];
-    const double* p = h->d_traj; const size_t c = (size_t)Lmax;
+    const real* p = h->d_traj; const size_t c = (size_t)Lmax;
     T.t = p; T.s = p + c; T.V = p + 2 * c; T.A = p + 3 * c; T.E = p + 4 * c; T.N = p + 5 * c; T.psi = p + 6 * c; T.kappa = p + 7 * c; T.edge_L = p + 8 * c; T.edge_R = p + 9 * c;
     h->dc.n_traj = n_traj; h->dc.traj_stride = (long)stride; h->dc.traj_len = h->d_traj_len; h->dc.traj_idx = nullptr;
     h->traj_L = L[0];
@@ -284,27 +336,34 @@ int pg_reset(pg_handle* h, const uint8_t* mask) {
     return PG_OK;
 }
 
-static int set_inputs(pg_handle* h, int32_t B, const double* state, const double* control, const double* t0, const double* other, const double* toff, hipMemcpyKind kind) {
+static int set_inputs(pg_handle* h, int32_t B, const void* state, const void* control, const double* t0, const void* other, const double* toff, bool host) {
     if (!h) return PG_ERR_INVALID;
     REQUIRE(h, B >= 1 && B <= h->cfg.batch_capacity, "batch size outside [1, batch_capacity]");
     REQUIRE(h, state && control && t0, "state, control and t0 are required");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     h->B = B;
-    HIPCHK(h, hipMemcpyAsync(h->d_state, state, (size_t)B * 6 * 8, kind, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_control, control, (size_t)B * 3 * 8, kind, h->stream));
+    const hipMemcpyKind kind = host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    int rc;
+    if (host) {
+        if ((rc = up(h, h->d_state, (const double*)state, (size_t)B * 6)) || (rc = up(h, h->d_control, (const double*)control, (size_t)B * 3))) return rc;
+        if (other && (rc = up(h, h->d_other, (const double*)other, (size_t)B * 4))) return rc;
+    } else {
+        HIPCHK(h, hipMemcpyAsync(h->d_state, state, (size_t)B * 6 * sizeof(real), kind, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_control, control, (size_t)B * 3 * sizeof(real), kind, h->stream));
+        if (other) HIPCHK(h, hipMemcpyAsync(h->d_other, other, (size_t)B * 4 * sizeof(real), kind, h->stream));
+    }
+    if (!other) HIPCHK(h, hipMemsetAsync(h->d_other, 0, (size_t)B * 4 * sizeof(real), h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_t0, t0, (size_t)B * 8, kind, h->stream));
-    if (other) HIPCHK(h, hipMemcpyAsync(h->d_other, other, (size_t)B * 4 * 8, kind, h->stream));
-    else HIPCHK(h, hipMemsetAsync(h->d_other, 0, (size_t)B * 4 * 8, h->stream));
     if (toff) HIPCHK(h, hipMemcpyAsync(h->d_toff, toff, (size_t)B * 8, kind, h->stream));
     else HIPCHK(h, hipMemsetAsync(h->d_toff, 0xFF, (size_t)B * 8, h->stream));      // all-ones bit pattern is a NaN: path-tracking mode
-    if (kind == hipMemcpyHostToDevice) HIPCHK(h, hipStreamSynchronize(h->stream));  // host buffers may be reused by the caller
+    if (host) HIPCHK(h, hipStreamSynchronize(h->stream));                           // host buffers may be reused by the caller
     return PG_OK;
 }
 int pg_set_inputs(pg_handle* h, int32_t B, const double* state, const double* control, const double* t0, const double* other, const double* toff) {
-    return set_inputs(h, B, state, control, t0, other, toff, hipMemcpyHostToDevice);
+    return set_inputs(h, B, state, control, t0, other, toff, true);
 }
-int pg_set_inputs_dev(pg_handle* h, int32_t B, const double* state, const double* control, const double* t0, const double* other, const double* toff) {
-    return set_inputs(h, B, state, control, t0, other, toff, hipMemcpyDeviceToDevice);
+int pg_set_inputs_dev(pg_handle* h, int32_t B, const void* state, const void* control, const double* t0, const void* other, const double* toff) {
+    return set_inputs(h, B, state, control, t0, other, toff, false);
 }
 
 static int check_ready(pg_handle* h) {
@@ -329,7 +388,7 @@ int pg_compute_linearization_nodes(pg_handle* h) {
     hipLaunchKernelGGL(k_project, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep);
     LAUNCH_CHECK(h);
     const bool staged = h->dc.n_traj == 1 && h->traj_L <= 2048;
-    const size_t traj_lds = staged ? (size_t)2 * h->traj_L * sizeof(double) : 0;
+    const size_t traj_lds = staged ? (size_t)2 * h->traj_L * sizeof(real) : 0;
     const dim3 grid((B + 63) / 64), block(64);
     if (h->dc.formulation == PG_DECOUPLED) {
         auto kern = staged ? k_nodes_dec<true> : k_nodes_dec<false>;
@@ -342,7 +401,7 @@ int pg_compute_linearization_nodes(pg_handle* h) {
     LAUNCH_CHECK(h);
     return PG_OK;
 }
-static int launch_hji_lookup(pg_handle* h, int B, const double* x7_dev, double* out8_dev) {
+static int launch_hji_lookup(pg_handle* h, int B, const real* x7_dev, real* out8_dev) {
     dim3 grid((unsigned)(((size_t)B * 16 + 255) / 256));
     if (h->hv.cdims == 7) hipLaunchKernelGGL(k_hji_lookup<7>, grid, dim3(256), 0, h->stream, h->hv, B, x7_dev, out8_dev);
     else if (h->hv.cdims == 5) hipLaunchKernelGGL(k_hji_lookup<5>, grid, dim3(256), 0, h->stream, h->hv, B, x7_dev, out8_dev);
@@ -399,36 +458,34 @@ int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     (void)hipFree(d);
     return PG_OK;
 }
-int pg_get_next_control_dev(pg_handle* h, double* u_out_dev) {
+int pg_get_next_control_dev(pg_handle* h, void* u_out_dev) {
     int rc = check_ready(h); if (rc) return rc;
-    if (u_out_dev) HIPCHK(h, hipMemcpyAsync(u_out_dev, h->d_u, (size_t)h->B * 3 * 8, hipMemcpyDeviceToDevice, h->stream));
+    if (u_out_dev) HIPCHK(h, hipMemcpyAsync(u_out_dev, h->d_u, (size_t)h->B * 3 * sizeof(real), hipMemcpyDeviceToDevice, h->stream));
     return PG_OK;
 }
 int pg_get_next_control(pg_handle* h, double* u_out) {
     int rc = check_ready(h); if (rc) return rc;
     REQUIRE(h, u_out, "u_out is null");
-    HIPCHK(h, hipMemcpyAsync(u_out, h->d_u, (size_t)h->B * 3 * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return PG_OK;
+    return down(h, u_out, h->d_u, (size_t)h->B * 3);
 }
 // ros_integration.jl:114-124: the HJI fallback policy takes the wheel when the value function says the situation is unsafe
 static int launch_hji_policy(pg_handle* h, int use_policy) {
     const int B = h->B;
     if (h->dc.formulation != PG_COUPLED) { h->err = "the HJI policy belongs to the coupled controller (ros_integration.jl:56,114)"; return PG_ERR_STATE; }
     if (!h->has_hji) {                      // no grid: V = +Inf everywhere, the MPC control always wins
-        HIPCHK(h, hipMemcpyAsync(h->d_pol_u, h->d_u, (size_t)B * 3 * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_pol_u, h->d_u, (size_t)B * 3 * sizeof(real), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_pol_src, 0, (size_t)B * sizeof(int), h->stream));
-        HIPCHK(h, hipMemsetAsync(h->d_pol_u2, 0, (size_t)B * 2 * 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_pol_u2, 0, (size_t)B * 2 * sizeof(real), h->stream));
         return PG_OK;
     }
     hipLaunchKernelGGL(k_hji_policy, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, use_policy, h->d_x7, h->d_vg8, h->d_toff, h->d_u, h->d_pol_u2, h->d_pol_u, h->d_pol_src);
     LAUNCH_CHECK(h);
     return PG_OK;
 }
-int pg_get_next_control_hji_dev(pg_handle* h, int32_t use_hji_policy, double* u_out_dev, int32_t* source_dev) {
+int pg_get_next_control_hji_dev(pg_handle* h, int32_t use_hji_policy, void* u_out_dev, int32_t* source_dev) {
     int rc = check_ready(h); if (rc) return rc;
     if ((rc = launch_hji_policy(h, use_hji_policy))) return rc;
-    if (u_out_dev) HIPCHK(h, hipMemcpyAsync(u_out_dev, h->d_pol_u, (size_t)h->B * 3 * 8, hipMemcpyDeviceToDevice, h->stream));
+    if (u_out_dev) HIPCHK(h, hipMemcpyAsync(u_out_dev, h->d_pol_u, (size_t)h->B * 3 * sizeof(real), hipMemcpyDeviceToDevice, h->stream));
     if (source_dev) HIPCHK(h, hipMemcpyAsync(source_dev, h->d_pol_src, (size_t)h->B * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
     return PG_OK;
 }
@@ -436,13 +493,11 @@ int pg_get_next_control_hji(pg_handle* h, int32_t use_hji_policy, double* u_out,
     int rc = check_ready(h); if (rc) return rc;
     REQUIRE(h, u_out, "u_out is null");
     if ((rc = launch_hji_policy(h, use_hji_policy))) return rc;
-    HIPCHK(h, hipMemcpyAsync(u_out, h->d_pol_u, (size_t)h->B * 3 * 8, hipMemcpyDeviceToHost, h->stream));
-    if (source) HIPCHK(h, hipMemcpyAsync(source, h->d_pol_src, (size_t)h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    if (u2_policy) HIPCHK(h, hipMemcpyAsync(u2_policy, h->d_pol_u2, (size_t)h->B * 2 * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((rc = down(h, u_out, h->d_pol_u, (size_t)h->B * 3)) || (rc = down_raw(h, source, h->d_pol_src, (size_t)h->B * sizeof(int))) ||
+        (rc = down(h, u2_policy, h->d_pol_u2, (size_t)h->B * 2))) return rc;
     return PG_OK;
 }
-int pg_step_dev(pg_handle* h, double* u_out_dev) {
+int pg_step_dev(pg_handle* h, void* u_out_dev) {
     int rc = check_ready(h); if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     if ((rc = pg_compute_time_steps(h))) return rc;
@@ -456,18 +511,14 @@ int pg_step_dev(pg_handle* h, double* u_out_dev) {
     h->timing_valid = true;
     return PG_OK;
 }
-static int d2h(pg_handle* h, void* dst, const void* src, size_t bytes) {
-    if (!dst) return PG_OK;
-    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
-    return PG_OK;
-}
-int pg_simulate_dev(pg_handle* h, int32_t steps, double dt, double* state_hist_dev, double* control_hist_dev) {
+int pg_simulate_dev(pg_handle* h, int32_t steps, double dt, void* state_hist_dev_, void* control_hist_dev_) {
     int rc = check_ready(h); if (rc) return rc;
     REQUIRE(h, steps >= 1 && dt > 0.0, "pg_simulate_dev: steps >= 1 and dt > 0 required");
     const int B = h->B;
+    real* state_hist_dev = (real*)state_hist_dev_; real* control_hist_dev = (real*)control_hist_dev_;
     for (int k = 0; k < steps; k++) {
-        if (state_hist_dev) HIPCHK(h, hipMemcpyAsync(state_hist_dev + (size_t)k * B * 6, h->d_state, (size_t)B * 6 * 8, hipMemcpyDeviceToDevice, h->stream));      // push!(qs, state) :88
-        if (control_hist_dev) HIPCHK(h, hipMemcpyAsync(control_hist_dev + (size_t)k * B * 3, h->d_control, (size_t)B * 3 * 8, hipMemcpyDeviceToDevice, h->stream)); // push!(us, control) :89
+        if (state_hist_dev) HIPCHK(h, hipMemcpyAsync(state_hist_dev + (size_t)k * B * 6, h->d_state, (size_t)B * 6 * sizeof(real), hipMemcpyDeviceToDevice, h->stream));      // push!(qs, state) :88
+        if (control_hist_dev) HIPCHK(h, hipMemcpyAsync(control_hist_dev + (size_t)k * B * 3, h->d_control, (size_t)B * 3 * sizeof(real), hipMemcpyDeviceToDevice, h->stream)); // push!(us, control) :89
         if ((rc = pg_compute_time_steps(h)) || (rc = pg_compute_linearization_nodes(h)) || (rc = pg_update_qp(h)) || (rc = pg_solve(h))) return rc;          // :90-93
         hipLaunchKernelGGL(k_advance, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, dt, h->d_state, h->d_control, h->d_u, h->d_t0);                  // :94-95
         LAUNCH_CHECK(h);
@@ -477,8 +528,7 @@ int pg_simulate_dev(pg_handle* h, int32_t steps, double dt, double* state_hist_d
 int pg_get_state(pg_handle* h, double* state, double* control, double* t0) {
     int rc = check_ready(h); if (rc) return rc;
     const size_t B = h->B;
-    if ((rc = d2h(h, state, h->d_state, B * 6 * 8)) || (rc = d2h(h, control, h->d_control, B * 3 * 8)) || (rc = d2h(h, t0, h->d_t0, B * 8))) return rc;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((rc = down(h, state, h->d_state, B * 6)) || (rc = down(h, control, h->d_control, B * 3)) || (rc = down_raw(h, t0, h->d_t0, B * 8))) return rc;
     return PG_OK;
 }
 int pg_get_phase_ms(pg_handle* h, float out3[3]) {
@@ -503,16 +553,14 @@ int pg_step(pg_handle* h, int32_t B, const double* state, const double* control,
 int pg_get_time_steps(pg_handle* h, double* ts, double* dt, double* prev_ts) {
     int rc = check_ready(h); if (rc) return rc;
     const size_t B = h->B; const DevCfg& C = h->dc;
-    if ((rc = d2h(h, ts, h->d_ts, B * C.NN * 8)) || (rc = d2h(h, dt, h->d_dt, B * C.N * 8)) || (rc = d2h(h, prev_ts, h->d_prev_ts, B * C.NN * 8))) return rc;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((rc = down_raw(h, ts, h->d_ts, B * C.NN * 8)) || (rc = down_raw(h, dt, h->d_dt, B * C.N * 8)) || (rc = down_raw(h, prev_ts, h->d_prev_ts, B * C.NN * 8))) return rc;
     return PG_OK;
 }
 int pg_get_nodes(pg_handle* h, double* qs, double* us, double* ps) {
     int rc = check_ready(h); if (rc) return rc;
     const size_t B = h->B; const DevCfg& C = h->dc;
     std::vector<double> nd(B * C.NN * 10);
-    HIPCHK(h, hipMemcpyAsync(nd.data(), h->d_nodes, nd.size() * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((rc = down(h, nd.data(), h->d_nodes, nd.size()))) return rc;
     for (size_t i = 0; i < B * C.NN; i++) {
         const double* r = &nd[i * 10];
         if (qs) for (int k = 0; k < 6; k++) qs[i * 6 + k] = r[k];
@@ -526,38 +574,33 @@ int pg_get_path_coordinates(pg_handle* h, double* sep) {
     REQUIRE(h, sep, "sep is null");
     const size_t B = h->B;
     std::vector<double> s4(B * 4);
-    HIPCHK(h, hipMemcpyAsync(s4.data(), h->d_sep, s4.size() * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((rc = down(h, s4.data(), h->d_sep, s4.size()))) return rc;
     for (size_t b = 0; b < B; b++) for (int k = 0; k < 3; k++) sep[b * 3 + k] = s4[b * 4 + k];
     return PG_OK;
 }
 int pg_get_qp(pg_handle* h, int32_t b0, int32_t n, double* out) {
     int rc = check_ready(h); if (rc) return rc;
     REQUIRE(h, out && b0 >= 0 && n >= 1 && b0 + n <= h->B, "pg_get_qp: range outside the batch");
-    HIPCHK(h, hipMemcpyAsync(out, h->d_qp + (size_t)b0 * h->dc.qp_len, (size_t)n * h->dc.qp_len * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return PG_OK;
+    return down(h, out, h->d_qp + (size_t)b0 * h->dc.qp_len, (size_t)n * h->dc.qp_len);
 }
 int pg_get_solution(pg_handle* h, double* x, double* sigma) {
     int rc = check_ready(h); if (rc) return rc;
     const size_t B = h->B; const DevCfg& C = h->dc;
-    if ((rc = d2h(h, x, h->d_solx, B * C.NN * 8 * 8)) || (rc = d2h(h, sigma, h->d_sigma, B * C.N * 3 * 8))) return rc;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((rc = down(h, x, h->d_solx, B * C.NN * 8)) || (rc = down(h, sigma, h->d_sigma, B * C.N * 3))) return rc;
     return PG_OK;
 }
 int pg_get_solve_info(pg_handle* h, int32_t* status, int32_t* iters, uint16_t* active, double* mu) {
     int rc = check_ready(h); if (rc) return rc;
     const size_t B = h->B; const DevCfg& C = h->dc;
-    if ((rc = d2h(h, status, h->d_status, B * 4)) || (rc = d2h(h, iters, h->d_iters, B * 4)) || (rc = d2h(h, active, h->d_active, B * C.N * 2)) ||
-        (rc = d2h(h, mu, h->d_mu, B * 8))) return rc;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((rc = down_raw(h, status, h->d_status, B * 4)) || (rc = down_raw(h, iters, h->d_iters, B * 4)) || (rc = down_raw(h, active, h->d_active, B * C.N * 2)) ||
+        (rc = down(h, mu, h->d_mu, B))) return rc;
     return PG_OK;
 }
 int pg_get_hji_constraint(pg_handle* h, double* M, double* b, double* V) {
     int rc = check_ready(h); if (rc) return rc;
     const size_t B = h->B;
     std::vector<double> mb(B * 4);
-    if (h->has_hji) { HIPCHK(h, hipMemcpyAsync(mb.data(), h->d_Mb, mb.size() * 8, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream)); }
+    if (h->has_hji && (rc = down(h, mb.data(), h->d_Mb, mb.size()))) return rc;
     for (size_t i = 0; i < B; i++) {
         if (!h->has_hji) { mb[4 * i] = 0; mb[4 * i + 1] = 0; mb[4 * i + 2] = 1; mb[4 * i + 3] = INFINITY; }
         if (M) { M[2 * i] = mb[4 * i]; M[2 * i + 1] = mb[4 * i + 1]; }
@@ -567,43 +610,42 @@ int pg_get_hji_constraint(pg_handle* h, double* M, double* b, double* V) {
     return PG_OK;
 }
 
-int pg_hji_lookup_dev(pg_handle* h, int32_t B, const double* x7_dev, double* V_dev, double* gradV_dev) {
+int pg_hji_lookup_dev(pg_handle* h, int32_t B, const void* x7_dev, void* V_dev, void* gradV_dev) {
     if (!h) return PG_ERR_INVALID;
     REQUIRE(h, h->has_hji, "no HJI grid installed");
     REQUIRE(h, B >= 1 && x7_dev, "pg_hji_lookup_dev: bad arguments");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    double* out8 = nullptr;
-    HIPCHK(h, hipMalloc((void**)&out8, (size_t)B * 8 * 8));
-    int rc = launch_hji_lookup(h, B, x7_dev, out8);
+    real* out8 = nullptr; const size_t R = sizeof(real);
+    HIPCHK(h, hipMalloc((void**)&out8, (size_t)B * 8 * R));
+    int rc = launch_hji_lookup(h, B, (const real*)x7_dev, out8);
     if (!rc) {
-        if (V_dev) HIPCHK(h, hipMemcpy2DAsync(V_dev, 8, out8, 64, 8, B, hipMemcpyDeviceToDevice, h->stream));
-        if (gradV_dev) HIPCHK(h, hipMemcpy2DAsync(gradV_dev, 56, out8 + 1, 64, 56, B, hipMemcpyDeviceToDevice, h->stream));
+        if (V_dev) HIPCHK(h, hipMemcpy2DAsync(V_dev, R, out8, 8 * R, R, B, hipMemcpyDeviceToDevice, h->stream));
+        if (gradV_dev) HIPCHK(h, hipMemcpy2DAsync(gradV_dev, 7 * R, out8 + 1, 8 * R, 7 * R, B, hipMemcpyDeviceToDevice, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     (void)hipFree(out8);
     return rc;
 }
-int pg_hji_lookup8_dev(pg_handle* h, int32_t B, const double* x7_dev, double* out8_dev) {
+int pg_hji_lookup8_dev(pg_handle* h, int32_t B, const void* x7_dev, void* out8_dev) {
     if (!h) return PG_ERR_INVALID;
     REQUIRE(h, h->has_hji, "no HJI grid installed");
     REQUIRE(h, B >= 1 && x7_dev && out8_dev, "pg_hji_lookup8_dev: bad arguments");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    return launch_hji_lookup(h, B, x7_dev, out8_dev);
+    return launch_hji_lookup(h, B, (const real*)x7_dev, (real*)out8_dev);
 }
 int pg_hji_lookup(pg_handle* h, int32_t B, const double* x7, double* V, double* gradV) {
     if (!h) return PG_ERR_INVALID;
     REQUIRE(h, h->has_hji, "no HJI grid installed");
     REQUIRE(h, B >= 1 && x7, "pg_hji_lookup: bad arguments");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    double *dx = nullptr, *dout = nullptr;
-    HIPCHK(h, hipMalloc((void**)&dx, (size_t)B * 7 * 8));
-    HIPCHK(h, hipMalloc((void**)&dout, (size_t)B * 8 * 8));
-    HIPCHK(h, hipMemcpyAsync(dx, x7, (size_t)B * 7 * 8, hipMemcpyHostToDevice, h->stream));
-    int rc = launch_hji_lookup(h, B, dx, dout);
+    real *dx = nullptr, *dout = nullptr;
+    HIPCHK(h, hipMalloc((void**)&dx, (size_t)B * 7 * sizeof(real)));
+    HIPCHK(h, hipMalloc((void**)&dout, (size_t)B * 8 * sizeof(real)));
+    int rc = up(h, dx, x7, (size_t)B * 7);
+    if (!rc) rc = launch_hji_lookup(h, B, dx, dout);
     std::vector<double> out((size_t)B * 8);
+    if (!rc) rc = down(h, out.data(), dout, out.size());
     if (!rc) {
-        HIPCHK(h, hipMemcpyAsync(out.data(), dout, out.size() * 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
         for (int i = 0; i < B; i++) { if (V) V[i] = out[8 * (size_t)i]; if (gradV) for (int k = 0; k < 7; k++) gradV[7 * (size_t)i + k] = out[8 * (size_t)i + 1 + k]; }
     }
     (void)hipFree(dx); (void)hipFree(dout);

@@ -9,6 +9,37 @@
 
 namespace pg {
 
+// PG_KEEP_BEGIN
+// Precision of the path arithmetic.  These sources are written in fp64.  The fp32 library (libpigeon_hip_f32.so, BASELINE configs 3/4) is
+// compiled from a GENERATED copy (tools/gen_f32_sources.py) in which every `double` reads `real` (= float) and every floating literal is
+// wrapped in real(...); blocks between PG_KEEP markers are copied verbatim.  `tdouble` marks the few quantities that stay fp64 in both
+// builds: absolute time (the time grid's ceil() lattice must not depend on the arithmetic type of the QP).
+#ifdef PG_F32
+typedef float real; typedef float2 real2;
+#define PG_BIG 1e30f
+#else
+typedef double real; typedef double2 real2;
+#define PG_BIG 1e300
+#endif
+typedef double tdouble;
+// device-side mirrors of pg_vehicle / pg_control_params (include/pigeon_mpc.h) in the arithmetic type of the build
+struct DevVehicle { real G, m, Izz, L, a, b, h, mu, Caf, Car, Cd0, Cd1, Cd2, fwd_frac, rwd_frac, fwb_frac, rwb_frac, Fx_max, Fx_min, Px_max, delta_max, kappa_max; };
+struct DevControl { real V_min, V_max, k_V, k_s, deltadot_max, Q_ds, Q_dpsi, Q_e, W_beta, W_r, W_HJI, R_delta, R_ddelta, R_Fx, R_dFx; int N_HJI; };
+// reciprocal: hardware seed + Newton steps (~1 ulp); the IEEE division sequence costs ~5x more issue slots
+#ifdef PG_F32
+PG_DEV float frcp(float x) { float r = __builtin_amdgcn_rcpf(x); float e = fmaf(-x, r, 1.0f); return fmaf(r, e, r); }
+PG_DEV void pg_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+#else
+PG_DEV double frcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0); r = fma(r, e, r);
+    e = fma(-x, r, 1.0); r = fma(r, e, r);
+    return r;
+}
+PG_DEV void pg_sincos(double x, double* s, double* c) { sincos(x, s, c); }
+#endif
+// PG_KEEP_END
+
 // ---- two-tangent forward-mode number (stands in for ForwardDiff.Dual inside `linearize` and HJI_computation.jl:167) ----
 struct D2 {
     double v, a, b;
@@ -20,13 +51,6 @@ PG_DEV D2 operator+(D2 x, D2 y) { return D2(x.v + y.v, x.a + y.a, x.b + y.b); }
 PG_DEV D2 operator-(D2 x, D2 y) { return D2(x.v - y.v, x.a - y.a, x.b - y.b); }
 PG_DEV D2 operator-(D2 x) { return D2(-x.v, -x.a, -x.b); }
 PG_DEV D2 operator*(D2 x, D2 y) { return D2(x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b); }
-// reciprocal: v_rcp_f64 seed + two Newton steps (~1 ulp); the IEEE division sequence costs ~5x more issue slots
-PG_DEV double frcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, r, 1.0); r = fma(r, e, r);
-    e = fma(-x, r, 1.0); r = fma(r, e, r);
-    return r;
-}
 PG_DEV D2 operator/(D2 x, D2 y) { double inv = frcp(y.v), q = x.v * inv; return D2(q, (x.a - q * y.a) * inv, (x.b - q * y.b) * inv); }
 PG_DEV D2 operator+(D2 x, double y) { return D2(x.v + y, x.a, x.b); }
 PG_DEV D2 operator+(double y, D2 x) { return D2(x.v + y, x.a, x.b); }
@@ -41,8 +65,8 @@ PG_DEV double val(double x) { return x; }
 PG_DEV double val(D2 x) { return x.v; }
 PG_DEV D2 chain(D2 x, double f, double df) { return D2(f, df * x.a, df * x.b); }
 
-PG_DEV void sincos_(double x, double& s, double& c) { sincos(x, &s, &c); }
-PG_DEV void sincos_(D2 x, D2& s, D2& c) { double sv, cv; sincos(x.v, &sv, &cv); s = chain(x, sv, cv); c = chain(x, cv, -sv); }
+PG_DEV void sincos_(double x, double& s, double& c) { pg_sincos(x, &s, &c); }
+PG_DEV void sincos_(D2 x, D2& s, D2& c) { double sv, cv; pg_sincos(x.v, &sv, &cv); s = chain(x, sv, cv); c = chain(x, cv, -sv); }
 PG_DEV double tan_(double x) { return tan(x); }
 PG_DEV D2 tan_(D2 x) { double t = tan(x.v); return chain(x, t, 1.0 + t * t); }
 PG_DEV double sqrt_(double x) { return sqrt(x); }
@@ -82,7 +106,7 @@ PG_DEV double inv_fiala_tan(double Fy, double Ca, double Fy_max) {
 }
 // vehicle_dynamics.jl:64-76: 3-iteration front-axle load-transfer fixed point, then rear
 template <class T>
-PG_DEV void lateral_forces(const pg_vehicle& P, T af, T ar, T Fxf, T Fxr, T sd, T cd, T& Fyf, T& Fyr) {   // af, ar: TANGENTS of the slip angles
+PG_DEV void lateral_forces(const DevVehicle& P, T af, T ar, T Fxf, T Fxr, T sd, T cd, T& Fyf, T& Fyr) {   // af, ar: TANGENTS of the slip angles
     const double W_b = P.m * P.G * P.b, W_a = P.m * P.G * P.a, invL = 1.0 / P.L;
     Fyf = cst<T>(0.0);
     T Fx = Fxf * cd + Fxr;
@@ -98,7 +122,7 @@ PG_DEV void lateral_forces(const pg_vehicle& P, T af, T ar, T Fxf, T Fxr, T sd, 
 
 // apply_control_limits (vehicle_dynamics.jl:293-298; Ux by value) followed by longitudinal_tire_forces (:279-283)
 template <class T>
-PG_DEV void actuate(const pg_vehicle& P, T delta, T Fx, double Ux, T& d_out, T& Fxf, T& Fxr) {
+PG_DEV void actuate(const DevVehicle& P, T delta, T Fx, double Ux, T& d_out, T& Fxf, T& Fxr) {
     double dv = val(delta);
     d_out = dv > P.delta_max ? cst<T>(P.delta_max) : (dv < -P.delta_max ? cst<T>(-P.delta_max) : delta);
     double cap = jmin(P.Fx_max, P.Px_max / Ux);
@@ -111,7 +135,7 @@ PG_DEV void actuate(const pg_vehicle& P, T delta, T Fx, double Ux, T& d_out, T& 
 
 // body-frame accelerations common to BicycleModel (:114-133) and TrackingBicycleModel (:162-178)
 template <class T>
-PG_DEV void body_accel(const pg_vehicle& P, T Ux, T Uy, T r, T delta, T Fxf, T Fxr, T& dUx, T& dUy, T& dr) {
+PG_DEV void body_accel(const DevVehicle& P, T Ux, T Uy, T r, T delta, T Fxf, T Fxr, T& dUx, T& dUy, T& dr) {
     T sd, cd; sincos_(delta, sd, cd);
     T tf = (Uy + P.a * r) / Ux, td = sd / cd;
     T taf = (tf - td) / (1.0 + tf * td);          // tan(atan2(Uy + a r, Ux) - delta)   (:118)
@@ -129,7 +153,7 @@ PG_DEV void body_accel(const pg_vehicle& P, T Ux, T Uy, T r, T delta, T Fxf, T F
 
 // VehicleModel{TrackingBicycleModel}: vehicle_dynamics.jl:310-315 over :159-183.  q=(ds,Ux,Uy,r,dpsi,e), u=(delta,Fx), p=(V,kappa)
 template <class T>
-PG_DEV void tracking_rhs(const pg_vehicle& P, const T q[6], T u0, T u1, double pV, double pK, T out[6]) {
+PG_DEV void tracking_rhs(const DevVehicle& P, const T q[6], T u0, T u1, double pV, double pK, T out[6]) {
     T d, Fxf, Fxr;
     actuate<T>(P, u0, u1, val(q[1]), d, Fxf, Fxr);
     T s, c; sincos_(q[4], s, c);
@@ -141,7 +165,7 @@ PG_DEV void tracking_rhs(const pg_vehicle& P, const T q[6], T u0, T u1, double p
 }
 // VehicleModel{BicycleModel}: vehicle_dynamics.jl:310-314 over :111-135; only the components the hot path reads (dUx,dUy,dr)
 template <class T>
-PG_DEV void world_body_rhs(const pg_vehicle& P, double Ux, double Uy, double r, T u0, T u1, T& dUx, T& dUy, T& dr) {
+PG_DEV void world_body_rhs(const DevVehicle& P, double Ux, double Uy, double r, T u0, T u1, T& dUx, T& dUy, T& dr) {
     T d, Fxf, Fxr;
     actuate<T>(P, u0, u1, Ux, d, Fxf, Fxr);
     body_accel<T>(P, cst<T>(Ux), cst<T>(Uy), cst<T>(r), d, Fxf, Fxr, dUx, dUy, dr);
@@ -150,7 +174,7 @@ PG_DEV void world_body_rhs(const pg_vehicle& P, double Ux, double Uy, double r, 
 // VehicleModel{LateralTrackingBicycleModel}: vehicle_dynamics.jl:310-316 over :205-224.  q = (Uy, r, dpsi, e), u = (delta, Fx), p = (Ux, kappa)
 // Ux is a parameter here (get_Ux = p[1], :309): the actuator limits see its VALUE only (:295) while the dynamics see the full number.
 template <class T>
-PG_DEV void lateral_rhs(const pg_vehicle& P, const T q[4], T u0, T u1, T pUx, T pK, T out[4]) {
+PG_DEV void lateral_rhs(const DevVehicle& P, const T q[4], T u0, T u1, T pUx, T pK, T out[4]) {
     T d, Fxf, Fxr;
     actuate<T>(P, u0, u1, val(pUx), d, Fxf, Fxr);
     T s, c; sincos_(q[2], s, c);
@@ -163,7 +187,7 @@ PG_DEV void lateral_rhs(const pg_vehicle& P, const T q[4], T u0, T u1, T pUx, T 
 
 // stable_limits: vehicle_dynamics.jl:227-263
 struct Envelope { double dmin, dmax, H[4][2], G[4]; };
-PG_DEV Envelope stable_limits(const pg_vehicle& B, double Ux, double Fxf, double Fxr) {
+PG_DEV Envelope stable_limits(const DevVehicle& B, double Ux, double Fxf, double Fxr) {
     double Fx = Fxf + Fxr;
     double Fzf = (B.m * B.G * B.b - B.h * Fx) / B.L, Fzr = (B.m * B.G * B.a + B.h * Fx) / B.L;
     double Ffm = B.mu * Fzf, Frm = B.mu * Fzr;
@@ -191,7 +215,7 @@ PG_DEV Envelope stable_limits(const pg_vehicle& B, double Ux, double Fxf, double
 
 // steady_state_estimates: vehicle_dynamics.jl:319-390
 struct Steady { double beta, Ux, Uy, r, A, delta, Fx; };
-PG_DEV Steady steady_state(const pg_vehicle& P, double V, double A_tan, double kappa, int num_iters, double r, double beta, double delta, double Fyf) {
+PG_DEV Steady steady_state(const DevVehicle& P, double V, double A_tan, double kappa, int num_iters, double r, double beta, double delta, double Fyf) {
     double A_rad = V * V * kappa;
     double A_max = P.mu * P.G;
     if (hypot(A_tan, A_rad) > A_max) {
@@ -202,7 +226,7 @@ PG_DEV Steady steady_state(const pg_vehicle& P, double V, double A_tan, double k
     double Fxr = 0.0, Fxf = 0.0, A_out = A_tan;
 #pragma unroll 1
     for (int i = 1;; i++) {
-        double sb, cb, sd, cd; sincos(beta, &sb, &cb); sincos(delta, &sd, &cd);
+        double sb, cb, sd, cd; pg_sincos(beta, &sb, &cb); pg_sincos(delta, &sd, &cd);
         double Ux = V * cb, Uy = V * sb;
         double Fx_drag = -P.Cd0 - Ux * (P.Cd1 + P.Cd2 * Ux);
         double Ax = A_tan * cb - A_rad * sb, Ay = A_tan * sb + A_rad * cb;
@@ -232,7 +256,7 @@ PG_DEV Steady steady_state(const pg_vehicle& P, double V, double A_tan, double k
         beta = atan(tanar + P.b * r / Ux);
     }
     Steady o;
-    double sb, cb; sincos(beta, &sb, &cb);
+    double sb, cb; pg_sincos(beta, &sb, &cb);
     o.beta = beta; o.Ux = V * cb; o.Uy = V * sb; o.r = r; o.A = A_out; o.delta = delta; o.Fx = Fxf + Fxr;
     return o;
 }
@@ -243,13 +267,13 @@ struct TrajView {
     const double *t, *s, *V, *A, *E, *N, *psi, *kappa, *edge_L, *edge_R;   // theta, phi are carried by the tube but read by nothing on this path
 };
 // count of elements < x  (Julia searchsortedfirst - 1)
-PG_DEV int count_less(const double* v, int n, double x) {
+template <class V> PG_DEV int count_less(const V* v, int n, double x) {
     int lo = 0, hi = n;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (v[mid] < x) lo = mid + 1; else hi = mid; }
     return lo;
 }
 // count of elements <= x (Julia searchsortedlast)
-PG_DEV int count_leq(const double* v, int n, double x) {
+template <class V> PG_DEV int count_leq(const V* v, int n, double x) {
     int lo = 0, hi = n;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (v[mid] <= x) lo = mid + 1; else hi = mid; }
     return lo;
@@ -269,7 +293,7 @@ PG_DEV TrajS traj_at_s(const TrajView& T, double sq) {
     double Ai = (T.V[i + 1] - T.V[i]) / (T.t[i + 1] - T.t[i]);
     double ds = sq - T.s[i], dt;
     if (fabs(Ai) < 1e-3 || sq > T.s[T.L - 1]) dt = ds / T.V[i];
-    else dt = (sqrt(2.0 * Ai * ds + T.V[i] * T.V[i]) - T.V[i]) / Ai;
+    else dt = 2.0 * ds / (sqrt(2.0 * Ai * ds + T.V[i] * T.V[i]) + T.V[i]);       // (sqrt(2 A ds + V^2) - V) / A of :63, rationalised (no cancellation)
     TrajS o; o.V = T.V[i] + Ai * dt; o.A = Ai;
     int j = clampi(count_leq(T.s, T.L, sq), 1, T.L - 1) - 1;          // interp_by_s: Gridded(Linear()) + Line() (trajectories.jl:32-35)
     double w = (sq - T.s[j]) / (T.s[j + 1] - T.s[j]);

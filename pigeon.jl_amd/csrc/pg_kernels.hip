@@ -15,10 +15,10 @@
 namespace pg {
 
 struct DevCfg {
-    pg_vehicle veh;
-    pg_control_params cp;
+    DevVehicle veh;
+    DevControl cp;
     int Ns, Nl, N, NN;            // NN = N + 1 nodes
-    double dt_short, dt_long;
+    tdouble dt_short, dt_long;
     int use_correction_step, nsub;
     int formulation;              // PG_COUPLED / PG_DECOUPLED
     int dbg_instance;             // diagnostic kernel build only: instance whose interior-point trace is printed (-1 = none; env PG_DEBUG_INSTANCE)
@@ -63,6 +63,7 @@ __host__ __device__ inline QpOff qp_offsets(int N) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// PG_KEEP_BEGIN  (absolute time stays fp64 in both builds)
 __global__ __launch_bounds__(64) void k_time_steps(DevCfg C, int B, const double* __restrict__ t0, double* __restrict__ ts, double* __restrict__ dt, double* __restrict__ prev_ts) {
 #pragma clang fp contract(off)   // the time grid is compared bit-for-bit with the CPU restatement: no fused multiply-add here
     int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(64) void k_time_steps(DevCfg C, int B, const double
     for (int i = 0; i < C.N; i++) D[i] = T[i + 1] - T[i];                          // :27-29
     if (C.alias_prev_ts) for (int i = 0; i < C.NN; i++) PT[i] = T[i];              // prev_ts IS ts in the reference (:15)
 }
+// PG_KEEP_END
 
 // ------------------------------------------------------------------------------------------------------------------
 // math.jl:4-9
@@ -106,10 +108,15 @@ __global__ __launch_bounds__(256) void k_project(DevCfg C, int B, const double* 
     if (lane == 0) {
         int i = bi;
         double vx = T.E[i + 1] - T.E[i], vy = T.N[i + 1] - T.N[i], wx = x - T.E[i], wy = y - T.N[i];
-        double ds = sqrt(wx * wx + wy * wy - best);                                // :82
+        // :82 sqrt(w.w - d^2) with d^2 = |w - lam v|^2 expanded: w.w - d^2 = lam (2 w.v - lam v.v).  Same value for every lam in [0,1], but no
+        // cancellation (the literal form loses half the digits when the foot point is near the segment start: 5 mm in fp32)
+        double vw = vx * wx + vy * wy, vv = vx * vx + vy * vy;
+        double lam = vw / vv; lam = lam < 0.0 ? 0.0 : (lam > 1.0 ? 1.0 : lam);
+        double ds = sqrt(fmax(lam * (2.0 * vw - lam * vv), 0.0));
         double cr = vx * wy - vy * wx;
         double Ai = (T.V[i + 1] - T.V[i]) / (T.t[i + 1] - T.t[i]);
-        double dt = fabs(Ai) < 1e-3 ? ds / T.V[i] : (sqrt(2.0 * Ai * ds + T.V[i] * T.V[i]) - T.V[i]) / Ai;
+        // (sqrt(2 A ds + V^2) - V) / A of :88, rationalised: same value, no cancellation (in fp32 the original loses 3 digits at |A| ~ 1e-3)
+        double dt = fabs(Ai) < 1e-3 ? ds / T.V[i] : 2.0 * ds / (sqrt(2.0 * Ai * ds + T.V[i] * T.V[i]) + T.V[i]);
         double* o = sep + (size_t)wave * 4;
         o[0] = T.s[i] + ds; o[1] = sqrt(best) * sgn(cr); o[2] = T.t[i] + dt; o[3] = (double)i;
     }
@@ -122,9 +129,9 @@ PG_DEV void put_node(double* __restrict__ ND, int i, const NodeRec& r) {
     double* o = ND + i * 10;
     o[0] = r.q0; o[1] = r.q1; o[2] = r.q2; o[3] = r.q3; o[4] = r.q4; o[5] = r.q5; o[6] = r.u0; o[7] = r.u1; o[8] = r.pV; o[9] = r.pK;
 }
-template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, int B, const double* __restrict__ state, const double* __restrict__ control, const double* __restrict__ toff,
-                        const int* __restrict__ solved, const double* __restrict__ sep, const double* __restrict__ ts, const double* __restrict__ dt,
-                        const double* __restrict__ prev_ts, const double* __restrict__ prev_x, double* __restrict__ nodes) {
+template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, int B, const double* __restrict__ state, const double* __restrict__ control, const tdouble* __restrict__ toff,
+                        const int* __restrict__ solved, const double* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt,
+                        const tdouble* __restrict__ prev_ts, const double* __restrict__ prev_x, double* __restrict__ nodes) {
     // the two searched channels (t, s) are staged in LDS when they fit: every node costs three binary searches whose ~10 dependent probes each
     // would otherwise pay L2 latency (the kernel is a 64-wave serial recurrence: latency, not bandwidth, is its whole cost)
     extern __shared__ double sh_traj[];
@@ -137,9 +144,9 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     if constexpr (!STAGED) T = traj_of(C, b);
-    const pg_vehicle& P = C.veh;
+    const DevVehicle& P = C.veh;
     const double* q0 = state + (size_t)b * 6; const double* u0 = control + (size_t)b * 3;
-    const double* TS = ts + (size_t)b * C.NN; const double* DT = dt + (size_t)b * C.N;
+    const tdouble* TS = ts + (size_t)b * C.NN; const tdouble* DT = dt + (size_t)b * C.N;
     double* ND = nodes + (size_t)b * C.NN * 10;
     const double s0 = sep[(size_t)b * 4], e0 = sep[(size_t)b * 4 + 1];
     const double psi0 = q0[2], Ux0 = q0[3], Uy0 = q0[4], r0 = q0[5];
@@ -152,7 +159,7 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
     r.q0 = ds0; r.q1 = Ux0; r.q2 = Uy0; r.q3 = r0; r.q4 = dpsi; r.q5 = e0; r.u0 = d0; r.u1 = Fxf0 + Fxr0; r.pV = tj.V; r.pK = tj.kappa;
     put_node(ND, 0, r);
     if (solved[b]) {                                                               // :82-102 with update_interpolations! (:189-195)
-        const double* PT = prev_ts + (size_t)b * C.NN; const double* PX = prev_x + (size_t)b * C.NN * 8;
+        const tdouble* PT = prev_ts + (size_t)b * C.NN; const double* PX = prev_x + (size_t)b * C.NN * 8;
         const double tlast = PT[C.NN - 1];
         for (int i = 1; i < C.NN; i++) {
             double t = TS[i];
@@ -171,12 +178,12 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
         return;
     }
     // cold start :103-141
-    double sdp, cdp; sincos(dpsi, &sdp, &cdp);
+    double sdp, cdp; pg_sincos(dpsi, &sdp, &cdp);
     double V = Ux0 * cdp - Uy0 * sdp;
     const double beta0 = atan2(Uy0, Ux0);
     double Fyf0, Fyr0;
     {   // lateral_tire_forces(bicycle, q0, u0): raw (delta, Fxf, Fxr), no actuator limits (:110; vehicle_dynamics.jl:78-87)
-        double sd, cd; sincos(d0, &sd, &cd);
+        double sd, cd; pg_sincos(d0, &sd, &cd);
         double af = tan(atan2(Uy0 + P.a * r0, Ux0) - d0), ar = tan(atan2(Uy0 - P.b * r0, Ux0));
         lateral_forces<double>(P, af, ar, Fxf0, Fxr0, sd, cd, Fyf0, Fyr0);
     }
@@ -216,7 +223,7 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
 // linearize: RK4 (nsub sub-steps) of the tracking model with two tangent directions per lane.
 // lane -> (instance, interval t, group g); group g carries tangents {2g, 2g+1} of (q[0..5], u0[0..1], uf[0..1]).
 // Writes raw Jacobian columns; group 0 also writes Phi (the propagated state) into the c slot.  k_limits finishes c and scales B.
-__global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const double* __restrict__ nodes, const double* __restrict__ dt, double* __restrict__ qp) {
+__global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const double* __restrict__ nodes, const tdouble* __restrict__ dt, double* __restrict__ qp) {
     long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long per = (long)C.N * 5;
     if (gid >= (long)B * per) return;
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const double
 }
 
 // finishes c = Phi - A q - B0 u0 - Bf uf, scales B by u_normalization, stability envelope + bounds (:354-367), q_curr/u_curr (:332-333), HJI row (:345-346)
-__global__ __launch_bounds__(256) void k_limits(DevCfg C, int B, const double* __restrict__ nodes, const double* __restrict__ dt, const double* __restrict__ hji_Mb, double* __restrict__ qp,
+__global__ __launch_bounds__(256) void k_limits(DevCfg C, int B, const double* __restrict__ nodes, const tdouble* __restrict__ dt, const double* __restrict__ hji_Mb, double* __restrict__ qp,
                                                 double* __restrict__ abar) {
     long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)B * C.N) return;
@@ -328,8 +335,8 @@ __global__ __launch_bounds__(256) void k_limits(DevCfg C, int B, const double* _
 //              through the actuator limits: vehicle_dynamics.jl:111-135,293-314)
 //   control <- get_next_control(mpc)     (one-step actuation delay: the state moves with the OLD control)
 //   t       <- t + dt
-__global__ __launch_bounds__(64) void k_advance(DevCfg C, int B, double dtp, double* __restrict__ state, double* __restrict__ control, const double* __restrict__ u_next,
-                                                double* __restrict__ t0) {
+__global__ __launch_bounds__(64) void k_advance(DevCfg C, int B, tdouble dtp, double* __restrict__ state, double* __restrict__ control, const double* __restrict__ u_next,
+                                                tdouble* __restrict__ t0) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     double* q = state + (size_t)b * 6; double* u = control + (size_t)b * 3;
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(64) void k_advance(DevCfg C, int B, double dtp, dou
     const double d = u[0], Fx = u[1] + u[2];
     const int nsub = C.nsub; const double h = dtp / nsub;
     auto rhs = [&](const double* y, double* o) {
-        double s, c; sincos(y[2], &s, &c);
+        double s, c; pg_sincos(y[2], &s, &c);
         o[0] = -y[3] * s - y[4] * c; o[1] = y[3] * c - y[4] * s; o[2] = y[5];          // psi measured from North (:127-129)
         world_body_rhs<double>(C.veh, y[3], y[4], y[5], d, Fx, o[3], o[4], o[5]);
     };
@@ -364,8 +371,8 @@ __global__ __launch_bounds__(64) void k_advance(DevCfg C, int B, double dtp, dou
 // never-active bounds on the three inert slots, so the same solve kernel serves both formulations (the inert slots are exactly
 // decoupled from the rest, the optimum of the embedded problem restricted to the live slots IS the lateral optimum).
 // Node record (10 doubles): (0, Ux parameter, Uy, r, dpsi, e, delta, Fx, 0, kappa).
-template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg C, int B, const double* __restrict__ state, const double* __restrict__ control, const double* __restrict__ toff,
-                                                  const double* __restrict__ sep, const double* __restrict__ ts, const double* __restrict__ dt, double* __restrict__ nodes) {
+template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg C, int B, const double* __restrict__ state, const double* __restrict__ control, const tdouble* __restrict__ toff,
+                                                  const double* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt, double* __restrict__ nodes) {
     extern __shared__ double sh_traj[];
     TrajView T = C.traj;
     if constexpr (STAGED) {                                 // single shared trajectory; compile-time so the searches compile to ds_read, not flat loads
@@ -376,9 +383,9 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg 
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     if constexpr (!STAGED) T = traj_of(C, b);
-    const pg_vehicle& P = C.veh;
+    const DevVehicle& P = C.veh;
     const double* q0 = state + (size_t)b * 6; const double* u0 = control + (size_t)b * 3;
-    const double* TS = ts + (size_t)b * C.NN; const double* DT = dt + (size_t)b * C.N;
+    const tdouble* TS = ts + (size_t)b * C.NN; const tdouble* DT = dt + (size_t)b * C.N;
     double* ND = nodes + (size_t)b * C.NN * 10;
     double s = sep[(size_t)b * 4]; const double e0 = sep[(size_t)b * 4 + 1];           // :65
     const double psi0 = q0[2], Ux0 = q0[3], Uy0 = q0[4], r0 = q0[5], d0 = u0[0], Fxf0 = u0[1], Fxr0 = u0[2];
@@ -386,7 +393,7 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg 
     const double beta0 = atan2(Uy0, Ux0);
     double Fyf0, Fyr0;
     {
-        double sd, cd; sincos(d0, &sd, &cd);
+        double sd, cd; pg_sincos(d0, &sd, &cd);
         double af = tan(atan2(Uy0 + P.a * r0, Ux0) - d0), ar = tan(atan2(Uy0 - P.b * r0, Ux0));
         lateral_forces<double>(P, af, ar, Fxf0, Fxr0, sd, cd, Fyf0, Fyr0);               // :71
     }
@@ -403,7 +410,7 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg 
             r.q1 = Ux0; r.q2 = Uy0; r.q3 = r0; r.q4 = adiff(psi0, tj.psi); r.q5 = e0; r.u0 = d0; r.u1 = Fxf0 + Fxr0;      // :79-81
             double dUx, dUy, dr;
             world_body_rhs<double>(P, Ux0, Uy0, r0, d0, Fxf0 + Fxr0, dUx, dUy, dr);                                          // :82
-            double sb, cb; sincos(beta0, &sb, &cb);
+            double sb, cb; pg_sincos(beta0, &sb, &cb);
             A = (dUx - r0 * Uy0) * cb + (dUy + r0 * Ux0) * sb;                                                               // :83
         } else {
             const bool shortp = i <= C.Ns;
@@ -434,7 +441,7 @@ PG_DEV M4d m4mul(const M4d& x, const M4d& y) { M4d r;
 // continuous Jacobians by forward mode (8 tangent directions: Uy, r, dpsi, e, delta, Fx, Ux, kappa), exact ZOH / FOH discretisation
 // (Ad = exp(A dt), G0 = int exp(A s) ds, G1 = (1/dt) int exp(A (dt - s)) s ds by Taylor series + scaling and squaring), envelope and bounds;
 // the result is written in the embedded coupled layout (QP block + the packed per-stage block k_solve streams).
-__global__ __launch_bounds__(128) void k_qp_dec(DevCfg C, int B, const double* __restrict__ nodes, const double* __restrict__ dt, double* __restrict__ qp, double* __restrict__ abar) {
+__global__ __launch_bounds__(128) void k_qp_dec(DevCfg C, int B, const double* __restrict__ nodes, const tdouble* __restrict__ dt, double* __restrict__ qp, double* __restrict__ abar) {
     long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)B * C.N) return;
     int b = (int)(gid / C.N), t = (int)(gid - (long)b * C.N);
@@ -557,7 +564,7 @@ __global__ __launch_bounds__(256) void k_hji_relstate(int B, const double* __res
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const double* us = state + (size_t)b * 6; const double* th = other + (size_t)b * 4; double* x = x7 + (size_t)b * 7;
-    double s, c; sincos(-us[2], &s, &c);
+    double s, c; pg_sincos(-us[2], &s, &c);
     double cpsi = s, spsi = c, dE = th[0] - us[0], dN = th[1] - us[1];
     x[0] = cpsi * dE + spsi * dN; x[1] = -spsi * dE + cpsi * dN; x[2] = adiff(th[2], us[2]);
     x[3] = us[3]; x[4] = us[4]; x[5] = th[3]; x[6] = us[5];
@@ -566,16 +573,26 @@ __global__ __launch_bounds__(256) void k_hji_relstate(int B, const double* __res
 // cache[x]: HJI_computation.jl:66-72.  SIXTEEN lanes per lookup (four lookups per wave): lane g of a group owns the corner bits of
 // dims 4..7 and gathers ONE cell record (the 8 corners of dims 1..3 = 256 contiguous, aligned bytes: 16 x dwordx4).  Weights and sums in fp64 (Float32 grid x Float64 query); the 8 channels are reduced over
 // the 16-lane row with DPP butterflies (no LDS crossbar).  out8[b] = (V, gradV[0..6]); out of bounds => (Inf, 0) (:70).
-PG_DEV double dpp_add(double v, int ctrl_is /*0: xor1, 1: xor2, 2: half mirror, 3: row mirror, 4: rotate 4, 5: rotate 8*/) {
-    int lo = __double2loint(v), hi = __double2hiint(v), plo, phi;
-    if (ctrl_is == 0) { plo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true); }        // quad_perm [1,0,3,2]
-    else if (ctrl_is == 1) { plo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true); }   // quad_perm [2,3,0,1]
-    else if (ctrl_is == 2) { plo = __builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true); } // row_half_mirror
-    else if (ctrl_is == 3) { plo = __builtin_amdgcn_mov_dpp(lo, 0x140, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0x140, 0xF, 0xF, true); } // row_mirror
-    else if (ctrl_is == 4) { plo = __builtin_amdgcn_mov_dpp(lo, 0x124, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0x124, 0xF, 0xF, true); } // row_ror:4
-    else { plo = __builtin_amdgcn_mov_dpp(lo, 0x128, 0xF, 0xF, true); phi = __builtin_amdgcn_mov_dpp(hi, 0x128, 0xF, 0xF, true); }                   // row_ror:8
-    return v + __hiloint2double(phi, plo);
+// PG_KEEP_BEGIN  (bit-level lane moves: one version per arithmetic type)
+template <int CTRL> PG_DEV int dpp_mov(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, 0xF, true); }
+template <int CTRL> PG_DEV real dpp_move(real v) {
+#ifdef PG_F32
+    return __int_as_float(dpp_mov<CTRL>(__float_as_int(v)));
+#else
+    return __hiloint2double(dpp_mov<CTRL>(__double2hiint(v)), dpp_mov<CTRL>(__double2loint(v)));
+#endif
 }
+PG_DEV real dpp_add(real v, int ctrl_is /*0: xor1, 1: xor2, 2: half mirror, 3: row mirror, 4: rotate 4, 5: rotate 8*/) {
+    real p;
+    if (ctrl_is == 0) p = dpp_move<0xB1>(v);          // quad_perm [1,0,3,2]
+    else if (ctrl_is == 1) p = dpp_move<0x4E>(v);     // quad_perm [2,3,0,1]
+    else if (ctrl_is == 2) p = dpp_move<0x141>(v);    // row_half_mirror
+    else if (ctrl_is == 3) p = dpp_move<0x140>(v);    // row_mirror
+    else if (ctrl_is == 4) p = dpp_move<0x124>(v);    // row_ror:4
+    else p = dpp_move<0x128>(v);                      // row_ror:8
+    return v + p;
+}
+// PG_KEEP_END
 template <int CD>
 __global__ __launch_bounds__(256) void k_hji_lookup(HjiView Hv, int B, const double* __restrict__ x7, double* __restrict__ out8) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -691,7 +708,7 @@ __global__ __launch_bounds__(64) void k_hji_constraint(DevCfg C, int B, const do
                                  double* __restrict__ Mb) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const pg_vehicle& P = C.veh;
+    const DevVehicle& P = C.veh;
     const double* x = x7 + (size_t)b * 7; const double* vg = vg8 + (size_t)b * 8; const double* g = vg + 1;
     double* o = Mb + (size_t)b * 4;
     double Vv = vg[0];
@@ -719,7 +736,7 @@ __global__ __launch_bounds__(64) void k_hji_constraint(DevCfg C, int B, const do
     double uR0 = u[0], uR1 = u[1] + u[2];
     D2 dUx, dUy, dr;
     world_body_rhs<D2>(P, x[3], x[4], x[6], D2(uR0, 1.0, 0.0), D2(uR1, 0.0, 1.0), dUx, dUy, dr);   // relative_dynamics :77
-    double s, c; sincos(x[2], &s, &c);
+    double s, c; pg_sincos(x[2], &s, &c);
     double f0 = x[5] * c - x[3] + x[1] * x[6], f1 = x[5] * s - x[4] - x[0] * x[6], f2 = uH0 - x[6];
     D2 Hm = g[3] * dUx + g[4] * dUy + g[6] * dr + (g[0] * f0 + g[1] * f1 + g[2] * f2 + g[5] * uH1);
     double M0 = Hm.a, M1 = Hm.b;
@@ -730,16 +747,16 @@ __global__ __launch_bounds__(64) void k_hji_constraint(DevCfg C, int B, const do
 // optimal_control (uMode=:max, N=50) HJI_computation.jl:133-158 and the control selection of the ROS loop (ros_integration.jl:114-124), lane = instance.
 // u2 [B][2] = (delta_opt, Fx_opt) whenever the relative state is inside the grid; u_next [B][3] = the policy's BicycleControl when it takes over
 // (traj mode, use_policy, V <= eps), else the MPC control u_mpc; source: 0 MPC, 1 HJI policy, 2 V <= eps but the policy is switched off.
-__global__ __launch_bounds__(64) void k_hji_policy(DevCfg C, int B, int use_policy, const double* __restrict__ x7, const double* __restrict__ vg8, const double* __restrict__ toff,
+__global__ __launch_bounds__(64) void k_hji_policy(DevCfg C, int B, int use_policy, const double* __restrict__ x7, const double* __restrict__ vg8, const tdouble* __restrict__ toff,
                                                    const double* __restrict__ u_mpc, double* __restrict__ u2, double* __restrict__ u_next, int* __restrict__ source) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const pg_vehicle& P = C.veh;
+    const DevVehicle& P = C.veh;
     const double* x = x7 + (size_t)b * 7; const double* vg = vg8 + (size_t)b * 8; const double* g = vg + 1;
     const double Ux = x[3], Uy = x[4], r = x[6];
     const double A = g[3] / P.m, Bc = g[4] / P.m + P.a * g[6] / P.Izz, Cc = g[4] / P.m - P.b * g[6] / P.Izz;      // :140-142
     const double d_opt = Bc >= 0.0 ? P.delta_max : -P.delta_max;                                                   // :143
-    double sd, cd; sincos(d_opt, &sd, &cd);
+    double sd, cd; pg_sincos(d_opt, &sd, &cd);
     const double tf = (Uy + P.a * r) / Ux, td = sd / cd;
     const double taf = (tf - td) / (1.0 + tf * td), tar = (Uy - P.b * r) / Ux;       // slip-angle tangents (vehicle_dynamics.jl:84-85), Ux > 0
     double V_opt = -INFINITY, Fx_opt = 0.0;
@@ -795,14 +812,26 @@ PG_DEV double wave_sum(double v) {
     return v;
 }
 
+// PG_KEEP_BEGIN
 // broadcast of lane `src` (compile-time constant) to the whole wave through SGPRs: no LDS, no barrier
-PG_DEV double rl(double v, int src) {
+PG_DEV real rl(real v, int src) {
+#ifdef PG_F32
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+#else
     int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
+#endif
 }
+// waves per SIMD the solve kernel is compiled for: the fp32 iterate needs half the registers and half the LDS, so two waves share a SIMD
+#ifdef PG_F32
+#define PG_SOLVE_WAVES(RING) 2
+#else
+#define PG_SOLVE_WAVES(RING) ((RING) ? 2 : 1)
+#endif
+// PG_KEEP_END
 
 template <bool PROF, bool RING>
-__global__ __launch_bounds__(64, RING ? 2 : 1) void k_solve(DevCfg C, int B, const double* __restrict__ qp, const double* __restrict__ abar, const double* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof) {
+__global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, int B, const double* __restrict__ qp, const double* __restrict__ abar, const double* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof) {
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int slot) { if (PROF) { unsigned long long now = clock64(); pc[slot] += now - tprev; tprev = now; } };
     if (PROF) tprev = clock64();
@@ -1129,9 +1158,9 @@ __global__ __launch_bounds__(64, RING ? 2 : 1) void k_solve(DevCfg C, int B, con
         forward(std::true_type{});
         double tp[NROW];
         newton_point(tp);
-        double tmin = 1e300;
+        double tmin = PG_BIG;
 #pragma unroll
-        for (int j = 0; j < NROW; j++) tmin = fmin(tmin, (act && j < nrows) ? tp[j] : 1e300);
+        for (int j = 0; j < NROW; j++) tmin = fmin(tmin, (act && j < nrows) ? tp[j] : PG_BIG);
         tmin = wave_min(tmin);
         const double shift = tmin < 1.0 ? 1.0 - tmin : 0.0;
         if (act) {
@@ -1156,7 +1185,7 @@ __global__ __launch_bounds__(64, RING ? 2 : 1) void k_solve(DevCfg C, int B, con
 #pragma unroll
         for (int j = 0; j < NROW; j++) musum += (act && j < nrows) ? R.t[j] * R.lam[j] : 0.0;
         mu = wave_sum(musum) / ntot;
-        if (!(mu == mu) || fabs(mu) > 1e300) { status = PG_NUMERICAL; break; }
+        if (!(mu == mu) || fabs(mu) > PG_BIG) { status = PG_NUMERICAL; break; }
         if (mu <= C.ipm_tol && phi * fmax(rp0, 1.0) <= C.ipm_tol) { status = PG_SOLVED; break; }
 #pragma unroll
         for (int j = 0; j < NROW; j++) it_[j] = frcp(R.t[j]);

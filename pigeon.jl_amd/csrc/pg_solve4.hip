@@ -21,10 +21,7 @@ __host__ __device__ inline size_t ws4_len(int N) { return (size_t)(NR_REC + XR_R
 __host__ __device__ inline int lds4_group(int N) { int n = 2 * SB + 96 + ST_REC * N + 8; return n + ((18 - (n & 15)) & 15); }   // == 2 (mod 16): even (16-byte aligned ring chunks), instance regions four banks apart
 __host__ __device__ inline size_t lds4_bytes(int N) { return (size_t)(4 * lds4_group(N) + 2 * SB + 64) * sizeof(double); }
 
-PG_DEV double dpp_x1(double v) {      // value of lane ^ 1 (quad_perm [1,0,3,2])
-    int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xF, 0xF, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
+PG_DEV double dpp_x1(double v) { return dpp_move<0xB1>(v); }      // value of lane ^ 1 (quad_perm [1,0,3,2])
 PG_DEV double g16_sum(double v) {
 #pragma unroll
     for (int s = 8; s >= 1; s >>= 1) v += __shfl_xor(v, s, 16);
@@ -457,7 +454,7 @@ __global__ __launch_bounds__(64, 1) void k_solve4(DevCfg C, int B, const double*
         if (mode == RUN) {
             mu = mu_now;
             const int cap = attempt == 0 ? C.ipm_max_iter : 3 * C.ipm_max_iter;
-            if (!(mu == mu) || fabs(mu) > 1e300) { status = PG_NUMERICAL; mode = DONE; }
+            if (!(mu == mu) || fabs(mu) > PG_BIG) { status = PG_NUMERICAL; mode = DONE; }
             else if (mu <= C.ipm_tol && phi * fmax(rp0, 1.0) <= C.ipm_tol) { status = PG_SOLVED; mode = DONE; }
             else if (fail || it >= cap) {
                 if (attempt == 0) { it_total += it; it = 0; attempt = 1; mode = LSQ; fail = false; }
@@ -487,7 +484,7 @@ __global__ __launch_bounds__(64, 1) void k_solve4(DevCfg C, int B, const double*
         stamp(3);
 
         // the slack of every row at the predictor's Newton point is parked in CO (free until the corrector's second-order term is formed)
-        double rmax = 0.0, tmin = 1e300, msum_a = 0.0;
+        double rmax = 0.0, tmin = PG_BIG, msum_a = 0.0;
 #pragma unroll
         for (int u = 0; u < NSLOT; u++) {
             const StageConst4 c = load_sc(u);
@@ -500,7 +497,7 @@ __global__ __launch_bounds__(64, 1) void k_solve4(DevCfg C, int B, const double*
                 double dt_ = CO[u][j] - T[u][j], dl_ = -(L[u][j] * itj) * CO[u][j];
                 double rj = fmax(-dt_ * itj, -dl_ * frcp(L[u][j]));
                 rmax = fmax(rmax, on ? rj : 0.0);
-                tmin = fmin(tmin, on ? CO[u][j] : 1e300);
+                tmin = fmin(tmin, on ? CO[u][j] : PG_BIG);
             }
         }
         rmax = g16_max(rmax); tmin = g16_min(tmin);

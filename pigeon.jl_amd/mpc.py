@@ -34,8 +34,14 @@ class BatchedTrajectoryTrackingMPC:
     """B copies of CoupledTrajectoryTrackingMPC(vehicle, trajectory; ...) (coupled_lat_long.jl:42-60) on one MI355X."""
 
     def __init__(self, trajectory, batch_capacity, vehicle=None, control_params=None, N_short=10, N_long=20, dt_short=0.01, dt_long=0.2,
-                 use_correction_step=True, rk4_substeps=10, device=0, ipm_max_iter=40, ipm_tol=1e-12, ipm_mu0=100.0, hji_eps=0.05, formulation="coupled"):
-        self.lib = _lib.load_library()
+                 use_correction_step=True, rk4_substeps=10, device=0, ipm_max_iter=40, ipm_tol=None, ipm_mu0=100.0, hji_eps=0.05, formulation="coupled",
+                 precision="f64"):
+        self.precision = precision
+        self.real = np.float64 if precision == "f64" else np.float32      # element type of DEVICE arrays handed to the *_dev entry points
+        if ipm_tol is None:
+            # fp32: the interior point stalls near 1e-5 (coupled) / 1e-4 (the ill-conditioned 8 s lateral horizon); see tests/test_gpu_f32.py
+            ipm_tol = 1e-12 if precision == "f64" else (1e-5 if formulation == "coupled" else 1e-4)
+        self.lib = _lib.load_library(precision)
         cfg = _lib.pg_config()
         assert formulation in ("coupled", "decoupled")
         self.formulation = formulation

@@ -15,13 +15,16 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(pg_[a-z0-9_]+)\s*\(", txt)))
 
 
-def test_library_exports_every_header_symbol(pkg):
-    lib = pkg.load_library()
+@pytest.mark.parametrize("precision,bits", [("f64", 64), ("f32", 32)])
+def test_library_exports_every_header_symbol(pkg, precision, bits):
+    """Both builds (fp64 = the reference's arithmetic type, fp32 = BASELINE configs 3/4) export the whole ABI."""
+    lib = pkg.load_library(precision)
     syms = header_symbols()
     assert len(syms) >= 30
     for s in syms:
         assert hasattr(lib, s), s
     assert sorted(pkg.SYMBOLS) == syms
+    assert lib.pg_precision_bits() == bits
 
 
 def test_default_config_matches_x1(pkg):

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
 export PG_SOLVER=quad
 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -15
-timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-hji --no-decoupled > gpurun_out/bench_quad.log 2>&1
+timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-hji --no-decoupled --no-f32 > gpurun_out/bench_quad.log 2>&1
 tail -1 gpurun_out/bench_quad.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ['value','ms_per_step','phase_ms','warm_value','solved','ipm_iters_mean']})"
