@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--no-hji", action="store_true")
     ap.add_argument("--no-decoupled", action="store_true")
     ap.add_argument("--no-f32", action="store_true")
+    ap.add_argument("--precision", choices=["f64", "f32"], default="f64",
+                    help="arithmetic type of the headline run: f64 = BASELINE configs[1] (default, the metric's config); f32 with --batch 8192 --gpus 8 = configs[3]")
     args = ap.parse_args()
 
     import torch
@@ -78,12 +80,14 @@ def main():
 
     B = args.batch
     traj = pkg.load_path_fixture("skidpadoval")
-    mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local)
+    mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision=args.precision)
+    npdt = np.float64 if args.precision == "f64" else np.float32; tdt = torch.float64 if args.precision == "f64" else torch.float32
     state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345 + rank, traj_mode=True)
     dev = torch.device("cuda", local)
-    d_state = torch.from_numpy(state).to(dev); d_control = torch.from_numpy(control).to(dev); d_t0 = torch.from_numpy(t0).to(dev); d_toff = torch.from_numpy(toff).to(dev)
-    u_out = torch.zeros(B, 3, dtype=torch.float64, device=dev)
-    gathered = torch.zeros(world * B, 3, dtype=torch.float64, device=dev) if world > 1 else None
+    d_state = torch.from_numpy(state.astype(npdt)).to(dev); d_control = torch.from_numpy(control.astype(npdt)).to(dev)
+    d_t0 = torch.from_numpy(t0).to(dev); d_toff = torch.from_numpy(toff).to(dev)            # absolute time is double in both builds
+    u_out = torch.zeros(B, 3, dtype=tdt, device=dev)
+    gathered = torch.zeros(world * B, 3, dtype=tdt, device=dev) if world > 1 else None
     mpc.set_stream(torch.cuda.current_stream().cuda_stream)
     mpc.set_inputs_dev(B, d_state.data_ptr(), d_control.data_ptr(), d_t0.data_ptr(), None, d_toff.data_ptr())
 
@@ -134,7 +138,7 @@ def main():
     # BASELINE config 5: decoupled (lateral) MPC, N = 50 (N_short = 10, N_long = 40), same batch, cold every step (that formulation has no warm branch)
     dec = None
     if rank == 0 and not args.no_decoupled:
-        mpc_d = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, device=local)
+        mpc_d = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, device=local, precision=args.precision)
         mpc_d.set_stream(torch.cuda.current_stream().cuda_stream)
         mpc_d.set_inputs_dev(B, d_state.data_ptr(), d_control.data_ptr(), d_t0.data_ptr(), None, d_toff.data_ptr())
         for _ in range(2):
@@ -144,7 +148,7 @@ def main():
             mpc_d.step_dev(u_out.data_ptr())
         torch.cuda.synchronize(); td = time.perf_counter() - td
         std, itd, _, _ = mpc_d.solve_info()
-        dec = {"workload": f"configs[4]: Batch={B} decoupled MPC, N=50 (no wall rows: not in the reference snapshot), fp64", "value": B * args.steps / td, "unit": "solves/s",
+        dec = {"workload": f"configs[4]: Batch={B} decoupled MPC, N=50 (no wall rows: not in the reference snapshot), {args.precision}", "value": B * args.steps / td, "unit": "solves/s",
                "ms_per_step": 1e3 * td / args.steps, "phase_ms": [float(v) for v in mpc_d.phase_ms()], "solved": f"{int((std == pkg.SOLVED).sum())}/{B}",
                "ipm_iters_mean": float(np.mean(itd))}
         mpc_d.close()
@@ -156,8 +160,8 @@ def main():
         knots, Vg, gg = pkg.synthetic.hji_grid_large()
         mpc.set_hji_cache(knots, Vg, gg)
         nq = 1 << 20
-        xq = torch.from_numpy(pkg.synthetic.hji_queries(knots, nq)).to(dev)
-        out8 = torch.empty(nq, 8, dtype=torch.float64, device=dev)
+        xq = torch.from_numpy(pkg.synthetic.hji_queries(knots, nq).astype(npdt)).to(dev)
+        out8 = torch.empty(nq, 8, dtype=tdt, device=dev)
         look = lambda: mpc._chk(mpc.lib.pg_hji_lookup8_dev(mpc.h, nq, C.c_void_p(xq.data_ptr()), C.c_void_p(out8.data_ptr())), "pg_hji_lookup8_dev")
         for _ in range(3):
             look()
@@ -177,7 +181,7 @@ def main():
 
     # BASELINE config 3: coupled MPC + HJI safety constraint on the precomputed 7-D grid, fp32 (libpigeon_hip_f32.so: same sources, arithmetic type swapped)
     f32 = None
-    if rank == 0 and not args.no_f32:
+    if rank == 0 and not args.no_f32 and args.precision == "f64":
         m32 = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision="f32")
         m32.set_stream(torch.cuda.current_stream().cuda_stream)
         other = pkg.synthetic.other_cars(state, seed=777)
@@ -214,7 +218,8 @@ def main():
         names = ["nodes(time_steps+project+nodes)", "update_qp(hji+linearize+limits)", "solve(k_solve+extract)"]
         dom = int(np.argmax(ph))
         dom_ms = float(ph[dom])
-        achieved = B * BYTES_PER_SOLVE_COLD_FP64 / (dom_ms * 1e-3) / 1e9
+        bytes_per_solve = BYTES_PER_SOLVE_COLD_FP64 if args.precision == "f64" else 68        # 112 B fp64; fp32 = 9 floats + t0 (double) in, 3 floats + status + iters out
+        achieved = B * bytes_per_solve / (dom_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -225,13 +230,15 @@ def main():
         line = {
             "metric": "MPC QP solves/sec (N=30 coupled, X1 model)", "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"configs[1]: Batch={B}/GPU coupled MPC, N=30 (N_short=10, N_long=20), X1, randomised x0 along skidpadoval, cold start, HJI inactive, fp64",
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": (f"configs[1]: Batch={B}/GPU coupled MPC, N=30 (N_short=10, N_long=20), X1, randomised x0 along skidpadoval, cold start, HJI inactive, fp64" if args.precision == "f64"
+                                    else f"configs[3]: Batch={world * B} coupled MPC, N=30, fp32, sharded {B}/GPU x{world}, RCCL all_gather of controls, cold start"),
                        "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}, all_gather of controls" if world > 1 else "single GPU",
-                       "solver": "Mehrotra interior point on the stage-structured QP (Riccati), tol 1e-12", "accuracy": "max|u-u*| <= 1e-6 (normalised) vs exact optimum"},
+                       "solver": "Mehrotra interior point on the stage-structured QP (Riccati), tol " + ("1e-12" if args.precision == "f64" else "1e-5"),
+                       "accuracy": "max|u-u*| <= 1e-6 (normalised) vs exact optimum" if args.precision == "f64" else "max|u-u*| <= 5e-3, median 5e-5 (normalised) vs exact optimum"},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": dom_ms,
-                         "note": "algorithmic HBM bytes are 112 B/solve (SURVEY 8d): the step is fp64-VALU/LDS/latency bound by construction, not HBM bound"},
+                         "note": f"algorithmic HBM bytes are {bytes_per_solve} B/solve (SURVEY 8d): the step is VALU/LDS/latency bound by construction, not HBM bound"},
             "phase_ms": {n: float(v) for n, v in zip(names, ph)},
             "warm_value": world * B * args.steps / warm_elapsed,
             "solved": f"{ok}/{B}", "ipm_iters_mean": float(np.mean(it)), "ipm_iters_max": int(np.max(it)),
