@@ -10,7 +10,10 @@ import Pigeon: compute_time_steps!, compute_linearization_nodes!, update_QP!, ge
                BicycleState, BicycleControl, SimpleCarState, TrajectoryTube, CoupledControlParams, X1
 import Parametron: solve!
 
+# libpigeon_hip.so computes in Float64 (the reference's type); libpigeon_hip_f32.so is the Float32 build of the same sources and the same ABI
+# (host arrays stay Float64; only device arrays handed to the *_dev entry points change element type).
 const LIB = get(ENV, "PIGEON_HIP_LIB", joinpath(@__DIR__, "..", "pigeon.jl_amd", "csrc", "libpigeon_hip.so"))
+precision_bits() = ccall((:pg_precision_bits, LIB), Cint, ())
 
 # mirrors of the C structs of include/pigeon_mpc.h (isbits, same field order)
 struct PgVehicle
@@ -28,7 +31,7 @@ struct PgConfig
     vehicle::PgVehicle; control::PgControlParams
     N_short::Int32; N_long::Int32; dt_short::Float64; dt_long::Float64
     use_correction_step::Int32; rk4_substeps::Int32; hji_eps::Float64
-    batch_capacity::Int32; device::Int32; ipm_max_iter::Int32; _pad::Int32; ipm_tol::Float64; ipm_mu0::Float64
+    batch_capacity::Int32; device::Int32; ipm_max_iter::Int32; formulation::Int32; ipm_tol::Float64; ipm_mu0::Float64    # formulation: 0 coupled, 1 decoupled
 end
 
 check(h, rc, what) = rc == 0 || error("$what failed ($rc): " * unsafe_string(ccall((:pg_last_error, LIB), Cstring, (Ptr{Cvoid},), h)))
@@ -55,7 +58,7 @@ function BatchedTrajectoryTrackingMPC(vehicle::Dict{Symbol,Float64}, trajectory:
     U = control_params
     cp = PgControlParams(U.V_min, U.V_max, U.k_V, U.k_s, U.δ̇_max, U.Q_Δs, U.Q_Δψ, U.Q_e, U.W_β, U.W_r, U.W_HJI, U.R_δ, U.R_Δδ, U.R_Fx, U.R_ΔFx, U.N_HJI, 0)
     cfg[] = PgConfig(veh, cp, N_short, N_long, dt_short, dt_long, use_correction_step, c.rk4_substeps, c.hji_eps, B, device,
-                     c.ipm_max_iter, 0, c.ipm_tol, c.ipm_mu0)
+                     c.ipm_max_iter, c.formulation, c.ipm_tol, c.ipm_mu0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:pg_create, LIB), Cint, (Ref{PgConfig}, Ref{Ptr{Cvoid}}), cfg, h)
     rc == 0 || error("pg_create failed ($rc): " * unsafe_string(ccall((:pg_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
@@ -70,6 +73,17 @@ end
 function set_trajectory!(mpc::BatchedTrajectoryTrackingMPC, tj::TrajectoryTube{Float64})
     check(mpc.handle, ccall((:pg_set_trajectory, LIB), Cint, (Ptr{Cvoid}, Int32, ntuple(_ -> Ptr{Float64}, 12)...),
                             mpc.handle, length(tj), tj.t, tj.s, tj.V, tj.A, tj.E, tj.N, tj.ψ, tj.κ, tj.θ, tj.ϕ, tj.edge_L, tj.edge_R), "pg_set_trajectory")
+end
+
+"One controller per (x0, reference trajectory) pair: a library of tubes and the tube each instance tracks (0-based index)"
+function set_trajectories!(mpc::BatchedTrajectoryTrackingMPC, tubes::Vector{TrajectoryTube{Float64}}, index::Vector{Int32})
+    Lmax = maximum(length, tubes); L = Int32[length(t) for t in tubes]
+    pack = zeros(Float64, Lmax, 10, length(tubes))                       # column-major [L][channel][tube] == the ABI's [n_traj][10][Lmax]
+    for (k, t) in enumerate(tubes), (c, ch) in enumerate((t.t, t.s, t.V, t.A, t.E, t.N, t.ψ, t.κ, t.edge_L, t.edge_R))
+        pack[1:length(t), c, k] .= ch
+    end
+    check(mpc.handle, ccall((:pg_set_trajectories, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Int32}, Ptr{Float64}), mpc.handle, length(tubes), Lmax, L, pack), "pg_set_trajectories")
+    check(mpc.handle, ccall((:pg_set_trajectory_index, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Int32}), mpc.handle, length(index), index), "pg_set_trajectory_index")
 end
 
 "mpc.HJI_cache = HJICache(fname) (src/Pigeon.jl:40): hand over grid_knots, V_raw, ∇V_raw exactly as stored in the JLD2 file"
@@ -98,6 +112,21 @@ function get_next_control(mpc::BatchedTrajectoryTrackingMPC)
     u = Vector{BicycleControl{Float64}}(undef, mpc.B)
     check(mpc.handle, ccall((:pg_get_next_control, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), mpc.handle, u), "pg_get_next_control")
     u
+end
+
+"The control the ROS loop sends (src/ros_integration.jl:114-124): HJI fallback policy optimal_control(...) when V <= HJI_ϵ in trajectory mode, else the MPC control"
+function get_next_control(mpc::BatchedTrajectoryTrackingMPC, use_HJI_policy::Bool)
+    u = Vector{BicycleControl{Float64}}(undef, mpc.B); source = Vector{Int32}(undef, mpc.B)
+    check(mpc.handle, ccall((:pg_get_next_control_hji, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}),
+                            mpc.handle, use_HJI_policy, u, source, C_NULL), "pg_get_next_control_hji")
+    u, source            # source: 0 MPC, 1 HJI policy ("with a hammer"), 2 unsafe but policy off ("with a feather")
+end
+
+"simulate(mpc, q0, u0, N) (src/model_predictive_control.jl:80-100) for the whole batch, closed loop resident on the GPU"
+function simulate!(mpc::BatchedTrajectoryTrackingMPC, steps::Integer; dt=0.01)
+    check(mpc.handle, ccall((:pg_simulate_dev, LIB), Cint, (Ptr{Cvoid}, Int32, Float64, Ptr{Cvoid}, Ptr{Cvoid}), mpc.handle, steps, dt, C_NULL, C_NULL), "pg_simulate_dev")
+    check(mpc.handle, ccall((:pg_get_state, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), mpc.handle, mpc.current_state, mpc.current_control, mpc.t), "pg_get_state")
+    mpc.current_state, mpc.current_control
 end
 
 "The convenience entry points named in the project brief: all five calls for every instance."
