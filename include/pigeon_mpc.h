@@ -83,6 +83,12 @@ typedef struct pg_config {
     int32_t formulation;            /* PG_COUPLED (src/coupled_lat_long.jl) or PG_DECOUPLED (src/decoupled_lat_long.jl) */
     double ipm_tol;                 /* complementarity / infeasibility tolerance (default 1e-12; tighter values lose accuracy to rounding) */
     double ipm_mu0;                 /* initial barrier parameter (default 100) */
+    int32_t walls;                  /* BUILD-DEFINED EXTENSION (BASELINE config 5 "both_walls"; the reference snapshot carries edge_L/edge_R through
+                                     * TrajectoryTube, src/trajectories.jl:19-20,33, but no constraint reads them, README.md:54): 1 adds to the DECOUPLED
+                                     * formulation, at nodes t = 2..N+1, the rows  e_t <= edge_L(s_t) + sw_t,  e_t >= edge_R(s_t) - sw_t,  sw_t >= 0  and the
+                                     * cost  wall_weight * dt_t * sw_t  (soft, like the stability-envelope rows of :193-211); 0 (default) = the reference's QP */
+    int32_t _pad2;
+    double wall_weight;             /* linear penalty on the wall slack per second (default 1000) */
 } pg_config;
 
 enum pg_formulation { PG_COUPLED = 0, PG_DECOUPLED = 1 };
@@ -194,6 +200,9 @@ int pg_hji_lookup_dev(pg_handle* h, int32_t B, const pg_real_dev* x7_dev, pg_rea
 int pg_hji_lookup8_dev(pg_handle* h, int32_t B, const pg_real_dev* x7_dev, pg_real_dev* out8_dev);
 /* compute_reachability_constraint for the installed inputs: M [B][2] (already multiplied by u_normalization), b [B], V [B] */
 int pg_get_hji_constraint(pg_handle* h, double* M, double* b, double* V);
+/* wall extension (pg_config.walls): (edge_L, edge_R) at nodes 2..N+1 of every instance, [B][N][2]; PG_ERR_STATE when walls are off.
+ * The wall slack sw is returned in the third column of pg_get_solution's sigma [B][N][3]. */
+int pg_get_walls(pg_handle* h, double* edges);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,7 @@ struct PgConfig
     N_short::Int32; N_long::Int32; dt_short::Float64; dt_long::Float64
     use_correction_step::Int32; rk4_substeps::Int32; hji_eps::Float64
     batch_capacity::Int32; device::Int32; ipm_max_iter::Int32; formulation::Int32; ipm_tol::Float64; ipm_mu0::Float64    # formulation: 0 coupled, 1 decoupled
+    walls::Int32; _pad2::Int32; wall_weight::Float64                                                                    # build-defined soft wall rows (decoupled only)
 end
 
 check(h, rc, what) = rc == 0 || error("$what failed ($rc): " * unsafe_string(ccall((:pg_last_error, LIB), Cstring, (Ptr{Cvoid},), h)))
@@ -58,7 +59,7 @@ function BatchedTrajectoryTrackingMPC(vehicle::Dict{Symbol,Float64}, trajectory:
     U = control_params
     cp = PgControlParams(U.V_min, U.V_max, U.k_V, U.k_s, U.δ̇_max, U.Q_Δs, U.Q_Δψ, U.Q_e, U.W_β, U.W_r, U.W_HJI, U.R_δ, U.R_Δδ, U.R_Fx, U.R_ΔFx, U.N_HJI, 0)
     cfg[] = PgConfig(veh, cp, N_short, N_long, dt_short, dt_long, use_correction_step, c.rk4_substeps, c.hji_eps, B, device,
-                     c.ipm_max_iter, c.formulation, c.ipm_tol, c.ipm_mu0)
+                     c.ipm_max_iter, c.formulation, c.ipm_tol, c.ipm_mu0, c.walls, 0, c.wall_weight)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:pg_create, LIB), Cint, (Ref{PgConfig}, Ref{Ptr{Cvoid}}), cfg, h)
     rc == 0 || error("pg_create failed ($rc): " * unsafe_string(ccall((:pg_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))

@@ -77,7 +77,7 @@ struct StageDataDec {
         dmin.assign(N, 0); dmax.assign(N, 0); ddmin.assign(N, 0); ddmax.assign(N, 0); dt.assign(N, 0);
     }
 };
-struct NodesDec { std::vector<double> qs, us, ps; };    // [i][4], [i][2], [i][4]
+struct NodesDec { std::vector<double> qs, us, ps, edges; };    // [i][4], [i][2], [i][4]; edges [i][2] = (edge_L, edge_R) of the tube at the node (trajectories.jl:19-20)
 
 struct DecoupledMPC {
     VehicleParams veh = X1();
@@ -91,7 +91,7 @@ struct DecoupledMPC {
     void linearization_nodes(const double q0[6], const double u0[3], double time_offset, NodesDec& out) const {
         int Ns = TS.N_short, Nn = N() + 1;
         const std::vector<double>&ts = TS.ts, &dt = TS.dt;
-        out.qs.assign(4 * Nn, 0); out.us.assign(2 * Nn, 0); out.ps.assign(4 * Nn, 0);
+        out.qs.assign(4 * Nn, 0); out.us.assign(2 * Nn, 0); out.ps.assign(4 * Nn, 0); out.edges.assign(2 * Nn, 0);
         double s, e0, t0;
         traj.path_coordinates(q0[0], q0[1], s, e0, t0);                                  // :65
         double V = std::hypot(q0[3], q0[4]);                                             // :67
@@ -122,6 +122,7 @@ struct DecoupledMPC {
             }
             for (int k = 0; k < 4; k++) { out.qs[4 * i + k] = q[k]; out.ps[4 * i + k] = p[k]; }
             out.us[2 * i] = u[0]; out.us[2 * i + 1] = u[1];
+            out.edges[2 * i] = tj.edge_L; out.edges[2 * i + 1] = tj.edge_R;
             if (i == Nn - 1) break;
             V = V + A * tau;
             s = s + V * tau + A * tau * tau / 2;

@@ -252,6 +252,17 @@ class Oracle:
         return u, sol, it, st, secs
 
 
+def solve_exact_generic(qp):
+    """Exact optimum of a canonical QP dict (Pd, q, Ap, Ai, Ax, l, u) with the oracle's sparse interior point: (x, y, info)."""
+    L = lib()
+    n = len(qp["Pd"]); m = len(qp["l"])
+    x = np.zeros(n); y = np.zeros(m); info = np.zeros(5)
+    Ap = np.ascontiguousarray(qp["Ap"], dtype=np.int32); Ai = np.ascontiguousarray(qp["Ai"], dtype=np.int32)
+    L.po_solve_exact_generic(n, m, _d(_arr(qp["Pd"])), _d(_arr(qp["q"])), Ap.ctypes.data_as(c_ip), Ai.ctypes.data_as(c_ip), _d(_arr(qp["Ax"])),
+                             _d(_arr(qp["l"])), _d(_arr(qp["u"])), _d(x), _d(y), _d(info))
+    return x, y, dict(iters=int(info[0]), status=int(info[1]), res_pri=info[2], res_dua=info[3], gap=info[4])
+
+
 def active_set(qp, x, y, tol=1e-7):
     """Index list of active inequality rows from an (x, y) pair of the canonical QP: +(i+1) upper-active, -(i+1) lower-active.
     Equality rows (l == u) are excluded.  A row is active when its multiplier exceeds `tol` in magnitude."""
@@ -298,6 +309,12 @@ class OracleDecoupled:
         qs = np.zeros((self.Nn, 4)); us = np.zeros((self.Nn, 2)); ps = np.zeros((self.Nn, 4))
         self.L.pd_nodes(self.h, _d(_arr(state6, 6)), _d(_arr(control3, 3)), C.c_double(time_offset), _d(_arr(ts, self.Nn)), _d(_arr(dt, self.N)), _d(qs), _d(us), _d(ps))
         return qs, us, ps
+
+    def node_edges(self, state6, control3, ts, dt, time_offset=float("nan")):
+        """(edge_L, edge_R) of the tube at every linearization node [Nn, 2]"""
+        e = np.zeros((self.Nn, 2))
+        self.L.pd_node_edges(self.h, _d(_arr(state6, 6)), _d(_arr(control3, 3)), C.c_double(time_offset), _d(_arr(ts, self.Nn)), _d(_arr(dt, self.N)), _d(e))
+        return e
 
     def update_qp(self, qs, us, ps, dt):
         sd = np.zeros(self.sd_len)

@@ -294,6 +294,25 @@ void pd_nodes(void* hv, const double* state6, const double* control3, double tim
     NodesDec nd; m.linearization_nodes(state6, control3, time_offset, nd);
     std::memcpy(qs, nd.qs.data(), nd.qs.size() * 8); std::memcpy(us, nd.us.data(), nd.us.size() * 8); std::memcpy(ps, nd.ps.data(), nd.ps.size() * 8);
 }
+// (edge_L, edge_R) of the tube at every linearization node: input of the build-defined wall rows (the reference snapshot has no constraint that reads them)
+void pd_node_edges(void* hv, const double* state6, const double* control3, double time_offset, const double* ts, const double* dt, double* edges) {
+    DecoupledMPC m = ((HandleDec*)hv)->mpc; int Nn = m.N() + 1;
+    m.TS.ts.assign(ts, ts + Nn); m.TS.dt.assign(dt, dt + Nn - 1);
+    NodesDec nd; m.linearization_nodes(state6, control3, time_offset, nd);
+    std::memcpy(edges, nd.edges.data(), nd.edges.size() * 8);
+}
+// exact solve of an arbitrary QP in the canonical form  min 1/2 x'diag(Pd)x + q'x  s.t.  l <= A x <= u  (A in CSC; rows are equalities or one-sided)
+int po_solve_exact_generic(int n, int m, const double* Pd, const double* q, const int* Ap, const int* Ai, const double* Ax, const double* l, const double* u,
+                           double* x, double* y, double* info5) {
+    QP qp; qp.n = n; qp.m = m; qp.Pd.assign(Pd, Pd + n); qp.q.assign(q, q + n); qp.Ap.assign(Ap, Ap + n + 1); qp.Ai.assign(Ai, Ai + Ap[n]); qp.Ax.assign(Ax, Ax + Ap[n]);
+    qp.l.assign(l, l + m); qp.u.assign(u, u + m);
+    KKTPattern K; K.build(n, m, qp.Ap, qp.Ai);
+    LDLNumeric ldl; ldl.init(&K.sym);
+    ExactResult R; int st = solve_exact_robust(qp, K, ldl, R);
+    if ((int)R.x.size() == n) { std::memcpy(x, R.x.data(), n * 8); std::memcpy(y, R.y.data(), m * 8); }
+    info5[0] = R.iters; info5[1] = R.status; info5[2] = R.res_pri; info5[3] = R.res_dua; info5[4] = R.gap;
+    return st;
+}
 void pd_update_qp(void* hv, const double* qs, const double* us, const double* ps, const double* dt, double* sd_flat) {
     DecoupledMPC m = ((HandleDec*)hv)->mpc; int Nn = m.N() + 1;
     m.TS.dt.assign(dt, dt + Nn - 1);

@@ -32,6 +32,7 @@ struct pg_handle {
     HjiView hv; float *d_knots = nullptr, *d_hnodes = nullptr, *d_hcells = nullptr; bool has_hji = false;
     hipEvent_t ev[4]; bool ev_ok = false; float phase_ms[3] = {0, 0, 0}; bool timing_valid = false;
     size_t solve_lds = 0; bool solve_ring = false;
+    real* d_walls = nullptr;                                    // [cap][N][2] wall extension
     real* d_ws4 = nullptr; bool solve_quad = false; size_t solve4_lds = 0;   // k_solve4 (four instances per wavefront)
 };
 
@@ -107,7 +108,7 @@ int pg_default_config(pg_config* c) {
     U.R_delta = 0.0; U.R_ddelta = 0.1; U.R_Fx = 0.0; U.R_dFx = 0.5;
     c->N_short = 10; c->N_long = 20; c->dt_short = 0.01; c->dt_long = 0.2; c->use_correction_step = 1;   // coupled_lat_long.jl:42-43
     c->rk4_substeps = 10; c->hji_eps = 0.05; c->batch_capacity = 4096; c->device = 0;
-    c->ipm_max_iter = 40; c->ipm_tol = 1e-12; c->ipm_mu0 = 100.0; c->formulation = PG_COUPLED;
+    c->ipm_max_iter = 40; c->ipm_tol = 1e-12; c->ipm_mu0 = 100.0; c->formulation = PG_COUPLED; c->walls = 0; c->wall_weight = 1000.0;
     return PG_OK;
 }
 
@@ -123,7 +124,7 @@ int pg_default_config_decoupled(pg_config* c) {
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_state, h->d_control, h->d_t0, h->d_other, h->d_toff, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_abar, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_abar, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->ev_ok) for (int i = 0; i < 4; i++) (void)hipEventDestroy(h->ev[i]);
 }
@@ -138,6 +139,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     if (e != hipSuccess || ndev <= 0) { g_create_error = "no HIP device available (this library has no CPU path)"; return PG_ERR_NO_DEVICE; }
     if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "device ordinal out of range"; return PG_ERR_INVALID; }
     if (cfg->formulation != PG_COUPLED && cfg->formulation != PG_DECOUPLED) { g_create_error = "unknown formulation"; return PG_ERR_INVALID; }
+    if (cfg->walls != 0 && (cfg->walls != 1 || cfg->formulation != PG_DECOUPLED)) { g_create_error = "walls = 1 is an option of the decoupled formulation only"; return PG_ERR_INVALID; }
     if (cfg->N_short < 1 || cfg->N_long < 0 || cfg->N_short + cfg->N_long + 1 > 64 || cfg->batch_capacity < 1 || cfg->rk4_substeps < 1) {
         g_create_error = "invalid horizon / capacity (need 1 <= N_short, N_short+N_long+1 <= 64)"; return PG_ERR_INVALID;
     }
@@ -169,6 +171,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_active, cap * N, uint16_t);
     { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (pg_solve4.hip)
     if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), real);
+    if (cfg->walls) { ALLOC(h->d_walls, cap * N * 2, real); C.walls = 1; C.wall_weight = (real)cfg->wall_weight; C.wall_edges = h->d_walls; if (h->solve_quad) { g_create_error = "PG_SOLVER=quad does not carry the wall rows"; free_all(h); delete h; return PG_ERR_INVALID; } }
     ALLOC(h->d_pol_u2, cap * 2, real); ALLOC(h->d_pol_u, cap * 3, real); ALLOC(h->d_pol_src, cap, int);
 #undef ALLOC
     // initial ts = 1..NN (model_predictive_control.jl:13), solved = false
@@ -595,6 +598,12 @@ int pg_get_solve_info(pg_handle* h, int32_t* status, int32_t* iters, uint16_t* a
     if ((rc = down_raw(h, status, h->d_status, B * 4)) || (rc = down_raw(h, iters, h->d_iters, B * 4)) || (rc = down_raw(h, active, h->d_active, B * C.N * 2)) ||
         (rc = down(h, mu, h->d_mu, B))) return rc;
     return PG_OK;
+}
+int pg_get_walls(pg_handle* h, double* edges) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!h->dc.walls) { h->err = "walls are off (pg_config.walls = 0)"; return PG_ERR_STATE; }
+    REQUIRE(h, edges, "edges is null");
+    return down(h, edges, h->d_walls, (size_t)h->B * h->dc.N * 2);
 }
 int pg_get_hji_constraint(pg_handle* h, double* M, double* b, double* V) {
     int rc = check_ready(h); if (rc) return rc;

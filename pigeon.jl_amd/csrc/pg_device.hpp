@@ -301,6 +301,12 @@ PG_DEV TrajS traj_at_s(const TrajView& T, double sq) {
     o.kappa = T.kappa[j] + w * (T.kappa[j + 1] - T.kappa[j]);
     return o;
 }
+// edge_L, edge_R channels of interp_by_s at arclength sq (trajectories.jl:32-35): read only by the build-defined wall rows
+PG_DEV void traj_edges_at_s(const TrajView& T, double sq, double& eL, double& eR) {
+    int j = clampi(count_leq(T.s, T.L, sq), 1, T.L - 1) - 1;
+    double w = (sq - T.s[j]) / (T.s[j + 1] - T.s[j]);
+    eL = T.edge_L[j] + w * (T.edge_L[j + 1] - T.edge_L[j]); eR = T.edge_R[j] + w * (T.edge_R[j + 1] - T.edge_R[j]);
+}
 // adiff: DifferentialDynamicsModels (absent); semantics restated at PigeonViz.jl:24-28
 PG_DEV double adiff(double x, double y) {
     const double twopi = 6.283185307179586476925286766559;

@@ -36,6 +36,9 @@ struct DevCfg {
     long traj_stride;             // doubles between consecutive trajectories of the library ([n_traj][10][Lmax])
     const int* traj_idx;          // [B] per-instance selection (nullptr when n_traj == 1)
     const int* traj_len;          // [n_traj] valid nodes of each trajectory
+    int walls;                    // build-defined extension: soft rows edge_R - sw <= e <= edge_L + sw, sw >= 0 at nodes 2..N+1 (decoupled formulation only)
+    double wall_weight;           // linear penalty on sw (per second, like W_beta)
+    double* wall_edges;           // [B][N][2] (edge_L, edge_R) at node k+1, written by k_nodes_dec, read by k_solve
 };
 // the reference trajectory instance b tracks (mpc.trajectory of that controller)
 PG_DEV TrajView traj_of(const DevCfg& C, int b) {
@@ -420,6 +423,7 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg 
             r.u0 = est.delta; r.u1 = est.Fx; A = est.A;
         }
         put_node(ND, i, r);
+        if (C.walls && i >= 1) { double eL, eR; traj_edges_at_s(T, s, eL, eR); double* w = C.wall_edges + ((size_t)b * C.N + i - 1) * 2; w[0] = eL; w[1] = eR; }
         V = V + A * tau;
         s = s + V * tau + A * tau * tau * 0.5;
     }
@@ -881,6 +885,9 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     double h0[4], h1[4], bb[NROW];
     const double M0 = Q[o.M], M1 = Q[o.M + 1];
     const bool hji_on = act && (s + 1 < (C.cp.N_HJI < C.Ns ? C.cp.N_HJI : C.Ns));
+    // wall extension (lateral formulation): rows 0, 1, 2 -- bounds on the INERT Ux / Fx slots of the embedding there -- carry  e <= edge_L + sw,  e >= edge_R - sw,
+    // sw >= 0, and sw takes the slot of the (absent) safety-row slack: the third stage-locally eliminated slack group
+    const bool wall_on = act && C.walls != 0;
     const double dts = Q[o.dt + s];
     const double Rd0 = 2.0 * C.cp.R_ddelta / dts, Rd1 = 2.0 * C.cp.R_dFx / dts;
     const double wb = C.cp.W_beta * dts, wr = C.cp.W_r * dts, wh = C.cp.W_HJI;
@@ -888,6 +895,9 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     for (int i = 0; i < 4; i++) { h0[i] = Q[o.H + 8 * s + 2 * i]; h1[i] = Q[o.H + 8 * s + 2 * i + 1]; bb[6 + i] = Q[o.G + 4 * s + i]; }
     bb[0] = -C.cp.V_min; bb[1] = C.cp.V_max; bb[2] = -C.fxmin_n; bb[3] = Q[o.dmax + s]; bb[4] = -Q[o.dmin + s]; bb[5] = Q[o.fxmax + s];
     bb[10] = 0.0; bb[11] = 0.0; bb[12] = Q[o.ddmax + s]; bb[13] = -Q[o.ddmin + s]; bb[14] = Q[o.b]; bb[15] = 0.0;
+    if (wall_on) { const double* w = C.wall_edges + ((size_t)b * N + s) * 2; bb[0] = w[0]; bb[1] = -w[1]; bb[2] = 0.0; }
+    const double ww = C.wall_weight * dts;
+    const double Qd5 = 2.0 * C.cp.Q_e * dts;
     if (act) {   // entries of the stage cost that never change
         double* Qo = sQ + 10 * (s + 1);
         Qo[0] = 2.0 * C.cp.Q_ds * dts; Qo[4] = 2.0 * C.cp.Q_dpsi * dts; Qo[5] = 2.0 * C.cp.Q_e * dts;
@@ -900,7 +910,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
 
     // slack of every row at the point w = (x[8], v0, s1, s2, sh)
     auto slacks = [&](const double* x, double v0, double s1, double s2, double sh, double* out) {
-        out[0] = x[1] + bb[0]; out[1] = bb[1] - x[1]; out[2] = x[7] + bb[2]; out[3] = bb[3] - x[6]; out[4] = x[6] + bb[4]; out[5] = bb[5] - x[7];
+        out[0] = wall_on ? bb[0] - x[5] + sh : x[1] + bb[0]; out[1] = wall_on ? bb[1] + x[5] + sh : bb[1] - x[1]; out[2] = wall_on ? sh : x[7] + bb[2];
+        out[3] = bb[3] - x[6]; out[4] = x[6] + bb[4]; out[5] = bb[5] - x[7];
 #pragma unroll
         for (int i = 0; i < 4; i++) out[6 + i] = bb[6 + i] - (h0[i] * x[2] + h1[i] * x[3]) + (i < 2 ? s1 : s2);
         out[10] = s1; out[11] = s2; out[12] = bb[12] - v0; out[13] = v0 + bb[13];
@@ -967,29 +978,31 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             W[j] = on ? R.lam[j] * it_[j] : 0.0;
             ell[j] = on ? (sigmu - R.corr[j]) * it_[j] + R.lam[j] - W[j] * bb[j] : 0.0;
         }
-        double g1 = -ell[0] + ell[1], g7 = -ell[2] + ell[5] - M1 * ell[14], g6 = ell[3] - ell[4] - M0 * ell[14];
+        double g1 = wall_on ? 0.0 : -ell[0] + ell[1], g7 = (wall_on ? 0.0 : -ell[2]) + ell[5] - M1 * ell[14], g6 = ell[3] - ell[4] - M0 * ell[14];
         double g2 = 0.0, g3 = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; i++) { g2 += h0[i] * ell[6 + i]; g3 += h1[i] * ell[6 + i]; }
-        e_g1 = wb - ell[6] - ell[7] - ell[10]; e_g2 = wr - ell[8] - ell[9] - ell[11]; e_gh = wh - ell[14] - ell[15];
+        e_g1 = wb - ell[6] - ell[7] - ell[10]; e_g2 = wr - ell[8] - ell[9] - ell[11]; e_gh = wall_on ? ww - ell[0] - ell[1] - ell[2] : wh - ell[14] - ell[15];
         double gv0 = ell[12] - ell[13];
-        e_d1 = frcp(W[6] + W[7] + W[10]); e_d2 = frcp(W[8] + W[9] + W[11]); e_dh = hji_on ? frcp(W[14] + W[15]) : 1.0;
+        e_d1 = frcp(W[6] + W[7] + W[10]); e_d2 = frcp(W[8] + W[9] + W[11]); e_dh = wall_on ? frcp(W[0] + W[1] + W[2]) : (hji_on ? frcp(W[14] + W[15]) : 1.0);
         e_c10 = -(W[6] * h0[0] + W[7] * h0[1]); e_c11 = -(W[6] * h1[0] + W[7] * h1[1]);
         e_c20 = -(W[8] * h0[2] + W[9] * h0[3]); e_c21 = -(W[8] * h1[2] + W[9] * h1[3]);
-        e_ch0 = W[14] * M0; e_ch1 = W[14] * M1;
-        if (!hji_on) e_gh = 0.0;
+        e_ch0 = wall_on ? -(W[0] - W[1]) : W[14] * M0; e_ch1 = wall_on ? 0.0 : W[14] * M1;      // wall rows: t = b -/+ e + sw, i.e. the envelope-row pattern with h = +1, -1 on e
+        if (!hji_on && !wall_on) e_gh = 0.0;
         if (act) {
             double* qo = sq + 8 * (s + 1);
             qo[1] = g1;
             qo[2] = g2 - e_c10 * e_g1 * e_d1 - e_c20 * e_g2 * e_d2;
             qo[3] = g3 - e_c11 * e_g1 * e_d1 - e_c21 * e_g2 * e_d2;
-            qo[6] = g6 - e_ch0 * e_gh * e_dh; qo[7] = g7 - e_ch1 * e_gh * e_dh;
+            qo[6] = g6 - (wall_on ? 0.0 : e_ch0 * e_gh * e_dh); qo[7] = g7 - e_ch1 * e_gh * e_dh;
+            if (wall_on) qo[5] = (ell[0] - ell[1]) - e_ch0 * e_gh * e_dh;
             sr[2 * s] = gv0;
             if (matrices) {
                 double* Qo = sQ + 10 * (s + 1);
-                Qo[1] = W[0] + W[1];
-                Qo[6] = Qd6 + W[3] + W[4] + M0 * M0 * W[14] - e_ch0 * e_ch0 * e_dh;
-                Qo[7] = Qd7 + W[2] + W[5] + M1 * M1 * W[14] - e_ch1 * e_ch1 * e_dh;
+                if (wall_on) Qo[5] = Qd5 + W[0] + W[1] - e_ch0 * e_ch0 * e_dh;
+                Qo[1] = wall_on ? 0.0 : W[0] + W[1];
+                Qo[6] = Qd6 + W[3] + W[4] + M0 * M0 * W[14] - (wall_on ? 0.0 : e_ch0 * e_ch0 * e_dh);
+                Qo[7] = Qd7 + (wall_on ? 0.0 : W[2]) + W[5] + M1 * M1 * W[14] - e_ch1 * e_ch1 * e_dh;
                 double yy = 0.0, yr = 0.0, rr = 0.0;
 #pragma unroll
                 for (int i = 0; i < 4; i++) { yy += W[6 + i] * h0[i] * h0[i]; yr += W[6 + i] * h0[i] * h1[i]; rr += W[6 + i] * h1[i] * h1[i]; }
@@ -1116,7 +1129,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         vn0 = sv[2 * s]; vn1 = sv[2 * s + 1];
         sn1 = -(e_c10 * xn[2] + e_c11 * xn[3] + e_g1) * e_d1;
         sn2 = -(e_c20 * xn[2] + e_c21 * xn[3] + e_g2) * e_d2;
-        snh = hji_on ? -(e_ch0 * xn[6] + e_ch1 * xn[7] + e_gh) * e_dh : 0.0;
+        snh = wall_on ? -(e_ch0 * xn[5] + e_gh) * e_dh : (hji_on ? -(e_ch0 * xn[6] + e_ch1 * xn[7] + e_gh) * e_dh : 0.0);
         slacks(xn, vn0, sn1, sn2, snh, tplus);
     };
 
@@ -1132,7 +1145,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         double sl[NROW];
         slacks(xs, 0.0, 0.0, 0.0, 0.0, sl);
         const double sig0 = 0.1, tau = 1e-4;
-        double sg1 = fmax(0.0, -fmin(sl[6], sl[7])) + sig0, sg2 = fmax(0.0, -fmin(sl[8], sl[9])) + sig0, sgh = hji_on ? fmax(0.0, -sl[14]) + sig0 : 0.0;
+        double sg1 = fmax(0.0, -fmin(sl[6], sl[7])) + sig0, sg2 = fmax(0.0, -fmin(sl[8], sl[9])) + sig0, sgh = wall_on ? fmax(0.0, -fmin(sl[0], sl[1])) + sig0 : (hji_on ? fmax(0.0, -sl[14]) + sig0 : 0.0);
         slacks(xs, 0.0, sg1, sg2, sgh, sl);
         if (act) {
 #pragma unroll

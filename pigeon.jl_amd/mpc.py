@@ -35,7 +35,7 @@ class BatchedTrajectoryTrackingMPC:
 
     def __init__(self, trajectory, batch_capacity, vehicle=None, control_params=None, N_short=10, N_long=20, dt_short=0.01, dt_long=0.2,
                  use_correction_step=True, rk4_substeps=10, device=0, ipm_max_iter=40, ipm_tol=None, ipm_mu0=100.0, hji_eps=0.05, formulation="coupled",
-                 precision="f64"):
+                 precision="f64", walls=False, wall_weight=1000.0):
         self.precision = precision
         self.real = np.float64 if precision == "f64" else np.float32      # element type of DEVICE arrays handed to the *_dev entry points
         if ipm_tol is None:
@@ -58,6 +58,10 @@ class BatchedTrajectoryTrackingMPC:
         cfg.N_short, cfg.N_long, cfg.dt_short, cfg.dt_long = N_short, N_long, dt_short, dt_long
         cfg.use_correction_step, cfg.rk4_substeps, cfg.batch_capacity, cfg.device = int(use_correction_step), rk4_substeps, batch_capacity, device
         cfg.ipm_max_iter, cfg.ipm_tol, cfg.ipm_mu0, cfg.hji_eps = ipm_max_iter, ipm_tol, ipm_mu0, hji_eps
+        cfg.walls = int(bool(walls))          # build-defined extension: soft rows edge_R - sw <= e <= edge_L + sw (decoupled formulation)
+        cfg.wall_weight = float(wall_weight)
+        self.wall_weight = float(wall_weight)
+        self.walls = bool(walls)
         self.cfg = cfg
         self.h = C.c_void_p()
         rc = self.lib.pg_create(C.byref(cfg), C.byref(self.h))
@@ -263,6 +267,12 @@ class BatchedTrajectoryTrackingMPC:
         self._chk(self.lib.pg_get_hji_constraint(self.h, _p(M), _p(b), _p(V)), "pg_get_hji_constraint")
         return M, b, V
 
+    def wall_edges(self):
+        """(edge_L, edge_R) at nodes 2..N+1 [B, N, 2] (wall extension)"""
+        e = np.zeros((self.B, self.N, 2))
+        self._chk(self.lib.pg_get_walls(self.h, _p(e)), "pg_get_walls")
+        return e
+
     def hji_lookup(self, x7):
         """cache[x] for a batch of HJIRelativeState rows: HJI_computation.jl:66-72."""
         x = _f64(x7).reshape(-1, 7); B = x.shape[0]
@@ -319,8 +329,9 @@ def DecoupledTrajectoryTrackingMPC(vehicle, trajectory, batch_capacity=1, **kw):
     return BatchedTrajectoryTrackingMPC(trajectory, batch_capacity, vehicle=vehicle, formulation="decoupled", **kw)
 
 
-def decoupled_canonical_active_set(N, N_short, act_masks):
-    """Signed 1-based active rows of the reference's LATERAL QP (decoupled_lat_long.jl:166-211 row order) from the per-stage masks."""
+def decoupled_canonical_active_set(N, N_short, act_masks, walls=False):
+    """Signed 1-based active rows of the reference's LATERAL QP (decoupled_lat_long.jl:166-211 row order) from the per-stage masks.
+    With the wall extension the 3N wall rows are numbered after the reference's rows: (e - sw <= edge_L, e + sw >= edge_R, sw >= 0) per node 2..N+1."""
     Ns, Nl = N_short, N - N_short
     r_1 = 0; r_2 = 2 * N; r_3 = r_2 + N; r_4 = r_3 + 4; r_5 = r_4 + 1; r_6 = r_5 + 4 * Ns; r_7 = r_6 + 4 * Nl
     out = []
@@ -335,6 +346,11 @@ def decoupled_canonical_active_set(N, N_short, act_masks):
         if bit(11): out.append(-(r_1 + 2 * k + 1 + 1))
         if bit(12): out.append(+(base + 6 + 1))
         if bit(13): out.append(-(base + 7 + 1))
+        if walls:
+            r_8 = r_7 + 8 * N
+            if bit(0): out.append(+(r_8 + 3 * k + 0 + 1))
+            if bit(1): out.append(-(r_8 + 3 * k + 1 + 1))
+            if bit(2): out.append(-(r_8 + 3 * k + 2 + 1))
     return sorted(out, key=abs)
 
 

@@ -62,3 +62,70 @@ def test_decoupled_refuses_hji(pkg, skidpad):
     knots, V, g = pkg.synthetic.hji_grid(dims=(3, 3, 3, 3, 3, 3, 3))
     with pytest.raises(pkg.PigeonError):
         mpc.set_hji_cache(knots, V, g)
+
+
+def test_walls_extension_matches_oracle_qp_with_wall_rows(pkg, oracle_mod, skidpad):
+    """BUILD-DEFINED extension (BASELINE config 5 "both_walls"; the reference snapshot has no wall constraint): soft rows
+    e_t <= edge_L(s_t) + sw_t, e_t >= edge_R(s_t) - sw_t, sw_t >= 0 with cost wall_weight dt_t sw_t at nodes 2..N+1 of the lateral QP.  Checked
+    against the oracle's canonical lateral QP extended in numpy (N slack columns, 3N rows) and solved by the oracle's sparse interior point.
+    The left wall sits at e = -0.05 m and every instance starts at e0 in [-0.5, -0.1]: the tracking cost pulls e to 0, so the wall binds."""
+    Ns, Nl, B, Ww = 10, 40, 48, 1000.0
+    t = skidpad
+    tube = pkg.TrajectoryTube(t.t, t.s, t.V, t.A, t.E, t.N, t.psi, t.kappa, edge_L=np.full(len(t), -0.05), edge_R=np.full(len(t), -4.0))
+    rng = np.random.default_rng(5)
+    s = rng.uniform(5.0, tube.s[-1] - 80.0, B)
+    E, N, psi, kappa, V, tt = pkg.synthetic.path_pose(tube, s)
+    e = rng.uniform(-0.5, -0.1, B)
+    state = np.stack([E - e * np.cos(psi), N - e * np.sin(psi), psi + rng.uniform(-0.05, 0.05, B), V * rng.uniform(0.95, 1.05, B), rng.uniform(-0.1, 0.1, B),
+                      kappa * V + rng.uniform(-0.02, 0.02, B)], axis=1)
+    control = np.stack([rng.uniform(-0.02, 0.02, B), np.zeros(B), rng.uniform(0, 300.0, B)], axis=1)
+    t0 = tt + rng.uniform(-0.1, 0.1, B); toff = np.zeros(B)
+    mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), tube, B, N_short=Ns, N_long=Nl, walls=True, wall_weight=Ww)
+    free = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), tube, B, N_short=Ns, N_long=Nl)
+    u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
+    uf, stf, _ = free.step_(state, control, t0, time_offset=toff)
+    assert np.all(status == 1), np.bincount(status)
+    x, sg = mpc.solution(); st, it, act, mu = mpc.solve_info(); edges = mpc.wall_edges(); xf, _ = free.solution()
+    orc = oracle_mod.OracleDecoupled(N_short=Ns, N_long=Nl); orc.set_trajectory(tube.data)
+    n, m, Nh = orc.n, orc.m, orc.N
+    n_active = 0; worst = 0.0
+    for b in range(B):
+        ts, dt = orc.time_steps(t0[b])
+        oq, ou, op = orc.nodes(state[b], control[b], ts, dt, time_offset=toff[b])
+        oe = orc.node_edges(state[b], control[b], ts, dt, time_offset=toff[b])
+        assert np.max(np.abs(edges[b] - oe[1:])) < 1e-12
+        sd = orc.update_qp(oq, ou, op, dt)
+        qpc = orc.assemble_qp(sd)
+        # extend: columns n..n+N-1 = sw_k; rows m+3k: e - sw <= edge_L, m+3k+1: e + sw >= edge_R, m+3k+2: sw >= 0; e = component 3 of q = (Uy, r, dpsi, e)
+        A = sp.csc_matrix((qpc["Ax"], qpc["Ai"], qpc["Ap"]), shape=(m, n))
+        W = sp.lil_matrix((3 * Nh, n + Nh)); lw = np.full(3 * Nh, -1e20); uw = np.full(3 * Nh, 1e20)
+        for k in range(Nh):
+            col = 4 * (k + 1) + 3
+            W[3 * k, col] = 1.0; W[3 * k, n + k] = -1.0; uw[3 * k] = oe[k + 1, 0]
+            W[3 * k + 1, col] = 1.0; W[3 * k + 1, n + k] = 1.0; lw[3 * k + 1] = oe[k + 1, 1]
+            W[3 * k + 2, n + k] = 1.0; lw[3 * k + 2] = 0.0
+        Aw = sp.vstack([sp.hstack([A, sp.csc_matrix((m, Nh))]), W]).tocsc(); Aw.sort_indices()
+        qpw = dict(Pd=np.concatenate([qpc["Pd"], np.zeros(Nh)]), q=np.concatenate([qpc["q"], Ww * dt]), Ap=Aw.indptr, Ai=Aw.indices, Ax=Aw.data,
+                   l=np.concatenate([qpc["l"], lw]), u=np.concatenate([qpc["u"], uw]))
+        xe, ye, info = oracle_mod.solve_exact_generic(qpw)
+        assert info["status"] == 1, (b, info)
+        X = orc.split_x(xe[:n])
+        worst = max(worst, abs(x[b, 1, 6] - X["delta"][1]))
+        xg = np.concatenate([x[b, :, 2:6].ravel(), x[b, :, 6], sg[b, :, :2].ravel(), np.diff(x[b, :, 6]), sg[b, :, 2]])
+        obj = lambda v: 0.5 * np.dot(qpw["Pd"] * v, v) + np.dot(qpw["q"], v)
+        assert abs(obj(xg) - obj(xe)) <= 1e-6 * (1.0 + abs(obj(xe))), (b, obj(xg), obj(xe))
+        Axg = Aw @ xg
+        assert max(np.max(qpw["l"] - Axg), np.max(Axg - qpw["u"])) < 1e-8
+        # active sets: the far-horizon steering is not unique (R_delta = 0) and where a wall starts or stops binding the multipliers are not unique
+        # either (sw = 0 together with a tight wall row), so the index lists are compared as a sandwich: every strongly active row of the oracle is
+        # active on the GPU, and every GPU-active row is tight at the GPU's optimum (whose optimality the objective/feasibility certificate above shows)
+        G = set(pkg.decoupled_canonical_active_set(Nh, Ns, act[b], walls=True))
+        strong = set(oracle_mod.active_set(qpw, xe, ye, tol=1e-3))
+        tight = {+(i + 1) for i in range(len(Axg)) if qpw["u"][i] - Axg[i] < 1e-6} | {-(i + 1) for i in range(len(Axg)) if Axg[i] - qpw["l"][i] < 1e-6}
+        assert strong <= G <= tight, (b, sorted(strong - G, key=abs)[:5], sorted(G - tight, key=abs)[:5])
+        n_active += sum(1 for k in range(Nh) if int(act[b][k]) & 1)
+    assert worst < 2e-5, worst          # (N = 50 with binding walls: a third of the instances stop at the rounding floor mu ~ 1e-10, see DESIGN.md 4.3)
+    assert n_active > 5 * B                                                            # the wall really binds
+    assert np.max(xf[:, 1:, 5]) > -0.04                                                # ... and without it the optimum crosses e = -0.05
+    with pytest.raises(pkg.PigeonError):
+        pkg.BatchedTrajectoryTrackingMPC(tube, 4, walls=True)                         # coupled + walls is refused
