@@ -1,0 +1,57 @@
+"""GPU parity sweep over every path the reference ships (test/path/*.world, committed as data under tests/golden/paths) in both tracking
+modes (trajectory mode: time_offset = 0; path mode: time_offset = NaN, ros_integration.jl:74-76), cold and warm.  Per path and mode: every
+instance solves; a subsample is compared with the oracle stage by stage (nodes 1e-9, QP data 1e-8, applied control 1e-6 against the exact
+optimum of the same QP data, identical active-set index lists)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, make_oracle
+
+pytestmark = pytest.mark.gpu
+
+PATHS = sorted(f[:-4] for f in os.listdir(os.path.join(ROOT, "tests", "golden", "paths")) if f.endswith(".npz"))
+B = 384
+
+
+def rel_inf(a, b, floor=1.0):
+    a = np.asarray(a); b = np.asarray(b)
+    return float(np.max(np.abs(a - b)) / max(floor, float(np.max(np.abs(b)))))
+
+
+@pytest.mark.parametrize("traj_mode", [True, False], ids=["traj", "path"])
+@pytest.mark.parametrize("path", PATHS)
+def test_path_sweep(pkg, oracle_mod, path, traj_mode):
+    tube = pkg.load_path_fixture(path)
+    s_range = None if tube.s[-1] > 90 else (2.0, 0.4 * tube.s[-1])
+    state, control, t0, toff = pkg.synthetic.config2_inputs(tube, B, seed=sum(map(ord, path)) % 1000, traj_mode=traj_mode, s_range=s_range)
+    mpc = pkg.BatchedTrajectoryTrackingMPC(tube, B)
+    orc = make_oracle(oracle_mod, tube)
+    u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
+    assert np.all(status == 1), (path, np.bincount(status))
+    qs, us, ps = mpc.nodes(); qp = mpc.qp_data(); x, _ = mpc.solution(); _, _, act, _ = mpc.solve_info()
+    for b in range(0, B, 48):
+        ts, dt = orc.time_steps(t0[b])
+        oq, ou, op = orc.nodes(state[b], control[b], ts, dt, time_offset=toff[b])
+        assert rel_inf(qs[b], oq) < 1e-9 and rel_inf(us[b], ou) < 1e-9 and rel_inf(ps[b], op) < 1e-9, (path, b)
+        sd = orc.update_qp(oq, ou, op, dt, state[b], control[b], (0, 0, 0, 0))
+        G = orc.unpack_sd(qp[b]); O = orc.unpack_sd(sd)
+        for k in O:
+            assert rel_inf(G[k], O[k]) < 1e-8, (path, b, k)
+        xe, ye, info = orc.solve_exact(qp[b])
+        assert info["status"] == 1
+        assert rel_inf(x[b, 1, 6:], orc.split_x(xe)["u"][1]) < 1e-6, (path, b)
+        assert mpc.canonical_active_set(b, act[b], qp[b]) == oracle_mod.active_set(orc.assemble_qp(qp[b]), xe, ye, tol=1e-6), (path, b)
+    # second (warm) step on the same handle: plant advanced by the oracle's model with the old control (simulate semantics)
+    sel = np.arange(0, B, 48)
+    state2 = state.copy()
+    for b in sel:
+        state2[b] = orc.plant_step(state[b], control[b], 0.01)
+    u2, status2, _ = mpc.step_(state2, u, t0 + 0.01, time_offset=toff)
+    assert np.all(status2[sel] == 1)
+    qp2 = mpc.qp_data(); x2, _ = mpc.solution()
+    for b in sel[:3]:
+        xe, ye, info = orc.solve_exact(qp2[b])
+        assert rel_inf(x2[b, 1, 6:], orc.split_x(xe)["u"][1]) < 1e-6, (path, b, "warm")
+    mpc.close()
