@@ -1,0 +1,58 @@
+"""GPU tests of the ABI's error behaviour and call-order contract (include/pigeon_mpc.h): negative status codes + pg_last_error text, never a crash;
+the reference raises Julia exceptions at the same places (ros_integration.jl:95-102 catches and logs them)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_call_order_and_argument_checks(pkg, skidpad):
+    from pigeon_jl_amd import _lib
+    lib = pkg.load_library()
+    m = pkg.BatchedTrajectoryTrackingMPC(None, 8)                     # no trajectory yet
+    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, 8, seed=2)
+    with pytest.raises(pkg.PigeonError, match="no inputs"):
+        m.compute_time_steps_()
+    m.set_inputs(state, control, t0, time_offset=toff)
+    with pytest.raises(pkg.PigeonError, match="no trajectory"):
+        m.compute_time_steps_()
+    m.set_trajectory(skidpad)
+    with pytest.raises(pkg.PigeonError, match="batch size"):
+        s9 = np.zeros((9, 6)); m.set_inputs(s9, np.zeros((9, 3)), np.zeros(9))      # B > batch_capacity
+    assert lib.pg_set_inputs(m.h, 8, None, None, None, None, None) == -2                 # PG_ERR_INVALID: required pointers
+    assert lib.pg_get_next_control(m.h, None) == -2
+    assert lib.pg_step(None, 8, None, None, None, None, None, None, None, None) == -2   # null handle
+    with pytest.raises(pkg.PigeonError, match="walls are off"):
+        m.wall_edges()
+    # a valid step still works after the rejected calls, and a smaller batch than the capacity is fine
+    u, status, iters = m.step_(state[:5], control[:5], t0[:5], time_offset=toff[:5])
+    assert u.shape == (5, 3) and np.all(status == 1)
+    cfg = _lib.pg_config(); lib.pg_default_config(C.byref(cfg))
+    h = C.c_void_p()
+    cfg.N_short, cfg.N_long = 10, 60                                                     # 71 nodes > 64
+    assert lib.pg_create(C.byref(cfg), C.byref(h)) == -2 and b"horizon" in lib.pg_last_error(None)
+    cfg.N_short, cfg.N_long, cfg.device = 10, 20, 99
+    assert lib.pg_create(C.byref(cfg), C.byref(h)) == -2 and b"device" in lib.pg_last_error(None)
+    m.close()
+
+
+def test_reset_mask_restarts_only_the_masked_instances(pkg, skidpad):
+    """mpc.solved = false for a subset (ros_integration.jl:34,41,147): masked instances take the cold branch again, the others stay warm."""
+    B = 64
+    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B, seed=9)
+    a = pkg.BatchedTrajectoryTrackingMPC(skidpad, B); b = pkg.BatchedTrajectoryTrackingMPC(skidpad, B)
+    a.step_(state, control, t0, time_offset=toff); b.step_(state, control, t0, time_offset=toff)
+    mask = np.zeros(B, dtype=np.uint8); mask[::3] = 1
+    a.reset(mask)
+    ua, _, _ = a.step_(state, control, t0 + 0.01, time_offset=toff)
+    qa = a.nodes()[0]
+    ub, _, _ = b.step_(state, control, t0 + 0.01, time_offset=toff)          # all warm
+    qb = b.nodes()[0]
+    b.reset(); uc, _, _ = b.step_(state, control, t0 + 0.01, time_offset=toff)  # all cold
+    qc = b.nodes()[0]
+    sel = mask.astype(bool)
+    assert np.array_equal(qa[sel], qc[sel]) and np.array_equal(qa[~sel], qb[~sel])
+    assert not np.array_equal(qb[sel], qc[sel])
+    a.close(); b.close()
