@@ -227,6 +227,17 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # secondary roofline of the dominant kernel: fp64 VALU issue slots (the resource that actually binds).  Instruction count per launch
+        # from the committed PMC pass (SQ_INSTS_VALU, a property of the code and the inputs), time live; peak = 1024 SIMDs x 2.4 GHz / 4 clocks per wave-instruction
+        valu = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_final", "pmc_summary.json")))
+            ins = pm["pg::k_solve<false, false>"]["SQ_INSTS_VALU"]["mean_per_launch"] * (B / 4096.0)
+            if args.precision == "f64" and dom == 2:
+                valu = {"wave_instructions_per_launch": ins, "achieved": ins / (dom_ms * 1e-3) / 1e9, "peak": 1024 * 2.4e9 / 4 / 1e9, "unit": "G wave-instr/s",
+                        "frac": ins / (dom_ms * 1e-3) / (1024 * 2.4e9 / 4), "source": "profiles/r01_final/pmc_summary.json (SQ_INSTS_VALU)"}
+        except Exception:
+            valu = None
         line = {
             "metric": "MPC QP solves/sec (N=30 coupled, X1 model)", "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -237,7 +248,7 @@ def main():
                        "solver": "Mehrotra interior point on the stage-structured QP (Riccati), tol " + ("1e-12" if args.precision == "f64" else "1e-5"),
                        "accuracy": "max|u-u*| <= 1e-6 (normalised) vs exact optimum" if args.precision == "f64" else "max|u-u*| <= 5e-3, median 5e-5 (normalised) vs exact optimum"},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "avg_launch_ms": dom_ms,
+                         "traffic": traffic, "avg_launch_ms": dom_ms, "valu_issue": valu,
                          "note": f"algorithmic HBM bytes are {bytes_per_solve} B/solve (SURVEY 8d): the step is VALU/LDS/latency bound by construction, not HBM bound"},
             "phase_ms": {n: float(v) for n, v in zip(names, ph)},
             "warm_value": world * B * args.steps / warm_elapsed,

@@ -23,6 +23,9 @@ os.makedirs(dst, exist_ok=True)
 ks = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
 assert len(ks) == 1, ks
 shutil.copy(ks[0], os.path.join(dst, "kernel_stats.csv"))
+ks32 = glob.glob(os.path.join(src, "stats_f32", "*", "*_kernel_stats.csv"))
+if len(ks32) == 1:
+    shutil.copy(ks32[0], os.path.join(dst, "kernel_stats_f32.csv"))
 
 
 def short(name):
