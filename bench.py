@@ -138,20 +138,25 @@ def main():
     # BASELINE config 5: decoupled (lateral) MPC, N = 50 (N_short = 10, N_long = 40), same batch, cold every step (that formulation has no warm branch)
     dec = None
     if rank == 0 and not args.no_decoupled:
-        mpc_d = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, device=local, precision=args.precision, walls=True)
-        mpc_d.set_stream(torch.cuda.current_stream().cuda_stream)
-        mpc_d.set_inputs_dev(B, d_state.data_ptr(), d_control.data_ptr(), d_t0.data_ptr(), None, d_toff.data_ptr())
-        for _ in range(2):
-            mpc_d.step_dev(u_out.data_ptr())
-        torch.cuda.synchronize(); td = time.perf_counter()
-        for _ in range(args.steps):
-            mpc_d.step_dev(u_out.data_ptr())
-        torch.cuda.synchronize(); td = time.perf_counter() - td
-        std, itd, _, _ = mpc_d.solve_info()
-        dec = {"workload": f"configs[4]: Batch={B} decoupled MPC, N=50 + both_walls (soft rows edge_R - sw <= e <= edge_L + sw from the tube's edge channels: a build-defined extension, the reference snapshot has no wall constraint), {args.precision}", "value": B * args.steps / td, "unit": "solves/s",
-               "ms_per_step": 1e3 * td / args.steps, "phase_ms": [float(v) for v in mpc_d.phase_ms()], "solved": f"{int((std == pkg.SOLVED).sum())}/{B}",
-               "ipm_iters_mean": float(np.mean(itd))}
-        mpc_d.close()
+        def run_dec(walls):
+            mpc_d = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, device=local, precision=args.precision, walls=walls)
+            mpc_d.set_stream(torch.cuda.current_stream().cuda_stream)
+            mpc_d.set_inputs_dev(B, d_state.data_ptr(), d_control.data_ptr(), d_t0.data_ptr(), None, d_toff.data_ptr())
+            for _ in range(2):
+                mpc_d.step_dev(u_out.data_ptr())
+            torch.cuda.synchronize(); td = time.perf_counter()
+            for _ in range(args.steps):
+                mpc_d.step_dev(u_out.data_ptr())
+            torch.cuda.synchronize(); td = time.perf_counter() - td
+            std, itd, _, _ = mpc_d.solve_info()
+            r = {"value": B * args.steps / td, "unit": "solves/s", "ms_per_step": 1e3 * td / args.steps, "phase_ms": [float(v) for v in mpc_d.phase_ms()],
+                 "solved": f"{int((std == pkg.SOLVED).sum())}/{B}", "ipm_iters_mean": float(np.mean(itd))}
+            mpc_d.close()
+            return r
+        dec = {"workload": f"configs[4]: Batch={B} decoupled MPC, N=50 + both_walls (soft rows edge_R - sw <= e <= edge_L + sw from the tube's edge channels: a build-defined "
+                           f"extension, the reference snapshot has no wall constraint), {args.precision}"}
+        dec.update(run_dec(True))
+        dec["without_walls"] = run_dec(False)            # the reference's own lateral QP (decoupled_lat_long.jl as it stands)
 
     # HJI value/gradient lookup (the bandwidth-bound kernel of the path): 2^20 random in-grid relative states against the config-3 grid
     hji = None
