@@ -828,7 +828,10 @@ PG_DEV real rl(real v, int src) {
 }
 // waves per SIMD the solve kernel is compiled for: the fp32 iterate needs half the registers and half the LDS, so two waves share a SIMD
 #ifdef PG_F32
-#define PG_SOLVE_WAVES(RING) 2
+#ifndef PG_F32_WAVES
+#define PG_F32_WAVES 2          // (-DPG_F32_WAVES=1 builds the fp32 kernel for one wave per SIMD: the experiment that isolates the occupancy effect)
+#endif
+#define PG_SOLVE_WAVES(RING) PG_F32_WAVES
 #else
 #define PG_SOLVE_WAVES(RING) ((RING) ? 2 : 1)
 #endif
