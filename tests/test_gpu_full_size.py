@@ -72,6 +72,30 @@ def test_random_subset_against_oracle(run, oracle_mod, skidpad):
     assert worst < 1e-6, worst
 
 
+def test_accuracy_distribution_over_the_batch(run, oracle_mod, skidpad):
+    """Applied control against the exact optimum of the same QP data for every 4th instance of the 4096 batch (1024 oracle solves, threaded).
+    Measured over all 4096 (tools/gpu_accuracy_full.py): median 2e-12, 99.9th percentile 2.5e-7, 3 instances between 1e-6 and 3e-6 -- nearly
+    degenerate instances (a row whose slack and multiplier are both ~sqrt(mu)) approach the optimum like sqrt(mu) and the rounding noise of the
+    Newton systems forbids mu < 1e-13.  The bar asserted here: 99.5 % within 1e-6, every instance within 1e-5."""
+    from concurrent.futures import ThreadPoolExecutor
+    mpc, state, control, t0, toff, u, status, iters = run
+    qp = mpc.qp_data(); x, _ = mpc.solution()
+    nthr = 8
+    orcs = [make_oracle(oracle_mod, skidpad) for _ in range(nthr)]
+    sel = np.arange(0, B, 4)
+
+    def work(w):
+        out = []
+        for b in sel[w::nthr]:
+            xe, ye, info = orcs[w].solve_exact(qp[b])
+            out.append(float(np.max(np.abs(x[b, 1, 6:] - orcs[w].split_x(xe)["u"][1]))) if info["status"] == 1 else np.nan)
+        return out
+    with ThreadPoolExecutor(nthr) as ex:
+        err = np.array(sum(ex.map(work, range(nthr)), []))
+    assert not np.any(np.isnan(err))
+    assert np.mean(err <= 1e-6) >= 0.995 and err.max() <= 1e-5 and np.median(err) <= 1e-9, (np.mean(err <= 1e-6), err.max(), np.median(err))
+
+
 def test_golden_cases_on_gpu(pkg):
     """The committed vectors (tools/make_golden_cases.py): cold step and warm second step on two of the reference's test paths."""
     G = np.load(os.path.join(ROOT, "tests", "golden", "coupled_cases.npz"))
