@@ -1054,18 +1054,19 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             sMT[9 * lj + li] = ma;
             *(lj < 3 ? sMT + 9 * (8 + lj) + li : sDum + lane) = aug;
             *(lj == 2 ? sMc + 8 * k + li : sDum + lane) = aug;
+            // S = Rhat + Bbar' (P Bbar): the two columns of P Bbar sit in the `aug` registers of lanes (m, 0) and (m, 1); broadcasting them through SGPRs
+            // keeps 16 wave-uniform doubles out of LDS and takes the 2x2 solve off the path that waits for the exchange below
+            double S00 = R0 + rl(aug, 48), S01 = rl(aug, 49), S11 = R1 + rl(aug, 57);
+#pragma unroll
+            for (int m = 0; m < 6; m++) { const double m0 = rl(aug, 8 * m), m1 = rl(aug, 8 * m + 1); S00 += bk0[m] * m0; S01 += bk0[m] * m1; S11 += bk1[m] * m1; }
+            const double idet = frcp(S00 * S11 - S01 * S01);
             __syncthreads();
-            double cj[8], ci[8], mb0[8], mb1[8];
+            double cj[8], ci[8];
 #pragma unroll
-            for (int m = 0; m < 8; m++) { cj[m] = sMT[9 * lj + m]; ci[m] = sMT[9 * li + m]; mb0[m] = sMT[72 + m]; mb1[m] = sMT[81 + m]; }
+            for (int m = 0; m < 8; m++) { cj[m] = sMT[9 * lj + m]; ci[m] = sMT[9 * li + m]; }
             double Fj0 = cj[6], Fj1 = cj[7], Fi0 = ci[6], Fi1 = ci[7];
-            double S00 = R0 + mb0[6], S01 = mb1[6], S11 = R1 + mb1[7];
 #pragma unroll
-            for (int m = 0; m < 6; m++) {
-                Fj0 += bk0[m] * cj[m]; Fj1 += bk1[m] * cj[m]; Fi0 += bk0[m] * ci[m]; Fi1 += bk1[m] * ci[m];
-                S00 += bk0[m] * mb0[m]; S01 += bk0[m] * mb1[m]; S11 += bk1[m] * mb1[m];
-            }
-            double idet = frcp(S00 * S11 - S01 * S01);
+            for (int m = 0; m < 6; m++) { Fj0 += bk0[m] * cj[m]; Fj1 += bk1[m] * cj[m]; Fi0 += bk0[m] * ci[m]; Fi1 += bk1[m] * ci[m]; }
             double I00 = S11 * idet, I01 = -S01 * idet, I11 = S00 * idet;
             double K0 = -(I00 * Fj0 + I01 * Fj1), K1 = -(I01 * Fj0 + I11 * Fj1);
             *(li < 2 ? sK + 16 * k + 8 * li + lj : sDum + lane) = li == 0 ? K0 : K1;
