@@ -837,6 +837,15 @@ PG_DEV real rl(real v, int src) {
 #endif
 // PG_KEEP_END
 
+// Ordering point between an LDS write and the LDS reads of OTHER lanes of the same wavefront.  k_solve's workgroup is one wave and the LDS pipeline
+// executes the DS instructions of a wave in order, so no s_barrier and no s_waitcnt lgkmcnt(0) are needed: the compiler only has to keep the order
+// (wavefront-scope fences + a scheduling barrier).  The write and the dependent reads then queue back to back instead of one round trip apart.
+PG_DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <bool PROF, bool RING>
 __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, int B, const double* __restrict__ qp, const double* __restrict__ abar, const double* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof) {
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -1043,7 +1052,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
 #pragma unroll
             for (int m = 0; m < 6; m++) a6v[m] = Ak[SB_ROW * m + r8];
             double qkv = sq[8 * k + r8], r0v = sr[2 * k], r1v = sr[2 * k + 1];
-            __syncthreads();
+            wave_sync();
             double prow[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) prow[m] = sP[9 * li + m];
@@ -1060,7 +1069,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
 #pragma unroll
             for (int m = 0; m < 6; m++) { const double m0 = rl(aug, 8 * m), m1 = rl(aug, 8 * m + 1); S00 += bk0[m] * m0; S01 += bk0[m] * m1; S11 += bk1[m] * m1; }
             const double idet = frcp(S00 * S11 - S01 * S01);
-            __syncthreads();
+            wave_sync();
             double cj[8], ci[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) { cj[m] = sMT[9 * lj + m]; ci[m] = sMT[9 * li + m]; }
