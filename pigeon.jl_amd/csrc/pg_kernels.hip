@@ -605,18 +605,20 @@ __global__ __launch_bounds__(256) void k_hji_lookup(HjiView Hv, int B, const dou
     const bool live = look < B;
     if (!live) look = B - 1;                       // keep whole rows active for the DPP reduction; results of dead groups are not stored
     const double* x = x7 + (size_t)look * 7;
-    // every lane searches all 7 dims (knot vectors are tiny and L1-resident): searchsortedlast, clamp to [1, n-1], in-bounds test (:67)
+    // lane d < 7 of the group searches dimension d (searchsortedlast, clamp to [1, n-1], in-bounds test :67; knot vectors are tiny and L1-resident) and
+    // the seven (index, weight, in-bounds) triples are shared over the 16-lane row: one 4-probe search per lane instead of seven in a row before the gather
     int idx[7]; double w[7]; bool inb = true;
-#pragma unroll
-    for (int d = 0; d < 7; d++) {
+    {
+        const int d = g < 7 ? g : 6;
         const float* k = Hv.knots + Hv.koff[d]; const int n = Hv.dims[d]; const double xv = x[d];
-        inb = inb && ((double)k[0] <= xv) && (xv <= (double)k[n - 1]);
+        const int in_m = ((double)k[0] <= xv) && (xv <= (double)k[n - 1]);
         int lo = 0, hi = n;
         while (lo < hi) { int mid = (lo + hi) >> 1; if ((double)k[mid] <= xv) lo = mid + 1; else hi = mid; }
-        int i = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
-        idx[d] = i - 1;
-        double k0 = k[i - 1], k1 = k[i];
-        w[d] = (xv - k0) / (k1 - k0);
+        const int i = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+        const double k0 = k[i - 1], k1 = k[i];
+        const double w_m = (xv - k0) / (k1 - k0);
+#pragma unroll
+        for (int e = 0; e < 7; e++) { idx[e] = __shfl(i - 1, e, 16); w[e] = __shfl(w_m, e, 16); inb = inb && (__shfl(in_m, e, 16) != 0); }
     }
     double acc[8];
 #pragma unroll
