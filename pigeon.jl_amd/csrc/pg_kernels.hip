@@ -636,9 +636,18 @@ __global__ __launch_bounds__(256) void k_hji_lookup(HjiView Hv, int B, const dou
         for (int j = 0; j < 16; j++) r[j] = p[16 * j];
         const int lb = g >> 1;
         const double wlo = ((lb & 1) ? w[0] : (1.0 - w[0])) * ((lb & 2) ? w[1] : (1.0 - w[1])) * ((lb & 4) ? w[2] : (1.0 - w[2]));
+        // tensor-product weights of dims 4..7 built as a tree (30 products instead of 80)
+        double wt[16];
+        wt[0] = wlo * (1.0 - w[3]); wt[1] = wlo * w[3];
+#pragma unroll
+        for (int j = 3; j >= 0; j--) { wt[j] = wt[j & 1] * ((j & 2) ? w[4] : (1.0 - w[4])); }
+#pragma unroll
+        for (int j = 7; j >= 0; j--) { wt[j] = wt[j & 3] * ((j & 4) ? w[5] : (1.0 - w[5])); }
+#pragma unroll
+        for (int j = 15; j >= 0; j--) { wt[j] = wt[j & 7] * ((j & 8) ? w[6] : (1.0 - w[6])); }
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            double wj = wlo * ((j & 1) ? w[3] : (1.0 - w[3])) * ((j & 2) ? w[4] : (1.0 - w[4])) * ((j & 4) ? w[5] : (1.0 - w[5])) * ((j & 8) ? w[6] : (1.0 - w[6]));
+            const double wj = wt[j];
             acc[0] += wj * (double)r[j].x; acc[1] += wj * (double)r[j].y; acc[2] += wj * (double)r[j].z; acc[3] += wj * (double)r[j].w;
         }
     }
