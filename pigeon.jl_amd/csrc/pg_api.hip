@@ -432,7 +432,7 @@ int pg_update_qp(pg_handle* h) {
     hipLaunchKernelGGL(k_linearize, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_qp);
     LAUNCH_CHECK(h);
     long nt = (long)B * C.N;
-    hipLaunchKernelGGL(k_limits, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp, h->d_abar);
+    hipLaunchKernelGGL(k_limits, dim3((unsigned)((nt * 8 + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp, h->d_abar);
     LAUNCH_CHECK(h);
     return PG_OK;
 }

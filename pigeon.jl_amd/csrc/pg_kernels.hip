@@ -284,47 +284,54 @@ __global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const double
     }
 }
 
-// finishes c = Phi - A q - B0 u0 - Bf uf, scales B by u_normalization, stability envelope + bounds (:354-367), q_curr/u_curr (:332-333), HJI row (:345-346)
+// finishes c = Phi - A q - B0 u0 - Bf uf, scales B by u_normalization, stability envelope + bounds (:354-367), q_curr/u_curr (:332-333), HJI row (:345-346).
+// EIGHT lanes per (instance, interval): lane i < 6 owns row i of the linearisation (its loads and stores are contiguous segments and the eight lanes of an
+// interval cover whole cache lines: one lane per interval touched 64 different lines per instruction); lane 6 does the envelope and the bounds, lane 7 the
+// per-instance header of interval 0.
 __global__ __launch_bounds__(256) void k_limits(DevCfg C, int B, const double* __restrict__ nodes, const tdouble* __restrict__ dt, const double* __restrict__ hji_Mb, double* __restrict__ qp,
                                                 double* __restrict__ abar) {
-    long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long)B * C.N) return;
-    int b = (int)(gid / C.N), t = (int)(gid - (long)b * C.N);
-    bool ramp = t >= C.Ns;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long it = gid >> 3; const int i = (int)(gid & 7);
+    if (it >= (long)B * C.N) return;
+    const int b = (int)(it / C.N), t = (int)(it - (long)b * C.N);
+    const bool ramp = t >= C.Ns;
     const double* n0 = nodes + ((size_t)b * C.NN + t) * 10; const double* n1 = n0 + 10;
-    QpOff o = qp_offsets(C.N);
+    const QpOff o = qp_offsets(C.N);
     double* Q = qp + (size_t)b * C.qp_len;
-    double* A = Q + o.A + 36 * t; double* B0 = Q + o.B0 + 12 * t; double* Bf = Q + o.Bf + 12 * t; double* c = Q + o.c + 6 * t;
-    for (int i = 0; i < 6; i++) {
-        double ci = c[i];
-        for (int j = 0; j < 6; j++) ci -= A[6 * i + j] * n0[j];
-        ci -= B0[2 * i] * n0[6] + B0[2 * i + 1] * n0[7];
-        if (ramp) ci -= Bf[2 * i] * n1[6] + Bf[2 * i + 1] * n1[7];
-        else { Bf[2 * i] = 0.0; Bf[2 * i + 1] = 0.0; }
-        c[i] = ci;
-        B0[2 * i] *= C.un0; B0[2 * i + 1] *= C.un1; Bf[2 * i] *= C.un0; Bf[2 * i + 1] *= C.un1;      // :338,350-351
-    }
-    {   // packed copy streamed by k_solve: rows 0..5 of Abar = [A | B0+Bf], Bbar = Bf, cbar = c  (SB doubles per stage)
-        double* P66 = abar + ((size_t)b * C.N + t) * SB;
-        for (int i = 0; i < 6; i++) {
-            for (int j = 0; j < 6; j++) P66[SB_ROW * i + j] = A[6 * i + j];
-            P66[SB_ROW * i + 6] = B0[2 * i] + Bf[2 * i]; P66[SB_ROW * i + 7] = B0[2 * i + 1] + Bf[2 * i + 1]; P66[SB_ROW * i + 8] = 0.0;
-            P66[SB_B + 2 * i] = Bf[2 * i]; P66[SB_B + 2 * i + 1] = Bf[2 * i + 1];
-            P66[SB_C + i] = c[i];
-        }
-    }
-    double Uxt = n1[1], Fx = n1[7];                                                                   // :357-358
-    double Fxf = Fx > 0.0 ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac, Fxr = Fx > 0.0 ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
-    Envelope e = stable_limits(C.veh, Uxt, Fxf, Fxr);
-    for (int i = 0; i < 4; i++) { Q[o.H + 8 * t + 2 * i] = e.H[i][0]; Q[o.H + 8 * t + 2 * i + 1] = e.H[i][1]; Q[o.G + 4 * t + i] = e.G[i]; }
-    double h = dt[(size_t)b * C.N + t];
-    Q[o.dmin + t] = jmax(e.dmin, -C.veh.delta_max) / C.un0;
-    Q[o.dmax + t] = jmin(e.dmax, C.veh.delta_max) / C.un0;
-    Q[o.fxmax + t] = jmin(C.veh.Px_max / Uxt, C.veh.Fx_max) / C.un1;
-    Q[o.ddmin + t] = -C.cp.deltadot_max * h / C.un0;
-    Q[o.ddmax + t] = C.cp.deltadot_max * h / C.un0;
-    Q[o.dt + t] = h;
-    if (t == 0) {
+    double* P66 = abar + ((size_t)b * C.N + t) * SB;      // packed copy streamed by k_solve: rows 0..5 of Abar = [A | B0+Bf], Bbar = Bf, cbar = c  (SB doubles per stage)
+    if (i < 6) {
+        double* A = Q + o.A + 36 * t + 6 * i; double* B0 = Q + o.B0 + 12 * t + 2 * i; double* Bf = Q + o.Bf + 12 * t + 2 * i; double* c = Q + o.c + 6 * t + i;
+        double ci = c[0];
+        double a[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { a[j] = A[j]; ci -= a[j] * n0[j]; }
+        double b00 = B0[0], b01 = B0[1], bf0 = ramp ? Bf[0] : 0.0, bf1 = ramp ? Bf[1] : 0.0;
+        ci -= b00 * n0[6] + b01 * n0[7];
+        if (ramp) ci -= bf0 * n1[6] + bf1 * n1[7];
+        c[0] = ci;
+        b00 *= C.un0; b01 *= C.un1; bf0 *= C.un0; bf1 *= C.un1;                                      // :338,350-351
+        B0[0] = b00; B0[1] = b01; Bf[0] = bf0; Bf[1] = bf1;
+        double* row = P66 + SB_ROW * i;
+#pragma unroll
+        for (int j = 0; j < 6; j++) row[j] = a[j];
+        row[6] = b00 + bf0; row[7] = b01 + bf1; row[8] = 0.0;
+        P66[SB_B + 2 * i] = bf0; P66[SB_B + 2 * i + 1] = bf1;
+        P66[SB_C + i] = ci;
+    } else if (i == 6) {
+        const double Uxt = n1[1], Fx = n1[7];                                                        // :357-358
+        const double Fxf = Fx > 0.0 ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac, Fxr = Fx > 0.0 ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
+        const Envelope e = stable_limits(C.veh, Uxt, Fxf, Fxr);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { Q[o.H + 8 * t + 2 * r] = e.H[r][0]; Q[o.H + 8 * t + 2 * r + 1] = e.H[r][1]; Q[o.G + 4 * t + r] = e.G[r]; }
+        const double h = dt[(size_t)b * C.N + t];
+        Q[o.dmin + t] = jmax(e.dmin, -C.veh.delta_max) / C.un0;
+        Q[o.dmax + t] = jmin(e.dmax, C.veh.delta_max) / C.un0;
+        Q[o.fxmax + t] = jmin(C.veh.Px_max / Uxt, C.veh.Fx_max) / C.un1;
+        Q[o.ddmin + t] = -C.cp.deltadot_max * h / C.un0;
+        Q[o.ddmax + t] = C.cp.deltadot_max * h / C.un0;
+        Q[o.dt + t] = h;
+    } else if (t == 0) {
+#pragma unroll
         for (int k = 0; k < 6; k++) Q[o.qcurr + k] = n0[k];
         Q[o.ucurr] = n0[6] / C.un0; Q[o.ucurr + 1] = n0[7] / C.un1;
         if (C.has_hji) { Q[o.M] = hji_Mb[(size_t)b * 4]; Q[o.M + 1] = hji_Mb[(size_t)b * 4 + 1]; Q[o.b] = hji_Mb[(size_t)b * 4 + 2]; }
