@@ -169,8 +169,10 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
     ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_u, cap * 3, real); ALLOC(h->d_mu, cap, real);
     ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_active, cap * N, uint16_t);
-    { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (pg_solve4.hip)
+#ifdef PG_EXPERIMENTAL_SOLVE4
+    { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (experimental/pg_solve4.hip)
     if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), real);
+#endif
     if (cfg->walls) { ALLOC(h->d_walls, cap * N * 2, real); C.walls = 1; C.wall_weight = (real)cfg->wall_weight; C.wall_edges = h->d_walls; if (h->solve_quad) { g_create_error = "PG_SOLVER=quad does not carry the wall rows"; free_all(h); delete h; return PG_ERR_INVALID; } }
     ALLOC(h->d_pol_u2, cap * 2, real); ALLOC(h->d_pol_u, cap * 3, real); ALLOC(h->d_pol_src, cap, int);
 #undef ALLOC
@@ -189,7 +191,9 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     h->ev_ok = true;
     // horizons up to 32 intervals keep their dynamics blocks resident in LDS (one pass over the QP data); longer ones stream them through a 4-slot ring
     h->solve_ring = N > 32;
+#ifdef PG_EXPERIMENTAL_SOLVE4
     h->solve4_lds = lds4_bytes(N);
+#endif
     h->solve_lds = (size_t)((h->solve_ring ? 4 : N) * SB + 10 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 72 + 100 + 8 + 64 + 2) * sizeof(real);
     if (h->solve_lds > 160 * 1024) { g_create_error = "horizon too long for LDS staging"; free_all(h); delete h; return PG_ERR_INVALID; }
     if (h->solve_lds > 48 * 1024)
@@ -439,8 +443,10 @@ int pg_update_qp(pg_handle* h) {
 int pg_solve(pg_handle* h) {
     int rc = check_ready(h); if (rc) return rc;
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved};
-    if (h->solve_quad) hipLaunchKernelGGL((k_solve4<2, false>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, h->d_ws4, O, (unsigned long long*)nullptr);
-    else if (h->solve_ring) hipLaunchKernelGGL((k_solve<false, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, (unsigned long long*)nullptr);
+#ifdef PG_EXPERIMENTAL_SOLVE4
+    if (h->solve_quad) { hipLaunchKernelGGL((k_solve4<2, false>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, h->d_ws4, O, (unsigned long long*)nullptr); LAUNCH_CHECK(h); return PG_OK; }
+#endif
+    if (h->solve_ring) hipLaunchKernelGGL((k_solve<false, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, (unsigned long long*)nullptr);
     else hipLaunchKernelGGL((k_solve<false, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, (unsigned long long*)nullptr);
     LAUNCH_CHECK(h);
     return PG_OK;
@@ -453,8 +459,11 @@ int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     HIPCHK(h, hipMalloc((void**)&d, ((size_t)h->B * 6 + 1024) * 8));
     HIPCHK(h, hipMemset(d, 0, ((size_t)h->B * 6 + 1024) * 8));
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved};
+#ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) hipLaunchKernelGGL((k_solve4<2, true>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, h->d_ws4, O, d);
-    else if (h->solve_ring) hipLaunchKernelGGL((k_solve<true, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, d);
+    else
+#endif
+    if (h->solve_ring) hipLaunchKernelGGL((k_solve<true, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, d);
     else hipLaunchKernelGGL((k_solve<true, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, d);
     LAUNCH_CHECK(h);
     HIPCHK(h, hipMemcpy(out, d, ((size_t)h->B * 6 + 1024) * 8, hipMemcpyDeviceToHost));      // out: [B][6] cycles + 1024-double trace of PG_DEBUG_INSTANCE

@@ -9,11 +9,11 @@
 
 namespace pg {
 
-// PG_KEEP_BEGIN
-// Precision of the path arithmetic.  These sources are written in fp64.  The fp32 library (libpigeon_hip_f32.so, BASELINE configs 3/4) is
-// compiled from a GENERATED copy (tools/gen_f32_sources.py) in which every `double` reads `real` (= float) and every floating literal is
-// wrapped in real(...); blocks between PG_KEEP markers are copied verbatim.  `tdouble` marks the few quantities that stay fp64 in both
-// builds: absolute time (the time grid's ceil() lattice must not depend on the arithmetic type of the QP).
+// Precision of the path arithmetic.  Every kernel is written against the scalar type `real`: one translation unit per instantiation, real = double
+// for libpigeon_hip.so (the reference's type) and real = float (-DPG_F32) for libpigeon_hip_f32.so (BASELINE configs 3/4).  Floating literals are
+// spelled real(...) so that no expression is silently promoted to double in the fp32 build; tools/check_f32_purity.py disassembles the fp32 code
+// object and fails the build when an fp64 arithmetic instruction shows up outside the kernels that own absolute time.  `tdouble` marks the few
+// quantities that stay fp64 in both builds: absolute time (the time grid's ceil() lattice must not depend on the arithmetic type of the QP).
 #ifdef PG_F32
 typedef float real; typedef float2 real2;
 #define PG_BIG 1e30f
@@ -38,77 +38,76 @@ PG_DEV double frcp(double x) {
 }
 PG_DEV void pg_sincos(double x, double* s, double* c) { sincos(x, s, c); }
 #endif
-// PG_KEEP_END
 
 // ---- two-tangent forward-mode number (stands in for ForwardDiff.Dual inside `linearize` and HJI_computation.jl:167) ----
 struct D2 {
-    double v, a, b;
+    real v, a, b;
     PG_DEV D2() {}
-    PG_DEV D2(double x) : v(x), a(0.0), b(0.0) {}
-    PG_DEV D2(double x, double da, double db) : v(x), a(da), b(db) {}
+    PG_DEV D2(real x) : v(x), a(real(0.0)), b(real(0.0)) {}
+    PG_DEV D2(real x, real da, real db) : v(x), a(da), b(db) {}
 };
 PG_DEV D2 operator+(D2 x, D2 y) { return D2(x.v + y.v, x.a + y.a, x.b + y.b); }
 PG_DEV D2 operator-(D2 x, D2 y) { return D2(x.v - y.v, x.a - y.a, x.b - y.b); }
 PG_DEV D2 operator-(D2 x) { return D2(-x.v, -x.a, -x.b); }
 PG_DEV D2 operator*(D2 x, D2 y) { return D2(x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b); }
-PG_DEV D2 operator/(D2 x, D2 y) { double inv = frcp(y.v), q = x.v * inv; return D2(q, (x.a - q * y.a) * inv, (x.b - q * y.b) * inv); }
-PG_DEV D2 operator+(D2 x, double y) { return D2(x.v + y, x.a, x.b); }
-PG_DEV D2 operator+(double y, D2 x) { return D2(x.v + y, x.a, x.b); }
-PG_DEV D2 operator-(D2 x, double y) { return D2(x.v - y, x.a, x.b); }
-PG_DEV D2 operator-(double y, D2 x) { return D2(y - x.v, -x.a, -x.b); }
-PG_DEV D2 operator*(D2 x, double y) { return D2(x.v * y, x.a * y, x.b * y); }
-PG_DEV D2 operator*(double y, D2 x) { return D2(x.v * y, x.a * y, x.b * y); }
-PG_DEV D2 operator/(D2 x, double y) { double inv = frcp(y); return D2(x.v * inv, x.a * inv, x.b * inv); }
-PG_DEV D2 operator/(double x, D2 y) { double inv = frcp(y.v), q = x * inv; return D2(q, -q * y.a * inv, -q * y.b * inv); }
+PG_DEV D2 operator/(D2 x, D2 y) { real inv = frcp(y.v), q = x.v * inv; return D2(q, (x.a - q * y.a) * inv, (x.b - q * y.b) * inv); }
+PG_DEV D2 operator+(D2 x, real y) { return D2(x.v + y, x.a, x.b); }
+PG_DEV D2 operator+(real y, D2 x) { return D2(x.v + y, x.a, x.b); }
+PG_DEV D2 operator-(D2 x, real y) { return D2(x.v - y, x.a, x.b); }
+PG_DEV D2 operator-(real y, D2 x) { return D2(y - x.v, -x.a, -x.b); }
+PG_DEV D2 operator*(D2 x, real y) { return D2(x.v * y, x.a * y, x.b * y); }
+PG_DEV D2 operator*(real y, D2 x) { return D2(x.v * y, x.a * y, x.b * y); }
+PG_DEV D2 operator/(D2 x, real y) { real inv = frcp(y); return D2(x.v * inv, x.a * inv, x.b * inv); }
+PG_DEV D2 operator/(real x, D2 y) { real inv = frcp(y.v), q = x * inv; return D2(q, -q * y.a * inv, -q * y.b * inv); }
 
-PG_DEV double val(double x) { return x; }
-PG_DEV double val(D2 x) { return x.v; }
-PG_DEV D2 chain(D2 x, double f, double df) { return D2(f, df * x.a, df * x.b); }
+PG_DEV real val(real x) { return x; }
+PG_DEV real val(D2 x) { return x.v; }
+PG_DEV D2 chain(D2 x, real f, real df) { return D2(f, df * x.a, df * x.b); }
 
-PG_DEV void sincos_(double x, double& s, double& c) { pg_sincos(x, &s, &c); }
-PG_DEV void sincos_(D2 x, D2& s, D2& c) { double sv, cv; pg_sincos(x.v, &sv, &cv); s = chain(x, sv, cv); c = chain(x, cv, -sv); }
-PG_DEV double tan_(double x) { return tan(x); }
-PG_DEV D2 tan_(D2 x) { double t = tan(x.v); return chain(x, t, 1.0 + t * t); }
-PG_DEV double sqrt_(double x) { return sqrt(x); }
-PG_DEV D2 sqrt_(D2 x) { double s = sqrt(x.v); return chain(x, s, 0.5 * frcp(s)); }
-PG_DEV double atan2_(double y, double x) { return atan2(y, x); }
-PG_DEV D2 atan2_(D2 y, D2 x) { double inv = 1.0 / (x.v * x.v + y.v * y.v); return D2(atan2(y.v, x.v), (x.v * y.a - y.v * x.a) * inv, (x.v * y.b - y.v * x.b) * inv); }
-PG_DEV double abs_(double x) { return fabs(x); }
-PG_DEV D2 abs_(D2 x) { return x.v < 0.0 ? -x : x; }
-PG_DEV double sgn(double x) { return (double)((x > 0.0) - (x < 0.0)); }
-template <class T> PG_DEV T cst(double x);
-template <> PG_DEV double cst<double>(double x) { return x; }
-template <> PG_DEV D2 cst<D2>(double x) { return D2(x); }
+PG_DEV void sincos_(real x, real& s, real& c) { pg_sincos(x, &s, &c); }
+PG_DEV void sincos_(D2 x, D2& s, D2& c) { real sv, cv; pg_sincos(x.v, &sv, &cv); s = chain(x, sv, cv); c = chain(x, cv, -sv); }
+PG_DEV real tan_(real x) { return tan(x); }
+PG_DEV D2 tan_(D2 x) { real t = tan(x.v); return chain(x, t, real(1.0) + t * t); }
+PG_DEV real sqrt_(real x) { return sqrt(x); }
+PG_DEV D2 sqrt_(D2 x) { real s = sqrt(x.v); return chain(x, s, real(0.5) * frcp(s)); }
+PG_DEV real atan2_(real y, real x) { return atan2(y, x); }
+PG_DEV D2 atan2_(D2 y, D2 x) { real inv = real(1.0) / (x.v * x.v + y.v * y.v); return D2(atan2(y.v, x.v), (x.v * y.a - y.v * x.a) * inv, (x.v * y.b - y.v * x.b) * inv); }
+PG_DEV real abs_(real x) { return fabs(x); }
+PG_DEV D2 abs_(D2 x) { return x.v < real(0.0) ? -x : x; }
+PG_DEV real sgn(real x) { return (real)((x > real(0.0)) - (x < real(0.0))); }
+template <class T> PG_DEV T cst(real x);
+template <> PG_DEV real cst<real>(real x) { return x; }
+template <> PG_DEV D2 cst<D2>(real x) { return D2(x); }
 
 // Julia min/max propagate NaN
-PG_DEV double jmin(double a, double b) { return (a != a || b != b) ? NAN : (b < a ? b : a); }
-PG_DEV double jmax(double a, double b) { return (a != a || b != b) ? NAN : (b > a ? b : a); }
-PG_DEV double clampd(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
+PG_DEV real jmin(real a, real b) { return (a != a || b != b) ? NAN : (b < a ? b : a); }
+PG_DEV real jmax(real a, real b) { return (a != a || b != b) ? NAN : (b > a ? b : a); }
+PG_DEV real clampd(real x, real lo, real hi) { return x > hi ? hi : (x < lo ? lo : x); }
 
 // ---- tire model: vehicle_dynamics.jl:35-48 ----
 // takes tan(alpha) directly: the slip angles of the reference are atan(...) - delta, and only their tangent is ever used
 // (vehicle_dynamics.jl:37), so tan(atan(y/x) - delta) = (y/x - tan delta)/(1 + (y/x) tan delta) replaces an atan2 + tan pair
 // (identical in exact arithmetic for Ux > 0, the only regime the MPC runs in: V_min = 1, ros_integration.jl:84-87)
 template <class T>
-PG_DEV T fiala(T tana, double Ca, double mu, T Fx, T Fz) {
+PG_DEV T fiala(T tana, real Ca, real mu, T Fx, T Fz) {
     T Fmax = mu * Fz;
-    if (abs_(val(Fx)) >= val(Fmax)) return cst<T>(0.0);
+    if (abs_(val(Fx)) >= val(Fmax)) return cst<T>(real(0.0));
     T Fy_max = sqrt_(Fmax * Fmax - Fx * Fx);
-    T slide = (3.0 / Ca) * Fy_max;
+    T slide = (real(3.0) / Ca) * Fy_max;
     T ratio = abs_(tana / slide);
-    if (val(ratio) <= 1.0) return -(Ca * tana) * (1.0 - ratio + ratio * ratio * (1.0 / 3.0));
+    if (val(ratio) <= real(1.0)) return -(Ca * tana) * (real(1.0) - ratio + ratio * ratio * (real(1.0) / real(3.0)));
     return -Fy_max * sgn(val(tana));
 }
 // vehicle_dynamics.jl:56-62 (returns tan(alpha))
-PG_DEV double inv_fiala_tan(double Fy, double Ca, double Fy_max) {
-    if (fabs(Fy) >= Fy_max) return -(3.0 * Fy_max / Ca) * sgn(Fy);
-    return -(1.0 + cbrt(fabs(Fy) / Fy_max - 1.0)) * sgn(Fy);
+PG_DEV real inv_fiala_tan(real Fy, real Ca, real Fy_max) {
+    if (fabs(Fy) >= Fy_max) return -(real(3.0) * Fy_max / Ca) * sgn(Fy);
+    return -(real(1.0) + cbrt(fabs(Fy) / Fy_max - real(1.0))) * sgn(Fy);
 }
 // vehicle_dynamics.jl:64-76: 3-iteration front-axle load-transfer fixed point, then rear
 template <class T>
 PG_DEV void lateral_forces(const DevVehicle& P, T af, T ar, T Fxf, T Fxr, T sd, T cd, T& Fyf, T& Fyr) {   // af, ar: TANGENTS of the slip angles
-    const double W_b = P.m * P.G * P.b, W_a = P.m * P.G * P.a, invL = 1.0 / P.L;
-    Fyf = cst<T>(0.0);
+    const real W_b = P.m * P.G * P.b, W_a = P.m * P.G * P.a, invL = real(1.0) / P.L;
+    Fyf = cst<T>(real(0.0));
     T Fx = Fxf * cd + Fxr;
 #pragma unroll 1
     for (int i = 0; i < 3; i++) {
@@ -122,14 +121,14 @@ PG_DEV void lateral_forces(const DevVehicle& P, T af, T ar, T Fxf, T Fxr, T sd, 
 
 // apply_control_limits (vehicle_dynamics.jl:293-298; Ux by value) followed by longitudinal_tire_forces (:279-283)
 template <class T>
-PG_DEV void actuate(const DevVehicle& P, T delta, T Fx, double Ux, T& d_out, T& Fxf, T& Fxr) {
-    double dv = val(delta);
+PG_DEV void actuate(const DevVehicle& P, T delta, T Fx, real Ux, T& d_out, T& Fxf, T& Fxr) {
+    real dv = val(delta);
     d_out = dv > P.delta_max ? cst<T>(P.delta_max) : (dv < -P.delta_max ? cst<T>(-P.delta_max) : delta);
-    double cap = jmin(P.Fx_max, P.Px_max / Ux);
+    real cap = jmin(P.Fx_max, P.Px_max / Ux);
     T f = Fx;
     if (cap < val(f)) f = cst<T>(cap);
     if (P.Fx_min > val(f)) f = cst<T>(P.Fx_min);
-    if (val(f) > 0.0) { Fxf = f * P.fwd_frac; Fxr = f * P.rwd_frac; }
+    if (val(f) > real(0.0)) { Fxf = f * P.fwd_frac; Fxr = f * P.rwd_frac; }
     else              { Fxf = f * P.fwb_frac; Fxr = f * P.rwb_frac; }
 }
 
@@ -138,14 +137,14 @@ template <class T>
 PG_DEV void body_accel(const DevVehicle& P, T Ux, T Uy, T r, T delta, T Fxf, T Fxr, T& dUx, T& dUy, T& dr) {
     T sd, cd; sincos_(delta, sd, cd);
     T tf = (Uy + P.a * r) / Ux, td = sd / cd;
-    T taf = (tf - td) / (1.0 + tf * td);          // tan(atan2(Uy + a r, Ux) - delta)   (:118)
+    T taf = (tf - td) / (real(1.0) + tf * td);          // tan(atan2(Uy + a r, Ux) - delta)   (:118)
     T tar = (Uy - P.b * r) / Ux;                   // tan(atan2(Uy - b r, Ux))           (:119)
     T Fyf, Fyr;
     lateral_forces<T>(P, taf, tar, Fxf, Fxr, sd, cd, Fyf, Fyr);
     T Fx_drag = -P.Cd0 - Ux * (P.Cd1 + P.Cd2 * Ux);
     T Fxf_t = Fxf * cd - Fyf * sd;
     T Fyf_t = Fyf * cd + Fxf * sd;
-    const double invm = 1.0 / P.m, invI = 1.0 / P.Izz;
+    const real invm = real(1.0) / P.m, invI = real(1.0) / P.Izz;
     dUx = (Fxf_t + Fxr + Fx_drag) * invm + r * Uy;
     dUy = (Fyf_t + Fyr) * invm - r * Ux;
     dr = (P.a * Fyf_t - P.b * Fyr) * invI;
@@ -153,7 +152,7 @@ PG_DEV void body_accel(const DevVehicle& P, T Ux, T Uy, T r, T delta, T Fxf, T F
 
 // VehicleModel{TrackingBicycleModel}: vehicle_dynamics.jl:310-315 over :159-183.  q=(ds,Ux,Uy,r,dpsi,e), u=(delta,Fx), p=(V,kappa)
 template <class T>
-PG_DEV void tracking_rhs(const DevVehicle& P, const T q[6], T u0, T u1, double pV, double pK, T out[6]) {
+PG_DEV void tracking_rhs(const DevVehicle& P, const T q[6], T u0, T u1, real pV, real pK, T out[6]) {
     T d, Fxf, Fxr;
     actuate<T>(P, u0, u1, val(q[1]), d, Fxf, Fxr);
     T s, c; sincos_(q[4], s, c);
@@ -165,7 +164,7 @@ PG_DEV void tracking_rhs(const DevVehicle& P, const T q[6], T u0, T u1, double p
 }
 // VehicleModel{BicycleModel}: vehicle_dynamics.jl:310-314 over :111-135; only the components the hot path reads (dUx,dUy,dr)
 template <class T>
-PG_DEV void world_body_rhs(const DevVehicle& P, double Ux, double Uy, double r, T u0, T u1, T& dUx, T& dUy, T& dr) {
+PG_DEV void world_body_rhs(const DevVehicle& P, real Ux, real Uy, real r, T u0, T u1, T& dUx, T& dUy, T& dr) {
     T d, Fxf, Fxr;
     actuate<T>(P, u0, u1, Ux, d, Fxf, Fxr);
     body_accel<T>(P, cst<T>(Ux), cst<T>(Uy), cst<T>(r), d, Fxf, Fxr, dUx, dUy, dr);
@@ -186,77 +185,77 @@ PG_DEV void lateral_rhs(const DevVehicle& P, const T q[4], T u0, T u1, T pUx, T 
 }
 
 // stable_limits: vehicle_dynamics.jl:227-263
-struct Envelope { double dmin, dmax, H[4][2], G[4]; };
-PG_DEV Envelope stable_limits(const DevVehicle& B, double Ux, double Fxf, double Fxr) {
-    double Fx = Fxf + Fxr;
-    double Fzf = (B.m * B.G * B.b - B.h * Fx) / B.L, Fzr = (B.m * B.G * B.a + B.h * Fx) / B.L;
-    double Ffm = B.mu * Fzf, Frm = B.mu * Fzr;
-    double Fyf_max = fabs(Fxf) > Ffm ? 0.0 : sqrt(Ffm * Ffm - Fxf * Fxf);
-    double Fyr_max = fabs(Fxr) > Frm ? 0.0 : sqrt(Frm * Frm - Fxr * Fxr);
-    double tf = 3.0 * Fyf_max / B.Caf, tr = 3.0 * Fyr_max / B.Car;
-    double af = atan(tf), ar = atan(tr);
+struct Envelope { real dmin, dmax, H[4][2], G[4]; };
+PG_DEV Envelope stable_limits(const DevVehicle& B, real Ux, real Fxf, real Fxr) {
+    real Fx = Fxf + Fxr;
+    real Fzf = (B.m * B.G * B.b - B.h * Fx) / B.L, Fzr = (B.m * B.G * B.a + B.h * Fx) / B.L;
+    real Ffm = B.mu * Fzf, Frm = B.mu * Fzr;
+    real Fyf_max = fabs(Fxf) > Ffm ? real(0.0) : sqrt(Ffm * Ffm - Fxf * Fxf);
+    real Fyr_max = fabs(Fxr) > Frm ? real(0.0) : sqrt(Frm * Frm - Fxr * Fxr);
+    real tf = real(3.0) * Fyf_max / B.Caf, tr = real(3.0) * Fyr_max / B.Car;
+    real af = atan(tf), ar = atan(tr);
     Envelope o;
-    double muG = B.mu * B.G, Ux2 = Ux * Ux;
+    real muG = B.mu * B.G, Ux2 = Ux * Ux;
     o.dmax = atan(B.L * muG / Ux2 - tr) + af;
     o.dmin = atan(-B.L * muG / Ux2 + tr) - af;
-    double rC = muG / Ux, UyC = -Ux * tr + B.b * rC;
-    double rD = Ux / B.L * (tan(af + o.dmax) - tr), UyD = Ux * tr + B.b * rD;
-    double mCD = (rD - rC) / (UyD - UyC);
-    double rE = Ux / B.L * (tan(-af + o.dmin) + tr), UyE = -Ux * tr + B.b * rE;
-    double rF = -muG / Ux, UyF = Ux * tr + B.b * rF;
-    double mEF = (rF - rE) / (UyF - UyE);
-    o.H[0][0] = 1.0 / Ux;  o.H[0][1] = -B.b / Ux;
-    o.H[1][0] = -1.0 / Ux; o.H[1][1] = B.b / Ux;
-    o.H[2][0] = -mCD;      o.H[2][1] = 1.0;
-    o.H[3][0] = mEF;       o.H[3][1] = -1.0;
+    real rC = muG / Ux, UyC = -Ux * tr + B.b * rC;
+    real rD = Ux / B.L * (tan(af + o.dmax) - tr), UyD = Ux * tr + B.b * rD;
+    real mCD = (rD - rC) / (UyD - UyC);
+    real rE = Ux / B.L * (tan(-af + o.dmin) + tr), UyE = -Ux * tr + B.b * rE;
+    real rF = -muG / Ux, UyF = Ux * tr + B.b * rF;
+    real mEF = (rF - rE) / (UyF - UyE);
+    o.H[0][0] = real(1.0) / Ux;  o.H[0][1] = -B.b / Ux;
+    o.H[1][0] = -real(1.0) / Ux; o.H[1][1] = B.b / Ux;
+    o.H[2][0] = -mCD;      o.H[2][1] = real(1.0);
+    o.H[3][0] = mEF;       o.H[3][1] = -real(1.0);
     o.G[0] = ar; o.G[1] = ar; o.G[2] = rC - UyC * mCD; o.G[3] = -rF + UyF * mEF;
     return o;
 }
 
 // steady_state_estimates: vehicle_dynamics.jl:319-390
-struct Steady { double beta, Ux, Uy, r, A, delta, Fx; };
-PG_DEV Steady steady_state(const DevVehicle& P, double V, double A_tan, double kappa, int num_iters, double r, double beta, double delta, double Fyf) {
-    double A_rad = V * V * kappa;
-    double A_max = P.mu * P.G;
+struct Steady { real beta, Ux, Uy, r, A, delta, Fx; };
+PG_DEV Steady steady_state(const DevVehicle& P, real V, real A_tan, real kappa, int num_iters, real r, real beta, real delta, real Fyf) {
+    real A_rad = V * V * kappa;
+    real A_max = P.mu * P.G;
     if (hypot(A_tan, A_rad) > A_max) {
-        if (fabs(A_rad) > A_max) { A_rad = A_max * sgn(A_rad); A_tan = 0.0; }
+        if (fabs(A_rad) > A_max) { A_rad = A_max * sgn(A_rad); A_tan = real(0.0); }
         else A_tan = sqrt(A_max * A_max - A_rad * A_rad) * sgn(A_tan);
     }
-    double rdot = A_tan * kappa;
-    double Fxr = 0.0, Fxf = 0.0, A_out = A_tan;
+    real rdot = A_tan * kappa;
+    real Fxr = real(0.0), Fxf = real(0.0), A_out = A_tan;
 #pragma unroll 1
     for (int i = 1;; i++) {
-        double sb, cb, sd, cd; pg_sincos(beta, &sb, &cb); pg_sincos(delta, &sd, &cd);
-        double Ux = V * cb, Uy = V * sb;
-        double Fx_drag = -P.Cd0 - Ux * (P.Cd1 + P.Cd2 * Ux);
-        double Ax = A_tan * cb - A_rad * sb, Ay = A_tan * sb + A_rad * cb;
-        double Fx = Ax * P.m - Fx_drag;
+        real sb, cb, sd, cd; pg_sincos(beta, &sb, &cb); pg_sincos(delta, &sd, &cd);
+        real Ux = V * cb, Uy = V * sb;
+        real Fx_drag = -P.Cd0 - Ux * (P.Cd1 + P.Cd2 * Ux);
+        real Ax = A_tan * cb - A_rad * sb, Ay = A_tan * sb + A_rad * cb;
+        real Fx = Ax * P.m - Fx_drag;
         Fx = jmin(Fx, jmin(P.Fx_max, P.Px_max / Ux) * (P.rwd_frac + P.fwd_frac * cd) - Fyf * sd);
-        double Fzr = (P.m * P.G * P.a + P.h * Fx) / P.L, Fzf = (P.m * P.G * P.b - P.h * Fx) / P.L;
-        double Frm = P.mu * Fzr, Ffm = P.mu * Fzf;
-        double frac = Fx > 0.0 ? P.rwd_frac / (P.rwd_frac + P.fwd_frac * cd) : P.rwb_frac / (P.rwb_frac + P.fwb_frac * cd);
+        real Fzr = (P.m * P.G * P.a + P.h * Fx) / P.L, Fzf = (P.m * P.G * P.b - P.h * Fx) / P.L;
+        real Frm = P.mu * Fzr, Ffm = P.mu * Fzf;
+        real frac = Fx > real(0.0) ? P.rwd_frac / (P.rwd_frac + P.fwd_frac * cd) : P.rwb_frac / (P.rwb_frac + P.fwb_frac * cd);
         Fxr = clampd((Fx + Fyf * sd) * frac, -Frm, Frm);
-        double Fyr_max = sqrt(Frm * Frm - Fxr * Fxr);
-        double Fyr = clampd((Ay * P.m - rdot * P.Izz / P.a) / (1.0 + P.b / P.a), -Fyr_max, Fyr_max);
-        double tanar = inv_fiala_tan(Fyr, P.Car, Fyr_max);
-        double Fxf_t = clampd(Fx - Fxr, -Ffm, Ffm);
-        double Fyf_tmax = sqrt(Ffm * Ffm - Fxf_t * Fxf_t);
-        double Fyf_t = clampd((P.b * Fyr + rdot * P.Izz) / P.a, -Fyf_tmax, Fyf_tmax);
+        real Fyr_max = sqrt(Frm * Frm - Fxr * Fxr);
+        real Fyr = clampd((Ay * P.m - rdot * P.Izz / P.a) / (real(1.0) + P.b / P.a), -Fyr_max, Fyr_max);
+        real tanar = inv_fiala_tan(Fyr, P.Car, Fyr_max);
+        real Fxf_t = clampd(Fx - Fxr, -Ffm, Ffm);
+        real Fyf_tmax = sqrt(Ffm * Ffm - Fxf_t * Fxf_t);
+        real Fyf_t = clampd((P.b * Fyr + rdot * P.Izz) / P.a, -Fyf_tmax, Fyf_tmax);
         Fxf = Fxf_t * cd + Fyf_t * sd;
         Fyf = Fyf_t * cd - Fxf_t * sd;
-        double Fyf_max = sqrt(Ffm * Ffm - Fxf * Fxf);
-        double af = atan(inv_fiala_tan(Fyf, P.Caf, Fyf_max));
+        real Fyf_max = sqrt(Ffm * Ffm - Fxf * Fxf);
+        real af = atan(inv_fiala_tan(Fyf, P.Caf, Fyf_max));
         delta = atan2(Uy + P.a * r, Ux) - af;
         if (i == num_iters) {
-            double Ax2 = (Fxf * cd - Fyf * sd + Fxr + Fx_drag) / P.m;
-            double Ay2 = (Fyf * cd + Fxf * sd + Fyr) / P.m;
+            real Ax2 = (Fxf * cd - Fyf * sd + Fxr + Fx_drag) / P.m;
+            real Ay2 = (Fyf * cd + Fxf * sd + Fyr) / P.m;
             A_out = Ax2 * cb + Ay2 * sb;
             break;
         }
         beta = atan(tanar + P.b * r / Ux);
     }
     Steady o;
-    double sb, cb; pg_sincos(beta, &sb, &cb);
+    real sb, cb; pg_sincos(beta, &sb, &cb);
     o.beta = beta; o.Ux = V * cb; o.Uy = V * sb; o.r = r; o.A = A_out; o.delta = delta; o.Fx = Fxf + Fxr;
     return o;
 }
@@ -264,55 +263,55 @@ PG_DEV Steady steady_state(const DevVehicle& P, double V, double A_tan, double k
 // ---- trajectory (trajectories.jl) ----
 struct TrajView {
     int L;
-    const double *t, *s, *V, *A, *E, *N, *psi, *kappa, *edge_L, *edge_R;   // theta, phi are carried by the tube but read by nothing on this path
+    const real *t, *s, *V, *A, *E, *N, *psi, *kappa, *edge_L, *edge_R;   // theta, phi are carried by the tube but read by nothing on this path
 };
 // count of elements < x  (Julia searchsortedfirst - 1)
-template <class V> PG_DEV int count_less(const V* v, int n, double x) {
+template <class V> PG_DEV int count_less(const V* v, int n, real x) {
     int lo = 0, hi = n;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (v[mid] < x) lo = mid + 1; else hi = mid; }
     return lo;
 }
 // count of elements <= x (Julia searchsortedlast)
-template <class V> PG_DEV int count_leq(const V* v, int n, double x) {
+template <class V> PG_DEV int count_leq(const V* v, int n, real x) {
     int lo = 0, hi = n;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (v[mid] <= x) lo = mid + 1; else hi = mid; }
     return lo;
 }
 PG_DEV int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 // traj(t).s : trajectories.jl:47-54 (only the arclength is read by the hot path, coupled_lat_long.jl:77,96,114)
-PG_DEV double traj_s_at_time(const TrajView& T, double tq) {
+PG_DEV real traj_s_at_time(const TrajView& T, real tq) {
     int i = clampi(count_less(T.t, T.L, tq), 1, T.L - 1) - 1;
-    double Ai = (T.V[i + 1] - T.V[i]) / (T.t[i + 1] - T.t[i]);
-    double dt = tq - T.t[i];
-    return T.s[i] + T.V[i] * dt + Ai * dt * dt * 0.5;
+    real Ai = (T.V[i + 1] - T.V[i]) / (T.t[i + 1] - T.t[i]);
+    real dt = tq - T.t[i];
+    return T.s[i] + T.V[i] * dt + Ai * dt * dt * real(0.5);
 }
 // traj[s] : trajectories.jl:55-68 -> (V, A, psi, kappa)
-struct TrajS { double V, A, psi, kappa; };
-PG_DEV TrajS traj_at_s(const TrajView& T, double sq) {
+struct TrajS { real V, A, psi, kappa; };
+PG_DEV TrajS traj_at_s(const TrajView& T, real sq) {
     int i = clampi(count_less(T.s, T.L, sq), 1, T.L - 1) - 1;
-    double Ai = (T.V[i + 1] - T.V[i]) / (T.t[i + 1] - T.t[i]);
-    double ds = sq - T.s[i], dt;
-    if (fabs(Ai) < 1e-3 || sq > T.s[T.L - 1]) dt = ds / T.V[i];
-    else dt = 2.0 * ds / (sqrt(2.0 * Ai * ds + T.V[i] * T.V[i]) + T.V[i]);       // (sqrt(2 A ds + V^2) - V) / A of :63, rationalised (no cancellation)
+    real Ai = (T.V[i + 1] - T.V[i]) / (T.t[i + 1] - T.t[i]);
+    real ds = sq - T.s[i], dt;
+    if (fabs(Ai) < real(1e-3) || sq > T.s[T.L - 1]) dt = ds / T.V[i];
+    else dt = real(2.0) * ds / (sqrt(real(2.0) * Ai * ds + T.V[i] * T.V[i]) + T.V[i]);       // (sqrt(2 A ds + V^2) - V) / A of :63, rationalised (no cancellation)
     TrajS o; o.V = T.V[i] + Ai * dt; o.A = Ai;
     int j = clampi(count_leq(T.s, T.L, sq), 1, T.L - 1) - 1;          // interp_by_s: Gridded(Linear()) + Line() (trajectories.jl:32-35)
-    double w = (sq - T.s[j]) / (T.s[j + 1] - T.s[j]);
+    real w = (sq - T.s[j]) / (T.s[j + 1] - T.s[j]);
     o.psi = T.psi[j] + w * (T.psi[j + 1] - T.psi[j]);
     o.kappa = T.kappa[j] + w * (T.kappa[j + 1] - T.kappa[j]);
     return o;
 }
 // edge_L, edge_R channels of interp_by_s at arclength sq (trajectories.jl:32-35): read only by the build-defined wall rows
-PG_DEV void traj_edges_at_s(const TrajView& T, double sq, double& eL, double& eR) {
+PG_DEV void traj_edges_at_s(const TrajView& T, real sq, real& eL, real& eR) {
     int j = clampi(count_leq(T.s, T.L, sq), 1, T.L - 1) - 1;
-    double w = (sq - T.s[j]) / (T.s[j + 1] - T.s[j]);
+    real w = (sq - T.s[j]) / (T.s[j + 1] - T.s[j]);
     eL = T.edge_L[j] + w * (T.edge_L[j + 1] - T.edge_L[j]); eR = T.edge_R[j] + w * (T.edge_R[j + 1] - T.edge_R[j]);
 }
 // adiff: DifferentialDynamicsModels (absent); semantics restated at PigeonViz.jl:24-28
-PG_DEV double adiff(double x, double y) {
-    const double twopi = 6.283185307179586476925286766559;
-    double d = fmod(x - y, twopi);
-    if (d < 0.0) d += twopi;
-    return d <= 3.14159265358979323846 ? d : d - twopi;
+PG_DEV real adiff(real x, real y) {
+    const real twopi = real(6.283185307179586476925286766559);
+    real d = fmod(x - y, twopi);
+    if (d < real(0.0)) d += twopi;
+    return d <= real(3.14159265358979323846) ? d : d - twopi;
 }
 
 }  // namespace pg

@@ -22,23 +22,23 @@ struct DevCfg {
     int use_correction_step, nsub;
     int formulation;              // PG_COUPLED / PG_DECOUPLED
     int dbg_instance;             // diagnostic kernel build only: instance whose interior-point trace is printed (-1 = none; env PG_DEBUG_INSTANCE)
-    double ux_dummy;              // decoupled: value of the inert Ux slot of the embedded 8-state problem (strictly inside [V_min, V_max])
+    real ux_dummy;              // decoupled: value of the inert Ux slot of the embedded 8-state problem (strictly inside [V_min, V_max])
     int alias_prev_ts;            // the reference's MPCTimeSteps passes `ts` as prev_ts too (model_predictive_control.jl:15): same array
     int has_hji;
-    double hji_eps;
-    double un0, un1;              // u_normalization (coupled_lat_long.jl:199)
-    double fxmin_n;               // Fx_min / un1
+    real hji_eps;
+    real un0, un1;              // u_normalization (coupled_lat_long.jl:199)
+    real fxmin_n;               // Fx_min / un1
     int qp_len;
     int ipm_max_iter;
-    double ipm_tol, ipm_mu0;
+    real ipm_tol, ipm_mu0;
     TrajView traj;                // trajectory 0 of the installed library
     int n_traj;                   // library size (1: every instance tracks `traj`)
     long traj_stride;             // doubles between consecutive trajectories of the library ([n_traj][10][Lmax])
     const int* traj_idx;          // [B] per-instance selection (nullptr when n_traj == 1)
     const int* traj_len;          // [n_traj] valid nodes of each trajectory
     int walls;                    // build-defined extension: soft rows edge_R - sw <= e <= edge_L + sw, sw >= 0 at nodes 2..N+1 (decoupled formulation only)
-    double wall_weight;           // linear penalty on sw (per second, like W_beta)
-    double* wall_edges;           // [B][N][2] (edge_L, edge_R) at node k+1, written by k_nodes_dec, read by k_solve
+    real wall_weight;           // linear penalty on sw (per second, like W_beta)
+    real* wall_edges;           // [B][N][2] (edge_L, edge_R) at node k+1, written by k_nodes_dec, read by k_solve
 };
 // the reference trajectory instance b tracks (mpc.trajectory of that controller)
 PG_DEV TrajView traj_of(const DevCfg& C, int b) {
@@ -66,7 +66,7 @@ __host__ __device__ inline QpOff qp_offsets(int N) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// PG_KEEP_BEGIN  (absolute time stays fp64 in both builds)
+// absolute time stays fp64 in both builds (tdouble)
 __global__ __launch_bounds__(64) void k_time_steps(DevCfg C, int B, const double* __restrict__ t0, double* __restrict__ ts, double* __restrict__ dt, double* __restrict__ prev_ts) {
 #pragma clang fp contract(off)   // the time grid is compared bit-for-bit with the CPU restatement: no fused multiply-add here
     int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -81,63 +81,62 @@ __global__ __launch_bounds__(64) void k_time_steps(DevCfg C, int B, const double
     for (int i = 0; i < C.N; i++) D[i] = T[i + 1] - T[i];                          // :27-29
     if (C.alias_prev_ts) for (int i = 0; i < C.NN; i++) PT[i] = T[i];              // prev_ts IS ts in the reference (:15)
 }
-// PG_KEEP_END
 
 // ------------------------------------------------------------------------------------------------------------------
 // math.jl:4-9
-PG_DEV double seg_dist2(double ax, double ay, double bx, double by, double x, double y) {
-    double vx = bx - ax, vy = by - ay;
-    double lam = (vx * (x - ax) + vy * (y - ay)) / (vx * vx + vy * vy);
-    lam = lam < 0.0 ? 0.0 : (lam > 1.0 ? 1.0 : lam);
-    double px = (1.0 - lam) * ax + lam * bx, py = (1.0 - lam) * ay + lam * by;
+PG_DEV real seg_dist2(real ax, real ay, real bx, real by, real x, real y) {
+    real vx = bx - ax, vy = by - ay;
+    real lam = (vx * (x - ax) + vy * (y - ay)) / (vx * vx + vy * vy);
+    lam = lam < real(0.0) ? real(0.0) : (lam > real(1.0) ? real(1.0) : lam);
+    real px = (real(1.0) - lam) * ax + lam * bx, py = (real(1.0) - lam) * ay + lam * by;
     return (px - x) * (px - x) + (py - y) * (py - y);
 }
 // one wave per instance; strict '<' with lowest index winning ties == the reference's sequential scan (:71-79)
-__global__ __launch_bounds__(256) void k_project(DevCfg C, int B, const double* __restrict__ state, double* __restrict__ sep) {
+__global__ __launch_bounds__(256) void k_project(DevCfg C, int B, const real* __restrict__ state, real* __restrict__ sep) {
     int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= B) return;
     const TrajView T = traj_of(C, wave);
-    double x = state[(size_t)wave * 6 + 0], y = state[(size_t)wave * 6 + 1];
-    double best = INFINITY; int bi = 0x7fffffff;
+    real x = state[(size_t)wave * 6 + 0], y = state[(size_t)wave * 6 + 1];
+    real best = INFINITY; int bi = 0x7fffffff;
     for (int i = lane; i < T.L - 1; i += 64) {
-        double d2 = seg_dist2(T.E[i], T.N[i], T.E[i + 1], T.N[i + 1], x, y);
+        real d2 = seg_dist2(T.E[i], T.N[i], T.E[i + 1], T.N[i + 1], x, y);
         if (d2 < best) { best = d2; bi = i; }           // i increases within a lane, so strict '<' keeps the lowest index
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-        double ob = __shfl_xor(best, off); int oi = __shfl_xor(bi, off);
+        real ob = __shfl_xor(best, off); int oi = __shfl_xor(bi, off);
         if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
     if (lane == 0) {
         int i = bi;
-        double vx = T.E[i + 1] - T.E[i], vy = T.N[i + 1] - T.N[i], wx = x - T.E[i], wy = y - T.N[i];
+        real vx = T.E[i + 1] - T.E[i], vy = T.N[i + 1] - T.N[i], wx = x - T.E[i], wy = y - T.N[i];
         // :82 sqrt(w.w - d^2) with d^2 = |w - lam v|^2 expanded: w.w - d^2 = lam (2 w.v - lam v.v).  Same value for every lam in [0,1], but no
         // cancellation (the literal form loses half the digits when the foot point is near the segment start: 5 mm in fp32)
-        double vw = vx * wx + vy * wy, vv = vx * vx + vy * vy;
-        double lam = vw / vv; lam = lam < 0.0 ? 0.0 : (lam > 1.0 ? 1.0 : lam);
-        double ds = sqrt(fmax(lam * (2.0 * vw - lam * vv), 0.0));
-        double cr = vx * wy - vy * wx;
-        double Ai = (T.V[i + 1] - T.V[i]) / (T.t[i + 1] - T.t[i]);
+        real vw = vx * wx + vy * wy, vv = vx * vx + vy * vy;
+        real lam = vw / vv; lam = lam < real(0.0) ? real(0.0) : (lam > real(1.0) ? real(1.0) : lam);
+        real ds = sqrt(fmax(lam * (real(2.0) * vw - lam * vv), real(0.0)));
+        real cr = vx * wy - vy * wx;
+        real Ai = (T.V[i + 1] - T.V[i]) / (T.t[i + 1] - T.t[i]);
         // (sqrt(2 A ds + V^2) - V) / A of :88, rationalised: same value, no cancellation (in fp32 the original loses 3 digits at |A| ~ 1e-3)
-        double dt = fabs(Ai) < 1e-3 ? ds / T.V[i] : 2.0 * ds / (sqrt(2.0 * Ai * ds + T.V[i] * T.V[i]) + T.V[i]);
-        double* o = sep + (size_t)wave * 4;
-        o[0] = T.s[i] + ds; o[1] = sqrt(best) * sgn(cr); o[2] = T.t[i] + dt; o[3] = (double)i;
+        real dt = fabs(Ai) < real(1e-3) ? ds / T.V[i] : real(2.0) * ds / (sqrt(real(2.0) * Ai * ds + T.V[i] * T.V[i]) + T.V[i]);
+        real* o = sep + (size_t)wave * 4;
+        o[0] = T.s[i] + ds; o[1] = sqrt(best) * sgn(cr); o[2] = T.t[i] + dt; o[3] = (real)i;
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // nodes record per node: q[6], u[2] (physical units), V, kappa  -> 10 doubles
-struct NodeRec { double q0, q1, q2, q3, q4, q5, u0, u1, pV, pK; };
-PG_DEV void put_node(double* __restrict__ ND, int i, const NodeRec& r) {
-    double* o = ND + i * 10;
+struct NodeRec { real q0, q1, q2, q3, q4, q5, u0, u1, pV, pK; };
+PG_DEV void put_node(real* __restrict__ ND, int i, const NodeRec& r) {
+    real* o = ND + i * 10;
     o[0] = r.q0; o[1] = r.q1; o[2] = r.q2; o[3] = r.q3; o[4] = r.q4; o[5] = r.q5; o[6] = r.u0; o[7] = r.u1; o[8] = r.pV; o[9] = r.pK;
 }
-template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, int B, const double* __restrict__ state, const double* __restrict__ control, const tdouble* __restrict__ toff,
-                        const int* __restrict__ solved, const double* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt,
-                        const tdouble* __restrict__ prev_ts, const double* __restrict__ prev_x, double* __restrict__ nodes) {
+template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, int B, const real* __restrict__ state, const real* __restrict__ control, const tdouble* __restrict__ toff,
+                        const int* __restrict__ solved, const real* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt,
+                        const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* __restrict__ nodes) {
     // the two searched channels (t, s) are staged in LDS when they fit: every node costs three binary searches whose ~10 dependent probes each
     // would otherwise pay L2 latency (the kernel is a 64-wave serial recurrence: latency, not bandwidth, is its whole cost)
-    extern __shared__ double sh_traj[];
+    extern __shared__ real sh_traj[];
     TrajView T = C.traj;
     if constexpr (STAGED) {                                 // single shared trajectory; compile-time so the searches compile to ds_read, not flat loads
         for (int i = threadIdx.x; i < T.L; i += blockDim.x) { sh_traj[i] = C.traj.t[i]; sh_traj[T.L + i] = C.traj.s[i]; }
@@ -148,32 +147,32 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
     if (b >= B) return;
     if constexpr (!STAGED) T = traj_of(C, b);
     const DevVehicle& P = C.veh;
-    const double* q0 = state + (size_t)b * 6; const double* u0 = control + (size_t)b * 3;
+    const real* q0 = state + (size_t)b * 6; const real* u0 = control + (size_t)b * 3;
     const tdouble* TS = ts + (size_t)b * C.NN; const tdouble* DT = dt + (size_t)b * C.N;
-    double* ND = nodes + (size_t)b * C.NN * 10;
-    const double s0 = sep[(size_t)b * 4], e0 = sep[(size_t)b * 4 + 1];
-    const double psi0 = q0[2], Ux0 = q0[3], Uy0 = q0[4], r0 = q0[5];
-    const double d0 = u0[0], Fxf0 = u0[1], Fxr0 = u0[2];
+    real* ND = nodes + (size_t)b * C.NN * 10;
+    const real s0 = sep[(size_t)b * 4], e0 = sep[(size_t)b * 4 + 1];
+    const real psi0 = q0[2], Ux0 = q0[3], Uy0 = q0[4], r0 = q0[5];
+    const real d0 = u0[0], Fxf0 = u0[1], Fxr0 = u0[2];
     TrajS tj = traj_at_s(T, s0);                                                   // :76
-    const double ds0 = s0 - traj_s_at_time(T, TS[0]);                              // :77
-    const double dpsi = adiff(psi0, tj.psi);                                       // :78
+    const real ds0 = s0 - traj_s_at_time(T, TS[0]);                              // :77
+    const real dpsi = adiff(psi0, tj.psi);                                       // :78
     // node 1 of the reference (index 0 here) is the measured state in both branches (:79-85, and i == 1 of the cold loop)
     NodeRec r;
     r.q0 = ds0; r.q1 = Ux0; r.q2 = Uy0; r.q3 = r0; r.q4 = dpsi; r.q5 = e0; r.u0 = d0; r.u1 = Fxf0 + Fxr0; r.pV = tj.V; r.pK = tj.kappa;
     put_node(ND, 0, r);
     if (solved[b]) {                                                               // :82-102 with update_interpolations! (:189-195)
-        const tdouble* PT = prev_ts + (size_t)b * C.NN; const double* PX = prev_x + (size_t)b * C.NN * 8;
-        const double tlast = PT[C.NN - 1];
+        const tdouble* PT = prev_ts + (size_t)b * C.NN; const real* PX = prev_x + (size_t)b * C.NN * 8;
+        const real tlast = PT[C.NN - 1];
         for (int i = 1; i < C.NN; i++) {
-            double t = TS[i];
-            double tq = (t < tlast) ? t : tlast;
+            real t = TS[i];
+            real tq = (t < tlast) ? t : tlast;
             int j = clampi(count_leq(PT, C.NN, tq), 1, C.NN - 1) - 1;
-            double w = (tq - PT[j]) / (PT[j + 1] - PT[j]);
-            const double* a = PX + j * 8; const double* c = a + 8;
-            r.q0 = (1.0 - w) * a[0] + w * c[0]; r.q1 = (1.0 - w) * a[1] + w * c[1]; r.q2 = (1.0 - w) * a[2] + w * c[2];
-            r.q3 = (1.0 - w) * a[3] + w * c[3]; r.q4 = (1.0 - w) * a[4] + w * c[4]; r.q5 = (1.0 - w) * a[5] + w * c[5];
-            r.u0 = ((1.0 - w) * a[6] + w * c[6]) * C.un0; r.u1 = ((1.0 - w) * a[7] + w * c[7]) * C.un1;
-            double s = traj_s_at_time(T, t) + r.q0;                                // :96
+            real w = (tq - PT[j]) / (PT[j + 1] - PT[j]);
+            const real* a = PX + j * 8; const real* c = a + 8;
+            r.q0 = (real(1.0) - w) * a[0] + w * c[0]; r.q1 = (real(1.0) - w) * a[1] + w * c[1]; r.q2 = (real(1.0) - w) * a[2] + w * c[2];
+            r.q3 = (real(1.0) - w) * a[3] + w * c[3]; r.q4 = (real(1.0) - w) * a[4] + w * c[4]; r.q5 = (real(1.0) - w) * a[5] + w * c[5];
+            r.u0 = ((real(1.0) - w) * a[6] + w * c[6]) * C.un0; r.u1 = ((real(1.0) - w) * a[7] + w * c[7]) * C.un1;
+            real s = traj_s_at_time(T, t) + r.q0;                                // :96
             tj = traj_at_s(T, s);
             r.pV = tj.V; r.pK = tj.kappa;
             put_node(ND, i, r);
@@ -181,44 +180,44 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
         return;
     }
     // cold start :103-141
-    double sdp, cdp; pg_sincos(dpsi, &sdp, &cdp);
-    double V = Ux0 * cdp - Uy0 * sdp;
-    const double beta0 = atan2(Uy0, Ux0);
-    double Fyf0, Fyr0;
+    real sdp, cdp; pg_sincos(dpsi, &sdp, &cdp);
+    real V = Ux0 * cdp - Uy0 * sdp;
+    const real beta0 = atan2(Uy0, Ux0);
+    real Fyf0, Fyr0;
     {   // lateral_tire_forces(bicycle, q0, u0): raw (delta, Fxf, Fxr), no actuator limits (:110; vehicle_dynamics.jl:78-87)
-        double sd, cd; pg_sincos(d0, &sd, &cd);
-        double af = tan(atan2(Uy0 + P.a * r0, Ux0) - d0), ar = tan(atan2(Uy0 - P.b * r0, Ux0));
-        lateral_forces<double>(P, af, ar, Fxf0, Fxr0, sd, cd, Fyf0, Fyr0);
+        real sd, cd; pg_sincos(d0, &sd, &cd);
+        real af = tan(atan2(Uy0 + P.a * r0, Ux0) - d0), ar = tan(atan2(Uy0 - P.b * r0, Ux0));
+        lateral_forces<real>(P, af, ar, Fxf0, Fxr0, sd, cd, Fyf0, Fyr0);
     }
     const bool traj_mode = !(toff[b] != toff[b]);
     // i == 1 of the reference loop: acceleration from the full nonlinear model (:117-119); its node record is already written above
-    double s = s0;
+    real s = s0;
     {
-        double tau = DT[0];
-        double dUx, dUy, dr;
-        world_body_rhs<double>(P, Ux0, Uy0, r0, d0, Fxf0 + Fxr0, dUx, dUy, dr);
-        double A = (dUx - r0 * Uy0) * cdp - (dUy + r0 * Ux0) * sdp;
+        real tau = DT[0];
+        real dUx, dUy, dr;
+        world_body_rhs<real>(P, Ux0, Uy0, r0, d0, Fxf0 + Fxr0, dUx, dUy, dr);
+        real A = (dUx - r0 * Uy0) * cdp - (dUy + r0 * Ux0) * sdp;
         V = V + A * tau;
-        s = s + V * tau + A * tau * tau * 0.5;
+        s = s + V * tau + A * tau * tau * real(0.5);
     }
 #pragma unroll 1
     for (int i = 1; i < C.NN; i++) {
-        double tau = (i == C.NN - 1) ? DT[i - 1] : DT[i];
+        real tau = (i == C.NN - 1) ? DT[i - 1] : DT[i];
         tj = traj_at_s(T, s);
-        double ds = s - traj_s_at_time(T, TS[i]);
-        double A_des = tj.A + C.cp.k_V * (tj.V - V) / tau + (traj_mode ? -C.cp.k_s * ds / tau / tau : 0.0);
+        real ds = s - traj_s_at_time(T, TS[i]);
+        real A_des = tj.A + C.cp.k_V * (tj.V - V) / tau + (traj_mode ? -C.cp.k_s * ds / tau / tau : real(0.0));
         A_des = jmin(jmax(A_des, (C.cp.V_min - V) / tau), (C.cp.V_max - V) / tau);
         const bool shortp = i <= C.Ns;
         Steady est = shortp ? steady_state(P, V, A_des, tj.kappa, 1, r0, beta0, d0, Fyf0)            // :122
-                            : steady_state(P, V, A_des, tj.kappa, 4, V * tj.kappa, 0.0, 0.0, 0.0);   // :128
+                            : steady_state(P, V, A_des, tj.kappa, 4, V * tj.kappa, real(0.0), real(0.0), real(0.0));   // :128
         r.q0 = ds;
         r.q1 = shortp ? Ux0 : est.Ux; r.q2 = shortp ? Uy0 : est.Uy; r.q3 = shortp ? r0 : est.r;
-        r.q4 = shortp ? adiff(psi0, tj.psi) : -est.beta; r.q5 = shortp ? e0 : 0.0;
+        r.q4 = shortp ? adiff(psi0, tj.psi) : -est.beta; r.q5 = shortp ? e0 : real(0.0);
         r.u0 = est.delta; r.u1 = est.Fx; r.pV = tj.V; r.pK = tj.kappa;
         put_node(ND, i, r);
-        double A = est.A;
+        real A = est.A;
         V = V + A * tau;
-        s = s + V * tau + A * tau * tau * 0.5;
+        s = s + V * tau + A * tau * tau * real(0.5);
     }
 }
 
@@ -226,48 +225,48 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
 // linearize: RK4 (nsub sub-steps) of the tracking model with two tangent directions per lane.
 // lane -> (instance, interval t, group g); group g carries tangents {2g, 2g+1} of (q[0..5], u0[0..1], uf[0..1]).
 // Writes raw Jacobian columns; group 0 also writes Phi (the propagated state) into the c slot.  k_limits finishes c and scales B.
-__global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const double* __restrict__ nodes, const tdouble* __restrict__ dt, double* __restrict__ qp) {
+__global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, real* __restrict__ qp) {
     long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long per = (long)C.N * 5;
     if (gid >= (long)B * per) return;
     int b = (int)(gid / per); int rem = (int)(gid - (long)b * per); int t = rem / 5, g = rem - t * 5;
     bool ramp = t >= C.Ns;
     if (!ramp && g == 4) return;
-    const double* n0 = nodes + ((size_t)b * C.NN + t) * 10; const double* n1 = n0 + 10;
-    double h_total = dt[(size_t)b * C.N + t];
+    const real* n0 = nodes + ((size_t)b * C.NN + t) * 10; const real* n1 = n0 + 10;
+    real h_total = dt[(size_t)b * C.N + t];
     D2 x[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) x[k] = D2(n0[k], (2 * g == k) ? 1.0 : 0.0, (2 * g + 1 == k) ? 1.0 : 0.0);
-    D2 u0a(n0[6], g == 3 ? 1.0 : 0.0, 0.0), u0b(n0[7], 0.0, g == 3 ? 1.0 : 0.0);
-    D2 ufa(ramp ? n1[6] : n0[6], g == 4 ? 1.0 : 0.0, 0.0), ufb(ramp ? n1[7] : n0[7], 0.0, g == 4 ? 1.0 : 0.0);
-    double pV0 = n0[8], pK0 = n0[9], pV1 = ramp ? n1[8] : n0[8], pK1 = ramp ? n1[9] : n0[9];
-    const int nsub = C.nsub; const double h = h_total / nsub;
-    auto rhs = [&](const D2* xx, double tau, D2* out) {
-        double w = ramp ? tau / h_total : 0.0;
+    for (int k = 0; k < 6; k++) x[k] = D2(n0[k], (2 * g == k) ? real(1.0) : real(0.0), (2 * g + 1 == k) ? real(1.0) : real(0.0));
+    D2 u0a(n0[6], g == 3 ? real(1.0) : real(0.0), real(0.0)), u0b(n0[7], real(0.0), g == 3 ? real(1.0) : real(0.0));
+    D2 ufa(ramp ? n1[6] : n0[6], g == 4 ? real(1.0) : real(0.0), real(0.0)), ufb(ramp ? n1[7] : n0[7], real(0.0), g == 4 ? real(1.0) : real(0.0));
+    real pV0 = n0[8], pK0 = n0[9], pV1 = ramp ? n1[8] : n0[8], pK1 = ramp ? n1[9] : n0[9];
+    const int nsub = C.nsub; const real h = h_total / nsub;
+    auto rhs = [&](const D2* xx, real tau, D2* out) {
+        real w = ramp ? tau / h_total : real(0.0);
         D2 ua = u0a + (ufa - u0a) * w, ub = u0b + (ufb - u0b) * w;
         tracking_rhs<D2>(C.veh, xx, ua, ub, pV0 + (pV1 - pV0) * w, pK0 + (pK1 - pK0) * w, out);
     };
 #pragma unroll 1
     for (int i = 0; i < nsub; i++) {
-        const double t0 = i * h;
+        const real t0 = i * h;
         D2 kk[6], xx[6], acc[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) { xx[k] = x[k]; acc[k] = D2(0.0); }
+        for (int k = 0; k < 6; k++) { xx[k] = x[k]; acc[k] = D2(real(0.0)); }
         // classical RK4 written as one rolled stage loop (one instance of the dynamics in the instruction stream, fewer live registers)
 #pragma unroll 1
         for (int st = 0; st < 4; st++) {
-            const double cst_ = st == 0 ? 0.0 : (st == 3 ? 1.0 : 0.5);        // stage time fraction
-            const double wgt = (st == 0 || st == 3) ? 1.0 : 2.0;              // quadrature weight (x h/6)
-            const double nxt = st == 2 ? 1.0 : 0.5;                           // coefficient of k in the NEXT stage's evaluation point
+            const real cst_ = st == 0 ? real(0.0) : (st == 3 ? real(1.0) : real(0.5));        // stage time fraction
+            const real wgt = (st == 0 || st == 3) ? real(1.0) : real(2.0);              // quadrature weight (x h/6)
+            const real nxt = st == 2 ? real(1.0) : real(0.5);                           // coefficient of k in the NEXT stage's evaluation point
             rhs(xx, t0 + cst_ * h, kk);
 #pragma unroll
             for (int k = 0; k < 6; k++) { acc[k] = acc[k] + kk[k] * wgt; xx[k] = x[k] + kk[k] * (nxt * h); }
         }
 #pragma unroll
-        for (int k = 0; k < 6; k++) x[k] = x[k] + acc[k] * (h / 6.0);
+        for (int k = 0; k < 6; k++) x[k] = x[k] + acc[k] * (h / real(6.0));
     }
     QpOff o = qp_offsets(C.N);
-    double* Q = qp + (size_t)b * C.qp_len;
+    real* Q = qp + (size_t)b * C.qp_len;
     if (g < 3) {
 #pragma unroll
         for (int i = 0; i < 6; i++) { Q[o.A + 36 * t + 6 * i + 2 * g] = x[i].a; Q[o.A + 36 * t + 6 * i + 2 * g + 1] = x[i].b; }
@@ -288,42 +287,42 @@ __global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const double
 // EIGHT lanes per (instance, interval): lane i < 6 owns row i of the linearisation (its loads and stores are contiguous segments and the eight lanes of an
 // interval cover whole cache lines: one lane per interval touched 64 different lines per instruction); lane 6 does the envelope and the bounds, lane 7 the
 // per-instance header of interval 0.
-__global__ __launch_bounds__(256) void k_limits(DevCfg C, int B, const double* __restrict__ nodes, const tdouble* __restrict__ dt, const double* __restrict__ hji_Mb, double* __restrict__ qp,
-                                                double* __restrict__ abar) {
+__global__ __launch_bounds__(256) void k_limits(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb, real* __restrict__ qp,
+                                                real* __restrict__ abar) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long it = gid >> 3; const int i = (int)(gid & 7);
     if (it >= (long)B * C.N) return;
     const int b = (int)(it / C.N), t = (int)(it - (long)b * C.N);
     const bool ramp = t >= C.Ns;
-    const double* n0 = nodes + ((size_t)b * C.NN + t) * 10; const double* n1 = n0 + 10;
+    const real* n0 = nodes + ((size_t)b * C.NN + t) * 10; const real* n1 = n0 + 10;
     const QpOff o = qp_offsets(C.N);
-    double* Q = qp + (size_t)b * C.qp_len;
-    double* P66 = abar + ((size_t)b * C.N + t) * SB;      // packed copy streamed by k_solve: rows 0..5 of Abar = [A | B0+Bf], Bbar = Bf, cbar = c  (SB doubles per stage)
+    real* Q = qp + (size_t)b * C.qp_len;
+    real* P66 = abar + ((size_t)b * C.N + t) * SB;      // packed copy streamed by k_solve: rows 0..5 of Abar = [A | B0+Bf], Bbar = Bf, cbar = c  (SB doubles per stage)
     if (i < 6) {
-        double* A = Q + o.A + 36 * t + 6 * i; double* B0 = Q + o.B0 + 12 * t + 2 * i; double* Bf = Q + o.Bf + 12 * t + 2 * i; double* c = Q + o.c + 6 * t + i;
-        double ci = c[0];
-        double a[6];
+        real* A = Q + o.A + 36 * t + 6 * i; real* B0 = Q + o.B0 + 12 * t + 2 * i; real* Bf = Q + o.Bf + 12 * t + 2 * i; real* c = Q + o.c + 6 * t + i;
+        real ci = c[0];
+        real a[6];
 #pragma unroll
         for (int j = 0; j < 6; j++) { a[j] = A[j]; ci -= a[j] * n0[j]; }
-        double b00 = B0[0], b01 = B0[1], bf0 = ramp ? Bf[0] : 0.0, bf1 = ramp ? Bf[1] : 0.0;
+        real b00 = B0[0], b01 = B0[1], bf0 = ramp ? Bf[0] : real(0.0), bf1 = ramp ? Bf[1] : real(0.0);
         ci -= b00 * n0[6] + b01 * n0[7];
         if (ramp) ci -= bf0 * n1[6] + bf1 * n1[7];
         c[0] = ci;
         b00 *= C.un0; b01 *= C.un1; bf0 *= C.un0; bf1 *= C.un1;                                      // :338,350-351
         B0[0] = b00; B0[1] = b01; Bf[0] = bf0; Bf[1] = bf1;
-        double* row = P66 + SB_ROW * i;
+        real* row = P66 + SB_ROW * i;
 #pragma unroll
         for (int j = 0; j < 6; j++) row[j] = a[j];
-        row[6] = b00 + bf0; row[7] = b01 + bf1; row[8] = 0.0;
+        row[6] = b00 + bf0; row[7] = b01 + bf1; row[8] = real(0.0);
         P66[SB_B + 2 * i] = bf0; P66[SB_B + 2 * i + 1] = bf1;
         P66[SB_C + i] = ci;
     } else if (i == 6) {
-        const double Uxt = n1[1], Fx = n1[7];                                                        // :357-358
-        const double Fxf = Fx > 0.0 ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac, Fxr = Fx > 0.0 ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
+        const real Uxt = n1[1], Fx = n1[7];                                                        // :357-358
+        const real Fxf = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac, Fxr = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
         const Envelope e = stable_limits(C.veh, Uxt, Fxf, Fxr);
 #pragma unroll
         for (int r = 0; r < 4; r++) { Q[o.H + 8 * t + 2 * r] = e.H[r][0]; Q[o.H + 8 * t + 2 * r + 1] = e.H[r][1]; Q[o.G + 4 * t + r] = e.G[r]; }
-        const double h = dt[(size_t)b * C.N + t];
+        const real h = dt[(size_t)b * C.N + t];
         Q[o.dmin + t] = jmax(e.dmin, -C.veh.delta_max) / C.un0;
         Q[o.dmax + t] = jmin(e.dmax, C.veh.delta_max) / C.un0;
         Q[o.fxmax + t] = jmin(C.veh.Px_max / Uxt, C.veh.Fx_max) / C.un1;
@@ -335,7 +334,7 @@ __global__ __launch_bounds__(256) void k_limits(DevCfg C, int B, const double* _
         for (int k = 0; k < 6; k++) Q[o.qcurr + k] = n0[k];
         Q[o.ucurr] = n0[6] / C.un0; Q[o.ucurr + 1] = n0[7] / C.un1;
         if (C.has_hji) { Q[o.M] = hji_Mb[(size_t)b * 4]; Q[o.M + 1] = hji_Mb[(size_t)b * 4 + 1]; Q[o.b] = hji_Mb[(size_t)b * 4 + 2]; }
-        else { Q[o.M] = 0.0; Q[o.M + 1] = 0.0; Q[o.b] = 1.0; }
+        else { Q[o.M] = real(0.0); Q[o.M + 1] = real(0.0); Q[o.b] = real(1.0); }
     }
 }
 
@@ -345,30 +344,30 @@ __global__ __launch_bounds__(256) void k_limits(DevCfg C, int B, const double* _
 //              through the actuator limits: vehicle_dynamics.jl:111-135,293-314)
 //   control <- get_next_control(mpc)     (one-step actuation delay: the state moves with the OLD control)
 //   t       <- t + dt
-__global__ __launch_bounds__(64) void k_advance(DevCfg C, int B, tdouble dtp, double* __restrict__ state, double* __restrict__ control, const double* __restrict__ u_next,
+__global__ __launch_bounds__(64) void k_advance(DevCfg C, int B, tdouble dtp, real* __restrict__ state, real* __restrict__ control, const real* __restrict__ u_next,
                                                 tdouble* __restrict__ t0) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    double* q = state + (size_t)b * 6; double* u = control + (size_t)b * 3;
-    double x[6] = {q[0], q[1], q[2], q[3], q[4], q[5]};
-    const double d = u[0], Fx = u[1] + u[2];
-    const int nsub = C.nsub; const double h = dtp / nsub;
-    auto rhs = [&](const double* y, double* o) {
-        double s, c; pg_sincos(y[2], &s, &c);
+    real* q = state + (size_t)b * 6; real* u = control + (size_t)b * 3;
+    real x[6] = {q[0], q[1], q[2], q[3], q[4], q[5]};
+    const real d = u[0], Fx = u[1] + u[2];
+    const int nsub = C.nsub; const real h = dtp / nsub;
+    auto rhs = [&](const real* y, real* o) {
+        real s, c; pg_sincos(y[2], &s, &c);
         o[0] = -y[3] * s - y[4] * c; o[1] = y[3] * c - y[4] * s; o[2] = y[5];          // psi measured from North (:127-129)
-        world_body_rhs<double>(C.veh, y[3], y[4], y[5], d, Fx, o[3], o[4], o[5]);
+        world_body_rhs<real>(C.veh, y[3], y[4], y[5], d, Fx, o[3], o[4], o[5]);
     };
 #pragma unroll 1
     for (int i = 0; i < nsub; i++) {
-        double k1[6], k2[6], k3[6], k4[6], y[6];
+        real k1[6], k2[6], k3[6], k4[6], y[6];
         rhs(x, k1);
-        for (int k = 0; k < 6; k++) y[k] = x[k] + k1[k] * (h * 0.5);
+        for (int k = 0; k < 6; k++) y[k] = x[k] + k1[k] * (h * real(0.5));
         rhs(y, k2);
-        for (int k = 0; k < 6; k++) y[k] = x[k] + k2[k] * (h * 0.5);
+        for (int k = 0; k < 6; k++) y[k] = x[k] + k2[k] * (h * real(0.5));
         rhs(y, k3);
         for (int k = 0; k < 6; k++) y[k] = x[k] + k3[k] * h;
         rhs(y, k4);
-        for (int k = 0; k < 6; k++) x[k] += (k1[k] + 2.0 * k2[k] + 2.0 * k3[k] + k4[k]) * (h / 6.0);
+        for (int k = 0; k < 6; k++) x[k] += (k1[k] + real(2.0) * k2[k] + real(2.0) * k3[k] + k4[k]) * (h / real(6.0));
     }
     for (int k = 0; k < 6; k++) q[k] = x[k];
     u[0] = u_next[(size_t)b * 3]; u[1] = u_next[(size_t)b * 3 + 1]; u[2] = u_next[(size_t)b * 3 + 2];
@@ -381,9 +380,9 @@ __global__ __launch_bounds__(64) void k_advance(DevCfg C, int B, tdouble dtp, do
 // never-active bounds on the three inert slots, so the same solve kernel serves both formulations (the inert slots are exactly
 // decoupled from the rest, the optimum of the embedded problem restricted to the live slots IS the lateral optimum).
 // Node record (10 doubles): (0, Ux parameter, Uy, r, dpsi, e, delta, Fx, 0, kappa).
-template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg C, int B, const double* __restrict__ state, const double* __restrict__ control, const tdouble* __restrict__ toff,
-                                                  const double* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt, double* __restrict__ nodes) {
-    extern __shared__ double sh_traj[];
+template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg C, int B, const real* __restrict__ state, const real* __restrict__ control, const tdouble* __restrict__ toff,
+                                                  const real* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt, real* __restrict__ nodes) {
+    extern __shared__ real sh_traj[];
     TrajView T = C.traj;
     if constexpr (STAGED) {                                 // single shared trajectory; compile-time so the searches compile to ds_read, not flat loads
         for (int i = threadIdx.x; i < T.L; i += blockDim.x) { sh_traj[i] = C.traj.t[i]; sh_traj[T.L + i] = C.traj.s[i]; }
@@ -394,55 +393,55 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg 
     if (b >= B) return;
     if constexpr (!STAGED) T = traj_of(C, b);
     const DevVehicle& P = C.veh;
-    const double* q0 = state + (size_t)b * 6; const double* u0 = control + (size_t)b * 3;
+    const real* q0 = state + (size_t)b * 6; const real* u0 = control + (size_t)b * 3;
     const tdouble* TS = ts + (size_t)b * C.NN; const tdouble* DT = dt + (size_t)b * C.N;
-    double* ND = nodes + (size_t)b * C.NN * 10;
-    double s = sep[(size_t)b * 4]; const double e0 = sep[(size_t)b * 4 + 1];           // :65
-    const double psi0 = q0[2], Ux0 = q0[3], Uy0 = q0[4], r0 = q0[5], d0 = u0[0], Fxf0 = u0[1], Fxr0 = u0[2];
-    double V = hypot(Ux0, Uy0);                                                         // :67
-    const double beta0 = atan2(Uy0, Ux0);
-    double Fyf0, Fyr0;
+    real* ND = nodes + (size_t)b * C.NN * 10;
+    real s = sep[(size_t)b * 4]; const real e0 = sep[(size_t)b * 4 + 1];           // :65
+    const real psi0 = q0[2], Ux0 = q0[3], Uy0 = q0[4], r0 = q0[5], d0 = u0[0], Fxf0 = u0[1], Fxr0 = u0[2];
+    real V = hypot(Ux0, Uy0);                                                         // :67
+    const real beta0 = atan2(Uy0, Ux0);
+    real Fyf0, Fyr0;
     {
-        double sd, cd; pg_sincos(d0, &sd, &cd);
-        double af = tan(atan2(Uy0 + P.a * r0, Ux0) - d0), ar = tan(atan2(Uy0 - P.b * r0, Ux0));
-        lateral_forces<double>(P, af, ar, Fxf0, Fxr0, sd, cd, Fyf0, Fyr0);               // :71
+        real sd, cd; pg_sincos(d0, &sd, &cd);
+        real af = tan(atan2(Uy0 + P.a * r0, Ux0) - d0), ar = tan(atan2(Uy0 - P.b * r0, Ux0));
+        lateral_forces<real>(P, af, ar, Fxf0, Fxr0, sd, cd, Fyf0, Fyr0);               // :71
     }
     const bool traj_mode = !(toff[b] != toff[b]);
 #pragma unroll 1
     for (int i = 0; i < C.NN; i++) {
-        double tau = (i == C.NN - 1) ? DT[i - 1] : DT[i];
+        real tau = (i == C.NN - 1) ? DT[i - 1] : DT[i];
         TrajS tj = traj_at_s(T, s);
-        double A_des = tj.A + C.cp.k_V * (tj.V - V) / tau + (traj_mode ? C.cp.k_s * (traj_s_at_time(T, TS[i]) - s) / tau / tau : 0.0);   // :76
+        real A_des = tj.A + C.cp.k_V * (tj.V - V) / tau + (traj_mode ? C.cp.k_s * (traj_s_at_time(T, TS[i]) - s) / tau / tau : real(0.0));   // :76
         A_des = jmin(jmax(A_des, (C.cp.V_min - V) / tau), (C.cp.V_max - V) / tau);
-        NodeRec r; double A;
-        r.q0 = 0.0; r.pV = 0.0; r.pK = tj.kappa;
+        NodeRec r; real A;
+        r.q0 = real(0.0); r.pV = real(0.0); r.pK = tj.kappa;
         if (i == 0) {
             r.q1 = Ux0; r.q2 = Uy0; r.q3 = r0; r.q4 = adiff(psi0, tj.psi); r.q5 = e0; r.u0 = d0; r.u1 = Fxf0 + Fxr0;      // :79-81
-            double dUx, dUy, dr;
-            world_body_rhs<double>(P, Ux0, Uy0, r0, d0, Fxf0 + Fxr0, dUx, dUy, dr);                                          // :82
-            double sb, cb; pg_sincos(beta0, &sb, &cb);
+            real dUx, dUy, dr;
+            world_body_rhs<real>(P, Ux0, Uy0, r0, d0, Fxf0 + Fxr0, dUx, dUy, dr);                                          // :82
+            real sb, cb; pg_sincos(beta0, &sb, &cb);
             A = (dUx - r0 * Uy0) * cb + (dUy + r0 * Ux0) * sb;                                                               // :83
         } else {
             const bool shortp = i <= C.Ns;
-            Steady est = shortp ? steady_state(P, V, A_des, tj.kappa, 1, r0, beta0, d0, Fyf0) : steady_state(P, V, A_des, tj.kappa, 4, V * tj.kappa, 0.0, 0.0, 0.0);
+            Steady est = shortp ? steady_state(P, V, A_des, tj.kappa, 1, r0, beta0, d0, Fyf0) : steady_state(P, V, A_des, tj.kappa, 4, V * tj.kappa, real(0.0), real(0.0), real(0.0));
             r.q1 = est.Ux;
-            r.q2 = shortp ? Uy0 : est.Uy; r.q3 = shortp ? r0 : est.r; r.q4 = shortp ? adiff(psi0, tj.psi) : -est.beta; r.q5 = shortp ? e0 : 0.0;   // :85,92
+            r.q2 = shortp ? Uy0 : est.Uy; r.q3 = shortp ? r0 : est.r; r.q4 = shortp ? adiff(psi0, tj.psi) : -est.beta; r.q5 = shortp ? e0 : real(0.0);   // :85,92
             r.u0 = est.delta; r.u1 = est.Fx; A = est.A;
         }
         put_node(ND, i, r);
-        if (C.walls && i >= 1) { double eL, eR; traj_edges_at_s(T, s, eL, eR); double* w = C.wall_edges + ((size_t)b * C.N + i - 1) * 2; w[0] = eL; w[1] = eR; }
+        if (C.walls && i >= 1) { real eL, eR; traj_edges_at_s(T, s, eL, eR); real* w = C.wall_edges + ((size_t)b * C.N + i - 1) * 2; w[0] = eL; w[1] = eR; }
         V = V + A * tau;
-        s = s + V * tau + A * tau * tau * 0.5;
+        s = s + V * tau + A * tau * tau * real(0.5);
     }
 }
 
 // 4x4 helpers for the exact discretisation
-struct M4d { double a[16]; };
+struct M4d { real a[16]; };
 PG_DEV M4d m4mul(const M4d& x, const M4d& y) { M4d r;
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) { double s = 0.0;
+        for (int j = 0; j < 4; j++) { real s = real(0.0);
 #pragma unroll
             for (int k = 0; k < 4; k++) s += x.a[4 * i + k] * y.a[4 * k + j];
             r.a[4 * i + j] = s; }
@@ -452,93 +451,93 @@ PG_DEV M4d m4mul(const M4d& x, const M4d& y) { M4d r;
 // continuous Jacobians by forward mode (8 tangent directions: Uy, r, dpsi, e, delta, Fx, Ux, kappa), exact ZOH / FOH discretisation
 // (Ad = exp(A dt), G0 = int exp(A s) ds, G1 = (1/dt) int exp(A (dt - s)) s ds by Taylor series + scaling and squaring), envelope and bounds;
 // the result is written in the embedded coupled layout (QP block + the packed per-stage block k_solve streams).
-__global__ __launch_bounds__(128) void k_qp_dec(DevCfg C, int B, const double* __restrict__ nodes, const tdouble* __restrict__ dt, double* __restrict__ qp, double* __restrict__ abar) {
+__global__ __launch_bounds__(128) void k_qp_dec(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, real* __restrict__ qp, real* __restrict__ abar) {
     long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)B * C.N) return;
     int b = (int)(gid / C.N), t = (int)(gid - (long)b * C.N);
     const bool ramp = t >= C.Ns;
-    const double* n0 = nodes + ((size_t)b * C.NN + t) * 10; const double* n1 = n0 + 10;
-    const double q[4] = {n0[2], n0[3], n0[4], n0[5]};
-    const double w0[4] = {n0[6], n0[7], n0[1], n0[9]}, wf[4] = {n1[6], n1[7], n1[1], n1[9]};      // (delta, Fx, Ux, kappa); theta = phi = 0 carry no derivative
-    const double T = dt[(size_t)b * C.N + t];
-    M4d A; double Bc[4][4], cc[4];
+    const real* n0 = nodes + ((size_t)b * C.NN + t) * 10; const real* n1 = n0 + 10;
+    const real q[4] = {n0[2], n0[3], n0[4], n0[5]};
+    const real w0[4] = {n0[6], n0[7], n0[1], n0[9]}, wf[4] = {n1[6], n1[7], n1[1], n1[9]};      // (delta, Fx, Ux, kappa); theta = phi = 0 carry no derivative
+    const real T = dt[(size_t)b * C.N + t];
+    M4d A; real Bc[4][4], cc[4];
     {
         D2 f[4];
-        D2 x[4] = {D2(q[0], 1.0, 0.0), D2(q[1], 0.0, 1.0), D2(q[2]), D2(q[3])};
+        D2 x[4] = {D2(q[0], real(1.0), real(0.0)), D2(q[1], real(0.0), real(1.0)), D2(q[2]), D2(q[3])};
         lateral_rhs<D2>(C.veh, x, D2(w0[0]), D2(w0[1]), D2(w0[2]), D2(w0[3]), f);
         for (int i = 0; i < 4; i++) { A.a[4 * i] = f[i].a; A.a[4 * i + 1] = f[i].b; cc[i] = f[i].v; }
-        D2 y[4] = {D2(q[0]), D2(q[1]), D2(q[2], 1.0, 0.0), D2(q[3], 0.0, 1.0)};
+        D2 y[4] = {D2(q[0]), D2(q[1]), D2(q[2], real(1.0), real(0.0)), D2(q[3], real(0.0), real(1.0))};
         lateral_rhs<D2>(C.veh, y, D2(w0[0]), D2(w0[1]), D2(w0[2]), D2(w0[3]), f);
         for (int i = 0; i < 4; i++) { A.a[4 * i + 2] = f[i].a; A.a[4 * i + 3] = f[i].b; }
         D2 z[4] = {D2(q[0]), D2(q[1]), D2(q[2]), D2(q[3])};
-        lateral_rhs<D2>(C.veh, z, D2(w0[0], 1.0, 0.0), D2(w0[1], 0.0, 1.0), D2(w0[2]), D2(w0[3]), f);
+        lateral_rhs<D2>(C.veh, z, D2(w0[0], real(1.0), real(0.0)), D2(w0[1], real(0.0), real(1.0)), D2(w0[2]), D2(w0[3]), f);
         for (int i = 0; i < 4; i++) { Bc[i][0] = f[i].a; Bc[i][1] = f[i].b; }
-        lateral_rhs<D2>(C.veh, z, D2(w0[0]), D2(w0[1]), D2(w0[2], 1.0, 0.0), D2(w0[3], 0.0, 1.0), f);
+        lateral_rhs<D2>(C.veh, z, D2(w0[0]), D2(w0[1]), D2(w0[2], real(1.0), real(0.0)), D2(w0[3], real(0.0), real(1.0)), f);
         for (int i = 0; i < 4; i++) { Bc[i][2] = f[i].a; Bc[i][3] = f[i].b; }
         for (int i = 0; i < 4; i++) {
-            double ci = cc[i];
+            real ci = cc[i];
             for (int j = 0; j < 4; j++) ci -= A.a[4 * i + j] * q[j] + Bc[i][j] * w0[j];
             cc[i] = ci;                                                                    // c = f - A x - B w
         }
     }
     // exp(A T) and its integrals
-    double nrm = 0.0;
-    for (int i = 0; i < 4; i++) { double sr = 0.0; for (int j = 0; j < 4; j++) sr += fabs(A.a[4 * i + j]); nrm = fmax(nrm, sr); }
-    int sq = 0; double h = T;
-    while (nrm * h > 0.25 && sq < 40) { h *= 0.5; sq++; }
+    real nrm = real(0.0);
+    for (int i = 0; i < 4; i++) { real sr = real(0.0); for (int j = 0; j < 4; j++) sr += fabs(A.a[4 * i + j]); nrm = fmax(nrm, sr); }
+    int sq = 0; real h = T;
+    while (nrm * h > real(0.25) && sq < 40) { h *= real(0.5); sq++; }
     M4d Ah, term, Ad, G0, G2;
-    for (int i = 0; i < 16; i++) { Ah.a[i] = A.a[i] * h; double e = (i % 5 == 0) ? 1.0 : 0.0; term.a[i] = e; Ad.a[i] = e; G0.a[i] = e * h; G2.a[i] = e * h * h * 0.5; }
+    for (int i = 0; i < 16; i++) { Ah.a[i] = A.a[i] * h; real e = (i % 5 == 0) ? real(1.0) : real(0.0); term.a[i] = e; Ad.a[i] = e; G0.a[i] = e * h; G2.a[i] = e * h * h * real(0.5); }
 #pragma unroll 1
     for (int k = 1; k <= 16; k++) {
         term = m4mul(term, Ah);
-        const double ik = 1.0 / k, c0 = h / (k + 1), c2 = h * h / ((k + 1.0) * (k + 2.0));
+        const real ik = real(1.0) / k, c0 = h / (k + 1), c2 = h * h / ((k + real(1.0)) * (k + real(2.0)));
         for (int i = 0; i < 16; i++) { term.a[i] *= ik; Ad.a[i] += term.a[i]; G0.a[i] += term.a[i] * c0; G2.a[i] += term.a[i] * c2; }
     }
 #pragma unroll 1
     for (int i = 0; i < sq; i++) {
         M4d AG2 = m4mul(Ad, G2), AG0 = m4mul(Ad, G0), AA = m4mul(Ad, Ad);
         for (int j = 0; j < 16; j++) { G2.a[j] = G2.a[j] + h * G0.a[j] + AG2.a[j]; G0.a[j] += AG0.a[j]; Ad.a[j] = AA.a[j]; }
-        h *= 2.0;
+        h *= real(2.0);
     }
-    double b0[4], bf[4], cd[4];
-    const double iT = 1.0 / T;
+    real b0[4], bf[4], cd[4];
+    const real iT = real(1.0) / T;
     for (int i = 0; i < 4; i++) {
-        double s0 = 0.0, sf = 0.0, sc = 0.0;
+        real s0 = real(0.0), sf = real(0.0), sc = real(0.0);
         for (int k = 0; k < 4; k++) {
-            double g0 = G0.a[4 * i + k], g1 = ramp ? G2.a[4 * i + k] * iT : 0.0;
+            real g0 = G0.a[4 * i + k], g1 = ramp ? G2.a[4 * i + k] * iT : real(0.0);
             s0 += (g0 - g1) * Bc[k][0]; sf += g1 * Bc[k][0];
-            double fold = cc[k] * g0;
-            for (int j = 1; j < 4; j++) fold += (g0 - g1) * Bc[k][j] * w0[j] + g1 * Bc[k][j] * (ramp ? wf[j] : 0.0);
+            real fold = cc[k] * g0;
+            for (int j = 1; j < 4; j++) fold += (g0 - g1) * Bc[k][j] * w0[j] + g1 * Bc[k][j] * (ramp ? wf[j] : real(0.0));
             sc += fold;
         }
         b0[i] = s0; bf[i] = sf; cd[i] = sc;
     }
     // ---- embedded coupled layout ----
     QpOff o = qp_offsets(C.N);
-    double* Q = qp + (size_t)b * C.qp_len;
-    double* A6 = Q + o.A + 36 * t; double* B06 = Q + o.B0 + 12 * t; double* Bf6 = Q + o.Bf + 12 * t; double* c6 = Q + o.c + 6 * t;
-    double* P66 = abar + ((size_t)b * C.N + t) * SB;
-    for (int i = 0; i < 36; i++) A6[i] = 0.0;
-    for (int i = 0; i < 12; i++) { B06[i] = 0.0; Bf6[i] = 0.0; }
-    for (int i = 0; i < SB; i++) P66[i] = 0.0;
-    A6[0] = 1.0; A6[7] = 1.0; P66[0] = 1.0; P66[SB_ROW + 1] = 1.0; c6[0] = 0.0; c6[1] = 0.0;
+    real* Q = qp + (size_t)b * C.qp_len;
+    real* A6 = Q + o.A + 36 * t; real* B06 = Q + o.B0 + 12 * t; real* Bf6 = Q + o.Bf + 12 * t; real* c6 = Q + o.c + 6 * t;
+    real* P66 = abar + ((size_t)b * C.N + t) * SB;
+    for (int i = 0; i < 36; i++) A6[i] = real(0.0);
+    for (int i = 0; i < 12; i++) { B06[i] = real(0.0); Bf6[i] = real(0.0); }
+    for (int i = 0; i < SB; i++) P66[i] = real(0.0);
+    A6[0] = real(1.0); A6[7] = real(1.0); P66[0] = real(1.0); P66[SB_ROW + 1] = real(1.0); c6[0] = real(0.0); c6[1] = real(0.0);
     for (int i = 0; i < 4; i++) {
         for (int j = 0; j < 4; j++) { A6[6 * (2 + i) + 2 + j] = Ad.a[4 * i + j]; P66[SB_ROW * (2 + i) + 2 + j] = Ad.a[4 * i + j]; }
         B06[2 * (2 + i)] = b0[i]; Bf6[2 * (2 + i)] = bf[i]; c6[2 + i] = cd[i];
         P66[SB_ROW * (2 + i) + 6] = b0[i] + bf[i]; P66[SB_B + 2 * (2 + i)] = bf[i]; P66[SB_C + 2 + i] = cd[i];
     }
     // envelope and bounds (:262-272): Ux from the NEXT node's parameter, Fx from its seeded control; nothing is normalised here
-    double Uxt = n1[1], Fx = n1[7];
-    double Fxf = Fx > 0.0 ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac, Fxr = Fx > 0.0 ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
+    real Uxt = n1[1], Fx = n1[7];
+    real Fxf = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac, Fxr = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
     Envelope e = stable_limits(C.veh, Uxt, Fxf, Fxr);
     for (int i = 0; i < 4; i++) { Q[o.H + 8 * t + 2 * i] = e.H[i][0]; Q[o.H + 8 * t + 2 * i + 1] = e.H[i][1]; Q[o.G + 4 * t + i] = e.G[i]; }
     Q[o.dmin + t] = jmax(e.dmin, -C.veh.delta_max); Q[o.dmax + t] = jmin(e.dmax, C.veh.delta_max);
-    Q[o.fxmax + t] = 1.0;                                           // inert Fx slot: 0 <= 1 is never active
+    Q[o.fxmax + t] = real(1.0);                                           // inert Fx slot: 0 <= 1 is never active
     Q[o.ddmin + t] = -C.cp.deltadot_max * T; Q[o.ddmax + t] = C.cp.deltadot_max * T;
     Q[o.dt + t] = T;
     if (t == 0) {
-        Q[o.qcurr] = 0.0; Q[o.qcurr + 1] = C.ux_dummy; for (int k = 0; k < 4; k++) Q[o.qcurr + 2 + k] = q[k];
-        Q[o.ucurr] = n0[6]; Q[o.ucurr + 1] = 0.0; Q[o.M] = 0.0; Q[o.M + 1] = 0.0; Q[o.b] = 1.0;
+        Q[o.qcurr] = real(0.0); Q[o.qcurr + 1] = C.ux_dummy; for (int k = 0; k < 4; k++) Q[o.qcurr + 2 + k] = q[k];
+        Q[o.ucurr] = n0[6]; Q[o.ucurr + 1] = real(0.0); Q[o.M] = real(0.0); Q[o.M + 1] = real(0.0); Q[o.b] = real(1.0);
     }
 }
 
@@ -571,12 +570,12 @@ __global__ __launch_bounds__(256) void k_hji_build_cells(HjiView Hv, long ncell,
 }
 
 // HJIRelativeState(us, them): HJI_computation.jl:20-24 (cpsi = sin(-psi), spsi = cos(-psi): names swapped in the reference)
-__global__ __launch_bounds__(256) void k_hji_relstate(int B, const double* __restrict__ state, const double* __restrict__ other, double* __restrict__ x7) {
+__global__ __launch_bounds__(256) void k_hji_relstate(int B, const real* __restrict__ state, const real* __restrict__ other, real* __restrict__ x7) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const double* us = state + (size_t)b * 6; const double* th = other + (size_t)b * 4; double* x = x7 + (size_t)b * 7;
-    double s, c; pg_sincos(-us[2], &s, &c);
-    double cpsi = s, spsi = c, dE = th[0] - us[0], dN = th[1] - us[1];
+    const real* us = state + (size_t)b * 6; const real* th = other + (size_t)b * 4; real* x = x7 + (size_t)b * 7;
+    real s, c; pg_sincos(-us[2], &s, &c);
+    real cpsi = s, spsi = c, dE = th[0] - us[0], dN = th[1] - us[1];
     x[0] = cpsi * dE + spsi * dN; x[1] = -spsi * dE + cpsi * dN; x[2] = adiff(th[2], us[2]);
     x[3] = us[3]; x[4] = us[4]; x[5] = th[3]; x[6] = us[5];
 }
@@ -584,7 +583,7 @@ __global__ __launch_bounds__(256) void k_hji_relstate(int B, const double* __res
 // cache[x]: HJI_computation.jl:66-72.  SIXTEEN lanes per lookup (four lookups per wave): lane g of a group owns the corner bits of
 // dims 4..7 and gathers ONE cell record (the 8 corners of dims 1..3 = 256 contiguous, aligned bytes: 16 x dwordx4).  Weights and sums in fp64 (Float32 grid x Float64 query); the 8 channels are reduced over
 // the 16-lane row with DPP butterflies (no LDS crossbar).  out8[b] = (V, gradV[0..6]); out of bounds => (Inf, 0) (:70).
-// PG_KEEP_BEGIN  (bit-level lane moves: one version per arithmetic type)
+// bit-level lane moves: one version per arithmetic type
 template <int CTRL> PG_DEV int dpp_mov(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, 0xF, true); }
 template <int CTRL> PG_DEV real dpp_move(real v) {
 #ifdef PG_F32
@@ -603,33 +602,32 @@ PG_DEV real dpp_add(real v, int ctrl_is /*0: xor1, 1: xor2, 2: half mirror, 3: r
     else p = dpp_move<0x128>(v);                      // row_ror:8
     return v + p;
 }
-// PG_KEEP_END
 template <int CD>
-__global__ __launch_bounds__(256) void k_hji_lookup(HjiView Hv, int B, const double* __restrict__ x7, double* __restrict__ out8) {
+__global__ __launch_bounds__(256) void k_hji_lookup(HjiView Hv, int B, const real* __restrict__ x7, real* __restrict__ out8) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int g = threadIdx.x & 15;
     long look = gid >> 4;
     const bool live = look < B;
     if (!live) look = B - 1;                       // keep whole rows active for the DPP reduction; results of dead groups are not stored
-    const double* x = x7 + (size_t)look * 7;
+    const real* x = x7 + (size_t)look * 7;
     // lane d < 7 of the group searches dimension d (searchsortedlast, clamp to [1, n-1], in-bounds test :67; knot vectors are tiny and L1-resident) and
     // the seven (index, weight, in-bounds) triples are shared over the 16-lane row: one 4-probe search per lane instead of seven in a row before the gather
-    int idx[7]; double w[7]; bool inb = true;
+    int idx[7]; real w[7]; bool inb = true;
     {
         const int d = g < 7 ? g : 6;
-        const float* k = Hv.knots + Hv.koff[d]; const int n = Hv.dims[d]; const double xv = x[d];
-        const int in_m = ((double)k[0] <= xv) && (xv <= (double)k[n - 1]);
+        const float* k = Hv.knots + Hv.koff[d]; const int n = Hv.dims[d]; const real xv = x[d];
+        const int in_m = ((real)k[0] <= xv) && (xv <= (real)k[n - 1]);
         int lo = 0, hi = n;
-        while (lo < hi) { int mid = (lo + hi) >> 1; if ((double)k[mid] <= xv) lo = mid + 1; else hi = mid; }
+        while (lo < hi) { int mid = (lo + hi) >> 1; if ((real)k[mid] <= xv) lo = mid + 1; else hi = mid; }
         const int i = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
-        const double k0 = k[i - 1], k1 = k[i];
-        const double w_m = (xv - k0) / (k1 - k0);
+        const real k0 = k[i - 1], k1 = k[i];
+        const real w_m = (xv - k0) / (k1 - k0);
 #pragma unroll
         for (int e = 0; e < 7; e++) { idx[e] = __shfl(i - 1, e, 16); w[e] = __shfl(w_m, e, 16); inb = inb && (__shfl(in_m, e, 16) != 0); }
     }
-    double acc[8];
+    real acc[8];
 #pragma unroll
-    for (int c = 0; c < 8; c++) acc[c] = 0.0;
+    for (int c = 0; c < 8; c++) acc[c] = real(0.0);
     if (inb && CD == 7) {
         // cdims = 7: ONE 4 KiB record holds all 128 corners of the lookup, ordered by the corner bits.  Lane g reads the float4s
         // 16 j + g (j = 0..15): every load instruction of the 16-lane group covers 256 contiguous bytes.  float4 f belongs to node f/2
@@ -642,43 +640,43 @@ __global__ __launch_bounds__(256) void k_hji_lookup(HjiView Hv, int B, const dou
 #pragma unroll
         for (int j = 0; j < 16; j++) r[j] = p[16 * j];
         const int lb = g >> 1;
-        const double wlo = ((lb & 1) ? w[0] : (1.0 - w[0])) * ((lb & 2) ? w[1] : (1.0 - w[1])) * ((lb & 4) ? w[2] : (1.0 - w[2]));
+        const real wlo = ((lb & 1) ? w[0] : (real(1.0) - w[0])) * ((lb & 2) ? w[1] : (real(1.0) - w[1])) * ((lb & 4) ? w[2] : (real(1.0) - w[2]));
         // tensor-product weights of dims 4..7 built as a tree (30 products instead of 80)
-        double wt[16];
-        wt[0] = wlo * (1.0 - w[3]); wt[1] = wlo * w[3];
+        real wt[16];
+        wt[0] = wlo * (real(1.0) - w[3]); wt[1] = wlo * w[3];
 #pragma unroll
-        for (int j = 3; j >= 0; j--) { wt[j] = wt[j & 1] * ((j & 2) ? w[4] : (1.0 - w[4])); }
+        for (int j = 3; j >= 0; j--) { wt[j] = wt[j & 1] * ((j & 2) ? w[4] : (real(1.0) - w[4])); }
 #pragma unroll
-        for (int j = 7; j >= 0; j--) { wt[j] = wt[j & 3] * ((j & 4) ? w[5] : (1.0 - w[5])); }
+        for (int j = 7; j >= 0; j--) { wt[j] = wt[j & 3] * ((j & 4) ? w[5] : (real(1.0) - w[5])); }
 #pragma unroll
-        for (int j = 15; j >= 0; j--) { wt[j] = wt[j & 7] * ((j & 8) ? w[6] : (1.0 - w[6])); }
+        for (int j = 15; j >= 0; j--) { wt[j] = wt[j & 7] * ((j & 8) ? w[6] : (real(1.0) - w[6])); }
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            const double wj = wt[j];
-            acc[0] += wj * (double)r[j].x; acc[1] += wj * (double)r[j].y; acc[2] += wj * (double)r[j].z; acc[3] += wj * (double)r[j].w;
+            const real wj = wt[j];
+            acc[0] += wj * (real)r[j].x; acc[1] += wj * (real)r[j].y; acc[2] += wj * (real)r[j].z; acc[3] += wj * (real)r[j].w;
         }
     }
     if (CD == 7) {
         // sum over the 8 lanes with the same channel half (same lane parity): xor 2 inside the quad, then rotations by 4 and 8 across quads
 #pragma unroll
-        for (int c = 0; c < 4; c++) { double v = acc[c]; v = dpp_add(v, 1); v = dpp_add(v, 4); v = dpp_add(v, 5); acc[c] = v; }
+        for (int c = 0; c < 4; c++) { real v = acc[c]; v = dpp_add(v, 1); v = dpp_add(v, 4); v = dpp_add(v, 5); acc[c] = v; }
         if (live && g < 8) {      // lanes 0,2,4,6 hold channels 0..3, lanes 1,3,5,7 channels 4..7: lane g stores channel g
             const int c = g >> 1;  // after the butterflies every even lane has the same sums, every odd lane too
-            double o = (c == 0) ? acc[0] : (c == 1 ? acc[1] : (c == 2 ? acc[2] : acc[3]));
+            real o = (c == 0) ? acc[0] : (c == 1 ? acc[1] : (c == 2 ? acc[2] : acc[3]));
             // channel index = 4 * (g & 1) + (g >> 1)
             int ch = 4 * (g & 1) + c;
-            if (!inb) o = (ch == 0) ? INFINITY : 0.0;
+            if (!inb) o = (ch == 0) ? INFINITY : real(0.0);
             out8[(size_t)look * 8 + ch] = o;
         }
         return;
     }
     if (inb && CD == 5) {
         // cdims = 5: lane g owns the corner bits of dims 2..5 = the 64 B chunk g (dim-1 pair) of a 1 KiB record; 4 records for dims 6,7
-        long cell = 0; double wt = 1.0;
+        long cell = 0; real wt = real(1.0);
 #pragma unroll
         for (int d = 0; d < 5; d++) cell += (long)idx[d] * Hv.cstride[d];
 #pragma unroll
-        for (int d = 1; d < 5; d++) { int bit = (g >> (d - 1)) & 1; wt *= bit ? w[d] : (1.0 - w[d]); }
+        for (int d = 1; d < 5; d++) { int bit = (g >> (d - 1)) & 1; wt *= bit ? w[d] : (real(1.0) - w[d]); }
         float4 r[4][4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
@@ -688,80 +686,80 @@ __global__ __launch_bounds__(256) void k_hji_lookup(HjiView Hv, int B, const dou
         }
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            double wc = wt * ((c & 1) ? w[5] : (1.0 - w[5])) * ((c >> 1) ? w[6] : (1.0 - w[6]));
-            double wa = wc * (1.0 - w[0]), wb = wc * w[0];
-            acc[0] += wa * (double)r[c][0].x + wb * (double)r[c][2].x; acc[1] += wa * (double)r[c][0].y + wb * (double)r[c][2].y;
-            acc[2] += wa * (double)r[c][0].z + wb * (double)r[c][2].z; acc[3] += wa * (double)r[c][0].w + wb * (double)r[c][2].w;
-            acc[4] += wa * (double)r[c][1].x + wb * (double)r[c][3].x; acc[5] += wa * (double)r[c][1].y + wb * (double)r[c][3].y;
-            acc[6] += wa * (double)r[c][1].z + wb * (double)r[c][3].z; acc[7] += wa * (double)r[c][1].w + wb * (double)r[c][3].w;
+            real wc = wt * ((c & 1) ? w[5] : (real(1.0) - w[5])) * ((c >> 1) ? w[6] : (real(1.0) - w[6]));
+            real wa = wc * (real(1.0) - w[0]), wb = wc * w[0];
+            acc[0] += wa * (real)r[c][0].x + wb * (real)r[c][2].x; acc[1] += wa * (real)r[c][0].y + wb * (real)r[c][2].y;
+            acc[2] += wa * (real)r[c][0].z + wb * (real)r[c][2].z; acc[3] += wa * (real)r[c][0].w + wb * (real)r[c][2].w;
+            acc[4] += wa * (real)r[c][1].x + wb * (real)r[c][3].x; acc[5] += wa * (real)r[c][1].y + wb * (real)r[c][3].y;
+            acc[6] += wa * (real)r[c][1].z + wb * (real)r[c][3].z; acc[7] += wa * (real)r[c][1].w + wb * (real)r[c][3].w;
         }
     }
     if (inb && CD == 3) {
         // cdims = 3: this lane's cell record: cell (idx1, idx2, idx3) at the corner of dims 4..7 selected by the lane bits
         long cell = (long)idx[0] * Hv.cstride[0] + (long)idx[1] * Hv.cstride[1] + (long)idx[2] * Hv.cstride[2];
-        double wt = 1.0;
+        real wt = real(1.0);
 #pragma unroll
-        for (int d = 3; d < 7; d++) { int bit = (g >> (d - 3)) & 1; wt *= bit ? w[d] : (1.0 - w[d]); cell += (long)(idx[d] + bit) * Hv.cstride[d]; }
+        for (int d = 3; d < 7; d++) { int bit = (g >> (d - 3)) & 1; wt *= bit ? w[d] : (real(1.0) - w[d]); cell += (long)(idx[d] + bit) * Hv.cstride[d]; }
         const float4* p = reinterpret_cast<const float4*>(Hv.cells + cell * 64);
         float4 r[16];
 #pragma unroll
         for (int c = 0; c < 16; c++) r[c] = p[c];  // 256 contiguous bytes: issue everything before the first use
 #pragma unroll
         for (int c = 0; c < 8; c++) {              // corner c of the cell: bits (b1, b2, b3)
-            double wc = wt * ((c & 1) ? w[0] : (1.0 - w[0])) * ((c & 2) ? w[1] : (1.0 - w[1])) * ((c & 4) ? w[2] : (1.0 - w[2]));
-            acc[0] += wc * (double)r[2 * c].x; acc[1] += wc * (double)r[2 * c].y; acc[2] += wc * (double)r[2 * c].z; acc[3] += wc * (double)r[2 * c].w;
-            acc[4] += wc * (double)r[2 * c + 1].x; acc[5] += wc * (double)r[2 * c + 1].y; acc[6] += wc * (double)r[2 * c + 1].z; acc[7] += wc * (double)r[2 * c + 1].w;
+            real wc = wt * ((c & 1) ? w[0] : (real(1.0) - w[0])) * ((c & 2) ? w[1] : (real(1.0) - w[1])) * ((c & 4) ? w[2] : (real(1.0) - w[2]));
+            acc[0] += wc * (real)r[2 * c].x; acc[1] += wc * (real)r[2 * c].y; acc[2] += wc * (real)r[2 * c].z; acc[3] += wc * (real)r[2 * c].w;
+            acc[4] += wc * (real)r[2 * c + 1].x; acc[5] += wc * (real)r[2 * c + 1].y; acc[6] += wc * (real)r[2 * c + 1].z; acc[7] += wc * (real)r[2 * c + 1].w;
         }
     }
     // reduction over the 16 lanes of the row (out-of-bounds groups reduce zeros)
 #pragma unroll
-    for (int c = 0; c < 8; c++) { double v = acc[c]; v = dpp_add(v, 0); v = dpp_add(v, 1); v = dpp_add(v, 2); v = dpp_add(v, 3); acc[c] = v; }
+    for (int c = 0; c < 8; c++) { real v = acc[c]; v = dpp_add(v, 0); v = dpp_add(v, 1); v = dpp_add(v, 2); v = dpp_add(v, 3); acc[c] = v; }
     if (live && g < 8) {
-        double o = acc[0];
+        real o = acc[0];
 #pragma unroll
         for (int c = 1; c < 8; c++) o = (g == c) ? acc[c] : o;
-        if (!inb) o = (g == 0) ? INFINITY : 0.0;
+        if (!inb) o = (g == 0) ? INFINITY : real(0.0);
         out8[(size_t)look * 8 + g] = o;
     }
 }
 
 // optimal_disturbance (dMode=:min) HJI_computation.jl:90-131 + compute_reachability_constraint :160-170, lane = instance
-__global__ __launch_bounds__(64) void k_hji_constraint(DevCfg C, int B, const double* __restrict__ x7, const double* __restrict__ vg8, const double* __restrict__ control,
-                                 double* __restrict__ Mb) {
+__global__ __launch_bounds__(64) void k_hji_constraint(DevCfg C, int B, const real* __restrict__ x7, const real* __restrict__ vg8, const real* __restrict__ control,
+                                 real* __restrict__ Mb) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const DevVehicle& P = C.veh;
-    const double* x = x7 + (size_t)b * 7; const double* vg = vg8 + (size_t)b * 8; const double* g = vg + 1;
-    double* o = Mb + (size_t)b * 4;
-    double Vv = vg[0];
+    const real* x = x7 + (size_t)b * 7; const real* vg = vg8 + (size_t)b * 8; const real* g = vg + 1;
+    real* o = Mb + (size_t)b * 4;
+    real Vv = vg[0];
     o[3] = Vv;
-    if (Vv > C.hji_eps) { o[0] = 0.0; o[1] = 0.0; o[2] = 1.0; return; }           // :163-164
-    double uH0, uH1;
+    if (Vv > C.hji_eps) { o[0] = real(0.0); o[1] = real(0.0); o[2] = real(1.0); return; }           // :163-164
+    real uH0, uH1;
     {
-        double Ax_max = P.Fx_max / P.m, Pmx = P.Px_max / P.m, maxA = 0.9 * P.mu * P.G;
-        double Vh = x[5], lam_Ax = g[5], lam_Ay = g[2] / Vh;
-        double nrm = (lam_Ax != lam_Ax || lam_Ay != lam_Ay) ? NAN : hypot(lam_Ax, lam_Ay);
-        if (nrm < 1e-3) { uH0 = 0.0; uH1 = 0.0; }
+        real Ax_max = P.Fx_max / P.m, Pmx = P.Px_max / P.m, maxA = real(0.9) * P.mu * P.G;
+        real Vh = x[5], lam_Ax = g[5], lam_Ay = g[2] / Vh;
+        real nrm = (lam_Ax != lam_Ax || lam_Ay != lam_Ay) ? NAN : hypot(lam_Ax, lam_Ay);
+        if (nrm < real(1e-3)) { uH0 = real(0.0); uH1 = real(0.0); }
         else {
-            double desAx = -lam_Ax * maxA / nrm, desAy = -lam_Ay * maxA / nrm;
-            double maxAx = jmin(Ax_max, Pmx / Vh), maxAy = P.kappa_max * Vh * Vh;
+            real desAx = -lam_Ax * maxA / nrm, desAy = -lam_Ay * maxA / nrm;
+            real maxAx = jmin(Ax_max, Pmx / Vh), maxAy = P.kappa_max * Vh * Vh;
             if (desAx > maxAx) {
                 if (fabs(desAy) < maxAy) maxAy = jmin(maxAy, sqrt(maxA * maxA - maxAx * maxAx));
                 uH0 = copysign(maxAy, desAy) / Vh; uH1 = maxAx;
             } else if (fabs(desAy) > maxAy) {
-                if (desAx > 0.0) { maxAx = jmin(sqrt(maxA * maxA - maxAy * maxAy), maxAx); uH0 = copysign(maxAy, desAy) / Vh; uH1 = maxAx; }
+                if (desAx > real(0.0)) { maxAx = jmin(sqrt(maxA * maxA - maxAy * maxAy), maxAx); uH0 = copysign(maxAy, desAy) / Vh; uH1 = maxAx; }
                 else { uH0 = copysign(maxAy, desAy) / Vh; uH1 = -sqrt(maxA * maxA - maxAy * maxAy); }
             } else { uH0 = desAy / Vh; uH1 = maxAx; }
         }
     }
-    const double* u = control + (size_t)b * 3;
-    double uR0 = u[0], uR1 = u[1] + u[2];
+    const real* u = control + (size_t)b * 3;
+    real uR0 = u[0], uR1 = u[1] + u[2];
     D2 dUx, dUy, dr;
-    world_body_rhs<D2>(P, x[3], x[4], x[6], D2(uR0, 1.0, 0.0), D2(uR1, 0.0, 1.0), dUx, dUy, dr);   // relative_dynamics :77
-    double s, c; pg_sincos(x[2], &s, &c);
-    double f0 = x[5] * c - x[3] + x[1] * x[6], f1 = x[5] * s - x[4] - x[0] * x[6], f2 = uH0 - x[6];
+    world_body_rhs<D2>(P, x[3], x[4], x[6], D2(uR0, real(1.0), real(0.0)), D2(uR1, real(0.0), real(1.0)), dUx, dUy, dr);   // relative_dynamics :77
+    real s, c; pg_sincos(x[2], &s, &c);
+    real f0 = x[5] * c - x[3] + x[1] * x[6], f1 = x[5] * s - x[4] - x[0] * x[6], f2 = uH0 - x[6];
     D2 Hm = g[3] * dUx + g[4] * dUy + g[6] * dr + (g[0] * f0 + g[1] * f1 + g[2] * f2 + g[5] * uH1);
-    double M0 = Hm.a, M1 = Hm.b;
+    real M0 = Hm.a, M1 = Hm.b;
     o[0] = M0 * C.un0; o[1] = M1 * C.un1;                                          // coupled_lat_long.jl:345
     o[2] = Hm.v - (M0 * uR0 + M1 * uR1);                                           // :168
 }
@@ -769,36 +767,36 @@ __global__ __launch_bounds__(64) void k_hji_constraint(DevCfg C, int B, const do
 // optimal_control (uMode=:max, N=50) HJI_computation.jl:133-158 and the control selection of the ROS loop (ros_integration.jl:114-124), lane = instance.
 // u2 [B][2] = (delta_opt, Fx_opt) whenever the relative state is inside the grid; u_next [B][3] = the policy's BicycleControl when it takes over
 // (traj mode, use_policy, V <= eps), else the MPC control u_mpc; source: 0 MPC, 1 HJI policy, 2 V <= eps but the policy is switched off.
-__global__ __launch_bounds__(64) void k_hji_policy(DevCfg C, int B, int use_policy, const double* __restrict__ x7, const double* __restrict__ vg8, const tdouble* __restrict__ toff,
-                                                   const double* __restrict__ u_mpc, double* __restrict__ u2, double* __restrict__ u_next, int* __restrict__ source) {
+__global__ __launch_bounds__(64) void k_hji_policy(DevCfg C, int B, int use_policy, const real* __restrict__ x7, const real* __restrict__ vg8, const tdouble* __restrict__ toff,
+                                                   const real* __restrict__ u_mpc, real* __restrict__ u2, real* __restrict__ u_next, int* __restrict__ source) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const DevVehicle& P = C.veh;
-    const double* x = x7 + (size_t)b * 7; const double* vg = vg8 + (size_t)b * 8; const double* g = vg + 1;
-    const double Ux = x[3], Uy = x[4], r = x[6];
-    const double A = g[3] / P.m, Bc = g[4] / P.m + P.a * g[6] / P.Izz, Cc = g[4] / P.m - P.b * g[6] / P.Izz;      // :140-142
-    const double d_opt = Bc >= 0.0 ? P.delta_max : -P.delta_max;                                                   // :143
-    double sd, cd; pg_sincos(d_opt, &sd, &cd);
-    const double tf = (Uy + P.a * r) / Ux, td = sd / cd;
-    const double taf = (tf - td) / (1.0 + tf * td), tar = (Uy - P.b * r) / Ux;       // slip-angle tangents (vehicle_dynamics.jl:84-85), Ux > 0
-    double V_opt = -INFINITY, Fx_opt = 0.0;
+    const real* x = x7 + (size_t)b * 7; const real* vg = vg8 + (size_t)b * 8; const real* g = vg + 1;
+    const real Ux = x[3], Uy = x[4], r = x[6];
+    const real A = g[3] / P.m, Bc = g[4] / P.m + P.a * g[6] / P.Izz, Cc = g[4] / P.m - P.b * g[6] / P.Izz;      // :140-142
+    const real d_opt = Bc >= real(0.0) ? P.delta_max : -P.delta_max;                                                   // :143
+    real sd, cd; pg_sincos(d_opt, &sd, &cd);
+    const real tf = (Uy + P.a * r) / Ux, td = sd / cd;
+    const real taf = (tf - td) / (real(1.0) + tf * td), tar = (Uy - P.b * r) / Ux;       // slip-angle tangents (vehicle_dynamics.jl:84-85), Ux > 0
+    real V_opt = -INFINITY, Fx_opt = real(0.0);
 #pragma unroll 1
     for (int n = 0; n < 50; n++) {
-        double frac = (double)n / 49.0;
-        double Fx = frac * P.Fx_max + (1.0 - frac) * P.Fx_min;
-        double Fxf = Fx > 0.0 ? Fx * P.fwd_frac : Fx * P.fwb_frac, Fxr = Fx > 0.0 ? Fx * P.rwd_frac : Fx * P.rwb_frac;       // longitudinal_tire_forces, no limits (:148)
-        double Fyf, Fyr;
-        lateral_forces<double>(P, taf, tar, Fxf, Fxr, sd, cd, Fyf, Fyr);
-        double V = A * Fx + Bc * Fyf + Cc * Fyr;
+        real frac = (real)n / real(49.0);
+        real Fx = frac * P.Fx_max + (real(1.0) - frac) * P.Fx_min;
+        real Fxf = Fx > real(0.0) ? Fx * P.fwd_frac : Fx * P.fwb_frac, Fxr = Fx > real(0.0) ? Fx * P.rwd_frac : Fx * P.rwb_frac;       // longitudinal_tire_forces, no limits (:148)
+        real Fyf, Fyr;
+        lateral_forces<real>(P, taf, tar, Fxf, Fxr, sd, cd, Fyf, Fyr);
+        real V = A * Fx + Bc * Fyf + Cc * Fyr;
         if (V > V_opt) { Fx_opt = Fx; V_opt = V; }
     }
     u2[(size_t)b * 2] = d_opt; u2[(size_t)b * 2 + 1] = Fx_opt;
     const bool traj_mode = toff[b] == toff[b];
     const bool unsafe = traj_mode && vg[0] <= C.hji_eps;
     int src = unsafe ? (use_policy ? 1 : 2) : 0;
-    double o0 = u_mpc[(size_t)b * 3], o1 = u_mpc[(size_t)b * 3 + 1], o2 = u_mpc[(size_t)b * 3 + 2];
+    real o0 = u_mpc[(size_t)b * 3], o1 = u_mpc[(size_t)b * 3 + 1], o2 = u_mpc[(size_t)b * 3 + 2];
     if (src == 1) {                  // BicycleControl(longitudinal_params, BicycleControl2(delta_opt, Fx_opt))  (vehicle_dynamics.jl:284)
-        o0 = d_opt; o1 = Fx_opt > 0.0 ? Fx_opt * P.fwd_frac : Fx_opt * P.fwb_frac; o2 = Fx_opt > 0.0 ? Fx_opt * P.rwd_frac : Fx_opt * P.rwb_frac;
+        o0 = d_opt; o1 = Fx_opt > real(0.0) ? Fx_opt * P.fwd_frac : Fx_opt * P.fwb_frac; o2 = Fx_opt > real(0.0) ? Fx_opt * P.rwd_frac : Fx_opt * P.rwb_frac;
     }
     u_next[(size_t)b * 3] = o0; u_next[(size_t)b * 3 + 1] = o1; u_next[(size_t)b * 3 + 2] = o2;
     source[b] = src;
@@ -810,31 +808,30 @@ __global__ __launch_bounds__(64) void k_hji_policy(DevCfg C, int B, int use_poli
 //   0: Ux >= V_min   1: Ux <= V_max   2: Fx >= Fx_min   3: delta <= dmax   4: delta >= dmin   5: Fx <= fxmax
 //   6..9: H_i [Uy;r] - sigma_{i/2} <= G_i     10: sigma1 >= 0   11: sigma2 >= 0    12: d_delta <= ddmax   13: d_delta >= ddmin
 //   14: M u + b + sigma_HJI >= 0              15: sigma_HJI >= 0        (14,15 only for nodes 1 .. min(N_HJI,Ns)-1)
-struct SolveOut { double* sol_x; double* sol_sigma; double* u_out; int* status; int* iters; uint16_t* active; double* mu; int* solved; };
+struct SolveOut { real* sol_x; real* sol_sigma; real* u_out; int* status; int* iters; uint16_t* active; real* mu; int* solved; };
 
 #define NROW 16
 
 struct StageRows {
-    double t[NROW], lam[NROW], corr[NROW];
+    real t[NROW], lam[NROW], corr[NROW];
 };
 
-PG_DEV double wave_min(double v) {
+PG_DEV real wave_min(real v) {
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) { double o = __shfl_xor(v, s); v = o < v ? o : v; }
+    for (int s = 32; s >= 1; s >>= 1) { real o = __shfl_xor(v, s); v = o < v ? o : v; }
     return v;
 }
-PG_DEV double wave_max(double v) {
+PG_DEV real wave_max(real v) {
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) { double o = __shfl_xor(v, s); v = o > v ? o : v; }
+    for (int s = 32; s >= 1; s >>= 1) { real o = __shfl_xor(v, s); v = o > v ? o : v; }
     return v;
 }
-PG_DEV double wave_sum(double v) {
+PG_DEV real wave_sum(real v) {
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
     return v;
 }
 
-// PG_KEEP_BEGIN
 // broadcast of lane `src` (compile-time constant) to the whole wave through SGPRs: no LDS, no barrier
 PG_DEV real rl(real v, int src) {
 #ifdef PG_F32
@@ -853,7 +850,6 @@ PG_DEV real rl(real v, int src) {
 #else
 #define PG_SOLVE_WAVES(RING) ((RING) ? 2 : 1)
 #endif
-// PG_KEEP_END
 
 // Ordering point between an LDS write and the LDS reads of OTHER lanes of the same wavefront.  k_solve's workgroup is one wave and the LDS pipeline
 // executes the DS instructions of a wave in order, so no s_barrier and no s_waitcnt lgkmcnt(0) are needed: the compiler only has to keep the order
@@ -865,81 +861,81 @@ PG_DEV void wave_sync() {
 }
 
 template <bool PROF, bool RING>
-__global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, int B, const double* __restrict__ qp, const double* __restrict__ abar, const double* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof) {
+__global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, int B, const real* __restrict__ qp, const real* __restrict__ abar, const real* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof) {
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int slot) { if (PROF) { unsigned long long now = clock64(); pc[slot] += now - tprev; tprev = now; } };
     if (PROF) tprev = clock64();
     const int b = blockIdx.x, lane = threadIdx.x;
     const int N = C.N, NN = C.NN;
-    extern __shared__ double lds[];
+    extern __shared__ real lds[];
     // The dynamics blocks are NOT resident: each pass streams them stage by stage from L2 through a 4-slot LDS ring
     // (slot = SB doubles: rows 0..5 of Abar_k = [A | B0+Bf] at row stride 9, rows 0..5 of Bbar_k = Bf (12), cbar_k = c (6)); rows 6,7 are [0 I] / I / 0.
-    double* sRing = lds;                 // RING: [4][SB] slots; otherwise all N stage blocks resident: [N][SB]
-    double* sQ = sRing + (RING ? 4 : N) * SB;         // [NN][10]: diagonal[8] (with (Uy,Uy),(r,r) at 2,3), (Uy,r) off-diagonal, (delta,Fx) off-diagonal
-    double* sq = sQ + 10 * NN;           // [NN][8]
-    double* sR = sq + 8 * NN;            // [N][2]   diagonal of Rhat
-    double* sr = sR + 2 * N;             // [N][2]
-    double* sK = sr + 2 * N;             // [N][2][8]
-    double* sSi = sK + 16 * N;           // [N][4]   (Sinv00, Sinv01, Sinv11, -)
-    double* sMc = sSi + 4 * N;           // [N][8]   P_{k+1} cbar_k
-    double* skf = sMc + 8 * N;           // [N][2]
-    double* sx = skf + 2 * N;            // [NN][8]  Newton point
-    double* sv = sx + 8 * NN;            // [N][2]
-    double* sP = sv + 2 * N;             // [8][9]   (row stride 9: conflict-free row reads)
-    double* sMT = sP + 72;               // [11][9]  (P [Abar | Bbar | cbar]) stored column-major, column stride 9
-    double* sx0 = sMT + 99 + 1;              // [8]
-    double* sDum = sx0 + 8;              // [64] sink for predicated-off stores (keeps the pass loops branch-free)
-    double* sZero = sDum + 64;           // [2]  a stored 0.0 (off-pattern entries of Qhat)
+    real* sRing = lds;                 // RING: [4][SB] slots; otherwise all N stage blocks resident: [N][SB]
+    real* sQ = sRing + (RING ? 4 : N) * SB;         // [NN][10]: diagonal[8] (with (Uy,Uy),(r,r) at 2,3), (Uy,r) off-diagonal, (delta,Fx) off-diagonal
+    real* sq = sQ + 10 * NN;           // [NN][8]
+    real* sR = sq + 8 * NN;            // [N][2]   diagonal of Rhat
+    real* sr = sR + 2 * N;             // [N][2]
+    real* sK = sr + 2 * N;             // [N][2][8]
+    real* sSi = sK + 16 * N;           // [N][4]   (Sinv00, Sinv01, Sinv11, -)
+    real* sMc = sSi + 4 * N;           // [N][8]   P_{k+1} cbar_k
+    real* skf = sMc + 8 * N;           // [N][2]
+    real* sx = skf + 2 * N;            // [NN][8]  Newton point
+    real* sv = sx + 8 * NN;            // [N][2]
+    real* sP = sv + 2 * N;             // [8][9]   (row stride 9: conflict-free row reads)
+    real* sMT = sP + 72;               // [11][9]  (P [Abar | Bbar | cbar]) stored column-major, column stride 9
+    real* sx0 = sMT + 99 + 1;              // [8]
+    real* sDum = sx0 + 8;              // [64] sink for predicated-off stores (keeps the pass loops branch-free)
+    real* sZero = sDum + 64;           // [2]  a stored 0.0 (off-pattern entries of Qhat)
 
     const QpOff o = qp_offsets(N);
-    const double* Q = qp + (size_t)b * C.qp_len;
+    const real* Q = qp + (size_t)b * C.qp_len;
     // ---- LDS ring fed from L2: lane l < 36 moves 16 bytes of the 576-byte stage block; two-deep software pipeline (register, then LDS) ----
-    const double2* gA = reinterpret_cast<const double2*>(abar + (size_t)b * N * SB);
+    const real2* gA = reinterpret_cast<const real2*>(abar + (size_t)b * N * SB);
     const int rlane = lane < SB_CHUNKS ? lane : 0;
-    double2 ring_pre;
-    auto ring_slot = [&](int k) -> double* { return sRing + (RING ? (k & 3) : k) * SB; };
+    real2 ring_pre;
+    auto ring_slot = [&](int k) -> real* { return sRing + (RING ? (k & 3) : k) * SB; };
     auto ring_load = [&](int k) { int kk = k < 0 ? 0 : (k >= N ? N - 1 : k); ring_pre = gA[kk * SB_CHUNKS + rlane]; };
-    auto ring_put = [&](int k) { double2* dst = lane < SB_CHUNKS ? reinterpret_cast<double2*>(ring_slot(k)) + lane : reinterpret_cast<double2*>(sDum) + (lane & 31); *dst = ring_pre; };
+    auto ring_put = [&](int k) { real2* dst = lane < SB_CHUNKS ? reinterpret_cast<real2*>(ring_slot(k)) + lane : reinterpret_cast<real2*>(sDum) + (lane & 31); *dst = ring_pre; };
     // prime(k0, dir): block k0 lands in the ring, block k0+dir is in flight.  step(k, dir) at the top of stage k: block k+dir lands, k+2dir takes off.
     auto ring_prime = [&](int k0, int dir) { if (RING) { ring_load(k0); ring_put(k0); ring_load(k0 + dir); } };
     auto ring_step = [&](int k, int dir) { if (RING) { ring_put(k + dir); ring_load(k + 2 * dir); } };
     if (!RING) {      // short horizons: every stage block is read from HBM exactly once and stays in LDS (SB N doubles = 17.3 KB at N = 30)
-        for (int i = lane; i < SB_CHUNKS * N; i += 64) reinterpret_cast<double2*>(sRing)[i] = gA[i];
+        for (int i = lane; i < SB_CHUNKS * N; i += 64) reinterpret_cast<real2*>(sRing)[i] = gA[i];
     }
-    if (lane < 2) sZero[lane] = 0.0;
+    if (lane < 2) sZero[lane] = real(0.0);
     if (lane < 8) sx0[lane] = lane < 6 ? Q[o.qcurr + lane] : Q[o.ucurr + lane - 6];
 
     // ---- per-stage constants in the registers of lane s (stage s = transition s, node s+1) ----
     const bool act = lane < N;
     const int s = act ? lane : 0;
-    double h0[4], h1[4], bb[NROW];
-    const double M0 = Q[o.M], M1 = Q[o.M + 1];
+    real h0[4], h1[4], bb[NROW];
+    const real M0 = Q[o.M], M1 = Q[o.M + 1];
     const bool hji_on = act && (s + 1 < (C.cp.N_HJI < C.Ns ? C.cp.N_HJI : C.Ns));
     // wall extension (lateral formulation): rows 0, 1, 2 -- bounds on the INERT Ux / Fx slots of the embedding there -- carry  e <= edge_L + sw,  e >= edge_R - sw,
     // sw >= 0, and sw takes the slot of the (absent) safety-row slack: the third stage-locally eliminated slack group
     const bool wall_on = act && C.walls != 0;
-    const double dts = Q[o.dt + s];
-    const double Rd0 = 2.0 * C.cp.R_ddelta / dts, Rd1 = 2.0 * C.cp.R_dFx / dts;
-    const double wb = C.cp.W_beta * dts, wr = C.cp.W_r * dts, wh = C.cp.W_HJI;
+    const real dts = Q[o.dt + s];
+    const real Rd0 = real(2.0) * C.cp.R_ddelta / dts, Rd1 = real(2.0) * C.cp.R_dFx / dts;
+    const real wb = C.cp.W_beta * dts, wr = C.cp.W_r * dts, wh = C.cp.W_HJI;
 #pragma unroll
     for (int i = 0; i < 4; i++) { h0[i] = Q[o.H + 8 * s + 2 * i]; h1[i] = Q[o.H + 8 * s + 2 * i + 1]; bb[6 + i] = Q[o.G + 4 * s + i]; }
     bb[0] = -C.cp.V_min; bb[1] = C.cp.V_max; bb[2] = -C.fxmin_n; bb[3] = Q[o.dmax + s]; bb[4] = -Q[o.dmin + s]; bb[5] = Q[o.fxmax + s];
-    bb[10] = 0.0; bb[11] = 0.0; bb[12] = Q[o.ddmax + s]; bb[13] = -Q[o.ddmin + s]; bb[14] = Q[o.b]; bb[15] = 0.0;
-    if (wall_on) { const double* w = C.wall_edges + ((size_t)b * N + s) * 2; bb[0] = w[0]; bb[1] = -w[1]; bb[2] = 0.0; }
-    const double ww = C.wall_weight * dts;
-    const double Qd5 = 2.0 * C.cp.Q_e * dts;
+    bb[10] = real(0.0); bb[11] = real(0.0); bb[12] = Q[o.ddmax + s]; bb[13] = -Q[o.ddmin + s]; bb[14] = Q[o.b]; bb[15] = real(0.0);
+    if (wall_on) { const real* w = C.wall_edges + ((size_t)b * N + s) * 2; bb[0] = w[0]; bb[1] = -w[1]; bb[2] = real(0.0); }
+    const real ww = C.wall_weight * dts;
+    const real Qd5 = real(2.0) * C.cp.Q_e * dts;
     if (act) {   // entries of the stage cost that never change
-        double* Qo = sQ + 10 * (s + 1);
-        Qo[0] = 2.0 * C.cp.Q_ds * dts; Qo[4] = 2.0 * C.cp.Q_dpsi * dts; Qo[5] = 2.0 * C.cp.Q_e * dts;
-        double* qo = sq + 8 * (s + 1);
-        qo[0] = 0.0; qo[4] = 0.0; qo[5] = 0.0;
-        sR[2 * s + 1] = Rd1; sr[2 * s + 1] = 0.0;
+        real* Qo = sQ + 10 * (s + 1);
+        Qo[0] = real(2.0) * C.cp.Q_ds * dts; Qo[4] = real(2.0) * C.cp.Q_dpsi * dts; Qo[5] = real(2.0) * C.cp.Q_e * dts;
+        real* qo = sq + 8 * (s + 1);
+        qo[0] = real(0.0); qo[4] = real(0.0); qo[5] = real(0.0);
+        sR[2 * s + 1] = Rd1; sr[2 * s + 1] = real(0.0);
     }
-    const double Qd6 = 2.0 * C.cp.R_delta * dts, Qd7 = 2.0 * C.cp.R_Fx * dts;
+    const real Qd6 = real(2.0) * C.cp.R_delta * dts, Qd7 = real(2.0) * C.cp.R_Fx * dts;
     __syncthreads();
 
     // slack of every row at the point w = (x[8], v0, s1, s2, sh)
-    auto slacks = [&](const double* x, double v0, double s1, double s2, double sh, double* out) {
+    auto slacks = [&](const real* x, real v0, real s1, real s2, real sh, real* out) {
         out[0] = wall_on ? bb[0] - x[5] + sh : x[1] + bb[0]; out[1] = wall_on ? bb[1] + x[5] + sh : bb[1] - x[1]; out[2] = wall_on ? sh : x[7] + bb[2];
         out[3] = bb[3] - x[6]; out[4] = x[6] + bb[4]; out[5] = bb[5] - x[7];
 #pragma unroll
@@ -954,34 +950,34 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     // The loop body is one basic block (predicated stores go to a dummy slot) so that all LDS reads of a stage issue back to back.
     auto forward = [&](auto use_gain_t) {
         constexpr bool use_gain = decltype(use_gain_t)::value;
-        double xi = sx0[r8];
+        real xi = sx0[r8];
         *(lane < 8 ? sx + lane : sDum + lane) = xi;
         ring_prime(0, +1);
         const int rr = r8 < 6 ? r8 : 5;
-        const double w_lo = r8 < 6 ? 1.0 : 0.0, w_6 = r8 == 6 ? 1.0 : 0.0, w_7 = r8 == 7 ? 1.0 : 0.0;
+        const real w_lo = r8 < 6 ? real(1.0) : real(0.0), w_6 = r8 == 6 ? real(1.0) : real(0.0), w_7 = r8 == 7 ? real(1.0) : real(0.0);
 #pragma unroll 1
         for (int k = 0; k < N; k++) {
             ring_step(k, +1);
-            const double* Rk = ring_slot(k);
-            const double* Kk = sK + 16 * k; const double* Ar = Rk + SB_ROW * rr;
-            double K0[8], K1[8], A8[8];
+            const real* Rk = ring_slot(k);
+            const real* Kk = sK + 16 * k; const real* Ar = Rk + SB_ROW * rr;
+            real K0[8], K1[8], A8[8];
 #pragma unroll
-            for (int m = 0; m < 8; m++) { A8[m] = Ar[m]; K0[m] = use_gain ? Kk[m] : 0.0; K1[m] = use_gain ? Kk[8 + m] : 0.0; }
-            double kf0 = use_gain ? skf[2 * k] : 0.0, kf1 = use_gain ? skf[2 * k + 1] : 0.0;
-            double cr = Rk[SB_C + rr], bf0 = Rk[SB_B + 2 * rr], bf1 = Rk[SB_B + 2 * rr + 1];
-            double xm[8];
+            for (int m = 0; m < 8; m++) { A8[m] = Ar[m]; K0[m] = use_gain ? Kk[m] : real(0.0); K1[m] = use_gain ? Kk[8 + m] : real(0.0); }
+            real kf0 = use_gain ? skf[2 * k] : real(0.0), kf1 = use_gain ? skf[2 * k + 1] : real(0.0);
+            real cr = Rk[SB_C + rr], bf0 = Rk[SB_B + 2 * rr], bf1 = Rk[SB_B + 2 * rr + 1];
+            real xm[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) xm[m] = rl(xi, m);
-            double a0 = kf0, a1 = 0.0, b0 = kf1, b1 = 0.0, e0 = cr, e1 = 0.0;
+            real a0 = kf0, a1 = real(0.0), b0 = kf1, b1 = real(0.0), e0 = cr, e1 = real(0.0);
 #pragma unroll
             for (int m = 0; m < 8; m += 2) {
                 a0 += K0[m] * xm[m]; a1 += K0[m + 1] * xm[m + 1]; b0 += K1[m] * xm[m]; b1 += K1[m + 1] * xm[m + 1];
                 e0 += A8[m] * xm[m]; e1 += A8[m + 1] * xm[m + 1];
             }
-            double v0 = a0 + a1, v1 = b0 + b1;
-            double xr = (e0 + e1) + (bf0 * v0 + bf1 * v1);
+            real v0 = a0 + a1, v1 = b0 + b1;
+            real xr = (e0 + e1) + (bf0 * v0 + bf1 * v1);
             // arithmetic blend instead of ?: so that the compiler keeps the LDS reads above unconditional (a branch here serialises them)
-            double xn = w_lo * xr + w_6 * (xm[6] + v0) + w_7 * (xm[7] + v1);
+            real xn = w_lo * xr + w_6 * (xm[6] + v0) + w_7 * (xm[7] + v1);
             xi = xn;
             *(lane < 8 ? sx + 8 * (k + 1) + lane : sDum + lane) = xn;
             *(lane < 2 ? sv + 2 * k + lane : sDum + lane) = lane == 0 ? v0 : v1;
@@ -991,49 +987,49 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
 
     StageRows R;
     // the damped iterate (x_{s+1}, sigma) of this stage is kept in the output buffers (read-modify-write once per iteration), not in registers
-    double* const SXs = O.sol_x + (size_t)b * NN * 8 + 8 * (s + 1);
-    double* const SGs = O.sol_sigma + ((size_t)b * N + s) * 3;
-    double rp0 = 0.0;
-    const double ntot = wave_sum(act ? (double)nrows : 0.0);
-    double phi = 1.0, mu = 0.0;
+    real* const SXs = O.sol_x + (size_t)b * NN * 8 + 8 * (s + 1);
+    real* const SGs = O.sol_sigma + ((size_t)b * N + s) * 3;
+    real rp0 = real(0.0);
+    const real ntot = wave_sum(act ? (real)nrows : real(0.0));
+    real phi = real(1.0), mu = real(0.0);
     int it = 0, status = PG_MAX_ITER;
 
-    double e_d1, e_c10, e_c11, e_g1, e_d2, e_c20, e_c21, e_g2, e_dh, e_ch0, e_ch1, e_gh;   // e_d* hold RECIPROCALS of the slack pivots
-    double it_[NROW];                    // 1 / t_j, refreshed once per interior-point iteration
-    auto assemble = [&](double sigmu, bool matrices) {
-        double W[NROW], ell[NROW];
+    real e_d1, e_c10, e_c11, e_g1, e_d2, e_c20, e_c21, e_g2, e_dh, e_ch0, e_ch1, e_gh;   // e_d* hold RECIPROCALS of the slack pivots
+    real it_[NROW];                    // 1 / t_j, refreshed once per interior-point iteration
+    auto assemble = [&](real sigmu, bool matrices) {
+        real W[NROW], ell[NROW];
 #pragma unroll
         for (int j = 0; j < NROW; j++) {
             bool on = j < nrows;
-            W[j] = on ? R.lam[j] * it_[j] : 0.0;
-            ell[j] = on ? (sigmu - R.corr[j]) * it_[j] + R.lam[j] - W[j] * bb[j] : 0.0;
+            W[j] = on ? R.lam[j] * it_[j] : real(0.0);
+            ell[j] = on ? (sigmu - R.corr[j]) * it_[j] + R.lam[j] - W[j] * bb[j] : real(0.0);
         }
-        double g1 = wall_on ? 0.0 : -ell[0] + ell[1], g7 = (wall_on ? 0.0 : -ell[2]) + ell[5] - M1 * ell[14], g6 = ell[3] - ell[4] - M0 * ell[14];
-        double g2 = 0.0, g3 = 0.0;
+        real g1 = wall_on ? real(0.0) : -ell[0] + ell[1], g7 = (wall_on ? real(0.0) : -ell[2]) + ell[5] - M1 * ell[14], g6 = ell[3] - ell[4] - M0 * ell[14];
+        real g2 = real(0.0), g3 = real(0.0);
 #pragma unroll
         for (int i = 0; i < 4; i++) { g2 += h0[i] * ell[6 + i]; g3 += h1[i] * ell[6 + i]; }
         e_g1 = wb - ell[6] - ell[7] - ell[10]; e_g2 = wr - ell[8] - ell[9] - ell[11]; e_gh = wall_on ? ww - ell[0] - ell[1] - ell[2] : wh - ell[14] - ell[15];
-        double gv0 = ell[12] - ell[13];
-        e_d1 = frcp(W[6] + W[7] + W[10]); e_d2 = frcp(W[8] + W[9] + W[11]); e_dh = wall_on ? frcp(W[0] + W[1] + W[2]) : (hji_on ? frcp(W[14] + W[15]) : 1.0);
+        real gv0 = ell[12] - ell[13];
+        e_d1 = frcp(W[6] + W[7] + W[10]); e_d2 = frcp(W[8] + W[9] + W[11]); e_dh = wall_on ? frcp(W[0] + W[1] + W[2]) : (hji_on ? frcp(W[14] + W[15]) : real(1.0));
         e_c10 = -(W[6] * h0[0] + W[7] * h0[1]); e_c11 = -(W[6] * h1[0] + W[7] * h1[1]);
         e_c20 = -(W[8] * h0[2] + W[9] * h0[3]); e_c21 = -(W[8] * h1[2] + W[9] * h1[3]);
-        e_ch0 = wall_on ? -(W[0] - W[1]) : W[14] * M0; e_ch1 = wall_on ? 0.0 : W[14] * M1;      // wall rows: t = b -/+ e + sw, i.e. the envelope-row pattern with h = +1, -1 on e
-        if (!hji_on && !wall_on) e_gh = 0.0;
+        e_ch0 = wall_on ? -(W[0] - W[1]) : W[14] * M0; e_ch1 = wall_on ? real(0.0) : W[14] * M1;      // wall rows: t = b -/+ e + sw, i.e. the envelope-row pattern with h = +1, -1 on e
+        if (!hji_on && !wall_on) e_gh = real(0.0);
         if (act) {
-            double* qo = sq + 8 * (s + 1);
+            real* qo = sq + 8 * (s + 1);
             qo[1] = g1;
             qo[2] = g2 - e_c10 * e_g1 * e_d1 - e_c20 * e_g2 * e_d2;
             qo[3] = g3 - e_c11 * e_g1 * e_d1 - e_c21 * e_g2 * e_d2;
-            qo[6] = g6 - (wall_on ? 0.0 : e_ch0 * e_gh * e_dh); qo[7] = g7 - e_ch1 * e_gh * e_dh;
+            qo[6] = g6 - (wall_on ? real(0.0) : e_ch0 * e_gh * e_dh); qo[7] = g7 - e_ch1 * e_gh * e_dh;
             if (wall_on) qo[5] = (ell[0] - ell[1]) - e_ch0 * e_gh * e_dh;
             sr[2 * s] = gv0;
             if (matrices) {
-                double* Qo = sQ + 10 * (s + 1);
+                real* Qo = sQ + 10 * (s + 1);
                 if (wall_on) Qo[5] = Qd5 + W[0] + W[1] - e_ch0 * e_ch0 * e_dh;
-                Qo[1] = wall_on ? 0.0 : W[0] + W[1];
-                Qo[6] = Qd6 + W[3] + W[4] + M0 * M0 * W[14] - (wall_on ? 0.0 : e_ch0 * e_ch0 * e_dh);
-                Qo[7] = Qd7 + (wall_on ? 0.0 : W[2]) + W[5] + M1 * M1 * W[14] - e_ch1 * e_ch1 * e_dh;
-                double yy = 0.0, yr = 0.0, rr = 0.0;
+                Qo[1] = wall_on ? real(0.0) : W[0] + W[1];
+                Qo[6] = Qd6 + W[3] + W[4] + M0 * M0 * W[14] - (wall_on ? real(0.0) : e_ch0 * e_ch0 * e_dh);
+                Qo[7] = Qd7 + (wall_on ? real(0.0) : W[2]) + W[5] + M1 * M1 * W[14] - e_ch1 * e_ch1 * e_dh;
+                real yy = real(0.0), yr = real(0.0), rr = real(0.0);
 #pragma unroll
                 for (int i = 0; i < 4; i++) { yy += W[6 + i] * h0[i] * h0[i]; yr += W[6 + i] * h0[i] * h1[i]; rr += W[6 + i] * h1[i] * h1[i]; }
                 Qo[2] = yy - e_c10 * e_c10 * e_d1 - e_c20 * e_c20 * e_d2;
@@ -1047,35 +1043,35 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     const int li = lane >> 3, lj = lane & 7;
     // slot of Qhat[li][lj] inside the packed 10-double node record; off-pattern entries read a stored zero (qmul = 0 kills the node stride)
     const int qidx = (li == lj) ? li : (((li == 2 && lj == 3) || (li == 3 && lj == 2)) ? 8 : (((li == 6 && lj == 7) || (li == 7 && lj == 6)) ? 9 : -1));
-    const double* qbase = qidx >= 0 ? sQ + qidx : sZero;
+    const real* qbase = qidx >= 0 ? sQ + qidx : sZero;
     const int qmul = qidx >= 0 ? 10 : 0;
 
     // Riccati matrix pass (once per IPM iteration): lane (li, lj) owns P[li][lj]; two LDS round trips per stage, branch-free body
     auto riccati_matrices = [&]() {
-        double Pij = qbase[qmul * N];
-        double pvec = sq[8 * N + r8];                  // predictor's backward vector recursion rides along (same stage order)
+        real Pij = qbase[qmul * N];
+        real pvec = sq[8 * N + r8];                  // predictor's backward vector recursion rides along (same stage order)
         const int ljb = lj < 2 ? lj : 0;
         ring_prime(N - 1, -1);
 #pragma unroll 1
         for (int k = N - 1; k >= 0; k--) {
             ring_step(k, -1);
-            const double* Ak = ring_slot(k); const double* Bk = Ak + SB_B; const double* ck = Ak + SB_C;
+            const real* Ak = ring_slot(k); const real* Bk = Ak + SB_B; const real* ck = Ak + SB_C;
             sP[9 * li + lj] = Pij;
             // stage constants (independent of the recursion): issue their reads before the barrier
-            double acol[6], arow[6], aug6[6], bk0[6], bk1[6];
+            real acol[6], arow[6], aug6[6], bk0[6], bk1[6];
 #pragma unroll
             for (int m = 0; m < 6; m++) { acol[m] = Ak[SB_ROW * m + lj]; arow[m] = Ak[SB_ROW * m + li]; aug6[m] = lj == 2 ? ck[m] : Bk[2 * m + ljb]; bk0[m] = Bk[2 * m]; bk1[m] = Bk[2 * m + 1]; }
-            double qh = qbase[qmul * k], R0 = sR[2 * k], R1 = sR[2 * k + 1];
-            double a6v[6];
+            real qh = qbase[qmul * k], R0 = sR[2 * k], R1 = sR[2 * k + 1];
+            real a6v[6];
 #pragma unroll
             for (int m = 0; m < 6; m++) a6v[m] = Ak[SB_ROW * m + r8];
-            double qkv = sq[8 * k + r8], r0v = sr[2 * k], r1v = sr[2 * k + 1];
+            real qkv = sq[8 * k + r8], r0v = sr[2 * k], r1v = sr[2 * k + 1];
             wave_sync();
-            double prow[8];
+            real prow[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) prow[m] = sP[9 * li + m];
-            double ma = lj == 6 ? prow[6] : (lj == 7 ? prow[7] : 0.0);
-            double aug = lj == 0 ? prow[6] : (lj == 1 ? prow[7] : 0.0);
+            real ma = lj == 6 ? prow[6] : (lj == 7 ? prow[7] : real(0.0));
+            real aug = lj == 0 ? prow[6] : (lj == 1 ? prow[7] : real(0.0));
 #pragma unroll
             for (int m = 0; m < 6; m++) { ma += prow[m] * acol[m]; aug += prow[m] * aug6[m]; }
             sMT[9 * lj + li] = ma;
@@ -1083,34 +1079,34 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             *(lj == 2 ? sMc + 8 * k + li : sDum + lane) = aug;
             // S = Rhat + Bbar' (P Bbar): the two columns of P Bbar sit in the `aug` registers of lanes (m, 0) and (m, 1); broadcasting them through SGPRs
             // keeps 16 wave-uniform doubles out of LDS and takes the 2x2 solve off the path that waits for the exchange below
-            double S00 = R0 + rl(aug, 48), S01 = rl(aug, 49), S11 = R1 + rl(aug, 57);
+            real S00 = R0 + rl(aug, 48), S01 = rl(aug, 49), S11 = R1 + rl(aug, 57);
 #pragma unroll
-            for (int m = 0; m < 6; m++) { const double m0 = rl(aug, 8 * m), m1 = rl(aug, 8 * m + 1); S00 += bk0[m] * m0; S01 += bk0[m] * m1; S11 += bk1[m] * m1; }
-            const double idet = frcp(S00 * S11 - S01 * S01);
+            for (int m = 0; m < 6; m++) { const real m0 = rl(aug, 8 * m), m1 = rl(aug, 8 * m + 1); S00 += bk0[m] * m0; S01 += bk0[m] * m1; S11 += bk1[m] * m1; }
+            const real idet = frcp(S00 * S11 - S01 * S01);
             wave_sync();
-            double cj[8], ci[8];
+            real cj[8], ci[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) { cj[m] = sMT[9 * lj + m]; ci[m] = sMT[9 * li + m]; }
-            double Fj0 = cj[6], Fj1 = cj[7], Fi0 = ci[6], Fi1 = ci[7];
+            real Fj0 = cj[6], Fj1 = cj[7], Fi0 = ci[6], Fi1 = ci[7];
 #pragma unroll
             for (int m = 0; m < 6; m++) { Fj0 += bk0[m] * cj[m]; Fj1 += bk1[m] * cj[m]; Fi0 += bk0[m] * ci[m]; Fi1 += bk1[m] * ci[m]; }
-            double I00 = S11 * idet, I01 = -S01 * idet, I11 = S00 * idet;
-            double K0 = -(I00 * Fj0 + I01 * Fj1), K1 = -(I01 * Fj0 + I11 * Fj1);
+            real I00 = S11 * idet, I01 = -S01 * idet, I11 = S00 * idet;
+            real K0 = -(I00 * Fj0 + I01 * Fj1), K1 = -(I01 * Fj0 + I11 * Fj1);
             *(li < 2 ? sK + 16 * k + 8 * li + lj : sDum + lane) = li == 0 ? K0 : K1;
             *(lane < 3 ? sSi + 4 * k + lane : sDum + lane) = lane == 0 ? I00 : (lane == 1 ? I01 : I11);
-            double pn = qh + Fi0 * K0 + Fi1 * K1 + (li == 6 ? cj[6] : (li == 7 ? cj[7] : 0.0));
+            real pn = qh + Fi0 * K0 + Fi1 * K1 + (li == 6 ? cj[6] : (li == 7 ? cj[7] : real(0.0)));
 #pragma unroll
             for (int m = 0; m < 6; m++) pn += arow[m] * cj[m];
             // symmetrise (lane (j,i) holds the transposed entry): without it the antisymmetric rounding error of the recursion is amplified by
             // |eig(Abar)|^2 per stage and wrecks long horizons whose linearised dynamics are open-loop unstable (N = 50, saturated tires)
-            Pij = 0.5 * (pn + __shfl(pn, 8 * lj + li));      // (k == 0: never used)
+            Pij = real(0.5) * (pn + __shfl(pn, 8 * lj + li));      // (k == 0: never used)
             // ---- vector recursion of the predictor: y = Mc_k + p_{k+1} (Mc_k = column 10 of the augmented product, in sMT[90..97]) ----
-            double yi = sMT[90 + r8] + pvec;
-            double y[8];
+            real yi = sMT[90 + r8] + pvec;
+            real y[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) y[m] = rl(yi, m);
-            double f0 = r0v + y[6], f1 = r1v + y[7], f0b = 0.0, f1b = 0.0;
-            double acc = qkv + (r8 == 6 ? y[6] : (r8 == 7 ? y[7] : 0.0)), accb = 0.0;
+            real f0 = r0v + y[6], f1 = r1v + y[7], f0b = real(0.0), f1b = real(0.0);
+            real acc = qkv + (r8 == 6 ? y[6] : (r8 == 7 ? y[7] : real(0.0))), accb = real(0.0);
 #pragma unroll
             for (int m = 0; m < 6; m += 2) {
                 f0 += bk0[m] * y[m]; f0b += bk0[m + 1] * y[m + 1]; f1 += bk1[m] * y[m]; f1b += bk1[m + 1] * y[m + 1];
@@ -1125,23 +1121,23 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     };
     // Riccati vector pass backward: lane r8 holds p_{k+1}[r8]; p_k = qhat_k + Abar' y + K' f, y = Mc_k + p_{k+1}, f = rhat + Bbar' y, kff = -Sinv f
     auto riccati_vectors = [&]() {
-        double pi = sq[8 * N + r8];
+        real pi = sq[8 * N + r8];
         ring_prime(N - 1, -1);
 #pragma unroll 1
         for (int k = N - 1; k >= 0; k--) {
             ring_step(k, -1);
-            const double* Ak = ring_slot(k); const double* Bk = Ak + SB_B;
-            double a6[6], b0[6], b1[6];
+            const real* Ak = ring_slot(k); const real* Bk = Ak + SB_B;
+            real a6[6], b0[6], b1[6];
 #pragma unroll
             for (int m = 0; m < 6; m++) { a6[m] = Ak[SB_ROW * m + r8]; b0[m] = Bk[2 * m]; b1[m] = Bk[2 * m + 1]; }
-            double mc = sMc[8 * k + r8], qk = sq[8 * k + r8], k0 = sK[16 * k + r8], k1 = sK[16 * k + 8 + r8], r0 = sr[2 * k], r1 = sr[2 * k + 1];
-            double I00 = sSi[4 * k], I01 = sSi[4 * k + 1], I11 = sSi[4 * k + 2];
-            double yi = mc + pi;
-            double y[8];
+            real mc = sMc[8 * k + r8], qk = sq[8 * k + r8], k0 = sK[16 * k + r8], k1 = sK[16 * k + 8 + r8], r0 = sr[2 * k], r1 = sr[2 * k + 1];
+            real I00 = sSi[4 * k], I01 = sSi[4 * k + 1], I11 = sSi[4 * k + 2];
+            real yi = mc + pi;
+            real y[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) y[m] = rl(yi, m);
-            double f0 = r0 + y[6], f1 = r1 + y[7], f0b = 0.0, f1b = 0.0;
-            double acc = qk + (r8 == 6 ? y[6] : (r8 == 7 ? y[7] : 0.0)), accb = 0.0;
+            real f0 = r0 + y[6], f1 = r1 + y[7], f0b = real(0.0), f1b = real(0.0);
+            real acc = qk + (r8 == 6 ? y[6] : (r8 == 7 ? y[7] : real(0.0))), accb = real(0.0);
 #pragma unroll
             for (int m = 0; m < 6; m += 2) {
                 f0 += b0[m] * y[m]; f0b += b0[m + 1] * y[m + 1]; f1 += b1[m] * y[m]; f1b += b1[m + 1] * y[m + 1];
@@ -1153,31 +1149,31 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         }
         __syncthreads();
     };
-    double xn[8], vn0, vn1, sn1, sn2, snh;
-    auto newton_point = [&](double* tplus) {
+    real xn[8], vn0, vn1, sn1, sn2, snh;
+    auto newton_point = [&](real* tplus) {
 #pragma unroll
         for (int m = 0; m < 8; m++) xn[m] = sx[8 * (s + 1) + m];
         vn0 = sv[2 * s]; vn1 = sv[2 * s + 1];
         sn1 = -(e_c10 * xn[2] + e_c11 * xn[3] + e_g1) * e_d1;
         sn2 = -(e_c20 * xn[2] + e_c21 * xn[3] + e_g2) * e_d2;
-        snh = wall_on ? -(e_ch0 * xn[5] + e_gh) * e_dh : (hji_on ? -(e_ch0 * xn[6] + e_ch1 * xn[7] + e_gh) * e_dh : 0.0);
+        snh = wall_on ? -(e_ch0 * xn[5] + e_gh) * e_dh : (hji_on ? -(e_ch0 * xn[6] + e_ch1 * xn[7] + e_gh) * e_dh : real(0.0));
         slacks(xn, vn0, sn1, sn2, snh, tplus);
     };
 
     int it_total = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
-    rp0 = 0.0; phi = 1.0;
+    rp0 = real(0.0); phi = real(1.0);
     if (attempt == 0) {
         // ---- first attempt: v = 0 roll-out (dynamics- and rate-feasible), sigma just feasible; t = max(slack, tau); lambda = mu0 / t ----
         forward(std::false_type{});
-        double xs[8];
+        real xs[8];
 #pragma unroll
         for (int m = 0; m < 8; m++) xs[m] = sx[8 * (s + 1) + m];
-        double sl[NROW];
-        slacks(xs, 0.0, 0.0, 0.0, 0.0, sl);
-        const double sig0 = 0.1, tau = 1e-4;
-        double sg1 = fmax(0.0, -fmin(sl[6], sl[7])) + sig0, sg2 = fmax(0.0, -fmin(sl[8], sl[9])) + sig0, sgh = wall_on ? fmax(0.0, -fmin(sl[0], sl[1])) + sig0 : (hji_on ? fmax(0.0, -sl[14]) + sig0 : 0.0);
-        slacks(xs, 0.0, sg1, sg2, sgh, sl);
+        real sl[NROW];
+        slacks(xs, real(0.0), real(0.0), real(0.0), real(0.0), sl);
+        const real sig0 = real(0.1), tau = real(1e-4);
+        real sg1 = fmax(real(0.0), -fmin(sl[6], sl[7])) + sig0, sg2 = fmax(real(0.0), -fmin(sl[8], sl[9])) + sig0, sgh = wall_on ? fmax(real(0.0), -fmin(sl[0], sl[1])) + sig0 : (hji_on ? fmax(real(0.0), -sl[14]) + sig0 : real(0.0));
+        slacks(xs, real(0.0), sg1, sg2, sgh, sl);
         if (act) {
 #pragma unroll
             for (int m = 0; m < 8; m++) SXs[m] = xs[m];
@@ -1186,8 +1182,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
 #pragma unroll
         for (int j = 0; j < NROW; j++) {
             bool on = act && j < nrows;
-            double tj = on ? fmax(sl[j], tau) : 1.0;
-            R.t[j] = tj; R.lam[j] = on ? C.ipm_mu0 / tj : 0.0; R.corr[j] = 0.0;
+            real tj = on ? fmax(sl[j], tau) : real(1.0);
+            R.t[j] = tj; R.lam[j] = on ? C.ipm_mu0 / tj : real(0.0); R.corr[j] = real(0.0);
             if (on) rp0 = fmax(rp0, tj - sl[j]);
         }
     } else {
@@ -1195,18 +1191,18 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         // unstable make the v = 0 roll-out explode, |e| ~ 500 m at N = 50): least-squares start.  One Newton solve with every row replaced
         // by a unit-weight quadratic penalty (closed-loop roll-out, bounded), then a UNIFORM shift that makes every slack >= 1. ----
 #pragma unroll
-        for (int j = 0; j < NROW; j++) { R.t[j] = 1.0; R.lam[j] = (act && j < nrows) ? 1.0 : 0.0; R.corr[j] = 0.0; it_[j] = 1.0; }
-        assemble(0.0, true);
+        for (int j = 0; j < NROW; j++) { R.t[j] = real(1.0); R.lam[j] = (act && j < nrows) ? real(1.0) : real(0.0); R.corr[j] = real(0.0); it_[j] = real(1.0); }
+        assemble(real(0.0), true);
         __syncthreads();
         riccati_matrices();
         forward(std::true_type{});
-        double tp[NROW];
+        real tp[NROW];
         newton_point(tp);
-        double tmin = PG_BIG;
+        real tmin = PG_BIG;
 #pragma unroll
         for (int j = 0; j < NROW; j++) tmin = fmin(tmin, (act && j < nrows) ? tp[j] : PG_BIG);
         tmin = wave_min(tmin);
-        const double shift = tmin < 1.0 ? 1.0 - tmin : 0.0;
+        const real shift = tmin < real(1.0) ? real(1.0) - tmin : real(0.0);
         if (act) {
 #pragma unroll
             for (int m = 0; m < 8; m++) SXs[m] = xn[m];
@@ -1215,8 +1211,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
 #pragma unroll
         for (int j = 0; j < NROW; j++) {
             bool on = act && j < nrows;
-            double tj = on ? tp[j] + shift : 1.0;
-            R.t[j] = tj; R.lam[j] = on ? C.ipm_mu0 / tj : 0.0; R.corr[j] = 0.0;
+            real tj = on ? tp[j] + shift : real(1.0);
+            R.t[j] = tj; R.lam[j] = on ? C.ipm_mu0 / tj : real(0.0); R.corr[j] = real(0.0);
         }
         rp0 = shift;
     }
@@ -1225,51 +1221,51 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     status = PG_MAX_ITER;
     const int iter_cap = attempt == 0 ? C.ipm_max_iter : 3 * C.ipm_max_iter;
     for (it = 0; it < iter_cap; it++) {
-        double musum = 0.0;
+        real musum = real(0.0);
 #pragma unroll
-        for (int j = 0; j < NROW; j++) musum += (act && j < nrows) ? R.t[j] * R.lam[j] : 0.0;
+        for (int j = 0; j < NROW; j++) musum += (act && j < nrows) ? R.t[j] * R.lam[j] : real(0.0);
         mu = wave_sum(musum) / ntot;
         if (!(mu == mu) || fabs(mu) > PG_BIG) { status = PG_NUMERICAL; break; }
-        if (mu <= C.ipm_tol && phi * fmax(rp0, 1.0) <= C.ipm_tol) { status = PG_SOLVED; break; }
+        if (mu <= C.ipm_tol && phi * fmax(rp0, real(1.0)) <= C.ipm_tol) { status = PG_SOLVED; break; }
 #pragma unroll
         for (int j = 0; j < NROW; j++) it_[j] = frcp(R.t[j]);
 
         // ---- predictor (sigma = 0, no correction) ----
 #pragma unroll
-        for (int j = 0; j < NROW; j++) R.corr[j] = 0.0;
+        for (int j = 0; j < NROW; j++) R.corr[j] = real(0.0);
         stamp(0);
-        assemble(0.0, true);
+        assemble(real(0.0), true);
         __syncthreads();
         stamp(1);
         riccati_matrices();                // matrix recursion + the predictor's vector recursion
         stamp(2);
         forward(std::true_type{});
         stamp(4);
-        double tp[NROW];
+        real tp[NROW];
         newton_point(tp);
         // step to the boundary: alpha_max = 1 / max_j( -dt_j / t_j, -dl_j / lam_j )  (only rows that move towards the boundary are positive)
-        double rmax = 0.0;
+        real rmax = real(0.0);
 #pragma unroll
         for (int j = 0; j < NROW; j++) {
             bool on = act && j < nrows;
-            double dt_ = tp[j] - R.t[j], dl_ = -(R.lam[j] * it_[j]) * tp[j];     // lambda+ - lambda with sigma*mu = 0, corr = 0
+            real dt_ = tp[j] - R.t[j], dl_ = -(R.lam[j] * it_[j]) * tp[j];     // lambda+ - lambda with sigma*mu = 0, corr = 0
             R.corr[j] = dt_ * dl_;
-            double rj = fmax(-dt_ * it_[j], -dl_ * frcp(R.lam[j]));
-            rmax = fmax(rmax, on ? rj : 0.0);
+            real rj = fmax(-dt_ * it_[j], -dl_ * frcp(R.lam[j]));
+            rmax = fmax(rmax, on ? rj : real(0.0));
         }
         rmax = wave_max(rmax);
-        double aaff = rmax > 1.0 ? 1.0 / rmax : 1.0;
+        real aaff = rmax > real(1.0) ? real(1.0) / rmax : real(1.0);
         // rounding floor: once mu is within 1e4x of the tolerance and the affine direction can no longer move (step to the boundary < 0.3),
         // further iterations only add noise (observed on long, ill-conditioned horizons): accept the iterate as it stands
-        if (mu <= 1e4 * C.ipm_tol && aaff < 0.3 && phi * fmax(rp0, 1.0) <= C.ipm_tol) { status = PG_SOLVED; break; }
-        double msum = 0.0;
+        if (mu <= real(1e4) * C.ipm_tol && aaff < real(0.3) && phi * fmax(rp0, real(1.0)) <= C.ipm_tol) { status = PG_SOLVED; break; }
+        real msum = real(0.0);
 #pragma unroll
         for (int j = 0; j < NROW; j++) {
-            double dt_ = tp[j] - R.t[j], dl_ = -(R.lam[j] * it_[j]) * tp[j];
-            msum += (act && j < nrows) ? (R.t[j] + aaff * dt_) * (R.lam[j] + aaff * dl_) : 0.0;
+            real dt_ = tp[j] - R.t[j], dl_ = -(R.lam[j] * it_[j]) * tp[j];
+            msum += (act && j < nrows) ? (R.t[j] + aaff * dt_) * (R.lam[j] + aaff * dl_) : real(0.0);
         }
-        double mu_aff = wave_sum(msum) / ntot;
-        double sg = fmin(mu_aff / mu, 1.0); sg = sg * sg * sg;          // Mehrotra centring parameter, never above 1
+        real mu_aff = wave_sum(msum) / ntot;
+        real sg = fmin(mu_aff / mu, real(1.0)); sg = sg * sg * sg;          // Mehrotra centring parameter, never above 1
         // ---- corrector ----
         assemble(sg * mu, false);
         __syncthreads();
@@ -1279,35 +1275,35 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         forward(std::true_type{});
         stamp(4);
         newton_point(tp);
-        rmax = 0.0;
+        rmax = real(0.0);
 #pragma unroll
         for (int j = 0; j < NROW; j++) {
             bool on = act && j < nrows;
-            double dt_ = tp[j] - R.t[j], dl_ = (sg * mu - R.corr[j]) * it_[j] - (R.lam[j] * it_[j]) * tp[j];
+            real dt_ = tp[j] - R.t[j], dl_ = (sg * mu - R.corr[j]) * it_[j] - (R.lam[j] * it_[j]) * tp[j];
             tp[j] = dl_;                              // keep d(lambda); d(t) is recomputed from the stage point below
             R.corr[j] = dt_;
-            double rj = fmax(-dt_ * it_[j], -dl_ * frcp(R.lam[j]));
-            rmax = fmax(rmax, on ? rj : 0.0);
+            real rj = fmax(-dt_ * it_[j], -dl_ * frcp(R.lam[j]));
+            rmax = fmax(rmax, on ? rj : real(0.0));
         }
         rmax = wave_max(rmax);
-        double alpha = rmax > 0.995 ? 0.995 / rmax : 1.0;
+        real alpha = rmax > real(0.995) ? real(0.995) / rmax : real(1.0);
 #pragma unroll
         for (int j = 0; j < NROW; j++) {
             bool on = act && j < nrows;
-            R.t[j] += on ? alpha * R.corr[j] : 0.0; R.lam[j] += on ? alpha * tp[j] : 0.0;
+            R.t[j] += on ? alpha * R.corr[j] : real(0.0); R.lam[j] += on ? alpha * tp[j] : real(0.0);
         }
         if (act) {
 #pragma unroll
-            for (int m = 0; m < 8; m++) { double c = SXs[m]; SXs[m] = c + alpha * (xn[m] - c); }
-            double c1 = SGs[0], c2 = SGs[1], c3 = SGs[2];
+            for (int m = 0; m < 8; m++) { real c = SXs[m]; SXs[m] = c + alpha * (xn[m] - c); }
+            real c1 = SGs[0], c2 = SGs[1], c3 = SGs[2];
             SGs[0] = c1 + alpha * (sn1 - c1); SGs[1] = c2 + alpha * (sn2 - c2); SGs[2] = c3 + alpha * (snh - c3);
         }
-        phi *= (1.0 - alpha);
+        phi *= (real(1.0) - alpha);
         if (PROF && b == C.dbg_instance && lane == 0 && it_total + it < 256) {      // trace region behind the [B][6] cycle counters: (mu, aaff, sigma, alpha) per iteration
-            double* tr = reinterpret_cast<double*>(prof + (size_t)B * 6) + 4 * (it_total + it);
+            real* tr = reinterpret_cast<real*>(prof + (size_t)B * 6) + 4 * (it_total + it);
             tr[0] = mu; tr[1] = aaff; tr[2] = sg; tr[3] = alpha;
         }
-        if (mu > 1e8 * C.ipm_mu0) break;          // diverging: give up on this start
+        if (mu > real(1e8) * C.ipm_mu0) break;          // diverging: give up on this start
     }
     it_total += it;
     if (status == PG_SOLVED || status == PG_NUMERICAL) break;
@@ -1316,11 +1312,11 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     stamp(0);
     if (PROF && lane == 0) { for (int i = 0; i < 6; i++) prof[(size_t)b * 6 + i] = pc[i]; }
     if (status == PG_SOLVED) {
-        double Ux0 = sx0[1], Fx0 = sx0[7];
+        real Ux0 = sx0[1], Fx0 = sx0[7];
         if (Ux0 < C.cp.V_min || Ux0 > C.cp.V_max || Fx0 < C.fxmin_n) status = PG_INFEASIBLE_X0;
     }
     // ---- outputs ----
-    double* SX = O.sol_x + (size_t)b * NN * 8;
+    real* SX = O.sol_x + (size_t)b * NN * 8;
     if (lane < 8) SX[lane] = sx0[lane];
     if (act) {
         unsigned mask = 0;
@@ -1330,14 +1326,16 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     }
     if (lane == 0) {
         // get_next_control: coupled_lat_long.jl:370-374 (node 2 of the reference = stage lane 0's node)
-        double d = SXs[6] * C.un0, Fx = SXs[7] * C.un1;         // lane 0 is stage 0: SXs is node 2 of the reference
+        real d = SXs[6] * C.un0, Fx = SXs[7] * C.un1;         // lane 0 is stage 0: SXs is node 2 of the reference
         if (C.formulation == PG_DECOUPLED) Fx = nodes[((size_t)b * NN + 1) * 10 + 7];      // decoupled_lat_long.jl:275-278: Fx of the seeded node 2
-        double* U = O.u_out + (size_t)b * 3;
-        U[0] = d; U[1] = Fx > 0.0 ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac; U[2] = Fx > 0.0 ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
+        real* U = O.u_out + (size_t)b * 3;
+        U[0] = d; U[1] = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac; U[2] = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
         O.status[b] = status; O.iters[b] = it; O.mu[b] = mu; O.solved[b] = 1;      // model_predictive_control.jl:76: solved = true
     }
 }
 
-#include "pg_solve4.hip"
+#ifdef PG_EXPERIMENTAL_SOLVE4      // four instances per wavefront: a measured negative result, kept out of the shipped libraries
+#include "experimental/pg_solve4.hip"
+#endif
 
 }  // namespace pg

@@ -104,3 +104,18 @@ def test_canonical_active_set_mapping(pkg):
     got = m.canonical_active_set(0, masks, qp)
     r_C13 = 60 + 10 + 30 + 30 + 93 + 8 + 60 + 10 + 120
     assert got == sorted([-(0 + 1), -(60 + 1), -(r_C13 + 8 + 1), +(r_C13 + 9 * 29 + 2 + 1)], key=abs)
+
+
+def test_fp32_instantiation_has_no_stray_fp64_arithmetic():
+    """The kernels are written against `real`; the fp32 translation unit must not issue fp64 arithmetic outside the kernels that own absolute
+    time (tools/check_f32_purity.py reads the gfx950 assembly hipcc cross-compiles here)."""
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "pigeon.jl_amd", "csrc")
+    subprocess.check_call(["make", "-s", "-C", csrc, "pg_api_f32.s"])
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_f32_purity
+    assert check_f32_purity.violations(os.path.join(csrc, "pg_api_f32.s")) == {}
+    # and the check itself bites: the fp64 build of the same sources is full of fp64 arithmetic
+    per = check_f32_purity.scan(os.path.join(csrc, "pg_api_f32.s"))
+    assert any(check_f32_purity.kernel_name(k) == "k_time_steps" for k in per)

@@ -148,23 +148,3 @@ def test_closed_loop_on_device_matches_oracle(pkg, oracle_mod, skidpad):
     assert np.max(np.abs(s - q) / np.maximum(1.0, np.abs(q))) < 1e-5 and np.max(np.abs(c - u) / un) < 1e-5 and np.allclose(t, tt)
     st, it, act, mu = mpc.solve_info()
     assert np.all(st == 1)
-
-
-def test_experimental_quad_solver_matches_default(pkg, skidpad, monkeypatch):
-    """PG_SOLVER=quad selects k_solve4 (four instances per wavefront, pg_solve4.hip): same interior-point method, different lane layout.
-    Both kernels must land on the same optimum (controls to 1e-6 normalised, identical active sets) on a ragged batch (B % 4 != 0)."""
-    B = 1023
-    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B, seed=77)
-    ref = pkg.BatchedTrajectoryTrackingMPC(skidpad, B)
-    u0, st0, it0 = ref.step_(state, control, t0, time_offset=toff)
-    x0, _ = ref.solution(); _, _, act0, _ = ref.solve_info()
-    monkeypatch.setenv("PG_SOLVER", "quad")
-    quad = pkg.BatchedTrajectoryTrackingMPC(skidpad, B)
-    u1, st1, it1 = quad.step_(state, control, t0, time_offset=toff)
-    x1, _ = quad.solution(); _, _, act1, _ = quad.solve_info()
-    assert np.all(st0 == 1) and np.all(st1 == 1)
-    un = np.array([ref.u_normalization[0], ref.u_normalization[1], ref.u_normalization[1]])
-    assert np.max(np.abs(u0 - u1) / un) < 1e-6
-    assert np.max(np.abs(x0[:, 1, 6:] - x1[:, 1, 6:])) < 1e-6
-    assert np.array_equal(act0, act1)
-    ref.close(); quad.close()
