@@ -81,7 +81,7 @@ typedef struct pg_config {
     int32_t device;                 /* HIP device ordinal */
     int32_t ipm_max_iter;           /* interior-point iteration cap (default 40) */
     int32_t formulation;            /* PG_COUPLED (src/coupled_lat_long.jl) or PG_DECOUPLED (src/decoupled_lat_long.jl) */
-    double ipm_tol;                 /* complementarity / infeasibility tolerance (default 1e-12; tighter values lose accuracy to rounding) */
+    double ipm_tol;                 /* complementarity / infeasibility tolerance of the interior point (default 1e-12 in the fp64 library, 1e-5 in the fp32 one) */
     double ipm_mu0;                 /* initial barrier parameter (default 100) */
     int32_t walls;                  /* BUILD-DEFINED EXTENSION (BASELINE config 5 "both_walls"; the reference snapshot carries edge_L/edge_R through
                                      * TrajectoryTube, src/trajectories.jl:19-20,33, but no constraint reads them, README.md:54): 1 adds to the DECOUPLED
@@ -89,6 +89,15 @@ typedef struct pg_config {
                                      * cost  wall_weight * dt_t * sw_t  (soft, like the stability-envelope rows of :193-211); 0 (default) = the reference's QP */
     int32_t _pad2;
     double wall_weight;             /* linear penalty on the wall slack per second (default 1000) */
+    int32_t polish;                 /* 1 (default): after the interior point has converged, an active-set polish (OSQP's `polish`, off in the reference's settings,
+                                     * src/coupled_lat_long.jl:201-203) solves the equality-constrained problem on the detected active set with the same Riccati passes
+                                     * and verifies primal/dual feasibility; removes the sqrt(mu) error of nearly degenerate rows.  0 = interior-point iterate as is */
+    int32_t _pad3;
+    double polish_rho;              /* penalty on the active rows inside the polish solves (default 1e6 in the fp64 library, 1e3 in the fp32 one) */
+    double polish_tol;              /* feasibility tolerance of the polish verification (default 1e-9 / 1e-4) */
+    double polish_ipm_tol;          /* with polish = 1 the interior point first stops at this (looser) tolerance and hands over to the polish (default 1e-6 / 1e-4);
+                                     * if the polish cannot verify an active set from there, the interior point resumes down to ipm_tol and the polish gets a second
+                                     * and last chance.  Values <= ipm_tol disable the early hand-over */
 } pg_config;
 
 enum pg_formulation { PG_COUPLED = 0, PG_DECOUPLED = 1 };
@@ -190,6 +199,9 @@ int pg_get_qp(pg_handle* h, int32_t b0, int32_t n, double* out);
 int pg_get_solution(pg_handle* h, double* x, double* sigma);
 /* status [B] (pg_solve_status), iters [B], active [B][N] bit masks over the 16 stage rows (row order in DESIGN.md), mu [B] final gap */
 int pg_get_solve_info(pg_handle* h, int32_t* status, int32_t* iters, uint16_t* active, double* mu);
+/* outcome of the active-set polish per instance, [B]: 0 = not run (polish off, or the interior point did not converge), k >= 1 = verified in round k (the
+ * solution is the exact optimum on its active set), -1 = did not verify (the interior-point iterate at ipm_tol was kept) */
+int pg_get_polish_info(pg_handle* h, int32_t* polish);
 /* milliseconds of the last pg_step_dev per phase: time_steps+nodes, update_qp (linearize, limits, HJI), solve (+extract); HIP events */
 int pg_get_phase_ms(pg_handle* h, float out3[3]);
 

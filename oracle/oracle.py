@@ -213,9 +213,9 @@ class Oracle:
         return dict(Pd=Pd, q=q, Ap=Ap, Ai=Ai, Ax=Ax, l=l, u=u)
 
     def solve_exact(self, sd):
-        x = np.zeros(self.n); y = np.zeros(self.m); info = np.zeros(5)
+        x = np.zeros(self.n); y = np.zeros(self.m); info = np.zeros(6)
         st = self.L.po_solve_exact(self.h, _d(_arr(sd, self.sd_len)), _d(x), _d(y), _d(info))
-        return x, y, dict(iters=int(info[0]), status=int(info[1]), res_pri=info[2], res_dua=info[3], gap=info[4])
+        return x, y, dict(iters=int(info[0]), status=int(info[1]), res_pri=info[2], res_dua=info[3], gap=info[4], polished=int(info[5]))
 
     def osqp_settings(self, rho=0.1, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_iter=4000, scaling=10, check_termination=25,
                       adaptive_rho=1, adaptive_rho_interval=25, warm_start=1):
@@ -256,11 +256,11 @@ def solve_exact_generic(qp):
     """Exact optimum of a canonical QP dict (Pd, q, Ap, Ai, Ax, l, u) with the oracle's sparse interior point: (x, y, info)."""
     L = lib()
     n = len(qp["Pd"]); m = len(qp["l"])
-    x = np.zeros(n); y = np.zeros(m); info = np.zeros(5)
+    x = np.zeros(n); y = np.zeros(m); info = np.zeros(6)
     Ap = np.ascontiguousarray(qp["Ap"], dtype=np.int32); Ai = np.ascontiguousarray(qp["Ai"], dtype=np.int32)
     L.po_solve_exact_generic(n, m, _d(_arr(qp["Pd"])), _d(_arr(qp["q"])), Ap.ctypes.data_as(c_ip), Ai.ctypes.data_as(c_ip), _d(_arr(qp["Ax"])),
                              _d(_arr(qp["l"])), _d(_arr(qp["u"])), _d(x), _d(y), _d(info))
-    return x, y, dict(iters=int(info[0]), status=int(info[1]), res_pri=info[2], res_dua=info[3], gap=info[4])
+    return x, y, dict(iters=int(info[0]), status=int(info[1]), res_pri=info[2], res_dua=info[3], gap=info[4], polished=int(info[5]))
 
 
 def active_set(qp, x, y, tol=1e-7):
@@ -336,9 +336,9 @@ class OracleDecoupled:
         return dict(Pd=Pd, q=q, Ap=Ap, Ai=Ai, Ax=Ax, l=l, u=u)
 
     def solve_exact(self, sd):
-        x = np.zeros(self.n); y = np.zeros(self.m); info = np.zeros(5)
+        x = np.zeros(self.n); y = np.zeros(self.m); info = np.zeros(6)
         self.L.pd_solve_exact(self.h, _d(_arr(sd, self.sd_len)), _d(x), _d(y), _d(info))
-        return x, y, dict(iters=int(info[0]), status=int(info[1]), res_pri=info[2], res_dua=info[3], gap=info[4])
+        return x, y, dict(iters=int(info[0]), status=int(info[1]), res_pri=info[2], res_dua=info[3], gap=info[4], polished=int(info[5]))
 
     def split_x(self, x):
         Nn, N = self.Nn, self.N

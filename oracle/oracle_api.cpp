@@ -163,14 +163,14 @@ void po_assemble_qp(void* hv, const double* sd_flat, double* Pd, double* q, int*
     std::memcpy(Ap, qp.Ap.data(), (qp.n + 1) * 4); std::memcpy(Ai, qp.Ai.data(), qp.Ai.size() * 4); std::memcpy(Ax, qp.Ax.data(), qp.Ax.size() * 8);
     std::memcpy(l, qp.l.data(), qp.m * 8); std::memcpy(u, qp.u.data(), qp.m * 8);
 }
-// info: [iters, status, res_pri, res_dua, gap]
+// info: [iters, status, res_pri, res_dua, gap, polished (0 = interior-point answer, k = active-set polish verified in round k)]
 int po_solve_exact(void* hv, const double* sd_flat, double* x, double* y, double* info5) {
     Handle* h = (Handle*)hv; StageData sd; flat_to_sd(sd_flat, h->mpc.TS.N_short, h->mpc.TS.N_long, sd);
     QP qp; h->lay.fill(sd, h->mpc.cp, h->mpc.veh, h->mpc.u_norm, qp);
     LDLNumeric ldl; ldl.init(&h->kkt.sym);
     ExactResult R; int st = solve_exact(qp, h->kkt, ldl, R);
     if ((int)R.x.size() == qp.n) { std::memcpy(x, R.x.data(), qp.n * 8); std::memcpy(y, R.y.data(), qp.m * 8); }
-    info5[0] = R.iters; info5[1] = R.status; info5[2] = R.res_pri; info5[3] = R.res_dua; info5[4] = R.gap;
+    info5[0] = R.iters; info5[1] = R.status; info5[2] = R.res_pri; info5[3] = R.res_dua; info5[4] = R.gap; info5[5] = R.polished;
     return st;
 }
 void po_osqp_settings(void* hv, double rho, double sigma, double alpha, double eps_abs, double eps_rel, int max_iter, int scaling,
@@ -310,7 +310,7 @@ int po_solve_exact_generic(int n, int m, const double* Pd, const double* q, cons
     LDLNumeric ldl; ldl.init(&K.sym);
     ExactResult R; int st = solve_exact_robust(qp, K, ldl, R);
     if ((int)R.x.size() == n) { std::memcpy(x, R.x.data(), n * 8); std::memcpy(y, R.y.data(), m * 8); }
-    info5[0] = R.iters; info5[1] = R.status; info5[2] = R.res_pri; info5[3] = R.res_dua; info5[4] = R.gap;
+    info5[0] = R.iters; info5[1] = R.status; info5[2] = R.res_pri; info5[3] = R.res_dua; info5[4] = R.gap; info5[5] = R.polished;
     return st;
 }
 void pd_update_qp(void* hv, const double* qs, const double* us, const double* ps, const double* dt, double* sd_flat) {
@@ -332,7 +332,7 @@ int pd_solve_exact(void* hv, const double* sd_flat, double* x, double* y, double
     LDLNumeric ldl; ldl.init(&h->kkt.sym);
     ExactResult R; int st = solve_exact_robust(qp, h->kkt, ldl, R);
     if ((int)R.x.size() == qp.n) { std::memcpy(x, R.x.data(), qp.n * 8); std::memcpy(y, R.y.data(), qp.m * 8); }
-    info5[0] = R.iters; info5[1] = R.status; info5[2] = R.res_pri; info5[3] = R.res_dua; info5[4] = R.gap;
+    info5[0] = R.iters; info5[1] = R.status; info5[2] = R.res_pri; info5[3] = R.res_dua; info5[4] = R.gap; info5[5] = R.polished;
     return st;
 }
 void pd_lateral_dynamics(void* hv, const double* q4, const double* u2, const double* p4, double* out4) { vehicle_lateral_dynamics<double>(((HandleDec*)hv)->mpc.veh, q4, u2, p4, out4); }

@@ -21,13 +21,13 @@ struct pg_handle {
     real *d_traj = nullptr; int traj_L = 0; int *d_traj_len = nullptr, *d_traj_idx = nullptr; int traj_idx_B = 0;
     real *d_state = nullptr, *d_control = nullptr, *d_other = nullptr;
     double *d_t0 = nullptr, *d_toff = nullptr;            // absolute time stays fp64 in both builds (tdouble)
-    int* d_solved = nullptr;
+    int* d_solved = nullptr; uint8_t* d_mask = nullptr;     // d_mask: staging of pg_reset's per-instance mask
     double *d_ts = nullptr, *d_dt = nullptr, *d_prev_ts = nullptr;
     real *d_sep = nullptr, *d_nodes = nullptr, *d_qp = nullptr;
     real *d_x7 = nullptr, *d_vg8 = nullptr, *d_Mb = nullptr, *d_abar = nullptr;
     real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     real *d_pol_u2 = nullptr, *d_pol_u = nullptr; int* d_pol_src = nullptr;   // HJI fallback policy (HJI_computation.jl:133-158)
-    int *d_status = nullptr, *d_iters = nullptr; uint16_t* d_active = nullptr;
+    int *d_status = nullptr, *d_iters = nullptr, *d_polish = nullptr; uint16_t* d_active = nullptr;
     // HJI grid
     HjiView hv; float *d_knots = nullptr, *d_hnodes = nullptr, *d_hcells = nullptr; bool has_hji = false;
     hipEvent_t ev[4]; bool ev_ok = false; float phase_ms[3] = {0, 0, 0}; bool timing_valid = false;
@@ -108,7 +108,13 @@ int pg_default_config(pg_config* c) {
     U.R_delta = 0.0; U.R_ddelta = 0.1; U.R_Fx = 0.0; U.R_dFx = 0.5;
     c->N_short = 10; c->N_long = 20; c->dt_short = 0.01; c->dt_long = 0.2; c->use_correction_step = 1;   // coupled_lat_long.jl:42-43
     c->rk4_substeps = 10; c->hji_eps = 0.05; c->batch_capacity = 4096; c->device = 0;
-    c->ipm_max_iter = 40; c->ipm_tol = 1e-12; c->ipm_mu0 = 100.0; c->formulation = PG_COUPLED; c->walls = 0; c->wall_weight = 1000.0;
+    c->ipm_max_iter = 40; c->ipm_mu0 = 100.0; c->formulation = PG_COUPLED; c->walls = 0; c->wall_weight = 1000.0;
+    c->polish = 1;
+#ifdef PG_F32
+    c->ipm_tol = 1e-5; c->polish_rho = 1e3; c->polish_tol = 1e-4; c->polish_ipm_tol = 1e-4;
+#else
+    c->ipm_tol = 1e-12; c->polish_rho = 1e6; c->polish_tol = 1e-9; c->polish_ipm_tol = 1e-6;
+#endif
     return PG_OK;
 }
 
@@ -119,12 +125,15 @@ int pg_default_config_decoupled(pg_config* c) {
     U.Q_ds = 0.0; U.Q_dpsi = 1.0 / (d10 * d10); U.Q_e = 1.0; U.W_beta = 50 / d10; U.W_r = 50.0; U.W_HJI = 0.0; U.N_HJI = 0;
     U.R_delta = 0.0; U.R_ddelta = 0.01 / (d10 * d10); U.R_Fx = 0.0; U.R_dFx = 1.0;      // R_dFx only pins the inert Fx slot of the embedding
     c->formulation = PG_DECOUPLED;
+#ifdef PG_F32
+    c->ipm_tol = 1e-4;                               // the ill-conditioned 8 s lateral horizon stalls near 1e-4 in fp32 (tests/test_gpu_f32.py)
+#endif
     return PG_OK;
 }
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_state, h->d_control, h->d_t0, h->d_other, h->d_toff, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_abar, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_abar, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->ev_ok) for (int i = 0; i < 4; i++) (void)hipEventDestroy(h->ev[i]);
 }
@@ -140,6 +149,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "device ordinal out of range"; return PG_ERR_INVALID; }
     if (cfg->formulation != PG_COUPLED && cfg->formulation != PG_DECOUPLED) { g_create_error = "unknown formulation"; return PG_ERR_INVALID; }
     if (cfg->walls != 0 && (cfg->walls != 1 || cfg->formulation != PG_DECOUPLED)) { g_create_error = "walls = 1 is an option of the decoupled formulation only"; return PG_ERR_INVALID; }
+    if (cfg->polish && !(cfg->polish_rho > 0.0 && cfg->polish_tol > 0.0)) { g_create_error = "polish needs polish_rho > 0 and polish_tol > 0"; return PG_ERR_INVALID; }
     if (cfg->N_short < 1 || cfg->N_long < 0 || cfg->N_short + cfg->N_long + 1 > 64 || cfg->batch_capacity < 1 || cfg->rk4_substeps < 1) {
         g_create_error = "invalid horizon / capacity (need 1 <= N_short, N_short+N_long+1 <= 64)"; return PG_ERR_INVALID;
     }
@@ -160,15 +170,16 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     }
     C.qp_len = 84 * C.N + 11;
     C.ipm_max_iter = cfg->ipm_max_iter; C.ipm_tol = (real)cfg->ipm_tol; C.ipm_mu0 = (real)cfg->ipm_mu0;
+    C.polish = cfg->polish != 0; C.polish_rho = (real)cfg->polish_rho; C.polish_tol = (real)cfg->polish_tol; C.polish_ipm_tol = (real)cfg->polish_ipm_tol;
     const size_t cap = (size_t)cfg->batch_capacity; const int N = C.N, NN = C.NN;
 #define ALLOC(ptr, count, type) do { if (hipMalloc((void**)&(ptr), (size_t)(count) * sizeof(type)) != hipSuccess) { g_create_error = "hipMalloc failed for " #ptr; free_all(h); delete h; return PG_ERR_HIP; } } while (0)
     ALLOC(h->d_state, cap * 6, real); ALLOC(h->d_control, cap * 3, real); ALLOC(h->d_t0, cap, double); ALLOC(h->d_other, cap * 4, real); ALLOC(h->d_toff, cap, double);
-    ALLOC(h->d_solved, cap, int); ALLOC(h->d_ts, cap * NN, double); ALLOC(h->d_dt, cap * N, double); ALLOC(h->d_prev_ts, cap * NN, double);
+    ALLOC(h->d_solved, cap, int); ALLOC(h->d_mask, cap, uint8_t); ALLOC(h->d_ts, cap * NN, double); ALLOC(h->d_dt, cap * N, double); ALLOC(h->d_prev_ts, cap * NN, double);
     ALLOC(h->d_sep, cap * 4, real); ALLOC(h->d_nodes, cap * NN * 10, real); ALLOC(h->d_qp, cap * C.qp_len, real);
     ALLOC(h->d_abar, cap * N * SB, real);
     ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
     ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_u, cap * 3, real); ALLOC(h->d_mu, cap, real);
-    ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_active, cap * N, uint16_t);
+    ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_polish, cap, int); ALLOC(h->d_active, cap * N, uint16_t);
 #ifdef PG_EXPERIMENTAL_SOLVE4
     { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (experimental/pg_solve4.hip)
     if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), real);
@@ -186,6 +197,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         (void)hipMemset(h->d_solved, 0, cap * sizeof(int));
         (void)hipMemset(h->d_other, 0, cap * 4 * sizeof(real));
         (void)hipMemset(h->d_solx, 0, cap * NN * 8 * sizeof(real));
+        if (hipDeviceSynchronize() != hipSuccess) { g_create_error = "initial fills failed"; free_all(h); delete h; return PG_ERR_HIP; }   // hipMemset may return before the fill has run
     }
     for (int i = 0; i < 4; i++) if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_create_error = "hipEventCreate failed"; free_all(h); delete h; return PG_ERR_HIP; }
     h->ev_ok = true;
@@ -196,8 +208,10 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
 #endif
     h->solve_lds = (size_t)((h->solve_ring ? 4 : N) * SB + 10 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 72 + 100 + 8 + 64 + 2) * sizeof(real);
     if (h->solve_lds > 160 * 1024) { g_create_error = "horizon too long for LDS staging"; free_all(h); delete h; return PG_ERR_INVALID; }
-    if (h->solve_lds > 48 * 1024)
+    static size_t lds_attr_max = 48 * 1024;      // hipFuncSetAttribute is process-global: a later handle with a shorter horizon must not lower the limit of an earlier one
+    if (h->solve_lds > lds_attr_max)
     {
+        lds_attr_max = h->solve_lds;
         (void)hipFuncSetAttribute((const void*)k_solve<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
         (void)hipFuncSetAttribute((const void*)k_solve<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
         (void)hipFuncSetAttribute((const void*)k_solve<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
@@ -334,12 +348,10 @@ int pg_reset(pg_handle* h, const uint8_t* mask) {
     const int cap = h->cfg.batch_capacity;
     if (!mask) { HIPCHK(h, hipMemsetAsync(h->d_solved, 0, (size_t)cap * sizeof(int), h->stream)); return PG_OK; }
     REQUIRE(h, h->B > 0, "pg_reset with a mask needs inputs installed (B known)");
-    uint8_t* dm = nullptr;
-    HIPCHK(h, hipMalloc((void**)&dm, h->B));
-    HIPCHK(h, hipMemcpy(dm, mask, h->B, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_reset, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, h->B, dm, h->d_solved);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    (void)hipFree(dm);
+    HIPCHK(h, hipMemcpyAsync(h->d_mask, mask, h->B, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_reset, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, h->B, h->d_mask, h->d_solved);
+    LAUNCH_CHECK(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));            // the caller may reuse `mask`
     return PG_OK;
 }
 
@@ -442,7 +454,7 @@ int pg_update_qp(pg_handle* h) {
 }
 int pg_solve(pg_handle* h) {
     int rc = check_ready(h); if (rc) return rc;
-    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved};
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish};
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) { hipLaunchKernelGGL((k_solve4<2, false>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, h->d_ws4, O, (unsigned long long*)nullptr); LAUNCH_CHECK(h); return PG_OK; }
 #endif
@@ -458,7 +470,7 @@ int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     unsigned long long* d = nullptr;
     HIPCHK(h, hipMalloc((void**)&d, ((size_t)h->B * 6 + 1024) * 8));
     HIPCHK(h, hipMemset(d, 0, ((size_t)h->B * 6 + 1024) * 8));
-    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved};
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish};
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) hipLaunchKernelGGL((k_solve4<2, true>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, h->d_ws4, O, d);
     else
@@ -555,8 +567,8 @@ int pg_step(pg_handle* h, int32_t B, const double* state, const double* control,
     int rc = pg_set_inputs(h, B, state, control, t0, other, toff); if (rc) return rc;
     if ((rc = pg_step_dev(h, nullptr))) return rc;
     if (u_out && (rc = pg_get_next_control(h, u_out))) return rc;
-    if (status) HIPCHK(h, hipMemcpy(status, h->d_status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost));
-    if (iters) HIPCHK(h, hipMemcpy(iters, h->d_iters, (size_t)B * sizeof(int), hipMemcpyDeviceToHost));
+    // read-backs are issued on the handle's stream (ordered after k_solve even when the caller installed a non-blocking stream)
+    if ((rc = down_raw(h, status, h->d_status, (size_t)B * sizeof(int))) || (rc = down_raw(h, iters, h->d_iters, (size_t)B * sizeof(int)))) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PG_OK;
 }
@@ -607,6 +619,11 @@ int pg_get_solve_info(pg_handle* h, int32_t* status, int32_t* iters, uint16_t* a
     if ((rc = down_raw(h, status, h->d_status, B * 4)) || (rc = down_raw(h, iters, h->d_iters, B * 4)) || (rc = down_raw(h, active, h->d_active, B * C.N * 2)) ||
         (rc = down(h, mu, h->d_mu, B))) return rc;
     return PG_OK;
+}
+int pg_get_polish_info(pg_handle* h, int32_t* polish) {
+    int rc = check_ready(h); if (rc) return rc;
+    REQUIRE(h, polish, "polish is null");
+    return down_raw(h, polish, h->d_polish, (size_t)h->B * 4);
 }
 int pg_get_walls(pg_handle* h, double* edges) {
     int rc = check_ready(h); if (rc) return rc;

@@ -31,6 +31,9 @@ struct DevCfg {
     int qp_len;
     int ipm_max_iter;
     real ipm_tol, ipm_mu0;
+    int polish;                   // active-set polish after the interior point (k_solve): 0 off, 1 on
+    real polish_rho, polish_tol;  // penalty of the active rows in the polish solves; feasibility tolerance of its verification
+    real polish_ipm_tol;          // interior-point tolerance at which the polish is first attempted (>= ipm_tol; a polish that fails there resumes the interior point down to ipm_tol)
     TrajView traj;                // trajectory 0 of the installed library
     int n_traj;                   // library size (1: every instance tracks `traj`)
     long traj_stride;             // doubles between consecutive trajectories of the library ([n_traj][10][Lmax])
@@ -109,6 +112,11 @@ __global__ __launch_bounds__(256) void k_project(DevCfg C, int B, const real* __
     }
     if (lane == 0) {
         int i = bi;
+        real* o = sep + (size_t)wave * 4;
+        // non-finite pose: every distance is NaN/Inf, no segment ever wins and bi keeps its sentinel.  The reference indexes traj[0] there (BoundsError,
+        // caught by the ROS loop, ros_integration.jl:95-102); here the instance is poisoned with NaN so that k_solve reports PG_NUMERICAL and no lane
+        // ever forms an address from the sentinel
+        if (i < 0 || i > T.L - 2) { o[0] = NAN; o[1] = NAN; o[2] = NAN; o[3] = real(0.0); return; }
         real vx = T.E[i + 1] - T.E[i], vy = T.N[i + 1] - T.N[i], wx = x - T.E[i], wy = y - T.N[i];
         // :82 sqrt(w.w - d^2) with d^2 = |w - lam v|^2 expanded: w.w - d^2 = lam (2 w.v - lam v.v).  Same value for every lam in [0,1], but no
         // cancellation (the literal form loses half the digits when the foot point is near the segment start: 5 mm in fp32)
@@ -119,7 +127,6 @@ __global__ __launch_bounds__(256) void k_project(DevCfg C, int B, const real* __
         real Ai = (T.V[i + 1] - T.V[i]) / (T.t[i + 1] - T.t[i]);
         // (sqrt(2 A ds + V^2) - V) / A of :88, rationalised: same value, no cancellation (in fp32 the original loses 3 digits at |A| ~ 1e-3)
         real dt = fabs(Ai) < real(1e-3) ? ds / T.V[i] : real(2.0) * ds / (sqrt(real(2.0) * Ai * ds + T.V[i] * T.V[i]) + T.V[i]);
-        real* o = sep + (size_t)wave * 4;
         o[0] = T.s[i] + ds; o[1] = sqrt(best) * sgn(cr); o[2] = T.t[i] + dt; o[3] = (real)i;
     }
 }
@@ -808,9 +815,10 @@ __global__ __launch_bounds__(64) void k_hji_policy(DevCfg C, int B, int use_poli
 //   0: Ux >= V_min   1: Ux <= V_max   2: Fx >= Fx_min   3: delta <= dmax   4: delta >= dmin   5: Fx <= fxmax
 //   6..9: H_i [Uy;r] - sigma_{i/2} <= G_i     10: sigma1 >= 0   11: sigma2 >= 0    12: d_delta <= ddmax   13: d_delta >= ddmin
 //   14: M u + b + sigma_HJI >= 0              15: sigma_HJI >= 0        (14,15 only for nodes 1 .. min(N_HJI,Ns)-1)
-struct SolveOut { real* sol_x; real* sol_sigma; real* u_out; int* status; int* iters; uint16_t* active; real* mu; int* solved; };
+struct SolveOut { real* sol_x; real* sol_sigma; real* u_out; int* status; int* iters; uint16_t* active; real* mu; int* solved; int* polish; };
 
 #define NROW 16
+#define PG_POLISH_ROUNDS 6      // active-set rounds of the polish before it gives up
 
 struct StageRows {
     real t[NROW], lam[NROW], corr[NROW];
@@ -996,13 +1004,28 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
 
     real e_d1, e_c10, e_c11, e_g1, e_d2, e_c20, e_c21, e_g2, e_dh, e_ch0, e_ch1, e_gh;   // e_d* hold RECIPROCALS of the slack pivots
     real it_[NROW];                    // 1 / t_j, refreshed once per interior-point iteration
+    // Polish state (see the loop below): pmode = 0 while the interior point runs, then the round number of the active-set polish;
+    // amask = this stage's rows currently held active.
+    int pmode = 0, pstat = 0; unsigned amask = 0, mask_ipm = 0;
+    const real rho = C.polish_rho, ptol = C.polish_tol;
     auto assemble = [&](real sigmu, bool matrices) {
         real W[NROW], ell[NROW];
+        if (pmode) {
+            // polish: active rows are equalities enforced by the augmented Lagrangian  -y t(z) + rho/2 t(z)^2  (y lives in R.lam), inactive rows are absent.
+            // Same shape as the barrier terms: W = rho, constant part of the multiplier = y - rho b.
 #pragma unroll
-        for (int j = 0; j < NROW; j++) {
-            bool on = j < nrows;
-            W[j] = on ? R.lam[j] * it_[j] : real(0.0);
-            ell[j] = on ? (sigmu - R.corr[j]) * it_[j] + R.lam[j] - W[j] * bb[j] : real(0.0);
+            for (int j = 0; j < NROW; j++) {
+                const bool a = j < nrows && ((amask >> j) & 1u);
+                W[j] = a ? rho : real(0.0);
+                ell[j] = a ? R.lam[j] - rho * bb[j] : real(0.0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NROW; j++) {
+                bool on = j < nrows;
+                W[j] = on ? R.lam[j] * it_[j] : real(0.0);
+                ell[j] = on ? (sigmu - R.corr[j]) * it_[j] + R.lam[j] - W[j] * bb[j] : real(0.0);
+            }
         }
         real g1 = wall_on ? real(0.0) : -ell[0] + ell[1], g7 = (wall_on ? real(0.0) : -ell[2]) + ell[5] - M1 * ell[14], g6 = ell[3] - ell[4] - M0 * ell[14];
         real g2 = real(0.0), g3 = real(0.0);
@@ -1162,7 +1185,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
 
     int it_total = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
-    rp0 = real(0.0); phi = real(1.0);
+    rp0 = real(0.0); phi = real(1.0); pmode = 0; pstat = 0;
     if (attempt == 0) {
         // ---- first attempt: v = 0 roll-out (dynamics- and rate-feasible), sigma just feasible; t = max(slack, tau); lambda = mu0 / t ----
         forward(std::false_type{});
@@ -1220,17 +1243,87 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     rp0 = wave_max(rp0);
     status = PG_MAX_ITER;
     const int iter_cap = attempt == 0 ? C.ipm_max_iter : 3 * C.ipm_max_iter;
-    for (it = 0; it < iter_cap; it++) {
-        real musum = real(0.0);
+    // Active-set polish (OSQP-style, on the stage-structured problem).  The interior point approaches nearly degenerate rows (slack and multiplier both ~ sqrt(mu))
+    // like sqrt(mu), so its iterate can sit 1e-6 away from the optimum at any tolerance fp64 rounding allows.  Once it has converged, the rows with
+    // lambda > t are held as EQUALITIES (augmented Lagrangian with penalty rho, multiplier estimates y = lambda), every other row is dropped, and the
+    // resulting equality-constrained LQ problem is solved by the SAME passes: one "predictor" (matrix pass) + one "corrector" (vector pass) per round, a
+    // multiplier update  y <- y - rho t(z+)  after each.  A round is accepted when the point is primal feasible (inactive rows t >= -ptol, active rows
+    // |t| <= ptol) and dual feasible (y >= 0); otherwise violated rows join the set, rows with y < 0 leave it, and the round repeats (PG_POLISH_ROUNDS at most).  A
+    // polish that does not verify leaves the interior-point iterate in place.
+    auto enter_polish = [&]() {
+        amask = 0;
 #pragma unroll
-        for (int j = 0; j < NROW; j++) musum += (act && j < nrows) ? R.t[j] * R.lam[j] : real(0.0);
-        mu = wave_sum(musum) / ntot;
-        if (!(mu == mu) || fabs(mu) > PG_BIG) { status = PG_NUMERICAL; break; }
-        if (mu <= C.ipm_tol && phi * fmax(rp0, real(1.0)) <= C.ipm_tol) { status = PG_SOLVED; break; }
+        for (int j = 0; j < NROW; j++) if (act && j < nrows && R.lam[j] > R.t[j]) amask |= (1u << j);
+        mask_ipm = amask;
 #pragma unroll
-        for (int j = 0; j < NROW; j++) it_[j] = frcp(R.t[j]);
+        for (int j = 0; j < NROW; j++) R.lam[j] = ((amask >> j) & 1u) ? R.lam[j] : real(0.0);
+        pmode = 1;
+    };
+    // after a polish solve (tp = slacks at the new point): multiplier update of the active rows, then the verification.  Returns 0 = verified (solution
+    // stored, pstat set), 1 = same set but the active rows are not yet at t = 0 within `ttol` (refine), 2 = the active set changed.
+    auto polish_check = [&](const real* tp, real ttol) -> int {
+        unsigned add = 0, drop = 0; bool settled = true;
+#pragma unroll
+        for (int j = 0; j < NROW; j++) {
+            const bool on = act && j < nrows, a = (amask >> j) & 1u;
+            if (a) R.lam[j] -= rho * tp[j];
+            if (on && a && R.lam[j] < real(0.0)) drop |= 1u << j;
+            if (on && a && !(fabs(tp[j]) <= ttol)) settled = false;            // written so that a NaN never verifies
+            if (on && !a && !(tp[j] >= -ptol)) add |= 1u << j;
+        }
+        const bool changed = __any((add | drop) != 0u), conv = __all(settled);
+        if (!changed && conv) {
+            if (act) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) SXs[m] = xn[m];
+                SGs[0] = sn1; SGs[1] = sn2; SGs[2] = snh;
+            }
+            pstat = pmode;
+            return 0;
+        }
+        if (!changed) return 1;
+        amask = (amask & ~drop) | add;
+#pragma unroll
+        for (int j = 0; j < NROW; j++) R.lam[j] = ((amask >> j) & 1u) ? R.lam[j] : real(0.0);
+        return 2;
+    };
+    // with the polish on, the interior point only has to get close enough for the active set to show (polish_ipm_tol); if the polish does not verify from
+    // there, the interior point resumes from the centred point (t, mu / t) and runs down to ipm_tol before the polish gets its second and last chance
+    real tol_cur = (C.polish && C.polish_ipm_tol > C.ipm_tol) ? C.polish_ipm_tol : C.ipm_tol;
+    auto polish_failed = [&]() -> bool {          // true: give up (keep the interior-point iterate); false: the interior point resumes
+        if (!(tol_cur > C.ipm_tol)) { pstat = -1; return true; }
+        tol_cur = C.ipm_tol; pmode = 0; status = PG_MAX_ITER;
+#pragma unroll
+        for (int j = 0; j < NROW; j++) R.lam[j] = (act && j < nrows) ? mu * frcp(R.t[j]) : real(0.0);
+        return false;
+    };
+    it = 0;
+    while (true) {
+        if (!pmode) {
+            if (it >= iter_cap) break;
+            real musum = real(0.0);
+#pragma unroll
+            for (int j = 0; j < NROW; j++) musum += (act && j < nrows) ? R.t[j] * R.lam[j] : real(0.0);
+            mu = wave_sum(musum) / ntot;
+            if (!(mu == mu) || fabs(mu) > PG_BIG) { status = PG_NUMERICAL; break; }
+            if (mu <= tol_cur && phi * fmax(rp0, real(1.0)) <= tol_cur) {
+                status = PG_SOLVED;
+                if (!C.polish) break;
+                enter_polish();
+            } else {
+#pragma unroll
+                for (int j = 0; j < NROW; j++) it_[j] = frcp(R.t[j]);
+            }
+        }
+        if (pmode) {
+            // every stage-locally eliminated slack needs a pivot: a group without an active row gets its sigma >= 0 row (the linear cost pushes sigma down to it)
+            if (!(amask & 0x04C0u)) amask |= 1u << 10;
+            if (!(amask & 0x0B00u)) amask |= 1u << 11;
+            if (hji_on && !(amask & 0xC000u)) amask |= 1u << 15;
+            if (wall_on && !(amask & 0x0007u)) amask |= 1u << 2;
+        }
 
-        // ---- predictor (sigma = 0, no correction) ----
+        // ---- predictor (sigma = 0, no correction) / first polish solve ----
 #pragma unroll
         for (int j = 0; j < NROW; j++) R.corr[j] = real(0.0);
         stamp(0);
@@ -1243,30 +1336,44 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         stamp(4);
         real tp[NROW];
         newton_point(tp);
-        // step to the boundary: alpha_max = 1 / max_j( -dt_j / t_j, -dl_j / lam_j )  (only rows that move towards the boundary are positive)
-        real rmax = real(0.0);
+        real sg = real(0.0);
+        if (!pmode) {
+            // step to the boundary: alpha_max = 1 / max_j( -dt_j / t_j, -dl_j / lam_j )  (only rows that move towards the boundary are positive)
+            real rmax = real(0.0);
 #pragma unroll
-        for (int j = 0; j < NROW; j++) {
-            bool on = act && j < nrows;
-            real dt_ = tp[j] - R.t[j], dl_ = -(R.lam[j] * it_[j]) * tp[j];     // lambda+ - lambda with sigma*mu = 0, corr = 0
-            R.corr[j] = dt_ * dl_;
-            real rj = fmax(-dt_ * it_[j], -dl_ * frcp(R.lam[j]));
-            rmax = fmax(rmax, on ? rj : real(0.0));
-        }
-        rmax = wave_max(rmax);
-        real aaff = rmax > real(1.0) ? real(1.0) / rmax : real(1.0);
-        // rounding floor: once mu is within 1e4x of the tolerance and the affine direction can no longer move (step to the boundary < 0.3),
-        // further iterations only add noise (observed on long, ill-conditioned horizons): accept the iterate as it stands
-        if (mu <= real(1e4) * C.ipm_tol && aaff < real(0.3) && phi * fmax(rp0, real(1.0)) <= C.ipm_tol) { status = PG_SOLVED; break; }
-        real msum = real(0.0);
+            for (int j = 0; j < NROW; j++) {
+                bool on = act && j < nrows;
+                real dt_ = tp[j] - R.t[j], dl_ = -(R.lam[j] * it_[j]) * tp[j];     // lambda+ - lambda with sigma*mu = 0, corr = 0
+                R.corr[j] = dt_ * dl_;
+                real rj = fmax(-dt_ * it_[j], -dl_ * frcp(R.lam[j]));
+                rmax = fmax(rmax, on ? rj : real(0.0));
+            }
+            rmax = wave_max(rmax);
+            real aaff = rmax > real(1.0) ? real(1.0) / rmax : real(1.0);
+            // rounding floor: once mu is within 1e4x of the tolerance and the affine direction can no longer move (step to the boundary < 0.3),
+            // further iterations only add noise (observed on long, ill-conditioned horizons): accept the iterate as it stands
+            if (mu <= real(1e4) * C.ipm_tol && aaff < real(0.3) && phi * fmax(rp0, real(1.0)) <= C.ipm_tol) {
+                status = PG_SOLVED;
+                if (!C.polish) break;
+                enter_polish();
+                continue;
+            }
+            real msum = real(0.0);
 #pragma unroll
-        for (int j = 0; j < NROW; j++) {
-            real dt_ = tp[j] - R.t[j], dl_ = -(R.lam[j] * it_[j]) * tp[j];
-            msum += (act && j < nrows) ? (R.t[j] + aaff * dt_) * (R.lam[j] + aaff * dl_) : real(0.0);
+            for (int j = 0; j < NROW; j++) {
+                real dt_ = tp[j] - R.t[j], dl_ = -(R.lam[j] * it_[j]) * tp[j];
+                msum += (act && j < nrows) ? (R.t[j] + aaff * dt_) * (R.lam[j] + aaff * dl_) : real(0.0);
+            }
+            real mu_aff = wave_sum(msum) / ntot;
+            sg = fmin(mu_aff / mu, real(1.0)); sg = sg * sg * sg;          // Mehrotra centring parameter, never above 1
+            if (PROF && b == C.dbg_instance && lane == 0 && it_total + it < 256) { real* tr = reinterpret_cast<real*>(prof + (size_t)B * 6) + 4 * (it_total + it); tr[1] = aaff; }
+        } else {
+            // first polish solve done: with multiplier estimates as good as the interior point's, it usually verifies at once (no refinement needed)
+            const int pc = polish_check(tp, real(0.01) * ptol);
+            if (pc == 0) break;
+            if (pc == 2) { if (++pmode > PG_POLISH_ROUNDS && polish_failed()) break; continue; }      // the set changed: next round directly
         }
-        real mu_aff = wave_sum(msum) / ntot;
-        real sg = fmin(mu_aff / mu, real(1.0)); sg = sg * sg * sg;          // Mehrotra centring parameter, never above 1
-        // ---- corrector ----
+        // ---- corrector / polish refinement ----
         assemble(sg * mu, false);
         __syncthreads();
         stamp(1);
@@ -1275,35 +1382,42 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         forward(std::true_type{});
         stamp(4);
         newton_point(tp);
-        rmax = real(0.0);
+        if (!pmode) {
+            real rmax = real(0.0);
 #pragma unroll
-        for (int j = 0; j < NROW; j++) {
-            bool on = act && j < nrows;
-            real dt_ = tp[j] - R.t[j], dl_ = (sg * mu - R.corr[j]) * it_[j] - (R.lam[j] * it_[j]) * tp[j];
-            tp[j] = dl_;                              // keep d(lambda); d(t) is recomputed from the stage point below
-            R.corr[j] = dt_;
-            real rj = fmax(-dt_ * it_[j], -dl_ * frcp(R.lam[j]));
-            rmax = fmax(rmax, on ? rj : real(0.0));
-        }
-        rmax = wave_max(rmax);
-        real alpha = rmax > real(0.995) ? real(0.995) / rmax : real(1.0);
+            for (int j = 0; j < NROW; j++) {
+                bool on = act && j < nrows;
+                real dt_ = tp[j] - R.t[j], dl_ = (sg * mu - R.corr[j]) * it_[j] - (R.lam[j] * it_[j]) * tp[j];
+                tp[j] = dl_;                              // keep d(lambda); d(t) is recomputed from the stage point below
+                R.corr[j] = dt_;
+                real rj = fmax(-dt_ * it_[j], -dl_ * frcp(R.lam[j]));
+                rmax = fmax(rmax, on ? rj : real(0.0));
+            }
+            rmax = wave_max(rmax);
+            real alpha = rmax > real(0.995) ? real(0.995) / rmax : real(1.0);
 #pragma unroll
-        for (int j = 0; j < NROW; j++) {
-            bool on = act && j < nrows;
-            R.t[j] += on ? alpha * R.corr[j] : real(0.0); R.lam[j] += on ? alpha * tp[j] : real(0.0);
-        }
-        if (act) {
+            for (int j = 0; j < NROW; j++) {
+                bool on = act && j < nrows;
+                R.t[j] += on ? alpha * R.corr[j] : real(0.0); R.lam[j] += on ? alpha * tp[j] : real(0.0);
+            }
+            if (act) {
 #pragma unroll
-            for (int m = 0; m < 8; m++) { real c = SXs[m]; SXs[m] = c + alpha * (xn[m] - c); }
-            real c1 = SGs[0], c2 = SGs[1], c3 = SGs[2];
-            SGs[0] = c1 + alpha * (sn1 - c1); SGs[1] = c2 + alpha * (sn2 - c2); SGs[2] = c3 + alpha * (snh - c3);
+                for (int m = 0; m < 8; m++) { real c = SXs[m]; SXs[m] = c + alpha * (xn[m] - c); }
+                real c1 = SGs[0], c2 = SGs[1], c3 = SGs[2];
+                SGs[0] = c1 + alpha * (sn1 - c1); SGs[1] = c2 + alpha * (sn2 - c2); SGs[2] = c3 + alpha * (snh - c3);
+            }
+            phi *= (real(1.0) - alpha);
+            if (PROF && b == C.dbg_instance && lane == 0 && it_total + it < 256) {      // trace region behind the [B][6] cycle counters: (mu, aaff, sigma, alpha) per iteration
+                real* tr = reinterpret_cast<real*>(prof + (size_t)B * 6) + 4 * (it_total + it);
+                tr[0] = mu; tr[2] = sg; tr[3] = alpha;
+            }
+            if (mu > real(1e8) * C.ipm_mu0) break;          // diverging: give up on this start
+            it++;
+        } else {
+            const int pc = polish_check(tp, ptol);
+            if (pc == 0) break;
+            if (++pmode > PG_POLISH_ROUNDS && polish_failed()) break;      // set changed, or the multiplier iteration has not settled yet: another round
         }
-        phi *= (real(1.0) - alpha);
-        if (PROF && b == C.dbg_instance && lane == 0 && it_total + it < 256) {      // trace region behind the [B][6] cycle counters: (mu, aaff, sigma, alpha) per iteration
-            real* tr = reinterpret_cast<real*>(prof + (size_t)B * 6) + 4 * (it_total + it);
-            tr[0] = mu; tr[1] = aaff; tr[2] = sg; tr[3] = alpha;
-        }
-        if (mu > real(1e8) * C.ipm_mu0) break;          // diverging: give up on this start
     }
     it_total += it;
     if (status == PG_SOLVED || status == PG_NUMERICAL) break;
@@ -1322,6 +1436,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         unsigned mask = 0;
 #pragma unroll
         for (int j = 0; j < NROW; j++) if (j < nrows && R.lam[j] > R.t[j]) mask |= (1u << j);
+        if (pstat != 0) mask = pstat > 0 ? amask : mask_ipm;       // polish ran: its verified set, or the interior point's when it did not verify
         O.active[(size_t)b * N + s] = (uint16_t)mask;
     }
     if (lane == 0) {
@@ -1330,7 +1445,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         if (C.formulation == PG_DECOUPLED) Fx = nodes[((size_t)b * NN + 1) * 10 + 7];      // decoupled_lat_long.jl:275-278: Fx of the seeded node 2
         real* U = O.u_out + (size_t)b * 3;
         U[0] = d; U[1] = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac; U[2] = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
-        O.status[b] = status; O.iters[b] = it; O.mu[b] = mu; O.solved[b] = 1;      // model_predictive_control.jl:76: solved = true
+        O.status[b] = status; O.iters[b] = it; O.mu[b] = mu; O.polish[b] = pstat; O.solved[b] = 1;      // model_predictive_control.jl:76: solved = true
     }
 }
 

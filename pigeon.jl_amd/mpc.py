@@ -35,17 +35,23 @@ class BatchedTrajectoryTrackingMPC:
 
     def __init__(self, trajectory, batch_capacity, vehicle=None, control_params=None, N_short=10, N_long=20, dt_short=0.01, dt_long=0.2,
                  use_correction_step=True, rk4_substeps=10, device=0, ipm_max_iter=40, ipm_tol=None, ipm_mu0=100.0, hji_eps=0.05, formulation="coupled",
-                 precision="f64", walls=False, wall_weight=1000.0):
+                 precision="f64", walls=False, wall_weight=1000.0, polish=True, polish_rho=None, polish_tol=None, polish_ipm_tol=None):
         self.precision = precision
         self.real = np.float64 if precision == "f64" else np.float32      # element type of DEVICE arrays handed to the *_dev entry points
-        if ipm_tol is None:
-            # fp32: the interior point stalls near 1e-5 (coupled) / 1e-4 (the ill-conditioned 8 s lateral horizon); see tests/test_gpu_f32.py
-            ipm_tol = 1e-12 if precision == "f64" else (1e-5 if formulation == "coupled" else 1e-4)
         self.lib = _lib.load_library(precision)
         cfg = _lib.pg_config()
         assert formulation in ("coupled", "decoupled")
         self.formulation = formulation
         (self.lib.pg_default_config if formulation == "coupled" else self.lib.pg_default_config_decoupled)(C.byref(cfg))
+        # solver tolerances default to the library's own (they depend on its arithmetic type: pg_default_config*)
+        ipm_tol = cfg.ipm_tol if ipm_tol is None else ipm_tol
+        cfg.polish = int(bool(polish))
+        if polish_rho is not None:
+            cfg.polish_rho = float(polish_rho)
+        if polish_tol is not None:
+            cfg.polish_tol = float(polish_tol)
+        if polish_ipm_tol is not None:
+            cfg.polish_ipm_tol = float(polish_ipm_tol)
         self.vehicle = X1() if vehicle is None else dict(vehicle)
         default_cp = CoupledControlParams() if formulation == "coupled" else DecoupledControlParams()
         self.control_params = default_cp if control_params is None else dict(control_params)
@@ -210,12 +216,13 @@ class BatchedTrajectoryTrackingMPC:
         qh = uh = None; dq = du = None
         if record:
             import torch
-            dq = torch.empty(steps, self.B, 6, dtype=torch.float64, device=f"cuda:{self.cfg.device}"); du = torch.empty(steps, self.B, 3, dtype=torch.float64, device=f"cuda:{self.cfg.device}")
+            tdt = torch.float64 if self.precision == "f64" else torch.float32         # device records have the library's own element type
+            dq = torch.empty(steps, self.B, 6, dtype=tdt, device=f"cuda:{self.cfg.device}"); du = torch.empty(steps, self.B, 3, dtype=tdt, device=f"cuda:{self.cfg.device}")
         self._chk(self.lib.pg_simulate_dev(self.h, steps, C_.c_double(dt), C_.c_void_p(dq.data_ptr()) if record else None, C_.c_void_p(du.data_ptr()) if record else None), "pg_simulate_dev")
         s = np.zeros((self.B, 6)); c = np.zeros((self.B, 3)); t = np.zeros(self.B)
         self._chk(self.lib.pg_get_state(self.h, _p(s), _p(c), _p(t)), "pg_get_state")
         if record:
-            qh = dq.cpu().numpy(); uh = du.cpu().numpy()
+            qh = dq.cpu().numpy().astype(np.float64); uh = du.cpu().numpy().astype(np.float64)
         return s, c, t, qh, uh
 
     def synchronize(self):
@@ -261,6 +268,12 @@ class BatchedTrajectoryTrackingMPC:
         self._chk(self.lib.pg_get_solve_info(self.h, _p(st, C.POINTER(C.c_int32)), _p(it, C.POINTER(C.c_int32)), _p(act, C.POINTER(C.c_uint16)), _p(mu)),
                   "pg_get_solve_info")
         return st, it, act, mu
+
+    def polish_info(self):
+        """Per instance: 0 polish not run, k >= 1 verified in round k, -1 not verified (interior-point iterate kept)."""
+        p = np.zeros(self.B, dtype=np.int32)
+        self._chk(self.lib.pg_get_polish_info(self.h, _p(p, C.POINTER(C.c_int32))), "pg_get_polish_info")
+        return p
 
     def hji_constraint(self):
         M = np.zeros((self.B, 2)); b = np.zeros(self.B); V = np.zeros(self.B)
