@@ -61,9 +61,25 @@ def main():
     ap.add_argument("--no-hji", action="store_true")
     ap.add_argument("--no-decoupled", action="store_true")
     ap.add_argument("--no-f32", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend for --gpus > 1: nccl = RCCL over xGMI (the product path); gloo = host-staged gather with the ranks sharing whatever GPUs exist "
+                         "(test mode: exercises launch -> shard -> step -> gather end to end on a 1-GPU box)")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64",
                     help="arithmetic type of the headline run: f64 = BASELINE configs[1] (default, the metric's config); f32 with --batch 8192 --gpus 8 = configs[3]")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` (N > 1) started as a plain process: launch the N ranks ourselves, one process per GPU, through torch.distributed.run as a
+    # CHILD process -- decided before anything here touches the GPU (no HIP call, no torch.cuda call has happened yet; a process that initialised the GPU
+    # must never exec another program on this pool).  Rank 0 of the children prints the JSON line; this parent only forwards the exit code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk_:
+            sk_.bind(("127.0.0.1", 0)); port = sk_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
@@ -73,10 +89,15 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    if args.backend == "gloo":
+        local = local % torch.cuda.device_count()          # test mode: ranks may share a GPU
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     B = args.batch
     traj = pkg.load_path_fixture("skidpadoval")
@@ -96,7 +117,12 @@ def main():
             mpc.reset()                                   # solved = false for every instance (hipMemsetAsync on the same stream)
         mpc.step_dev(u_out.data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(gathered, u_out)  # RCCL over xGMI: the only collective on the path
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(gathered, u_out)  # RCCL over xGMI: the only collective on the path
+            else:
+                g_host = torch.empty(world * B, 3, dtype=tdt)
+                dist.all_gather_into_tensor(g_host, u_out.cpu())
+                gathered.copy_(g_host)
 
     def sync():
         if world > 1:
@@ -115,7 +141,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t_begin
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -134,6 +160,8 @@ def main():
 
     st, it, act, mu = mpc.solve_info()
     ok = int((st == pkg.SOLVED).sum())
+    # the gathered controls hold every rank's shard: this rank's block equals its own output
+    gather_ok = True if world == 1 else bool(torch.equal(gathered[rank * B:(rank + 1) * B], u_out) and torch.isfinite(gathered).all().item())
 
     # BASELINE config 5: decoupled (lateral) MPC, N = 50 (N_short = 10, N_long = 40), same batch, cold every step (that formulation has no warm branch)
     dec = None
@@ -257,7 +285,7 @@ def main():
                          "note": f"algorithmic HBM bytes are {bytes_per_solve} B/solve (SURVEY 8d): the step is VALU/LDS/latency bound by construction, not HBM bound"},
             "phase_ms": {n: float(v) for n, v in zip(names, ph)},
             "warm_value": world * B * args.steps / warm_elapsed,
-            "solved": f"{ok}/{B}", "ipm_iters_mean": float(np.mean(it)), "ipm_iters_max": int(np.max(it)),
+            "solved": f"{ok}/{B}", "gather_ok": gather_ok, "ipm_iters_mean": float(np.mean(it)), "ipm_iters_max": int(np.max(it)),
         }
         if hji is not None:
             line["hji_lookup"] = hji

@@ -72,28 +72,44 @@ def test_random_subset_against_oracle(run, oracle_mod, skidpad):
     assert worst < 1e-6, worst
 
 
-def test_accuracy_distribution_over_the_batch(run, oracle_mod, skidpad):
-    """Applied control against the exact optimum of the same QP data for every 4th instance of the 4096 batch (1024 oracle solves, threaded).
-    Measured over all 4096 (tools/gpu_accuracy_full.py): median 2e-12, 99.9th percentile 2.5e-7, 3 instances between 1e-6 and 3e-6 -- nearly
-    degenerate instances (a row whose slack and multiplier are both ~sqrt(mu)) approach the optimum like sqrt(mu) and the rounding noise of the
-    Newton systems forbids mu < 1e-13.  The bar asserted here: 99.5 % within 1e-6, every instance within 1e-5."""
+def test_accuracy_of_every_instance_of_the_batch(run, oracle_mod, skidpad, pkg):
+    """BASELINE north star: controls within 1e-6 (rel-inf, normalised controls) of the reference on identical inputs, active-set indices bit-exact.
+    Here for EVERY one of the 4096 config-2 instances (threaded oracle, exact optimum of the same QP data):
+      * applied control and every control of the horizon <= 1e-6 (measured: 5e-11 / 2e-9 -- the active-set polish removed the sqrt(mu) tail that left
+        3 of 4096 instances at 1e-6..3e-6 in round 1);
+      * whole primal solution (states) <= 1e-6 relative;
+      * the signed canonical active-set list identical to the oracle's, except on rows that are degenerate in the oracle's own solution
+        (|multiplier| <= 1e-6 there: which side of "active" such a row falls on is not defined by the QP);
+      * every instance polished (verified KKT point), none fell back to the interior-point iterate."""
     from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as om
     mpc, state, control, t0, toff, u, status, iters = run
-    qp = mpc.qp_data(); x, _ = mpc.solution()
-    nthr = 8
+    qp = mpc.qp_data(); x, _ = mpc.solution(); _, _, act, _ = mpc.solve_info(); pol = mpc.polish_info()
+    assert np.all(pol >= 1), np.bincount(pol + 1)
+    nthr = min(16, len(os.sched_getaffinity(0)))
     orcs = [make_oracle(oracle_mod, skidpad) for _ in range(nthr)]
-    sel = np.arange(0, B, 4)
 
     def work(w):
-        out = []
-        for b in sel[w::nthr]:
-            xe, ye, info = orcs[w].solve_exact(qp[b])
-            out.append(float(np.max(np.abs(x[b, 1, 6:] - orcs[w].split_x(xe)["u"][1]))) if info["status"] == 1 else np.nan)
+        o = orcs[w]; out = []
+        for b in range(w, B, nthr):
+            xe, ye, info = o.solve_exact(qp[b]); X = o.split_x(xe)
+            assert info["status"] == 1
+            e_u2 = float(np.max(np.abs(x[b, 1, 6:] - X["u"][1]))); e_u = float(np.max(np.abs(x[b, :, 6:] - X["u"])))
+            e_q = float(np.max(np.abs(x[b, :, :6] - X["q"]) / np.maximum(1.0, np.abs(X["q"]))))
+            Q = o.assemble_qp(qp[b])
+            mine = set(mpc.canonical_active_set(b, act[b], qp[b])); theirs = set(om.active_set(Q, xe, ye, tol=1e-6))
+            diff = mine ^ theirs
+            bad = [i for i in diff if abs(ye[abs(i) - 1]) > 1e-4]          # a disagreement on a row the oracle holds with a real multiplier
+            out.append((e_u2, e_u, e_q, len(bad), len(diff)))
         return out
     with ThreadPoolExecutor(nthr) as ex:
-        err = np.array(sum(ex.map(work, range(nthr)), []))
-    assert not np.any(np.isnan(err))
-    assert np.mean(err <= 1e-6) >= 0.995 and err.max() <= 1e-5 and np.median(err) <= 1e-9, (np.mean(err <= 1e-6), err.max(), np.median(err))
+        res = np.array(sum(ex.map(work, range(nthr)), []))
+    assert res.shape == (B, 5)
+    assert res[:, 0].max() <= 1e-6 and res[:, 1].max() <= 1e-6 and res[:, 2].max() <= 1e-6, res.max(axis=0)
+    assert np.median(res[:, 0]) <= 1e-11
+    assert res[:, 3].sum() == 0, int(res[:, 3].sum())
+    assert np.mean(res[:, 4] == 0) >= 0.98                            # and the lists are IDENTICAL for (nearly) all instances
+    print(f"max |u2-u2*| {res[:, 0].max():.2e}, max |u-u*| {res[:, 1].max():.2e}, max rel |q-q*| {res[:, 2].max():.2e}, identical active-set lists {int((res[:, 4] == 0).sum())}/{B}")
 
 
 def test_golden_cases_on_gpu(pkg):
