@@ -24,7 +24,7 @@ struct pg_handle {
     int* d_solved = nullptr; uint8_t* d_mask = nullptr;     // d_mask: staging of pg_reset's per-instance mask
     double *d_ts = nullptr, *d_dt = nullptr, *d_prev_ts = nullptr;
     real *d_sep = nullptr, *d_nodes = nullptr, *d_qp = nullptr;
-    real *d_x7 = nullptr, *d_vg8 = nullptr, *d_Mb = nullptr, *d_abar = nullptr;
+    real *d_x7 = nullptr, *d_vg8 = nullptr, *d_Mb = nullptr;
     real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     real *d_pol_u2 = nullptr, *d_pol_u = nullptr; int* d_pol_src = nullptr;   // HJI fallback policy (HJI_computation.jl:133-158)
     int *d_status = nullptr, *d_iters = nullptr, *d_polish = nullptr; uint16_t* d_active = nullptr;
@@ -133,7 +133,7 @@ int pg_default_config_decoupled(pg_config* c) {
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_state, h->d_control, h->d_t0, h->d_other, h->d_toff, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_abar, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->ev_ok) for (int i = 0; i < 4; i++) (void)hipEventDestroy(h->ev[i]);
 }
@@ -176,7 +176,6 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_state, cap * 6, real); ALLOC(h->d_control, cap * 3, real); ALLOC(h->d_t0, cap, double); ALLOC(h->d_other, cap * 4, real); ALLOC(h->d_toff, cap, double);
     ALLOC(h->d_solved, cap, int); ALLOC(h->d_mask, cap, uint8_t); ALLOC(h->d_ts, cap * NN, double); ALLOC(h->d_dt, cap * N, double); ALLOC(h->d_prev_ts, cap * NN, double);
     ALLOC(h->d_sep, cap * 4, real); ALLOC(h->d_nodes, cap * NN * 10, real); ALLOC(h->d_qp, cap * C.qp_len, real);
-    ALLOC(h->d_abar, cap * N * SB, real);
     ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
     ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_u, cap * 3, real); ALLOC(h->d_mu, cap, real);
     ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_polish, cap, int); ALLOC(h->d_active, cap * N, uint16_t);
@@ -433,7 +432,7 @@ int pg_update_qp(pg_handle* h) {
     const int B = h->B; const DevCfg& C = h->dc;
     if (C.formulation == PG_DECOUPLED) {
         long nt = (long)B * C.N;
-        hipLaunchKernelGGL(k_qp_dec, dim3((unsigned)((nt + 127) / 128)), dim3(128), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_qp, h->d_abar);
+        hipLaunchKernelGGL(k_qp_dec, dim3((unsigned)((nt + 127) / 128)), dim3(128), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_qp);
         LAUNCH_CHECK(h);
         return PG_OK;
     }
@@ -444,11 +443,8 @@ int pg_update_qp(pg_handle* h) {
         hipLaunchKernelGGL(k_hji_constraint, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, h->d_x7, h->d_vg8, h->d_control, h->d_Mb);
         LAUNCH_CHECK(h);
     }
-    long nl = (long)B * C.N * 5;
-    hipLaunchKernelGGL(k_linearize, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_qp);
-    LAUNCH_CHECK(h);
-    long nt = (long)B * C.N;
-    hipLaunchKernelGGL(k_limits, dim3((unsigned)((nt * 8 + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp, h->d_abar);
+    long nl = (long)B * C.N * 2;         // two lanes per (instance, interval)
+    hipLaunchKernelGGL(k_linearize, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp);
     LAUNCH_CHECK(h);
     return PG_OK;
 }
@@ -456,10 +452,10 @@ int pg_solve(pg_handle* h) {
     int rc = check_ready(h); if (rc) return rc;
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish};
 #ifdef PG_EXPERIMENTAL_SOLVE4
-    if (h->solve_quad) { hipLaunchKernelGGL((k_solve4<2, false>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, h->d_ws4, O, (unsigned long long*)nullptr); LAUNCH_CHECK(h); return PG_OK; }
+    if (h->solve_quad) { hipLaunchKernelGGL((k_solve4<2, false>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, (unsigned long long*)nullptr); LAUNCH_CHECK(h); return PG_OK; }
 #endif
-    if (h->solve_ring) hipLaunchKernelGGL((k_solve<false, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, (unsigned long long*)nullptr);
-    else hipLaunchKernelGGL((k_solve<false, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, (unsigned long long*)nullptr);
+    if (h->solve_ring) hipLaunchKernelGGL((k_solve<false, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr);
+    else hipLaunchKernelGGL((k_solve<false, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr);
     LAUNCH_CHECK(h);
     return PG_OK;
 }
@@ -472,11 +468,11 @@ int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     HIPCHK(h, hipMemset(d, 0, ((size_t)h->B * 6 + 1024) * 8));
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish};
 #ifdef PG_EXPERIMENTAL_SOLVE4
-    if (h->solve_quad) hipLaunchKernelGGL((k_solve4<2, true>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, h->d_ws4, O, d);
+    if (h->solve_quad) hipLaunchKernelGGL((k_solve4<2, true>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, d);
     else
 #endif
-    if (h->solve_ring) hipLaunchKernelGGL((k_solve<true, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, d);
-    else hipLaunchKernelGGL((k_solve<true, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_abar, h->d_nodes, O, d);
+    if (h->solve_ring) hipLaunchKernelGGL((k_solve<true, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, d);
+    else hipLaunchKernelGGL((k_solve<true, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, d);
     LAUNCH_CHECK(h);
     HIPCHK(h, hipMemcpy(out, d, ((size_t)h->B * 6 + 1024) * 8, hipMemcpyDeviceToHost));      // out: [B][6] cycles + 1024-double trace of PG_DEBUG_INSTANCE
     (void)hipFree(d);

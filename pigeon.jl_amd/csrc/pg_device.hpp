@@ -79,6 +79,36 @@ template <class T> PG_DEV T cst(real x);
 template <> PG_DEV real cst<real>(real x) { return x; }
 template <> PG_DEV D2 cst<D2>(real x) { return D2(x); }
 
+// ---- K-tangent forward-mode number (k_linearize carries 4 directions per lane: one primal trajectory serves four Jacobian columns) ----
+template <int K> struct DK {
+    real v, d[K];
+    PG_DEV DK() {}
+    PG_DEV DK(real x) : v(x) {
+#pragma unroll
+        for (int k = 0; k < K; k++) d[k] = real(0.0);
+    }
+};
+#define PG_DK_LOOP _Pragma("unroll") for (int k = 0; k < K; k++)
+template <int K> PG_DEV DK<K> operator+(DK<K> x, DK<K> y) { DK<K> r; r.v = x.v + y.v; PG_DK_LOOP r.d[k] = x.d[k] + y.d[k]; return r; }
+template <int K> PG_DEV DK<K> operator-(DK<K> x, DK<K> y) { DK<K> r; r.v = x.v - y.v; PG_DK_LOOP r.d[k] = x.d[k] - y.d[k]; return r; }
+template <int K> PG_DEV DK<K> operator-(DK<K> x) { DK<K> r; r.v = -x.v; PG_DK_LOOP r.d[k] = -x.d[k]; return r; }
+template <int K> PG_DEV DK<K> operator*(DK<K> x, DK<K> y) { DK<K> r; r.v = x.v * y.v; PG_DK_LOOP r.d[k] = x.d[k] * y.v + x.v * y.d[k]; return r; }
+template <int K> PG_DEV DK<K> operator/(DK<K> x, DK<K> y) { real inv = frcp(y.v), q = x.v * inv; DK<K> r; r.v = q; PG_DK_LOOP r.d[k] = (x.d[k] - q * y.d[k]) * inv; return r; }
+template <int K> PG_DEV DK<K> operator+(DK<K> x, real y) { x.v += y; return x; }
+template <int K> PG_DEV DK<K> operator+(real y, DK<K> x) { x.v += y; return x; }
+template <int K> PG_DEV DK<K> operator-(DK<K> x, real y) { x.v -= y; return x; }
+template <int K> PG_DEV DK<K> operator-(real y, DK<K> x) { DK<K> r; r.v = y - x.v; PG_DK_LOOP r.d[k] = -x.d[k]; return r; }
+template <int K> PG_DEV DK<K> operator*(DK<K> x, real y) { x.v *= y; PG_DK_LOOP x.d[k] *= y; return x; }
+template <int K> PG_DEV DK<K> operator*(real y, DK<K> x) { x.v *= y; PG_DK_LOOP x.d[k] *= y; return x; }
+template <int K> PG_DEV DK<K> operator/(DK<K> x, real y) { real inv = frcp(y); x.v *= inv; PG_DK_LOOP x.d[k] *= inv; return x; }
+template <int K> PG_DEV DK<K> operator/(real x, DK<K> y) { real inv = frcp(y.v), q = x * inv; DK<K> r; r.v = q; PG_DK_LOOP r.d[k] = -q * y.d[k] * inv; return r; }
+template <int K> PG_DEV real val(DK<K> x) { return x.v; }
+template <int K> PG_DEV DK<K> chain(DK<K> x, real f, real df) { DK<K> r; r.v = f; PG_DK_LOOP r.d[k] = df * x.d[k]; return r; }
+template <int K> PG_DEV void sincos_(DK<K> x, DK<K>& s, DK<K>& c) { real sv, cv; pg_sincos(x.v, &sv, &cv); s = chain(x, sv, cv); c = chain(x, cv, -sv); }
+template <int K> PG_DEV DK<K> sqrt_(DK<K> x) { real s = sqrt(x.v); return chain(x, s, real(0.5) * frcp(s)); }
+template <int K> PG_DEV DK<K> abs_(DK<K> x) { return x.v < real(0.0) ? -x : x; }
+template <> PG_DEV DK<4> cst<DK<4>>(real x) { return DK<4>(x); }
+
 // Julia min/max propagate NaN
 PG_DEV real jmin(real a, real b) { return (a != a || b != b) ? NAN : (b < a ? b : a); }
 PG_DEV real jmax(real a, real b) { return (a != a || b != b) ? NAN : (b > a ? b : a); }

@@ -54,9 +54,9 @@ PG_DEV TrajView traj_of(const DevCfg& C, int b) {
     return T;
 }
 
-// Packed stage block streamed by k_solve: rows 0..5 of Abar = [A | B0+Bf] at a row stride of 9 doubles (odd stride: the 8 rows land on distinct LDS
+// Stage block as k_solve keeps it in LDS (packed from the QP data on the way in): rows 0..5 of Abar = [A | B0+Bf] at a row stride of 9 doubles (odd stride: the 8 rows land on distinct LDS
 // banks, so the row-indexed reads of the Riccati passes are conflict-free), then Bbar = Bf (12) at SB_B, cbar = c (6) at SB_C.
-constexpr int SB = 72, SB_ROW = 9, SB_B = 54, SB_C = 66, SB_CHUNKS = SB / 2;
+constexpr int SB = 72, SB_ROW = 9, SB_B = 54, SB_C = 66;
 
 // offsets inside one instance's QP block (doubles); same order as pg_get_qp documents
 struct QpOff { int A, B0, Bf, c, H, G, dmin, dmax, fxmax, ddmin, ddmax, dt, qcurr, ucurr, M, b; };
@@ -229,36 +229,46 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// linearize: RK4 (nsub sub-steps) of the tracking model with two tangent directions per lane.
-// lane -> (instance, interval t, group g); group g carries tangents {2g, 2g+1} of (q[0..5], u0[0..1], uf[0..1]).
-// Writes raw Jacobian columns; group 0 also writes Phi (the propagated state) into the c slot.  k_limits finishes c and scales B.
-__global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, real* __restrict__ qp) {
+// update_QP! of the coupled formulation (coupled_lat_long.jl:315-368) in ONE kernel: `linearize` of every interval + c + u-normalisation (:335-353), the
+// stability envelope and the bounds (:354-367), q_curr/u_curr (:332-333) and the safety row (:345-346).
+// linearize = RK4 (nsub sub-steps) of VehicleModel{TrackingBicycleModel} on forward-mode numbers (third-party LinearDynamicsModels; restated in DESIGN.md 2).
+// TWO lanes per (instance, interval), four tangent directions each (DK<4>): lane 0 carries d/d(Ux, Uy, r, dpsi), lane 1 d/d(u0[0], u0[1], uf[0], uf[1]).
+// The tracking model does not read ds or e (vehicle_dynamics.jl:159-183: neither appears on the right-hand side), so dPhi/d(ds) = e_0 and dPhi/d(e) = e_5
+// EXACTLY -- those two columns of A are written as constants instead of being integrated (round 1 propagated all ten tangents in five lanes of two, i.e.
+// five primal trajectories per interval; now two).  c = Phi - A q - B0 u0 - Bf uf is finished in the same lanes (one shuffle inside the lane pair), lane 1
+// also evaluates stable_limits for the interval.
+__global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb, real* __restrict__ qp) {
+    typedef DK<4> D4;
     long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long per = (long)C.N * 5;
-    if (gid >= (long)B * per) return;
-    int b = (int)(gid / per); int rem = (int)(gid - (long)b * per); int t = rem / 5, g = rem - t * 5;
-    bool ramp = t >= C.Ns;
-    if (!ramp && g == 4) return;
+    const long per = (long)C.N * 2;
+    const bool live = gid < (long)B * per;
+    if (!live) gid = (long)B * per - 1;                       // keep the lane pair whole for the shuffle; dead lanes store nothing
+    const int b = (int)(gid / per); const int rem = (int)(gid - (long)b * per); const int t = rem >> 1, g = rem & 1;
+    const bool ramp = t >= C.Ns;
     const real* n0 = nodes + ((size_t)b * C.NN + t) * 10; const real* n1 = n0 + 10;
-    real h_total = dt[(size_t)b * C.N + t];
-    D2 x[6];
+    const real h_total = dt[(size_t)b * C.N + t];
+    D4 x[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) x[k] = D2(n0[k], (2 * g == k) ? real(1.0) : real(0.0), (2 * g + 1 == k) ? real(1.0) : real(0.0));
-    D2 u0a(n0[6], g == 3 ? real(1.0) : real(0.0), real(0.0)), u0b(n0[7], real(0.0), g == 3 ? real(1.0) : real(0.0));
-    D2 ufa(ramp ? n1[6] : n0[6], g == 4 ? real(1.0) : real(0.0), real(0.0)), ufb(ramp ? n1[7] : n0[7], real(0.0), g == 4 ? real(1.0) : real(0.0));
-    real pV0 = n0[8], pK0 = n0[9], pV1 = ramp ? n1[8] : n0[8], pK1 = ramp ? n1[9] : n0[9];
+    for (int k = 0; k < 6; k++) {
+        x[k] = D4(n0[k]);
+#pragma unroll
+        for (int d = 0; d < 4; d++) x[k].d[d] = (g == 0 && k == d + 1) ? real(1.0) : real(0.0);
+    }
+    D4 u0a(n0[6]), u0b(n0[7]), ufa(ramp ? n1[6] : n0[6]), ufb(ramp ? n1[7] : n0[7]);
+    if (g == 1) { u0a.d[0] = real(1.0); u0b.d[1] = real(1.0); ufa.d[2] = real(1.0); ufb.d[3] = real(1.0); }
+    const real pV0 = n0[8], pK0 = n0[9], pV1 = ramp ? n1[8] : n0[8], pK1 = ramp ? n1[9] : n0[9];
     const int nsub = C.nsub; const real h = h_total / nsub;
-    auto rhs = [&](const D2* xx, real tau, D2* out) {
+    auto rhs = [&](const D4* xx, real tau, D4* out) {
         real w = ramp ? tau / h_total : real(0.0);
-        D2 ua = u0a + (ufa - u0a) * w, ub = u0b + (ufb - u0b) * w;
-        tracking_rhs<D2>(C.veh, xx, ua, ub, pV0 + (pV1 - pV0) * w, pK0 + (pK1 - pK0) * w, out);
+        D4 ua = u0a + (ufa - u0a) * w, ub = u0b + (ufb - u0b) * w;
+        tracking_rhs<D4>(C.veh, xx, ua, ub, pV0 + (pV1 - pV0) * w, pK0 + (pK1 - pK0) * w, out);
     };
 #pragma unroll 1
     for (int i = 0; i < nsub; i++) {
         const real t0 = i * h;
-        D2 kk[6], xx[6], acc[6];
+        D4 kk[6], xx[6], acc[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) { xx[k] = x[k]; acc[k] = D2(real(0.0)); }
+        for (int k = 0; k < 6; k++) { xx[k] = x[k]; acc[k] = D4(real(0.0)); }
         // classical RK4 written as one rolled stage loop (one instance of the dynamics in the instruction stream, fewer live registers)
 #pragma unroll 1
         for (int st = 0; st < 4; st++) {
@@ -272,76 +282,60 @@ __global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const real* 
 #pragma unroll
         for (int k = 0; k < 6; k++) x[k] = x[k] + acc[k] * (h / real(6.0));
     }
-    QpOff o = qp_offsets(C.N);
-    real* Q = qp + (size_t)b * C.qp_len;
-    if (g < 3) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) { Q[o.A + 36 * t + 6 * i + 2 * g] = x[i].a; Q[o.A + 36 * t + 6 * i + 2 * g + 1] = x[i].b; }
-    } else if (g == 3) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) { Q[o.B0 + 12 * t + 2 * i] = x[i].a; Q[o.B0 + 12 * t + 2 * i + 1] = x[i].b; }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 6; i++) { Q[o.Bf + 12 * t + 2 * i] = x[i].a; Q[o.Bf + 12 * t + 2 * i + 1] = x[i].b; }
-    }
+    // this lane's share of c_i = Phi_i - A_i. q - B0_i. u0 - Bf_i. uf   (raw, un-normalised Jacobians: coupled_lat_long.jl:336-353)
+    real part[6];
     if (g == 0) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) Q[o.c + 6 * t + i] = x[i].v;
+        for (int i = 0; i < 6; i++) {
+            real ci = x[i].v - (x[i].d[0] * n0[1] + x[i].d[1] * n0[2] + x[i].d[2] * n0[3] + x[i].d[3] * n0[4]);
+            if (i == 0) ci -= n0[0];
+            if (i == 5) ci -= n0[5];
+            part[i] = ci;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; i++) part[i] = -(x[i].d[0] * n0[6] + x[i].d[1] * n0[7]) - (ramp ? x[i].d[2] * n1[6] + x[i].d[3] * n1[7] : real(0.0));
     }
-}
-
-// finishes c = Phi - A q - B0 u0 - Bf uf, scales B by u_normalization, stability envelope + bounds (:354-367), q_curr/u_curr (:332-333), HJI row (:345-346).
-// EIGHT lanes per (instance, interval): lane i < 6 owns row i of the linearisation (its loads and stores are contiguous segments and the eight lanes of an
-// interval cover whole cache lines: one lane per interval touched 64 different lines per instruction); lane 6 does the envelope and the bounds, lane 7 the
-// per-instance header of interval 0.
-__global__ __launch_bounds__(256) void k_limits(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb, real* __restrict__ qp,
-                                                real* __restrict__ abar) {
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long it = gid >> 3; const int i = (int)(gid & 7);
-    if (it >= (long)B * C.N) return;
-    const int b = (int)(it / C.N), t = (int)(it - (long)b * C.N);
-    const bool ramp = t >= C.Ns;
-    const real* n0 = nodes + ((size_t)b * C.NN + t) * 10; const real* n1 = n0 + 10;
+#pragma unroll
+    for (int i = 0; i < 6; i++) part[i] += __shfl_xor(part[i], 1);
+    if (!live) return;
     const QpOff o = qp_offsets(C.N);
     real* Q = qp + (size_t)b * C.qp_len;
-    real* P66 = abar + ((size_t)b * C.N + t) * SB;      // packed copy streamed by k_solve: rows 0..5 of Abar = [A | B0+Bf], Bbar = Bf, cbar = c  (SB doubles per stage)
-    if (i < 6) {
-        real* A = Q + o.A + 36 * t + 6 * i; real* B0 = Q + o.B0 + 12 * t + 2 * i; real* Bf = Q + o.Bf + 12 * t + 2 * i; real* c = Q + o.c + 6 * t + i;
-        real ci = c[0];
-        real a[6];
+    if (g == 0) {
+        real* A = Q + o.A + 36 * t;
 #pragma unroll
-        for (int j = 0; j < 6; j++) { a[j] = A[j]; ci -= a[j] * n0[j]; }
-        real b00 = B0[0], b01 = B0[1], bf0 = ramp ? Bf[0] : real(0.0), bf1 = ramp ? Bf[1] : real(0.0);
-        ci -= b00 * n0[6] + b01 * n0[7];
-        if (ramp) ci -= bf0 * n1[6] + bf1 * n1[7];
-        c[0] = ci;
-        b00 *= C.un0; b01 *= C.un1; bf0 *= C.un0; bf1 *= C.un1;                                      // :338,350-351
-        B0[0] = b00; B0[1] = b01; Bf[0] = bf0; Bf[1] = bf1;
-        real* row = P66 + SB_ROW * i;
+        for (int i = 0; i < 6; i++) {
+            A[6 * i] = i == 0 ? real(1.0) : real(0.0);
 #pragma unroll
-        for (int j = 0; j < 6; j++) row[j] = a[j];
-        row[6] = b00 + bf0; row[7] = b01 + bf1; row[8] = real(0.0);
-        P66[SB_B + 2 * i] = bf0; P66[SB_B + 2 * i + 1] = bf1;
-        P66[SB_C + i] = ci;
-    } else if (i == 6) {
-        const real Uxt = n1[1], Fx = n1[7];                                                        // :357-358
+            for (int d = 0; d < 4; d++) A[6 * i + 1 + d] = x[i].d[d];
+            A[6 * i + 5] = i == 5 ? real(1.0) : real(0.0);
+            Q[o.c + 6 * t + i] = part[i];
+        }
+        if (t == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) Q[o.qcurr + k] = n0[k];
+            Q[o.ucurr] = n0[6] / C.un0; Q[o.ucurr + 1] = n0[7] / C.un1;
+            if (C.has_hji) { Q[o.M] = hji_Mb[(size_t)b * 4]; Q[o.M + 1] = hji_Mb[(size_t)b * 4 + 1]; Q[o.b] = hji_Mb[(size_t)b * 4 + 2]; }
+            else { Q[o.M] = real(0.0); Q[o.M + 1] = real(0.0); Q[o.b] = real(1.0); }
+        }
+    } else {
+        real* B0 = Q + o.B0 + 12 * t; real* Bf = Q + o.Bf + 12 * t;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {                                                                   // :338,350-351 (B scaled by u_normalization)
+            B0[2 * i] = x[i].d[0] * C.un0; B0[2 * i + 1] = x[i].d[1] * C.un1;
+            Bf[2 * i] = ramp ? x[i].d[2] * C.un0 : real(0.0); Bf[2 * i + 1] = ramp ? x[i].d[3] * C.un1 : real(0.0);
+        }
+        const real Uxt = n1[1], Fx = n1[7];                                                             // :357-358
         const real Fxf = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac, Fxr = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
         const Envelope e = stable_limits(C.veh, Uxt, Fxf, Fxr);
 #pragma unroll
         for (int r = 0; r < 4; r++) { Q[o.H + 8 * t + 2 * r] = e.H[r][0]; Q[o.H + 8 * t + 2 * r + 1] = e.H[r][1]; Q[o.G + 4 * t + r] = e.G[r]; }
-        const real h = dt[(size_t)b * C.N + t];
         Q[o.dmin + t] = jmax(e.dmin, -C.veh.delta_max) / C.un0;
         Q[o.dmax + t] = jmin(e.dmax, C.veh.delta_max) / C.un0;
         Q[o.fxmax + t] = jmin(C.veh.Px_max / Uxt, C.veh.Fx_max) / C.un1;
-        Q[o.ddmin + t] = -C.cp.deltadot_max * h / C.un0;
-        Q[o.ddmax + t] = C.cp.deltadot_max * h / C.un0;
-        Q[o.dt + t] = h;
-    } else if (t == 0) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) Q[o.qcurr + k] = n0[k];
-        Q[o.ucurr] = n0[6] / C.un0; Q[o.ucurr + 1] = n0[7] / C.un1;
-        if (C.has_hji) { Q[o.M] = hji_Mb[(size_t)b * 4]; Q[o.M + 1] = hji_Mb[(size_t)b * 4 + 1]; Q[o.b] = hji_Mb[(size_t)b * 4 + 2]; }
-        else { Q[o.M] = real(0.0); Q[o.M + 1] = real(0.0); Q[o.b] = real(1.0); }
+        Q[o.ddmin + t] = -C.cp.deltadot_max * h_total / C.un0;
+        Q[o.ddmax + t] = C.cp.deltadot_max * h_total / C.un0;
+        Q[o.dt + t] = h_total;
     }
 }
 
@@ -458,7 +452,7 @@ PG_DEV M4d m4mul(const M4d& x, const M4d& y) { M4d r;
 // continuous Jacobians by forward mode (8 tangent directions: Uy, r, dpsi, e, delta, Fx, Ux, kappa), exact ZOH / FOH discretisation
 // (Ad = exp(A dt), G0 = int exp(A s) ds, G1 = (1/dt) int exp(A (dt - s)) s ds by Taylor series + scaling and squaring), envelope and bounds;
 // the result is written in the embedded coupled layout (QP block + the packed per-stage block k_solve streams).
-__global__ __launch_bounds__(128) void k_qp_dec(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, real* __restrict__ qp, real* __restrict__ abar) {
+__global__ __launch_bounds__(128) void k_qp_dec(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, real* __restrict__ qp) {
     long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)B * C.N) return;
     int b = (int)(gid / C.N), t = (int)(gid - (long)b * C.N);
@@ -523,15 +517,12 @@ __global__ __launch_bounds__(128) void k_qp_dec(DevCfg C, int B, const real* __r
     QpOff o = qp_offsets(C.N);
     real* Q = qp + (size_t)b * C.qp_len;
     real* A6 = Q + o.A + 36 * t; real* B06 = Q + o.B0 + 12 * t; real* Bf6 = Q + o.Bf + 12 * t; real* c6 = Q + o.c + 6 * t;
-    real* P66 = abar + ((size_t)b * C.N + t) * SB;
     for (int i = 0; i < 36; i++) A6[i] = real(0.0);
     for (int i = 0; i < 12; i++) { B06[i] = real(0.0); Bf6[i] = real(0.0); }
-    for (int i = 0; i < SB; i++) P66[i] = real(0.0);
-    A6[0] = real(1.0); A6[7] = real(1.0); P66[0] = real(1.0); P66[SB_ROW + 1] = real(1.0); c6[0] = real(0.0); c6[1] = real(0.0);
+    A6[0] = real(1.0); A6[7] = real(1.0); c6[0] = real(0.0); c6[1] = real(0.0);
     for (int i = 0; i < 4; i++) {
-        for (int j = 0; j < 4; j++) { A6[6 * (2 + i) + 2 + j] = Ad.a[4 * i + j]; P66[SB_ROW * (2 + i) + 2 + j] = Ad.a[4 * i + j]; }
+        for (int j = 0; j < 4; j++) A6[6 * (2 + i) + 2 + j] = Ad.a[4 * i + j];
         B06[2 * (2 + i)] = b0[i]; Bf6[2 * (2 + i)] = bf[i]; c6[2 + i] = cd[i];
-        P66[SB_ROW * (2 + i) + 6] = b0[i] + bf[i]; P66[SB_B + 2 * (2 + i)] = bf[i]; P66[SB_C + 2 + i] = cd[i];
     }
     // envelope and bounds (:262-272): Ux from the NEXT node's parameter, Fx from its seeded control; nothing is normalised here
     real Uxt = n1[1], Fx = n1[7];
@@ -869,7 +860,7 @@ PG_DEV void wave_sync() {
 }
 
 template <bool PROF, bool RING>
-__global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, int B, const real* __restrict__ qp, const real* __restrict__ abar, const real* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof) {
+__global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, int B, const real* __restrict__ qp, const real* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof) {
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int slot) { if (PROF) { unsigned long long now = clock64(); pc[slot] += now - tprev; tprev = now; } };
     if (PROF) tprev = clock64();
@@ -897,18 +888,34 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
 
     const QpOff o = qp_offsets(N);
     const real* Q = qp + (size_t)b * C.qp_len;
-    // ---- LDS ring fed from L2: lane l < 36 moves 16 bytes of the 576-byte stage block; two-deep software pipeline (register, then LDS) ----
-    const real2* gA = reinterpret_cast<const real2*>(abar + (size_t)b * N * SB);
-    const int rlane = lane < SB_CHUNKS ? lane : 0;
-    real2 ring_pre;
+    // ---- stage blocks come straight from the QP data update_QP! wrote (A[N][36], B0[N][12], Bf[N][12], c[N][6]: no second, packed copy in HBM) and are packed
+    // into the LDS layout on the way in: lane l < 36 moves A entry l; lanes 36..47 the (B0, Bf) pair l - 36 (columns 6,7 of Abar are B0 + Bf, Bbar = Bf);
+    // lanes 48..53 move c.  RING: two-deep software pipeline (register, then LDS) through a 4-slot ring; otherwise everything lands once ----
+    const bool mvA = lane < 36, mvB = lane >= 36 && lane < 48, mvC = lane >= 48 && lane < 54;
+    const int src0 = mvA ? o.A + lane : (mvB ? o.B0 + lane - 36 : (mvC ? o.c + lane - 48 : o.A));
+    const int sstr = mvA ? 36 : (mvB ? 12 : (mvC ? 6 : 36));
+    const int src1 = mvB ? o.Bf + lane - 36 : o.Bf;
+    const int dst0 = mvA ? SB_ROW * (lane / 6) + lane % 6 : (mvB ? SB_ROW * ((lane - 36) >> 1) + 6 + ((lane - 36) & 1) : SB_C + lane - 48);
+    const int dst1 = SB_B + lane - 36;
+    real ring_v0, ring_v1;
     auto ring_slot = [&](int k) -> real* { return sRing + (RING ? (k & 3) : k) * SB; };
-    auto ring_load = [&](int k) { int kk = k < 0 ? 0 : (k >= N ? N - 1 : k); ring_pre = gA[kk * SB_CHUNKS + rlane]; };
-    auto ring_put = [&](int k) { real2* dst = lane < SB_CHUNKS ? reinterpret_cast<real2*>(ring_slot(k)) + lane : reinterpret_cast<real2*>(sDum) + (lane & 31); *dst = ring_pre; };
+    auto ring_load = [&](int k) { int kk = k < 0 ? 0 : (k >= N ? N - 1 : k); ring_v0 = Q[src0 + sstr * kk]; ring_v1 = Q[src1 + 12 * kk]; };
+    auto ring_put = [&](int k) {
+        real* slot = ring_slot(k);
+        *((mvA || mvB || mvC) ? slot + dst0 : sDum + lane) = mvB ? ring_v0 + ring_v1 : ring_v0;
+        *(mvB ? slot + dst1 : sDum + lane) = ring_v1;
+    };
     // prime(k0, dir): block k0 lands in the ring, block k0+dir is in flight.  step(k, dir) at the top of stage k: block k+dir lands, k+2dir takes off.
     auto ring_prime = [&](int k0, int dir) { if (RING) { ring_load(k0); ring_put(k0); ring_load(k0 + dir); } };
     auto ring_step = [&](int k, int dir) { if (RING) { ring_put(k + dir); ring_load(k + 2 * dir); } };
     if (!RING) {      // short horizons: every stage block is read from HBM exactly once and stays in LDS (SB N doubles = 17.3 KB at N = 30)
-        for (int i = lane; i < SB_CHUNKS * N; i += 64) reinterpret_cast<real2*>(sRing)[i] = gA[i];
+        for (int k0 = 0; k0 < N; k0 += 6) {      // six stages in flight per lane
+            real v0[6], v1[6];
+#pragma unroll
+            for (int u = 0; u < 6; u++) { const int kk = k0 + u < N ? k0 + u : N - 1; v0[u] = Q[src0 + sstr * kk]; v1[u] = Q[src1 + 12 * kk]; }
+#pragma unroll
+            for (int u = 0; u < 6; u++) if (k0 + u < N) { ring_v0 = v0[u]; ring_v1 = v1[u]; ring_put(k0 + u); }
+        }
     }
     if (lane < 2) sZero[lane] = real(0.0);
     if (lane < 8) sx0[lane] = lane < 6 ? Q[o.qcurr + lane] : Q[o.ucurr + lane - 6];
