@@ -29,6 +29,7 @@ struct DevControl { real V_min, V_max, k_V, k_s, deltadot_max, Q_ds, Q_dpsi, Q_e
 #ifdef PG_F32
 PG_DEV float frcp(float x) { float r = __builtin_amdgcn_rcpf(x); float e = fmaf(-x, r, 1.0f); return fmaf(r, e, r); }
 PG_DEV void pg_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+PG_DEV float pg_rsqrt(float x) { return rsqrtf(x); }
 #else
 PG_DEV double frcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
@@ -37,6 +38,7 @@ PG_DEV double frcp(double x) {
     return r;
 }
 PG_DEV void pg_sincos(double x, double* s, double* c) { sincos(x, s, c); }
+PG_DEV double pg_rsqrt(double x) { return rsqrt(x); }
 #endif
 
 // ---- two-tangent forward-mode number (stands in for ForwardDiff.Dual inside `linearize` and HJI_computation.jl:167) ----
@@ -242,9 +244,16 @@ PG_DEV Envelope stable_limits(const DevVehicle& B, real Ux, real Fxf, real Fxr) 
     return o;
 }
 
-// steady_state_estimates: vehicle_dynamics.jl:319-390
+// steady_state_estimates: vehicle_dynamics.jl:319-390.
+// The fixed point of the reference re-evaluates sincos(beta) and sincos(delta) at the top of every iteration, with beta = atan(..) and
+// delta = atan2(..) - atan(..) produced at the bottom of the previous one.  Here the pair (sin, cos) is carried instead of the angle:
+//   beta = atan(tb)                       =>  cos beta = 1/sqrt(1 + tb^2), sin beta = tb cos beta
+//   delta = atan2(y, Ux) - atan(taf)      =>  tan delta = (ty - taf)/(1 + ty taf) with ty = y/Ux (Ux = V cos beta > 0), and cos delta has the sign of
+//                                             (1 + ty taf) because cos(x - y) = cos x cos y (1 + tan x tan y) with both cosines positive
+// (identical values in exact arithmetic; the serial 90-iteration chain of the cold node seeding drops four transcendental calls per iteration).
+// The ANGLES are formed once, at exit, with the reference's own expressions.  beta, (sb, cb), (sd, cd): the initial estimates and their sines/cosines.
 struct Steady { real beta, Ux, Uy, r, A, delta, Fx; };
-PG_DEV Steady steady_state(const DevVehicle& P, real V, real A_tan, real kappa, int num_iters, real r, real beta, real delta, real Fyf) {
+PG_DEV Steady steady_state(const DevVehicle& P, real V, real A_tan, real kappa, int num_iters, real r, real beta, real sb, real cb, real delta, real sd, real cd, real Fyf) {
     real A_rad = V * V * kappa;
     real A_max = P.mu * P.G;
     if (hypot(A_tan, A_rad) > A_max) {
@@ -252,10 +261,10 @@ PG_DEV Steady steady_state(const DevVehicle& P, real V, real A_tan, real kappa, 
         else A_tan = sqrt(A_max * A_max - A_rad * A_rad) * sgn(A_tan);
     }
     real rdot = A_tan * kappa;
-    real Fxr = real(0.0), Fxf = real(0.0), A_out = A_tan;
+    real Fxr = real(0.0), Fxf = real(0.0), A_out = A_tan, tb = real(0.0);
+    bool beta_is_tan = false;
 #pragma unroll 1
     for (int i = 1;; i++) {
-        real sb, cb, sd, cd; pg_sincos(beta, &sb, &cb); pg_sincos(delta, &sd, &cd);
         real Ux = V * cb, Uy = V * sb;
         real Fx_drag = -P.Cd0 - Ux * (P.Cd1 + P.Cd2 * Ux);
         real Ax = A_tan * cb - A_rad * sb, Ay = A_tan * sb + A_rad * cb;
@@ -274,19 +283,21 @@ PG_DEV Steady steady_state(const DevVehicle& P, real V, real A_tan, real kappa, 
         Fxf = Fxf_t * cd + Fyf_t * sd;
         Fyf = Fyf_t * cd - Fxf_t * sd;
         real Fyf_max = sqrt(Ffm * Ffm - Fxf * Fxf);
-        real af = atan(inv_fiala_tan(Fyf, P.Caf, Fyf_max));
-        delta = atan2(Uy + P.a * r, Ux) - af;
+        real taf = inv_fiala_tan(Fyf, P.Caf, Fyf_max);                         // tan(alpha_f)
         if (i == num_iters) {
+            delta = atan2(Uy + P.a * r, Ux) - atan(taf);                         // :376-377, the angle itself
             real Ax2 = (Fxf * cd - Fyf * sd + Fxr + Fx_drag) / P.m;
             real Ay2 = (Fyf * cd + Fxf * sd + Fyr) / P.m;
             A_out = Ax2 * cb + Ay2 * sb;
             break;
         }
-        beta = atan(tanar + P.b * r / Ux);
+        real ty = (Uy + P.a * r) / Ux, den = real(1.0) + ty * taf, td = (ty - taf) / den;
+        cd = copysign(pg_rsqrt(real(1.0) + td * td), den); sd = td * cd;       // sincos of the new delta
+        tb = tanar + P.b * r / Ux; beta_is_tan = true;                         // beta = atan(tb)  (:379)
+        cb = pg_rsqrt(real(1.0) + tb * tb); sb = tb * cb;
     }
     Steady o;
-    real sb, cb; pg_sincos(beta, &sb, &cb);
-    o.beta = beta; o.Ux = V * cb; o.Uy = V * sb; o.r = r; o.A = A_out; o.delta = delta; o.Fx = Fxf + Fxr;
+    o.beta = beta_is_tan ? atan(tb) : beta; o.Ux = V * cb; o.Uy = V * sb; o.r = r; o.A = A_out; o.delta = delta; o.Fx = Fxf + Fxr;
     return o;
 }
 

@@ -190,9 +190,10 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
     real sdp, cdp; pg_sincos(dpsi, &sdp, &cdp);
     real V = Ux0 * cdp - Uy0 * sdp;
     const real beta0 = atan2(Uy0, Ux0);
-    real Fyf0, Fyr0;
+    real Fyf0, Fyr0, sb0, cb0, sd0, cd0;
+    pg_sincos(beta0, &sb0, &cb0); pg_sincos(d0, &sd0, &cd0);
     {   // lateral_tire_forces(bicycle, q0, u0): raw (delta, Fxf, Fxr), no actuator limits (:110; vehicle_dynamics.jl:78-87)
-        real sd, cd; pg_sincos(d0, &sd, &cd);
+        real sd = sd0, cd = cd0;
         real af = tan(atan2(Uy0 + P.a * r0, Ux0) - d0), ar = tan(atan2(Uy0 - P.b * r0, Ux0));
         lateral_forces<real>(P, af, ar, Fxf0, Fxr0, sd, cd, Fyf0, Fyr0);
     }
@@ -215,8 +216,9 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
         real A_des = tj.A + C.cp.k_V * (tj.V - V) / tau + (traj_mode ? -C.cp.k_s * ds / tau / tau : real(0.0));
         A_des = jmin(jmax(A_des, (C.cp.V_min - V) / tau), (C.cp.V_max - V) / tau);
         const bool shortp = i <= C.Ns;
-        Steady est = shortp ? steady_state(P, V, A_des, tj.kappa, 1, r0, beta0, d0, Fyf0)            // :122
-                            : steady_state(P, V, A_des, tj.kappa, 4, V * tj.kappa, real(0.0), real(0.0), real(0.0));   // :128
+        // :122 short nodes: one iteration from the measured (r0, beta0, delta0, Fyf0); :128 long nodes: four iterations from (V kappa, 0, 0, 0)
+        Steady est = steady_state(P, V, A_des, tj.kappa, shortp ? 1 : 4, shortp ? r0 : V * tj.kappa, shortp ? beta0 : real(0.0), shortp ? sb0 : real(0.0), shortp ? cb0 : real(1.0),
+                                  shortp ? d0 : real(0.0), shortp ? sd0 : real(0.0), shortp ? cd0 : real(1.0), shortp ? Fyf0 : real(0.0));
         r.q0 = ds;
         r.q1 = shortp ? Ux0 : est.Ux; r.q2 = shortp ? Uy0 : est.Uy; r.q3 = shortp ? r0 : est.r;
         r.q4 = shortp ? adiff(psi0, tj.psi) : -est.beta; r.q5 = shortp ? e0 : real(0.0);
@@ -401,9 +403,10 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg 
     const real psi0 = q0[2], Ux0 = q0[3], Uy0 = q0[4], r0 = q0[5], d0 = u0[0], Fxf0 = u0[1], Fxr0 = u0[2];
     real V = hypot(Ux0, Uy0);                                                         // :67
     const real beta0 = atan2(Uy0, Ux0);
-    real Fyf0, Fyr0;
+    real Fyf0, Fyr0, sb0, cb0, sd0, cd0;
+    pg_sincos(beta0, &sb0, &cb0); pg_sincos(d0, &sd0, &cd0);
     {
-        real sd, cd; pg_sincos(d0, &sd, &cd);
+        real sd = sd0, cd = cd0;
         real af = tan(atan2(Uy0 + P.a * r0, Ux0) - d0), ar = tan(atan2(Uy0 - P.b * r0, Ux0));
         lateral_forces<real>(P, af, ar, Fxf0, Fxr0, sd, cd, Fyf0, Fyr0);               // :71
     }
@@ -424,7 +427,8 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg 
             A = (dUx - r0 * Uy0) * cb + (dUy + r0 * Ux0) * sb;                                                               // :83
         } else {
             const bool shortp = i <= C.Ns;
-            Steady est = shortp ? steady_state(P, V, A_des, tj.kappa, 1, r0, beta0, d0, Fyf0) : steady_state(P, V, A_des, tj.kappa, 4, V * tj.kappa, real(0.0), real(0.0), real(0.0));
+            Steady est = steady_state(P, V, A_des, tj.kappa, shortp ? 1 : 4, shortp ? r0 : V * tj.kappa, shortp ? beta0 : real(0.0), shortp ? sb0 : real(0.0), shortp ? cb0 : real(1.0),
+                                      shortp ? d0 : real(0.0), shortp ? sd0 : real(0.0), shortp ? cd0 : real(1.0), shortp ? Fyf0 : real(0.0));
             r.q1 = est.Ux;
             r.q2 = shortp ? Uy0 : est.Uy; r.q3 = shortp ? r0 : est.r; r.q4 = shortp ? adiff(psi0, tj.psi) : -est.beta; r.q5 = shortp ? e0 : real(0.0);   // :85,92
             r.u0 = est.delta; r.u1 = est.Fx; A = est.A;
