@@ -168,7 +168,7 @@ int po_solve_exact(void* hv, const double* sd_flat, double* x, double* y, double
     Handle* h = (Handle*)hv; StageData sd; flat_to_sd(sd_flat, h->mpc.TS.N_short, h->mpc.TS.N_long, sd);
     QP qp; h->lay.fill(sd, h->mpc.cp, h->mpc.veh, h->mpc.u_norm, qp);
     LDLNumeric ldl; ldl.init(&h->kkt.sym);
-    ExactResult R; int st = solve_exact(qp, h->kkt, ldl, R);
+    ExactResult R; int st = solve_exact_robust(qp, h->kkt, ldl, R);
     if ((int)R.x.size() == qp.n) { std::memcpy(x, R.x.data(), qp.n * 8); std::memcpy(y, R.y.data(), qp.m * 8); }
     info5[0] = R.iters; info5[1] = R.status; info5[2] = R.res_pri; info5[3] = R.res_dua; info5[4] = R.gap; info5[5] = R.polished;
     return st;

@@ -474,6 +474,46 @@ struct OSQPPort {
 // convention (y_i < 0 active lower bound, y_i > 0 active upper bound) so that P x + q + A'y = 0.
 struct ExactResult { std::vector<double> x, y; int iters = 0; int status = 0; int polished = 0; double res_pri = 0, res_dua = 0, gap = 0; };
 
+// ---- active-set polish (the published OSQP polish step, applied to a converged answer): the rows in `actv` are held as equalities, the others are
+// dropped, the KKT system of that equality-constrained QP is solved with a regularised factorisation + iterative refinement against the UNregularised
+// residuals, and the result is accepted only if it is primal feasible on the dropped rows and dual feasible on the held ones (then it satisfies the KKT
+// conditions of the full QP to rounding: it IS the optimum, free of the sqrt(mu) error an interior point keeps on nearly degenerate rows).  Violated rows
+// join the set, rows with a negative multiplier leave it; a few rounds at most; otherwise the answer in R stands.  cls: 0 eq, 1 lower-only, 2 upper-only, 3 free.
+inline void polish_exact(const QP& qp, LDLNumeric& ldl, const std::vector<int>& cls, const std::vector<double>& bnd, std::vector<char> actv, ExactResult& R) {
+    const int n = qp.n, m = qp.m;
+    std::vector<double> xp(R.x), yp(m, 0.0), vals(n + m + qp.Ax.size()), res(n + m), Axv(m), Aty(n);
+    for (size_t p = 0; p < qp.Ax.size(); p++) vals[n + m + p] = qp.Ax[p];
+    for (int i = 0; i < m; i++) yp[i] = actv[i] ? R.y[i] : 0.0;
+    const double nq = vnorm_inf(qp.q.data(), n), nb = vnorm_inf(bnd.data(), m);
+    const double ptol = 1e-9 * (1 + nb), reg = 1e-9;
+    for (int round = 0; round < 8; round++) {
+        for (int j = 0; j < n; j++) vals[j] = qp.Pd[j] + reg;
+        for (int i = 0; i < m; i++) vals[n + i] = actv[i] ? -reg : -1e12;
+        if (!ldl.factor(vals.data(), vals.size())) return;
+        double rn = 0;
+        for (int ref = 0; ref < 12; ref++) {
+            A_mul(qp, qp.Ax.data(), xp.data(), Axv.data()); At_mul(qp, qp.Ax.data(), yp.data(), Aty.data());
+            rn = 0;
+            for (int j = 0; j < n; j++) { res[j] = -(qp.Pd[j] * xp[j] + qp.q[j] + Aty[j]); rn = std::max(rn, std::fabs(res[j])); }
+            for (int i = 0; i < m; i++) { res[n + i] = actv[i] ? bnd[i] - Axv[i] : 0.0; rn = std::max(rn, std::fabs(res[n + i])); }
+            if (rn <= 1e-13 * (1 + nq + nb)) break;
+            ldl.solve(res.data());
+            for (int j = 0; j < n; j++) xp[j] += res[j];
+            for (int i = 0; i < m; i++) if (actv[i]) yp[i] += res[n + i];
+        }
+        if (!(rn <= 1e-9 * (1 + nq + nb))) return;              // refinement did not converge (singular active set): keep the answer as it is
+        A_mul(qp, qp.Ax.data(), xp.data(), Axv.data());
+        bool changed = false;
+        for (int i = 0; i < m; i++) {
+            if (cls[i] != 1 && cls[i] != 2) continue;
+            const double ti = cls[i] == 1 ? Axv[i] - bnd[i] : bnd[i] - Axv[i], li = cls[i] == 1 ? -yp[i] : yp[i];
+            if (actv[i] && li < 0.0) { actv[i] = 0; yp[i] = 0.0; changed = true; }
+            else if (!actv[i] && ti < -ptol) { actv[i] = 1; changed = true; }
+        }
+        if (!changed) { R.x = xp; R.y = yp; R.polished = 1 + round; R.res_dua = rn; return; }
+    }
+}
+
 inline int solve_exact(const QP& qp, const KKTPattern& K, LDLNumeric& ldl, ExactResult& R, int max_iter = 120, double tol = 1e-10, double tol_gap = 1e-14) {
     const int n = qp.n, m = qp.m;
     const double delta = 1e-10, eps_eq = 1e-10;
@@ -591,43 +631,10 @@ inline int solve_exact(const QP& qp, const KKTPattern& K, LDLNumeric& ldl, Exact
     if (status == -2 && R.gap <= 1e-10 && R.res_pri <= tol * (1 + nb) && R.res_dua <= 1e3 * tol * (1 + nq)) status = 1;
     for (int i = 0; i < m; i++) y[i] = cls[i] == 1 ? -lam[i] : (cls[i] == 2 ? lam[i] : (cls[i] == 0 ? y[i] : 0.0));
     R.x = x; R.y = y; R.iters = it; R.status = status; R.polished = 0;
-    // ---- active-set polish (the published OSQP polish step, applied to the interior point's answer): rows with lam > t are held as equalities, the
-    // others are dropped, the KKT system of that equality-constrained QP is solved with the regularised factorisation + iterative refinement against the
-    // UNregularised residuals, and the result is accepted only if it is primal feasible on the dropped rows and dual feasible on the held ones (then it
-    // satisfies the KKT conditions of the full QP to rounding: it IS the optimum, free of the sqrt(mu) error an interior point keeps on nearly
-    // degenerate rows).  Violated rows join the set, rows with a negative multiplier leave it; a few rounds at most; otherwise the IPM answer stands.
     if (status == 1) {
         std::vector<char> actv(m, 0);
         for (int i = 0; i < m; i++) actv[i] = cls[i] == 0 || ((cls[i] == 1 || cls[i] == 2) && lam[i] > t[i]);
-        std::vector<double> xp(x), yp(m, 0.0);
-        for (int i = 0; i < m; i++) yp[i] = actv[i] ? y[i] : 0.0;
-        const double ptol = 1e-9 * (1 + nb), reg = 1e-9;
-        for (int round = 0; round < 8; round++) {
-            for (int j = 0; j < n; j++) vals[j] = qp.Pd[j] + reg;
-            for (int i = 0; i < m; i++) vals[n + i] = actv[i] ? -reg : -1e12;
-            if (!ldl.factor(vals.data(), vals.size())) break;
-            double rn = 0;
-            for (int ref = 0; ref < 12; ref++) {
-                A_mul(qp, qp.Ax.data(), xp.data(), Axv.data()); At_mul(qp, qp.Ax.data(), yp.data(), Aty.data());
-                rn = 0;
-                for (int j = 0; j < n; j++) { res[j] = -(qp.Pd[j] * xp[j] + qp.q[j] + Aty[j]); rn = std::max(rn, std::fabs(res[j])); }
-                for (int i = 0; i < m; i++) { res[n + i] = actv[i] ? bnd[i] - Axv[i] : 0.0; rn = std::max(rn, std::fabs(res[n + i])); }
-                if (rn <= 1e-13 * (1 + nq + nb)) break;
-                ldl.solve(res.data());
-                for (int j = 0; j < n; j++) xp[j] += res[j];
-                for (int i = 0; i < m; i++) if (actv[i]) yp[i] += res[n + i];
-            }
-            if (!(rn <= 1e-9 * (1 + nq + nb))) break;              // refinement did not converge (singular active set): keep the IPM answer
-            A_mul(qp, qp.Ax.data(), xp.data(), Axv.data());
-            bool changed = false;
-            for (int i = 0; i < m; i++) {
-                if (cls[i] != 1 && cls[i] != 2) continue;
-                const double ti = cls[i] == 1 ? Axv[i] - bnd[i] : bnd[i] - Axv[i], li = cls[i] == 1 ? -yp[i] : yp[i];
-                if (actv[i] && li < 0.0) { actv[i] = 0; yp[i] = 0.0; changed = true; }
-                else if (!actv[i] && ti < -ptol) { actv[i] = 1; changed = true; }
-            }
-            if (!changed) { R.x = xp; R.y = yp; R.polished = 1 + round; R.res_dua = rn; break; }
-        }
+        polish_exact(qp, ldl, cls, bnd, actv, R);
     }
     return status;
 }
@@ -643,7 +650,18 @@ inline int solve_exact_robust(const QP& qp, const KKTPattern& K, LDLNumeric& ldl
     OSQPSettings s; s.eps_abs = 1e-10; s.eps_rel = 1e-10; s.max_iter = 400000; s.warm_start = 0;
     OSQPPort admm; admm.init(&K, s);
     int sa = admm.solve(qp);
-    if (sa == 1) { R.x = admm.x; R.y = admm.y; R.iters = -admm.last_iters; R.status = 1; R.res_pri = admm.last_pri; R.res_dua = admm.last_dua; R.gap = 0.0; return 1; }
+    if (sa == 1) {
+        R.x = admm.x; R.y = admm.y; R.iters = -admm.last_iters; R.status = 1; R.res_pri = admm.last_pri; R.res_dua = admm.last_dua; R.gap = 0.0; R.polished = 0;
+        const int m = qp.m;
+        std::vector<int> cls(m); std::vector<double> bnd(m, 0.0); std::vector<char> actv(m, 0);
+        for (int i = 0; i < m; i++) {
+            bool hl = qp.l[i] > -QP_INF, hu = qp.u[i] < QP_INF;
+            cls[i] = (hl && hu) ? 0 : (hl ? 1 : (hu ? 2 : 3)); bnd[i] = hu && !hl ? qp.u[i] : (hl ? qp.l[i] : 0.0);
+            actv[i] = cls[i] == 0 || (cls[i] != 3 && std::fabs(R.y[i]) > 1e-7);
+        }
+        polish_exact(qp, ldl, cls, bnd, actv, R);
+        return 1;
+    }
     return st;
 }
 }  // namespace po

@@ -225,6 +225,9 @@ def stable_limits(P, Ux, Fxf, Fxr):
     return d_min, d_max, H, Gv
 
 
+SATURATION_MARGINS = None      # set to a list to record, per steady_state_estimates call, how close the front force came to the jump of _inv_fiala
+
+
 def steady_state_estimates(P, V, A_tan, kappa, num_iters=4, r=None, beta0=0.0, delta0=0.0, Fyf0=0.0):
     """vehicle_dynamics.jl:319-390"""
     r = V * kappa if r is None else r
@@ -262,6 +265,8 @@ def steady_state_estimates(P, V, A_tan, kappa, num_iters=4, r=None, beta0=0.0, d
         Fxf = Fxf_t * cd + Fyf_t * sd
         Fyf = Fyf_t * cd - Fxf_t * sd
         Fyf_max = math.sqrt(Ff * Ff - Fxf * Fxf)
+        if SATURATION_MARGINS is not None:
+            SATURATION_MARGINS.append(abs(abs(Fyf) - Fyf_max) / Ff)
         af = math.atan(_inv_fiala(Fyf, P["Caf"], Fyf_max))
         delta = math.atan2(Uy + a * r, Ux) - af
         if i == num_iters:

@@ -216,14 +216,26 @@ PG_DEV void lateral_rhs(const DevVehicle& P, const T q[4], T u0, T u1, T pUx, T 
     out[3] = pUx * s + q[0] * c;
 }
 
+// sqrt(a^2 - b^2) where b may have been CLAMPED onto +-a (a tire force on the friction circle, vehicle_dynamics.jl:356,363): the reference gets exactly 0
+// there because Julia rounds every product on its own.  A fused multiply-add does not: hipcc contracts across statements, so `Frm = mu * Fzr` was fused
+// into `Frm * Frm - Fxr * Fxr` with its UNROUNDED value, the difference came out as minus one rounding error, the square root as NaN, the clamps that
+// use it as a bound stopped clamping, and friction-saturated braking seeds were a few percent off on a coin-flip subset of nodes (found by
+// tests/test_gpu_edge_cases.py::test_friction_saturated_seeding in round 2; present since round 1).  Hence: the factored form here, and
+// `fp contract(off)` in the two functions whose branches rely on exact cancellation (stable_limits, steady_state).
+PG_DEV real sqrt_diff_sq(real a, real b) {
+#pragma clang fp contract(off)
+    return sqrt((a - b) * (a + b));
+}
+
 // stable_limits: vehicle_dynamics.jl:227-263
 struct Envelope { real dmin, dmax, H[4][2], G[4]; };
 PG_DEV Envelope stable_limits(const DevVehicle& B, real Ux, real Fxf, real Fxr) {
+#pragma clang fp contract(off)
     real Fx = Fxf + Fxr;
     real Fzf = (B.m * B.G * B.b - B.h * Fx) / B.L, Fzr = (B.m * B.G * B.a + B.h * Fx) / B.L;
     real Ffm = B.mu * Fzf, Frm = B.mu * Fzr;
-    real Fyf_max = fabs(Fxf) > Ffm ? real(0.0) : sqrt(Ffm * Ffm - Fxf * Fxf);
-    real Fyr_max = fabs(Fxr) > Frm ? real(0.0) : sqrt(Frm * Frm - Fxr * Fxr);
+    real Fyf_max = fabs(Fxf) > Ffm ? real(0.0) : sqrt_diff_sq(Ffm, Fxf);
+    real Fyr_max = fabs(Fxr) > Frm ? real(0.0) : sqrt_diff_sq(Frm, Fxr);
     real tf = real(3.0) * Fyf_max / B.Caf, tr = real(3.0) * Fyr_max / B.Car;
     real af = atan(tf), ar = atan(tr);
     Envelope o;
@@ -254,11 +266,12 @@ PG_DEV Envelope stable_limits(const DevVehicle& B, real Ux, real Fxf, real Fxr) 
 // The ANGLES are formed once, at exit, with the reference's own expressions.  beta, (sb, cb), (sd, cd): the initial estimates and their sines/cosines.
 struct Steady { real beta, Ux, Uy, r, A, delta, Fx; };
 PG_DEV Steady steady_state(const DevVehicle& P, real V, real A_tan, real kappa, int num_iters, real r, real beta, real sb, real cb, real delta, real sd, real cd, real Fyf) {
+#pragma clang fp contract(off)
     real A_rad = V * V * kappa;
     real A_max = P.mu * P.G;
     if (hypot(A_tan, A_rad) > A_max) {
         if (fabs(A_rad) > A_max) { A_rad = A_max * sgn(A_rad); A_tan = real(0.0); }
-        else A_tan = sqrt(A_max * A_max - A_rad * A_rad) * sgn(A_tan);
+        else A_tan = sqrt_diff_sq(A_max, A_rad) * sgn(A_tan);
     }
     real rdot = A_tan * kappa;
     real Fxr = real(0.0), Fxf = real(0.0), A_out = A_tan, tb = real(0.0);
@@ -274,15 +287,15 @@ PG_DEV Steady steady_state(const DevVehicle& P, real V, real A_tan, real kappa, 
         real Frm = P.mu * Fzr, Ffm = P.mu * Fzf;
         real frac = Fx > real(0.0) ? P.rwd_frac / (P.rwd_frac + P.fwd_frac * cd) : P.rwb_frac / (P.rwb_frac + P.fwb_frac * cd);
         Fxr = clampd((Fx + Fyf * sd) * frac, -Frm, Frm);
-        real Fyr_max = sqrt(Frm * Frm - Fxr * Fxr);
+        real Fyr_max = sqrt_diff_sq(Frm, Fxr);
         real Fyr = clampd((Ay * P.m - rdot * P.Izz / P.a) / (real(1.0) + P.b / P.a), -Fyr_max, Fyr_max);
         real tanar = inv_fiala_tan(Fyr, P.Car, Fyr_max);
         real Fxf_t = clampd(Fx - Fxr, -Ffm, Ffm);
-        real Fyf_tmax = sqrt(Ffm * Ffm - Fxf_t * Fxf_t);
+        real Fyf_tmax = sqrt_diff_sq(Ffm, Fxf_t);
         real Fyf_t = clampd((P.b * Fyr + rdot * P.Izz) / P.a, -Fyf_tmax, Fyf_tmax);
         Fxf = Fxf_t * cd + Fyf_t * sd;
         Fyf = Fyf_t * cd - Fxf_t * sd;
-        real Fyf_max = sqrt(Ffm * Ffm - Fxf * Fxf);
+        real Fyf_max = sqrt_diff_sq(Ffm, Fxf);
         real taf = inv_fiala_tan(Fyf, P.Caf, Fyf_max);                         // tan(alpha_f)
         if (i == num_iters) {
             delta = atan2(Uy + P.a * r, Ux) - atan(taf);                         // :376-377, the angle itself

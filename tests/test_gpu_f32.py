@@ -119,3 +119,67 @@ def test_f32_decoupled_n50(pkg, skidpad):
     err = np.abs(u32[ok, 0] - u64[ok, 0]) / 0.314159
     assert np.median(err) <= 5e-4 and np.percentile(err, 99) <= 1e-2 and err.max() <= 5e-2, (np.median(err), np.percentile(err, 99), err.max())
     d64.close(); d32.close()
+
+
+def test_config3_full_size_grid_and_batch(pkg, oracle_mod, skidpad):
+    """BASELINE configs[2] as stated: B = 4096, fp32, HJI safety row on the 13x13x9x9x9x9x9 grid (10 M nodes, 41 GB of cell records on the device),
+    default HJI_eps = 0.05.  Every instance solves; the rows that are active (V <= eps) and a sample of the others are compared with the oracle."""
+    n = 4096
+    knots, V, g = pkg.synthetic.hji_grid_large()
+    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, n, seed=12345)
+    state, control = f32_round(state), f32_round(control)
+    other = f32_round(pkg.synthetic.other_cars(state, seed=777))
+    m32 = pkg.BatchedTrajectoryTrackingMPC(skidpad, n, precision="f32")
+    m32.set_hji_cache(knots, V, g)
+    u, status, iters = m32.step_(state, control, t0, other_car_state=other, time_offset=toff)
+    assert np.all(status == 1), np.bincount(status)
+    M, b, Vv = m32.hji_constraint()
+    in_grid = np.isfinite(Vv); active = in_grid & (Vv <= 0.05)
+    assert in_grid.sum() > n // 2 and active.sum() >= 8, (int(in_grid.sum()), int(active.sum()))
+    assert np.all(M[~active] == 0.0) and np.all(b[~active] == 1.0)                     # HJI_computation.jl:163-164
+    orc = make_oracle(oracle_mod, skidpad); orc.set_hji_grid(knots, V, g)
+    sample = list(np.flatnonzero(active)[:48]) + list(np.flatnonzero(in_grid & ~active)[:16])
+    for i in sample:
+        Mo, bo, Vo = orc.hji_constraint(state[i], other[i], control[i])
+        Mo = Mo * orc.u_norm
+        assert abs(Vv[i] - Vo) <= 5e-5 * max(1, abs(Vo)), i
+        if abs(Vo - 0.05) > 1e-4:                                                       # (a value within fp32 rounding of eps may fall on either side)
+            assert np.max(np.abs(M[i] - Mo)) <= 3e-3 * max(1.0, np.max(np.abs(Mo))) and abs(b[i] - bo) <= 3e-3 * max(1.0, abs(bo)), i
+    x, sg = m32.solution(); qp = m32.qp_data()
+    errs = []
+    for i in list(np.flatnonzero(active)[:24]) + list(range(0, n, 256)):
+        xe, ye, info = orc.solve_exact(qp[i])
+        errs.append(np.max(np.abs(x[i, 1, 6:] - orc.split_x(xe)["u"][1])))
+    assert np.max(errs) <= 1e-3, np.max(errs)
+    m32.close()
+
+
+def test_config4_per_gpu_share(pkg, oracle_mod, skidpad):
+    """BASELINE configs[3] shards 65536 instances over 8 GPUs: 8192 per GPU, fp32.  One GPU's share at full size: every instance solves, the solution
+    satisfies its own QP (dynamics rows, bounds) to fp32 rounding, and a sample agrees with the exact optimum of the same QP data."""
+    n = 8192
+    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, n, seed=12345 + 3)          # rank 3's shard of the bench
+    state, control = f32_round(state), f32_round(control)
+    m32 = pkg.BatchedTrajectoryTrackingMPC(skidpad, n, precision="f32")
+    u, status, iters = m32.step_(state, control, t0, time_offset=toff)
+    assert np.all(status == 1), np.bincount(status)
+    qp = m32.qp_data(); x, sg = m32.solution()
+    N = m32.N; o = 0
+    A = qp[:, o:o + 36 * N].reshape(n, N, 6, 6); o += 36 * N
+    B0 = qp[:, o:o + 12 * N].reshape(n, N, 6, 2); o += 12 * N
+    Bf = qp[:, o:o + 12 * N].reshape(n, N, 6, 2); o += 12 * N
+    c = qp[:, o:o + 6 * N].reshape(n, N, 6); o += 6 * N
+    o += 12 * N
+    dmin = qp[:, o:o + N]; o += N; dmax = qp[:, o:o + N]; o += N; fxmax = qp[:, o:o + N]; o += N
+    q = x[:, :, :6]; un = x[:, :, 6:]
+    pred = np.einsum("bkij,bkj->bki", A, q[:, :-1]) + np.einsum("bkij,bkj->bki", B0, un[:, :-1]) + np.einsum("bkij,bkj->bki", Bf, un[:, 1:]) + c
+    assert np.max(np.abs(pred - q[:, 1:]) / np.maximum(1.0, np.abs(q[:, 1:]))) < 2e-4
+    tol = 1e-4
+    assert np.all(un[:, 1:, 0] <= dmax + tol) and np.all(un[:, 1:, 0] >= dmin - tol) and np.all(un[:, 1:, 1] <= fxmax + tol)
+    orc = make_oracle(oracle_mod, skidpad)
+    errs = []
+    for i in range(0, n, 128):
+        xe, ye, info = orc.solve_exact(qp[i])
+        errs.append(np.max(np.abs(x[i, 1, 6:] - orc.split_x(xe)["u"][1])))
+    assert np.max(errs) <= 1e-3 and np.median(errs) <= 1e-5, (np.max(errs), np.median(errs))
+    m32.close()
