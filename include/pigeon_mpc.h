@@ -89,15 +89,15 @@ typedef struct pg_config {
                                      * cost  wall_weight * dt_t * sw_t  (soft, like the stability-envelope rows of :193-211); 0 (default) = the reference's QP */
     int32_t _pad2;
     double wall_weight;             /* linear penalty on the wall slack per second (default 1000) */
-    int32_t polish;                 /* 1 (default): after the interior point has converged, an active-set polish (OSQP's `polish`, off in the reference's settings,
+    int32_t polish;                 /* 1 (default for the coupled formulation; 0 for the decoupled one, see pg_default_config_decoupled): after the interior point has converged, an active-set polish (OSQP's `polish`, off in the reference's settings,
                                      * src/coupled_lat_long.jl:201-203) solves the equality-constrained problem on the detected active set with the same Riccati passes
                                      * and verifies primal/dual feasibility; removes the sqrt(mu) error of nearly degenerate rows.  0 = interior-point iterate as is */
     int32_t _pad3;
     double polish_rho;              /* penalty on the active rows inside the polish solves (default 1e6 in the fp64 library, 1e3 in the fp32 one) */
     double polish_tol;              /* feasibility tolerance of the polish verification (default 1e-9 / 1e-4) */
     double polish_ipm_tol;          /* with polish = 1 the interior point first stops at this (looser) tolerance and hands over to the polish (default 1e-6 / 1e-4);
-                                     * if the polish cannot verify an active set from there, the interior point resumes down to ipm_tol and the polish gets a second
-                                     * and last chance.  Values <= ipm_tol disable the early hand-over */
+                                     * if the polish cannot verify an active set from there (or the sets cycle), the interior point resumes down to ipm_tol and its
+                                     * iterate is the answer, exactly as with polish = 0.  Values <= ipm_tol disable the early hand-over */
 } pg_config;
 
 enum pg_formulation { PG_COUPLED = 0, PG_DECOUPLED = 1 };

@@ -340,6 +340,16 @@ class OracleDecoupled:
         self.L.pd_solve_exact(self.h, _d(_arr(sd, self.sd_len)), _d(x), _d(y), _d(info))
         return x, y, dict(iters=int(info[0]), status=int(info[1]), res_pri=info[2], res_dua=info[3], gap=info[4], polished=int(info[5]))
 
+    def step_batch(self, states6, controls3, t0, time_offsets=None, nthreads=1):
+        """Whole lateral step per instance with the OSQP port (cold): (u [B,3], iters, status, wall seconds)."""
+        B = len(t0)
+        u = np.zeros((B, 3)); it = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32)
+        to = _arr(time_offsets, B) if time_offsets is not None else None
+        self.L.pd_step_batch.restype = C.c_double
+        secs = self.L.pd_step_batch(self.h, B, _d(_arr(states6, 6 * B)), _d(_arr(controls3, 3 * B)), _d(_arr(t0, B)), _d(to) if to is not None else None, nthreads,
+                                    _d(u), it.ctypes.data_as(c_ip), st.ctypes.data_as(c_ip))
+        return u, it, st, secs
+
     def split_x(self, x):
         Nn, N = self.Nn, self.N
         return dict(q=x[:4 * Nn].reshape(Nn, 4), delta=x[4 * Nn:5 * Nn], sigma=x[5 * Nn:5 * Nn + 2 * N].reshape(N, 2), ddelta=x[5 * Nn + 2 * N:])

@@ -335,6 +335,37 @@ int pd_solve_exact(void* hv, const double* sd_flat, double* x, double* y, double
     info5[0] = R.iters; info5[1] = R.status; info5[2] = R.res_pri; info5[3] = R.res_dua; info5[4] = R.gap; info5[5] = R.polished;
     return st;
 }
+// whole decoupled step for a batch with the reference ALGORITHM (OSQP port, default settings, cold: the lateral formulation has no warm branch):
+// time grid -> nodes (decoupled_lat_long.jl:52-104) -> update_QP! (:228-273) -> solve! -> get_next_control (:275-278).  CPU baseline of BASELINE config 5.
+double pd_step_batch(void* hv, int B, const double* states6, const double* controls3, const double* t0, const double* time_offsets, int nthreads,
+                     double* u_out, int* iters, int* status) {
+    HandleDec* h = (HandleDec*)hv;
+    auto t_start = std::chrono::steady_clock::now();
+    auto work = [&](int b0, int b1) {
+        DecoupledMPC m = h->mpc; const int Nn = m.N() + 1;
+        OSQPSettings st_; OSQPPort osqp; osqp.init(&h->kkt, st_);
+        NodesDec nd; StageDataDec sd; QP qp;
+        for (int b = b0; b < b1; b++) {
+            m.TS.compute(t0[b]);
+            m.linearization_nodes(states6 + 6 * b, controls3 + 3 * b, time_offsets ? time_offsets[b] : NAN, nd);
+            m.update_qp(nd, sd);
+            h->lay.fill(sd, m.cp, qp);
+            osqp.reset();
+            int st = osqp.solve(qp);
+            const double delta = osqp.x[4 * Nn + 1];                      // delta of node 2 (variable order: q (4 x N+1), delta (N+1), ...)
+            m.next_control(delta, nd.us[2 * 1 + 1], u_out + 3 * b);
+            if (iters) iters[b] = osqp.last_iters;
+            if (status) status[b] = st;
+        }
+    };
+    if (nthreads <= 1) work(0, B);
+    else {
+        std::vector<std::thread> th; int per = (B + nthreads - 1) / nthreads;
+        for (int t = 0; t < nthreads; t++) { int b0 = t * per, b1 = std::min(B, b0 + per); if (b0 < b1) th.emplace_back(work, b0, b1); }
+        for (auto& t : th) t.join();
+    }
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+}
 void pd_lateral_dynamics(void* hv, const double* q4, const double* u2, const double* p4, double* out4) { vehicle_lateral_dynamics<double>(((HandleDec*)hv)->mpc.veh, q4, u2, p4, out4); }
 void pd_linearize_interval(void* hv, const double* q4, const double* w0, const double* wf, double dt, int ramp, double* A16, double* B0, double* Bf, double* c) {
     ((HandleDec*)hv)->mpc.linearize_interval(q4, w0, wf, dt, ramp != 0, A16, B0, Bf, c);

@@ -125,6 +125,10 @@ int pg_default_config_decoupled(pg_config* c) {
     U.Q_ds = 0.0; U.Q_dpsi = 1.0 / (d10 * d10); U.Q_e = 1.0; U.W_beta = 50 / d10; U.W_r = 50.0; U.W_HJI = 0.0; U.N_HJI = 0;
     U.R_delta = 0.0; U.R_ddelta = 0.01 / (d10 * d10); U.R_Fx = 0.0; U.R_dFx = 1.0;      // R_dFx only pins the inert Fx slot of the embedding
     c->formulation = PG_DECOUPLED;
+    // polish off by default here: the lateral QP's far horizon is weakly determined (degenerate rows), ~9 % of the N = 50 instances do not verify an active set,
+    // and what the polish improves there (the far-horizon steering, p99 error 4e-4 -> 6e-8) feeds nothing: this formulation has no warm start and only delta_2
+    // is applied, which the interior point already has to 1e-13 (median).  Measured: +8 % solve time (tools/gpu_dec_polish.py).  Set polish = 1 to have it.
+    c->polish = 0; c->polish_tol = 1e-7;
 #ifdef PG_F32
     c->ipm_tol = 1e-4;                               // the ill-conditioned 8 s lateral horizon stalls near 1e-4 in fp32 (tests/test_gpu_f32.py)
 #endif

@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     real it_[NROW];                    // 1 / t_j, refreshed once per interior-point iteration
     // Polish state (see the loop below): pmode = 0 while the interior point runs, then the round number of the active-set polish;
     // amask = this stage's rows currently held active.
-    int pmode = 0, pstat = 0; unsigned amask = 0, mask_ipm = 0;
+    int pmode = 0, pstat = 0; unsigned amask = 0, mask_ipm = 0, amask_1ago = 0xFFFFFFFFu, amask_2ago = 0xFFFFFFFFu; bool polish_gave_up = false;
     const real rho = C.polish_rho, ptol = C.polish_tol;
     auto assemble = [&](real sigmu, bool matrices) {
         real W[NROW], ell[NROW];
@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
 
     int it_total = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
-    rp0 = real(0.0); phi = real(1.0); pmode = 0; pstat = 0;
+    rp0 = real(0.0); phi = real(1.0); pmode = 0; pstat = 0; polish_gave_up = false; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu;
     if (attempt == 0) {
         // ---- first attempt: v = 0 roll-out (dynamics- and rate-feasible), sigma just feasible; t = max(slack, tau); lambda = mu0 / t ----
         forward(std::false_type{});
@@ -1271,7 +1271,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         pmode = 1;
     };
     // after a polish solve (tp = slacks at the new point): multiplier update of the active rows, then the verification.  Returns 0 = verified (solution
-    // stored, pstat set), 1 = same set but the active rows are not yet at t = 0 within `ttol` (refine), 2 = the active set changed.
+    // stored, pstat set), 1 = same set but the active rows are not yet at t = 0 within `ttol` (refine), 2 = the active set changed, 3 = the sets cycle.
     auto polish_check = [&](const real* tp, real ttol) -> int {
         unsigned add = 0, drop = 0; bool settled = true;
 #pragma unroll
@@ -1293,16 +1293,23 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             return 0;
         }
         if (!changed) return 1;
-        amask = (amask & ~drop) | add;
+        const unsigned next = (amask & ~drop) | add;
+        // a set that comes back after two rounds is a cycle between two inconsistent guesses (degenerate rows; typical of the weakly determined far end of
+        // the N = 50 lateral horizon): further rounds would only repeat it
+        const bool cycle = __all(next == amask_2ago);
+        amask_2ago = amask_1ago; amask_1ago = amask;
+        if (cycle) return 3;
+        amask = next;
 #pragma unroll
         for (int j = 0; j < NROW; j++) R.lam[j] = ((amask >> j) & 1u) ? R.lam[j] : real(0.0);
         return 2;
     };
     // with the polish on, the interior point only has to get close enough for the active set to show (polish_ipm_tol); if the polish does not verify from
-    // there, the interior point resumes from the centred point (t, mu / t) and runs down to ipm_tol before the polish gets its second and last chance
+    // there, the interior point resumes from the centred point (t, mu / t) and runs down to ipm_tol (its iterate is then the answer, as without polish)
     real tol_cur = (C.polish && C.polish_ipm_tol > C.ipm_tol) ? C.polish_ipm_tol : C.ipm_tol;
     auto polish_failed = [&]() -> bool {          // true: give up (keep the interior-point iterate); false: the interior point resumes
-        if (!(tol_cur > C.ipm_tol)) { pstat = -1; return true; }
+        polish_gave_up = true; pstat = -1;            // one attempt per solve: an active set that does not verify at the loose tolerance rarely does later
+        if (!(tol_cur > C.ipm_tol)) return true;
         tol_cur = C.ipm_tol; pmode = 0; status = PG_MAX_ITER;
 #pragma unroll
         for (int j = 0; j < NROW; j++) R.lam[j] = (act && j < nrows) ? mu * frcp(R.t[j]) : real(0.0);
@@ -1319,7 +1326,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             if (!(mu == mu) || fabs(mu) > PG_BIG) { status = PG_NUMERICAL; break; }
             if (mu <= tol_cur && phi * fmax(rp0, real(1.0)) <= tol_cur) {
                 status = PG_SOLVED;
-                if (!C.polish) break;
+                if (!C.polish || polish_gave_up) break;
                 enter_polish();
             } else {
 #pragma unroll
@@ -1365,7 +1372,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             // further iterations only add noise (observed on long, ill-conditioned horizons): accept the iterate as it stands
             if (mu <= real(1e4) * C.ipm_tol && aaff < real(0.3) && phi * fmax(rp0, real(1.0)) <= C.ipm_tol) {
                 status = PG_SOLVED;
-                if (!C.polish) break;
+                if (!C.polish || polish_gave_up) break;
                 enter_polish();
                 continue;
             }
@@ -1382,6 +1389,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             // first polish solve done: with multiplier estimates as good as the interior point's, it usually verifies at once (no refinement needed)
             const int pc = polish_check(tp, real(0.01) * ptol);
             if (pc == 0) break;
+            if (pc == 3) { if (polish_failed()) break; continue; }
             if (pc == 2) { if (++pmode > PG_POLISH_ROUNDS && polish_failed()) break; continue; }      // the set changed: next round directly
         }
         // ---- corrector / polish refinement ----
@@ -1427,7 +1435,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         } else {
             const int pc = polish_check(tp, ptol);
             if (pc == 0) break;
-            if (++pmode > PG_POLISH_ROUNDS && polish_failed()) break;      // set changed, or the multiplier iteration has not settled yet: another round
+            if ((pc == 3 || ++pmode > PG_POLISH_ROUNDS) && polish_failed()) break;      // set changed, or the multiplier iteration has not settled yet: another round
         }
     }
     it_total += it;
@@ -1447,7 +1455,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         unsigned mask = 0;
 #pragma unroll
         for (int j = 0; j < NROW; j++) if (j < nrows && R.lam[j] > R.t[j]) mask |= (1u << j);
-        if (pstat != 0) mask = pstat > 0 ? amask : mask_ipm;       // polish ran: its verified set, or the interior point's when it did not verify
+        if (pstat > 0) mask = amask;                               // the polish's verified set
+        else if (pmode) mask = mask_ipm;                           // polish ended unverified with the multipliers overwritten: the interior point's set at hand-over
         O.active[(size_t)b * N + s] = (uint16_t)mask;
     }
     if (lane == 0) {

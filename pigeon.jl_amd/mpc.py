@@ -35,7 +35,7 @@ class BatchedTrajectoryTrackingMPC:
 
     def __init__(self, trajectory, batch_capacity, vehicle=None, control_params=None, N_short=10, N_long=20, dt_short=0.01, dt_long=0.2,
                  use_correction_step=True, rk4_substeps=10, device=0, ipm_max_iter=40, ipm_tol=None, ipm_mu0=100.0, hji_eps=0.05, formulation="coupled",
-                 precision="f64", walls=False, wall_weight=1000.0, polish=True, polish_rho=None, polish_tol=None, polish_ipm_tol=None):
+                 precision="f64", walls=False, wall_weight=1000.0, polish=None, polish_rho=None, polish_tol=None, polish_ipm_tol=None):
         self.precision = precision
         self.real = np.float64 if precision == "f64" else np.float32      # element type of DEVICE arrays handed to the *_dev entry points
         self.lib = _lib.load_library(precision)
@@ -45,7 +45,8 @@ class BatchedTrajectoryTrackingMPC:
         (self.lib.pg_default_config if formulation == "coupled" else self.lib.pg_default_config_decoupled)(C.byref(cfg))
         # solver tolerances default to the library's own (they depend on its arithmetic type: pg_default_config*)
         ipm_tol = cfg.ipm_tol if ipm_tol is None else ipm_tol
-        cfg.polish = int(bool(polish))
+        if polish is not None:                    # None: the library's default for the formulation (on for coupled, off for decoupled)
+            cfg.polish = int(bool(polish))
         if polish_rho is not None:
             cfg.polish_rho = float(polish_rho)
         if polish_tol is not None:

@@ -4,7 +4,8 @@ Stated fp32 tolerance (normalised controls delta/0.314, Fx/16794; inputs rounded
   * against the fp64 library on the same inputs: median <= 2e-4, 99th percentile <= 2e-3, max <= 1e-2.  The tail is NOT solver noise: the
     reference's path projection is discontinuous at path vertices (trajectories.jl:71-94: the winning segment flips and s jumps by
     millimetres, `test_projection_discontinuity_is_the_tail`), and fp32 rounding flips a handful of instances per thousand;
-  * against the exact optimum of the fp32 library's OWN QP data (oracle, fp64): max <= 5e-3, median <= 2e-4 (what an fp32 interior point reaches);
+  * against the exact optimum of the fp32 library's OWN QP data (oracle, fp64): max <= 5e-4, median <= 1e-5 (measured 1e-4 / 4e-8 with the active-set
+    polish; an fp32 interior point alone stops at sqrt(mu) ~ 2e-3);
   * the time grid is bit-identical to the fp64 build (absolute time stays double in both);
   * every instance reports PG_SOLVED.
 """
@@ -69,7 +70,7 @@ def test_f32_solver_against_exact_optimum_of_its_qp(pair, oracle_mod, skidpad):
         xe, ye, info = orc.solve_exact(qp[b])
         assert info["status"] == 1
         errs.append(np.max(np.abs(x[b, 1, 6:] - orc.split_x(xe)["u"][1])))
-    assert np.max(errs) <= 5e-3 and np.median(errs) <= 2e-4, (np.max(errs), np.median(errs))
+    assert np.max(errs) <= 5e-4 and np.median(errs) <= 1e-5, (np.max(errs), np.median(errs))          # (round 1, without the polish: 5e-3 / 2e-4)
 
 
 def test_f32_with_hji_constraint(pkg, oracle_mod, skidpad):
@@ -101,7 +102,7 @@ def test_f32_with_hji_constraint(pkg, oracle_mod, skidpad):
     for i in range(0, n, 8):
         xe, ye, info = orc.solve_exact(qp[i])
         errs.append(np.max(np.abs(x[i, 1, 6:] - orc.split_x(xe)["u"][1])))
-    assert np.max(errs) <= 5e-3, np.max(errs)
+    assert np.max(errs) <= 1e-3, np.max(errs)
     m32.close()
 
 

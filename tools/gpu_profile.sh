@@ -4,6 +4,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 BENCH="bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-decoupled --no-f32"
+# (the full default bench line is taken separately: python bench.py > gpurun_out/bench_full.log)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $BENCH > $OUT/bench_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $BENCH > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $BENCH > $OUT/bench_write.log 2>&1

@@ -44,16 +44,32 @@ for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
 summary = {k: {c: {"launches": v[1], "mean_per_launch": v[0] / v[1]} for c, v in cs.items()} for k, cs in acc.items()}
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
 
-# dominant kernel by total time
+# HBM bytes per launch of the dominant kernel (k_solve) and of the bandwidth-bound one (k_hji_lookup)
 rows = list(csv.DictReader(open(ks[0])))
-dom = max((r for r in rows if "pg::k_solve" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
-dk = short(dom["Name"])
-fs = summary[dk]["FETCH_SIZE"]["mean_per_launch"]; ws = summary[dk]["WRITE_SIZE"]["mean_per_launch"]
-json.dump({"kernel": dk, "hbm_bytes_per_launch": (2 * fs + ws) * 1024, "fetch_size_kib": fs, "write_size_kib": ws,
-           "avg_launch_ns_rocprof": float(dom["AverageNs"]),
-           "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md HBM section)",
-           "source": f"profiles/{tag}/pmc_summary.json", "workload": "bench.py B=4096 coupled fp64 cold"},
-          open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+
+
+def traffic_of(match):
+    cand = [r for r in rows if match in r["Name"]]
+    if not cand:
+        return None
+    dom = max(cand, key=lambda r: float(r["TotalDurationNs"]))
+    dk = short(dom["Name"])
+    if dk not in summary or "FETCH_SIZE" not in summary[dk]:
+        return None
+    fs = summary[dk]["FETCH_SIZE"]["mean_per_launch"]; ws = summary[dk]["WRITE_SIZE"]["mean_per_launch"]
+    return dk, {"hbm_bytes_per_launch": (2 * fs + ws) * 1024, "fetch_size_kib": fs, "write_size_kib": ws, "avg_launch_ns_rocprof": float(dom["AverageNs"]),
+                "source": f"profiles/{tag}/pmc_summary.json"}
+
+
+out = {"formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction for wide coalesced reads, MI355X_MICROARCH.md HBM section; separate --pmc passes)",
+       "workload": "bench.py B=4096 coupled fp64 cold (k_solve); 2^20 lookups on the 13x13x9^5 grid (k_hji_lookup)", "kernels": {}}
+for m in ("pg::k_solve", "pg::k_hji_lookup", "pg::k_linearize", "pg::k_nodes"):
+    t = traffic_of(m)
+    if t:
+        out["kernels"][t[0]] = t[1]
+        if m == "pg::k_solve":
+            out.update({"kernel": t[0], **t[1]})
+json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 for r in rows[:8]:
     print(f"{short(r['Name'])[:60]:60s} calls {r['Calls']:>4s} avg {float(r['AverageNs'])/1e3:9.1f} us  {r['Percentage']:>6s} %")
 print(json.dumps({k: {c: round(v['mean_per_launch']) for c, v in cs.items()} for k, cs in summary.items() if 'k_solve' in k or 'lookup' in k}, indent=1))
