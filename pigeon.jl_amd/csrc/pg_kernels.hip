@@ -1305,12 +1305,12 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         return 2;
     };
     // with the polish on, the interior point only has to get close enough for the active set to show (polish_ipm_tol); if the polish does not verify from
-    // there, the interior point resumes from the centred point (t, mu / t) and runs down to ipm_tol (its iterate is then the answer, as without polish)
+    // there, the interior point resumes from the centred point (t, mu / t) and runs down to ipm_tol before the polish gets its second and last chance
     real tol_cur = (C.polish && C.polish_ipm_tol > C.ipm_tol) ? C.polish_ipm_tol : C.ipm_tol;
     auto polish_failed = [&]() -> bool {          // true: give up (keep the interior-point iterate); false: the interior point resumes
-        polish_gave_up = true; pstat = -1;            // one attempt per solve: an active set that does not verify at the loose tolerance rarely does later
-        if (!(tol_cur > C.ipm_tol)) return true;
-        tol_cur = C.ipm_tol; pmode = 0; status = PG_MAX_ITER;
+        pstat = -1;
+        if (!(tol_cur > C.ipm_tol)) { polish_gave_up = true; return true; }
+        tol_cur = C.ipm_tol; pmode = 0; status = PG_MAX_ITER; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu;
 #pragma unroll
         for (int j = 0; j < NROW; j++) R.lam[j] = (act && j < nrows) ? mu * frcp(R.t[j]) : real(0.0);
         return false;
