@@ -211,6 +211,14 @@ int pg_hji_lookup(pg_handle* h, int32_t B, const double* x7, double* V, double* 
 int pg_hji_lookup_dev(pg_handle* h, int32_t B, const pg_real_dev* x7_dev, pg_real_dev* V_dev, pg_real_dev* gradV_dev);
 /* packed form, no temporaries, asynchronous on the handle's stream: out8 [B][8] = (V, gradV[0..6]) per lookup (the kernel's native output) */
 int pg_hji_lookup8_dev(pg_handle* h, int32_t B, const pg_real_dev* x7_dev, pg_real_dev* out8_dev);
+/* dims of the installed grid (HJICache.grid_knots lengths) */
+int pg_hji_grid_dims(pg_handle* h, int32_t dims[7]);
+/* 2-D value slices for the RViz consumers, batched: src/rviz.jl:23-40 (update_HJI_values_marker!) and :60-69 (update_HJI_contour_marker!) evaluate
+ * cache[HJIRelativeState(x, y, q[3..7])].V at every knot pair (x, y) of grid dimensions 1 and 2.  q7 [B][7] relative states (components 0, 1 are replaced by
+ * the knots); V_out [B][n1][n2] = V(X[i], Y[j]);  rgb_out [B][n1][n2][3] or NULL = value_to_RGB(V) (rviz.jl:41-44);  zero-level crossings = the vertex set of
+ * contour(X, Y, V, 0) (:63): cross_x [B][n1-1][n2] = x where V changes sign between (X[i], Y[j]) and (X[i+1], Y[j]), NaN where it does not;
+ * cross_y [B][n1][n2-1] likewise along y (either may be NULL).  An edge carries a vertex iff exactly one end has V > 0 (Contour.jl's marching-squares rule). */
+int pg_hji_slice(pg_handle* h, int32_t B, const double* q7, double* V_out, double* rgb_out, double* cross_x, double* cross_y);
 /* compute_reachability_constraint for the installed inputs: M [B][2] (already multiplied by u_normalization), b [B], V [B] */
 int pg_get_hji_constraint(pg_handle* h, double* M, double* b, double* V);
 /* wall extension (pg_config.walls): (edge_L, edge_R) at nodes 2..N+1 of every instance, [B][N][2]; PG_ERR_STATE when walls are off.

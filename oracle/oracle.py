@@ -166,6 +166,23 @@ class Oracle:
         inb = self.L.po_hji_lookup(self.h, _d(_arr(x7, 7)), C.byref(V), _d(g))
         return V.value, g, bool(inb)
 
+    def hji_slice(self, knots, q7):
+        """rviz.jl:23-40,60-69 restated: V at every knot pair (x, y) of grid dimensions 1, 2 with the other five components of the relative state q7;
+        marker colours (value_to_RGB :41-44); zero-level crossings on the grid edges = vertex set of Contour.jl's contour(X, Y, V, 0)
+        (an edge carries a vertex iff exactly one end is above the level; linear interpolation along the edge)."""
+        X = np.asarray(knots[0], dtype=np.float64); Y = np.asarray(knots[1], dtype=np.float64)
+        V = np.zeros((len(X), len(Y)))
+        for i, x in enumerate(X):
+            for j, y in enumerate(Y):
+                V[i, j] = self.hji_lookup([x, y] + [float(v) for v in q7[2:]])[0]
+        xx = np.clip(np.where(V < 0, 0.5 * (-3.0 - V) / -3.0, 0.5 + 0.5 * V / 20.0), 0.0, 1.0)
+        rgb = (1 - xx)[..., None] * np.array([1.0, 0.5, 0.0]) + xx[..., None] * np.array([0.0, 0.5, 1.0])
+        up = V > 0
+        with np.errstate(invalid="ignore", divide="ignore"):
+            cx = np.where(up[:-1] != up[1:], X[:-1, None] + (0 - V[:-1]) / (V[1:] - V[:-1]) * (X[1:, None] - X[:-1, None]), np.nan)
+            cy = np.where(up[:, :-1] != up[:, 1:], Y[None, :-1] + (0 - V[:, :-1]) / (V[:, 1:] - V[:, :-1]) * (Y[None, 1:] - Y[None, :-1]), np.nan)
+        return V, rgb, cx, cy
+
     def hji_optimal_control(self, state6, other4):
         """(V, (delta_opt, Fx_opt)): optimal_control of HJI_computation.jl:133-158 at cache[relative_state].gradV"""
         u2 = np.zeros(2)

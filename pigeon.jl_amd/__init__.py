@@ -6,4 +6,5 @@ from ._lib import PigeonError, load_library, LIB_PATH, LIB_PATH_F32, SYMBOLS  # 
 from .mpc import BatchedTrajectoryTrackingMPC, CoupledTrajectoryTrackingMPC, DecoupledTrajectoryTrackingMPC, decoupled_canonical_active_set, simulate, SOLVED, MAX_ITER, NUMERICAL, INFEASIBLE_X0  # noqa: F401
 from .trajectories import TrajectoryTube, straight_trajectory, load_path_fixture, invcumtrapz  # noqa: F401
 from .vehicles import X1, CoupledControlParams, DecoupledControlParams  # noqa: F401
-from . import synthetic, sharding  # noqa: F401
+from .hji_io import load_hji_grid, save_hji_grid, trace_zero_contour  # noqa: F401
+from . import synthetic, sharding, trajectories, hji_io  # noqa: F401

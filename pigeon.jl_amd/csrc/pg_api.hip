@@ -668,6 +668,38 @@ int pg_hji_lookup8_dev(pg_handle* h, int32_t B, const void* x7_dev, void* out8_d
     HIPCHK(h, hipSetDevice(h->cfg.device));
     return launch_hji_lookup(h, B, (const real*)x7_dev, (real*)out8_dev);
 }
+int pg_hji_grid_dims(pg_handle* h, int32_t dims[7]) {
+    if (!h || !dims) return PG_ERR_INVALID;
+    REQUIRE(h, h->has_hji, "no HJI grid installed");
+    for (int d = 0; d < 7; d++) dims[d] = h->hv.dims[d];
+    return PG_OK;
+}
+int pg_hji_slice(pg_handle* h, int32_t B, const double* q7, double* V_out, double* rgb_out, double* cross_x, double* cross_y) {
+    if (!h) return PG_ERR_INVALID;
+    REQUIRE(h, h->has_hji, "no HJI grid installed");
+    REQUIRE(h, B >= 1 && q7 && V_out, "pg_hji_slice: need B >= 1, the relative states and V_out");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int n1 = h->hv.dims[0], n2 = h->hv.dims[1]; const size_t npt = (size_t)B * n1 * n2;
+    real *dq = nullptr, *dx = nullptr, *dv = nullptr, *dV = nullptr, *drgb = nullptr, *dcx = nullptr, *dcy = nullptr;
+    int rc = PG_OK;
+    auto cleanup = [&]() { for (void* p : {(void*)dq, (void*)dx, (void*)dv, (void*)dV, (void*)drgb, (void*)dcx, (void*)dcy}) if (p) (void)hipFree(p); };
+#define SL_ALLOC(ptr, count) do { if (hipMalloc((void**)&(ptr), (size_t)(count) * sizeof(real)) != hipSuccess) { h->err = "pg_hji_slice: hipMalloc failed"; cleanup(); return PG_ERR_HIP; } } while (0)
+    SL_ALLOC(dq, (size_t)B * 7); SL_ALLOC(dx, npt * 7); SL_ALLOC(dv, npt * 8); SL_ALLOC(dV, npt);
+    if (rgb_out) SL_ALLOC(drgb, npt * 3);
+    if (cross_x) SL_ALLOC(dcx, (size_t)B * (n1 - 1) * n2);
+    if (cross_y) SL_ALLOC(dcy, (size_t)B * n1 * (n2 - 1));
+#undef SL_ALLOC
+    if ((rc = up(h, dq, q7, (size_t)B * 7))) { cleanup(); return rc; }
+    const dim3 grid((unsigned)((npt + 255) / 256));
+    hipLaunchKernelGGL(k_hji_slice_queries, grid, dim3(256), 0, h->stream, h->hv, B, dq, dx);
+    if ((rc = launch_hji_lookup(h, (int)npt, dx, dv))) { cleanup(); return rc; }
+    hipLaunchKernelGGL(k_hji_slice_post, grid, dim3(256), 0, h->stream, h->hv, B, dv, dV, drgb, dcx, dcy);
+    if (hipGetLastError() != hipSuccess) { h->err = "pg_hji_slice: kernel launch failed"; cleanup(); return PG_ERR_HIP; }
+    if ((rc = down(h, V_out, dV, npt)) || (rc = down(h, rgb_out, drgb, npt * 3)) || (rc = down(h, cross_x, dcx, (size_t)B * (n1 - 1) * n2)) ||
+        (rc = down(h, cross_y, dcy, (size_t)B * n1 * (n2 - 1)))) { cleanup(); return rc; }
+    cleanup();
+    return PG_OK;
+}
 int pg_hji_lookup(pg_handle* h, int32_t B, const double* x7, double* V, double* gradV) {
     if (!h) return PG_ERR_INVALID;
     REQUIRE(h, h->has_hji, "no HJI grid installed");

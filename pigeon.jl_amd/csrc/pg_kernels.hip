@@ -725,6 +725,45 @@ __global__ __launch_bounds__(256) void k_hji_lookup(HjiView Hv, int B, const rea
     }
 }
 
+// 2-D value slices for the RViz consumers (rviz.jl:23-40 update_HJI_values_marker!, :60-69 update_HJI_contour_marker!): both evaluate
+// cache[HJIRelativeState(x, y, q[3], ..., q[7])].V at every knot pair (x, y) of grid dimensions 1 and 2.  k_hji_slice_queries writes those relative states
+// (thread = (instance, i, j)), k_hji_lookup evaluates them (the same gather kernel as the safety row), k_hji_slice_post turns the values into the marker
+// colours (value_to_RGB, rviz.jl:41-44) and into the zero-level crossings on the grid edges -- the vertex set of Contour.jl's contour(X, Y, V, 0):
+// an edge carries a vertex iff exactly one of its ends is above the level (z > 0), at the linearly interpolated position.
+__global__ __launch_bounds__(256) void k_hji_slice_queries(HjiView Hv, int B, const real* __restrict__ q7, real* __restrict__ x7) {
+    const int n1 = Hv.dims[0], n2 = Hv.dims[1];
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)B * n1 * n2) return;
+    const int b = (int)(gid / (n1 * n2)); const int r = (int)(gid - (long)b * n1 * n2); const int i = r / n2, j = r - i * n2;
+    const real* q = q7 + (size_t)b * 7; real* x = x7 + (size_t)gid * 7;
+    x[0] = (real)Hv.knots[Hv.koff[0] + i]; x[1] = (real)Hv.knots[Hv.koff[1] + j];
+#pragma unroll
+    for (int d = 2; d < 7; d++) x[d] = q[d];
+}
+__global__ __launch_bounds__(256) void k_hji_slice_post(HjiView Hv, int B, const real* __restrict__ vg8, real* __restrict__ V_out, real* __restrict__ rgb, real* __restrict__ cross_x,
+                                                        real* __restrict__ cross_y) {
+    const int n1 = Hv.dims[0], n2 = Hv.dims[1];
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)B * n1 * n2) return;
+    const int b = (int)(gid / (n1 * n2)); const int r = (int)(gid - (long)b * n1 * n2); const int i = r / n2, j = r - i * n2;
+    const real z = vg8[(size_t)gid * 8];
+    V_out[gid] = z;
+    if (rgb) {                                   // value_to_RGB(V, V_lo = -3, V_hi = 20, C_lo = (1, .5, 0), C_hi = (0, .5, 1))
+        real xx = z < real(0.0) ? real(0.5) * (real(-3.0) - z) / real(-3.0) : real(0.5) + real(0.5) * z / real(20.0);
+        xx = xx < real(0.0) ? real(0.0) : (xx > real(1.0) ? real(1.0) : xx);
+        rgb[gid * 3] = real(1.0) - xx; rgb[gid * 3 + 1] = real(0.5); rgb[gid * 3 + 2] = xx;
+    }
+    const real x0 = (real)Hv.knots[Hv.koff[0] + i], y0 = (real)Hv.knots[Hv.koff[1] + j];
+    if (cross_x && i + 1 < n1) {
+        const real z1 = vg8[(size_t)(gid + n2) * 8], x1 = (real)Hv.knots[Hv.koff[0] + i + 1];
+        cross_x[((size_t)b * (n1 - 1) + i) * n2 + j] = ((z > real(0.0)) != (z1 > real(0.0))) ? x0 + (real(0.0) - z) / (z1 - z) * (x1 - x0) : NAN;
+    }
+    if (cross_y && j + 1 < n2) {
+        const real z1 = vg8[(size_t)(gid + 1) * 8], y1 = (real)Hv.knots[Hv.koff[1] + j + 1];
+        cross_y[((size_t)b * n1 + i) * (n2 - 1) + j] = ((z > real(0.0)) != (z1 > real(0.0))) ? y0 + (real(0.0) - z) / (z1 - z) * (y1 - y0) : NAN;
+    }
+}
+
 // optimal_disturbance (dMode=:min) HJI_computation.jl:90-131 + compute_reachability_constraint :160-170, lane = instance
 __global__ __launch_bounds__(64) void k_hji_constraint(DevCfg C, int B, const real* __restrict__ x7, const real* __restrict__ vg8, const real* __restrict__ control,
                                  real* __restrict__ Mb) {

@@ -294,6 +294,18 @@ class BatchedTrajectoryTrackingMPC:
         self._chk(self.lib.pg_hji_lookup(self.h, B, _p(x), _p(V), _p(g)), "pg_hji_lookup")
         return V, g
 
+    def hji_value_slice(self, q7, colors=False, contour=True):
+        """rviz.jl:23-40,60-69 for a batch of relative states: V [B, n1, n2] at every knot pair of grid dimensions 1, 2 (the other five components from q7),
+        optionally the marker colours [B, n1, n2, 3] and the zero-level crossings on the grid edges (cross_x [B, n1-1, n2], cross_y [B, n1, n2-1]; NaN = none)."""
+        q = _f64(q7).reshape(-1, 7); B = q.shape[0]
+        dims = np.zeros(7, dtype=np.int32)
+        self._chk(self.lib.pg_hji_grid_dims(self.h, _p(dims, C.POINTER(C.c_int32))), "pg_hji_grid_dims")
+        n1, n2 = int(dims[0]), int(dims[1])
+        V = np.zeros((B, n1, n2)); rgb = np.zeros((B, n1, n2, 3)) if colors else None
+        cx = np.zeros((B, n1 - 1, n2)) if contour else None; cy = np.zeros((B, n1, n2 - 1)) if contour else None
+        self._chk(self.lib.pg_hji_slice(self.h, B, _p(q), _p(V), _p(rgb), _p(cx), _p(cy)), "pg_hji_slice")
+        return V, rgb, cx, cy
+
     # ---- canonical active-set indices (row numbering of the reference's QP, SURVEY.md section 8a) ----
     def canonical_active_set(self, b, act_masks, qp_row):
         """Signed 1-based row indices of the reference QP that are active for instance b: +i upper bound, -i lower bound.

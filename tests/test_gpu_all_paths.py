@@ -11,8 +11,16 @@ from conftest import ROOT, make_oracle
 
 pytestmark = pytest.mark.gpu
 
-PATHS = sorted(f[:-4] for f in os.listdir(os.path.join(ROOT, "tests", "golden", "paths")) if f.endswith(".npz"))
+PATHS = sorted(f[:-4] for f in os.listdir(os.path.join(ROOT, "tests", "golden", "paths")) if f.endswith(".npz")) + ["raw:curvy.world", "raw:curvy.msg"]
 B = 384
+
+
+def load_tube(pkg, path):
+    """npz fixtures (decoded channels) or, for the raw data files, the product's own ingest (TrajectoryTube.from_world / from_path_msg)."""
+    if path.startswith("raw:"):
+        f = os.path.join(ROOT, "tests", "golden", "raw", path[4:])
+        return pkg.TrajectoryTube.from_world(f) if f.endswith(".world") else pkg.TrajectoryTube.from_path_msg(f)
+    return pkg.load_path_fixture(path)
 
 
 def rel_inf(a, b, floor=1.0):
@@ -23,7 +31,7 @@ def rel_inf(a, b, floor=1.0):
 @pytest.mark.parametrize("traj_mode", [True, False], ids=["traj", "path"])
 @pytest.mark.parametrize("path", PATHS)
 def test_path_sweep(pkg, oracle_mod, path, traj_mode):
-    tube = pkg.load_path_fixture(path)
+    tube = load_tube(pkg, path)
     s_range = None if tube.s[-1] > 90 else (2.0, 0.4 * tube.s[-1])
     state, control, t0, toff = pkg.synthetic.config2_inputs(tube, B, seed=sum(map(ord, path)) % 1000, traj_mode=traj_mode, s_range=s_range)
     mpc = pkg.BatchedTrajectoryTrackingMPC(tube, B)

@@ -126,3 +126,39 @@ def test_hji_fallback_policy(pkg, oracle_mod, skidpad, grid):
             assert np.array_equal(u_on[i], u_mpc[i])
     assert seen == {0, 1}, seen                                      # both outcomes exercised
     mpc.close()
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_value_slices_colours_and_zero_contour(pkg, oracle_mod, skidpad, precision):
+    """SURVEY 8(f) N4, the RViz consumers (rviz.jl:23-40 values marker, :60-69 contour marker) as one batched call: V at every (x, y) knot pair, the marker
+    colours, and the zero-level crossings, against the oracle's restatement; the traced line is a walk along V = 0."""
+    knots, V, g = pkg.synthetic.hji_grid(dims=(21, 17, 5, 4, 4, 5, 4), seed=4)
+    mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, 8, precision=precision)
+    mpc.set_hji_cache(knots, V, g)
+    orc = make_oracle(oracle_mod, skidpad); orc.set_hji_grid(knots, V, g)
+    rng = np.random.default_rng(1)
+    lo = np.array([k[0] for k in knots], dtype=np.float64); hi = np.array([k[-1] for k in knots], dtype=np.float64)
+    q = lo + (hi - lo) * rng.uniform(0.1, 0.9, (6, 7))
+    q[5, 5] = hi[5] + 1.0                                            # one relative state outside the grid: the whole slice is +Inf, no contour
+    if precision == "f32":
+        q = q.astype(np.float32).astype(np.float64)
+    Vs, rgb, cx, cy = mpc.hji_value_slice(q, colors=True)
+    tol = 1e-12 if precision == "f64" else 2e-6
+    n_lines = 0
+    for b in range(6):
+        Vo, rgbo, cxo, cyo = orc.hji_slice(knots, q[b])
+        if b == 5:
+            assert np.all(np.isinf(Vs[b])) and np.all(np.isnan(cx[b])) and np.all(np.isnan(cy[b]))
+            continue
+        assert np.max(np.abs(Vs[b] - Vo)) <= tol * max(1.0, np.max(np.abs(Vo)))
+        assert np.max(np.abs(rgb[b] - rgbo)) <= max(tol, 1e-12) * 10
+        if precision == "f64":                                       # (in fp32 a value within rounding of 0 may change sides)
+            assert np.array_equal(np.isnan(cx[b]), np.isnan(cxo)) and np.array_equal(np.isnan(cy[b]), np.isnan(cyo))
+            assert np.nanmax(np.abs(cx[b] - cxo), initial=0.0) <= 1e-10 and np.nanmax(np.abs(cy[b] - cyo), initial=0.0) <= 1e-10
+        line = pkg.trace_zero_contour(knots[0], knots[1], cx[b], cy[b])
+        if line:
+            n_lines += 1
+            for (x, y) in line[:: max(1, len(line) // 8)]:          # V vanishes at the traced vertices (bilinear interpolation along a grid edge is exact)
+                assert abs(mpc.hji_lookup(np.array([x, y] + list(q[b, 2:])))[0][0]) <= (1e-9 if precision == "f64" else 1e-4)
+    assert n_lines >= 3
+    mpc.close()
