@@ -103,6 +103,12 @@ typedef struct pg_config {
 
 enum pg_formulation { PG_COUPLED = 0, PG_DECOUPLED = 1 };
 
+/* Layout check for hand-written mirrors of this header (ctypes, Julia): fills out[0..] with sizeof(pg_config), sizeof(pg_vehicle), sizeof(pg_control_params)
+ * and the byte offsets inside pg_config of: control, N_short, dt_short, use_correction_step, hji_eps, batch_capacity, ipm_max_iter, formulation, ipm_tol, ipm_mu0,
+ * walls, wall_weight, polish, polish_rho, polish_tol, polish_ipm_tol; then offsetof(pg_control_params, N_HJI) and offsetof(pg_vehicle, kappa_max).
+ * Returns the number of entries (21); out may be NULL, at most n entries are written. */
+int pg_abi_layout(int32_t* out, int32_t n);
+
 /* X1() and the default keyword values of the reference constructors (coupled formulation) */
 int pg_default_config(pg_config* cfg);
 /* DecoupledTrajectoryTrackingMPC(vehicle, trajectory; ...) defaults: src/decoupled_lat_long.jl:18-33.  The lateral formulation uses the

@@ -31,7 +31,7 @@ class pg_config(C.Structure):
 
 
 # every symbol include/pigeon_mpc.h declares (tests check that the built library exports each one)
-SYMBOLS = ["pg_precision_bits", "pg_default_config", "pg_default_config_decoupled", "pg_create", "pg_destroy", "pg_last_error", "pg_get_config", "pg_get_u_normalization", "pg_set_trajectory", "pg_set_trajectories", "pg_set_trajectory_index",
+SYMBOLS = ["pg_precision_bits", "pg_abi_layout", "pg_default_config", "pg_default_config_decoupled", "pg_create", "pg_destroy", "pg_last_error", "pg_get_config", "pg_get_u_normalization", "pg_set_trajectory", "pg_set_trajectories", "pg_set_trajectory_index",
            "pg_set_hji_grid", "pg_clear_hji_grid", "pg_reset", "pg_set_inputs", "pg_set_inputs_dev", "pg_compute_time_steps",
            "pg_compute_linearization_nodes", "pg_update_qp", "pg_solve", "pg_get_next_control", "pg_get_next_control_dev", "pg_get_next_control_hji", "pg_get_next_control_hji_dev", "pg_step", "pg_step_dev", "pg_simulate_dev", "pg_get_state",
            "pg_set_stream", "pg_synchronize", "pg_get_time_steps", "pg_get_nodes", "pg_get_path_coordinates", "pg_qp_len", "pg_get_qp", "pg_get_solution",
@@ -56,8 +56,28 @@ def load_library(precision="f64"):
     for s in SYMBOLS:
         getattr(lib, s)
     assert lib.pg_precision_bits() == (64 if precision == "f64" else 32)
+    check_layout(lib)
     _libs[precision] = lib
     return lib
+
+
+LAYOUT_FIELDS = ["control", "N_short", "dt_short", "use_correction_step", "hji_eps", "batch_capacity", "ipm_max_iter", "formulation", "ipm_tol", "ipm_mu0", "walls", "wall_weight",
+                 "polish", "polish_rho", "polish_tol", "polish_ipm_tol"]
+
+
+def mirror_layout():
+    """The numbers pg_abi_layout reports, computed from the ctypes mirrors above."""
+    return [C.sizeof(pg_config), C.sizeof(pg_vehicle), C.sizeof(pg_control_params)] + [getattr(pg_config, f).offset for f in LAYOUT_FIELDS] + \
+           [pg_control_params.N_HJI.offset, pg_vehicle.kappa_max.offset]
+
+
+def check_layout(lib):
+    """The ctypes structs are a hand copy of include/pigeon_mpc.h: refuse to run against a library whose struct layout differs."""
+    n = lib.pg_abi_layout(None, 0)
+    out = (C.c_int32 * n)()
+    lib.pg_abi_layout(out, n)
+    if list(out) != mirror_layout():
+        raise PigeonError(f"struct layout of the ctypes mirror {mirror_layout()} differs from the library's {list(out)}: update pigeon.jl_amd/_lib.py to include/pigeon_mpc.h")
 
 
 def check(lib, h, rc, what):

@@ -2,6 +2,7 @@
 // The product path has NO CPU fallback: without a HIP device pg_create fails with PG_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -33,6 +34,7 @@ struct pg_handle {
     hipEvent_t ev[4]; bool ev_ok = false; float phase_ms[3] = {0, 0, 0}; bool timing_valid = false;
     size_t solve_lds = 0; bool solve_ring = false;
     real* d_walls = nullptr;                                    // [cap][N][2] wall extension
+    char* h_stage = nullptr; size_t stage_bytes = 0;            // pinned host staging of pg_set_inputs / pg_step (one stream synchronisation per call instead of one per array)
     real* d_ws4 = nullptr; bool solve_quad = false; size_t solve4_lds = 0;   // k_solve4 (four instances per wavefront)
 };
 
@@ -139,6 +141,7 @@ static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_state, h->d_control, h->d_t0, h->d_other, h->d_toff, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
                     h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->ev_ok) for (int i = 0; i < 4; i++) (void)hipEventDestroy(h->ev[i]);
 }
 
@@ -190,6 +193,8 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     if (cfg->walls) { ALLOC(h->d_walls, cap * N * 2, real); C.walls = 1; C.wall_weight = (real)cfg->wall_weight; C.wall_edges = h->d_walls; if (h->solve_quad) { g_create_error = "PG_SOLVER=quad does not carry the wall rows"; free_all(h); delete h; return PG_ERR_INVALID; } }
     ALLOC(h->d_pol_u2, cap * 2, real); ALLOC(h->d_pol_u, cap * 3, real); ALLOC(h->d_pol_src, cap, int);
 #undef ALLOC
+    h->stage_bytes = cap * (13 * sizeof(real) + 16);          // inputs: state 6 + control 3 + other 4 (real) + t0 + time_offset (double); outputs reuse the front of it
+    if (hipHostMalloc((void**)&h->h_stage, h->stage_bytes, hipHostMallocDefault) != hipSuccess) { g_create_error = "hipHostMalloc failed for the staging buffer"; free_all(h); delete h; return PG_ERR_HIP; }
     // initial ts = 1..NN (model_predictive_control.jl:13), solved = false
     {
         std::vector<double> ts(cap * NN), dt(cap * N, 1.0);
@@ -233,6 +238,18 @@ int pg_get_u_normalization(const pg_handle* h, double out[2]) {
     return PG_OK;
 }
 int pg_precision_bits(void) { return (int)(8 * sizeof(real)); }
+// Layout of the configuration structs as THIS library was compiled: the ctypes mirror (pigeon.jl_amd/_lib.py) and the Julia mirror (julia/PigeonMI355X.jl)
+// are hand-written copies of include/pigeon_mpc.h; they compare their own sizeof / field offsets with these numbers before the first pg_create.
+int pg_abi_layout(int32_t* out, int32_t n) {
+#define OFF(f) (int32_t)offsetof(pg_config, f)
+    const int32_t v[] = {(int32_t)sizeof(pg_config), (int32_t)sizeof(pg_vehicle), (int32_t)sizeof(pg_control_params), OFF(control), OFF(N_short), OFF(dt_short), OFF(use_correction_step),
+                         OFF(hji_eps), OFF(batch_capacity), OFF(ipm_max_iter), OFF(formulation), OFF(ipm_tol), OFF(ipm_mu0), OFF(walls), OFF(wall_weight), OFF(polish), OFF(polish_rho),
+                         OFF(polish_tol), OFF(polish_ipm_tol), (int32_t)offsetof(pg_control_params, N_HJI), (int32_t)offsetof(pg_vehicle, kappa_max)};
+#undef OFF
+    const int32_t cnt = (int32_t)(sizeof(v) / sizeof(v[0]));
+    if (out) for (int32_t i = 0; i < cnt && i < n; i++) out[i] = v[i];
+    return cnt;
+}
 int pg_qp_len(const pg_handle* h) { return h ? h->dc.qp_len : PG_ERR_INVALID; }
 int pg_set_stream(pg_handle* h, void* s) { if (!h) return PG_ERR_INVALID; h->stream = (hipStream_t)s; return PG_OK; }
 int pg_synchronize(pg_handle* h) { if (!h) return PG_ERR_INVALID; HIPCHK(h, hipStreamSynchronize(h->stream)); return PG_OK; }
@@ -367,18 +384,33 @@ static int set_inputs(pg_handle* h, int32_t B, const void* state, const void* co
     const hipMemcpyKind kind = host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     int rc;
     if (host) {
-        if ((rc = up(h, h->d_state, (const double*)state, (size_t)B * 6)) || (rc = up(h, h->d_control, (const double*)control, (size_t)B * 3))) return rc;
-        if (other && (rc = up(h, h->d_other, (const double*)other, (size_t)B * 4))) return rc;
-    } else {
-        HIPCHK(h, hipMemcpyAsync(h->d_state, state, (size_t)B * 6 * sizeof(real), kind, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->d_control, control, (size_t)B * 3 * sizeof(real), kind, h->stream));
-        if (other) HIPCHK(h, hipMemcpyAsync(h->d_other, other, (size_t)B * 4 * sizeof(real), kind, h->stream));
+        // the caller's arrays are converted / copied into the pinned staging buffer here and now (so they may be reused as soon as this returns) and travel
+        // from there with asynchronous copies ordered before the kernels on the handle's stream: no synchronisation on the way in.  A previous call's
+        // copies must have left the buffer first.
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        real* st = (real*)h->h_stage; real* ct = st + (size_t)B * 6; real* ot = ct + (size_t)B * 3; double* tt = (double*)(ot + (size_t)B * 4); double* ft = tt + B;
+        const double* s_ = (const double*)state; const double* c_ = (const double*)control; const double* o_ = (const double*)other;
+        for (size_t i = 0; i < (size_t)B * 6; i++) st[i] = (real)s_[i];
+        for (size_t i = 0; i < (size_t)B * 3; i++) ct[i] = (real)c_[i];
+        if (o_) for (size_t i = 0; i < (size_t)B * 4; i++) ot[i] = (real)o_[i];
+        memcpy(tt, t0, (size_t)B * 8);
+        if (toff) memcpy(ft, toff, (size_t)B * 8);
+        HIPCHK(h, hipMemcpyAsync(h->d_state, st, (size_t)B * 6 * sizeof(real), kind, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_control, ct, (size_t)B * 3 * sizeof(real), kind, h->stream));
+        if (o_) HIPCHK(h, hipMemcpyAsync(h->d_other, ot, (size_t)B * 4 * sizeof(real), kind, h->stream));
+        else HIPCHK(h, hipMemsetAsync(h->d_other, 0, (size_t)B * 4 * sizeof(real), h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_t0, tt, (size_t)B * 8, kind, h->stream));
+        if (toff) HIPCHK(h, hipMemcpyAsync(h->d_toff, ft, (size_t)B * 8, kind, h->stream));
+        else HIPCHK(h, hipMemsetAsync(h->d_toff, 0xFF, (size_t)B * 8, h->stream));      // all-ones bit pattern is a NaN: path-tracking mode
+        return PG_OK;
     }
-    if (!other) HIPCHK(h, hipMemsetAsync(h->d_other, 0, (size_t)B * 4 * sizeof(real), h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_state, state, (size_t)B * 6 * sizeof(real), kind, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_control, control, (size_t)B * 3 * sizeof(real), kind, h->stream));
+    if (other) HIPCHK(h, hipMemcpyAsync(h->d_other, other, (size_t)B * 4 * sizeof(real), kind, h->stream));
+    else HIPCHK(h, hipMemsetAsync(h->d_other, 0, (size_t)B * 4 * sizeof(real), h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_t0, t0, (size_t)B * 8, kind, h->stream));
     if (toff) HIPCHK(h, hipMemcpyAsync(h->d_toff, toff, (size_t)B * 8, kind, h->stream));
     else HIPCHK(h, hipMemsetAsync(h->d_toff, 0xFF, (size_t)B * 8, h->stream));      // all-ones bit pattern is a NaN: path-tracking mode
-    if (host) HIPCHK(h, hipStreamSynchronize(h->stream));                           // host buffers may be reused by the caller
     return PG_OK;
 }
 int pg_set_inputs(pg_handle* h, int32_t B, const double* state, const double* control, const double* t0, const double* other, const double* toff) {
@@ -566,10 +598,16 @@ int pg_step(pg_handle* h, int32_t B, const double* state, const double* control,
             double* u_out, int32_t* status, int32_t* iters) {
     int rc = pg_set_inputs(h, B, state, control, t0, other, toff); if (rc) return rc;
     if ((rc = pg_step_dev(h, nullptr))) return rc;
-    if (u_out && (rc = pg_get_next_control(h, u_out))) return rc;
-    // read-backs are issued on the handle's stream (ordered after k_solve even when the caller installed a non-blocking stream)
-    if ((rc = down_raw(h, status, h->d_status, (size_t)B * sizeof(int))) || (rc = down_raw(h, iters, h->d_iters, (size_t)B * sizeof(int)))) return rc;
+    // controls, status and iteration counts come back through the pinned staging buffer: three asynchronous copies behind k_solve on the handle's stream
+    // (ordered even when the caller installed a non-blocking stream), ONE synchronisation, then the conversion into the caller's arrays
+    real* us = (real*)h->h_stage; int* ss = (int*)(us + (size_t)B * 3); int* is = ss + B;
+    if (u_out) HIPCHK(h, hipMemcpyAsync(us, h->d_u, (size_t)B * 3 * sizeof(real), hipMemcpyDeviceToHost, h->stream));
+    if (status) HIPCHK(h, hipMemcpyAsync(ss, h->d_status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (iters) HIPCHK(h, hipMemcpyAsync(is, h->d_iters, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (u_out) for (size_t i = 0; i < (size_t)B * 3; i++) u_out[i] = (double)us[i];
+    if (status) memcpy(status, ss, (size_t)B * sizeof(int));
+    if (iters) memcpy(iters, is, (size_t)B * sizeof(int));
     return PG_OK;
 }
 
