@@ -130,7 +130,7 @@ int pg_default_config_decoupled(pg_config* c) {
     // polish off by default here: the lateral QP's far horizon is weakly determined (degenerate rows), ~9 % of the N = 50 instances do not verify an active set,
     // and what the polish improves there (the far-horizon steering, p99 error 4e-4 -> 6e-8) feeds nothing: this formulation has no warm start and only delta_2
     // is applied, which the interior point already has to 1e-13 (median).  Measured: +8 % solve time (tools/gpu_dec_polish.py).  Set polish = 1 to have it.
-    c->polish = 0; c->polish_tol = 1e-7;
+    c->polish = 0;
 #ifdef PG_F32
     c->ipm_tol = 1e-4;                               // the ill-conditioned 8 s lateral horizon stalls near 1e-4 in fp32 (tests/test_gpu_f32.py)
 #endif

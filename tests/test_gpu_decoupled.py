@@ -19,7 +19,7 @@ def embed_sd(orc, sd, ux_dummy=8.0):
 @pytest.mark.parametrize("Ns,Nl", [(10, 20), (10, 40)])
 def test_decoupled_matches_oracle(pkg, oracle_mod, skidpad, Ns, Nl):
     B = 64
-    mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, B, N_short=Ns, N_long=Nl)
+    mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, B, N_short=Ns, N_long=Nl, polish=True)      # (off by default for this formulation: see pg_default_config_decoupled)
     assert np.array_equal(mpc.u_normalization, [1.0, 1.0])
     orc = oracle_mod.OracleDecoupled(N_short=Ns, N_long=Nl); orc.set_trajectory(skidpad.data)
     assert (orc.n, orc.m) == ((245, 455) if Nl == 20 else (405, 755))
@@ -80,7 +80,7 @@ def test_walls_extension_matches_oracle_qp_with_wall_rows(pkg, oracle_mod, skidp
                       kappa * V + rng.uniform(-0.02, 0.02, B)], axis=1)
     control = np.stack([rng.uniform(-0.02, 0.02, B), np.zeros(B), rng.uniform(0, 300.0, B)], axis=1)
     t0 = tt + rng.uniform(-0.1, 0.1, B); toff = np.zeros(B)
-    mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), tube, B, N_short=Ns, N_long=Nl, walls=True, wall_weight=Ww)
+    mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), tube, B, N_short=Ns, N_long=Nl, walls=True, wall_weight=Ww, polish=True)
     free = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), tube, B, N_short=Ns, N_long=Nl)
     u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
     uf, stf, _ = free.step_(state, control, t0, time_offset=toff)
