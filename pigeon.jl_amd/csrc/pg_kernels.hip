@@ -1119,14 +1119,16 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     const real* qbase = qidx >= 0 ? sQ + qidx : sZero;
     const int qmul = qidx >= 0 ? 10 : 0;
 
-#if !defined(PG_F32) && !defined(PG_NO_MFMA)
-    // ---- Riccati matrix pass on the matrix cores (fp64): v_mfma_f64_16x16x4_f64, lane = (g, c) = (lane >> 4, lane & 15) -------------------------------------
+#if !defined(PG_NO_MFMA)
+    // ---- Riccati matrix pass on the matrix cores: v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32, lane = (g, c) = (lane >> 4, lane & 15) ------------------------
     // The stage recursion  M = P [A B c],  C = [A B]' [M_A M_B y],  P_k = Q + A'M_A + F'K,  K = -S^-1 F  is three chained products of genuinely dense 8 x {8,11}
-    // blocks.  Operand layout of the instruction: A-operand lane holds A[m = c][k = 4s + g], B-operand lane holds B[k = 4s + g][n = c], result register r of
-    // lane (g, c) holds D[g + 4 r][c] -- so rows 0..7 of a RESULT (registers 0, 1) are, as they stand, the B operands of the two k-steps of the next product, and
-    // (P being symmetric) also its A operands: the chain needs no cross-lane movement at all, and the 8 x 8 x 11 product that cost 24 LDS reads + 14 FMAs per lane
-    // costs two operand reads and two MFMAs.  Column 10 carries the predictor's VECTOR recursion through the same products: M[:,10] = P c, the second product
-    // is fed y = P c + p_{k+1} in that column, and the third adds F' kff, so that column 10 of the result is A'y + K'f = p_k - q.
+    // blocks.  Operand layout of the instruction: A-operand lane holds A[m = c][k = 4s + g], B-operand lane holds B[k = 4s + g][n = c].  In the "operand layout"
+    // used below a matrix Z is held as two values per lane, z_s = Z[4s + g][c] (s = 0, 1: rows 0..7): that IS the B operand of k-step s, and -- P being
+    // symmetric -- also the A operand.  The fp64 instruction returns result register r = D[g + 4r][c], i.e. registers 0, 1 of a RESULT are already in operand
+    // layout: the chain needs no cross-lane movement at all; the fp32 instruction returns D[4g + r][c] and needs one 4 x 4 (row group x register) transpose per
+    // hand-over, four v_permlane{16,32}_swap.  The 8 x 8 x 11 product that cost 24 LDS reads + 14 FMAs per lane on the VALU costs two operand reads and two
+    // MFMAs.  Column 10 carries the predictor's VECTOR recursion through the same products: M[:,10] = P c, the second product is fed y = P c + p_{k+1} in
+    // that column, and the third adds F' kff, so that column 10 of the result is A'y + K'f = p_k - q.
     // Round 1 ran this pass on the VALU with two LDS exchanges per stage (46 % of the kernel: 2450 cycles per stage, co-limited by LDS bandwidth and issue).
     const int mg = lane >> 4, mc = lane & 15;
     int xoff[2]; bool xlds[2]; real xcst[2];
@@ -1137,74 +1139,99 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         xoff[sgi] = !xlds[sgi] ? 0 : (mc < 8 ? SB_ROW * row + mc : (mc < 10 ? SB_B + 2 * row + (mc - 8) : SB_C + row));
         xcst[sgi] = (row == 6 && (mc == 6 || mc == 8)) || (row == 7 && (mc == 7 || mc == 9)) ? real(1.0) : real(0.0);
     }
-    const real* abase[2]; int amul[2];             // what is added to result register r: Qhat_k[g + 4 r][c] (c < 8), qhat_k[g + 4 r] (c == 10), nothing elsewhere
+    const real* abase[2]; int amul[2];             // what is added to the operand-layout value s: Qhat_k[4s + g][c] (c < 8), qhat_k[4s + g] (c == 10), nothing elsewhere
 #pragma unroll
     for (int r = 0; r < 2; r++) {
-        const int row = mg + 4 * r;
+        const int row = 4 * r + mg;
         const int qi = (row == mc) ? row : (((row == 2 && mc == 3) || (row == 3 && mc == 2)) ? 8 : (((row == 6 && mc == 7) || (row == 7 && mc == 6)) ? 9 : -1));
         abase[r] = mc < 8 ? (qi >= 0 ? sQ + qi : sZero) : (mc == 10 ? sq + row : sZero);
         amul[r] = mc < 8 ? (qi >= 0 ? 10 : 0) : (mc == 10 ? 8 : 0);
     }
-    typedef double mfma_acc __attribute__((ext_vector_type(4)));
-    auto all_rows = [&](double v, double& r0, double& r1) {     // v held by rows 0 and 1 (lanes (0, c), (1, c)) -> every row gets both values (two lane-half / row swaps, no LDS)
-        unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-        auto sl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false); auto sh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);      // rows (R0, R1, R0, R1)
-        auto tl = __builtin_amdgcn_permlane16_swap(sl[0], sl[0], false, false); auto th = __builtin_amdgcn_permlane16_swap(sh[0], sh[0], false, false);
-        r0 = __hiloint2double((int)th[0], (int)tl[0]); r1 = __hiloint2double((int)th[1], (int)tl[1]);
+#ifdef PG_F32
+    typedef float mfma_acc __attribute__((ext_vector_type(4)));
+#define PG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+    // result (register r of lane (g, c) = D[4g + r][c]) -> operand layout: o_s = D[4s + g][c] = register g of lane (s, c): the 4 x 4 transpose of (row group, register)
+    auto to_operands = [&](const mfma_acc& a, real& o0, real& o1) {
+        auto p01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[0]), __float_as_uint(a[1]), false, false);      // rows: (R0.0, R1.0, R0.2, R1.2) / (R0.1, R1.1, R0.3, R1.3)
+        auto p23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[2]), __float_as_uint(a[3]), false, false);
+        auto q0 = __builtin_amdgcn_permlane32_swap(p01[0], p23[0], false, false);                                       // [0]: (R0.0, R1.0, R2.0, R3.0)
+        auto q1 = __builtin_amdgcn_permlane32_swap(p01[1], p23[1], false, false);                                       // [0]: (R0.1, R1.1, R2.1, R3.1)
+        o0 = __uint_as_float(q0[0]); o1 = __uint_as_float(q1[0]);
     };
+    // rows 8, 9 of a result (D[8 + j][c] = register j of lane (2, c)) broadcast to every row group
+    auto rows89 = [&](const mfma_acc& a, real& f0, real& f1) {
+        auto bc = [&](float v) { unsigned u = __float_as_uint(v); auto s2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // [1]: rows (r2, r3, r2, r3)
+                                 auto t2 = __builtin_amdgcn_permlane16_swap(s2[1], s2[1], false, false); return __uint_as_float(t2[0]); };   // [0]: (r2, r2, r2, r2)
+        f0 = bc(a[0]); f1 = bc(a[1]);
+    };
+#else
+    typedef double mfma_acc __attribute__((ext_vector_type(4)));
+#define PG_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0)
+    auto to_operands = [&](const mfma_acc& a, real& o0, real& o1) { o0 = a[0]; o1 = a[1]; };          // register r = D[g + 4r][c]: already the operand of k-step r
+    // rows 8, 9 (register 2 of lanes (0, c), (1, c)) broadcast to every row group: two lane-half / row swaps per dword, no LDS
+    auto rows89 = [&](const mfma_acc& a, real& f0, real& f1) {
+        unsigned lo = (unsigned)__double2loint(a[2]), hi = (unsigned)__double2hiint(a[2]);
+        auto sl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false); auto sh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);      // [0]: rows (r0, r1, r0, r1)
+        auto tl = __builtin_amdgcn_permlane16_swap(sl[0], sl[0], false, false); auto th = __builtin_amdgcn_permlane16_swap(sh[0], sh[0], false, false);
+        f0 = __hiloint2double((int)th[0], (int)tl[0]); f1 = __hiloint2double((int)th[1], (int)tl[1]);
+    };
+#endif
     auto riccati_matrices = [&]() {
-        double V0 = abase[0][amul[0] * N], V1 = abase[1][amul[1] * N];          // terminal: P_N = Qhat_N, p_N = qhat_N (same registers, column 10)
+        real V0 = abase[0][amul[0] * N], V1 = abase[1][amul[1] * N];          // terminal: P_N = Qhat_N, p_N = qhat_N (operand layout; the vector lives in column 10)
         ring_prime(N - 1, -1);
 #pragma unroll 1
         for (int k = N - 1; k >= 0; k--) {
             ring_step(k, -1);
             const real* Xk = ring_slot(k);
             // stage constants: none of these reads depends on the recursion
-            const double x0l = Xk[xoff[0]], x1l = Xk[xoff[1]];
-            const double add0 = abase[0][amul[0] * k], add1 = abase[1][amul[1] * k];
-            const double R0 = sR[2 * k], R1 = sR[2 * k + 1], r0v = sr[2 * k], r1v = sr[2 * k + 1];
-            const double b10 = xlds[0] ? x0l : xcst[0], b11 = xlds[1] ? x1l : xcst[1];
+            const real x0l = Xk[xoff[0]], x1l = Xk[xoff[1]];
+            const real add0 = abase[0][amul[0] * k], add1 = abase[1][amul[1] * k];
+            const real R0 = sR[2 * k], R1 = sR[2 * k + 1], r0v = sr[2 * k], r1v = sr[2 * k + 1];
+            const real b10 = xlds[0] ? x0l : xcst[0], b11 = xlds[1] ? x1l : xcst[1];
             // M = P X
-            mfma_acc M = {0.0, 0.0, 0.0, 0.0};
-            M = __builtin_amdgcn_mfma_f64_16x16x4f64(mc < 8 ? V0 : 0.0, b10, M, 0, 0, 0);
-            M = __builtin_amdgcn_mfma_f64_16x16x4f64(mc < 8 ? V1 : 0.0, b11, M, 0, 0, 0);
-            *(mc == 10 ? sMc + 8 * k + mg : sDum + lane) = M[0];                   // Mc_k = P_{k+1} cbar_k for the corrector's vector pass
-            *(mc == 10 ? sMc + 8 * k + 4 + mg : sDum + lane) = M[1];
+            mfma_acc Ma = {real(0.0), real(0.0), real(0.0), real(0.0)};
+            Ma = PG_MFMA(mc < 8 ? V0 : real(0.0), b10, Ma);
+            Ma = PG_MFMA(mc < 8 ? V1 : real(0.0), b11, Ma);
+            real M0, M1; to_operands(Ma, M0, M1);
+            *(mc == 10 ? sMc + 8 * k + mg : sDum + lane) = M0;                     // Mc_k = P_{k+1} cbar_k for the corrector's vector pass
+            *(mc == 10 ? sMc + 8 * k + 4 + mg : sDum + lane) = M1;
             // C = [Abar Bbar]' [M_A | M_B | y]
-            mfma_acc Cc = {0.0, 0.0, 0.0, 0.0};
-            Cc = __builtin_amdgcn_mfma_f64_16x16x4f64(mc < 10 ? b10 : 0.0, mc == 10 ? M[0] + V0 : M[0], Cc, 0, 0, 0);
-            Cc = __builtin_amdgcn_mfma_f64_16x16x4f64(mc < 10 ? b11 : 0.0, mc == 10 ? M[1] + V1 : M[1], Cc, 0, 0, 0);
-            // rows 8, 9 of C (register 2 of lanes (0, c), (1, c)): F = Bbar' M_A (c < 8), S - Rhat (c = 8, 9), Bbar' y (c = 10)
-            double F0c, F1c; all_rows(Cc[2], F0c, F1c);
-            const double S00 = R0 + rl(F0c, 8), S01 = rl(F0c, 9), S11 = R1 + rl(F1c, 9);
-            const double idet = frcp(S00 * S11 - S01 * S01);
-            const double I00 = S11 * idet, I01 = -S01 * idet, I11 = S00 * idet;
-            const double K0 = -(I00 * F0c + I01 * F1c), K1 = -(I01 * F0c + I11 * F1c);
-            const double f0 = r0v + F0c, f1 = r1v + F1c;                            // (meaningful in column 10)
-            const double kf0 = -(I00 * f0 + I01 * f1), kf1 = -(I01 * f0 + I11 * f1);
+            mfma_acc Cc = {real(0.0), real(0.0), real(0.0), real(0.0)};
+            Cc = PG_MFMA(mc < 10 ? b10 : real(0.0), mc == 10 ? M0 + V0 : M0, Cc);
+            Cc = PG_MFMA(mc < 10 ? b11 : real(0.0), mc == 10 ? M1 + V1 : M1, Cc);
+            // rows 8, 9 of C: F = Bbar' M_A (c < 8), S - Rhat (c = 8, 9), Bbar' y (c = 10)
+            real F0c, F1c; rows89(Cc, F0c, F1c);
+            const real S00 = R0 + rl(F0c, 8), S01 = rl(F0c, 9), S11 = R1 + rl(F1c, 9);
+            const real idet = frcp(S00 * S11 - S01 * S01);
+            const real I00 = S11 * idet, I01 = -S01 * idet, I11 = S00 * idet;
+            const real K0 = -(I00 * F0c + I01 * F1c), K1 = -(I01 * F0c + I11 * F1c);
+            const real f0 = r0v + F0c, f1 = r1v + F1c;                              // (meaningful in column 10)
+            const real kf0 = -(I00 * f0 + I01 * f1), kf1 = -(I01 * f0 + I11 * f1);
             *((mg < 2 && mc < 8) ? sK + 16 * k + 8 * mg + mc : sDum + lane) = mg == 0 ? K0 : K1;
             *(lane < 3 ? sSi + 4 * k + lane : sDum + lane) = lane == 0 ? I00 : (lane == 1 ? I01 : I11);
             *((mc == 10 && mg < 2) ? skf + 2 * k + mg : sDum + lane) = mg == 0 ? kf0 : kf1;
             // C += F' [K | kff]
-            const double a3 = mg == 0 ? F0c : (mg == 1 ? F1c : 0.0);
-            const double b3 = mg == 0 ? (mc == 10 ? kf0 : K0) : (mg == 1 ? (mc == 10 ? kf1 : K1) : 0.0);
-            Cc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, Cc, 0, 0, 0);
-            V0 = Cc[0] + add0; V1 = Cc[1] + add1;
+            const real a3 = mg == 0 ? F0c : (mg == 1 ? F1c : real(0.0));
+            const real b3 = mg == 0 ? (mc == 10 ? kf0 : K0) : (mg == 1 ? (mc == 10 ? kf1 : K1) : real(0.0));
+            Cc = PG_MFMA(a3, b3, Cc);
+            real C0, C1; to_operands(Cc, C0, C1);
+            V0 = C0 + add0; V1 = C1 + add1;
             // symmetrise P (see the note in the VALU version below) by a transpose through LDS -- every fourth stage: the A operand above reads P through its
-            // own result registers, i.e. as P', so an antisymmetric rounding error e changes sign each stage and grows by |eig(Abar)|^2; four stages of that
+            // own result, i.e. as P', so an antisymmetric rounding error e changes sign each stage and grows by |eig(Abar)|^2; four stages of that
             // are harmless for the N <= 32 horizons, and three LDS round trips in four leave the serial chain
             if (RING || (k & 3) == 0) {        // (long horizons -- the ring variant, N > 32 -- symmetrise every stage: at N = 50 the sparser schedule cost the interior point stragglers of 90 iterations)
                 *(mc < 8 ? sP + 9 * mg + mc : sDum + lane) = V0;
                 *(mc < 8 ? sP + 9 * (mg + 4) + mc : sDum + lane) = V1;
                 wave_sync();
                 const int tc = mc < 8 ? mc : 0;
-                const double T0 = sP[9 * tc + mg], T1 = sP[9 * tc + mg + 4];
-                V0 = mc < 8 ? 0.5 * (V0 + T0) : V0; V1 = mc < 8 ? 0.5 * (V1 + T1) : V1;
+                const real T0 = sP[9 * tc + mg], T1 = sP[9 * tc + mg + 4];
+                V0 = mc < 8 ? real(0.5) * (V0 + T0) : V0; V1 = mc < 8 ? real(0.5) * (V1 + T1) : V1;
                 wave_sync();
             }
         }
         __syncthreads();
     };
+#undef PG_MFMA
 #else
     // Riccati matrix pass (once per IPM iteration): lane (li, lj) owns P[li][lj]; two LDS round trips per stage, branch-free body
     auto riccati_matrices = [&]() {
