@@ -289,6 +289,17 @@ def main():
             hji["traffic"] = tr["hbm_bytes_per_launch"]; hji["traffic_source"] = tr["source"]
         except Exception:
             hji["traffic"] = None
+        # the two smaller device layouts pg_set_hji_grid falls back to when HBM is short (1 KiB records: 10 GB table; 256 B records: 2.6 GB), same grid -- far beyond
+        # the 256 MiB Infinity Cache in every layout (PG_HJI_CELL_DIMS is the library's test hook for forcing one)
+        fb = {}
+        for cd, lbl in ((5, "1 KiB cell records (4 per lookup)"), (3, "256 B cell records (16 per lookup)")):
+            os.environ["PG_HJI_CELL_DIMS"] = str(cd)
+            try:
+                r = lookup_rate(*pkg.synthetic.hji_grid_large(), lbl)
+                fb[lbl] = {k: r[k] for k in ("lookups_per_s", "avg_launch_ms", "achieved", "frac")}
+            finally:
+                os.environ.pop("PG_HJI_CELL_DIMS", None)
+        hji["fallback_layouts"] = fb
         # SURVEY 8(d) secondary number: a FOUR-dimensional value grid (BASELINE.json says "4D": relative position, heading, other-car speed) run through the
         # same 7-D kernel with the three remaining dimensions collapsed to two knots each -- every lookup still gathers one 4 KiB record
         hji["grid_4d"] = lookup_rate(*pkg.synthetic.hji_grid_large(dims=(49, 49, 25, 2, 2, 25, 2)), "4-D grid 49x49x25x25 embedded as 49x49x25x2x2x25x2 (three collapsed dimensions), 12 M nodes")

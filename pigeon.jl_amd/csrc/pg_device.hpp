@@ -135,6 +135,11 @@ PG_DEV real inv_fiala_tan(real Fy, real Ca, real Fy_max) {
     if (fabs(Fy) >= Fy_max) return -(real(3.0) * Fy_max / Ca) * sgn(Fy);
     return -(real(1.0) + cbrt(fabs(Fy) / Fy_max - real(1.0))) * sgn(Fy);
 }
+// same with 3 / Ca precomputed
+PG_DEV real inv_fiala_tan3(real Fy, real three_over_Ca, real Fy_max) {
+    if (fabs(Fy) >= Fy_max) return -(Fy_max * three_over_Ca) * sgn(Fy);
+    return -(real(1.0) + cbrt(fabs(Fy) / Fy_max - real(1.0))) * sgn(Fy);
+}
 // vehicle_dynamics.jl:64-76: 3-iteration front-axle load-transfer fixed point, then rear
 template <class T>
 PG_DEV void lateral_forces(const DevVehicle& P, T af, T ar, T Fxf, T Fxr, T sd, T cd, T& Fyf, T& Fyr) {   // af, ar: TANGENTS of the slip angles
@@ -276,6 +281,10 @@ PG_DEV Steady steady_state(const DevVehicle& P, real V, real A_tan, real kappa, 
     real rdot = A_tan * kappa;
     real Fxr = real(0.0), Fxf = real(0.0), A_out = A_tan, tb = real(0.0);
     bool beta_is_tan = false;
+    // loop-invariant reciprocals (the 90-iteration serial chain of the cold seeding pays ~100 cycles per fp64 division): the same number is used wherever the
+    // quotient is used, so the exact-cancellation logic below is unaffected
+    const real invL = real(1.0) / P.L, inva = real(1.0) / P.a, invm = real(1.0) / P.m, inv1ba = real(1.0) / (real(1.0) + P.b / P.a);
+    const real mGa = P.m * P.G * P.a, mGb = P.m * P.G * P.b, Izz_a = P.Izz / P.a, s3Caf = real(3.0) / P.Caf, s3Car = real(3.0) / P.Car;
 #pragma unroll 1
     for (int i = 1;; i++) {
         real Ux = V * cb, Uy = V * sb;
@@ -283,24 +292,24 @@ PG_DEV Steady steady_state(const DevVehicle& P, real V, real A_tan, real kappa, 
         real Ax = A_tan * cb - A_rad * sb, Ay = A_tan * sb + A_rad * cb;
         real Fx = Ax * P.m - Fx_drag;
         Fx = jmin(Fx, jmin(P.Fx_max, P.Px_max / Ux) * (P.rwd_frac + P.fwd_frac * cd) - Fyf * sd);
-        real Fzr = (P.m * P.G * P.a + P.h * Fx) / P.L, Fzf = (P.m * P.G * P.b - P.h * Fx) / P.L;
+        real Fzr = (mGa + P.h * Fx) * invL, Fzf = (mGb - P.h * Fx) * invL;
         real Frm = P.mu * Fzr, Ffm = P.mu * Fzf;
         real frac = Fx > real(0.0) ? P.rwd_frac / (P.rwd_frac + P.fwd_frac * cd) : P.rwb_frac / (P.rwb_frac + P.fwb_frac * cd);
         Fxr = clampd((Fx + Fyf * sd) * frac, -Frm, Frm);
         real Fyr_max = sqrt_diff_sq(Frm, Fxr);
-        real Fyr = clampd((Ay * P.m - rdot * P.Izz / P.a) / (real(1.0) + P.b / P.a), -Fyr_max, Fyr_max);
-        real tanar = inv_fiala_tan(Fyr, P.Car, Fyr_max);
+        real Fyr = clampd((Ay * P.m - rdot * Izz_a) * inv1ba, -Fyr_max, Fyr_max);
+        real tanar = inv_fiala_tan3(Fyr, s3Car, Fyr_max);
         real Fxf_t = clampd(Fx - Fxr, -Ffm, Ffm);
         real Fyf_tmax = sqrt_diff_sq(Ffm, Fxf_t);
-        real Fyf_t = clampd((P.b * Fyr + rdot * P.Izz) / P.a, -Fyf_tmax, Fyf_tmax);
+        real Fyf_t = clampd((P.b * Fyr + rdot * P.Izz) * inva, -Fyf_tmax, Fyf_tmax);
         Fxf = Fxf_t * cd + Fyf_t * sd;
         Fyf = Fyf_t * cd - Fxf_t * sd;
         real Fyf_max = sqrt_diff_sq(Ffm, Fxf);
-        real taf = inv_fiala_tan(Fyf, P.Caf, Fyf_max);                         // tan(alpha_f)
+        real taf = inv_fiala_tan3(Fyf, s3Caf, Fyf_max);                        // tan(alpha_f)
         if (i == num_iters) {
             delta = atan2(Uy + P.a * r, Ux) - atan(taf);                         // :376-377, the angle itself
-            real Ax2 = (Fxf * cd - Fyf * sd + Fxr + Fx_drag) / P.m;
-            real Ay2 = (Fyf * cd + Fxf * sd + Fyr) / P.m;
+            real Ax2 = (Fxf * cd - Fyf * sd + Fxr + Fx_drag) * invm;
+            real Ay2 = (Fyf * cd + Fxf * sd + Fyr) * invm;
             A_out = Ax2 * cb + Ay2 * sb;
             break;
         }
@@ -353,6 +362,35 @@ PG_DEV TrajS traj_at_s(const TrajView& T, real sq) {
     o.psi = T.psi[j] + w * (T.psi[j + 1] - T.psi[j]);
     o.kappa = T.kappa[j] + w * (T.kappa[j + 1] - T.kappa[j]);
     return o;
+}
+// traj[sq] and traj(tq).s of one node in ONE loop: the two binary searches (arclength channel, time channel) advance in lockstep so that their dependent
+// LDS / L2 probes overlap, and searchsortedlast on the arclength channel is derived from searchsortedfirst (the knots are strictly increasing: at most
+// one equals sq) instead of being searched again.  Same results as traj_at_s + traj_s_at_time.
+PG_DEV void traj_lookup2(const TrajView& T, real sq, real tq, TrajS& o, real& s_at_t) {
+    int lo_s = 0, hi_s = T.L, lo_t = 0, hi_t = T.L;
+    while (lo_s < hi_s || lo_t < hi_t) {
+        const int ms = (lo_s + hi_s) >> 1, mt = (lo_t + hi_t) >> 1;
+        const real vs = T.s[ms < T.L ? ms : T.L - 1], vt = T.t[mt < T.L ? mt : T.L - 1];
+        if (lo_s < hi_s) { if (vs < sq) lo_s = ms + 1; else hi_s = ms; }
+        if (lo_t < hi_t) { if (vt < tq) lo_t = mt + 1; else hi_t = mt; }
+    }
+    {   // traj(tq).s : trajectories.jl:47-54
+        const int i = clampi(lo_t, 1, T.L - 1) - 1;
+        const real Ai = (T.V[i + 1] - T.V[i]) / (T.t[i + 1] - T.t[i]);
+        const real dt = tq - T.t[i];
+        s_at_t = T.s[i] + T.V[i] * dt + Ai * dt * dt * real(0.5);
+    }
+    const int i = clampi(lo_s, 1, T.L - 1) - 1;          // traj[sq] : trajectories.jl:55-68
+    const real Ai = (T.V[i + 1] - T.V[i]) / (T.t[i + 1] - T.t[i]);
+    const real ds = sq - T.s[i]; real dt;
+    if (fabs(Ai) < real(1e-3) || sq > T.s[T.L - 1]) dt = ds / T.V[i];
+    else dt = real(2.0) * ds / (sqrt(real(2.0) * Ai * ds + T.V[i] * T.V[i]) + T.V[i]);
+    o.V = T.V[i] + Ai * dt; o.A = Ai;
+    const int leq = lo_s + ((lo_s < T.L && T.s[lo_s < T.L ? lo_s : T.L - 1] == sq) ? 1 : 0);
+    const int j = clampi(leq, 1, T.L - 1) - 1;
+    const real w = (sq - T.s[j]) / (T.s[j + 1] - T.s[j]);
+    o.psi = T.psi[j] + w * (T.psi[j + 1] - T.psi[j]);
+    o.kappa = T.kappa[j] + w * (T.kappa[j + 1] - T.kappa[j]);
 }
 // edge_L, edge_R channels of interp_by_s at arclength sq (trajectories.jl:32-35): read only by the build-defined wall rows
 PG_DEV void traj_edges_at_s(const TrajView& T, real sq, real& eL, real& eR) {

@@ -211,8 +211,8 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
 #pragma unroll 1
     for (int i = 1; i < C.NN; i++) {
         real tau = (i == C.NN - 1) ? DT[i - 1] : DT[i];
-        tj = traj_at_s(T, s);
-        real ds = s - traj_s_at_time(T, TS[i]);
+        real s_ref; traj_lookup2(T, s, TS[i], tj, s_ref);
+        real ds = s - s_ref;
         real A_des = tj.A + C.cp.k_V * (tj.V - V) / tau + (traj_mode ? -C.cp.k_s * ds / tau / tau : real(0.0));
         A_des = jmin(jmax(A_des, (C.cp.V_min - V) / tau), (C.cp.V_max - V) / tau);
         const bool shortp = i <= C.Ns;
