@@ -1006,36 +1006,40 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
 
     // forward roll-out: lanes r8 hold x_k[r8] in a register; broadcasts by readlane; results published to sx/sv for the stage lanes.
     // The loop body is one basic block (predicated stores go to a dummy slot) so that all LDS reads of a stage issue back to back.
+    // Lane roles inside each 16-lane row (rows mirror each other): lanes 0..5 own the six dynamics rows of Abar, lanes 6, 7 the two input states, lanes 8, 9 the two
+    // rows of the gain K -- every lane does ONE 8-term dot product against the broadcast state and the two inputs come back through SGPRs (round 1 had all eight
+    // component lanes evaluate both gain rows as well: 24 FMAs and 29 LDS reads per lane and stage, now 10 and 11).
     auto forward = [&](auto use_gain_t) {
         constexpr bool use_gain = decltype(use_gain_t)::value;
+        const int f16 = lane & 15;
+        const bool isA = f16 < 6, isK = f16 == 8 || f16 == 9;
+        const int rrA = isA ? f16 : 5, kro = 8 * (isK ? f16 - 8 : 0);
         real xi = sx0[r8];
         *(lane < 8 ? sx + lane : sDum + lane) = xi;
         ring_prime(0, +1);
-        const int rr = r8 < 6 ? r8 : 5;
-        const real w_lo = r8 < 6 ? real(1.0) : real(0.0), w_6 = r8 == 6 ? real(1.0) : real(0.0), w_7 = r8 == 7 ? real(1.0) : real(0.0);
+        const real w_lo = isA ? real(1.0) : real(0.0), w_6 = f16 == 6 ? real(1.0) : real(0.0), w_7 = f16 == 7 ? real(1.0) : real(0.0);
 #pragma unroll 1
         for (int k = 0; k < N; k++) {
             ring_step(k, +1);
             const real* Rk = ring_slot(k);
-            const real* Kk = sK + 16 * k; const real* Ar = Rk + SB_ROW * rr;
-            real K0[8], K1[8], A8[8];
+            const real* rowp = (use_gain && isK) ? sK + 16 * k + kro : Rk + SB_ROW * rrA;
+            real rw[8];
 #pragma unroll
-            for (int m = 0; m < 8; m++) { A8[m] = Ar[m]; K0[m] = use_gain ? Kk[m] : real(0.0); K1[m] = use_gain ? Kk[8 + m] : real(0.0); }
-            real kf0 = use_gain ? skf[2 * k] : real(0.0), kf1 = use_gain ? skf[2 * k + 1] : real(0.0);
-            real cr = Rk[SB_C + rr], bf0 = Rk[SB_B + 2 * rr], bf1 = Rk[SB_B + 2 * rr + 1];
+            for (int m = 0; m < 8; m++) rw[m] = rowp[m];
+            const real addc = isK ? (use_gain ? skf[2 * k + (f16 - 8)] : real(0.0)) : Rk[SB_C + rrA];
+            const real bf0 = Rk[SB_B + 2 * rrA], bf1 = Rk[SB_B + 2 * rrA + 1];
             real xm[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) xm[m] = rl(xi, m);
-            real a0 = kf0, a1 = real(0.0), b0 = kf1, b1 = real(0.0), e0 = cr, e1 = real(0.0);
+            real d0 = addc, d1 = real(0.0);
 #pragma unroll
-            for (int m = 0; m < 8; m += 2) {
-                a0 += K0[m] * xm[m]; a1 += K0[m + 1] * xm[m + 1]; b0 += K1[m] * xm[m]; b1 += K1[m + 1] * xm[m + 1];
-                e0 += A8[m] * xm[m]; e1 += A8[m + 1] * xm[m + 1];
-            }
-            real v0 = a0 + a1, v1 = b0 + b1;
-            real xr = (e0 + e1) + (bf0 * v0 + bf1 * v1);
+            for (int m = 0; m < 8; m += 2) { d0 += rw[m] * xm[m]; d1 += rw[m + 1] * xm[m + 1]; }
+            real d = d0 + d1;
+            if (!use_gain) d = isK ? real(0.0) : d;            // v = 0 roll-out of the first start
+            const real v0 = rl(d, 8), v1 = rl(d, 9);
+            const real xr = d + (bf0 * v0 + bf1 * v1);
             // arithmetic blend instead of ?: so that the compiler keeps the LDS reads above unconditional (a branch here serialises them)
-            real xn = w_lo * xr + w_6 * (xm[6] + v0) + w_7 * (xm[7] + v1);
+            const real xn = w_lo * xr + w_6 * (xm[6] + v0) + w_7 * (xm[7] + v1);
             xi = xn;
             *(lane < 8 ? sx + 8 * (k + 1) + lane : sDum + lane) = xn;
             *(lane < 2 ? sv + 2 * k + lane : sDum + lane) = lane == 0 ? v0 : v1;
@@ -1307,6 +1311,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         __syncthreads();
     };
 #endif
+    // (the lane-role split that pays in the roll-out -- gain rows in their own lanes -- was tried here too: fewer instructions, but the extra SGPR hop sits on the
+    // serial chain y -> f -> p and the pass got 12 % slower; this pass is chain-bound, the roll-out was issue-bound)
     // Riccati vector pass backward: lane r8 holds p_{k+1}[r8]; p_k = qhat_k + Abar' y + K' f, y = Mc_k + p_{k+1}, f = rhat + Bbar' y, kff = -Sinv f
     auto riccati_vectors = [&]() {
         real pi = sq[8 * N + r8];
