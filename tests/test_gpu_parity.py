@@ -121,3 +121,34 @@ def test_warm_second_step(setup):
         xe, ye, info = orc.solve_exact(qp[b])
         X = orc.split_x(xe)
         assert rel_inf(x2[b, 1, 6:], X["u"][1]) < 1e-6
+
+
+def test_gpu_against_the_independent_numpy_spec(pkg):
+    """The HIP path against oracle/spec_numpy.py DIRECTLY (not through the C++ oracle): time grid bit-exact, cold nodes 1e-9, refreshed QP data from the same
+    nodes 1e-8, and the canonical QP the spec assembles from those data solved to its exact optimum gives the applied control of the GPU (1e-6)."""
+    from oracle import spec_numpy as S
+    from oracle import oracle as om
+    import scipy.sparse as sp
+    traj = pkg.load_path_fixture("vail")
+    n = 3
+    state, control, t0, toff = pkg.synthetic.config2_inputs(traj, n, seed=404, s_range=(5.0, 30.0))
+    mpc = pkg.BatchedTrajectoryTrackingMPC(traj, n)
+    u, st, _ = mpc.step_(state, control, t0, time_offset=toff)
+    assert np.all(st == 1)
+    ts_g, dt_g, _ = mpc.time_steps(); qs_g, us_g, ps_g = mpc.nodes(); qp_g = mpc.qp_data(); x_g, _ = mpc.solution()
+    P, U, T = S.X1(), S.coupled_control_params(), S.Trajectory(traj.data)
+    for b in range(n):
+        ts, dt = S.compute_time_steps(float(t0[b]))
+        assert np.array_equal(ts, ts_g[b]) and np.array_equal(dt, dt_g[b])
+        qs, us, ps = S.compute_linearization_nodes(P, U, T, state[b], control[b], ts, dt, 10, 20, time_offset=float(toff[b]))
+        for mine, theirs in ((qs_g[b], qs), (us_g[b], us), (ps_g[b], ps)):
+            assert np.max(np.abs(mine - theirs) / np.maximum(1.0, np.abs(theirs))) < 1e-9, b
+        D = S.update_qp(P, U, qs_g[b], us_g[b], ps_g[b], dt, 10, 20)
+        assert np.max(np.abs(D["flat"] - qp_g[b]) / np.maximum(1.0, np.abs(D["flat"]))) < 1e-8, b
+        Q = S.assemble_canonical_qp(P, U, D, 10, 20)
+        A = sp.csc_matrix(Q["A"])
+        xe, ye, info = om.solve_exact_generic(dict(Pd=Q["Pd"], q=Q["q"], Ap=A.indptr, Ai=A.indices, Ax=A.data, l=Q["l"], u=Q["u"]))
+        assert info["status"] == 1
+        u2 = xe[6 * 31 + 2: 6 * 31 + 4]                       # u[:, 2] of the reference's variable order: q (6 x 31), then u (2 x 31)
+        assert np.max(np.abs(x_g[b, 1, 6:] - u2)) < 1e-6, b
+    mpc.close()
