@@ -225,13 +225,29 @@ def main():
     ph = np.mean(np.array(ph), axis=0)
     st, it, act, mu = mpc.solve_info(); pol = mpc.polish_info()
     ok = int((st == pkg.SOLVED).sum())
-    # warm steps (second and later consecutive steps): reported as an extra, not as `value`
+    # warm steps (second and later consecutive steps on the same inputs: warm nodes + warm start of the active set): reported as an extra, not as `value`
     sync(); tw = time.perf_counter()
     for _ in range(args.steps):
         one_step(cold=False)
     sync(); warm_elapsed = time.perf_counter() - tw
     # the gathered controls hold every rank's shard: this rank's block equals its own output
     gather_ok = True if world == 1 else bool(torch.equal(gathered[rank * B:(rank + 1) * B], u_out) and torch.isfinite(gathered).all().item())
+
+    # closed-loop rollouts resident on the device (pg_simulate_dev = simulate of model_predictive_control.jl:80-100 for the whole batch): per step the
+    # four compute phases + the plant's RK4 step; warm branch of the nodes and warm start of the active set (vs the same loop with that warm start off)
+    roll = None
+    if rank == 0:
+        roll = {"workload": f"{B} controllers in closed loop on the device, 40 steps of 10 ms after 4 warm-up steps (skidpadoval, config-2 initial states), {args.precision}"}
+        for warm in (True, False):
+            mr = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision=args.precision, warm_polish=warm)
+            mr.set_stream(torch.cuda.current_stream().cuda_stream)
+            mr.set_inputs_dev(B, d_state.data_ptr(), d_control.data_ptr(), d_t0.data_ptr(), None, d_toff.data_ptr())
+            mr.simulate_(4); torch.cuda.synchronize(); tr_ = time.perf_counter()
+            mr.simulate_(40); torch.cuda.synchronize(); tr_ = time.perf_counter() - tr_
+            str_, itr_, _, _ = mr.solve_info()
+            roll["warm_start_of_active_set" if warm else "without_it"] = {"value": B * 40 / tr_, "unit": "solves/s", "ms_per_step": 1e3 * tr_ / 40, "solved_last_step": f"{int((str_ == pkg.SOLVED).sum())}/{B}",
+                                                                          "ipm_iters_mean_last_step": float(np.mean(itr_)), "served_by_warm_polish_alone": int((itr_ == 0).sum())}
+            mr.close()
 
     # BASELINE config 5: decoupled (lateral) MPC, N = 50 (N_short = 10, N_long = 40), same batch, cold every step (that formulation has no warm branch)
     dec = None
@@ -376,6 +392,8 @@ def main():
             "solved": f"{ok}/{B}", "gather_ok": gather_ok, "ipm_iters_mean": float(np.mean(it)), "ipm_iters_max": int(np.max(it)), "ipm_iters_hist": hist(it),
             "polish_rounds_hist": hist(pol), "polish_note": "k >= 1: verified in round k; 0: not run; -1: not verified (interior-point iterate at 1e-12 kept)",
         }
+        if roll is not None:
+            line["closed_loop_rollout"] = roll
         if hji is not None:
             line["hji_lookup"] = hji
         if dec is not None:

@@ -99,14 +99,19 @@ typedef struct pg_config {
                                      * if the polish cannot verify an active set from there (or the sets cycle), the interior point resumes down to ipm_tol and the polish
                                      * gets a second and last chance; if that fails too the interior-point iterate is the answer, exactly as with polish = 0.
                                      * Values <= ipm_tol disable the early hand-over */
+    int32_t warm_polish;            /* 1 (default): an instance whose previous step ended in a solved QP (solved flag set, status PG_SOLVED) first tries the polish from that
+                                     * step's active set and multipliers on the new QP data -- the counterpart of the reference's OSQP warm start
+                                     * (src/coupled_lat_long.jl:218).  A verified round is the exact optimum of the new QP (iters = 0 then); otherwise the interior point runs
+                                     * as for a cold instance.  Ignored when polish = 0 */
+    int32_t _pad4;
 } pg_config;
 
 enum pg_formulation { PG_COUPLED = 0, PG_DECOUPLED = 1 };
 
 /* Layout check for hand-written mirrors of this header (ctypes, Julia): fills out[0..] with sizeof(pg_config), sizeof(pg_vehicle), sizeof(pg_control_params)
  * and the byte offsets inside pg_config of: control, N_short, dt_short, use_correction_step, hji_eps, batch_capacity, ipm_max_iter, formulation, ipm_tol, ipm_mu0,
- * walls, wall_weight, polish, polish_rho, polish_tol, polish_ipm_tol; then offsetof(pg_control_params, N_HJI) and offsetof(pg_vehicle, kappa_max).
- * Returns the number of entries (21); out may be NULL, at most n entries are written. */
+ * walls, wall_weight, polish, polish_rho, polish_tol, polish_ipm_tol, warm_polish; then offsetof(pg_control_params, N_HJI) and offsetof(pg_vehicle, kappa_max).
+ * Returns the number of entries (22); out may be NULL, at most n entries are written. */
 int pg_abi_layout(int32_t* out, int32_t n);
 
 /* X1() and the default keyword values of the reference constructors (coupled formulation) */

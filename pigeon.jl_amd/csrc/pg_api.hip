@@ -27,6 +27,7 @@ struct pg_handle {
     real *d_sep = nullptr, *d_nodes = nullptr, *d_qp = nullptr;
     real *d_x7 = nullptr, *d_vg8 = nullptr, *d_Mb = nullptr;
     real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
+    real* d_lam = nullptr;                                      // [cap][N][16] multipliers of the last solve (warm start of the polish)
     real *d_pol_u2 = nullptr, *d_pol_u = nullptr; int* d_pol_src = nullptr;   // HJI fallback policy (HJI_computation.jl:133-158)
     int *d_status = nullptr, *d_iters = nullptr, *d_polish = nullptr; uint16_t* d_active = nullptr;
     // HJI grid
@@ -111,7 +112,7 @@ int pg_default_config(pg_config* c) {
     c->N_short = 10; c->N_long = 20; c->dt_short = 0.01; c->dt_long = 0.2; c->use_correction_step = 1;   // coupled_lat_long.jl:42-43
     c->rk4_substeps = 10; c->hji_eps = 0.05; c->batch_capacity = 4096; c->device = 0;
     c->ipm_max_iter = 40; c->ipm_mu0 = 100.0; c->formulation = PG_COUPLED; c->walls = 0; c->wall_weight = 1000.0;
-    c->polish = 1;
+    c->polish = 1; c->warm_polish = 1;
 #ifdef PG_F32
     c->ipm_tol = 1e-5; c->polish_rho = 1e3; c->polish_tol = 1e-4; c->polish_ipm_tol = 1e-4;
 #else
@@ -139,7 +140,7 @@ int pg_default_config_decoupled(pg_config* c) {
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_state, h->d_control, h->d_t0, h->d_other, h->d_toff, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->ev_ok) for (int i = 0; i < 4; i++) (void)hipEventDestroy(h->ev[i]);
@@ -177,7 +178,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     }
     C.qp_len = 84 * C.N + 11;
     C.ipm_max_iter = cfg->ipm_max_iter; C.ipm_tol = (real)cfg->ipm_tol; C.ipm_mu0 = (real)cfg->ipm_mu0;
-    C.polish = cfg->polish != 0; C.polish_rho = (real)cfg->polish_rho; C.polish_tol = (real)cfg->polish_tol; C.polish_ipm_tol = (real)cfg->polish_ipm_tol;
+    C.polish = cfg->polish != 0; C.polish_rho = (real)cfg->polish_rho; C.polish_tol = (real)cfg->polish_tol; C.polish_ipm_tol = (real)cfg->polish_ipm_tol; C.warm_polish = cfg->warm_polish != 0;
     const size_t cap = (size_t)cfg->batch_capacity; const int N = C.N, NN = C.NN;
 #define ALLOC(ptr, count, type) do { if (hipMalloc((void**)&(ptr), (size_t)(count) * sizeof(type)) != hipSuccess) { g_create_error = "hipMalloc failed for " #ptr; free_all(h); delete h; return PG_ERR_HIP; } } while (0)
     ALLOC(h->d_state, cap * 6, real); ALLOC(h->d_control, cap * 3, real); ALLOC(h->d_t0, cap, double); ALLOC(h->d_other, cap * 4, real); ALLOC(h->d_toff, cap, double);
@@ -185,7 +186,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_sep, cap * 4, real); ALLOC(h->d_nodes, cap * NN * 10, real); ALLOC(h->d_qp, cap * C.qp_len, real);
     ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
     ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_u, cap * 3, real); ALLOC(h->d_mu, cap, real);
-    ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_polish, cap, int); ALLOC(h->d_active, cap * N, uint16_t);
+    ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_polish, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_active, cap * N, uint16_t);
 #ifdef PG_EXPERIMENTAL_SOLVE4
     { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (experimental/pg_solve4.hip)
     if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), real);
@@ -203,6 +204,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         (void)hipMemcpy(h->d_prev_ts, ts.data(), ts.size() * 8, hipMemcpyHostToDevice);
         (void)hipMemcpy(h->d_dt, dt.data(), dt.size() * 8, hipMemcpyHostToDevice);
         (void)hipMemset(h->d_solved, 0, cap * sizeof(int));
+        (void)hipMemset(h->d_status, 0, cap * sizeof(int));
         (void)hipMemset(h->d_other, 0, cap * 4 * sizeof(real));
         (void)hipMemset(h->d_solx, 0, cap * NN * 8 * sizeof(real));
         if (hipDeviceSynchronize() != hipSuccess) { g_create_error = "initial fills failed"; free_all(h); delete h; return PG_ERR_HIP; }   // hipMemset may return before the fill has run
@@ -244,7 +246,7 @@ int pg_abi_layout(int32_t* out, int32_t n) {
 #define OFF(f) (int32_t)offsetof(pg_config, f)
     const int32_t v[] = {(int32_t)sizeof(pg_config), (int32_t)sizeof(pg_vehicle), (int32_t)sizeof(pg_control_params), OFF(control), OFF(N_short), OFF(dt_short), OFF(use_correction_step),
                          OFF(hji_eps), OFF(batch_capacity), OFF(ipm_max_iter), OFF(formulation), OFF(ipm_tol), OFF(ipm_mu0), OFF(walls), OFF(wall_weight), OFF(polish), OFF(polish_rho),
-                         OFF(polish_tol), OFF(polish_ipm_tol), (int32_t)offsetof(pg_control_params, N_HJI), (int32_t)offsetof(pg_vehicle, kappa_max)};
+                         OFF(polish_tol), OFF(polish_ipm_tol), OFF(warm_polish), (int32_t)offsetof(pg_control_params, N_HJI), (int32_t)offsetof(pg_vehicle, kappa_max)};
 #undef OFF
     const int32_t cnt = (int32_t)(sizeof(v) / sizeof(v[0]));
     if (out) for (int32_t i = 0; i < cnt && i < n; i++) out[i] = v[i];
@@ -486,7 +488,7 @@ int pg_update_qp(pg_handle* h) {
 }
 int pg_solve(pg_handle* h) {
     int rc = check_ready(h); if (rc) return rc;
-    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish};
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam};
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) { hipLaunchKernelGGL((k_solve4<2, false>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, (unsigned long long*)nullptr); LAUNCH_CHECK(h); return PG_OK; }
 #endif
@@ -502,7 +504,7 @@ int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     unsigned long long* d = nullptr;
     HIPCHK(h, hipMalloc((void**)&d, ((size_t)h->B * 6 + 1024) * 8));
     HIPCHK(h, hipMemset(d, 0, ((size_t)h->B * 6 + 1024) * 8));
-    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish};
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam};
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) hipLaunchKernelGGL((k_solve4<2, true>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, d);
     else

@@ -33,6 +33,7 @@ struct DevCfg {
     real ipm_tol, ipm_mu0;
     int polish;                   // active-set polish after the interior point (k_solve): 0 off, 1 on
     real polish_rho, polish_tol;  // penalty of the active rows in the polish solves; feasibility tolerance of its verification
+    int warm_polish;              // instances with a previous solution first try the polish from its active set and multipliers (no interior point if it verifies)
     real polish_ipm_tol;          // interior-point tolerance at which the polish is first attempted (>= ipm_tol; a polish that fails there resumes the interior point down to ipm_tol)
     TrajView traj;                // trajectory 0 of the installed library
     int n_traj;                   // library size (1: every instance tracks `traj`)
@@ -849,7 +850,7 @@ __global__ __launch_bounds__(64) void k_hji_policy(DevCfg C, int B, int use_poli
 //   0: Ux >= V_min   1: Ux <= V_max   2: Fx >= Fx_min   3: delta <= dmax   4: delta >= dmin   5: Fx <= fxmax
 //   6..9: H_i [Uy;r] - sigma_{i/2} <= G_i     10: sigma1 >= 0   11: sigma2 >= 0    12: d_delta <= ddmax   13: d_delta >= ddmin
 //   14: M u + b + sigma_HJI >= 0              15: sigma_HJI >= 0        (14,15 only for nodes 1 .. min(N_HJI,Ns)-1)
-struct SolveOut { real* sol_x; real* sol_sigma; real* u_out; int* status; int* iters; uint16_t* active; real* mu; int* solved; int* polish; };
+struct SolveOut { real* sol_x; real* sol_sigma; real* u_out; int* status; int* iters; uint16_t* active; real* mu; int* solved; int* polish; real* lam; };
 
 #define NROW 16
 #define PG_POLISH_ROUNDS 6      // active-set rounds of the polish before it gives up
@@ -1355,9 +1356,22 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     };
 
     int it_total = 0;
-    for (int attempt = 0; attempt < 2; attempt++) {
+    // Warm start of the ACTIVE SET (the reference's warm start is OSQP's: previous (x, y) as the initial iterate, src/coupled_lat_long.jl:218 WarmStart = true).
+    // An instance whose previous step ended in a solved QP first tries the polish directly from that step's active set and multipliers on the NEW QP data
+    // (attempt -1): in closed loop the set rarely changes from one 10 ms step to the next, and a verified round IS the exact optimum of the new QP whatever the
+    // guess was, so nothing is lost in accuracy; if three rounds do not verify, the interior point runs as for a cold instance.
+    real* const Lst = O.lam + ((size_t)b * N + s) * NROW;
+    const bool warm = C.polish && C.warm_polish && O.solved[b] != 0 && O.status[b] == PG_SOLVED;
+    bool warm_attempt = false;
+    for (int attempt = warm ? -1 : 0; attempt < 2; attempt++) {
     rp0 = real(0.0); phi = real(1.0); pmode = 0; pstat = 0; polish_gave_up = false; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu;
-    if (attempt == 0) {
+    warm_attempt = attempt < 0;
+    if (attempt < 0) {
+        amask = act ? (unsigned)O.active[(size_t)b * N + s] : 0u; mask_ipm = amask;
+#pragma unroll
+        for (int j = 0; j < NROW; j++) { R.t[j] = real(1.0); R.corr[j] = real(0.0); R.lam[j] = (act && ((amask >> j) & 1u)) ? Lst[j] : real(0.0); }
+        pmode = 1; mu = real(0.0);
+    } else if (attempt == 0) {
         // ---- first attempt: v = 0 roll-out (dynamics- and rate-feasible), sigma just feasible; t = max(slack, tau); lambda = mu0 / t ----
         forward(std::false_type{});
         real xs[8];
@@ -1412,8 +1426,9 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     }
     stamp(5);
     rp0 = wave_max(rp0);
-    status = PG_MAX_ITER;
-    const int iter_cap = attempt == 0 ? C.ipm_max_iter : 3 * C.ipm_max_iter;
+    status = warm_attempt ? PG_SOLVED : PG_MAX_ITER;
+    const int iter_cap = attempt <= 0 ? C.ipm_max_iter : 3 * C.ipm_max_iter;
+    const int round_cap = warm_attempt ? 3 : PG_POLISH_ROUNDS;
     // Active-set polish (OSQP-style, on the stage-structured problem).  The interior point approaches nearly degenerate rows (slack and multiplier both ~ sqrt(mu))
     // like sqrt(mu), so its iterate can sit 1e-6 away from the optimum at any tolerance fp64 rounding allows.  Once it has converged, the rows with
     // lambda > t are held as EQUALITIES (augmented Lagrangian with penalty rho, multiplier estimates y = lambda), every other row is dropped, and the
@@ -1468,6 +1483,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     // there, the interior point resumes from the centred point (t, mu / t) and runs down to ipm_tol before the polish gets its second and last chance
     real tol_cur = (C.polish && C.polish_ipm_tol > C.ipm_tol) ? C.polish_ipm_tol : C.ipm_tol;
     auto polish_failed = [&]() -> bool {          // true: give up (keep the interior-point iterate); false: the interior point resumes
+        if (warm_attempt) { pstat = 0; status = PG_MAX_ITER; return true; }      // warm guess did not verify: on to the cold start
         pstat = -1;
         if (!(tol_cur > C.ipm_tol)) { polish_gave_up = true; return true; }
         tol_cur = C.ipm_tol; pmode = 0; status = PG_MAX_ITER; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu;
@@ -1550,7 +1566,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             const int pc = polish_check(tp, real(0.01) * ptol);
             if (pc == 0) break;
             if (pc == 3) { if (polish_failed()) break; continue; }
-            if (pc == 2) { if (++pmode > PG_POLISH_ROUNDS && polish_failed()) break; continue; }      // the set changed: next round directly
+            if (pc == 2) { if (++pmode > round_cap && polish_failed()) break; continue; }      // the set changed: next round directly
         }
         // ---- corrector / polish refinement ----
         assemble(sg * mu, false);
@@ -1595,7 +1611,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         } else {
             const int pc = polish_check(tp, ptol);
             if (pc == 0) break;
-            if ((pc == 3 || ++pmode > PG_POLISH_ROUNDS) && polish_failed()) break;      // set changed, or the multiplier iteration has not settled yet: another round
+            if ((pc == 3 || ++pmode > round_cap) && polish_failed()) break;      // set changed, or the multiplier iteration has not settled yet: another round
         }
     }
     it_total += it;
@@ -1618,6 +1634,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         if (pstat > 0) mask = amask;                               // the polish's verified set
         else if (pmode) mask = mask_ipm;                           // polish ended unverified with the multipliers overwritten: the interior point's set at hand-over
         O.active[(size_t)b * N + s] = (uint16_t)mask;
+#pragma unroll
+        for (int j = 0; j < NROW; j++) Lst[j] = R.lam[j];          // multipliers for the next step's warm polish
     }
     if (lane == 0) {
         // get_next_control: coupled_lat_long.jl:370-374 (node 2 of the reference = stage lane 0's node)

@@ -164,3 +164,26 @@ def test_closed_loop_on_device_matches_oracle(pkg, oracle_mod, skidpad):
     assert np.max(np.abs(s - q) / np.maximum(1.0, np.abs(q))) < 1e-5 and np.max(np.abs(c - u) / un) < 1e-5 and np.allclose(t, tt)
     st, it, act, mu = mpc.solve_info()
     assert np.all(st == 1)
+
+
+def test_warm_start_of_the_active_set_is_exact_and_mostly_sufficient(pkg, skidpad):
+    """Closed loop on the device (pg_simulate_dev), 1024 instances, 12 steps: with the warm start of the active set (pg_config.warm_polish, the counterpart of the
+    reference's OSQP warm start) an instance first tries the polish from the previous step's active set and multipliers.  A verified round is the exact optimum of
+    the NEW QP, so the trajectories with and without it must coincide (both are exact solvers of the same QPs); and in closed loop nearly every instance is
+    served by the warm polish alone (iters == 0)."""
+    Bc = 1024
+    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, Bc, seed=31)
+    out = {}
+    for warm in (True, False):
+        mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, Bc, warm_polish=warm)
+        mpc.set_inputs(state, control, t0, time_offset=toff)
+        s, c, t, _, _ = mpc.simulate_(12)
+        st, it, _, _ = mpc.solve_info(); pol = mpc.polish_info()
+        assert np.all(st == pkg.SOLVED)
+        out[warm] = (s, c, it, pol)
+        mpc.close()
+    un = np.array([0.314159, 16793.7, 16793.7])
+    assert np.max(np.abs(out[True][1] - out[False][1]) / un) < 1e-7                      # controls after 12 closed-loop steps
+    assert np.max(np.abs(out[True][0] - out[False][0]) / np.maximum(1.0, np.abs(out[False][0]))) < 1e-8
+    assert np.mean(out[True][2] == 0) > 0.9 and np.all(out[True][3] >= 1)               # served by the warm polish, every instance a verified KKT point
+    assert np.all(out[False][2] > 0)
