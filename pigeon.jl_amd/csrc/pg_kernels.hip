@@ -1359,7 +1359,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     // Warm start of the ACTIVE SET (the reference's warm start is OSQP's: previous (x, y) as the initial iterate, src/coupled_lat_long.jl:218 WarmStart = true).
     // An instance whose previous step ended in a solved QP first tries the polish directly from that step's active set and multipliers on the NEW QP data
     // (attempt -1): in closed loop the set rarely changes from one 10 ms step to the next, and a verified round IS the exact optimum of the new QP whatever the
-    // guess was, so nothing is lost in accuracy; if three rounds do not verify, the interior point runs as for a cold instance.
+    // guess was, so nothing is lost in accuracy; if the rounds do not verify, the interior point runs as for a cold instance.
     real* const Lst = O.lam + ((size_t)b * N + s) * NROW;
     const bool warm = C.polish && C.warm_polish && O.solved[b] != 0 && O.status[b] == PG_SOLVED;
     bool warm_attempt = false;
@@ -1428,7 +1428,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     rp0 = wave_max(rp0);
     status = warm_attempt ? PG_SOLVED : PG_MAX_ITER;
     const int iter_cap = attempt <= 0 ? C.ipm_max_iter : 3 * C.ipm_max_iter;
-    const int round_cap = warm_attempt ? 3 : PG_POLISH_ROUNDS;
+    const int round_cap = PG_POLISH_ROUNDS;      // (also for the warm attempt: a fall-back to the cold start costs ten rounds, and the slowest instance sets the kernel time)
     // Active-set polish (OSQP-style, on the stage-structured problem).  The interior point approaches nearly degenerate rows (slack and multiplier both ~ sqrt(mu))
     // like sqrt(mu), so its iterate can sit 1e-6 away from the optimum at any tolerance fp64 rounding allows.  Once it has converged, the rows with
     // lambda > t are held as EQUALITIES (augmented Lagrangian with penalty rho, multiplier estimates y = lambda), every other row is dropped, and the
