@@ -16,6 +16,7 @@ struct pg_handle {
     pg_config cfg;
     DevCfg dc;
     int B = 0;                       // current batch
+    int warm_B = 0;                  // instances [0, warm_B) are known to carry a previous solution (solved = true): set by pg_solve, cleared by pg_reset
     hipStream_t stream = nullptr;
     std::string err;
     // device buffers
@@ -368,6 +369,7 @@ int pg_reset(pg_handle* h, const uint8_t* mask) {
     if (!h) return PG_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int cap = h->cfg.batch_capacity;
+    h->warm_B = 0;
     if (!mask) { HIPCHK(h, hipMemsetAsync(h->d_solved, 0, (size_t)cap * sizeof(int), h->stream)); return PG_OK; }
     REQUIRE(h, h->B > 0, "pg_reset with a mask needs inputs installed (B known)");
     HIPCHK(h, hipMemcpyAsync(h->d_mask, mask, h->B, hipMemcpyHostToDevice, h->stream));
@@ -450,9 +452,16 @@ int pg_compute_linearization_nodes(pg_handle* h) {
         auto kern = staged ? k_nodes_dec<true> : k_nodes_dec<false>;
         hipLaunchKernelGGL(kern, grid, block, traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_sep, h->d_ts, h->d_dt, h->d_nodes);
     } else {
-        auto kern = staged ? k_nodes<true> : k_nodes<false>;
-        hipLaunchKernelGGL(kern, grid, block, traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
-                           h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes);
+        if (h->warm_B >= B) {           // every instance takes the warm branch: lane = (instance, node)
+            auto kern = staged ? k_nodes_warm<true> : k_nodes_warm<false>;
+            const long nth = (long)B * h->dc.NN;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((nth + 255) / 256)), dim3(256), traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_sep, h->d_ts, h->d_prev_ts, h->d_solx,
+                               h->d_nodes);
+        } else {
+            auto kern = staged ? k_nodes<true> : k_nodes<false>;
+            hipLaunchKernelGGL(kern, grid, block, traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
+                               h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes);
+        }
     }
     LAUNCH_CHECK(h);
     return PG_OK;
@@ -495,6 +504,7 @@ int pg_solve(pg_handle* h) {
     if (h->solve_ring) hipLaunchKernelGGL((k_solve<false, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr);
     else hipLaunchKernelGGL((k_solve<false, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr);
     LAUNCH_CHECK(h);
+    if (h->B > h->warm_B) h->warm_B = h->B;           // model_predictive_control.jl:76: solved = true for every instance of the batch
     return PG_OK;
 }
 // debug (not part of the public header): per-phase shader-clock cycles of one solve launch, out [B][6] =

@@ -231,6 +231,50 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
     }
 }
 
+// Warm branch of compute_linearization_nodes! (coupled_lat_long.jl:82-102) for a batch in which EVERY instance has a previous solution (closed loop after the
+// first step): the 31 nodes of an instance are independent of each other there -- node i interpolates the previous solution at ts[i] and looks the reference up at
+// the resulting arclength -- so the lane is (instance, node) instead of the instance (k_nodes runs the same arithmetic node after node in one lane because the
+// COLD seeding is a recurrence; mixed batches keep using it).  Same operations per node as k_nodes' warm branch: bit-identical nodes.
+template <bool STAGED> __global__ __launch_bounds__(256) void k_nodes_warm(DevCfg C, int B, const real* __restrict__ state, const real* __restrict__ control, const real* __restrict__ sep,
+                             const tdouble* __restrict__ ts, const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* __restrict__ nodes) {
+    extern __shared__ real sh_traj[];
+    TrajView T = C.traj;
+    if constexpr (STAGED) {
+        for (int i = threadIdx.x; i < T.L; i += blockDim.x) { sh_traj[i] = C.traj.t[i]; sh_traj[T.L + i] = C.traj.s[i]; }
+        __syncthreads();
+        T.t = sh_traj; T.s = sh_traj + T.L;
+    }
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = (int)(gid / C.NN), i = (int)(gid - (long)b * C.NN);
+    if (b >= B) return;
+    if constexpr (!STAGED) T = traj_of(C, b);
+    const tdouble* TS = ts + (size_t)b * C.NN;
+    real* ND = nodes + (size_t)b * C.NN * 10;
+    NodeRec r;
+    if (i == 0) {                                                                   // node 1 of the reference: the measured state (:76-85)
+        const real* q0 = state + (size_t)b * 6; const real* u0 = control + (size_t)b * 3;
+        const real s0 = sep[(size_t)b * 4], e0 = sep[(size_t)b * 4 + 1];
+        TrajS tj = traj_at_s(T, s0);
+        r.q0 = s0 - traj_s_at_time(T, TS[0]); r.q1 = q0[3]; r.q2 = q0[4]; r.q3 = q0[5]; r.q4 = adiff(q0[2], tj.psi); r.q5 = e0;
+        r.u0 = u0[0]; r.u1 = u0[1] + u0[2]; r.pV = tj.V; r.pK = tj.kappa;
+    } else {                                                                        // :87-101 with update_interpolations! (:189-195)
+        const tdouble* PT = prev_ts + (size_t)b * C.NN; const real* PX = prev_x + (size_t)b * C.NN * 8;
+        const real tlast = PT[C.NN - 1];
+        real t = TS[i];
+        real tq = (t < tlast) ? t : tlast;
+        int j = clampi(count_leq(PT, C.NN, tq), 1, C.NN - 1) - 1;
+        real w = (tq - PT[j]) / (PT[j + 1] - PT[j]);
+        const real* a = PX + j * 8; const real* c = a + 8;
+        r.q0 = (real(1.0) - w) * a[0] + w * c[0]; r.q1 = (real(1.0) - w) * a[1] + w * c[1]; r.q2 = (real(1.0) - w) * a[2] + w * c[2];
+        r.q3 = (real(1.0) - w) * a[3] + w * c[3]; r.q4 = (real(1.0) - w) * a[4] + w * c[4]; r.q5 = (real(1.0) - w) * a[5] + w * c[5];
+        r.u0 = ((real(1.0) - w) * a[6] + w * c[6]) * C.un0; r.u1 = ((real(1.0) - w) * a[7] + w * c[7]) * C.un1;
+        real s = traj_s_at_time(T, t) + r.q0;                                   // :96
+        TrajS tj = traj_at_s(T, s);
+        r.pV = tj.V; r.pK = tj.kappa;
+    }
+    put_node(ND, i, r);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // update_QP! of the coupled formulation (coupled_lat_long.jl:315-368) in ONE kernel: `linearize` of every interval + c + u-normalisation (:335-353), the
 // stability envelope and the bounds (:354-367), q_curr/u_curr (:332-333) and the safety row (:345-346).
