@@ -29,6 +29,7 @@ struct pg_handle {
     real *d_x7 = nullptr, *d_vg8 = nullptr, *d_Mb = nullptr;
     real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     real* d_lam = nullptr;                                      // [cap][N][16] multipliers of the last solve (warm start of the polish)
+    int* d_order = nullptr; int order_cur = 0; int order_B = 0;  // [2][cap] + 2 counters: launch order of k_solve for the next warm step (slow instances first)
     real *d_pol_u2 = nullptr, *d_pol_u = nullptr; int* d_pol_src = nullptr;   // HJI fallback policy (HJI_computation.jl:133-158)
     int *d_status = nullptr, *d_iters = nullptr, *d_polish = nullptr; uint16_t* d_active = nullptr;
     // HJI grid
@@ -141,7 +142,7 @@ int pg_default_config_decoupled(pg_config* c) {
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_state, h->d_control, h->d_t0, h->d_other, h->d_toff, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_order};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->ev_ok) for (int i = 0; i < 4; i++) (void)hipEventDestroy(h->ev[i]);
@@ -187,7 +188,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_sep, cap * 4, real); ALLOC(h->d_nodes, cap * NN * 10, real); ALLOC(h->d_qp, cap * C.qp_len, real);
     ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
     ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_u, cap * 3, real); ALLOC(h->d_mu, cap, real);
-    ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_polish, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_active, cap * N, uint16_t);
+    ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_polish, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_active, cap * N, uint16_t);
 #ifdef PG_EXPERIMENTAL_SOLVE4
     { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (experimental/pg_solve4.hip)
     if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), real);
@@ -369,7 +370,7 @@ int pg_reset(pg_handle* h, const uint8_t* mask) {
     if (!h) return PG_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int cap = h->cfg.batch_capacity;
-    h->warm_B = 0;
+    h->warm_B = 0; h->order_B = 0;
     if (!mask) { HIPCHK(h, hipMemsetAsync(h->d_solved, 0, (size_t)cap * sizeof(int), h->stream)); return PG_OK; }
     REQUIRE(h, h->B > 0, "pg_reset with a mask needs inputs installed (B known)");
     HIPCHK(h, hipMemcpyAsync(h->d_mask, mask, h->B, hipMemcpyHostToDevice, h->stream));
@@ -497,7 +498,14 @@ int pg_update_qp(pg_handle* h) {
 }
 int pg_solve(pg_handle* h) {
     int rc = check_ready(h); if (rc) return rc;
-    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam};
+    // launch order: the one the previous solve of this same batch filed (warm steps only: a reset batch has no history and keeps the index order)
+    const size_t cap = (size_t)h->cfg.batch_capacity;
+    int* cnt = h->d_order + 2 * cap;
+    const bool use_order = h->dc.polish && h->dc.warm_polish && h->warm_B >= h->B && h->order_B == h->B;
+    HIPCHK(h, hipMemsetAsync(cnt, 0, 2 * sizeof(int), h->stream));
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam,
+               use_order ? h->d_order + (size_t)h->order_cur * cap : nullptr, h->d_order + (size_t)(1 - h->order_cur) * cap, cnt};
+    h->order_cur = 1 - h->order_cur; h->order_B = h->B;
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) { hipLaunchKernelGGL((k_solve4<2, false>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, (unsigned long long*)nullptr); LAUNCH_CHECK(h); return PG_OK; }
 #endif
@@ -514,7 +522,7 @@ int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     unsigned long long* d = nullptr;
     HIPCHK(h, hipMalloc((void**)&d, ((size_t)h->B * 6 + 1024) * 8));
     HIPCHK(h, hipMemset(d, 0, ((size_t)h->B * 6 + 1024) * 8));
-    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam};
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, nullptr, nullptr, nullptr};
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) hipLaunchKernelGGL((k_solve4<2, true>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, d);
     else

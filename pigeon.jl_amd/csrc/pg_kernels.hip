@@ -894,7 +894,8 @@ __global__ __launch_bounds__(64) void k_hji_policy(DevCfg C, int B, int use_poli
 //   0: Ux >= V_min   1: Ux <= V_max   2: Fx >= Fx_min   3: delta <= dmax   4: delta >= dmin   5: Fx <= fxmax
 //   6..9: H_i [Uy;r] - sigma_{i/2} <= G_i     10: sigma1 >= 0   11: sigma2 >= 0    12: d_delta <= ddmax   13: d_delta >= ddmin
 //   14: M u + b + sigma_HJI >= 0              15: sigma_HJI >= 0        (14,15 only for nodes 1 .. min(N_HJI,Ns)-1)
-struct SolveOut { real* sol_x; real* sol_sigma; real* u_out; int* status; int* iters; uint16_t* active; real* mu; int* solved; int* polish; real* lam; };
+struct SolveOut { real* sol_x; real* sol_sigma; real* u_out; int* status; int* iters; uint16_t* active; real* mu; int* solved; int* polish; real* lam;
+                  const int* order_in; int* order_out; int* order_cnt; };
 
 #define NROW 16
 #define PG_POLISH_ROUNDS 6      // active-set rounds of the polish before it gives up
@@ -952,7 +953,10 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int slot) { if (PROF) { unsigned long long now = clock64(); pc[slot] += now - tprev; tprev = now; } };
     if (PROF) tprev = clock64();
-    const int b = blockIdx.x, lane = threadIdx.x;
+    // Launch order: workgroup i solves instance order_in[i] when an order is supplied.  The kernel ends with its slowest wave, and in closed loop ~1 % of the
+    // instances need a full interior-point solve (ten times a warm polish round): each solve files its instance for the NEXT step at the front (slow: needed the
+    // interior point or more than one round) or at the back of order_out, so that the likely stragglers start first instead of wherever their index falls.
+    const int b = O.order_in ? O.order_in[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;
     const int N = C.N, NN = C.NN;
     extern __shared__ real lds[];
     // The dynamics blocks are NOT resident: each pass streams them stage by stage from L2 through a 4-slot LDS ring
@@ -1687,6 +1691,11 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         if (C.formulation == PG_DECOUPLED) Fx = nodes[((size_t)b * NN + 1) * 10 + 7];      // decoupled_lat_long.jl:275-278: Fx of the seeded node 2
         real* U = O.u_out + (size_t)b * 3;
         U[0] = d; U[1] = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac; U[2] = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
+        if (O.order_out) {
+            const bool slow = it > 0 || pstat != 1;
+            const int pos = slow ? atomicAdd(O.order_cnt, 1) : B - 1 - atomicAdd(O.order_cnt + 1, 1);
+            O.order_out[pos] = b;
+        }
         O.status[b] = status; O.iters[b] = it; O.mu[b] = mu; O.polish[b] = pstat; O.solved[b] = 1;      // model_predictive_control.jl:76: solved = true
     }
 }
