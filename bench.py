@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--no-hji", action="store_true")
     ap.add_argument("--no-decoupled", action="store_true")
     ap.add_argument("--no-f32", action="store_true")
+    ap.add_argument("--no-rollout", action="store_true", help="skip the closed-loop rollout object")
+    ap.add_argument("--no-warm", action="store_true", help="skip the warm-step loop (the profile campaign uses it so that every k_solve launch of the trace is a cold headline launch)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend for --gpus > 1: nccl = RCCL over xGMI (the product path); gloo = host-staged gather with the ranks sharing whatever GPUs exist "
                          "(test mode: exercises launch -> shard -> step -> gather end to end on a 1-GPU box)")
@@ -227,7 +229,7 @@ def main():
     ok = int((st == pkg.SOLVED).sum())
     # warm steps (second and later consecutive steps on the same inputs: warm nodes + warm start of the active set): reported as an extra, not as `value`
     sync(); tw = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(0 if args.no_warm else args.steps):
         one_step(cold=False)
     sync(); warm_elapsed = time.perf_counter() - tw
     # the gathered controls hold every rank's shard: this rank's block equals its own output
@@ -236,7 +238,7 @@ def main():
     # closed-loop rollouts resident on the device (pg_simulate_dev = simulate of model_predictive_control.jl:80-100 for the whole batch): per step the
     # four compute phases + the plant's RK4 step; warm branch of the nodes and warm start of the active set (vs the same loop with that warm start off)
     roll = None
-    if rank == 0:
+    if rank == 0 and not args.no_rollout:
         roll = {"workload": f"{B} controllers in closed loop on the device, 40 steps of 10 ms after 4 warm-up steps (skidpadoval, config-2 initial states), {args.precision}"}
         for warm in (True, False):
             mr = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision=args.precision, warm_polish=warm)
@@ -388,7 +390,7 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": dom_ms, "valu": valu,
                          "note": f"algorithmic HBM bytes are {bytes_per_solve} B/solve (SURVEY 8d): the step is VALU/LDS/latency bound by construction, not HBM bound; see roofline.valu and hji_lookup"},
             "phase_ms": {n: float(v) for n, v in zip(names, ph)},
-            "warm_value": world * B * args.steps / warm_elapsed,
+            "warm_value": None if args.no_warm else world * B * args.steps / warm_elapsed,
             "solved": f"{ok}/{B}", "gather_ok": gather_ok, "ipm_iters_mean": float(np.mean(it)), "ipm_iters_max": int(np.max(it)), "ipm_iters_hist": hist(it),
             "polish_rounds_hist": hist(pol), "polish_note": "k >= 1: verified in round k; 0: not run; -1: not verified (interior-point iterate at 1e-12 kept)",
         }
