@@ -441,10 +441,17 @@ int pg_compute_time_steps(pg_handle* h) {
     LAUNCH_CHECK(h);
     return PG_OK;
 }
+static int launch_nodes(pg_handle* h, bool with_time_grid);
 int pg_compute_linearization_nodes(pg_handle* h) {
     int rc = check_ready(h); if (rc) return rc;
+    return launch_nodes(h, false);
+}
+// compute_time_steps! + compute_linearization_nodes! of pg_step_dev / pg_simulate_dev: the time grid rides in the projection kernel (one launch fewer)
+static int launch_nodes(pg_handle* h, bool with_time_grid) {
     const int B = h->B;
-    hipLaunchKernelGGL(k_project, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep);
+    if (with_time_grid) hipLaunchKernelGGL(k_project<true>, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep, h->d_t0, h->d_ts, h->d_dt, h->d_prev_ts);
+    else hipLaunchKernelGGL(k_project<false>, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep, (const double*)nullptr, (double*)nullptr, (double*)nullptr,
+                            (double*)nullptr);
     LAUNCH_CHECK(h);
     const bool staged = h->dc.n_traj == 1 && h->traj_L <= 2048;
     const size_t traj_lds = staged ? (size_t)2 * h->traj_L * sizeof(real) : 0;
@@ -576,8 +583,7 @@ int pg_get_next_control_hji(pg_handle* h, int32_t use_hji_policy, double* u_out,
 int pg_step_dev(pg_handle* h, void* u_out_dev) {
     int rc = check_ready(h); if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-    if ((rc = pg_compute_time_steps(h))) return rc;
-    if ((rc = pg_compute_linearization_nodes(h))) return rc;
+    if ((rc = launch_nodes(h, true))) return rc;
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     if ((rc = pg_update_qp(h))) return rc;
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
@@ -595,7 +601,7 @@ int pg_simulate_dev(pg_handle* h, int32_t steps, double dt, void* state_hist_dev
     for (int k = 0; k < steps; k++) {
         if (state_hist_dev) HIPCHK(h, hipMemcpyAsync(state_hist_dev + (size_t)k * B * 6, h->d_state, (size_t)B * 6 * sizeof(real), hipMemcpyDeviceToDevice, h->stream));      // push!(qs, state) :88
         if (control_hist_dev) HIPCHK(h, hipMemcpyAsync(control_hist_dev + (size_t)k * B * 3, h->d_control, (size_t)B * 3 * sizeof(real), hipMemcpyDeviceToDevice, h->stream)); // push!(us, control) :89
-        if ((rc = pg_compute_time_steps(h)) || (rc = pg_compute_linearization_nodes(h)) || (rc = pg_update_qp(h)) || (rc = pg_solve(h))) return rc;          // :90-93
+        if ((rc = launch_nodes(h, true)) || (rc = pg_update_qp(h)) || (rc = pg_solve(h))) return rc;          // :90-93 (time grid fused into the projection launch)
         hipLaunchKernelGGL(k_advance, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, dt, h->d_state, h->d_control, h->d_u, h->d_t0);                  // :94-95
         LAUNCH_CHECK(h);
     }

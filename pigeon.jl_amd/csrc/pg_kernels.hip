@@ -95,10 +95,28 @@ PG_DEV real seg_dist2(real ax, real ay, real bx, real by, real x, real y) {
     real px = (real(1.0) - lam) * ax + lam * bx, py = (real(1.0) - lam) * ay + lam * by;
     return (px - x) * (px - x) + (py - y) * (py - y);
 }
-// one wave per instance; strict '<' with lowest index winning ties == the reference's sequential scan (:71-79)
-__global__ __launch_bounds__(256) void k_project(DevCfg C, int B, const real* __restrict__ state, real* __restrict__ sep) {
+// compute_time_steps! for lane i = node i of one instance (the same statements as k_time_steps, one node per lane): used by the fused launch of pg_step_dev
+PG_DEV void time_grid_lane(const DevCfg& C, int i, double t, double* T, double* D, double* PT) {
+#pragma clang fp contract(off)   // bit-for-bit with the CPU restatement: no fused multiply-add
+    if (i >= C.NN) return;
+    PT[i] = T[i];                                                                   // :20
+    double t0_long = t + C.Ns * C.dt_short;                                         // :21
+    if (C.use_correction_step) t0_long = C.dt_long * ceil((t0_long + C.dt_short) / C.dt_long - 1.0);   // :23
+    const double Ti = i <= C.Ns ? t + C.dt_short * i : t0_long + C.dt_long * (i - C.Ns);            // :25-26
+    const int n = i + 1;
+    const double Tn = n <= C.Ns ? t + C.dt_short * n : t0_long + C.dt_long * (n - C.Ns);
+    T[i] = Ti;
+    if (i < C.N) D[i] = Tn - Ti;                                                    // :27-29
+    if (C.alias_prev_ts) PT[i] = Ti;                                                // prev_ts IS ts in the reference (:15)
+}
+// one wave per instance; strict '<' with lowest index winning ties == the reference's sequential scan (:71-79).  With t0 != nullptr the same wave also
+// writes the instance's time grid (lane = node): pg_step_dev launches time grid + projection as one kernel (TG = true; the fp32 purity check allows fp64
+// arithmetic in that instantiation only).
+template <bool TG> __global__ __launch_bounds__(256) void k_project(DevCfg C, int B, const real* __restrict__ state, real* __restrict__ sep, const double* __restrict__ t0, double* __restrict__ ts,
+                                                 double* __restrict__ dt, double* __restrict__ prev_ts) {
     int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= B) return;
+    if constexpr (TG) time_grid_lane(C, lane, t0[wave], ts + (size_t)wave * C.NN, dt + (size_t)wave * C.N, prev_ts + (size_t)wave * C.NN);
     const TrajView T = traj_of(C, wave);
     real x = state[(size_t)wave * 6 + 0], y = state[(size_t)wave * 6 + 1];
     real best = INFINITY; int bi = 0x7fffffff;
