@@ -103,15 +103,19 @@ typedef struct pg_config {
                                      * step's active set and multipliers on the new QP data -- the counterpart of the reference's OSQP warm start
                                      * (src/coupled_lat_long.jl:218).  A verified round is the exact optimum of the new QP (iters = 0 then); otherwise the interior point runs
                                      * as for a cold instance.  Ignored when polish = 0 */
-    int32_t _pad4;
+    int32_t cold_guess;             /* rounds (default 4; 0 = off) a COLD instance may spend on the polish started from the EMPTY active set before the interior point is
+                                     * called: round 1 is the unconstrained LQ optimum, violated rows join the set, rows with negative multipliers leave it.  A verified round
+                                     * is the exact optimum (iters = 0 then), as for the warm start; most instances of a tracking problem have a handful of active rows and
+                                     * verify within 1-4 rounds, each the price of one interior-point iteration.  Instances whose rounds do not verify (or cycle) run the
+                                     * interior point exactly as with cold_guess = 0.  Ignored when polish = 0 */
 } pg_config;
 
 enum pg_formulation { PG_COUPLED = 0, PG_DECOUPLED = 1 };
 
 /* Layout check for hand-written mirrors of this header (ctypes, Julia): fills out[0..] with sizeof(pg_config), sizeof(pg_vehicle), sizeof(pg_control_params)
  * and the byte offsets inside pg_config of: control, N_short, dt_short, use_correction_step, hji_eps, batch_capacity, ipm_max_iter, formulation, ipm_tol, ipm_mu0,
- * walls, wall_weight, polish, polish_rho, polish_tol, polish_ipm_tol, warm_polish; then offsetof(pg_control_params, N_HJI) and offsetof(pg_vehicle, kappa_max).
- * Returns the number of entries (22); out may be NULL, at most n entries are written. */
+ * walls, wall_weight, polish, polish_rho, polish_tol, polish_ipm_tol, warm_polish, cold_guess; then offsetof(pg_control_params, N_HJI) and offsetof(pg_vehicle, kappa_max).
+ * Returns the number of entries (23); out may be NULL, at most n entries are written. */
 int pg_abi_layout(int32_t* out, int32_t n);
 
 /* X1() and the default keyword values of the reference constructors (coupled formulation) */

@@ -63,7 +63,7 @@ struct PgConfig
     polish_tol::Float64
     polish_ipm_tol::Float64
     warm_polish::Int32          # previous active set + multipliers as the polish's first guess (the counterpart of OSQP's warm start)
-    _pad4::Int32
+    cold_guess::Int32           # rounds a cold instance may spend on the polish started from the empty active set before the interior point runs (0 = off)
 end
 
 "The structs above are a hand copy of include/pigeon_mpc.h: compare their layout with what the library was compiled with (pg_abi_layout) before the first pg_create."
@@ -74,7 +74,7 @@ function check_layout(h)
     off(f) = Int32(fieldoffset(PgConfig, Base.fieldindex(PgConfig, f)))
     mine = Int32[sizeof(PgConfig), sizeof(PgVehicle), sizeof(PgControlParams),
                  off(:control), off(:N_short), off(:dt_short), off(:use_correction_step), off(:hji_eps), off(:batch_capacity), off(:ipm_max_iter), off(:formulation),
-                 off(:ipm_tol), off(:ipm_mu0), off(:walls), off(:wall_weight), off(:polish), off(:polish_rho), off(:polish_tol), off(:polish_ipm_tol), off(:warm_polish),
+                 off(:ipm_tol), off(:ipm_mu0), off(:walls), off(:wall_weight), off(:polish), off(:polish_rho), off(:polish_tol), off(:polish_ipm_tol), off(:warm_polish), off(:cold_guess),
                  fieldoffset(PgControlParams, Base.fieldindex(PgControlParams, :N_HJI)), fieldoffset(PgVehicle, Base.fieldindex(PgVehicle, :kappa_max))]
     mine == theirs || error("PigeonMI355X.jl struct layout $mine differs from the library's $theirs: update the mirrors to include/pigeon_mpc.h")
 end
@@ -118,7 +118,7 @@ function BatchedTrajectoryTrackingMPC(vehicle::Dict{Symbol,Float64}, trajectory:
     U = control_params
     cp = PgControlParams(U.V_min, U.V_max, U.k_V, U.k_s, U.δ̇_max, U.Q_Δs, U.Q_Δψ, U.Q_e, U.W_β, U.W_r, U.W_HJI, U.R_δ, U.R_Δδ, U.R_Fx, U.R_ΔFx, U.N_HJI, 0)
     _create(PgConfig(_vehicle(vehicle), cp, N_short, N_long, dt_short, dt_long, use_correction_step, c.rk4_substeps, c.hji_eps, B, device,
-                     c.ipm_max_iter, 0, c.ipm_tol, c.ipm_mu0, 0, 0, c.wall_weight, polish, 0, c.polish_rho, c.polish_tol, c.polish_ipm_tol, c.warm_polish, 0), L, trajectory, B)
+                     c.ipm_max_iter, 0, c.ipm_tol, c.ipm_mu0, 0, 0, c.wall_weight, polish, 0, c.polish_rho, c.polish_tol, c.polish_ipm_tol, c.warm_polish, c.cold_guess), L, trajectory, B)
 end
 
 "DecoupledTrajectoryTrackingMPC(vehicle, trajectory; ...) for a batch of B (src/decoupled_lat_long.jl:32-50).  `walls = true` adds the build-defined soft corridor rows
@@ -133,7 +133,7 @@ function BatchedDecoupledTrajectoryTrackingMPC(vehicle::Dict{Symbol,Float64}, tr
     U = control_params                                # the lateral formulation has no Q_Δs / R_Fx / R_ΔFx / W_HJI / N_HJI: those slots keep the library's defaults
     cp = PgControlParams(U.V_min, U.V_max, U.k_V, U.k_s, U.δ̇_max, d.Q_ds, U.Q_Δψ, U.Q_e, U.W_β, U.W_r, d.W_HJI, U.R_δ, U.R_Δδ, d.R_Fx, d.R_dFx, d.N_HJI, 0)
     _create(PgConfig(_vehicle(vehicle), cp, N_short, N_long, dt_short, dt_long, use_correction_step, c.rk4_substeps, c.hji_eps, B, device,
-                     c.ipm_max_iter, 1, c.ipm_tol, c.ipm_mu0, walls, 0, wall_weight, polish, 0, c.polish_rho, c.polish_tol, c.polish_ipm_tol, c.warm_polish, 0), L, trajectory, B)
+                     c.ipm_max_iter, 1, c.ipm_tol, c.ipm_mu0, walls, 0, wall_weight, polish, 0, c.polish_rho, c.polish_tol, c.polish_ipm_tol, c.warm_polish, c.cold_guess), L, trajectory, B)
 end
 
 "mpc.trajectory = latest_trajectory[] (src/ros_integration.jl:53)"

@@ -28,7 +28,7 @@ class pg_config(C.Structure):
                 ("batch_capacity", C.c_int32), ("device", C.c_int32), ("ipm_max_iter", C.c_int32), ("formulation", C.c_int32), ("ipm_tol", C.c_double),
                 ("ipm_mu0", C.c_double), ("walls", C.c_int32), ("_pad2", C.c_int32), ("wall_weight", C.c_double),
                 ("polish", C.c_int32), ("_pad3", C.c_int32), ("polish_rho", C.c_double), ("polish_tol", C.c_double), ("polish_ipm_tol", C.c_double),
-                ("warm_polish", C.c_int32), ("_pad4", C.c_int32)]
+                ("warm_polish", C.c_int32), ("cold_guess", C.c_int32)]
 
 
 # every symbol include/pigeon_mpc.h declares (tests check that the built library exports each one)
@@ -63,7 +63,7 @@ def load_library(precision="f64"):
 
 
 LAYOUT_FIELDS = ["control", "N_short", "dt_short", "use_correction_step", "hji_eps", "batch_capacity", "ipm_max_iter", "formulation", "ipm_tol", "ipm_mu0", "walls", "wall_weight",
-                 "polish", "polish_rho", "polish_tol", "polish_ipm_tol", "warm_polish"]
+                 "polish", "polish_rho", "polish_tol", "polish_ipm_tol", "warm_polish", "cold_guess"]
 
 
 def mirror_layout():

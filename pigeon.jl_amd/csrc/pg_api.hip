@@ -29,7 +29,8 @@ struct pg_handle {
     real *d_x7 = nullptr, *d_vg8 = nullptr, *d_Mb = nullptr;
     real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     real* d_lam = nullptr;                                      // [cap][N][16] multipliers of the last solve (warm start of the polish)
-    int* d_order = nullptr; int order_cur = 0; int order_B = 0;  // [2][cap] + 2 counters: launch order of k_solve for the next warm step (slow instances first)
+    int* d_order = nullptr; int order_cur = 0; int order_B = 0;  // [2][cap] + 2 counters: launch order of k_solve for the next warm step (slow instances first); then [cap] + 2 counters: the order k_linearize files for a cold batch
+    int corder_B = 0;
     real *d_pol_u2 = nullptr, *d_pol_u = nullptr; int* d_pol_src = nullptr;   // HJI fallback policy (HJI_computation.jl:133-158)
     int *d_status = nullptr, *d_iters = nullptr, *d_polish = nullptr; uint16_t* d_active = nullptr;
     // HJI grid
@@ -114,7 +115,7 @@ int pg_default_config(pg_config* c) {
     c->N_short = 10; c->N_long = 20; c->dt_short = 0.01; c->dt_long = 0.2; c->use_correction_step = 1;   // coupled_lat_long.jl:42-43
     c->rk4_substeps = 10; c->hji_eps = 0.05; c->batch_capacity = 4096; c->device = 0;
     c->ipm_max_iter = 40; c->ipm_mu0 = 100.0; c->formulation = PG_COUPLED; c->walls = 0; c->wall_weight = 1000.0;
-    c->polish = 1; c->warm_polish = 1;
+    c->polish = 1; c->warm_polish = 1; c->cold_guess = 4;
 #ifdef PG_F32
     c->ipm_tol = 1e-5; c->polish_rho = 1e3; c->polish_tol = 1e-4; c->polish_ipm_tol = 1e-4;
 #else
@@ -180,7 +181,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     }
     C.qp_len = 84 * C.N + 11;
     C.ipm_max_iter = cfg->ipm_max_iter; C.ipm_tol = (real)cfg->ipm_tol; C.ipm_mu0 = (real)cfg->ipm_mu0;
-    C.polish = cfg->polish != 0; C.polish_rho = (real)cfg->polish_rho; C.polish_tol = (real)cfg->polish_tol; C.polish_ipm_tol = (real)cfg->polish_ipm_tol; C.warm_polish = cfg->warm_polish != 0;
+    C.polish = cfg->polish != 0; C.polish_rho = (real)cfg->polish_rho; C.polish_tol = (real)cfg->polish_tol; C.polish_ipm_tol = (real)cfg->polish_ipm_tol; C.warm_polish = cfg->warm_polish != 0; C.cold_guess = cfg->cold_guess > 0 ? cfg->cold_guess : 0;
     const size_t cap = (size_t)cfg->batch_capacity; const int N = C.N, NN = C.NN;
 #define ALLOC(ptr, count, type) do { if (hipMalloc((void**)&(ptr), (size_t)(count) * sizeof(type)) != hipSuccess) { g_create_error = "hipMalloc failed for " #ptr; free_all(h); delete h; return PG_ERR_HIP; } } while (0)
     ALLOC(h->d_state, cap * 6, real); ALLOC(h->d_control, cap * 3, real); ALLOC(h->d_t0, cap, double); ALLOC(h->d_other, cap * 4, real); ALLOC(h->d_toff, cap, double);
@@ -188,7 +189,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_sep, cap * 4, real); ALLOC(h->d_nodes, cap * NN * 10, real); ALLOC(h->d_qp, cap * C.qp_len, real);
     ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
     ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_u, cap * 3, real); ALLOC(h->d_mu, cap, real);
-    ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_polish, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_active, cap * N, uint16_t);
+    ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_polish, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 3 * cap + 4, int); ALLOC(h->d_active, cap * N, uint16_t);
 #ifdef PG_EXPERIMENTAL_SOLVE4
     { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (experimental/pg_solve4.hip)
     if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), real);
@@ -248,7 +249,7 @@ int pg_abi_layout(int32_t* out, int32_t n) {
 #define OFF(f) (int32_t)offsetof(pg_config, f)
     const int32_t v[] = {(int32_t)sizeof(pg_config), (int32_t)sizeof(pg_vehicle), (int32_t)sizeof(pg_control_params), OFF(control), OFF(N_short), OFF(dt_short), OFF(use_correction_step),
                          OFF(hji_eps), OFF(batch_capacity), OFF(ipm_max_iter), OFF(formulation), OFF(ipm_tol), OFF(ipm_mu0), OFF(walls), OFF(wall_weight), OFF(polish), OFF(polish_rho),
-                         OFF(polish_tol), OFF(polish_ipm_tol), OFF(warm_polish), (int32_t)offsetof(pg_control_params, N_HJI), (int32_t)offsetof(pg_vehicle, kappa_max)};
+                         OFF(polish_tol), OFF(polish_ipm_tol), OFF(warm_polish), OFF(cold_guess), (int32_t)offsetof(pg_control_params, N_HJI), (int32_t)offsetof(pg_vehicle, kappa_max)};
 #undef OFF
     const int32_t cnt = (int32_t)(sizeof(v) / sizeof(v[0]));
     if (out) for (int32_t i = 0; i < cnt && i < n; i++) out[i] = v[i];
@@ -489,6 +490,7 @@ int pg_update_qp(pg_handle* h) {
         long nt = (long)B * C.N;
         hipLaunchKernelGGL(k_qp_dec, dim3((unsigned)((nt + 127) / 128)), dim3(128), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_qp);
         LAUNCH_CHECK(h);
+        h->corder_B = 0;
         return PG_OK;
     }
     if (h->has_hji) {
@@ -499,8 +501,12 @@ int pg_update_qp(pg_handle* h) {
         LAUNCH_CHECK(h);
     }
     long nl = (long)B * C.N * 2;         // two lanes per (instance, interval)
-    hipLaunchKernelGGL(k_linearize, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp);
+    const size_t cap = (size_t)h->cfg.batch_capacity;
+    int* cord = h->d_order + 2 * cap + 2;                  // cold launch order [cap] + its two counters
+    HIPCHK(h, hipMemsetAsync(cord + cap, 0, 2 * sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_linearize, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp, cord, cord + cap);
     LAUNCH_CHECK(h);
+    h->corder_B = B;
     return PG_OK;
 }
 int pg_solve(pg_handle* h) {
@@ -509,9 +515,10 @@ int pg_solve(pg_handle* h) {
     const size_t cap = (size_t)h->cfg.batch_capacity;
     int* cnt = h->d_order + 2 * cap;
     const bool use_order = h->dc.polish && h->dc.warm_polish && h->warm_B >= h->B && h->order_B == h->B;
+    const bool use_cold_order = !use_order && h->dc.polish && h->dc.cold_guess > 0 && h->corder_B == h->B;
     HIPCHK(h, hipMemsetAsync(cnt, 0, 2 * sizeof(int), h->stream));
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam,
-               use_order ? h->d_order + (size_t)h->order_cur * cap : nullptr, h->d_order + (size_t)(1 - h->order_cur) * cap, cnt};
+               use_order ? h->d_order + (size_t)h->order_cur * cap : (use_cold_order ? h->d_order + 2 * cap + 2 : nullptr), h->d_order + (size_t)(1 - h->order_cur) * cap, cnt};
     h->order_cur = 1 - h->order_cur; h->order_B = h->B;
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) { hipLaunchKernelGGL((k_solve4<2, false>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, (unsigned long long*)nullptr); LAUNCH_CHECK(h); return PG_OK; }

@@ -33,6 +33,7 @@ struct DevCfg {
     real ipm_tol, ipm_mu0;
     int polish;                   // active-set polish after the interior point (k_solve): 0 off, 1 on
     real polish_rho, polish_tol;  // penalty of the active rows in the polish solves; feasibility tolerance of its verification
+    int cold_guess;               // > 0: a COLD instance first tries the polish from the empty active set (unconstrained LQ optimum + add/drop rounds), at most this many rounds
     int warm_polish;              // instances with a previous solution first try the polish from its active set and multipliers (no interior point if it verifies)
     real polish_ipm_tol;          // interior-point tolerance at which the polish is first attempted (>= ipm_tol; a polish that fails there resumes the interior point down to ipm_tol)
     TrajView traj;                // trajectory 0 of the installed library
@@ -302,7 +303,8 @@ template <bool STAGED> __global__ __launch_bounds__(256) void k_nodes_warm(DevCf
 // EXACTLY -- those two columns of A are written as constants instead of being integrated (round 1 propagated all ten tangents in five lanes of two, i.e.
 // five primal trajectories per interval; now two).  c = Phi - A q - B0 u0 - Bf uf is finished in the same lanes (one shuffle inside the lane pair), lane 1
 // also evaluates stable_limits for the interval.
-__global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb, real* __restrict__ qp) {
+__global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb, real* __restrict__ qp,
+                                                  int* __restrict__ order_out, int* __restrict__ order_cnt) {
     typedef DK<4> D4;
     long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long per = (long)C.N * 2;
@@ -363,10 +365,11 @@ __global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const real* 
     }
 #pragma unroll
     for (int i = 0; i < 6; i++) part[i] += __shfl_xor(part[i], 1);
-    if (!live) return;
+    real env0 = -PG_BIG;
     const QpOff o = qp_offsets(C.N);
     real* Q = qp + (size_t)b * C.qp_len;
-    if (g == 0) {
+    if (!live) { }
+    else if (g == 0) {
         real* A = Q + o.A + 36 * t;
 #pragma unroll
         for (int i = 0; i < 6; i++) {
@@ -401,6 +404,21 @@ __global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const real* 
         Q[o.ddmin + t] = -C.cp.deltadot_max * h_total / C.un0;
         Q[o.ddmax + t] = C.cp.deltadot_max * h_total / C.un0;
         Q[o.dt + t] = h_total;
+        if (t == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) env0 = jmax(env0, e.H[r][0] * n0[2] + e.H[r][1] * n0[3] - e.G[r]);
+        }
+    }
+    // Launch order of k_solve for a cold batch.  The kernel ends with its slowest wave; the instances that need many polish rounds or the interior point are, in
+    // this problem, (i) the ones whose steering has far to go at the rate limit (a rate-limited ramp: one or two rows join the working set per round) and (ii) the
+    // ones that start outside (or at the edge of) the stability envelope (soft rows active from the first stage on).  File those at the front, the rest from the
+    // back: |delta(node 1) - delta(now)| / deltadot_max > 1.5 x the short horizon, or envelope margin of the current (Uy, r) below 0.05.  A hint only: it moves
+    // no result.
+    env0 = jmax(env0, __shfl_xor(env0, 1));
+    if (live && order_out && t == 0 && g == 0) {
+        const bool hard = fabs(n1[6] - n0[6]) > real(1.5) * C.cp.deltadot_max * ((real)C.Ns * (real)C.dt_short) || env0 > real(-0.05);
+        const int pos = hard ? atomicAdd(order_cnt, 1) : B - 1 - atomicAdd(order_cnt + 1, 1);
+        order_out[pos] = b;
     }
 }
 
@@ -1069,6 +1087,19 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         out[14] = bb[14] + M0 * x[6] + M1 * x[7] + sh; out[15] = sh;
     };
     const int nrows = hji_on ? 16 : 14;
+    // Rows that can never be active: delta at node s+1 cannot reach its bound when even the rate limit on every transition up to s leaves it short of it
+    // (delta_{s+1} <= delta_0 + sum_{k<=s} ddmax_k).  The polish never takes such a row into its working set: at a point that overshoots -- the optimum of a
+    // working set that still lacks some rate rows does -- the bound looks violated, and holding it as an equality TOGETHER with the rate rows before it is an
+    // inconsistent system (the typical failure of the add-all-violated rule on a rate-limited ramp of the steering angle to its stop).
+    unsigned addable = 0xFFFFu;
+    {
+        real up = act ? bb[12] : real(0.0), dn = act ? bb[13] : real(0.0);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { real a = __shfl_up(up, d), c = __shfl_up(dn, d); if (lane >= d) { up += a; dn += c; } }
+        const real d0 = sx0[6], slk = C.polish_tol * real(10.0);
+        if (d0 + up < bb[3] - slk) addable &= ~(1u << 3);
+        if (d0 - dn > -bb[4] + slk) addable &= ~(1u << 4);
+    }
     const int r8 = lane & 7;             // component index for the vector passes (lanes >= 8 mirror lanes 0..7)
 
     // forward roll-out: lanes r8 hold x_k[r8] in a register; broadcasts by readlane; results published to sx/sv for the stage lanes.
@@ -1428,14 +1459,15 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     // guess was, so nothing is lost in accuracy; if the rounds do not verify, the interior point runs as for a cold instance.
     real* const Lst = O.lam + ((size_t)b * N + s) * NROW;
     const bool warm = C.polish && C.warm_polish && O.solved[b] != 0 && O.status[b] == PG_SOLVED;
+    const bool guess = C.polish && !warm && C.cold_guess > 0;
     bool warm_attempt = false;
-    for (int attempt = warm ? -1 : 0; attempt < 2; attempt++) {
+    for (int attempt = (warm || guess) ? -1 : 0; attempt < 2; attempt++) {
     rp0 = real(0.0); phi = real(1.0); pmode = 0; pstat = 0; polish_gave_up = false; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu;
     warm_attempt = attempt < 0;
     if (attempt < 0) {
-        amask = act ? (unsigned)O.active[(size_t)b * N + s] : 0u; mask_ipm = amask;
+        amask = (act && warm) ? (unsigned)O.active[(size_t)b * N + s] : 0u; mask_ipm = amask;
 #pragma unroll
-        for (int j = 0; j < NROW; j++) { R.t[j] = real(1.0); R.corr[j] = real(0.0); R.lam[j] = (act && ((amask >> j) & 1u)) ? Lst[j] : real(0.0); }
+        for (int j = 0; j < NROW; j++) { R.t[j] = real(1.0); R.corr[j] = real(0.0); R.lam[j] = (act && warm && ((amask >> j) & 1u)) ? Lst[j] : real(0.0); }
         pmode = 1; mu = real(0.0);
     } else if (attempt == 0) {
         // ---- first attempt: v = 0 roll-out (dynamics- and rate-feasible), sigma just feasible; t = max(slack, tau); lambda = mu0 / t ----
@@ -1494,7 +1526,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     rp0 = wave_max(rp0);
     status = warm_attempt ? PG_SOLVED : PG_MAX_ITER;
     const int iter_cap = attempt <= 0 ? C.ipm_max_iter : 3 * C.ipm_max_iter;
-    const int round_cap = PG_POLISH_ROUNDS;      // (also for the warm attempt: a fall-back to the cold start costs ten rounds, and the slowest instance sets the kernel time)
+    const int round_cap = (warm_attempt && !warm) ? C.cold_guess : PG_POLISH_ROUNDS;      // (also for the warm attempt: a fall-back to the cold start costs ten rounds, and the slowest instance sets the kernel time)
     // Active-set polish (OSQP-style, on the stage-structured problem).  The interior point approaches nearly degenerate rows (slack and multiplier both ~ sqrt(mu))
     // like sqrt(mu), so its iterate can sit 1e-6 away from the optimum at any tolerance fp64 rounding allows.  Once it has converged, the rows with
     // lambda > t are held as EQUALITIES (augmented Lagrangian with penalty rho, multiplier estimates y = lambda), every other row is dropped, and the
@@ -1524,6 +1556,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             if (on && !a && !(tp[j] >= -ptol)) add |= 1u << j;
         }
         const bool changed = __any((add | drop) != 0u), conv = __all(settled);
+        const bool stalled = changed && !__any(((add & addable) | drop) != 0u);      // only unreachable rows are violated (then a rate row is too: not expected)
+        add &= addable;
         if (!changed && conv) {
             if (act) {
 #pragma unroll
@@ -1534,12 +1568,21 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             return 0;
         }
         if (!changed) return 1;
+        // a violated SOFT row joins the set with its slack FREE (the sigma >= 0 row of its group leaves): held together with sigma = 0 it would be a hard equality,
+        // inconsistent wherever the state cannot move (the envelope rows of the first stages, whose states the current control already fixes); if the slack
+        // comes out negative, its sigma >= 0 row is violated and comes back next round
+        if (warm_attempt && !warm) {
+        if (add & 0x00C0u) drop |= amask & (1u << 10);
+        if (add & 0x0300u) drop |= amask & (1u << 11);
+        if (hji_on && (add & (1u << 14))) drop |= amask & (1u << 15);
+        if (wall_on && (add & 0x0003u)) drop |= amask & (1u << 2);
+        }
         const unsigned next = (amask & ~drop) | add;
         // a set that comes back after two rounds is a cycle between two inconsistent guesses (degenerate rows; typical of the weakly determined far end of
         // the N = 50 lateral horizon): further rounds would only repeat it
         const bool cycle = __all(next == amask_2ago);
         amask_2ago = amask_1ago; amask_1ago = amask;
-        if (cycle) return 3;
+        if (cycle || stalled) return 3;
         amask = next;
 #pragma unroll
         for (int j = 0; j < NROW; j++) R.lam[j] = ((amask >> j) & 1u) ? R.lam[j] : real(0.0);
@@ -1714,7 +1757,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             const int pos = slow ? atomicAdd(O.order_cnt, 1) : B - 1 - atomicAdd(O.order_cnt + 1, 1);
             O.order_out[pos] = b;
         }
-        O.status[b] = status; O.iters[b] = it; O.mu[b] = mu; O.polish[b] = pstat; O.solved[b] = 1;      // model_predictive_control.jl:76: solved = true
+        O.status[b] = status; O.iters[b] = it; O.mu[b] = mu; O.polish[b] = pstat;
+        O.solved[b] = 1;      // model_predictive_control.jl:76: solved = true
     }
 }
 

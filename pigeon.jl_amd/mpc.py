@@ -35,7 +35,7 @@ class BatchedTrajectoryTrackingMPC:
 
     def __init__(self, trajectory, batch_capacity, vehicle=None, control_params=None, N_short=10, N_long=20, dt_short=0.01, dt_long=0.2,
                  use_correction_step=True, rk4_substeps=10, device=0, ipm_max_iter=40, ipm_tol=None, ipm_mu0=100.0, hji_eps=0.05, formulation="coupled",
-                 precision="f64", walls=False, wall_weight=1000.0, polish=None, polish_rho=None, polish_tol=None, polish_ipm_tol=None, warm_polish=None):
+                 precision="f64", walls=False, wall_weight=1000.0, polish=None, polish_rho=None, polish_tol=None, polish_ipm_tol=None, warm_polish=None, cold_guess=None):
         self.precision = precision
         self.real = np.float64 if precision == "f64" else np.float32      # element type of DEVICE arrays handed to the *_dev entry points
         self.lib = _lib.load_library(precision)
@@ -55,6 +55,8 @@ class BatchedTrajectoryTrackingMPC:
             cfg.polish_ipm_tol = float(polish_ipm_tol)
         if warm_polish is not None:
             cfg.warm_polish = int(bool(warm_polish))
+        if cold_guess is not None:
+            cfg.cold_guess = int(cold_guess)
         self.vehicle = X1() if vehicle is None else dict(vehicle)
         default_cp = CoupledControlParams() if formulation == "coupled" else DecoupledControlParams()
         self.control_params = default_cp if control_params is None else dict(control_params)

@@ -42,7 +42,7 @@ int main(void) {
     CHECK(rc == PG_OK, "pg_step: %d (%s)", rc, pg_last_error(h));
     for (int b = 0; b < 2; b++) {
         CHECK(st[b] == PG_SOLVED, "instance %d: status %d", b, st[b]);
-        CHECK(it[b] >= 3 && it[b] <= 40, "instance %d: %d iterations", b, it[b]);
+        CHECK(it[b] >= 0 && it[b] <= 40, "instance %d: %d iterations", b, it[b]);      /* 0: served by the active-set guess alone (pg_config.cold_guess) */
         CHECK(isfinite(u[3 * b]) && fabs(u[3 * b]) <= cfg.vehicle.delta_max + 1e-9, "instance %d: steering %g outside the actuator range", b, u[3 * b]);
     }
     double sep[6], ts[2 * 31], x[2 * 31 * 8];

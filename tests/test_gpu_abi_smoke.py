@@ -37,14 +37,14 @@ def test_mirror_layout_matches_the_library(pkg):
         lib = pkg.load_library(prec)
         n = lib.pg_abi_layout(None, 0)
         out = (C.c_int32 * n)(); lib.pg_abi_layout(out, n)
-        assert list(out) == _lib.mirror_layout() and n == 22
+        assert list(out) == _lib.mirror_layout() and n == 23
     # the Julia struct lists the same fields in the same order as the C struct (types: Cdouble / Int32)
     import re
     hdr = open(os.path.join(ROOT, "include", "pigeon_mpc.h")).read()
     body = re.search(r"typedef struct pg_config \{(.*?)\} pg_config;", hdr, re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     c_fields = [f.strip() for decl in re.findall(r"(?:double|int32_t)\s+([^;]+);", body) for f in decl.split(",")]
-    assert c_fields[0] == "N_short" and c_fields[-1] == "_pad4"
+    assert c_fields[0] == "N_short" and c_fields[-1] == "cold_guess"
     jl = open(os.path.join(ROOT, "julia", "PigeonMI355X.jl")).read()
     jbody = re.search(r"struct PgConfig(.*?)\nend", jl, re.S).group(1)
     j_fields = re.findall(r"^\s*([A-Za-z_0-9]+)::", jbody, re.M)

@@ -141,9 +141,16 @@ def test_first_node_outside_the_hard_bounds(pkg, skidpad):
 def test_iteration_cap_is_reported(pkg, skidpad):
     B = 64
     state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B, seed=10)
-    mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, B, ipm_max_iter=1)
+    mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, B, ipm_max_iter=1, cold_guess=0)
     u, st, it = mpc.step_(state, control, t0, time_offset=toff)
     assert np.all(st == pkg.MAX_ITER) and np.all(np.isfinite(u))             # the iterate at the cap is still a finite, dynamics-feasible point
+    mpc.close()
+    # with the active-set guess on (the default) the cap only binds for the instances the guess does not serve: those come back MAX_ITER, the others SOLVED with
+    # zero interior-point iterations
+    mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, B, ipm_max_iter=1)
+    u, st, it = mpc.step_(state, control, t0, time_offset=toff)
+    pol = mpc.polish_info()
+    assert np.all((st == pkg.SOLVED) == (it == 0)) and np.all(pol[st == pkg.SOLVED] >= 1) and np.all(st[it > 0] == pkg.MAX_ITER) and np.mean(it == 0) > 0.5
     mpc.close()
 
 
@@ -154,7 +161,7 @@ def test_second_start_is_reached_and_lands_on_the_same_optimum(pkg, skidpad, ora
     state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B, seed=12)
     ref = pkg.BatchedTrajectoryTrackingMPC(skidpad, B)
     u0, st0, it0 = ref.step_(state, control, t0, time_offset=toff)
-    mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, B, ipm_max_iter=7)
+    mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, B, ipm_max_iter=7, cold_guess=0)      # (the active-set guess off: every instance goes through the interior point)
     u1, st1, it1 = mpc.step_(state, control, t0, time_offset=toff)
     second = it1 > 7
     assert second.sum() >= B // 8, int(second.sum())
