@@ -18,6 +18,7 @@ struct pg_handle {
     int B = 0;                       // current batch
     int warm_B = 0;                  // instances [0, warm_B) are known to carry a previous solution (solved = true): set by pg_solve, cleared by pg_reset
     hipStream_t stream = nullptr;
+    bool fuse = false;                                        // pg_step_dev / pg_simulate_dev: linearisation fused into the solve kernel (pg_set_fusion; off by default)
     std::string err;
     // device buffers
     real *d_traj = nullptr; int traj_L = 0; int *d_traj_len = nullptr, *d_traj_idx = nullptr; int traj_idx_B = 0;
@@ -29,8 +30,7 @@ struct pg_handle {
     real *d_x7 = nullptr, *d_vg8 = nullptr, *d_Mb = nullptr;
     real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     real* d_lam = nullptr;                                      // [cap][N][16] multipliers of the last solve (warm start of the polish)
-    int* d_order = nullptr; int order_cur = 0; int order_B = 0;  // [2][cap] + 2 counters: launch order of k_solve for the next warm step (slow instances first); then [cap] + 2 counters: the order k_linearize files for a cold batch
-    int corder_B = 0;
+    int* d_order = nullptr; int order_B = 0;  // [cap] + 2 counters: launch order filed by the nodes kernels of the current step (likely slow instances first); order_B = batch it is valid for
     real *d_pol_u2 = nullptr, *d_pol_u = nullptr; int* d_pol_src = nullptr;   // HJI fallback policy (HJI_computation.jl:133-158)
     int *d_status = nullptr, *d_iters = nullptr, *d_polish = nullptr; uint16_t* d_active = nullptr;
     // HJI grid
@@ -189,7 +189,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_sep, cap * 4, real); ALLOC(h->d_nodes, cap * NN * 10, real); ALLOC(h->d_qp, cap * C.qp_len, real);
     ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
     ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_u, cap * 3, real); ALLOC(h->d_mu, cap, real);
-    ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_polish, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 3 * cap + 4, int); ALLOC(h->d_active, cap * N, uint16_t);
+    ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_polish, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, cap + 2, int); ALLOC(h->d_active, cap * N, uint16_t);
 #ifdef PG_EXPERIMENTAL_SOLVE4
     { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (experimental/pg_solve4.hip)
     if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), real);
@@ -214,6 +214,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     }
     for (int i = 0; i < 4; i++) if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_create_error = "hipEventCreate failed"; free_all(h); delete h; return PG_ERR_HIP; }
     h->ev_ok = true;
+    { const char* e = getenv("PG_FUSE"); h->fuse = e && e[0] == '1'; }
     // horizons up to 32 intervals keep their dynamics blocks resident in LDS (one pass over the QP data); longer ones stream them through a 4-slot ring
     h->solve_ring = N > 32;
 #ifdef PG_EXPERIMENTAL_SOLVE4
@@ -225,10 +226,11 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     if (h->solve_lds > lds_attr_max)
     {
         lds_attr_max = h->solve_lds;
-        (void)hipFuncSetAttribute((const void*)k_solve<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
-        (void)hipFuncSetAttribute((const void*)k_solve<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
-        (void)hipFuncSetAttribute((const void*)k_solve<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
-        (void)hipFuncSetAttribute((const void*)k_solve<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+        (void)hipFuncSetAttribute((const void*)k_solve<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+        (void)hipFuncSetAttribute((const void*)k_solve<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+        (void)hipFuncSetAttribute((const void*)k_solve<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+        (void)hipFuncSetAttribute((const void*)k_solve<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+        (void)hipFuncSetAttribute((const void*)k_solve<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
     }
     *out = h;
     return PG_OK;
@@ -257,6 +259,7 @@ int pg_abi_layout(int32_t* out, int32_t n) {
 }
 int pg_qp_len(const pg_handle* h) { return h ? h->dc.qp_len : PG_ERR_INVALID; }
 int pg_set_stream(pg_handle* h, void* s) { if (!h) return PG_ERR_INVALID; h->stream = (hipStream_t)s; return PG_OK; }
+int pg_set_fusion(pg_handle* h, int32_t on) { if (!h) return PG_ERR_INVALID; h->fuse = on != 0; return PG_OK; }
 int pg_synchronize(pg_handle* h) { if (!h) return PG_ERR_INVALID; HIPCHK(h, hipStreamSynchronize(h->stream)); return PG_OK; }
 
 // install a library: channels[n_traj][10][Lmax] (t, s, V, A, E, N, psi, kappa, edge_L, edge_R), L[k] valid nodes of trajectory k
@@ -457,6 +460,11 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
     const bool staged = h->dc.n_traj == 1 && h->traj_L <= 2048;
     const size_t traj_lds = staged ? (size_t)2 * h->traj_L * sizeof(real) : 0;
     const dim3 grid((B + 63) / 64), block(64);
+    const size_t cap = (size_t)h->cfg.batch_capacity;
+    const bool file = h->dc.formulation != PG_DECOUPLED && h->dc.polish;
+    OrderOut F{h->d_status, h->d_iters, h->d_polish, file ? h->d_order : nullptr, h->d_order + cap};
+    if (file) HIPCHK(h, hipMemsetAsync(h->d_order + cap, 0, 2 * sizeof(int), h->stream));
+    h->order_B = file ? B : 0;
     if (h->dc.formulation == PG_DECOUPLED) {
         auto kern = staged ? k_nodes_dec<true> : k_nodes_dec<false>;
         hipLaunchKernelGGL(kern, grid, block, traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_sep, h->d_ts, h->d_dt, h->d_nodes);
@@ -465,11 +473,11 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
             auto kern = staged ? k_nodes_warm<true> : k_nodes_warm<false>;
             const long nth = (long)B * h->dc.NN;
             hipLaunchKernelGGL(kern, dim3((unsigned)((nth + 255) / 256)), dim3(256), traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_sep, h->d_ts, h->d_prev_ts, h->d_solx,
-                               h->d_nodes);
+                               h->d_nodes, F);
         } else {
             auto kern = staged ? k_nodes<true> : k_nodes<false>;
             hipLaunchKernelGGL(kern, grid, block, traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
-                               h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes);
+                               h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes, F);
         }
     }
     LAUNCH_CHECK(h);
@@ -483,6 +491,23 @@ static int launch_hji_lookup(pg_handle* h, int B, const real* x7_dev, real* out8
     LAUNCH_CHECK(h);
     return PG_OK;
 }
+// the safety row of update_QP! (coupled_lat_long.jl:345-346): relative state, value / gradient look-up, (M, b) per instance
+static int launch_hji_rows(pg_handle* h) {
+    if (!h->has_hji) return PG_OK;
+    const int B = h->B;
+    hipLaunchKernelGGL(k_hji_relstate, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, h->d_state, h->d_other, h->d_x7);
+    LAUNCH_CHECK(h);
+    int rc = launch_hji_lookup(h, B, h->d_x7, h->d_vg8); if (rc) return rc;
+    hipLaunchKernelGGL(k_hji_constraint, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, h->d_x7, h->d_vg8, h->d_control, h->d_Mb);
+    LAUNCH_CHECK(h);
+    return PG_OK;
+}
+static int launch_linearize(pg_handle* h, int n) {
+    long nl = (long)n * h->dc.N * 2;         // two lanes per (instance, interval)
+    hipLaunchKernelGGL(k_linearize, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, h->stream, h->dc, n, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp);
+    LAUNCH_CHECK(h);
+    return PG_OK;
+}
 int pg_update_qp(pg_handle* h) {
     int rc = check_ready(h); if (rc) return rc;
     const int B = h->B; const DevCfg& C = h->dc;
@@ -490,43 +515,53 @@ int pg_update_qp(pg_handle* h) {
         long nt = (long)B * C.N;
         hipLaunchKernelGGL(k_qp_dec, dim3((unsigned)((nt + 127) / 128)), dim3(128), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_qp);
         LAUNCH_CHECK(h);
-        h->corder_B = 0;
         return PG_OK;
     }
-    if (h->has_hji) {
-        hipLaunchKernelGGL(k_hji_relstate, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, h->d_state, h->d_other, h->d_x7);
-        LAUNCH_CHECK(h);
-        rc = launch_hji_lookup(h, B, h->d_x7, h->d_vg8); if (rc) return rc;
-        hipLaunchKernelGGL(k_hji_constraint, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, h->d_x7, h->d_vg8, h->d_control, h->d_Mb);
-        LAUNCH_CHECK(h);
-    }
-    long nl = (long)B * C.N * 2;         // two lanes per (instance, interval)
-    const size_t cap = (size_t)h->cfg.batch_capacity;
-    int* cord = h->d_order + 2 * cap + 2;                  // cold launch order [cap] + its two counters
-    HIPCHK(h, hipMemsetAsync(cord + cap, 0, 2 * sizeof(int), h->stream));
-    hipLaunchKernelGGL(k_linearize, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp, cord, cord + cap);
+    if ((rc = launch_hji_rows(h))) return rc;
+    return launch_linearize(h, B);
+}
+// k_solve over `n` instances on stream `st`: the whole batch in index order (order == nullptr) or the sub-range order[0..n) of the launch order
+static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n) {
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, order};
+#ifdef PG_EXPERIMENTAL_SOLVE4
+    if (h->solve_quad) { hipLaunchKernelGGL((k_solve4<2, false>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, (unsigned long long*)nullptr); LAUNCH_CHECK(h); return PG_OK; }
+#endif
+    if (h->solve_ring) hipLaunchKernelGGL((k_solve<false, true, false>), dim3(n), dim3(64), h->solve_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
+    else hipLaunchKernelGGL((k_solve<false, false, false>), dim3(n), dim3(64), h->solve_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
     LAUNCH_CHECK(h);
-    h->corder_B = B;
     return PG_OK;
 }
 int pg_solve(pg_handle* h) {
     int rc = check_ready(h); if (rc) return rc;
-    // launch order: the one the previous solve of this same batch filed (warm steps only: a reset batch has no history and keeps the index order)
-    const size_t cap = (size_t)h->cfg.batch_capacity;
-    int* cnt = h->d_order + 2 * cap;
-    const bool use_order = h->dc.polish && h->dc.warm_polish && h->warm_B >= h->B && h->order_B == h->B;
-    const bool use_cold_order = !use_order && h->dc.polish && h->dc.cold_guess > 0 && h->corder_B == h->B;
-    HIPCHK(h, hipMemsetAsync(cnt, 0, 2 * sizeof(int), h->stream));
-    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam,
-               use_order ? h->d_order + (size_t)h->order_cur * cap : (use_cold_order ? h->d_order + 2 * cap + 2 : nullptr), h->d_order + (size_t)(1 - h->order_cur) * cap, cnt};
-    h->order_cur = 1 - h->order_cur; h->order_B = h->B;
-#ifdef PG_EXPERIMENTAL_SOLVE4
-    if (h->solve_quad) { hipLaunchKernelGGL((k_solve4<2, false>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, (unsigned long long*)nullptr); LAUNCH_CHECK(h); return PG_OK; }
-#endif
-    if (h->solve_ring) hipLaunchKernelGGL((k_solve<false, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr);
-    else hipLaunchKernelGGL((k_solve<false, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr);
-    LAUNCH_CHECK(h);
+    // launch order: the one the nodes kernels of this step filed (likely slow instances first)
+    const bool use_order = h->dc.polish && h->order_B == h->B;
+    if ((rc = launch_solve(h, h->stream, use_order ? h->d_order : nullptr, h->B))) return rc;
     if (h->B > h->warm_B) h->warm_B = h->B;           // model_predictive_control.jl:76: solved = true for every instance of the batch
+    return PG_OK;
+}
+// update_QP! + solve! of one step.  For the coupled formulation with N <= 32 both run in ONE kernel (k_solve<.., FUSE = true>): the wavefront that solves an instance
+// first linearises it (two lanes per interval = 60 of its 64 lanes), writes the QP data (still readable through pg_get_qp) and goes on to the solve.  k_solve ends
+// with its slowest wave -- an instance that needs the interior point takes 0.5 ms whatever the batch size -- and as a separate kernel it leaves part of the machine
+// idle for the last third of its run; fused, the SIMDs that are done with their quick instances linearise and solve the next ones meanwhile.  Same device
+// functions, same per-instance arithmetic: results are bit-identical to the two-kernel sequence.  MEASURED (B = 4096, MI355X): 1.23 vs 1.30 ms per cold step on
+// skidpadoval, but 1.52 vs 1.40 on vail and 1.13 vs 1.05 on EastPaddock -- the linearisation runs ~15 % slower inside the big kernel (the waves of a CU are then
+// spread over 85 KB of code instead of sharing one loop in the 64 KB instruction cache), and where no straggler tail exists there is nothing to win.  Hence OFF by
+// default (pg_set_fusion / PG_FUSE=1 turn it on).
+static int update_and_solve(pg_handle* h, hipEvent_t after_update) {
+    int rc;
+    const bool fused = h->fuse && h->dc.formulation != PG_DECOUPLED && !h->solve_ring && 2 * h->dc.N <= 64 && !h->solve_quad;
+    if (!fused) {
+        if ((rc = pg_update_qp(h))) return rc;
+        if (after_update) HIPCHK(h, hipEventRecord(after_update, h->stream));
+        return pg_solve(h);
+    }
+    if ((rc = launch_hji_rows(h))) return rc;
+    if (after_update) HIPCHK(h, hipEventRecord(after_update, h->stream));
+    const bool use_order = h->dc.polish && h->order_B == h->B;
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, use_order ? h->d_order : nullptr};
+    hipLaunchKernelGGL((k_solve<false, false, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
+    LAUNCH_CHECK(h);
+    if (h->B > h->warm_B) h->warm_B = h->B;
     return PG_OK;
 }
 // debug (not part of the public header): per-phase shader-clock cycles of one solve launch, out [B][6] =
@@ -536,13 +571,13 @@ int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     unsigned long long* d = nullptr;
     HIPCHK(h, hipMalloc((void**)&d, ((size_t)h->B * 6 + 1024) * 8));
     HIPCHK(h, hipMemset(d, 0, ((size_t)h->B * 6 + 1024) * 8));
-    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, nullptr, nullptr, nullptr};
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, nullptr};
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) hipLaunchKernelGGL((k_solve4<2, true>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, d);
     else
 #endif
-    if (h->solve_ring) hipLaunchKernelGGL((k_solve<true, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, d);
-    else hipLaunchKernelGGL((k_solve<true, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, d);
+    if (h->solve_ring) hipLaunchKernelGGL((k_solve<true, true, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, d, h->d_dt, h->d_Mb);
+    else hipLaunchKernelGGL((k_solve<true, false, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, d, h->d_dt, h->d_Mb);
     LAUNCH_CHECK(h);
     HIPCHK(h, hipMemcpy(out, d, ((size_t)h->B * 6 + 1024) * 8, hipMemcpyDeviceToHost));      // out: [B][6] cycles + 1024-double trace of PG_DEBUG_INSTANCE
     (void)hipFree(d);
@@ -592,9 +627,7 @@ int pg_step_dev(pg_handle* h, void* u_out_dev) {
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     if ((rc = launch_nodes(h, true))) return rc;
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-    if ((rc = pg_update_qp(h))) return rc;
-    HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
-    if ((rc = pg_solve(h))) return rc;
+    if ((rc = update_and_solve(h, h->ev[2]))) return rc;       // (chunked: ev[2] marks the end of the LAST update_QP chunk; earlier solve chunks run under it)
     if ((rc = pg_get_next_control_dev(h, u_out_dev))) return rc;
     HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
     h->timing_valid = true;
@@ -608,7 +641,7 @@ int pg_simulate_dev(pg_handle* h, int32_t steps, double dt, void* state_hist_dev
     for (int k = 0; k < steps; k++) {
         if (state_hist_dev) HIPCHK(h, hipMemcpyAsync(state_hist_dev + (size_t)k * B * 6, h->d_state, (size_t)B * 6 * sizeof(real), hipMemcpyDeviceToDevice, h->stream));      // push!(qs, state) :88
         if (control_hist_dev) HIPCHK(h, hipMemcpyAsync(control_hist_dev + (size_t)k * B * 3, h->d_control, (size_t)B * 3 * sizeof(real), hipMemcpyDeviceToDevice, h->stream)); // push!(us, control) :89
-        if ((rc = launch_nodes(h, true)) || (rc = pg_update_qp(h)) || (rc = pg_solve(h))) return rc;          // :90-93 (time grid fused into the projection launch)
+        if ((rc = launch_nodes(h, true)) || (rc = update_and_solve(h, nullptr))) return rc;          // :90-93 (time grid fused into the projection launch)
         hipLaunchKernelGGL(k_advance, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, dt, h->d_state, h->d_control, h->d_u, h->d_t0);                  // :94-95
         LAUNCH_CHECK(h);
     }

@@ -154,13 +154,26 @@ template <bool TG> __global__ __launch_bounds__(256) void k_project(DevCfg C, in
 // ------------------------------------------------------------------------------------------------------------------
 // nodes record per node: q[6], u[2] (physical units), V, kappa  -> 10 doubles
 struct NodeRec { real q0, q1, q2, q3, q4, q5, u0, u1, pV, pK; };
+// Launch order of the solve (and, in the chunked step, of update_QP): the nodes kernels file every instance either at the FRONT of `order` (likely slow) or from the
+// BACK (likely quick).  k_solve ends with its slowest wave and a slow instance costs 5-10 quick ones, so the slow ones should start first.  A hint: it moves no result.
+//  * warm instance: slow if the previous step needed the interior point or more than one polish round (in closed loop ~1 % of the batch, mostly the same ones);
+//  * cold instance: slow if (i) the steering has far to go at the rate limit -- |delta(node 1) - delta(now)| / deltadot_max > 1.5 x the short horizon: a rate-limited
+//    ramp, one or two rows join the working set per round -- or (ii) it starts outside or at the edge of the stability envelope (margin of (Uy, r) below 0.05:
+//    soft rows active from the first stage on).  These two groups hold nearly all instances the active-set guess does not serve on the reference's paths.
+struct OrderOut { const int* prev_status; const int* prev_iters; const int* prev_polish; int* order; int* cnt; };
+PG_DEV void file_order(const OrderOut& F, int B, int b, bool slow) {
+    if (!F.order) return;
+    const int pos = slow ? atomicAdd(F.cnt, 1) : B - 1 - atomicAdd(F.cnt + 1, 1);
+    F.order[pos] = b;
+}
+PG_DEV bool warm_slow(const OrderOut& F, int b) { return F.order && (F.prev_status[b] != PG_SOLVED || F.prev_iters[b] > 0 || F.prev_polish[b] != 1); }
 PG_DEV void put_node(real* __restrict__ ND, int i, const NodeRec& r) {
     real* o = ND + i * 10;
     o[0] = r.q0; o[1] = r.q1; o[2] = r.q2; o[3] = r.q3; o[4] = r.q4; o[5] = r.q5; o[6] = r.u0; o[7] = r.u1; o[8] = r.pV; o[9] = r.pK;
 }
 template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, int B, const real* __restrict__ state, const real* __restrict__ control, const tdouble* __restrict__ toff,
                         const int* __restrict__ solved, const real* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt,
-                        const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* __restrict__ nodes) {
+                        const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* __restrict__ nodes, OrderOut F) {
     // the two searched channels (t, s) are staged in LDS when they fit: every node costs three binary searches whose ~10 dependent probes each
     // would otherwise pay L2 latency (the kernel is a 64-wave serial recurrence: latency, not bandwidth, is its whole cost)
     extern __shared__ real sh_traj[];
@@ -204,6 +217,7 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
             r.pV = tj.V; r.pK = tj.kappa;
             put_node(ND, i, r);
         }
+        file_order(F, B, b, warm_slow(F, b));
         return;
     }
     // cold start :103-141
@@ -219,7 +233,7 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
     }
     const bool traj_mode = !(toff[b] != toff[b]);
     // i == 1 of the reference loop: acceleration from the full nonlinear model (:117-119); its node record is already written above
-    real s = s0;
+    real s = s0, d1 = d0, Fx1 = real(0.0);
     {
         real tau = DT[0];
         real dUx, dUy, dr;
@@ -244,9 +258,17 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
         r.q4 = shortp ? adiff(psi0, tj.psi) : -est.beta; r.q5 = shortp ? e0 : real(0.0);
         r.u0 = est.delta; r.u1 = est.Fx; r.pV = tj.V; r.pK = tj.kappa;
         put_node(ND, i, r);
+        if (i == 1) { d1 = est.delta; Fx1 = est.Fx; }
         real A = est.A;
         V = V + A * tau;
         s = s + V * tau + A * tau * tau * real(0.5);
+    }
+    if (F.order) {
+        bool slow = fabs(d1 - d0) > real(1.5) * C.cp.deltadot_max * ((real)C.Ns * (real)C.dt_short);
+        const Envelope e = stable_limits(P, Ux0, Fx1 > real(0.0) ? Fx1 * P.fwd_frac : Fx1 * P.fwb_frac, Fx1 > real(0.0) ? Fx1 * P.rwd_frac : Fx1 * P.rwb_frac);
+#pragma unroll
+        for (int k = 0; k < 4; k++) slow = slow || (e.H[k][0] * Uy0 + e.H[k][1] * r0 - e.G[k] > real(-0.05));
+        file_order(F, B, b, slow);
     }
 }
 
@@ -255,7 +277,7 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
 // the resulting arclength -- so the lane is (instance, node) instead of the instance (k_nodes runs the same arithmetic node after node in one lane because the
 // COLD seeding is a recurrence; mixed batches keep using it).  Same operations per node as k_nodes' warm branch: bit-identical nodes.
 template <bool STAGED> __global__ __launch_bounds__(256) void k_nodes_warm(DevCfg C, int B, const real* __restrict__ state, const real* __restrict__ control, const real* __restrict__ sep,
-                             const tdouble* __restrict__ ts, const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* __restrict__ nodes) {
+                             const tdouble* __restrict__ ts, const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* __restrict__ nodes, OrderOut F) {
     extern __shared__ real sh_traj[];
     TrajView T = C.traj;
     if constexpr (STAGED) {
@@ -276,6 +298,7 @@ template <bool STAGED> __global__ __launch_bounds__(256) void k_nodes_warm(DevCf
         TrajS tj = traj_at_s(T, s0);
         r.q0 = s0 - traj_s_at_time(T, TS[0]); r.q1 = q0[3]; r.q2 = q0[4]; r.q3 = q0[5]; r.q4 = adiff(q0[2], tj.psi); r.q5 = e0;
         r.u0 = u0[0]; r.u1 = u0[1] + u0[2]; r.pV = tj.V; r.pK = tj.kappa;
+        file_order(F, B, b, warm_slow(F, b));
     } else {                                                                        // :87-101 with update_interpolations! (:189-195)
         const tdouble* PT = prev_ts + (size_t)b * C.NN; const real* PX = prev_x + (size_t)b * C.NN * 8;
         const real tlast = PT[C.NN - 1];
@@ -303,14 +326,10 @@ template <bool STAGED> __global__ __launch_bounds__(256) void k_nodes_warm(DevCf
 // EXACTLY -- those two columns of A are written as constants instead of being integrated (round 1 propagated all ten tangents in five lanes of two, i.e.
 // five primal trajectories per interval; now two).  c = Phi - A q - B0 u0 - Bf uf is finished in the same lanes (one shuffle inside the lane pair), lane 1
 // also evaluates stable_limits for the interval.
-__global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb, real* __restrict__ qp,
-                                                  int* __restrict__ order_out, int* __restrict__ order_cnt) {
+// (the lane pair (g = 0, 1) of an interval must be two adjacent lanes of one wavefront; a lane that is not `live` computes along with its partner and stores nothing)
+PG_DEV void linearize_pair(const DevCfg& C, int b, int t, int g, bool live, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb,
+                           real* __restrict__ qp) {
     typedef DK<4> D4;
-    long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long per = (long)C.N * 2;
-    const bool live = gid < (long)B * per;
-    if (!live) gid = (long)B * per - 1;                       // keep the lane pair whole for the shuffle; dead lanes store nothing
-    const int b = (int)(gid / per); const int rem = (int)(gid - (long)b * per); const int t = rem >> 1, g = rem & 1;
     const bool ramp = t >= C.Ns;
     const real* n0 = nodes + ((size_t)b * C.NN + t) * 10; const real* n1 = n0 + 10;
     const real h_total = dt[(size_t)b * C.N + t];
@@ -365,11 +384,10 @@ __global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const real* 
     }
 #pragma unroll
     for (int i = 0; i < 6; i++) part[i] += __shfl_xor(part[i], 1);
-    real env0 = -PG_BIG;
+    if (!live) return;
     const QpOff o = qp_offsets(C.N);
     real* Q = qp + (size_t)b * C.qp_len;
-    if (!live) { }
-    else if (g == 0) {
+    if (g == 0) {
         real* A = Q + o.A + 36 * t;
 #pragma unroll
         for (int i = 0; i < 6; i++) {
@@ -404,22 +422,15 @@ __global__ __launch_bounds__(256) void k_linearize(DevCfg C, int B, const real* 
         Q[o.ddmin + t] = -C.cp.deltadot_max * h_total / C.un0;
         Q[o.ddmax + t] = C.cp.deltadot_max * h_total / C.un0;
         Q[o.dt + t] = h_total;
-        if (t == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) env0 = jmax(env0, e.H[r][0] * n0[2] + e.H[r][1] * n0[3] - e.G[r]);
-        }
     }
-    // Launch order of k_solve for a cold batch.  The kernel ends with its slowest wave; the instances that need many polish rounds or the interior point are, in
-    // this problem, (i) the ones whose steering has far to go at the rate limit (a rate-limited ramp: one or two rows join the working set per round) and (ii) the
-    // ones that start outside (or at the edge of) the stability envelope (soft rows active from the first stage on).  File those at the front, the rest from the
-    // back: |delta(node 1) - delta(now)| / deltadot_max > 1.5 x the short horizon, or envelope margin of the current (Uy, r) below 0.05.  A hint only: it moves
-    // no result.
-    env0 = jmax(env0, __shfl_xor(env0, 1));
-    if (live && order_out && t == 0 && g == 0) {
-        const bool hard = fabs(n1[6] - n0[6]) > real(1.5) * C.cp.deltadot_max * ((real)C.Ns * (real)C.dt_short) || env0 > real(-0.05);
-        const int pos = hard ? atomicAdd(order_cnt, 1) : B - 1 - atomicAdd(order_cnt + 1, 1);
-        order_out[pos] = b;
-    }
+}
+__global__ __launch_bounds__(64) void k_linearize(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb, real* __restrict__ qp) {
+    long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)C.N * 2;
+    const bool live = gid < (long)B * per;
+    if (!live) gid = (long)B * per - 1;                       // keep the lane pair whole for the shuffle; dead lanes store nothing
+    const int b = (int)(gid / per); const int rem = (int)(gid - (long)b * per);
+    linearize_pair(C, b, rem >> 1, rem & 1, live, nodes, dt, hji_Mb, qp);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -931,7 +942,7 @@ __global__ __launch_bounds__(64) void k_hji_policy(DevCfg C, int B, int use_poli
 //   6..9: H_i [Uy;r] - sigma_{i/2} <= G_i     10: sigma1 >= 0   11: sigma2 >= 0    12: d_delta <= ddmax   13: d_delta >= ddmin
 //   14: M u + b + sigma_HJI >= 0              15: sigma_HJI >= 0        (14,15 only for nodes 1 .. min(N_HJI,Ns)-1)
 struct SolveOut { real* sol_x; real* sol_sigma; real* u_out; int* status; int* iters; uint16_t* active; real* mu; int* solved; int* polish; real* lam;
-                  const int* order_in; int* order_out; int* order_cnt; };
+                  const int* order_in; };
 
 #define NROW 16
 #define PG_POLISH_ROUNDS 6      // active-set rounds of the polish before it gives up
@@ -984,16 +995,25 @@ PG_DEV void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool PROF, bool RING>
-__global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, int B, const real* __restrict__ qp, const real* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof) {
+template <bool PROF, bool RING, bool FUSE>
+__global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, int B, real* qp, const real* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof,
+                                                                          const tdouble* __restrict__ dt_grid, const real* __restrict__ hji_Mb) {
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int slot) { if (PROF) { unsigned long long now = clock64(); pc[slot] += now - tprev; tprev = now; } };
     if (PROF) tprev = clock64();
-    // Launch order: workgroup i solves instance order_in[i] when an order is supplied.  The kernel ends with its slowest wave, and in closed loop ~1 % of the
-    // instances need a full interior-point solve (ten times a warm polish round): each solve files its instance for the NEXT step at the front (slow: needed the
-    // interior point or more than one round) or at the back of order_out, so that the likely stragglers start first instead of wherever their index falls.
+    // Launch order: workgroup i solves instance order_in[i] when an order is supplied (filed by the nodes kernels, likely stragglers first: see OrderOut)
     const int b = O.order_in ? O.order_in[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;
     const int N = C.N, NN = C.NN;
+    // FUSE: update_QP! of this instance first, by the wave that is about to solve it -- lane pair (2t, 2t+1) linearises interval t (2N <= 64; lanes beyond 2N mirror
+    // the last interval and store nothing).  The QP data go to memory exactly as k_linearize writes them (pg_get_qp reads them; the solve below reads them back
+    // through L2: fence + barrier in between).  Why fuse: k_solve ends with its slowest wave, and as a kernel of its own it idles most of the machine during that
+    // tail; here the SIMDs that are done with quick instances linearise and solve the next ones meanwhile.
+    if constexpr (FUSE) {
+        const int lp = lane < 2 * N ? lane : 2 * N - 2 + (lane & 1);
+        linearize_pair(C, b, lp >> 1, lp & 1, lane < 2 * N, nodes, dt_grid, hji_Mb, qp);
+        __threadfence();
+        __syncthreads();
+    }
     extern __shared__ real lds[];
     // The dynamics blocks are NOT resident: each pass streams them stage by stage from L2 through a 4-slot LDS ring
     // (slot = SB doubles: rows 0..5 of Abar_k = [A | B0+Bf] at row stride 9, rows 0..5 of Bbar_k = Bf (12), cbar_k = c (6)); rows 6,7 are [0 I] / I / 0.
@@ -1752,11 +1772,6 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         if (C.formulation == PG_DECOUPLED) Fx = nodes[((size_t)b * NN + 1) * 10 + 7];      // decoupled_lat_long.jl:275-278: Fx of the seeded node 2
         real* U = O.u_out + (size_t)b * 3;
         U[0] = d; U[1] = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac; U[2] = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
-        if (O.order_out) {
-            const bool slow = it > 0 || pstat != 1;
-            const int pos = slow ? atomicAdd(O.order_cnt, 1) : B - 1 - atomicAdd(O.order_cnt + 1, 1);
-            O.order_out[pos] = b;
-        }
         O.status[b] = status; O.iters[b] = it; O.mu[b] = mu; O.polish[b] = pstat;
         O.solved[b] = 1;      // model_predictive_control.jl:76: solved = true
     }

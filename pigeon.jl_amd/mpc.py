@@ -236,6 +236,10 @@ class BatchedTrajectoryTrackingMPC:
     def set_stream(self, hip_stream):
         self._chk(self.lib.pg_set_stream(self.h, C.c_void_p(hip_stream)), "pg_set_stream")
 
+    def set_fusion(self, on):
+        """Fused step (update_QP! inside the solve kernel, include/pigeon_mpc.h pg_set_fusion); off by default."""
+        self._chk(self.lib.pg_set_fusion(self.h, int(bool(on))), "pg_set_fusion")
+
     def phase_ms(self):
         out = (C.c_float * 3)()
         self._chk(self.lib.pg_get_phase_ms(self.h, out), "pg_get_phase_ms")

@@ -221,3 +221,23 @@ def test_cold_guess_serves_most_instances_and_changes_no_answer(pkg, skidpad):
     assert np.max(np.abs(res[4][2] - res[0][2])) < 1e-6                      # the whole primal solution, every node
     same = np.all(res[4][3] == res[0][3], axis=1)
     assert np.mean(same) > 0.97                                               # active sets identical except where a row is degenerate (active with a zero multiplier)
+
+
+def test_fused_step_is_bit_identical(pkg, skidpad):
+    """pg_set_fusion(1): update_QP! runs inside the solve kernel (the wave that solves an instance linearises it first).  Same device functions, so the QP data, the
+    solution and the controls are bit-identical to the two-kernel sequence -- cold step and a warm step after it."""
+    B = 2048
+    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B, seed=77)
+    out = {}
+    for fused in (False, True):
+        mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, B)
+        mpc.set_fusion(fused)
+        mpc.set_inputs(state, control, t0, time_offset=toff)
+        mpc.step_dev(); mpc.synchronize()
+        u1 = mpc.get_next_control().copy(); qp1 = mpc.qp_data().copy(); x1 = mpc.solution()[0].copy(); it1 = mpc.solve_info()[1].copy()
+        mpc.step_dev(); mpc.synchronize()                     # warm step on the same inputs
+        u2 = mpc.get_next_control().copy(); qp2 = mpc.qp_data().copy()
+        out[fused] = (u1, qp1, x1, it1, u2, qp2)
+        mpc.close()
+    for a, b in zip(out[False], out[True]):
+        assert np.array_equal(a, b)
