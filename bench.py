@@ -233,7 +233,7 @@ def main():
         one_step(cold=False)
     sync(); warm_elapsed = time.perf_counter() - tw
     # the same cold workload with the active-set guess OFF (every instance through the interior point; round-2-mid behaviour), as a reference for what the guess buys
-    ipm_only = None
+    ipm_only = None; fused_line = None
     if rank == 0 and world == 1 and not args.no_warm:
         m0 = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision=args.precision, cold_guess=0)
         m0.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -249,6 +249,17 @@ def main():
                     "solved": f"{int((st0_ == pkg.SOLVED).sum())}/{B}", "ipm_iters_mean": float(np.mean(it0_)), "polish_rounds_hist": hist(p0_),
                     "config": "pg_config.cold_guess = 0: Mehrotra interior point to mu <= 3e-6 + active-set polish for every instance"}
         m0.close()
+        # ... and with update_QP! fused into the solve kernel (pg_set_fusion, opt-in: SURVEY 7.1 step 6; bit-identical results)
+        mpc.set_fusion(True)
+        for _ in range(2):
+            mpc.reset(); mpc.step_dev(u_out.data_ptr())
+        torch.cuda.synchronize(); t_ = time.perf_counter()
+        for _ in range(args.steps):
+            mpc.reset(); mpc.step_dev(u_out.data_ptr())
+        torch.cuda.synchronize(); t_ = time.perf_counter() - t_
+        fused_line = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": [float(v) for v in mpc.phase_ms()],
+                      "config": "pg_set_fusion(1): the wave that solves an instance linearises it first (one kernel for update_QP! + solve!); off by default"}
+        mpc.set_fusion(False)
         mpc.reset(); mpc.step_dev(u_out.data_ptr()); torch.cuda.synchronize()         # (leave the headline controller's outputs as the last thing in u_out)
     # the gathered controls hold every rank's shard: this rank's block equals its own output
     gather_ok = True if world == 1 else bool(torch.equal(gathered[rank * B:(rank + 1) * B], u_out) and torch.isfinite(gathered).all().item())
@@ -416,6 +427,7 @@ def main():
         }
         if ipm_only is not None:
             line["interior_point_only"] = ipm_only
+            line["fused_step"] = fused_line
         if roll is not None:
             line["closed_loop_rollout"] = roll
         if hji is not None:

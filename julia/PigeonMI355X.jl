@@ -110,7 +110,7 @@ _vehicle(v::Dict{Symbol,Float64}) = PgVehicle((v[k] for k in (:G, :m, :Izz, :L, 
 "CoupledTrajectoryTrackingMPC(vehicle, trajectory; ...) for a batch of B (src/coupled_lat_long.jl:42-60)"
 function BatchedTrajectoryTrackingMPC(vehicle::Dict{Symbol,Float64}, trajectory::TrajectoryTube{Float64}, B::Integer;
                                       control_params=CoupledControlParams(), N_short=10, N_long=20, dt_short=0.01, dt_long=0.2,
-                                      use_correction_step=true, device=0, precision::Symbol=:f64, polish=true)
+                                      use_correction_step=true, device=0, precision::Symbol=:f64, polish=true, cold_guess=nothing)
     L = lib(precision)
     cfg = Ref{PgConfig}()
     ccall(Libdl.dlsym(L, :pg_default_config), Cint, (Ref{PgConfig},), cfg)          # solver tolerances default to the library's own (they depend on its arithmetic type)
@@ -118,7 +118,8 @@ function BatchedTrajectoryTrackingMPC(vehicle::Dict{Symbol,Float64}, trajectory:
     U = control_params
     cp = PgControlParams(U.V_min, U.V_max, U.k_V, U.k_s, U.δ̇_max, U.Q_Δs, U.Q_Δψ, U.Q_e, U.W_β, U.W_r, U.W_HJI, U.R_δ, U.R_Δδ, U.R_Fx, U.R_ΔFx, U.N_HJI, 0)
     _create(PgConfig(_vehicle(vehicle), cp, N_short, N_long, dt_short, dt_long, use_correction_step, c.rk4_substeps, c.hji_eps, B, device,
-                     c.ipm_max_iter, 0, c.ipm_tol, c.ipm_mu0, 0, 0, c.wall_weight, polish, 0, c.polish_rho, c.polish_tol, c.polish_ipm_tol, c.warm_polish, c.cold_guess), L, trajectory, B)
+                     c.ipm_max_iter, 0, c.ipm_tol, c.ipm_mu0, 0, 0, c.wall_weight, polish, 0, c.polish_rho, c.polish_tol, c.polish_ipm_tol, c.warm_polish,
+                     cold_guess === nothing ? c.cold_guess : Int32(cold_guess)), L, trajectory, B)
 end
 
 "DecoupledTrajectoryTrackingMPC(vehicle, trajectory; ...) for a batch of B (src/decoupled_lat_long.jl:32-50).  `walls = true` adds the build-defined soft corridor rows
@@ -201,6 +202,11 @@ function polish_info(mpc::BatchedTrajectoryTrackingMPC)
     p = Vector{Int32}(undef, mpc.B)
     check(mpc, ccall(sym(mpc, :pg_get_polish_info), Cint, (Ptr{Cvoid}, Ptr{Int32}), mpc.handle, p), "pg_get_polish_info")
     p
+end
+
+"Opt-in: update_QP! inside the solve kernel for step! / simulate! (pg_set_fusion; bit-identical results, pays where a few slow instances dominate the solve)"
+function set_fusion!(mpc::BatchedTrajectoryTrackingMPC, on::Bool)
+    check(mpc, ccall(sym(mpc, :pg_set_fusion), Cint, (Ptr{Cvoid}, Int32), mpc.handle, Int32(on)), "pg_set_fusion")
 end
 
 "update_HJI_values_marker! / update_HJI_contour_marker! (src/rviz.jl:23-40,60-69) for a batch of relative states q (7 x B): V at every (x, y) knot pair of grid
