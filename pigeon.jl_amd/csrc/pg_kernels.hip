@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     real it_[NROW];                    // 1 / t_j, refreshed once per interior-point iteration
     // Polish state (see the loop below): pmode = 0 while the interior point runs, then the round number of the active-set polish;
     // amask = this stage's rows currently held active.
-    int pmode = 0, pstat = 0; unsigned amask = 0, mask_ipm = 0, amask_1ago = 0xFFFFFFFFu, amask_2ago = 0xFFFFFFFFu; bool polish_gave_up = false;
+    int pmode = 0, pstat = 0; unsigned amask = 0, mask_ipm = 0, amask_1ago = 0xFFFFFFFFu, amask_2ago = 0xFFFFFFFFu; bool polish_gave_up = false, cycle_broken = false;
     const real rho = C.polish_rho, ptol = C.polish_tol;
     auto assemble = [&](real sigmu, bool matrices) {
         real W[NROW], ell[NROW];
@@ -1482,7 +1482,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     const bool guess = C.polish && !warm && C.cold_guess > 0;
     bool warm_attempt = false;
     for (int attempt = (warm || guess) ? -1 : 0; attempt < 2; attempt++) {
-    rp0 = real(0.0); phi = real(1.0); pmode = 0; pstat = 0; polish_gave_up = false; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu;
+    rp0 = real(0.0); phi = real(1.0); pmode = 0; pstat = 0; polish_gave_up = false; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu; cycle_broken = false;
     warm_attempt = attempt < 0;
     if (attempt < 0) {
         amask = (act && warm) ? (unsigned)O.active[(size_t)b * N + s] : 0u; mask_ipm = amask;
@@ -1597,10 +1597,24 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         if (hji_on && (add & (1u << 14))) drop |= amask & (1u << 15);
         if (wall_on && (add & 0x0003u)) drop |= amask & (1u << 2);
         }
-        const unsigned next = (amask & ~drop) | add;
-        // a set that comes back after two rounds is a cycle between two inconsistent guesses (degenerate rows; typical of the weakly determined far end of
-        // the N = 50 lateral horizon): further rounds would only repeat it
+        unsigned next = (amask & ~drop) | add;
+        // a set that comes back after two rounds (A -> B -> C -> A) is a cycle between inconsistent guesses (degenerate rows; typical of the weakly determined far
+        // end of the N = 50 lateral horizon): further rounds would only repeat it.
+        // One kind of A -> B -> A alternation has a known way out.  A soft row sits a hair inside its bound at the optimum (slack 1e-8 .. 1e-6: the interior point cannot tell, and hands it
+        // over as active together with its sigma >= 0 row).  Held with sigma = 0 the pair is a hard equality whose sigma row gets a negative multiplier -> the sigma row
+        // leaves; with sigma free the slack comes out (slightly) negative -> the sigma row returns; and so on.  The consistent third choice is the one neither set
+        // tries: the soft row OUT, its sigma row in.  Taken once per polish.
+        // (A -> B -> A alone is not given up on: the multipliers are still settling, and revisited sets often verify; A -> B -> C -> A is.)
         const bool cycle = __all(next == amask_2ago);
+        if (!cycle && !cycle_broken && __all(next == amask_1ago)) {
+            const unsigned tog = amask ^ next;
+            unsigned nx = next;
+            if (tog & (1u << 10)) nx = (nx | (1u << 10)) & ~0x00C0u;
+            if (tog & (1u << 11)) nx = (nx | (1u << 11)) & ~0x0300u;
+            if (hji_on && (tog & (1u << 15))) nx = (nx | (1u << 15)) & ~(1u << 14);
+            if (wall_on && (tog & (1u << 2))) nx = (nx | (1u << 2)) & ~0x0003u;
+            if (__any(nx != next)) { cycle_broken = true; next = nx; }
+        }
         amask_2ago = amask_1ago; amask_1ago = amask;
         if (cycle || stalled) return 3;
         amask = next;
@@ -1615,7 +1629,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         if (warm_attempt) { pstat = 0; status = PG_MAX_ITER; return true; }      // warm guess did not verify: on to the cold start
         pstat = -1;
         if (!(tol_cur > C.ipm_tol)) { polish_gave_up = true; return true; }
-        tol_cur = C.ipm_tol; pmode = 0; status = PG_MAX_ITER; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu;
+        tol_cur = C.ipm_tol; pmode = 0; status = PG_MAX_ITER; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu; cycle_broken = false;
 #pragma unroll
         for (int j = 0; j < NROW; j++) R.lam[j] = (act && j < nrows) ? mu * frcp(R.t[j]) : real(0.0);
         return false;
