@@ -249,7 +249,7 @@ def main():
                     "solved": f"{int((st0_ == pkg.SOLVED).sum())}/{B}", "ipm_iters_mean": float(np.mean(it0_)), "polish_rounds_hist": hist(p0_),
                     "config": "pg_config.cold_guess = 0: Mehrotra interior point to mu <= 3e-6 + active-set polish for every instance"}
         m0.close()
-        # ... and with update_QP! fused into the solve kernel (pg_set_fusion, opt-in: SURVEY 7.1 step 6; bit-identical results)
+        # ... and with update_QP! fused into the solve kernel (pg_set_fusion(1); by default only all-warm batches run fused: SURVEY 7.1 step 6; bit-identical results)
         mpc.set_fusion(True)
         for _ in range(2):
             mpc.reset(); mpc.step_dev(u_out.data_ptr())
@@ -258,8 +258,8 @@ def main():
             mpc.reset(); mpc.step_dev(u_out.data_ptr())
         torch.cuda.synchronize(); t_ = time.perf_counter() - t_
         fused_line = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": [float(v) for v in mpc.phase_ms()],
-                      "config": "pg_set_fusion(1): the wave that solves an instance linearises it first (one kernel for update_QP! + solve!); off by default"}
-        mpc.set_fusion(False)
+                      "config": "pg_set_fusion(1): the wave that solves an instance linearises it first (one kernel for update_QP! + solve!); the default (mode 2) fuses all-warm batches only"}
+        mpc.set_fusion(2)
         mpc.reset(); mpc.step_dev(u_out.data_ptr()); torch.cuda.synchronize()         # (leave the headline controller's outputs as the last thing in u_out)
     # the gathered controls hold every rank's shard: this rank's block equals its own output
     gather_ok = True if world == 1 else bool(torch.equal(gathered[rank * B:(rank + 1) * B], u_out) and torch.isfinite(gathered).all().item())

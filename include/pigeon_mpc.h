@@ -197,11 +197,11 @@ int pg_get_state(pg_handle* h, double* state, double* control, double* t0);
 
 /* stream to launch on (hipStream_t as void*); NULL = the null stream */
 int pg_set_stream(pg_handle* h, void* hip_stream);
-/* Fused step (default OFF; the environment variable PG_FUSE=1 at pg_create turns it on): pg_step / pg_step_dev / pg_simulate_dev run update_QP! and solve! of the
- * coupled formulation (N <= 32) in ONE kernel -- the wavefront that solves an instance linearises it first (same device functions: results are bit-identical with
- * it off; the QP data are still written and pg_get_qp reads them).  The four compute calls invoked one by one are never fused.  Measured neutral to slightly
- * negative on MI355X, which is why it is opt-in. */
-int pg_set_fusion(pg_handle* h, int32_t on);
+/* Fused step: pg_step / pg_step_dev / pg_simulate_dev can run update_QP! and solve! of the coupled formulation (N <= 32) in ONE kernel -- the wavefront that
+ * solves an instance linearises it first (same device functions: results are bit-identical either way; the QP data are still written and pg_get_qp reads them).
+ * mode 0 = never, 1 = always, 2 (default; PG_FUSE=0/1/2 at pg_create overrides) = for batches of >= 1024 instances in which every instance is warm (closed loop),
+ * where it is 5-8 % faster on MI355X; on cold batches it is neutral to slightly negative.  The four compute calls invoked one by one are never fused. */
+int pg_set_fusion(pg_handle* h, int32_t mode);
 int pg_synchronize(pg_handle* h);
 
 /* ---- read-backs for parity tests and logging (host pointers, any may be NULL) ---------------------------------- */

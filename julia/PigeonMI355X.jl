@@ -204,9 +204,9 @@ function polish_info(mpc::BatchedTrajectoryTrackingMPC)
     p
 end
 
-"Opt-in: update_QP! inside the solve kernel for step! / simulate! (pg_set_fusion; bit-identical results, pays where a few slow instances dominate the solve)"
-function set_fusion!(mpc::BatchedTrajectoryTrackingMPC, on::Bool)
-    check(mpc, ccall(sym(mpc, :pg_set_fusion), Cint, (Ptr{Cvoid}, Int32), mpc.handle, Int32(on)), "pg_set_fusion")
+"update_QP! inside the solve kernel for step! / simulate! (pg_set_fusion; bit-identical results): mode 0 never, 1 always, 2 (default) for all-warm batches"
+function set_fusion!(mpc::BatchedTrajectoryTrackingMPC, mode::Integer)
+    check(mpc, ccall(sym(mpc, :pg_set_fusion), Cint, (Ptr{Cvoid}, Int32), mpc.handle, Int32(mode)), "pg_set_fusion")
 end
 
 "update_HJI_values_marker! / update_HJI_contour_marker! (src/rviz.jl:23-40,60-69) for a batch of relative states q (7 x B): V at every (x, y) knot pair of grid

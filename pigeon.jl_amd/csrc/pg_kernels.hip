@@ -1111,7 +1111,10 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     // (delta_{s+1} <= delta_0 + sum_{k<=s} ddmax_k).  The polish never takes such a row into its working set: at a point that overshoots -- the optimum of a
     // working set that still lacks some rate rows does -- the bound looks violated, and holding it as an equality TOGETHER with the rate rows before it is an
     // inconsistent system (the typical failure of the add-all-violated rule on a rate-limited ramp of the steering angle to its stop).
-    unsigned addable = 0xFFFFu;
+    // The mirror image: a working set that holds the rate row on EVERY transition up to s puts delta_{s+1} exactly at that reach; where the reach lies beyond the
+    // steering bound the rate row of transition s cannot be part of such a run (`overshoot`; the polish takes it out before it solves: the previous step's set,
+    // shifted by one stage on the new QP, is the typical offender -- a ramp to the stop that now ends one stage earlier).
+    unsigned addable = 0xFFFFu, overshoot = 0u, excl = 0u;
     {
         real up = act ? bb[12] : real(0.0), dn = act ? bb[13] : real(0.0);
 #pragma unroll
@@ -1119,6 +1122,19 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         const real d0 = sx0[6], slk = C.polish_tol * real(10.0);
         if (d0 + up < bb[3] - slk) addable &= ~(1u << 3);
         if (d0 - dn > -bb[4] + slk) addable &= ~(1u << 4);
+        if (act && d0 + up > bb[3] + slk) overshoot |= 1u << 12;
+        if (act && d0 - dn < -bb[4] - slk) overshoot |= 1u << 13;
+        // Pairs of delta rows that cannot be active together (delta is an integrator chain with box and rate limits; dmax_p / dmin_p = the bounds of delta at the
+        // START of this lane's transition, node 0 being the fixed delta_0):
+        //   bit 0: delta_{s+1} at its upper bound AND the rate row that steers down at full rate: delta_s would sit above its own upper bound;  bit 1: the mirror image;
+        //   bit 2: delta_s and delta_{s+1} both at their upper bounds leave the increment no room to be at either rate limit;                   bit 3: the mirror image.
+        // A row whose partner is in the working set (or joins it in the same round) is not added: at the optimum of a set that lacks a row, delta overshoots around
+        // the missing row and these partners LOOK violated (the row that ends a ramp and the first row of the stop are the typical pair).
+        const real dmax_p = lane > 0 ? __shfl_up(bb[3], 1) : d0, dmin_p = lane > 0 ? -__shfl_up(bb[4], 1) : d0, ddm = fmin(bb[12], bb[13]);
+        if (bb[3] + bb[13] > dmax_p + slk) excl |= 1u;
+        if (-bb[4] - bb[12] < dmin_p - slk) excl |= 2u;
+        if (lane > 0 && fabs(bb[3] - dmax_p) < ddm - slk) excl |= 4u;
+        if (lane > 0 && fabs(-bb[4] - dmin_p) < ddm - slk) excl |= 8u;
     }
     const int r8 = lane & 7;             // component index for the vector passes (lanes >= 8 mirror lanes 0..7)
 
@@ -1472,22 +1488,24 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         slacks(xn, vn0, sn1, sn2, snh, tplus);
     };
 
-    int it_total = 0;
+    int it_total = 0, ptr_n = 0;
     // Warm start of the ACTIVE SET (the reference's warm start is OSQP's: previous (x, y) as the initial iterate, src/coupled_lat_long.jl:218 WarmStart = true).
     // An instance whose previous step ended in a solved QP first tries the polish directly from that step's active set and multipliers on the NEW QP data
     // (attempt -1): in closed loop the set rarely changes from one 10 ms step to the next, and a verified round IS the exact optimum of the new QP whatever the
     // guess was, so nothing is lost in accuracy; if the rounds do not verify, the interior point runs as for a cold instance.
     real* const Lst = O.lam + ((size_t)b * N + s) * NROW;
     const bool warm = C.polish && C.warm_polish && O.solved[b] != 0 && O.status[b] == PG_SOLVED;
-    const bool guess = C.polish && !warm && C.cold_guess > 0;
-    bool warm_attempt = false;
-    for (int attempt = (warm || guess) ? -1 : 0; attempt < 2; attempt++) {
+    const bool guess = C.polish && C.cold_guess > 0;       // attempt -1: the polish from the EMPTY set (cold instances, and warm ones whose previous set did not verify)
+    int last_nchg = 0; real last_tmax = real(0.0);
+    bool warm_attempt = false, from_prev = false;          // warm_attempt: a polish without an interior point in front (attempts -2, -1); from_prev: attempt -2
+    for (int attempt = warm ? -2 : (guess ? -1 : 0); attempt < 2; attempt++) {
+    if (attempt == -1 && !guess) continue;
     rp0 = real(0.0); phi = real(1.0); pmode = 0; pstat = 0; polish_gave_up = false; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu; cycle_broken = false;
-    warm_attempt = attempt < 0;
+    warm_attempt = attempt < 0; from_prev = attempt == -2;
     if (attempt < 0) {
-        amask = (act && warm) ? (unsigned)O.active[(size_t)b * N + s] : 0u; mask_ipm = amask;
+        amask = (act && from_prev) ? (unsigned)O.active[(size_t)b * N + s] : 0u; mask_ipm = amask;
 #pragma unroll
-        for (int j = 0; j < NROW; j++) { R.t[j] = real(1.0); R.corr[j] = real(0.0); R.lam[j] = (act && warm && ((amask >> j) & 1u)) ? Lst[j] : real(0.0); }
+        for (int j = 0; j < NROW; j++) { R.t[j] = real(1.0); R.corr[j] = real(0.0); R.lam[j] = (act && from_prev && ((amask >> j) & 1u)) ? Lst[j] : real(0.0); }
         pmode = 1; mu = real(0.0);
     } else if (attempt == 0) {
         // ---- first attempt: v = 0 roll-out (dynamics- and rate-feasible), sigma just feasible; t = max(slack, tau); lambda = mu0 / t ----
@@ -1546,7 +1564,10 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     rp0 = wave_max(rp0);
     status = warm_attempt ? PG_SOLVED : PG_MAX_ITER;
     const int iter_cap = attempt <= 0 ? C.ipm_max_iter : 3 * C.ipm_max_iter;
-    const int round_cap = (warm_attempt && !warm) ? C.cold_guess : PG_POLISH_ROUNDS;      // (also for the warm attempt: a fall-back to the cold start costs ten rounds, and the slowest instance sets the kernel time)
+    const int round_cap = attempt == -1 ? C.cold_guess : PG_POLISH_ROUNDS;
+    // a set that moves by a row or two per round on a nearly feasible point is a ramp being extended or released one stage at a time (the multiplier of the next row
+    // only changes sign once the previous one has left): it gets there, and eight more 25 us rounds are far cheaper than the interior point they avoid
+    auto over_cap = [&](int pass) { return pass > round_cap + ((last_nchg <= 2 && last_tmax < real(1e-6)) ? 8 : 0); };      // (also for the warm attempt: a fall-back to the cold start costs ten rounds, and the slowest instance sets the kernel time)
     // Active-set polish (OSQP-style, on the stage-structured problem).  The interior point approaches nearly degenerate rows (slack and multiplier both ~ sqrt(mu))
     // like sqrt(mu), so its iterate can sit 1e-6 away from the optimum at any tolerance fp64 rounding allows.  Once it has converged, the rows with
     // lambda > t are held as EQUALITIES (augmented Lagrangian with penalty rho, multiplier estimates y = lambda), every other row is dropped, and the
@@ -1576,8 +1597,28 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             if (on && !a && !(tp[j] >= -ptol)) add |= 1u << j;
         }
         const bool changed = __any((add | drop) != 0u), conv = __all(settled);
-        const bool stalled = changed && !__any(((add & addable) | drop) != 0u);      // only unreachable rows are violated (then a rate row is too: not expected)
-        add &= addable;
+        {   // rows that cannot be active (addable) or cannot be active next to a row that is, or is about to be, in the set (excl)
+            unsigned addf = add & addable;
+            const unsigned wa = amask | addf, wa_p = __shfl_up(wa, 1);
+            if ((wa & (1u << 3)) && (excl & 1u)) addf &= ~(1u << 13);
+            if ((wa & (1u << 4)) && (excl & 2u)) addf &= ~(1u << 12);
+            if ((wa & (1u << 3)) && (wa_p & (1u << 3)) && (excl & 4u)) addf &= ~(3u << 12);
+            if ((wa & (1u << 4)) && (wa_p & (1u << 4)) && (excl & 8u)) addf &= ~(3u << 12);
+            // at most one NEW row per slack group and round, the more violated one: two rows that share a slack, both held with the slack free, pin a combination of
+            // the states hard -- a pair picked up together at an overshooting point has sent the multipliers of a whole (correct) ramp of rate rows negative
+            if ((addf & 0x00C0u) == 0x00C0u) addf &= ~(tp[6] <= tp[7] ? (1u << 7) : (1u << 6));
+            if ((addf & 0x0300u) == 0x0300u) addf &= ~(tp[8] <= tp[9] ? (1u << 9) : (1u << 8));
+            if (wall_on && (addf & 0x0003u) == 0x0003u) addf &= ~(tp[0] <= tp[1] ? 2u : 1u);
+            add = addf;
+        }
+        const bool stalled = changed && !__any((add | drop) != 0u);      // only rows that cannot be active are violated (then another row is too: not expected)
+        {   // progress of the set iteration, for the round cap and the bail-out below
+            real tmx = real(0.0);
+#pragma unroll
+            for (int j = 0; j < NROW; j++) tmx = fmax(tmx, (act && ((amask >> j) & 1u)) ? fabs(tp[j]) : real(0.0));
+            last_tmax = wave_max(tmx);
+            last_nchg = (int)wave_sum(real(__popc(add | drop)));
+        }
         if (!changed && conv) {
             if (act) {
 #pragma unroll
@@ -1588,10 +1629,13 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             return 0;
         }
         if (!changed) return 1;
+        // a working set whose rows cannot be met together (|t| of order one on rows held as equalities) is not worth iterating on when there is no interior-point
+        // iterate to protect: a polish without an interior point in front moves on to its fall-back at once
+        if (warm_attempt && !(last_tmax < real(0.3))) return 3;
         // a violated SOFT row joins the set with its slack FREE (the sigma >= 0 row of its group leaves): held together with sigma = 0 it would be a hard equality,
         // inconsistent wherever the state cannot move (the envelope rows of the first stages, whose states the current control already fixes); if the slack
         // comes out negative, its sigma >= 0 row is violated and comes back next round
-        if (warm_attempt && !warm) {
+        if (attempt == -1) {
         if (add & 0x00C0u) drop |= amask & (1u << 10);
         if (add & 0x0300u) drop |= amask & (1u << 11);
         if (hji_on && (add & (1u << 14))) drop |= amask & (1u << 15);
@@ -1634,6 +1678,19 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         for (int j = 0; j < NROW; j++) R.lam[j] = (act && j < nrows) ? mu * frcp(R.t[j]) : real(0.0);
         return false;
     };
+    // diagnostic build: one trace record per polish check of PG_DEBUG_INSTANCE behind the interior-point records (entries 128..255 of the trace region):
+    // (attempt * 100 + pass number, outcome of the check, rows set in the working set, max |t| over its rows)
+    auto ptrace = [&](int pc, const real* tp) {
+        if constexpr (PROF) {
+            if (b != C.dbg_instance) return;
+            real mx = real(0.0), cnt = real(0.0);
+#pragma unroll
+            for (int j = 0; j < NROW; j++) if (act && ((amask >> j) & 1u)) { mx = fmax(mx, fabs(tp[j])); cnt += real(1.0); }
+            mx = wave_max(mx); cnt = wave_sum(cnt);
+            if (lane == 0 && ptr_n < 128) { real* tr = reinterpret_cast<real*>(prof + (size_t)B * 6) + 4 * (128 + ptr_n); tr[0] = real(100 * (attempt + 2) + pmode); tr[1] = real(pc); tr[2] = cnt; tr[3] = mx; }
+            ptr_n++;
+        }
+    };
     it = 0;
     while (true) {
         if (!pmode) {
@@ -1658,6 +1715,11 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             if (!(amask & 0x0B00u)) amask |= 1u << 11;
             if (hji_on && !(amask & 0xC000u)) amask |= 1u << 15;
             if (wall_on && !(amask & 0x0007u)) amask |= 1u << 2;
+            // rate rows that would carry an unbroken run from the first transition past the steering bound (see `overshoot`)
+            const unsigned long long run_up = __ballot(act && ((amask >> 12) & 1u)), run_dn = __ballot(act && ((amask >> 13) & 1u));
+            const int end_up = __ffsll((long long)~run_up) - 1, end_dn = __ffsll((long long)~run_dn) - 1;      // first stage outside the run (lanes >= N are never in it)
+            if (s < end_up) amask &= ~(overshoot & (1u << 12));
+            if (s < end_dn) amask &= ~(overshoot & (1u << 13));
         }
 
         // ---- predictor (sigma = 0, no correction) / first polish solve ----
@@ -1707,9 +1769,10 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         } else {
             // first polish solve done: with multiplier estimates as good as the interior point's, it usually verifies at once (no refinement needed)
             const int pc = polish_check(tp, real(0.01) * ptol);
+            ptrace(pc, tp);
             if (pc == 0) break;
             if (pc == 3) { if (polish_failed()) break; continue; }
-            if (pc == 2) { if (++pmode > round_cap && polish_failed()) break; continue; }      // the set changed: next round directly
+            if (pc == 2) { if (over_cap(++pmode) && polish_failed()) break; continue; }      // the set changed: next round directly
         }
         // ---- corrector / polish refinement ----
         assemble(sg * mu, false);
@@ -1753,8 +1816,9 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             it++;
         } else {
             const int pc = polish_check(tp, ptol);
+            ptrace(pc + 10, tp);
             if (pc == 0) break;
-            if ((pc == 3 || ++pmode > round_cap) && polish_failed()) break;      // set changed, or the multiplier iteration has not settled yet: another round
+            if ((pc == 3 || over_cap(++pmode)) && polish_failed()) break;      // set changed, or the multiplier iteration has not settled yet: another round
         }
     }
     it_total += it;

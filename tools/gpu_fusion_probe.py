@@ -10,7 +10,7 @@ for path in os.environ.get("PG_PATHS", "skidpadoval,vail,EastPaddock").split(","
     B = int(os.environ.get("PG_B", "4096"))
     state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345)
     ref = None
-    for ov in (False, True):
+    for ov in (0, 1, 2):
         mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B)
         mpc.set_fusion(ov)
         mpc.set_inputs(state, control, t0, time_offset=toff)
@@ -24,6 +24,6 @@ for path in os.environ.get("PG_PATHS", "skidpadoval,vail,EastPaddock").split(","
         if ref is None: ref = u.copy()
         ph = mpc.phase_ms()
         mpc.simulate_(4); mpc.synchronize(); a = time.perf_counter(); mpc.simulate_(40); mpc.synchronize(); dt_cl = (time.perf_counter() - a) / 40
-        print(f"{path} fused={ov}: cold step {1e3 * dt_cold:.3f} ms ({B / dt_cold / 1e6:.2f} M solves/s) phases {[round(x, 3) for x in ph]}; closed loop {1e3 * dt_cl:.3f} ms/step ({B / dt_cl / 1e6:.2f} M/s); "
+        print(f"{path} fusion mode {ov}: cold step {1e3 * dt_cold:.3f} ms ({B / dt_cold / 1e6:.2f} M solves/s) phases {[round(x, 3) for x in ph]}; closed loop {1e3 * dt_cl:.3f} ms/step ({B / dt_cl / 1e6:.2f} M/s); "
               f"solved {(st == 1).sum()}, identical controls: {np.array_equal(u, ref)}", flush=True)
         mpc.close()

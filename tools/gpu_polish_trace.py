@@ -1,0 +1,30 @@
+"""Diagnostic: interior-point and polish trace of ONE instance (PG_DEBUG_INSTANCE, read at pg_create) at closed-loop step PG_STEP on path PG_PATH -- the closed
+loop runs PG_STEP - 1 steps on the device, then the step's phases are called one by one with the diagnostic build of k_solve in place of solve!."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import _load_pkg
+pkg = _load_pkg()
+path = os.environ.get("PG_PATH", "EastPaddock"); step = int(os.environ.get("PG_STEP", "27")); inst = int(os.environ["PG_DEBUG_INSTANCE"])
+traj = pkg.load_path_fixture(path)
+B = 4096
+state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345)
+mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B)
+mpc.set_inputs(state, control, t0, time_offset=toff)
+if step > 1:
+    mpc.simulate_(step - 1); mpc.synchronize()
+st0, it0, act0, _ = mpc.solve_info(); ps0 = mpc.polish_info()
+print(f"before step {step}: instance {inst} status {st0[inst]} iters {it0[inst]} polish {ps0[inst]} active rows {sum(bin(int(m)).count('1') for m in act0[inst])}")
+mpc.compute_time_steps_(); mpc.compute_linearization_nodes_(); mpc.update_QP_()
+out = np.zeros(B * 6 + 1024, dtype=np.uint64)
+rc = mpc.lib.pg_debug_solve_cycles(mpc.h, out.ctypes.data_as(C.c_void_p)); assert rc == 0
+tr = out[B * 6:].view(np.float64).reshape(256, 4)
+st, it, act, mu = mpc.solve_info(); ps = mpc.polish_info()
+print(f"step {step}: instance {inst} status {st[inst]} iters {it[inst]} polish {ps[inst]} active rows {sum(bin(int(m)).count('1') for m in act[inst])}; batch: iters>0 {(it > 0).sum()} max {it.max()}")
+w = np.argsort(-it)[:8]; print("slowest instances of the batch (index, iters, polish):", [(int(b), int(it[b]), int(ps[b])) for b in w])
+print("interior-point records (mu, alpha_aff, sigma, alpha):")
+for k in range(128):
+    if tr[k].any(): print(f"  {k:3d}  mu {tr[k, 0]:.3e}  aaff {tr[k, 1]:.3f}  sigma {tr[k, 2]:.3e}  alpha {tr[k, 3]:.3f}")
+print("polish checks ((attempt + 2) * 100 + pass [attempt -2 = previous set, -1 = empty set, 0 / 1 = after the interior point], outcome [0 verified, 1 refine, 2 set changed, 3 cycle; +10 = after a refinement], rows in the set, max |t| over them):")
+for k in range(128, 256):
+    if tr[k].any(): print(f"  {int(tr[k, 0]):4d}  outcome {int(tr[k, 1]):2d}  rows {int(tr[k, 2]):3d}  max|t| {tr[k, 3]:.3e}")
