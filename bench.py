@@ -249,7 +249,7 @@ def main():
                     "solved": f"{int((st0_ == pkg.SOLVED).sum())}/{B}", "ipm_iters_mean": float(np.mean(it0_)), "polish_rounds_hist": hist(p0_),
                     "config": "pg_config.cold_guess = 0: Mehrotra interior point to mu <= 3e-6 + active-set polish for every instance"}
         m0.close()
-        # ... and with update_QP! fused into the solve kernel (pg_set_fusion(1); by default only all-warm batches run fused: SURVEY 7.1 step 6; bit-identical results)
+        # ... and with update_QP! fused into the solve kernel (pg_set_fusion(1), off by default: SURVEY 7.1 step 6; bit-identical results)
         mpc.set_fusion(True)
         for _ in range(2):
             mpc.reset(); mpc.step_dev(u_out.data_ptr())
@@ -258,8 +258,8 @@ def main():
             mpc.reset(); mpc.step_dev(u_out.data_ptr())
         torch.cuda.synchronize(); t_ = time.perf_counter() - t_
         fused_line = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": [float(v) for v in mpc.phase_ms()],
-                      "config": "pg_set_fusion(1): the wave that solves an instance linearises it first (one kernel for update_QP! + solve!); the default (mode 2) fuses all-warm batches only"}
-        mpc.set_fusion(2)
+                      "config": "pg_set_fusion(1): the wave that solves an instance linearises it first (one kernel for update_QP! + solve!); off by default"}
+        mpc.set_fusion(0)
         mpc.reset(); mpc.step_dev(u_out.data_ptr()); torch.cuda.synchronize()         # (leave the headline controller's outputs as the last thing in u_out)
     # the gathered controls hold every rank's shard: this rank's block equals its own output
     gather_ok = True if world == 1 else bool(torch.equal(gathered[rank * B:(rank + 1) * B], u_out) and torch.isfinite(gathered).all().item())
@@ -395,9 +395,17 @@ def main():
         traffic = None; traffic_src = None
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            traffic = tr.get("hbm_bytes_per_launch"); traffic_src = tr.get("source")
+            kern = {0: "k_nodes", 1: "k_linearize", 2: "k_solve"}[dom]                  # the kernel that makes up the dominant phase (no HJI row in the headline run)
+            hit = [v for k, v in tr.get("kernels", {}).items() if kern in k]
+            traffic = hit[0]["hbm_bytes_per_launch"] if hit else tr.get("hbm_bytes_per_launch"); traffic_src = (hit[0] if hit else tr).get("source")
         except Exception:
             pass
+        # k_linearize is throughput-bound on the fp64 vector unit: 40 dynamics evaluations x N intervals x (130 value + 8 tangent directions x 260) flops per instance
+        lin_fl = float(B) * 40 * mpc.N * (130 + 8 * 260)
+        peak_lin = FP64_VALU_PEAK_TF if args.precision == "f64" else 2 * FP64_VALU_PEAK_TF
+        valu_lin = {"bound": "valu-" + args.precision, "kernel": "k_linearize", "algorithmic_flops_per_launch": lin_fl, "achieved": lin_fl / (float(ph[1]) * 1e-3) / 1e12, "peak": peak_lin,
+                    "unit": "TFLOP/s", "frac": lin_fl / (float(ph[1]) * 1e-3) / 1e12 / peak_lin, "avg_launch_ms": float(ph[1]),
+                    "source": "flop model of the forward-mode RK4 linearisation (DESIGN.md 6); time live (HIP events: the update_qp phase, no HJI row in the headline run)"}
         # secondary roofline of the dominant kernel: ALGORITHMIC flops (model above x the iteration counts of THIS run) against the fp64 / fp32 vector peak --
         # the resource class that binds (the step moves 112 B per solve through HBM, so its HBM fraction is ~1e-5 by construction)
         rounds = np.where(pol > 0, pol, np.where(pol < 0, 6, 0))
@@ -413,11 +421,11 @@ def main():
             "config": {"workload": (f"configs[1]: Batch={B}/GPU coupled MPC, N=30 (N_short=10, N_long=20), X1, randomised x0 along skidpadoval, cold start, HJI inactive, fp64" if args.precision == "f64"
                                     else f"configs[3]: Batch={world * B} coupled MPC, N=30, fp32, sharded {B}/GPU x{world}, RCCL all_gather of controls, cold start"),
                        "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}, all_gather of controls ({args.backend})" if world > 1 else "single GPU",
-                       "solver": "active-set rounds from the empty set on the stage-structured QP (Riccati; pg_config.cold_guess = 4), verified KKT point; instances the rounds do not serve: "
+                       "solver": "active-set rounds from the empty set on the stage-structured QP (Riccati; pg_config.cold_guess = 8 + structural rules for the steering rows), verified KKT point; instances the rounds do not serve: "
                                  "Mehrotra interior point to mu <= " + ("3e-6" if args.precision == "f64" else "1e-4") + ", then active-set polish (verified KKT point)",
-                       "accuracy": "measured in this run: cpu_baseline.accuracy (sample of 256); every one of the 4096 instances <= 1e-6 is asserted by tests/test_gpu_full_size.py (measured max 5e-11)"},
+                       "accuracy": "measured in this run: cpu_baseline.accuracy (sample of 256); every one of the 4096 instances <= 1e-6 is asserted by tests/test_gpu_full_size.py (measured max 1e-9)"},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": dom_ms, "valu": valu,
+                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": dom_ms, "valu": valu, "valu_linearize": valu_lin,
                          "note": f"algorithmic HBM bytes are {bytes_per_solve} B/solve (SURVEY 8d): the step is VALU/LDS/latency bound by construction, not HBM bound; see roofline.valu and hji_lookup"},
             "phase_ms": {n: float(v) for n, v in zip(names, ph)},
             "warm_value": None if args.no_warm else world * B * args.steps / warm_elapsed,

@@ -103,10 +103,10 @@ typedef struct pg_config {
                                      * step's active set and multipliers on the new QP data -- the counterpart of the reference's OSQP warm start
                                      * (src/coupled_lat_long.jl:218).  A verified round is the exact optimum of the new QP (iters = 0 then); otherwise the interior point runs
                                      * as for a cold instance.  Ignored when polish = 0 */
-    int32_t cold_guess;             /* rounds (default 4; 0 = off) a COLD instance may spend on the polish started from the EMPTY active set before the interior point is
+    int32_t cold_guess;             /* rounds (default 8; 0 = off) a COLD instance may spend on the polish started from the EMPTY active set before the interior point is
                                      * called: round 1 is the unconstrained LQ optimum, violated rows join the set, rows with negative multipliers leave it.  A verified round
                                      * is the exact optimum (iters = 0 then), as for the warm start; most instances of a tracking problem have a handful of active rows and
-                                     * verify within 1-4 rounds, each the price of one interior-point iteration.  Instances whose rounds do not verify (or cycle) run the
+                                     * verify within 1-4 rounds (a rate-limited steering ramp: up to ~10), each the price of one interior-point iteration.  Instances whose rounds do not verify (or cycle) run the
                                      * interior point exactly as with cold_guess = 0.  Ignored when polish = 0 */
 } pg_config;
 
@@ -199,8 +199,9 @@ int pg_get_state(pg_handle* h, double* state, double* control, double* t0);
 int pg_set_stream(pg_handle* h, void* hip_stream);
 /* Fused step: pg_step / pg_step_dev / pg_simulate_dev can run update_QP! and solve! of the coupled formulation (N <= 32) in ONE kernel -- the wavefront that
  * solves an instance linearises it first (same device functions: results are bit-identical either way; the QP data are still written and pg_get_qp reads them).
- * mode 0 = never, 1 = always, 2 (default; PG_FUSE=0/1/2 at pg_create overrides) = for batches of >= 1024 instances in which every instance is warm (closed loop),
- * where it is 5-8 % faster on MI355X; on cold batches it is neutral to slightly negative.  The four compute calls invoked one by one are never fused. */
+ * mode 0 = never (default; PG_FUSE=0/1/2 at pg_create overrides), 1 = always, 2 = for batches of >= 1024 instances in which every instance is warm (closed loop).
+ * Measured on MI355X: +7 % on the cold benchmark batch (skidpadoval), -5..-8 % on the other paths and in closed loop -- it pays only where a few
+ * slow instances dominate the solve kernel.  The four compute calls invoked one by one are never fused. */
 int pg_set_fusion(pg_handle* h, int32_t mode);
 int pg_synchronize(pg_handle* h);
 

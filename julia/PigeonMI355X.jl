@@ -204,7 +204,7 @@ function polish_info(mpc::BatchedTrajectoryTrackingMPC)
     p
 end
 
-"update_QP! inside the solve kernel for step! / simulate! (pg_set_fusion; bit-identical results): mode 0 never, 1 always, 2 (default) for all-warm batches"
+"update_QP! inside the solve kernel for step! / simulate! (pg_set_fusion; bit-identical results): mode 0 never (default), 1 always, 2 for all-warm batches"
 function set_fusion!(mpc::BatchedTrajectoryTrackingMPC, mode::Integer)
     check(mpc, ccall(sym(mpc, :pg_set_fusion), Cint, (Ptr{Cvoid}, Int32), mpc.handle, Int32(mode)), "pg_set_fusion")
 end

@@ -18,7 +18,7 @@ struct pg_handle {
     int B = 0;                       // current batch
     int warm_B = 0;                  // instances [0, warm_B) are known to carry a previous solution (solved = true): set by pg_solve, cleared by pg_reset
     hipStream_t stream = nullptr;
-    bool fuse = false;                                        // pg_step_dev / pg_simulate_dev: linearisation fused into the solve kernel (pg_set_fusion; off by default)
+    int fuse = 0;                                             // pg_step_dev / pg_simulate_dev: linearisation fused into the solve kernel (pg_set_fusion): 0 never (default), 1 always, 2 for all-warm batches
     std::string err;
     // device buffers
     real *d_traj = nullptr; int traj_L = 0; int *d_traj_len = nullptr, *d_traj_idx = nullptr; int traj_idx_B = 0;
@@ -115,7 +115,7 @@ int pg_default_config(pg_config* c) {
     c->N_short = 10; c->N_long = 20; c->dt_short = 0.01; c->dt_long = 0.2; c->use_correction_step = 1;   // coupled_lat_long.jl:42-43
     c->rk4_substeps = 10; c->hji_eps = 0.05; c->batch_capacity = 4096; c->device = 0;
     c->ipm_max_iter = 40; c->ipm_mu0 = 100.0; c->formulation = PG_COUPLED; c->walls = 0; c->wall_weight = 1000.0;
-    c->polish = 1; c->warm_polish = 1; c->cold_guess = 4;
+    c->polish = 1; c->warm_polish = 1; c->cold_guess = 8;
 #ifdef PG_F32
     c->ipm_tol = 1e-5; c->polish_rho = 1e3; c->polish_tol = 1e-4; c->polish_ipm_tol = 1e-4;
 #else
@@ -189,7 +189,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_sep, cap * 4, real); ALLOC(h->d_nodes, cap * NN * 10, real); ALLOC(h->d_qp, cap * C.qp_len, real);
     ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
     ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_u, cap * 3, real); ALLOC(h->d_mu, cap, real);
-    ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_polish, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, cap + 2, int); ALLOC(h->d_active, cap * N, uint16_t);
+    ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_polish, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_active, cap * N, uint16_t);
 #ifdef PG_EXPERIMENTAL_SOLVE4
     { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (experimental/pg_solve4.hip)
     if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), real);
@@ -214,7 +214,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     }
     for (int i = 0; i < 4; i++) if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_create_error = "hipEventCreate failed"; free_all(h); delete h; return PG_ERR_HIP; }
     h->ev_ok = true;
-    { const char* e = getenv("PG_FUSE"); h->fuse = e && e[0] == '1'; }
+    { const char* e = getenv("PG_FUSE"); if (e && e[0] >= '0' && e[0] <= '2') h->fuse = e[0] - '0'; }
     // horizons up to 32 intervals keep their dynamics blocks resident in LDS (one pass over the QP data); longer ones stream them through a 4-slot ring
     h->solve_ring = N > 32;
 #ifdef PG_EXPERIMENTAL_SOLVE4
@@ -259,7 +259,7 @@ int pg_abi_layout(int32_t* out, int32_t n) {
 }
 int pg_qp_len(const pg_handle* h) { return h ? h->dc.qp_len : PG_ERR_INVALID; }
 int pg_set_stream(pg_handle* h, void* s) { if (!h) return PG_ERR_INVALID; h->stream = (hipStream_t)s; return PG_OK; }
-int pg_set_fusion(pg_handle* h, int32_t on) { if (!h) return PG_ERR_INVALID; h->fuse = on != 0; return PG_OK; }
+int pg_set_fusion(pg_handle* h, int32_t mode) { if (!h || mode < 0 || mode > 2) return PG_ERR_INVALID; h->fuse = mode; return PG_OK; }
 int pg_synchronize(pg_handle* h) { if (!h) return PG_ERR_INVALID; HIPCHK(h, hipStreamSynchronize(h->stream)); return PG_OK; }
 
 // install a library: channels[n_traj][10][Lmax] (t, s, V, A, E, N, psi, kappa, edge_L, edge_R), L[k] valid nodes of trajectory k
@@ -462,7 +462,7 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
     const dim3 grid((B + 63) / 64), block(64);
     const size_t cap = (size_t)h->cfg.batch_capacity;
     const bool file = h->dc.formulation != PG_DECOUPLED && h->dc.polish;
-    OrderOut F{h->d_status, h->d_iters, h->d_polish, file ? h->d_order : nullptr, h->d_order + cap};
+    OrderOut F{h->d_status, h->d_iters, h->d_polish, file ? h->d_order : nullptr, h->d_order + cap, h->d_order + cap + 2};
     if (file) HIPCHK(h, hipMemsetAsync(h->d_order + cap, 0, 2 * sizeof(int), h->stream));
     h->order_B = file ? B : 0;
     if (h->dc.formulation == PG_DECOUPLED) {
@@ -500,6 +500,13 @@ static int launch_hji_rows(pg_handle* h) {
     int rc = launch_hji_lookup(h, B, h->d_x7, h->d_vg8); if (rc) return rc;
     hipLaunchKernelGGL(k_hji_constraint, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, h->d_x7, h->d_vg8, h->d_control, h->d_Mb);
     LAUNCH_CHECK(h);
+    if (h->dc.polish && h->order_B == B) {              // launch order again, now that the safety rows are known (k_order_hji)
+        const size_t cap = (size_t)h->cfg.batch_capacity;
+        OrderOut F{h->d_status, h->d_iters, h->d_polish, h->d_order, h->d_order + cap, h->d_order + cap + 2};
+        HIPCHK(h, hipMemsetAsync(h->d_order + cap, 0, 2 * sizeof(int), h->stream));
+        hipLaunchKernelGGL(k_order_hji, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_control, h->d_Mb, F);
+        LAUNCH_CHECK(h);
+    }
     return PG_OK;
 }
 static int launch_linearize(pg_handle* h, int n) {
@@ -545,11 +552,14 @@ int pg_solve(pg_handle* h) {
 // idle for the last third of its run; fused, the SIMDs that are done with their quick instances linearise and solve the next ones meanwhile.  Same device
 // functions, same per-instance arithmetic: results are bit-identical to the two-kernel sequence.  MEASURED (B = 4096, MI355X): 1.23 vs 1.30 ms per cold step on
 // skidpadoval, but 1.52 vs 1.40 on vail and 1.13 vs 1.05 on EastPaddock -- the linearisation runs ~15 % slower inside the big kernel (the waves of a CU are then
-// spread over 85 KB of code instead of sharing one loop in the 64 KB instruction cache), and where no straggler tail exists there is nothing to win.  Hence OFF by
-// default (pg_set_fusion / PG_FUSE=1 turn it on).
+// spread over 85 KB of code instead of sharing one loop in the 64 KB instruction cache), and where no straggler tail exists there is nothing to win.  Closed
+// loops were 5-8 % faster fused as long as a few instances per step fell back to the interior point; with those stragglers gone (the polish rules of k_solve)
+// the two-kernel sequence wins there too (0.91 vs 0.99, 1.06 vs 1.11, 0.87 vs 0.98 ms per closed-loop step).  Hence OFF by default (pg_set_fusion / PG_FUSE:
+// 0 never, 1 always, 2 for all-warm batches of >= 1024 instances).
 static int update_and_solve(pg_handle* h, hipEvent_t after_update) {
     int rc;
-    const bool fused = h->fuse && h->dc.formulation != PG_DECOUPLED && !h->solve_ring && 2 * h->dc.N <= 64 && !h->solve_quad;
+    const bool want = h->fuse == 1 || (h->fuse == 2 && h->warm_B >= h->B && h->B >= 1024);
+    const bool fused = want && h->dc.formulation != PG_DECOUPLED && !h->solve_ring && 2 * h->dc.N <= 64 && !h->solve_quad;
     if (!fused) {
         if ((rc = pg_update_qp(h))) return rc;
         if (after_update) HIPCHK(h, hipEventRecord(after_update, h->stream));

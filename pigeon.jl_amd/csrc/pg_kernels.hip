@@ -160,9 +160,21 @@ struct NodeRec { real q0, q1, q2, q3, q4, q5, u0, u1, pV, pK; };
 //  * cold instance: slow if (i) the steering has far to go at the rate limit -- |delta(node 1) - delta(now)| / deltadot_max > 1.5 x the short horizon: a rate-limited
 //    ramp, one or two rows join the working set per round -- or (ii) it starts outside or at the edge of the stability envelope (margin of (Uy, r) below 0.05:
 //    soft rows active from the first stage on).  These two groups hold nearly all instances the active-set guess does not serve on the reference's paths.
-struct OrderOut { const int* prev_status; const int* prev_iters; const int* prev_polish; int* order; int* cnt; };
+struct OrderOut { const int* prev_status; const int* prev_iters; const int* prev_polish; int* order; int* cnt; int* slow; };      // slow: the verdict per instance, [B]
 PG_DEV void file_order(const OrderOut& F, int B, int b, bool slow) {
     if (!F.order) return;
+    const int pos = slow ? atomicAdd(F.cnt, 1) : B - 1 - atomicAdd(F.cnt + 1, 1);
+    F.order[pos] = b;
+    F.slow[b] = slow ? 1 : 0;
+}
+// with the safety row installed the order is filed AGAIN once (M, b) are known: an instance whose row is violated at the current control goes through the interior
+// point (k_solve skips the empty-set rounds there), i.e. it is slow whatever the nodes kernel thought of it
+__global__ __launch_bounds__(256) void k_order_hji(DevCfg C, int B, const real* __restrict__ control, const real* __restrict__ Mb, OrderOut F) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const real* u = control + (size_t)b * 3; const real* m = Mb + (size_t)b * 4;
+    const bool hot = m[0] * (u[0] / C.un0) + m[1] * ((u[1] + u[2]) / C.un1) + m[2] < real(0.0);
+    const bool slow = F.slow[b] != 0 || hot;
     const int pos = slow ? atomicAdd(F.cnt, 1) : B - 1 - atomicAdd(F.cnt + 1, 1);
     F.order[pos] = b;
 }
@@ -946,6 +958,10 @@ struct SolveOut { real* sol_x; real* sol_sigma; real* u_out; int* status; int* i
 
 #define NROW 16
 #define PG_POLISH_ROUNDS 6      // active-set rounds of the polish before it gives up
+#ifndef PG_PROGRESS_ROWS
+#define PG_PROGRESS_ROWS 4
+#endif
+#define PG_CHAOS_ROWS 20
 
 struct StageRows {
     real t[NROW], lam[NROW], corr[NROW];
@@ -1495,7 +1511,10 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     // guess was, so nothing is lost in accuracy; if the rounds do not verify, the interior point runs as for a cold instance.
     real* const Lst = O.lam + ((size_t)b * N + s) * NROW;
     const bool warm = C.polish && C.warm_polish && O.solved[b] != 0 && O.status[b] == PG_SOLVED;
-    const bool guess = C.polish && C.cold_guess > 0;       // attempt -1: the polish from the EMPTY set (cold instances, and warm ones whose previous set did not verify)
+    // attempt -1: the polish from the EMPTY set (cold instances, and warm ones whose previous set did not verify).  Not where the safety row is violated at the
+    // current control: its weight (W_HJI) then overrides the tracking cost, the optimum is close to bang-bang (rate rows of both signs, force bounds, soft rows all
+    // change together) and the add / drop iteration turns over dozens of rows per round -- the interior point needs its usual 8 iterations there
+    const bool guess = C.polish && C.cold_guess > 0 && !(C.has_hji && M0 * sx0[6] + M1 * sx0[7] + Q[o.b] < real(0.0));
     int last_nchg = 0; real last_tmax = real(0.0);
     bool warm_attempt = false, from_prev = false;          // warm_attempt: a polish without an interior point in front (attempts -2, -1); from_prev: attempt -2
     for (int attempt = warm ? -2 : (guess ? -1 : 0); attempt < 2; attempt++) {
@@ -1567,7 +1586,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     const int round_cap = attempt == -1 ? C.cold_guess : PG_POLISH_ROUNDS;
     // a set that moves by a row or two per round on a nearly feasible point is a ramp being extended or released one stage at a time (the multiplier of the next row
     // only changes sign once the previous one has left): it gets there, and eight more 25 us rounds are far cheaper than the interior point they avoid
-    auto over_cap = [&](int pass) { return pass > round_cap + ((last_nchg <= 2 && last_tmax < real(1e-6)) ? 8 : 0); };      // (also for the warm attempt: a fall-back to the cold start costs ten rounds, and the slowest instance sets the kernel time)
+    auto over_cap = [&](int pass) { return pass > round_cap + ((last_nchg <= PG_PROGRESS_ROWS && last_tmax < real(1.0)) ? 8 : 0); };      // (also for the warm attempt: a fall-back to the cold start costs ten rounds, and the slowest instance sets the kernel time)
     // Active-set polish (OSQP-style, on the stage-structured problem).  The interior point approaches nearly degenerate rows (slack and multiplier both ~ sqrt(mu))
     // like sqrt(mu), so its iterate can sit 1e-6 away from the optimum at any tolerance fp64 rounding allows.  Once it has converged, the rows with
     // lambda > t are held as EQUALITIES (augmented Lagrangian with penalty rho, multiplier estimates y = lambda), every other row is dropped, and the
@@ -1629,9 +1648,10 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             return 0;
         }
         if (!changed) return 1;
-        // a working set whose rows cannot be met together (|t| of order one on rows held as equalities) is not worth iterating on when there is no interior-point
-        // iterate to protect: a polish without an interior point in front moves on to its fall-back at once
-        if (warm_attempt && !(last_tmax < real(0.3))) return 3;
+        // a working set whose rows cannot be met together (|t| of order one on rows held as equalities), or one that turns over dozens of rows after the first round
+        // (healthy iterations add ~12 rows in round 1 and a handful later; 25+ is an iteration that has lost the plot), is not worth iterating on when there is no
+        // interior-point iterate to protect: a polish without an interior point in front moves on to its fall-back at once
+        if (warm_attempt && (!(last_tmax < real(1.0)) || (pmode >= 2 && last_nchg > PG_CHAOS_ROWS))) return 3;
         // a violated SOFT row joins the set with its slack FREE (the sigma >= 0 row of its group leaves): held together with sigma = 0 it would be a hard equality,
         // inconsistent wherever the state cannot move (the envelope rows of the first stages, whose states the current control already fixes); if the slack
         // comes out negative, its sigma >= 0 row is violated and comes back next round

@@ -237,7 +237,7 @@ class BatchedTrajectoryTrackingMPC:
         self._chk(self.lib.pg_set_stream(self.h, C.c_void_p(hip_stream)), "pg_set_stream")
 
     def set_fusion(self, mode):
-        """Fused step (update_QP! inside the solve kernel, include/pigeon_mpc.h pg_set_fusion): False / 0 never, True / 1 always, 2 (the default) for all-warm batches."""
+        """Fused step (update_QP! inside the solve kernel, include/pigeon_mpc.h pg_set_fusion): False / 0 never (the default), True / 1 always, 2 for all-warm batches."""
         self._chk(self.lib.pg_set_fusion(self.h, int(mode)), "pg_set_fusion")
 
     def phase_ms(self):

@@ -10,12 +10,16 @@ traj = pkg.load_path_fixture(path)
 B = 4096
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345)
 ref = None
+prec = os.environ.get("PG_PREC", "f64"); with_hji = bool(int(os.environ.get("PG_HJI", "0")))      # PG_PREC=f32 PG_HJI=1: BASELINE config 3
+other = pkg.synthetic.other_cars(state, seed=777) if with_hji else None
 for cg in [int(x) for x in os.environ.get("PG_CG", "0,1,2,3,4,6").split(",")]:
-    mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, cold_guess=cg)
+    mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, cold_guess=cg, precision=prec)
+    if with_hji:
+        mpc.set_hji_cache(*pkg.synthetic.hji_grid_large())
     ts = []
     for rep in range(6):
         mpc.reset()
-        mpc.set_inputs(state, control, t0, time_offset=toff)
+        mpc.set_inputs(state, control, t0, other_car_state=other, time_offset=toff)
         mpc.step_dev(); mpc.synchronize()
         ts.append(mpc.phase_ms()[2])
     u = mpc.get_next_control()

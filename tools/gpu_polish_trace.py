@@ -9,8 +9,11 @@ path = os.environ.get("PG_PATH", "EastPaddock"); step = int(os.environ.get("PG_S
 traj = pkg.load_path_fixture(path)
 B = 4096
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345)
-mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B)
-mpc.set_inputs(state, control, t0, time_offset=toff)
+mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, precision=os.environ.get("PG_PREC", "f64"))
+other = None
+if int(os.environ.get("PG_HJI", "0")):                     # PG_HJI=1 (+ PG_PREC=f32): BASELINE config 3
+    mpc.set_hji_cache(*pkg.synthetic.hji_grid_large()); other = pkg.synthetic.other_cars(state, seed=777)
+mpc.set_inputs(state, control, t0, other_car_state=other, time_offset=toff)
 if step > 1:
     mpc.simulate_(step - 1); mpc.synchronize()
 st0, it0, act0, _ = mpc.solve_info(); ps0 = mpc.polish_info()
@@ -18,7 +21,7 @@ print(f"before step {step}: instance {inst} status {st0[inst]} iters {it0[inst]}
 mpc.compute_time_steps_(); mpc.compute_linearization_nodes_(); mpc.update_QP_()
 out = np.zeros(B * 6 + 1024, dtype=np.uint64)
 rc = mpc.lib.pg_debug_solve_cycles(mpc.h, out.ctypes.data_as(C.c_void_p)); assert rc == 0
-tr = out[B * 6:].view(np.float64).reshape(256, 4)
+tr = out[B * 6:].view(np.float64 if mpc.precision == 'f64' else np.float32).reshape(-1, 4)[:256]
 st, it, act, mu = mpc.solve_info(); ps = mpc.polish_info()
 print(f"step {step}: instance {inst} status {st[inst]} iters {it[inst]} polish {ps[inst]} active rows {sum(bin(int(m)).count('1') for m in act[inst])}; batch: iters>0 {(it > 0).sum()} max {it.max()}")
 w = np.argsort(-it)[:8]; print("slowest instances of the batch (index, iters, polish):", [(int(b), int(it[b]), int(ps[b])) for b in w])
