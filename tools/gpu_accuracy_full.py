@@ -9,7 +9,7 @@ from conftest import load_pkg, make_oracle
 from oracle import oracle as om
 pkg = load_pkg(); sk = pkg.load_path_fixture(os.environ.get("PG_PATH", "skidpadoval"))
 B = int(os.environ.get("PG_B", "4096"))
-state, control, t0, toff = pkg.synthetic.config2_inputs(sk, B, seed=12345)
+s_end = float(sk.s[-1]); state, control, t0, toff = pkg.synthetic.config2_inputs(sk, B, seed=int(os.environ.get("PG_SEED", "12345")), **(dict(s_range=(2.0, 0.4 * s_end)) if s_end <= 90 else {}))
 cases = [(float(a), int(b)) for a, b in (c.split(":") for c in os.environ.get("PG_CASES", "1e-12:0,1e-12:1,1e-10:1,1e-8:1,1e-6:1").split(","))]
 ref = None
 nthr = len(os.sched_getaffinity(0))
