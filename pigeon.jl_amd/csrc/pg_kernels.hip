@@ -961,7 +961,7 @@ struct SolveOut { real* sol_x; real* sol_sigma; real* u_out; int* status; int* i
 #ifndef PG_PROGRESS_ROWS
 #define PG_PROGRESS_ROWS 4
 #endif
-#define PG_CHAOS_ROWS 20
+
 
 struct StageRows {
     real t[NROW], lam[NROW], corr[NROW];
@@ -1651,7 +1651,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         // a working set whose rows cannot be met together (|t| of order one on rows held as equalities), or one that turns over dozens of rows after the first round
         // (healthy iterations add ~12 rows in round 1 and a handful later; 25+ is an iteration that has lost the plot), is not worth iterating on when there is no
         // interior-point iterate to protect: a polish without an interior point in front moves on to its fall-back at once
-        if (warm_attempt && (!(last_tmax < real(1.0)) || (pmode >= 2 && last_nchg > PG_CHAOS_ROWS))) return 3;
+        if (warm_attempt && (!(last_tmax < real(1.0)) || (pmode >= 2 && last_nchg > (2 * N) / 3))) return 3;
         // a violated SOFT row joins the set with its slack FREE (the sigma >= 0 row of its group leaves): held together with sigma = 0 it would be a hard equality,
         // inconsistent wherever the state cannot move (the envelope rows of the first stages, whose states the current control already fixes); if the slack
         // comes out negative, its sigma >= 0 row is violated and comes back next round

@@ -9,7 +9,10 @@ path = os.environ.get("PG_PATH", "EastPaddock"); step = int(os.environ.get("PG_S
 traj = pkg.load_path_fixture(path)
 B = 4096
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345)
-mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, precision=os.environ.get("PG_PREC", "f64"))
+if int(os.environ.get("PG_DEC", "0")):                     # PG_DEC=1: the decoupled N = 50 formulation (BASELINE config 5) with the polish and the empty-set rounds switched on
+    mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, walls=bool(int(os.environ.get("PG_WALLS", "0"))), polish=True, cold_guess=8)
+else:
+    mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, precision=os.environ.get("PG_PREC", "f64"))
 other = None
 if int(os.environ.get("PG_HJI", "0")):                     # PG_HJI=1 (+ PG_PREC=f32): BASELINE config 3
     mpc.set_hji_cache(*pkg.synthetic.hji_grid_large()); other = pkg.synthetic.other_cars(state, seed=777)
