@@ -510,8 +510,18 @@ static int launch_hji_rows(pg_handle* h) {
     return PG_OK;
 }
 static int launch_linearize(pg_handle* h, int n) {
-    long nl = (long)n * h->dc.N * 2;         // two lanes per (instance, interval)
-    hipLaunchKernelGGL(k_linearize, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, h->stream, h->dc, n, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp);
+    // two lanes per (instance, interval) with four tangent directions each; small batches -- a handful of wavefronts whose duration is the latency of one lane --
+    // spread the eight directions over four or eight lanes instead (same arithmetic per direction)
+#ifdef PG_F32
+    const int G = 2;         // (fp32: the compiler contracts the tangent arithmetic differently in the K = 1, 2 instantiations -- results would depend on the batch size)
+#else
+    const int G = n <= 256 ? 8 : (n <= 512 ? 4 : 2);        // bit-identical across K in fp64 (tests/test_gpu_multiprocess.py steps 1024 = 2 x 512 and 1001 = 501 + 500)
+#endif
+    const long nl = (long)n * h->dc.N * G;
+    const dim3 grid((unsigned)((nl + 63) / 64)), block(64);
+    if (G == 8) hipLaunchKernelGGL(k_linearize<1>, grid, block, 0, h->stream, h->dc, n, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp);
+    else if (G == 4) hipLaunchKernelGGL(k_linearize<2>, grid, block, 0, h->stream, h->dc, n, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp);
+    else hipLaunchKernelGGL(k_linearize<4>, grid, block, 0, h->stream, h->dc, n, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp);
     LAUNCH_CHECK(h);
     return PG_OK;
 }

@@ -339,34 +339,44 @@ template <bool STAGED> __global__ __launch_bounds__(256) void k_nodes_warm(DevCf
 // five primal trajectories per interval; now two).  c = Phi - A q - B0 u0 - Bf uf is finished in the same lanes (one shuffle inside the lane pair), lane 1
 // also evaluates stable_limits for the interval.
 // (the lane pair (g = 0, 1) of an interval must be two adjacent lanes of one wavefront; a lane that is not `live` computes along with its partner and stores nothing)
-PG_DEV void linearize_pair(const DevCfg& C, int b, int t, int g, bool live, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb,
-                           real* __restrict__ qp) {
-    typedef DK<4> D4;
+// K tangent directions per lane, G = 8 / K adjacent lanes per interval (K = 4: the lane PAIR of the description above; K = 2, 1: four / eight lanes per interval for
+// small batches, where the kernel is a handful of wavefronts and its duration is the latency of ONE lane -- fewer directions per lane, shorter chain).  Direction
+// j = g K + d: j < 4 the state components (Ux, Uy, r, dpsi), j = 4, 5: u0, j = 6, 7: uf.  Every direction is propagated by the same arithmetic whatever K is, so the
+// Jacobians are bit-identical across K; c differs by the order of its cross-lane sum (1e-16).
+template <int K>
+PG_DEV void linearize_lanes(const DevCfg& C, int b, int t, int g, bool live, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb,
+                            real* __restrict__ qp) {
+    typedef DK<K> DT;
+    constexpr int G = 8 / K;
     const bool ramp = t >= C.Ns;
     const real* n0 = nodes + ((size_t)b * C.NN + t) * 10; const real* n1 = n0 + 10;
     const real h_total = dt[(size_t)b * C.N + t];
-    D4 x[6];
+    DT x[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
-        x[k] = D4(n0[k]);
+        x[k] = DT(n0[k]);
 #pragma unroll
-        for (int d = 0; d < 4; d++) x[k].d[d] = (g == 0 && k == d + 1) ? real(1.0) : real(0.0);
+        for (int d = 0; d < K; d++) x[k].d[d] = (g * K + d < 4 && g * K + d + 1 == k) ? real(1.0) : real(0.0);          // (directions 0..3 seed components 1..4)
     }
-    D4 u0a(n0[6]), u0b(n0[7]), ufa(ramp ? n1[6] : n0[6]), ufb(ramp ? n1[7] : n0[7]);
-    if (g == 1) { u0a.d[0] = real(1.0); u0b.d[1] = real(1.0); ufa.d[2] = real(1.0); ufb.d[3] = real(1.0); }
+    DT u0a(n0[6]), u0b(n0[7]), ufa(ramp ? n1[6] : n0[6]), ufb(ramp ? n1[7] : n0[7]);
+#pragma unroll
+    for (int d = 0; d < K; d++) {
+        const int j = g * K + d;
+        u0a.d[d] = j == 4 ? real(1.0) : real(0.0); u0b.d[d] = j == 5 ? real(1.0) : real(0.0); ufa.d[d] = j == 6 ? real(1.0) : real(0.0); ufb.d[d] = j == 7 ? real(1.0) : real(0.0);
+    }
     const real pV0 = n0[8], pK0 = n0[9], pV1 = ramp ? n1[8] : n0[8], pK1 = ramp ? n1[9] : n0[9];
     const int nsub = C.nsub; const real h = h_total / nsub;
-    auto rhs = [&](const D4* xx, real tau, D4* out) {
+    auto rhs = [&](const DT* xx, real tau, DT* out) {
         real w = ramp ? tau / h_total : real(0.0);
-        D4 ua = u0a + (ufa - u0a) * w, ub = u0b + (ufb - u0b) * w;
-        tracking_rhs<D4>(C.veh, xx, ua, ub, pV0 + (pV1 - pV0) * w, pK0 + (pK1 - pK0) * w, out);
+        DT ua = u0a + (ufa - u0a) * w, ub = u0b + (ufb - u0b) * w;
+        tracking_rhs<DT>(C.veh, xx, ua, ub, pV0 + (pV1 - pV0) * w, pK0 + (pK1 - pK0) * w, out);
     };
 #pragma unroll 1
     for (int i = 0; i < nsub; i++) {
         const real t0 = i * h;
-        D4 kk[6], xx[6], acc[6];
+        DT kk[6], xx[6], acc[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) { xx[k] = x[k]; acc[k] = D4(real(0.0)); }
+        for (int k = 0; k < 6; k++) { xx[k] = x[k]; acc[k] = DT(real(0.0)); }
         // classical RK4 written as one rolled stage loop (one instance of the dynamics in the instruction stream, fewer live registers)
 #pragma unroll 1
         for (int st = 0; st < 4; st++) {
@@ -381,34 +391,50 @@ PG_DEV void linearize_pair(const DevCfg& C, int b, int t, int g, bool live, cons
         for (int k = 0; k < 6; k++) x[k] = x[k] + acc[k] * (h / real(6.0));
     }
     // this lane's share of c_i = Phi_i - A_i. q - B0_i. u0 - Bf_i. uf   (raw, un-normalised Jacobians: coupled_lat_long.jl:336-353)
+    // The eight products d_j coef_j are rounded one by one, brought to the group's first lane and summed THERE in one fixed order, so that c -- like the Jacobians --
+    // does not depend on K: a batch gives the same bits whether it is stepped whole or in shards of another size (tests/test_gpu_multiprocess.py)
     real part[6];
-    if (g == 0) {
+    {
+#pragma clang fp contract(off)
+        real coef[K];
+#pragma unroll
+        for (int d = 0; d < K; d++) {
+            const int j = g * K + d;
+            coef[d] = j < 4 ? n0[j + 1] : (j == 4 ? n0[6] : (j == 5 ? n0[7] : (ramp ? (j == 6 ? n1[6] : n1[7]) : real(0.0))));
+        }
+        const int base = (int)(threadIdx.x & 63u) - g;
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            real ci = x[i].v - (x[i].d[0] * n0[1] + x[i].d[1] * n0[2] + x[i].d[2] * n0[3] + x[i].d[3] * n0[4]);
+            real q8[8];
+#pragma unroll
+            for (int jg = 0; jg < G; jg++) {
+#pragma unroll
+                for (int d = 0; d < K; d++) { const real pr = x[i].d[d] * coef[d]; q8[jg * K + d] = __shfl(pr, base + jg); }
+            }
+            real ci = x[i].v - (((q8[0] + q8[1]) + q8[2]) + q8[3]);
             if (i == 0) ci -= n0[0];
             if (i == 5) ci -= n0[5];
-            part[i] = ci;
+            part[i] = ci - (((q8[4] + q8[5]) + q8[6]) + q8[7]);
         }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 6; i++) part[i] = -(x[i].d[0] * n0[6] + x[i].d[1] * n0[7]) - (ramp ? x[i].d[2] * n1[6] + x[i].d[3] * n1[7] : real(0.0));
     }
-#pragma unroll
-    for (int i = 0; i < 6; i++) part[i] += __shfl_xor(part[i], 1);
     if (!live) return;
     const QpOff o = qp_offsets(C.N);
     real* Q = qp + (size_t)b * C.qp_len;
-    if (g == 0) {
-        real* A = Q + o.A + 36 * t;
+    real* A = Q + o.A + 36 * t; real* B0 = Q + o.B0 + 12 * t; real* Bf = Q + o.Bf + 12 * t;
+#pragma unroll
+    for (int d = 0; d < K; d++) {
+        const int j = g * K + d;
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            A[6 * i] = i == 0 ? real(1.0) : real(0.0);
-#pragma unroll
-            for (int d = 0; d < 4; d++) A[6 * i + 1 + d] = x[i].d[d];
-            A[6 * i + 5] = i == 5 ? real(1.0) : real(0.0);
-            Q[o.c + 6 * t + i] = part[i];
+            const real v = x[i].d[d];
+            if (j < 4) A[6 * i + 1 + j] = v;
+            else if (j < 6) B0[2 * i + (j - 4)] = v * (j == 4 ? C.un0 : C.un1);                          // :338,350-351 (B scaled by u_normalization)
+            else Bf[2 * i + (j - 6)] = ramp ? v * (j == 6 ? C.un0 : C.un1) : real(0.0);
         }
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) { A[6 * i] = i == 0 ? real(1.0) : real(0.0); A[6 * i + 5] = i == 5 ? real(1.0) : real(0.0); Q[o.c + 6 * t + i] = part[i]; }
         if (t == 0) {
 #pragma unroll
             for (int k = 0; k < 6; k++) Q[o.qcurr + k] = n0[k];
@@ -416,13 +442,8 @@ PG_DEV void linearize_pair(const DevCfg& C, int b, int t, int g, bool live, cons
             if (C.has_hji) { Q[o.M] = hji_Mb[(size_t)b * 4]; Q[o.M + 1] = hji_Mb[(size_t)b * 4 + 1]; Q[o.b] = hji_Mb[(size_t)b * 4 + 2]; }
             else { Q[o.M] = real(0.0); Q[o.M + 1] = real(0.0); Q[o.b] = real(1.0); }
         }
-    } else {
-        real* B0 = Q + o.B0 + 12 * t; real* Bf = Q + o.Bf + 12 * t;
-#pragma unroll
-        for (int i = 0; i < 6; i++) {                                                                   // :338,350-351 (B scaled by u_normalization)
-            B0[2 * i] = x[i].d[0] * C.un0; B0[2 * i + 1] = x[i].d[1] * C.un1;
-            Bf[2 * i] = ramp ? x[i].d[2] * C.un0 : real(0.0); Bf[2 * i + 1] = ramp ? x[i].d[3] * C.un1 : real(0.0);
-        }
+    }
+    if (g == G - 1) {
         const real Uxt = n1[1], Fx = n1[7];                                                             // :357-358
         const real Fxf = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac, Fxr = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
         const Envelope e = stable_limits(C.veh, Uxt, Fxf, Fxr);
@@ -436,13 +457,19 @@ PG_DEV void linearize_pair(const DevCfg& C, int b, int t, int g, bool live, cons
         Q[o.dt + t] = h_total;
     }
 }
+PG_DEV void linearize_pair(const DevCfg& C, int b, int t, int g, bool live, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb,
+                           real* __restrict__ qp) {
+    linearize_lanes<4>(C, b, t, g, live, nodes, dt, hji_Mb, qp);
+}
+template <int K>
 __global__ __launch_bounds__(64) void k_linearize(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb, real* __restrict__ qp) {
+    constexpr int G = 8 / K;
     long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long per = (long)C.N * 2;
+    const long per = (long)C.N * G;
     const bool live = gid < (long)B * per;
-    if (!live) gid = (long)B * per - 1;                       // keep the lane pair whole for the shuffle; dead lanes store nothing
+    if (!live) gid = (long)B * per - G + (gid & (G - 1));        // keep the lane group whole for the shuffles; dead lanes store nothing
     const int b = (int)(gid / per); const int rem = (int)(gid - (long)b * per);
-    linearize_pair(C, b, rem >> 1, rem & 1, live, nodes, dt, hji_Mb, qp);
+    linearize_lanes<K>(C, b, rem / G, rem % G, live, nodes, dt, hji_Mb, qp);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
