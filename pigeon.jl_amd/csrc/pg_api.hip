@@ -515,8 +515,15 @@ static int launch_linearize(pg_handle* h, int n) {
 #ifdef PG_F32
     const int G = 2;         // (fp32: the compiler contracts the tangent arithmetic differently in the K = 1, 2 instantiations -- results would depend on the batch size)
 #else
-    const int G = n <= 256 ? 8 : (n <= 512 ? 4 : 2);        // bit-identical across K in fp64 (tests/test_gpu_multiprocess.py steps 1024 = 2 x 512 and 1001 = 501 + 500)
+    const int G = n <= 256 ? 8 : (n <= 512 ? 4 : 2);        // bit-identical across K in fp64 (tests/test_gpu_multiprocess.py steps 1024 = 2 x 512, 1001 = 501 + 500, 400 = 2 x 200)
 #endif
+    if (G == 2 && h->dc.Ns > 0 && h->dc.Ns < h->dc.N) {     // large batches: short-horizon intervals with three directions per lane (k_linearize_split)
+        const long nz = (long)n * h->dc.Ns * 2, nr = (long)n * (h->dc.N - h->dc.Ns) * 2;
+        const int nbz = (int)((nz + 63) / 64), nbr = (int)((nr + 63) / 64);
+        hipLaunchKernelGGL(k_linearize_split, dim3((unsigned)(nbz + nbr)), dim3(64), 0, h->stream, h->dc, n, nbz, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp);
+        LAUNCH_CHECK(h);
+        return PG_OK;
+    }
     const long nl = (long)n * h->dc.N * G;
     const dim3 grid((unsigned)((nl + 63) / 64)), block(64);
     if (G == 8) hipLaunchKernelGGL(k_linearize<1>, grid, block, 0, h->stream, h->dc, n, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp);

@@ -122,6 +122,7 @@ template <int K> PG_DEV void sincos_(DK<K> x, DK<K>& s, DK<K>& c) { real sv, cv;
 template <int K> PG_DEV DK<K> sqrt_(DK<K> x) { real s = sqrt(x.v); return chain(x, s, real(0.5) * frcp(s)); }
 template <int K> PG_DEV DK<K> abs_(DK<K> x) { return x.v < real(0.0) ? -x : x; }
 template <> PG_DEV DK<4> cst<DK<4>>(real x) { return DK<4>(x); }
+template <> PG_DEV DK<3> cst<DK<3>>(real x) { return DK<3>(x); }
 template <> PG_DEV DK<2> cst<DK<2>>(real x) { return DK<2>(x); }
 template <> PG_DEV DK<1> cst<DK<1>>(real x) { return DK<1>(x); }
 

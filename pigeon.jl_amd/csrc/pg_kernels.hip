@@ -343,12 +343,14 @@ template <bool STAGED> __global__ __launch_bounds__(256) void k_nodes_warm(DevCf
 // small batches, where the kernel is a handful of wavefronts and its duration is the latency of ONE lane -- fewer directions per lane, shorter chain).  Direction
 // j = g K + d: j < 4 the state components (Ux, Uy, r, dpsi), j = 4, 5: u0, j = 6, 7: uf.  Every direction is propagated by the same arithmetic whatever K is, so the
 // Jacobians are bit-identical across K; c differs by the order of its cross-lane sum (1e-16).
-template <int K>
+// ND = 6: an interval of the short horizon (zero-order hold: uf is not a variable, directions 6 and 7 vanish identically) with the six remaining directions on
+// G = 6 / K lanes; the Bf block is written as zeros and c sums the same six products in the same order -- the same bits as ND = 8 gives on such an interval.
+template <int K, int ND = 8>
 PG_DEV void linearize_lanes(const DevCfg& C, int b, int t, int g, bool live, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb,
                             real* __restrict__ qp) {
     typedef DK<K> DT;
-    constexpr int G = 8 / K;
-    const bool ramp = t >= C.Ns;
+    constexpr int G = ND / K;
+    const bool ramp = ND == 8 && t >= C.Ns;
     const real* n0 = nodes + ((size_t)b * C.NN + t) * 10; const real* n1 = n0 + 10;
     const real h_total = dt[(size_t)b * C.N + t];
     DT x[6];
@@ -405,7 +407,7 @@ PG_DEV void linearize_lanes(const DevCfg& C, int b, int t, int g, bool live, con
         const int base = (int)(threadIdx.x & 63u) - g;
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            real q8[8];
+            real q8[8] = {real(0.0), real(0.0), real(0.0), real(0.0), real(0.0), real(0.0), real(0.0), real(0.0)};
 #pragma unroll
             for (int jg = 0; jg < G; jg++) {
 #pragma unroll
@@ -443,6 +445,10 @@ PG_DEV void linearize_lanes(const DevCfg& C, int b, int t, int g, bool live, con
             else { Q[o.M] = real(0.0); Q[o.M + 1] = real(0.0); Q[o.b] = real(1.0); }
         }
     }
+    if (ND == 6 && g == G - 1) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) Bf[i] = real(0.0);
+    }
     if (g == G - 1) {
         const real Uxt = n1[1], Fx = n1[7];                                                             // :357-358
         const real Fxf = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac, Fxr = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
@@ -460,6 +466,21 @@ PG_DEV void linearize_lanes(const DevCfg& C, int b, int t, int g, bool live, con
 PG_DEV void linearize_pair(const DevCfg& C, int b, int t, int g, bool live, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb,
                            real* __restrict__ qp) {
     linearize_lanes<4>(C, b, t, g, live, nodes, dt, hji_Mb, qp);
+}
+// the large-batch form: the Ns zero-order-hold intervals of every instance with three directions per lane (ND = 6), the N - Ns ramp intervals with four (ND = 8);
+// blocks [0, nb_zoh) take the first group -- a wavefront runs one of the two instruction streams, 8 instead of 10 dynamics "units" per short interval
+__global__ __launch_bounds__(64) void k_linearize_split(DevCfg C, int B, int nb_zoh, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb,
+                                                        real* __restrict__ qp) {
+    const bool zoh = (int)blockIdx.x < nb_zoh;
+    const int nint = zoh ? C.Ns : C.N - C.Ns;                      // intervals of this group per instance
+    long gid = (long)(zoh ? blockIdx.x : blockIdx.x - nb_zoh) * blockDim.x + threadIdx.x;
+    const long per = (long)nint * 2;
+    const bool live = gid < (long)B * per;
+    if (!live) gid = (long)B * per - 2 + (gid & 1);
+    const int b = (int)(gid / per); const int rem = (int)(gid - (long)b * per);
+    const int t = (zoh ? 0 : C.Ns) + (rem >> 1), g = rem & 1;
+    if (zoh) linearize_lanes<3, 6>(C, b, t, g, live, nodes, dt, hji_Mb, qp);
+    else linearize_lanes<4, 8>(C, b, t, g, live, nodes, dt, hji_Mb, qp);
 }
 template <int K>
 __global__ __launch_bounds__(64) void k_linearize(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb, real* __restrict__ qp) {
