@@ -400,8 +400,9 @@ def main():
             traffic = hit[0]["hbm_bytes_per_launch"] if hit else tr.get("hbm_bytes_per_launch"); traffic_src = (hit[0] if hit else tr).get("source")
         except Exception:
             pass
-        # k_linearize is throughput-bound on the fp64 vector unit: 40 dynamics evaluations x N intervals x (130 value + 8 tangent directions x 260) flops per instance
-        lin_fl = float(B) * 40 * mpc.N * (130 + 8 * 260)
+        # k_linearize is throughput-bound on the fp64 vector unit: 40 dynamics evaluations per interval x (130 value + 260 per tangent direction) flops -- eight
+        # directions on the ramp intervals, six on the zero-order-hold intervals of the short horizon (uf is not a variable there)
+        lin_fl = float(B) * 40 * (mpc.N_short * (130 + 6 * 260) + (mpc.N - mpc.N_short) * (130 + 8 * 260))
         peak_lin = FP64_VALU_PEAK_TF if args.precision == "f64" else 2 * FP64_VALU_PEAK_TF
         valu_lin = {"bound": "valu-" + args.precision, "kernel": "k_linearize", "algorithmic_flops_per_launch": lin_fl, "achieved": lin_fl / (float(ph[1]) * 1e-3) / 1e12, "peak": peak_lin,
                     "unit": "TFLOP/s", "frac": lin_fl / (float(ph[1]) * 1e-3) / 1e12 / peak_lin, "avg_launch_ms": float(ph[1]),
