@@ -424,7 +424,7 @@ def main():
                        "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}, all_gather of controls ({args.backend})" if world > 1 else "single GPU",
                        "solver": "active-set rounds from the empty set on the stage-structured QP (Riccati; pg_config.cold_guess = 8 + structural rules for the steering rows), verified KKT point; instances the rounds do not serve: "
                                  "Mehrotra interior point to mu <= " + ("3e-6" if args.precision == "f64" else "1e-4") + ", then active-set polish (verified KKT point)",
-                       "accuracy": "measured in this run: cpu_baseline.accuracy (sample of 256); every one of the 4096 instances <= 1e-6 is asserted by tests/test_gpu_full_size.py (measured max 1e-9)"},
+                       "accuracy": "measured in this run: cpu_baseline.accuracy (sample of 256); every one of the 4096 instances <= 1e-6 is asserted by tests/test_gpu_full_size.py (measured max 5e-11)"},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": dom_ms, "valu": valu, "valu_linearize": valu_lin,
                          "note": f"algorithmic HBM bytes are {bytes_per_solve} B/solve (SURVEY 8d): the step is VALU/LDS/latency bound by construction, not HBM bound; see roofline.valu and hji_lookup"},

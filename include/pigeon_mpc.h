@@ -93,7 +93,7 @@ typedef struct pg_config {
                                      * src/coupled_lat_long.jl:201-203) solves the equality-constrained problem on the detected active set with the same Riccati passes
                                      * and verifies primal/dual feasibility; removes the sqrt(mu) error of nearly degenerate rows.  0 = interior-point iterate as is */
     int32_t _pad3;
-    double polish_rho;              /* penalty on the active rows inside the polish solves (default 1e6 in the fp64 library, 1e3 in the fp32 one) */
+    double polish_rho;              /* penalty on the active rows inside the polish solves (default 1e7 in the fp64 library, 1e3 in the fp32 one) */
     double polish_tol;              /* feasibility tolerance of the polish verification (default 1e-9 / 1e-4) */
     double polish_ipm_tol;          /* with polish = 1 the interior point first stops at this (looser) tolerance and hands over to the polish (default 3e-6 / 1e-4);
                                      * if the polish cannot verify an active set from there (or the sets cycle), the interior point resumes down to ipm_tol and the polish

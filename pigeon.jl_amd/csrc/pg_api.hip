@@ -119,7 +119,7 @@ int pg_default_config(pg_config* c) {
 #ifdef PG_F32
     c->ipm_tol = 1e-5; c->polish_rho = 1e3; c->polish_tol = 1e-4; c->polish_ipm_tol = 1e-4;
 #else
-    c->ipm_tol = 1e-12; c->polish_rho = 1e6; c->polish_tol = 1e-9; c->polish_ipm_tol = 3e-6;
+    c->ipm_tol = 1e-12; c->polish_rho = 1e7; c->polish_tol = 1e-9; c->polish_ipm_tol = 3e-6;
 #endif
     return PG_OK;
 }

@@ -1634,7 +1634,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     const int round_cap = attempt == -1 ? C.cold_guess : PG_POLISH_ROUNDS;
     // a set that moves by a row or two per round on a nearly feasible point is a ramp being extended or released one stage at a time (the multiplier of the next row
     // only changes sign once the previous one has left): it gets there, and eight more 25 us rounds are far cheaper than the interior point they avoid
-    auto over_cap = [&](int pass) { return pass > round_cap + ((last_nchg <= PG_PROGRESS_ROWS && last_tmax < real(1.0)) ? 8 : 0); };      // (also for the warm attempt: a fall-back to the cold start costs ten rounds, and the slowest instance sets the kernel time)
+    auto over_cap = [&](int pass) { return pass > round_cap + (last_tmax < real(1.0) ? (last_nchg <= 2 ? 16 : (last_nchg <= PG_PROGRESS_ROWS ? 8 : 0)) : 0); };      // (also for the warm attempt: a fall-back to the cold start costs ten rounds, and the slowest instance sets the kernel time)
     // Active-set polish (OSQP-style, on the stage-structured problem).  The interior point approaches nearly degenerate rows (slack and multiplier both ~ sqrt(mu))
     // like sqrt(mu), so its iterate can sit 1e-6 away from the optimum at any tolerance fp64 rounding allows.  Once it has converged, the rows with
     // lambda > t are held as EQUALITIES (augmented Lagrangian with penalty rho, multiplier estimates y = lambda), every other row is dropped, and the

@@ -75,7 +75,7 @@ def test_random_subset_against_oracle(run, oracle_mod, skidpad):
 def test_accuracy_of_every_instance_of_the_batch(run, oracle_mod, skidpad, pkg):
     """BASELINE north star: controls within 1e-6 (rel-inf, normalised controls) of the reference on identical inputs, active-set indices bit-exact.
     Here for EVERY one of the 4096 config-2 instances (threaded oracle, exact optimum of the same QP data):
-      * applied control and every control of the horizon <= 1e-6 (measured: 1e-9 / 5e-8 with the active-set rounds, 5e-11 / 2e-9 through the interior point -- the active-set polish removed the sqrt(mu) tail that left
+      * applied control and every control of the horizon <= 1e-6 (measured: 5e-11 / 4e-9, through the active-set rounds as through the interior point -- the active-set polish removed the sqrt(mu) tail that left
         3 of 4096 instances at 1e-6..3e-6 in round 1);
       * whole primal solution (states) <= 1e-6 relative;
       * the signed canonical active-set list identical to the oracle's, except on rows that are degenerate in the oracle's own solution
