@@ -42,7 +42,7 @@ def test_wide_random_inputs(pkg, oracle_mod, path, seed):
         assert np.all((st == pkg.SOLVED) | (st == pkg.MAX_ITER) | (st == pkg.INFEASIBLE_X0) | num), np.bincount(st)
         assert num.sum() <= 4 and all(not np.all(np.isfinite(qp[b])) or np.max(np.abs(qp[b])) > 1e10 for b in np.flatnonzero(num)), (path, step, int(num.sum()))
         worst, n_bad = 0.0, 0
-        idx = rng.choice(B, 72, replace=False)
+        idx = rng.choice(B, 192, replace=False)
         for b in idx:
             if ok[b]:
                 xe, ye, info = orc.solve_exact(qp[b])
@@ -50,9 +50,9 @@ def test_wide_random_inputs(pkg, oracle_mod, path, seed):
                     continue                                 # (an instance the oracle's own solver gives up on proves nothing either way)
                 worst = max(worst, float(np.max(np.abs(x[b, 1, 6:] - orc.split_x(xe)["u"][1]))))
         assert worst < 1e-6, (path, step, worst)
-        for b in [b for b in idx if st[b] == pkg.MAX_ITER][:2]:
+        for b in [b for b in idx if st[b] == pkg.MAX_ITER][:4]:
             xe, ye, info = orc.solve_exact(qp[b])
-            n_bad += int(info["status"] == 1)
+            n_bad += int(info["status"] == 1 and info["iters"] >= 0)      # (iters < 0: the oracle's own interior point gave up too and its ADMM fall-back answered, after 1e3-1e5 iterations)
         assert n_bad == 0, (path, step, "gave up on a QP the oracle solves")
         if step == 1:
             assert np.mean(it[ok] == 0) > 0.15           # a share of the warm instances is served by the warm polish alone even in this regime (30-50 %; > 99 % in normal tracking)

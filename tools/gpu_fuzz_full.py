@@ -1,4 +1,4 @@
-"""Diagnostic: the wide-random-input stress of tests/test_gpu_fuzz.py with EVERY solved instance checked against the oracle's exact optimum (the test samples 72
+"""Diagnostic: the wide-random-input stress of tests/test_gpu_fuzz.py with EVERY solved instance checked against the oracle's exact optimum (the test samples 192
 of 768) -- cold step and the warm step after it.  PG_FUZZ="path:seed,..."; prints the worst instances (index, error, iterations, polish outcome)."""
 import os, sys
 import numpy as np
