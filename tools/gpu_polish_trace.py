@@ -10,7 +10,7 @@ traj = pkg.load_path_fixture(path)
 B = 4096
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345)
 if int(os.environ.get("PG_DEC", "0")):                     # PG_DEC=1: the decoupled N = 50 formulation (BASELINE config 5) with the polish and the empty-set rounds switched on
-    mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, walls=bool(int(os.environ.get("PG_WALLS", "0"))), polish=True, cold_guess=8)
+    mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, walls=bool(int(os.environ.get("PG_WALLS", "0"))), **(dict(polish=True, cold_guess=8) if int(os.environ.get("PG_DEC_POLISH", "1")) else {}))
 else:
     mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, precision=os.environ.get("PG_PREC", "f64"))
 other = None
