@@ -1563,11 +1563,11 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     // current control: its weight (W_HJI) then overrides the tracking cost, the optimum is close to bang-bang (rate rows of both signs, force bounds, soft rows all
     // change together) and the add / drop iteration turns over dozens of rows per round -- the interior point needs its usual 8 iterations there
     const bool guess = C.polish && C.cold_guess > 0 && !(C.has_hji && M0 * sx0[6] + M1 * sx0[7] + Q[o.b] < real(0.0));
-    int last_nchg = 0; real last_tmax = real(0.0);
+    int last_nchg = 0, good_steps = 0; real last_tmax = real(0.0);
     bool warm_attempt = false, from_prev = false;          // warm_attempt: a polish without an interior point in front (attempts -2, -1); from_prev: attempt -2
     for (int attempt = warm ? -2 : (guess ? -1 : 0); attempt < 2; attempt++) {
     if (attempt == -1 && !guess) continue;
-    rp0 = real(0.0); phi = real(1.0); pmode = 0; pstat = 0; polish_gave_up = false; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu; cycle_broken = false;
+    rp0 = real(0.0); phi = real(1.0); pmode = 0; pstat = 0; polish_gave_up = false; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu; cycle_broken = false; good_steps = 0;
     warm_attempt = attempt < 0; from_prev = attempt == -2;
     if (attempt < 0) {
         amask = (act && from_prev) ? (unsigned)O.active[(size_t)b * N + s] : 0u; mask_ipm = amask;
@@ -1634,7 +1634,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     const int round_cap = attempt == -1 ? C.cold_guess : PG_POLISH_ROUNDS;
     // a set that moves by a row or two per round on a nearly feasible point is a ramp being extended or released one stage at a time (the multiplier of the next row
     // only changes sign once the previous one has left): it gets there, and eight more 25 us rounds are far cheaper than the interior point they avoid
-    auto over_cap = [&](int pass) { return pass > round_cap + (last_tmax < real(1.0) ? (last_nchg <= 2 ? 16 : (last_nchg <= PG_PROGRESS_ROWS ? 8 : 0)) : 0); };      // (also for the warm attempt: a fall-back to the cold start costs ten rounds, and the slowest instance sets the kernel time)
+    auto over_cap = [&](int pass) { return pass > round_cap + (((warm_attempt || sizeof(real) == 8) && last_tmax < real(1.0)) ? (last_nchg <= 2 ? (sizeof(real) == 8 ? 16 : 8) : (last_nchg <= PG_PROGRESS_ROWS ? 8 : 0)) : 0); };      // (also for the warm attempt: a fall-back to the cold start costs ten rounds, and the slowest instance sets the kernel time)
     // Active-set polish (OSQP-style, on the stage-structured problem).  The interior point approaches nearly degenerate rows (slack and multiplier both ~ sqrt(mu))
     // like sqrt(mu), so its iterate can sit 1e-6 away from the optimum at any tolerance fp64 rounding allows.  Once it has converged, the rows with
     // lambda > t are held as EQUALITIES (augmented Lagrangian with penalty rho, multiplier estimates y = lambda), every other row is dropped, and the
@@ -1762,7 +1762,9 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     it = 0;
     while (true) {
         if (!pmode) {
-            if (it >= iter_cap) break;
+            // (an attempt that is converging at its cap -- three steps in a row longer than one half -- gets twenty more iterations (caps of 20 and more: not the test settings that force the second start): the alternative is a second start
+            // from scratch; long lateral horizons with wall rows spend 25-30 iterations on tiny steps before the iteration takes off)
+            if (it >= iter_cap && !(iter_cap >= 20 && good_steps >= 3 && it < iter_cap + 20)) break;
             real musum = real(0.0);
 #pragma unroll
             for (int j = 0; j < NROW; j++) musum += (act && j < nrows) ? R.t[j] * R.lam[j] : real(0.0);
@@ -1864,6 +1866,16 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             }
             rmax = wave_max(rmax);
             real alpha = rmax > real(0.995) ? real(0.995) / rmax : real(1.0);
+            // rounding floor, third form: in exact arithmetic a step takes mu to (1 - alpha (1 - sigma)) mu; a step that would MULTIPLY mu near the tolerance is a Newton
+            // direction computed at a conditioning fp64 no longer carries (W = lambda / t ~ 1e10) -- the iterate at hand is as good as it gets, taking the step throws
+            // it away (an N = 50 lateral instance: mu 1.3e-8 -> 3e-7 -> 3, attempt failed at its cap, 80 more iterations in the second: the whole batch waited 8 ms)
+            if ((!C.polish || polish_gave_up) && mu <= (sizeof(real) == 8 ? real(1e5) : real(1e2)) * C.ipm_tol && phi * fmax(rp0, real(1.0)) <= C.ipm_tol) {
+                real mnew = real(0.0);
+#pragma unroll
+                for (int j = 0; j < NROW; j++) mnew += (act && j < nrows) ? (R.t[j] + alpha * R.corr[j]) * (R.lam[j] + alpha * tp[j]) : real(0.0);
+                mnew = wave_sum(mnew) / ntot;
+                if (!(mnew <= real(4.0) * mu)) { status = PG_SOLVED; break; }      // (only where no polish follows: with one, the hand-over happens long before)
+            }
 #pragma unroll
             for (int j = 0; j < NROW; j++) {
                 bool on = act && j < nrows;
@@ -1876,6 +1888,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
                 SGs[0] = c1 + alpha * (sn1 - c1); SGs[1] = c2 + alpha * (sn2 - c2); SGs[2] = c3 + alpha * (snh - c3);
             }
             phi *= (real(1.0) - alpha);
+            good_steps = alpha > real(0.5) ? good_steps + 1 : 0;
             if (PROF && b == C.dbg_instance && lane == 0 && it_total + it < 256) {      // trace region behind the [B][6] cycle counters: (mu, aaff, sigma, alpha) per iteration
                 real* tr = reinterpret_cast<real*>(prof + (size_t)B * 6) + 4 * (it_total + it);
                 tr[0] = mu; tr[2] = sg; tr[3] = alpha;
