@@ -1582,7 +1582,10 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         for (int m = 0; m < 8; m++) xs[m] = sx[8 * (s + 1) + m];
         real sl[NROW];
         slacks(xs, real(0.0), real(0.0), real(0.0), real(0.0), sl);
-        const real sig0 = real(0.1), tau = real(1e-4);
+        // margin of the soft-row slacks above "just feasible": 0.1 for the coupled problem (tuned there: 6.6 iterations; 1 costs two more), 1 for the lateral one, whose
+        // v = 0 roll-out drifts tens of metres off over 8 s -- the first Newton directions are that long, and a margin of 0.1 on the envelope / wall rows lets them
+        // advance by 1e-2 of their length per iteration (25-30 iterations of tiny steps; with the wall rows some instances ran into the cap first: 110 iterations)
+        const real sig0 = C.formulation == PG_DECOUPLED ? real(1.0) : real(0.1), tau = real(1e-4);
         real sg1 = fmax(real(0.0), -fmin(sl[6], sl[7])) + sig0, sg2 = fmax(real(0.0), -fmin(sl[8], sl[9])) + sig0, sgh = wall_on ? fmax(real(0.0), -fmin(sl[0], sl[1])) + sig0 : (hji_on ? fmax(real(0.0), -sl[14]) + sig0 : real(0.0));
         slacks(xs, real(0.0), sg1, sg2, sgh, sl);
         if (act) {
