@@ -1872,12 +1872,13 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             // rounding floor, third form: in exact arithmetic a step takes mu to (1 - alpha (1 - sigma)) mu; a step that would MULTIPLY mu near the tolerance is a Newton
             // direction computed at a conditioning fp64 no longer carries (W = lambda / t ~ 1e10) -- the iterate at hand is as good as it gets, taking the step throws
             // it away (an N = 50 lateral instance: mu 1.3e-8 -> 3e-7 -> 3, attempt failed at its cap, 80 more iterations in the second: the whole batch waited 8 ms)
-            if ((!C.polish || polish_gave_up) && mu <= (sizeof(real) == 8 ? real(1e5) : real(1e2)) * C.ipm_tol && phi * fmax(rp0, real(1.0)) <= C.ipm_tol) {
+            if (!C.polish && mu <= (sizeof(real) == 8 ? real(1e5) : real(1e2)) * C.ipm_tol && phi * fmax(rp0, real(1.0)) <= C.ipm_tol) {
                 real mnew = real(0.0);
 #pragma unroll
                 for (int j = 0; j < NROW; j++) mnew += (act && j < nrows) ? (R.t[j] + alpha * R.corr[j]) * (R.lam[j] + alpha * tp[j]) : real(0.0);
                 mnew = wave_sum(mnew) / ntot;
-                if (!(mnew <= real(4.0) * mu)) { status = PG_SOLVED; break; }      // (only where no polish follows: with one, the hand-over happens long before)
+                if (!(mnew <= real(4.0) * mu)) { status = PG_SOLVED; break; }      // (only with the polish off: with it on, the hand-over happens long before, and an
+                                                                                   // instance whose polish gave up should get as close as the interior point can take it)
             }
 #pragma unroll
             for (int j = 0; j < NROW; j++) {
