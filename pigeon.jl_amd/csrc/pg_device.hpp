@@ -171,16 +171,20 @@ PG_DEV real inv_fiala_tan3(real Fy, real three_over_Ca, real Fy_max) {
 }
 // vehicle_dynamics.jl:64-76: 3-iteration front-axle load-transfer fixed point, then rear
 template <class T>
-PG_DEV void lateral_forces(const DevVehicle& P, T af, T ar, T Fxf, T Fxr, T sd, T cd, T& Fyf, T& Fyr) {   // af, ar: TANGENTS of the slip angles
+PG_DEV void lateral_forces(const DevVehicle& P, T af, T ar, T Fxf, T Fxr, T sd, T cd, T& Fyf, T& Fyr, T* Fxf_t_out = nullptr) {   // af, ar: TANGENTS of the slip angles
     const real W_b = P.m * P.G * P.b, W_a = P.m * P.G * P.a, invL = real(1.0) / P.L;
     Fyf = cst<T>(real(0.0));
-    T Fx = Fxf * cd + Fxr;
+    const T FxfC = Fxf * cd;                       // (formed once: the loop and the caller used to multiply it out four times; same association, same bits)
+    T Fxt = FxfC;
+    T Fx = FxfC + Fxr;
 #pragma unroll 1
     for (int i = 0; i < 3; i++) {
         T Fzf = (W_b - P.h * Fx) * invL;
         Fyf = fiala<T>(af, P.Caf, P.mu, Fxf, Fzf);
-        Fx = Fxf * cd - Fyf * sd + Fxr;
+        Fxt = FxfC - Fyf * sd;                     // the longitudinal front force in the body frame at this load-transfer iterate
+        Fx = Fxt + Fxr;
     }
+    if (Fxf_t_out) *Fxf_t_out = Fxt;
     T Fzr = (W_a + P.h * Fx) * invL;
     Fyr = fiala<T>(ar, P.Car, P.mu, Fxr, Fzr);
 }
@@ -206,9 +210,9 @@ PG_DEV void body_accel(const DevVehicle& P, T Ux, T Uy, T r, T delta, T Fxf, T F
     T taf = (tf - td) / (real(1.0) + tf * td);          // tan(atan2(Uy + a r, Ux) - delta)   (:118)
     T tar = (Uy - P.b * r) / Ux;                   // tan(atan2(Uy - b r, Ux))           (:119)
     T Fyf, Fyr;
-    lateral_forces<T>(P, taf, tar, Fxf, Fxr, sd, cd, Fyf, Fyr);
+    T Fxf_t;
+    lateral_forces<T>(P, taf, tar, Fxf, Fxr, sd, cd, Fyf, Fyr, &Fxf_t);
     T Fx_drag = -P.Cd0 - Ux * (P.Cd1 + P.Cd2 * Ux);
-    T Fxf_t = Fxf * cd - Fyf * sd;
     T Fyf_t = Fyf * cd + Fxf * sd;
     const real invm = real(1.0) / P.m, invI = real(1.0) / P.Izz;
     dUx = (Fxf_t + Fxr + Fx_drag) * invm + r * Uy;
