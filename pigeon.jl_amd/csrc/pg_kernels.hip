@@ -1784,10 +1784,12 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         }
         if (pmode) {
             // every stage-locally eliminated slack needs a pivot: a group without an active row gets its sigma >= 0 row (the linear cost pushes sigma down to it)
-            if (!(amask & 0x04C0u)) amask |= 1u << 10;
-            if (!(amask & 0x0B00u)) amask |= 1u << 11;
-            if (hji_on && !(amask & 0xC000u)) amask |= 1u << 15;
-            if (wall_on && !(amask & 0x0007u)) amask |= 1u << 2;
+            // (a pivot that is the only active row of its group has a KNOWN multiplier, the linear cost coefficient of its slack: starting the augmented Lagrangian
+            // there instead of at zero spares the refinement pass whose only job would be to find it -- every instance served from the empty set had one)
+            if (!(amask & 0x04C0u)) { amask |= 1u << 10; if (act) R.lam[10] = wb; }
+            if (!(amask & 0x0B00u)) { amask |= 1u << 11; if (act) R.lam[11] = wr; }
+            if (hji_on && !(amask & 0xC000u)) { amask |= 1u << 15; R.lam[15] = wh; }
+            if (wall_on && !(amask & 0x0007u)) { amask |= 1u << 2; R.lam[2] = ww; }
             // rate rows that would carry an unbroken run from the first transition past the steering bound (see `overshoot`)
             const unsigned long long run_up = __ballot(act && ((amask >> 12) & 1u)), run_dn = __ballot(act && ((amask >> 13) & 1u));
             const int end_up = __ffsll((long long)~run_up) - 1, end_dn = __ffsll((long long)~run_dn) - 1;      // first stage outside the run (lanes >= N are never in it)
