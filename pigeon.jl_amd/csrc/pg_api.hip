@@ -26,7 +26,7 @@ struct pg_handle {
     double *d_t0 = nullptr, *d_toff = nullptr;            // absolute time stays fp64 in both builds (tdouble)
     int* d_solved = nullptr; uint8_t* d_mask = nullptr;     // d_mask: staging of pg_reset's per-instance mask
     double *d_ts = nullptr, *d_dt = nullptr, *d_prev_ts = nullptr;
-    real *d_sep = nullptr, *d_nodes = nullptr, *d_qp = nullptr;
+    real *d_sep = nullptr, *d_nodes = nullptr, *d_qp = nullptr, *d_naux = nullptr;      // d_naux [cap][NN][4]: arguments of the angles k_nodes leaves to k_nodes_angles
     real *d_x7 = nullptr, *d_vg8 = nullptr, *d_Mb = nullptr;
     real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     real* d_lam = nullptr;                                      // [cap][N][16] multipliers of the last solve (warm start of the polish)
@@ -143,7 +143,7 @@ int pg_default_config_decoupled(pg_config* c) {
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_state, h->d_control, h->d_t0, h->d_other, h->d_toff, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_order};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_order, h->d_naux};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->ev_ok) for (int i = 0; i < 4; i++) (void)hipEventDestroy(h->ev[i]);
@@ -189,7 +189,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_sep, cap * 4, real); ALLOC(h->d_nodes, cap * NN * 10, real); ALLOC(h->d_qp, cap * C.qp_len, real);
     ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
     ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_u, cap * 3, real); ALLOC(h->d_mu, cap, real);
-    ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_polish, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_active, cap * N, uint16_t);
+    ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_polish, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_naux, cap * NN * 4, real); ALLOC(h->d_active, cap * N, uint16_t);
 #ifdef PG_EXPERIMENTAL_SOLVE4
     { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (experimental/pg_solve4.hip)
     if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), real);
@@ -477,7 +477,10 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
         } else {
             auto kern = staged ? k_nodes<true> : k_nodes<false>;
             hipLaunchKernelGGL(kern, grid, block, traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
-                               h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes, F);
+                               h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes, F, h->d_naux);
+            LAUNCH_CHECK(h);
+            const long nn = (long)B * h->dc.NN;
+            hipLaunchKernelGGL(k_nodes_angles, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_naux, h->d_nodes);
         }
     }
     LAUNCH_CHECK(h);

@@ -302,9 +302,12 @@ PG_DEV Envelope stable_limits(const DevVehicle& B, real Ux, real Fxf, real Fxr) 
 //                                             (1 + ty taf) because cos(x - y) = cos x cos y (1 + tan x tan y) with both cosines positive
 // (identical values in exact arithmetic; the serial 90-iteration chain of the cold node seeding drops four transcendental calls per iteration).
 // The ANGLES are formed once, at exit, with the reference's own expressions.  beta, (sb, cb), (sd, cd): the initial estimates and their sines/cosines.
-struct Steady { real beta, Ux, Uy, r, A, delta, Fx; };
-PG_DEV Steady steady_state(const DevVehicle& P, real V, real A_tan, real kappa, int num_iters, real r, real beta, real sb, real cb, real delta, real sd, real cd, real Fyf) {
+// (defer = true: the three inverse tangents of the exit are left to the caller -- ang_y, ang_x, ang_t, tb carry their arguments: delta = atan2(ang_y, ang_x) - atan(ang_t),
+// beta = atan(tb) when beta_is_tan.  The cold node seeding is one serial chain per instance; the angles feed nothing in it and cost a fifth of its instructions)
+struct Steady { real beta, Ux, Uy, r, A, delta, Fx, ang_y, ang_x, ang_t, tb; bool beta_is_tan; };
+PG_DEV Steady steady_state(const DevVehicle& P, real V, real A_tan, real kappa, int num_iters, real r, real beta, real sb, real cb, real delta, real sd, real cd, real Fyf, bool defer = false) {
 #pragma clang fp contract(off)
+    real ang_y = real(0.0), ang_x = real(1.0), ang_t = real(0.0);
     real A_rad = V * V * kappa;
     real A_max = P.mu * P.G;
     if (hypot(A_tan, A_rad) > A_max) {
@@ -340,7 +343,8 @@ PG_DEV Steady steady_state(const DevVehicle& P, real V, real A_tan, real kappa, 
         real Fyf_max = sqrt_diff_sq(Ffm, Fxf);
         real taf = inv_fiala_tan3(Fyf, s3Caf, Fyf_max);                        // tan(alpha_f)
         if (i == num_iters) {
-            delta = atan2(Uy + P.a * r, Ux) - atan(taf);                         // :376-377, the angle itself
+            ang_y = Uy + P.a * r; ang_x = Ux; ang_t = taf;
+            if (!defer) delta = atan2(ang_y, ang_x) - atan(ang_t);                // :376-377, the angle itself
             real Ax2 = (Fxf * cd - Fyf * sd + Fxr + Fx_drag) * invm;
             real Ay2 = (Fyf * cd + Fxf * sd + Fyr) * invm;
             A_out = Ax2 * cb + Ay2 * sb;
@@ -352,7 +356,7 @@ PG_DEV Steady steady_state(const DevVehicle& P, real V, real A_tan, real kappa, 
         cb = pg_rsqrt(real(1.0) + tb * tb); sb = tb * cb;
     }
     Steady o;
-    o.beta = beta_is_tan ? atan(tb) : beta; o.Ux = V * cb; o.Uy = V * sb; o.r = r; o.A = A_out; o.delta = delta; o.Fx = Fxf + Fxr;
+    o.beta = (beta_is_tan && !defer) ? atan(tb) : beta; o.ang_y = ang_y; o.ang_x = ang_x; o.ang_t = ang_t; o.tb = tb; o.beta_is_tan = beta_is_tan; o.Ux = V * cb; o.Uy = V * sb; o.r = r; o.A = A_out; o.delta = delta; o.Fx = Fxf + Fxr;
     return o;
 }
 

@@ -185,7 +185,7 @@ PG_DEV void put_node(real* __restrict__ ND, int i, const NodeRec& r) {
 }
 template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, int B, const real* __restrict__ state, const real* __restrict__ control, const tdouble* __restrict__ toff,
                         const int* __restrict__ solved, const real* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt,
-                        const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* __restrict__ nodes, OrderOut F) {
+                        const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* __restrict__ nodes, OrderOut F, real* __restrict__ naux) {
     // the two searched channels (t, s) are staged in LDS when they fit: every node costs three binary searches whose ~10 dependent probes each
     // would otherwise pay L2 latency (the kernel is a 64-wave serial recurrence: latency, not bandwidth, is its whole cost)
     extern __shared__ real sh_traj[];
@@ -229,9 +229,11 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
             r.pV = tj.V; r.pK = tj.kappa;
             put_node(ND, i, r);
         }
+        for (int i = 0; i < C.NN; i++) naux[((size_t)b * C.NN + i) * 4] = NAN;          // (nothing deferred for a warm instance: k_nodes_angles skips it)
         file_order(F, B, b, warm_slow(F, b));
         return;
     }
+    naux[(size_t)b * C.NN * 4] = NAN;                     // node 0 is the measured state
     // cold start :103-141
     real sdp, cdp; pg_sincos(dpsi, &sdp, &cdp);
     real V = Ux0 * cdp - Uy0 * sdp;
@@ -264,13 +266,17 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
         const bool shortp = i <= C.Ns;
         // :122 short nodes: one iteration from the measured (r0, beta0, delta0, Fyf0); :128 long nodes: four iterations from (V kappa, 0, 0, 0)
         Steady est = steady_state(P, V, A_des, tj.kappa, shortp ? 1 : 4, shortp ? r0 : V * tj.kappa, shortp ? beta0 : real(0.0), shortp ? sb0 : real(0.0), shortp ? cb0 : real(1.0),
-                                  shortp ? d0 : real(0.0), shortp ? sd0 : real(0.0), shortp ? cd0 : real(1.0), shortp ? Fyf0 : real(0.0));
+                                  shortp ? d0 : real(0.0), shortp ? sd0 : real(0.0), shortp ? cd0 : real(1.0), shortp ? Fyf0 : real(0.0), true);
         r.q0 = ds;
         r.q1 = shortp ? Ux0 : est.Ux; r.q2 = shortp ? Uy0 : est.Uy; r.q3 = shortp ? r0 : est.r;
-        r.q4 = shortp ? adiff(psi0, tj.psi) : -est.beta; r.q5 = shortp ? e0 : real(0.0);
-        r.u0 = est.delta; r.u1 = est.Fx; r.pV = tj.V; r.pK = tj.kappa;
+        r.q4 = shortp ? adiff(psi0, tj.psi) : real(0.0); r.q5 = shortp ? e0 : real(0.0);      // long nodes: q4 = -beta and u0 = delta are finished by k_nodes_angles
+        r.u0 = real(0.0); r.u1 = est.Fx; r.pV = tj.V; r.pK = tj.kappa;
         put_node(ND, i, r);
-        if (i == 1) { d1 = est.delta; Fx1 = est.Fx; }
+        {
+            real* ax = naux + ((size_t)b * C.NN + i) * 4;
+            ax[0] = est.ang_y; ax[1] = est.ang_x; ax[2] = est.ang_t; ax[3] = (!shortp && est.beta_is_tan) ? est.tb : NAN;      // (NaN: q4 stands as written)
+        }
+        if (i == 1) { d1 = atan2(est.ang_y, est.ang_x) - atan(est.ang_t); Fx1 = est.Fx; }          // (the launch-order hint needs this one angle now)
         real A = est.A;
         V = V + A * tau;
         s = s + V * tau + A * tau * tau * real(0.5);
@@ -284,6 +290,18 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
     }
 }
 
+// The angles k_nodes deferred (steady_state(.., defer = true)): delta = atan2(y, x) - atan(t) of every seeded node and beta = atan(tb) of the long ones -- the same
+// expressions on the same arguments, evaluated with lane = (instance, node) instead of inside the serial chain of the instance (three inverse tangents per node were a
+// fifth of that chain's instructions).
+__global__ __launch_bounds__(256) void k_nodes_angles(DevCfg C, int B, const real* __restrict__ naux, real* __restrict__ nodes) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)B * C.NN) return;
+    const real* ax = naux + (size_t)gid * 4;
+    if (ax[0] != ax[0]) return;                                   // measured node / warm instance: nothing deferred
+    real* nd = nodes + (size_t)gid * 10;
+    nd[6] = atan2(ax[0], ax[1]) - atan(ax[2]);
+    if (ax[3] == ax[3]) nd[4] = -atan(ax[3]);
+}
 // Warm branch of compute_linearization_nodes! (coupled_lat_long.jl:82-102) for a batch in which EVERY instance has a previous solution (closed loop after the
 // first step): the 31 nodes of an instance are independent of each other there -- node i interpolates the previous solution at ts[i] and looks the reference up at
 // the resulting arclength -- so the lane is (instance, node) instead of the instance (k_nodes runs the same arithmetic node after node in one lane because the
