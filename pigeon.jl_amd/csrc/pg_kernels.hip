@@ -1065,7 +1065,9 @@ PG_DEV real rl(real v, int src) {
 #endif
 #define PG_SOLVE_WAVES(RING) PG_F32_WAVES
 #else
-#define PG_SOLVE_WAVES(RING) ((RING) ? 2 : 1)
+#define PG_SOLVE_WAVES(RING) 1          // (the ring variant used to ask for two waves per SIMD: its LDS footprint, 30 KB at N = 50, allows five waves per CU, i.e. one per
+                                        // SIMD anyway, and the 256-VGPR budget cost it 452 spilled registers: 8.3 -> 6.9 ms on the N = 50 lateral batch.  A deeper register
+                                        // prefetch of the stage blocks, 2 / 4 / 6 loads in flight instead of one, was measured on top: 7.4 / 7.6 / 7.8 ms -- not load-bound)
 #endif
 
 // Ordering point between an LDS write and the LDS reads of OTHER lanes of the same wavefront.  k_solve's workgroup is one wave and the LDS pipeline
