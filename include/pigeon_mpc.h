@@ -217,6 +217,9 @@ int pg_get_path_coordinates(pg_handle* h, double* sep);
  * (the numeric content update_QP! writes into the Parametron parameters, coupled_lat_long.jl:323-366; B's scaled by u_normalization) */
 int pg_qp_len(const pg_handle* h);
 int pg_get_qp(pg_handle* h, int32_t b0, int32_t n, double* out);
+/* the inverse: install QP data for instances [b0, b0+n) in the same layout (what setting the Parametron parameters by hand is to the reference); pg_solve then solves
+ * exactly these problems.  For replaying recorded QPs and for solver tests on constructed (e.g. degenerate) problems; a step (pg_update_qp, pg_step*) overwrites them. */
+int pg_set_qp(pg_handle* h, int32_t b0, int32_t n, const double* in);
 /* primal solution: x [B][N+1][8] = (q (6), normalised u (2)) per node; sigma [B][N][3] = (sigma1, sigma2, sigma_HJI of node k+1) */
 int pg_get_solution(pg_handle* h, double* x, double* sigma);
 /* status [B] (pg_solve_status), iters [B], active [B][N] bit masks over the 16 stage rows (row order in DESIGN.md), mu [B] final gap */

@@ -741,6 +741,11 @@ int pg_get_qp(pg_handle* h, int32_t b0, int32_t n, double* out) {
     REQUIRE(h, out && b0 >= 0 && n >= 1 && b0 + n <= h->B, "pg_get_qp: range outside the batch");
     return down(h, out, h->d_qp + (size_t)b0 * h->dc.qp_len, (size_t)n * h->dc.qp_len);
 }
+int pg_set_qp(pg_handle* h, int32_t b0, int32_t n, const double* in) {
+    int rc = check_ready(h); if (rc) return rc;
+    REQUIRE(h, in && b0 >= 0 && n >= 1 && b0 + n <= h->B, "pg_set_qp: range outside the batch");
+    return up(h, h->d_qp + (size_t)b0 * h->dc.qp_len, in, (size_t)n * h->dc.qp_len);
+}
 int pg_get_solution(pg_handle* h, double* x, double* sigma) {
     int rc = check_ready(h); if (rc) return rc;
     const size_t B = h->B; const DevCfg& C = h->dc;

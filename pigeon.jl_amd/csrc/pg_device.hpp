@@ -103,6 +103,7 @@ template <int K> struct DK {
     }
 };
 #define PG_DK_LOOP _Pragma("unroll") for (int k = 0; k < K; k++)
+#define PG_DK_LOOP_T(T) _Pragma("unroll") for (int k = 0; k < (int)(sizeof(T::d) / sizeof(real)); k++)
 template <int K> PG_DEV DK<K> operator+(DK<K> x, DK<K> y) { DK<K> r; r.v = x.v + y.v; PG_DK_LOOP r.d[k] = x.d[k] + y.d[k]; return r; }
 template <int K> PG_DEV DK<K> operator-(DK<K> x, DK<K> y) { DK<K> r; r.v = x.v - y.v; PG_DK_LOOP r.d[k] = x.d[k] - y.d[k]; return r; }
 template <int K> PG_DEV DK<K> operator-(DK<K> x) { DK<K> r; r.v = -x.v; PG_DK_LOOP r.d[k] = -x.d[k]; return r; }
@@ -144,14 +145,29 @@ PG_DEV T fiala(T tana, real Ca, real mu, T Fx, T Fz) {
     T Fmax = mu * Fz;
     if (abs_(val(Fx)) >= val(Fmax)) return cst<T>(real(0.0));
     if constexpr (is_dk<T>::value) {
-        // forward-mode numbers (k_linearize: four of these per dynamics evaluation, 57 % of its instructions): ONE reciprocal square root gives 1 / Fy_max, which is
-        // what the slip ratio needs -- instead of a square root, its reciprocal for the tangents and the division tana / slide (~35 instructions fewer per call);
-        // Fy_max itself is only formed on the sliding branch.  Same function, other rounding (1e-16).
-        T w = Fmax * Fmax - Fx * Fx;
-        T z = rsqrt_(w);
-        T ratio = abs_(tana * z) * (Ca * (real(1.0) / real(3.0)));
-        if (val(ratio) <= real(1.0)) return -(Ca * tana) * (real(1.0) - ratio + ratio * ratio * (real(1.0) / real(3.0)));
-        return -(w * z) * sgn(val(tana));
+        // forward-mode numbers (k_linearize: four of these per dynamics evaluation, half of its instructions): the tire force is treated as ONE elementary function
+        // of three scalars, Fy(tan alpha, Fx, Fz) -- value and the three partial derivatives in scalar arithmetic, then one three-term combination per direction --
+        // instead of carrying every direction through each of its ~20 operations.  With z = 1 / sqrt(w), w = (mu Fz)^2 - Fx^2, rho = |tan alpha| z Ca / 3:
+        //   adhesion (rho <= 1):  Fy = -Ca tan(alpha) (1 - rho + rho^2/3),   dFy/dtan = -Ca (1 - rho)^2,   dFy/dw = Ca tan(alpha) (2 rho / 3 - 1) rho z^2 / 2
+        //   sliding:              Fy = -sqrt(w) sgn,                         dFy/dtan = 0,                 dFy/dw = -sgn z / 2
+        // and dw = 2 mu^2 Fz dFz - 2 Fx dFx.  ONE reciprocal square root serves the value and the derivatives.  Same function as the generic branch below, other rounding (1e-16).
+        const real fm = val(Fmax), fx = val(Fx), ta = val(tana);
+        const real w = fm * fm - fx * fx, z = pg_rsqrt(w);
+        const real rho = fabs(ta * z) * (Ca * (real(1.0) / real(3.0)));
+        real Fy, g_t, g_w;
+        if (rho <= real(1.0)) {
+            const real cat = Ca * ta, omr = real(1.0) - rho;
+            Fy = -cat * (omr + rho * rho * (real(1.0) / real(3.0)));
+            g_t = -Ca * omr * omr;
+            g_w = cat * (rho * (real(2.0) / real(3.0)) - real(1.0)) * rho * (real(0.5) * z * z);
+        } else {
+            const real sg = sgn(ta);
+            Fy = -(w * z) * sg; g_t = real(0.0); g_w = real(-0.5) * z * sg;
+        }
+        const real g_z = g_w * (real(2.0) * fm * mu), g_x = g_w * (real(-2.0) * fx);
+        T r; r.v = Fy;
+        PG_DK_LOOP_T(T) r.d[k] = g_t * tana.d[k] + g_z * Fz.d[k] + g_x * Fx.d[k];
+        return r;
     }
     T Fy_max = sqrt_(Fmax * Fmax - Fx * Fx);
     T slide = (real(3.0) / Ca) * Fy_max;

@@ -1227,12 +1227,12 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     // Lane roles inside each 16-lane row (rows mirror each other): lanes 0..5 own the six dynamics rows of Abar, lanes 6, 7 the two input states, lanes 8, 9 the two
     // rows of the gain K -- every lane does ONE 8-term dot product against the broadcast state and the two inputs come back through SGPRs (round 1 had all eight
     // component lanes evaluate both gain rows as well: 24 FMAs and 29 LDS reads per lane and stage, now 10 and 11).
-    auto forward = [&](auto use_gain_t) {
+    auto forward = [&](auto use_gain_t, bool delta = false) {      // delta: the roll-out of a CORRECTION (starts at 0, no affine term: see the polish refinement)
         constexpr bool use_gain = decltype(use_gain_t)::value;
         const int f16 = lane & 15;
         const bool isA = f16 < 6, isK = f16 == 8 || f16 == 9;
         const int rrA = isA ? f16 : 5, kro = 8 * (isK ? f16 - 8 : 0);
-        real xi = sx0[r8];
+        real xi = delta ? real(0.0) : sx0[r8];
         *(lane < 8 ? sx + lane : sDum + lane) = xi;
         ring_prime(0, +1);
         const real w_lo = isA ? real(1.0) : real(0.0), w_6 = f16 == 6 ? real(1.0) : real(0.0), w_7 = f16 == 7 ? real(1.0) : real(0.0);
@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             real rw[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) rw[m] = rowp[m];
-            const real addc = isK ? (use_gain ? skf[2 * k + (f16 - 8)] : real(0.0)) : Rk[SB_C + rrA];
+            const real addc = isK ? (use_gain ? skf[2 * k + (f16 - 8)] : real(0.0)) : (delta ? real(0.0) : Rk[SB_C + rrA]);
             const real bf0 = Rk[SB_B + 2 * rrA], bf1 = Rk[SB_B + 2 * rrA + 1];
             real xm[8];
 #pragma unroll
@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     // Polish state (see the loop below): pmode = 0 while the interior point runs, then the round number of the active-set polish;
     // amask = this stage's rows currently held active.
     int pmode = 0, pstat = 0; unsigned amask = 0, mask_ipm = 0, amask_1ago = 0xFFFFFFFFu, amask_2ago = 0xFFFFFFFFu; bool polish_gave_up = false, cycle_broken = false;
-    const real rho = C.polish_rho, ptol = C.polish_tol;
+    const real rho = C.polish_rho, ptol = C.polish_tol, dtol = real(1000.0) * C.polish_tol;      // dtol: largest correction of the last refinement pass a verified point may have had
     auto assemble = [&](real sigmu, bool matrices) {
         real W[NROW], ell[NROW];
         if (pmode) {
@@ -1532,7 +1532,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     // (the lane-role split that pays in the roll-out -- gain rows in their own lanes -- was tried here too: fewer instructions, but the extra SGPR hop sits on the
     // serial chain y -> f -> p and the pass got 12 % slower; this pass is chain-bound, the roll-out was issue-bound)
     // Riccati vector pass backward: lane r8 holds p_{k+1}[r8]; p_k = qhat_k + Abar' y + K' f, y = Mc_k + p_{k+1}, f = rhat + Bbar' y, kff = -Sinv f
-    auto riccati_vectors = [&]() {
+    auto riccati_vectors = [&](bool delta = false) {
         real pi = sq[8 * N + r8];
         ring_prime(N - 1, -1);
 #pragma unroll 1
@@ -1542,7 +1542,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             real a6[6], b0[6], b1[6];
 #pragma unroll
             for (int m = 0; m < 6; m++) { a6[m] = Ak[SB_ROW * m + r8]; b0[m] = Bk[2 * m]; b1[m] = Bk[2 * m + 1]; }
-            real mc = sMc[8 * k + r8], qk = sq[8 * k + r8], k0 = sK[16 * k + r8], k1 = sK[16 * k + 8 + r8], r0 = sr[2 * k], r1 = sr[2 * k + 1];
+            real mc = delta ? real(0.0) : sMc[8 * k + r8], qk = sq[8 * k + r8], k0 = sK[16 * k + r8], k1 = sK[16 * k + 8 + r8], r0 = sr[2 * k], r1 = sr[2 * k + 1];
             real I00 = sSi[4 * k], I01 = sSi[4 * k + 1], I11 = sSi[4 * k + 2];
             real yi = mc + pi;
             real y[8];
@@ -1561,11 +1561,17 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         }
         __syncthreads();
     };
-    real xn[8], vn0, vn1, sn1, sn2, snh;
-    auto newton_point = [&](real* tplus) {
+    real xn[8], vn0, vn1, sn1, sn2, snh, last_dmax = real(0.0);
+    auto newton_point = [&](real* tplus, bool delta = false) {
 #pragma unroll
-        for (int m = 0; m < 8; m++) xn[m] = sx[8 * (s + 1) + m];
-        vn0 = sv[2 * s]; vn1 = sv[2 * s + 1];
+        for (int m = 0; m < 8; m++) xn[m] = (delta ? xn[m] : real(0.0)) + sx[8 * (s + 1) + m];
+        vn0 = (delta ? vn0 : real(0.0)) + sv[2 * s]; vn1 = (delta ? vn1 : real(0.0)) + sv[2 * s + 1];
+        if (delta) {      // size of the correction (largest component of any stage): the refinement has converged when it is small
+            real dm = real(0.0);
+#pragma unroll
+            for (int m = 0; m < 8; m++) dm = fmax(dm, act ? fabs(sx[8 * (s + 1) + m]) : real(0.0));
+            last_dmax = wave_max(dm);
+        }
         sn1 = -(e_c10 * xn[2] + e_c11 * xn[3] + e_g1) * e_d1;
         sn2 = -(e_c20 * xn[2] + e_c21 * xn[3] + e_g2) * e_d2;
         snh = wall_on ? -(e_ch0 * xn[5] + e_gh) * e_dh : (hji_on ? -(e_ch0 * xn[6] + e_ch1 * xn[7] + e_gh) * e_dh : real(0.0));
@@ -1583,7 +1589,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     // current control: its weight (W_HJI) then overrides the tracking cost, the optimum is close to bang-bang (rate rows of both signs, force bounds, soft rows all
     // change together) and the add / drop iteration turns over dozens of rows per round -- the interior point needs its usual 8 iterations there
     const bool guess = C.polish && C.cold_guess > 0 && !(C.has_hji && M0 * sx0[6] + M1 * sx0[7] + Q[o.b] < real(0.0));
-    int last_nchg = 0, good_steps = 0; real last_tmax = real(0.0);
+    int last_nchg = 0, good_steps = 0; real last_tmax = real(0.0); bool refine_only = false;
     bool warm_attempt = false, from_prev = false;          // warm_attempt: a polish without an interior point in front (attempts -2, -1); from_prev: attempt -2
     for (int attempt = warm ? -2 : (guess ? -1 : 0); attempt < 2; attempt++) {
     if (attempt == -1 && !guess) continue;
@@ -1676,8 +1682,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     };
     // after a polish solve (tp = slacks at the new point): multiplier update of the active rows, then the verification.  Returns 0 = verified (solution
     // stored, pstat set), 1 = same set but the active rows are not yet at t = 0 within `ttol` (refine), 2 = the active set changed, 3 = the sets cycle.
-    auto polish_check = [&](const real* tp, real ttol) -> int {
-        unsigned add = 0, drop = 0; bool settled = true;
+    auto polish_check = [&](const real* tp, real ttol, real dmax = real(0.0)) -> int {
+        unsigned add = 0, drop = 0; bool settled = !(dmax > dtol);
 #pragma unroll
         for (int j = 0; j < NROW; j++) {
             const bool on = act && j < nrows, a = (amask >> j) & 1u;
@@ -1802,6 +1808,9 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
                 for (int j = 0; j < NROW; j++) it_[j] = frcp(R.t[j]);
             }
         }
+        real tp[NROW];
+        real sg = real(0.0);
+        if (!(pmode && refine_only)) {
         if (pmode) {
             // every stage-locally eliminated slack needs a pivot: a group without an active row gets its sigma >= 0 row (the linear cost pushes sigma down to it)
             // (a pivot that is the only active row of its group has a KNOWN multiplier, the linear cost coefficient of its slack: starting the augmented Lagrangian
@@ -1828,9 +1837,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         stamp(2);
         forward(std::true_type{});
         stamp(4);
-        real tp[NROW];
         newton_point(tp);
-        real sg = real(0.0);
         if (!pmode) {
             // step to the boundary: alpha_max = 1 / max_j( -dt_j / t_j, -dl_j / lam_j )  (only rows that move towards the boundary are positive)
             real rmax = real(0.0);
@@ -1869,15 +1876,36 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             if (pc == 3) { if (polish_failed()) break; continue; }
             if (pc == 2) { if (over_cap(++pmode) && polish_failed()) break; continue; }      // the set changed: next round directly
         }
+        }
+        refine_only = false;
         // ---- corrector / polish refinement ----
         assemble(sg * mu, false);
+        // Polish: the corrector is solved as a CORRECTION to the point the predictor returned (x = xbar + d): same matrices, linear terms = the gradient of the
+        // stage costs AT xbar with the updated multipliers (qhat + Qhat xbar, rhat + Rhat vbar), no affine dynamics term (the roll-out that produced xbar satisfies
+        // the dynamics to rounding), d_0 = 0.  In exact arithmetic this is the same point as the absolute solve; in floating point it is one step of iterative
+        // refinement for free -- the Riccati recursion with the penalty rho on the working set carries entries of size rho, and where weakly curved directions
+        // couple with penalised ones its absolute solution is only good to ~ eps rho / curvature (a recorded QP of the stress regime: controls 4e-3 off at rho = 1e7,
+        // tests/test_gpu_qp_replay.py); the correction is computed from a residual evaluated at the actual point, so that error is squared.
+        const bool dlt = pmode != 0;
+        if (dlt && act) {
+            real* qo = sq + 8 * (s + 1); const real* Qo = sQ + 10 * (s + 1);
+            qo[0] = Qo[0] * xn[0]; qo[1] += Qo[1] * xn[1]; qo[2] += Qo[2] * xn[2] + Qo[8] * xn[3]; qo[3] += Qo[3] * xn[3] + Qo[8] * xn[2];
+            qo[4] = Qo[4] * xn[4]; qo[5] = (wall_on ? qo[5] : real(0.0)) + Qo[5] * xn[5];
+            qo[6] += Qo[6] * xn[6] + Qo[9] * xn[7]; qo[7] += Qo[7] * xn[7] + Qo[9] * xn[6];
+            sr[2 * s] += sR[2 * s] * vn0; sr[2 * s + 1] = sR[2 * s + 1] * vn1;
+        }
         __syncthreads();
         stamp(1);
-        riccati_vectors();
+        riccati_vectors(dlt);
+        if (dlt && act) {      // (the entries assemble() never rewrites go back to their constants for the next absolute solve)
+            real* qo = sq + 8 * (s + 1);
+            qo[0] = real(0.0); qo[4] = real(0.0); if (!wall_on) qo[5] = real(0.0);
+            sr[2 * s + 1] = real(0.0);
+        }
         stamp(3);
-        forward(std::true_type{});
+        forward(std::true_type{}, dlt);
         stamp(4);
-        newton_point(tp);
+        newton_point(tp, dlt);
         if (!pmode) {
             real rmax = real(0.0);
 #pragma unroll
@@ -1922,10 +1950,12 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             if (mu > real(1e8) * C.ipm_mu0) break;          // diverging: give up on this start
             it++;
         } else {
-            const int pc = polish_check(tp, ptol);
+            const int pc = polish_check(tp, ptol, last_dmax);
             ptrace(pc + 10, tp);
             if (pc == 0) break;
-            if ((pc == 3 || over_cap(++pmode)) && polish_failed()) break;      // set changed, or the multiplier iteration has not settled yet: another round
+            // same set, but the rows are not at t = 0 yet or the correction was not small: another refinement pass on the same matrices (no predictor)
+            refine_only = pc == 1;
+            if ((pc == 3 || over_cap(++pmode)) && polish_failed()) { refine_only = false; break; }      // (set changed: another round)
         }
     }
     it_total += it;

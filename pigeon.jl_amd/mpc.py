@@ -267,6 +267,11 @@ class BatchedTrajectoryTrackingMPC:
         self._chk(self.lib.pg_get_qp(self.h, b0, n, _p(out)), "pg_get_qp")
         return out
 
+    def set_qp_data(self, qp, b0=0):
+        """Install QP data (layout of qp_data) for instances [b0, b0 + len(qp)): solve_() then solves exactly these problems (include/pigeon_mpc.h pg_set_qp)."""
+        q = _f64(qp).reshape(-1, self.qp_len)
+        self._chk(self.lib.pg_set_qp(self.h, b0, q.shape[0], _p(q)), "pg_set_qp")
+
     def solution(self):
         x = np.zeros((self.B, self.NN, 8)); sg = np.zeros((self.B, self.N, 3))
         self._chk(self.lib.pg_get_solution(self.h, _p(x), _p(sg)), "pg_get_solution")

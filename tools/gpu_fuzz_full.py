@@ -1,5 +1,5 @@
 """Diagnostic: the wide-random-input stress of tests/test_gpu_fuzz.py with EVERY solved instance checked against the oracle's exact optimum (the test samples 192
-of 768) -- cold step and the warm step after it.  PG_FUZZ="path:seed,..."; prints the worst instances (index, error, iterations, polish outcome)."""
+of 768) -- cold step and the warm step after it.  PG_FUZZ="path:seed,..."; PG_DUMP="step:instance,..." saves those instances; prints the worst instances (index, error, iterations, polish outcome)."""
 import os, sys
 import numpy as np
 from concurrent.futures import ThreadPoolExecutor
@@ -46,6 +46,12 @@ for spec in os.environ.get("PG_FUZZ", "skidpadoval:1,vail:2,EastPaddock:3").spli
         w = np.argsort(-errs)[:4]
         print(f"{path} step {step}: solved {ok.sum()}/{B}, status {np.bincount(st, minlength=5).tolist()}, iters==0 {(it[ok] == 0).sum()}, polish unverified {(pol[ok] < 1).sum()}, > 1e-6: {(errs > 1e-6).sum()}; "
               f"worst (b, err, iters, polish, oracle iters<0 = ADMM fall-back) {[(int(b), float('%.2g' % errs[b]), int(it[b]), int(pol[b]), int(oit[b])) for b in w]}", flush=True)
+        if os.environ.get("PG_DUMP"):                       # "step:b,..." -> gpurun_out/fuzz_dump_<path>_<step>_<b>.npz (QP data, solution, solver outcome)
+            for sp in os.environ["PG_DUMP"].split(","):
+                ds, db = (int(v) for v in sp.split(":"))
+                if ds == step:
+                    os.makedirs("gpurun_out", exist_ok=True)
+                    np.savez(f"gpurun_out/fuzz_dump_{path}_{step}_{db}.npz", qp=qp[db], x=x[db], pol=pol[db], it=it[db], st=st[db], active=mpc.solve_info()[2][db])
         state = np.stack([orcs[0].plant_step(state[b], control[b], 0.01) for b in range(B)]); control = np.where(ok[:, None], u, control); t0 = t0 + 0.01
         if not np.all(ok): mpc.reset(mask=~ok)
     mpc.close()
