@@ -222,13 +222,26 @@ PG_DEV void actuate(const DevVehicle& P, T delta, T Fx, real Ux, T& d_out, T& Fx
 template <class T>
 PG_DEV void body_accel(const DevVehicle& P, T Ux, T Uy, T r, T delta, T Fxf, T Fxr, T& dUx, T& dUy, T& dr) {
     T sd, cd; sincos_(delta, sd, cd);
-    T tf = (Uy + P.a * r) / Ux, td = sd / cd;
-    T taf = (tf - td) / (real(1.0) + tf * td);          // tan(atan2(Uy + a r, Ux) - delta)   (:118)
+    T taf, Fx_drag;
+    if constexpr (is_dk<T>::value) {
+        // forward-mode numbers: tan(alpha_f) as ONE elementary function of (y = Uy + a r, Ux, delta) -- value and three partial derivatives in scalars, one
+        // three-term combination per direction -- instead of carrying every direction through two quotients and the tangent-difference formula; likewise the drag
+        const real iux = frcp(val(Ux)), yv = val(Uy) + P.a * val(r), tfv = yv * iux, tdv = val(sd) * frcp(val(cd));
+        const real iden = frcp(real(1.0) + tfv * tdv), id2 = iden * iden;
+        const real c_y = (real(1.0) + tdv * tdv) * id2 * iux, c_u = -c_y * tfv, c_d = -(real(1.0) + tfv * tfv) * id2 * (real(1.0) + tdv * tdv);
+        taf.v = (tfv - tdv) * iden;
+        const real dd = -(P.Cd1 + real(2.0) * P.Cd2 * val(Ux));
+        Fx_drag.v = -P.Cd0 - val(Ux) * (P.Cd1 + P.Cd2 * val(Ux));
+        PG_DK_LOOP_T(T) { taf.d[k] = c_y * (Uy.d[k] + P.a * r.d[k]) + c_u * Ux.d[k] + c_d * delta.d[k]; Fx_drag.d[k] = dd * Ux.d[k]; }
+    } else {
+        T tf = (Uy + P.a * r) / Ux, td = sd / cd;
+        taf = (tf - td) / (real(1.0) + tf * td);          // tan(atan2(Uy + a r, Ux) - delta)   (:118)
+        Fx_drag = -P.Cd0 - Ux * (P.Cd1 + P.Cd2 * Ux);
+    }
     T tar = (Uy - P.b * r) / Ux;                   // tan(atan2(Uy - b r, Ux))           (:119)
     T Fyf, Fyr;
     T Fxf_t;
     lateral_forces<T>(P, taf, tar, Fxf, Fxr, sd, cd, Fyf, Fyr, &Fxf_t);
-    T Fx_drag = -P.Cd0 - Ux * (P.Cd1 + P.Cd2 * Ux);
     T Fyf_t = Fyf * cd + Fxf * sd;
     const real invm = real(1.0) / P.m, invI = real(1.0) / P.Izz;
     dUx = (Fxf_t + Fxr + Fx_drag) * invm + r * Uy;
