@@ -209,6 +209,11 @@ function set_fusion!(mpc::BatchedTrajectoryTrackingMPC, mode::Integer)
     check(mpc, ccall(sym(mpc, :pg_set_fusion), Cint, (Ptr{Cvoid}, Int32), mpc.handle, Int32(mode)), "pg_set_fusion")
 end
 
+"nodes + update_QP! of a large batch with cold instances as one pipelined launch (pg_set_pipeline; bit-identical results): mode 1 where it applies (default), 0 never"
+function set_pipeline!(mpc::BatchedTrajectoryTrackingMPC, mode::Integer)
+    check(mpc, ccall(sym(mpc, :pg_set_pipeline), Cint, (Ptr{Cvoid}, Int32), mpc.handle, Int32(mode)), "pg_set_pipeline")
+end
+
 "update_HJI_values_marker! / update_HJI_contour_marker! (src/rviz.jl:23-40,60-69) for a batch of relative states q (7 x B): V at every (x, y) knot pair of grid
 dimensions 1, 2 and the zero-level crossings on the grid edges (NaN = none)"
 function hji_value_slice(mpc::BatchedTrajectoryTrackingMPC, q::Matrix{Float64})

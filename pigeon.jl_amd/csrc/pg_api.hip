@@ -18,6 +18,9 @@ struct pg_handle {
     int B = 0;                       // current batch
     int warm_B = 0;                  // instances [0, warm_B) are known to carry a previous solution (solved = true): set by pg_solve, cleared by pg_reset
     hipStream_t stream = nullptr;
+    int pipeline = 1;                                         // pg_set_pipeline: 1 = nodes + update_QP of a large batch with cold instances as one pipelined launch (k_nodes_linearize), 0 = never
+    bool lin_done = false;                                    // this step's launch_nodes already linearised (update_and_solve skips update_QP)
+    int* d_progress = nullptr;                                // [cap / 64 + 1] nodes completed per nodes wavefront (k_nodes_linearize)
     int fuse = 0;                                             // pg_step_dev / pg_simulate_dev: linearisation fused into the solve kernel (pg_set_fusion): 0 never (default), 1 always, 2 for all-warm batches
     std::string err;
     // device buffers
@@ -143,7 +146,7 @@ int pg_default_config_decoupled(pg_config* c) {
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_state, h->d_control, h->d_t0, h->d_other, h->d_toff, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_order, h->d_naux};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_order, h->d_naux, h->d_progress};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->ev_ok) for (int i = 0; i < 4; i++) (void)hipEventDestroy(h->ev[i]);
@@ -189,7 +192,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_sep, cap * 4, real); ALLOC(h->d_nodes, cap * NN * 10, real); ALLOC(h->d_qp, cap * C.qp_len, real);
     ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
     ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_u, cap * 3, real); ALLOC(h->d_mu, cap, real);
-    ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_polish, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_naux, cap * NN * 4, real); ALLOC(h->d_active, cap * N, uint16_t);
+    ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_polish, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_naux, cap * NN * 4, real); ALLOC(h->d_progress, cap / 64 + 2, int); ALLOC(h->d_active, cap * N, uint16_t);
 #ifdef PG_EXPERIMENTAL_SOLVE4
     { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (experimental/pg_solve4.hip)
     if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), real);
@@ -215,6 +218,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     for (int i = 0; i < 4; i++) if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_create_error = "hipEventCreate failed"; free_all(h); delete h; return PG_ERR_HIP; }
     h->ev_ok = true;
     { const char* e = getenv("PG_FUSE"); if (e && e[0] >= '0' && e[0] <= '2') h->fuse = e[0] - '0'; }
+    { const char* e = getenv("PG_PIPELINE"); if (e && e[0] >= '0' && e[0] <= '1') h->pipeline = e[0] - '0'; }
     // horizons up to 32 intervals keep their dynamics blocks resident in LDS (one pass over the QP data); longer ones stream them through a 4-slot ring
     h->solve_ring = N > 32;
 #ifdef PG_EXPERIMENTAL_SOLVE4
@@ -259,6 +263,7 @@ int pg_abi_layout(int32_t* out, int32_t n) {
 }
 int pg_qp_len(const pg_handle* h) { return h ? h->dc.qp_len : PG_ERR_INVALID; }
 int pg_set_stream(pg_handle* h, void* s) { if (!h) return PG_ERR_INVALID; h->stream = (hipStream_t)s; return PG_OK; }
+int pg_set_pipeline(pg_handle* h, int32_t mode) { if (!h || mode < 0 || mode > 1) return PG_ERR_INVALID; h->pipeline = mode; return PG_OK; }
 int pg_set_fusion(pg_handle* h, int32_t mode) { if (!h || mode < 0 || mode > 2) return PG_ERR_INVALID; h->fuse = mode; return PG_OK; }
 int pg_synchronize(pg_handle* h) { if (!h) return PG_ERR_INVALID; HIPCHK(h, hipStreamSynchronize(h->stream)); return PG_OK; }
 
@@ -451,11 +456,23 @@ int pg_compute_linearization_nodes(pg_handle* h) {
     return launch_nodes(h, false);
 }
 // compute_time_steps! + compute_linearization_nodes! of pg_step_dev / pg_simulate_dev: the time grid rides in the projection kernel (one launch fewer)
+// the pipelined nodes + update_QP launch (k_nodes_linearize) serves the steps of pg_step_dev / pg_simulate_dev when: coupled formulation without the safety row (its
+// (M, b) and the re-filed launch order sit between the two phases), some instance is cold (an all-warm batch has no recurrence: k_nodes_warm), the batch is large
+// enough for the linearisation to need several rounds of wavefronts (below, the sum of the two kernels is the latency of the pipeline anyway) and small enough for
+// the nodes wavefronts to be resident at once (<= 256 of the 1024 SIMD slots), and the linearisation is not fused into the solve kernel
+static bool pipeline_applies(const pg_handle* h) {
+    const DevCfg& C = h->dc;
+    const bool fuse_wanted = h->fuse == 1;
+    return h->pipeline == 1 && C.formulation != PG_DECOUPLED && !h->has_hji && h->warm_B < h->B && h->B >= 2048 && h->B <= 16384 && C.Ns > 0 && C.Ns < C.N && !fuse_wanted;
+}
 static int launch_nodes(pg_handle* h, bool with_time_grid) {
     const int B = h->B;
-    if (with_time_grid) hipLaunchKernelGGL(k_project<true>, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep, h->d_t0, h->d_ts, h->d_dt, h->d_prev_ts);
+    const bool pipelined = with_time_grid && pipeline_applies(h);
+    h->lin_done = false;
+    if (with_time_grid) hipLaunchKernelGGL(k_project<true>, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep, h->d_t0, h->d_ts, h->d_dt, h->d_prev_ts,
+                                           pipelined ? h->d_progress : (int*)nullptr, (B + 63) / 64);
     else hipLaunchKernelGGL(k_project<false>, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep, (const double*)nullptr, (double*)nullptr, (double*)nullptr,
-                            (double*)nullptr);
+                            (double*)nullptr, (int*)nullptr, 0);
     LAUNCH_CHECK(h);
     const bool staged = h->dc.n_traj == 1 && h->traj_L <= 2048;
     const size_t traj_lds = staged ? (size_t)2 * h->traj_L * sizeof(real) : 0;
@@ -474,6 +491,21 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
             const long nth = (long)B * h->dc.NN;
             hipLaunchKernelGGL(kern, dim3((unsigned)((nth + 255) / 256)), dim3(256), traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_sep, h->d_ts, h->d_prev_ts, h->d_solx,
                                h->d_nodes, F);
+        } else if (pipelined) {
+            const int nbn = (B + 63) / 64, nbt = (B + 31) / 32;
+            const size_t lds = traj_lds > 64 * 20 * sizeof(real) ? traj_lds : 64 * 20 * sizeof(real);
+            auto kern = staged ? k_nodes_linearize<true> : k_nodes_linearize<false>;
+            int nzf = (1024 - nbn + nbt - 1) / nbt;               // short-horizon intervals that go first: one wavefront for every SIMD the recurrence leaves free
+            if (nzf > h->dc.Ns) nzf = h->dc.Ns;
+            if (nzf < 1) nzf = 1;
+            // nodes after which the recurrence publishes its progress (each publication is a device-scope release, i.e. an L2 write-back): every third node of the
+            // short horizon, every fifth of the long one (N = 30, Ns = 10: nodes 3, 6, 9, 14, 19, 24); the end of the recurrence always publishes
+            unsigned long long pub = 0ull;
+            for (int i = 1; i < h->dc.N - 2 && i < 64; i++)
+                if (i <= h->dc.Ns ? i % 3 == 0 : (i - h->dc.Ns) % 5 == 4) pub |= 1ull << i;
+            hipLaunchKernelGGL(kern, dim3((unsigned)(nbn + nbt * h->dc.N)), block, lds, h->stream, h->dc, B, nbn, nzf, pub, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
+                               h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes, F, h->d_naux, h->d_progress, h->d_qp);
+            h->lin_done = true;
         } else {
             auto kern = staged ? k_nodes<true> : k_nodes<false>;
             hipLaunchKernelGGL(kern, grid, block, traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
@@ -580,6 +612,11 @@ static int update_and_solve(pg_handle* h, hipEvent_t after_update) {
     int rc;
     const bool want = h->fuse == 1 || (h->fuse == 2 && h->warm_B >= h->B && h->B >= 1024);
     const bool fused = want && h->dc.formulation != PG_DECOUPLED && !h->solve_ring && 2 * h->dc.N <= 64 && !h->solve_quad;
+    if (h->lin_done) {                   // the QP data of this step are already there (k_nodes_linearize)
+        h->lin_done = false;
+        if (after_update) HIPCHK(h, hipEventRecord(after_update, h->stream));
+        return pg_solve(h);
+    }
     if (!fused) {
         if ((rc = pg_update_qp(h))) return rc;
         if (after_update) HIPCHK(h, hipEventRecord(after_update, h->stream));

@@ -114,8 +114,9 @@ PG_DEV void time_grid_lane(const DevCfg& C, int i, double t, double* T, double* 
 // writes the instance's time grid (lane = node): pg_step_dev launches time grid + projection as one kernel (TG = true; the fp32 purity check allows fp64
 // arithmetic in that instantiation only).
 template <bool TG> __global__ __launch_bounds__(256) void k_project(DevCfg C, int B, const real* __restrict__ state, real* __restrict__ sep, const double* __restrict__ t0, double* __restrict__ ts,
-                                                 double* __restrict__ dt, double* __restrict__ prev_ts) {
+                                                 double* __restrict__ dt, double* __restrict__ prev_ts, int* __restrict__ progress = nullptr, int n_progress = 0) {
     int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (progress && blockIdx.x == 0) { for (int i = threadIdx.x; i < n_progress; i += blockDim.x) progress[i] = 0; }      // (k_nodes_linearize of this step counts from 0)
     if (wave >= B) return;
     if constexpr (TG) time_grid_lane(C, lane, t0[wave], ts + (size_t)wave * C.NN, dt + (size_t)wave * C.N, prev_ts + (size_t)wave * C.NN);
     const TrajView T = traj_of(C, wave);
@@ -183,9 +184,11 @@ PG_DEV void put_node(real* __restrict__ ND, int i, const NodeRec& r) {
     real* o = ND + i * 10;
     o[0] = r.q0; o[1] = r.q1; o[2] = r.q2; o[3] = r.q3; o[4] = r.q4; o[5] = r.q5; o[6] = r.u0; o[7] = r.u1; o[8] = r.pV; o[9] = r.pK;
 }
-template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, int B, const real* __restrict__ state, const real* __restrict__ control, const tdouble* __restrict__ toff,
+// PUB (k_nodes_linearize, the pipelined nodes + update_QP launch): a wavefront whose 64 instances are all cold publishes, after every node of the seeding
+// recurrence, how many nodes of its instances are complete (`progress[blk]`, release at device scope) -- the linearisation of interval t only needs nodes t, t + 1.
+template <bool STAGED, bool PUB> PG_DEV void nodes_body(const DevCfg& C, int B, int blk, const real* __restrict__ state, const real* __restrict__ control, const tdouble* __restrict__ toff,
                         const int* __restrict__ solved, const real* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt,
-                        const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* __restrict__ nodes, OrderOut F, real* __restrict__ naux) {
+                        const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* __restrict__ nodes, OrderOut F, real* __restrict__ naux, int* __restrict__ progress, unsigned long long pub_mask) {
     // the two searched channels (t, s) are staged in LDS when they fit: every node costs three binary searches whose ~10 dependent probes each
     // would otherwise pay L2 latency (the kernel is a 64-wave serial recurrence: latency, not bandwidth, is its whole cost)
     extern __shared__ real sh_traj[];
@@ -195,8 +198,10 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
         __syncthreads();
         T.t = sh_traj; T.s = sh_traj + T.L;
     }
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    int b = blk * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    bool publish = false;
+    if constexpr (PUB) publish = __all(solved[b] == 0) != 0;          // (over the live lanes of the wavefront; lane 0 is always live)
     if constexpr (!STAGED) T = traj_of(C, b);
     const DevVehicle& P = C.veh;
     const real* q0 = state + (size_t)b * 6; const real* u0 = control + (size_t)b * 3;
@@ -277,6 +282,12 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
             ax[0] = est.ang_y; ax[1] = est.ang_x; ax[2] = est.ang_t; ax[3] = (!shortp && est.beta_is_tan) ? est.tb : NAN;      // (NaN: q4 stands as written)
         }
         if (i == 1) { d1 = atan2(est.ang_y, est.ang_x) - atan(est.ang_t); Fx1 = est.Fx; }          // (the launch-order hint needs this one angle now)
+        if constexpr (PUB) {
+            if (publish && ((pub_mask >> i) & 1ull)) {                 // nodes 0..i of all 64 instances are in memory: release, then the count
+                __threadfence();
+                if (threadIdx.x == 0) __hip_atomic_store(progress + blk, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         real A = est.A;
         V = V + A * tau;
         s = s + V * tau + A * tau * tau * real(0.5);
@@ -288,6 +299,12 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
         for (int k = 0; k < 4; k++) slow = slow || (e.H[k][0] * Uy0 + e.H[k][1] * r0 - e.G[k] > real(-0.05));
         file_order(F, B, b, slow);
     }
+}
+
+template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, int B, const real* __restrict__ state, const real* __restrict__ control, const tdouble* __restrict__ toff,
+                        const int* __restrict__ solved, const real* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt,
+                        const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* __restrict__ nodes, OrderOut F, real* __restrict__ naux) {
+    nodes_body<STAGED, false>(C, B, (int)blockIdx.x, state, control, toff, solved, sep, ts, dt, prev_ts, prev_x, nodes, F, naux, nullptr, 0ull);
 }
 
 // The angles k_nodes deferred (steady_state(.., defer = true)): delta = atan2(y, x) - atan(t) of every seeded node and beta = atan(tb) of the long ones -- the same
@@ -363,13 +380,13 @@ template <bool STAGED> __global__ __launch_bounds__(256) void k_nodes_warm(DevCf
 // Jacobians are bit-identical across K; c differs by the order of its cross-lane sum (1e-16).
 // ND = 6: an interval of the short horizon (zero-order hold: uf is not a variable, directions 6 and 7 vanish identically) with the six remaining directions on
 // G = 6 / K lanes; the Bf block is written as zeros and c sums the same six products in the same order -- the same bits as ND = 8 gives on such an interval.
+// (n0, n1: the node records of the interval's two ends -- in the nodes array, or a copy of them: k_nodes_linearize)
 template <int K, int ND = 8>
-PG_DEV void linearize_lanes(const DevCfg& C, int b, int t, int g, bool live, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb,
-                            real* __restrict__ qp) {
+PG_DEV void linearize_lanes_at(const DevCfg& C, int b, int t, int g, bool live, const real* __restrict__ n0, const real* __restrict__ n1, const tdouble* __restrict__ dt,
+                               const real* __restrict__ hji_Mb, real* __restrict__ qp) {
     typedef DK<K> DT;
     constexpr int G = ND / K;
     const bool ramp = ND == 8 && t >= C.Ns;
-    const real* n0 = nodes + ((size_t)b * C.NN + t) * 10; const real* n1 = n0 + 10;
     const real h_total = dt[(size_t)b * C.N + t];
     DT x[6];
 #pragma unroll
@@ -481,6 +498,12 @@ PG_DEV void linearize_lanes(const DevCfg& C, int b, int t, int g, bool live, con
         Q[o.dt + t] = h_total;
     }
 }
+template <int K, int ND = 8>
+PG_DEV void linearize_lanes(const DevCfg& C, int b, int t, int g, bool live, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb,
+                            real* __restrict__ qp) {
+    const real* n0 = nodes + ((size_t)b * C.NN + t) * 10;
+    linearize_lanes_at<K, ND>(C, b, t, g, live, n0, n0 + 10, dt, hji_Mb, qp);
+}
 PG_DEV void linearize_pair(const DevCfg& C, int b, int t, int g, bool live, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb,
                            real* __restrict__ qp) {
     linearize_lanes<4>(C, b, t, g, live, nodes, dt, hji_Mb, qp);
@@ -509,6 +532,81 @@ __global__ __launch_bounds__(64) void k_linearize(DevCfg C, int B, const real* _
     if (!live) gid = (long)B * per - G + (gid & (G - 1));        // keep the lane group whole for the shuffles; dead lanes store nothing
     const int b = (int)(gid / per); const int rem = (int)(gid - (long)b * per);
     linearize_lanes<K>(C, b, rem / G, rem % G, live, nodes, dt, hji_Mb, qp);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// compute_linearization_nodes! and update_QP! of a batch with cold instances as ONE launch (pg_step_dev / pg_simulate_dev, large batches without the safety row).
+// The cold seeding is a serial recurrence over the 31 nodes of an instance (lane = instance: 64 wavefronts at B = 4096, 0.18 ms of pure latency on 64 of the
+// 1024 SIMDs), and `linearize` of interval t reads nodes t and t + 1 only -- so the linearisation of the early intervals can run while the recurrence is still
+// on its way down the horizon.  Blocks [0, nb_nodes) run the nodes recurrence (the body of k_nodes) and publish their progress after every node; the blocks
+// behind them are the linearisation in INTERVAL-major order (block = 32 instances x 2 lanes of one interval t; t < Ns: three directions per lane, else four --
+// the two instruction streams of k_linearize_split) and wait until nodes t, t + 1 of their 32 instances are published.  The same device functions on the same
+// arguments as the two-launch sequence: bit-identical nodes and QP data.
+//  * Forward progress: workgroups are dispatched in index order, so the nodes blocks are resident before any waiting block (nb_nodes <= 256 of 1024 SIMD slots is
+//    required by the host); they never wait for anything.  A waiting wavefront sleeps between polls and gives up after ~0.1 s: it then poisons its share of the
+//    QP data with NaN (k_solve reports PG_NUMERICAL for those instances) and exits, so the grid drains whatever happens.
+//  * The angles k_nodes defers to k_nodes_angles (delta of every seeded node, -beta of the long ones) are finished by the linearisation lanes from the same
+//    arguments (`naux`) and written into the nodes array by the lanes of the interval that starts at the node (and the last interval for node N).
+//  * Visibility: release (fence + relaxed store at device scope) on the producer side, relaxed polls + acquire fence on the consumer side.  A device-scope release
+//    writes the dirty lines of the XCD's L2 back -- including the QP data the linearisation wavefronts of that XCD are in the middle of writing -- so the recurrence
+//    publishes after a few chosen nodes (`pub_mask`), not after every node: measured, B = 16384: 1.595 ms with 30 publications per wavefront, 1.434 with 6 (two launches:
+//    1.45); fp32 at 8192: 0.572 / 0.483 (0.555); B = 4096: 0.41 / 0.40 (0.53).
+template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_linearize(DevCfg C, int B, int nb_nodes, int nz_first, unsigned long long pub_mask, const real* __restrict__ state, const real* __restrict__ control,
+                        const tdouble* __restrict__ toff, const int* __restrict__ solved, const real* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt,
+                        const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* nodes, OrderOut F, real* naux, int* progress, real* __restrict__ qp) {
+    if ((int)blockIdx.x < nb_nodes) {
+        nodes_body<STAGED, true>(C, B, (int)blockIdx.x, state, control, toff, solved, sep, ts, dt, prev_ts, prev_x, nodes, F, naux, progress, pub_mask);
+        __threadfence();                                                  // (warm or mixed wavefronts publish once, here; every lane is back from the body)
+        if (threadIdx.x == 0) __hip_atomic_store(progress + blockIdx.x, C.NN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    extern __shared__ real sh_rec[];                                      // (the dynamic LDS of the launch: max(trajectory channels, 64 x 20 node-record entries))
+    // a block = one interval t of 32 instances, two lanes each.  Order of the intervals: the first nz_first intervals of the short horizon (enough wavefronts to
+    // fill the machine while the recurrence is still in the short horizon), then the ramp intervals of the long horizon, and the remaining short-horizon
+    // intervals LAST -- the launch ends with its cheapest wavefronts (0.408 -> 0.399 ms; grouping several intervals of an instance in a wavefront: no difference)
+    const int w = (int)blockIdx.x - nb_nodes, nbt = (B + 31) >> 5;
+    int t = w / nbt; const int grp = w - t * nbt;
+    if (t >= nz_first) t = t < nz_first + (C.N - C.Ns) ? t - nz_first + C.Ns : t - (C.N - C.Ns);
+    const int lane = (int)threadIdx.x, g = lane & 1;
+    int b = grp * 32 + (lane >> 1);
+    const bool live = b < B;
+    if (!live) b = B - 1;
+    {
+        const int* flag = progress + ((grp * 32) >> 6);                     // (the nodes wavefront of these 32 instances)
+        const int need = t + 2;                                             // nodes 0 .. t + 1
+        int spins = 0; bool gave_up = false;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > 200000) { gave_up = true; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (gave_up) {
+            if (live && g == 0) { real* Q = qp + (size_t)b * C.qp_len + qp_offsets(C.N).c + 6 * t; for (int i = 0; i < 6; i++) Q[i] = NAN; }
+            return;
+        }
+    }
+    const real* n0g = nodes + ((size_t)b * C.NN + t) * 10;
+    const real* a0 = naux + ((size_t)b * C.NN + t) * 4;
+    real* rec = sh_rec + lane * 20;
+#pragma unroll
+    for (int k = 0; k < 20; k++) rec[k] = n0g[k];
+    {   // k_nodes_angles, for the two nodes of this interval
+        const real y0 = a0[0], x0 = a0[1], t0 = a0[2], b0 = a0[3], y1 = a0[4], x1 = a0[5], t1 = a0[6], b1 = a0[7];
+        if (y0 == y0) {
+            rec[6] = atan2(y0, x0) - atan(t0);
+            if (b0 == b0) rec[4] = -atan(b0);
+            if (live && g == 0) { real* nd = nodes + ((size_t)b * C.NN + t) * 10; nd[6] = rec[6]; nd[4] = rec[4]; }
+        }
+        if (y1 == y1) {
+            rec[16] = atan2(y1, x1) - atan(t1);
+            if (t == C.N - 1) {
+                if (b1 == b1) rec[14] = -atan(b1);
+                if (live && g == 1) { real* nd = nodes + ((size_t)b * C.NN + t + 1) * 10; nd[6] = rec[16]; nd[4] = rec[14]; }
+            }
+        }
+    }
+    if (t < C.Ns) linearize_lanes_at<3, 6>(C, b, t, g, live, rec, rec + 10, dt, nullptr, qp);
+    else linearize_lanes_at<4, 8>(C, b, t, g, live, rec, rec + 10, dt, nullptr, qp);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -240,6 +240,10 @@ class BatchedTrajectoryTrackingMPC:
         """Fused step (update_QP! inside the solve kernel, include/pigeon_mpc.h pg_set_fusion): False / 0 never (the default), True / 1 always, 2 for all-warm batches."""
         self._chk(self.lib.pg_set_fusion(self.h, int(mode)), "pg_set_fusion")
 
+    def set_pipeline(self, mode):
+        """Pipelined nodes + update_QP launch for large batches with cold instances (include/pigeon_mpc.h pg_set_pipeline): True / 1 where it applies (default), False / 0 never."""
+        self._chk(self.lib.pg_set_pipeline(self.h, int(mode)), "pg_set_pipeline")
+
     def phase_ms(self):
         out = (C.c_float * 3)()
         self._chk(self.lib.pg_get_phase_ms(self.h, out), "pg_get_phase_ms")

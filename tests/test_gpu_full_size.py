@@ -241,3 +241,28 @@ def test_fused_step_is_bit_identical(pkg, skidpad):
         mpc.close()
     for a, b in zip(out[False], out[True]):
         assert np.array_equal(a, b)
+
+
+def test_pipelined_nodes_and_update_qp_are_bit_identical(pkg, skidpad):
+    """pg_set_pipeline (default on, 2048 <= B <= 16384 with cold instances): compute_linearization_nodes! and update_QP! run as one launch in which interval t is
+    linearised as soon as nodes t, t + 1 are seeded.  Same device functions on the same arguments: nodes, QP data, solution and controls are bit-identical to the
+    launch-per-phase sequence -- on a cold batch, on a MIXED batch (half the instances reset after a step: their wavefronts publish once, at the end) and with a
+    ragged last wavefront (B not a multiple of 64)."""
+    for Bn in (4096, 2048 + 37):
+        state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, Bn, seed=5)
+        out = {}
+        for piped in (False, True):
+            mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, Bn)
+            mpc.set_pipeline(piped)
+            mpc.set_inputs(state, control, t0, time_offset=toff)
+            mpc.step_dev(); mpc.synchronize()
+            r = [np.concatenate([a.reshape(Bn, -1) for a in mpc.nodes()], axis=1), mpc.qp_data().copy(), mpc.get_next_control().copy(), mpc.solution()[0].copy(), mpc.solve_info()[0].copy()]
+            mask = np.zeros(Bn, bool); mask[::2] = True; mask[:64] = True; mask[64:128] = False
+            mpc.reset(mask)                                   # a batch of cold and warm instances: one all-cold, one all-warm and many mixed wavefronts
+            mpc.step_dev(); mpc.synchronize()
+            r += [np.concatenate([a.reshape(Bn, -1) for a in mpc.nodes()], axis=1), mpc.qp_data().copy(), mpc.get_next_control().copy(), mpc.solve_info()[0].copy()]
+            out[piped] = r
+            mpc.close()
+        assert np.all(out[True][4] == pkg.SOLVED)
+        for a, b in zip(out[False], out[True]):
+            assert np.array_equal(a, b, equal_nan=True)

@@ -15,7 +15,7 @@ import os
 import re
 import sys
 
-TIME_KERNELS = ("k_time_steps", "k_nodes", "k_nodes_warm", "k_nodes_dec", "k_advance")
+TIME_KERNELS = ("k_time_steps", "k_nodes", "k_nodes_linearize", "k_nodes_warm", "k_nodes_dec", "k_advance")
 HARMLESS = re.compile(r"^v_(cvt_|cmp_|cmpx_|frexp_)")
 
 
