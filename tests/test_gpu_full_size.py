@@ -266,3 +266,29 @@ def test_pipelined_nodes_and_update_qp_are_bit_identical(pkg, skidpad):
         assert np.all(out[True][4] == pkg.SOLVED)
         for a, b in zip(out[False], out[True]):
             assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_pipelined_launch_with_a_trajectory_library(pkg):
+    """The pipelined launch with a LIBRARY of tubes and a per-instance selection (the un-staged instantiation: the searched channels stay in memory): bit-identical to
+    the launch-per-phase sequence, at the smallest batch the pipeline serves."""
+    paths = ["skidpadoval", "vail", "EastPaddock", "variable_speed"]
+    tubes = [pkg.load_path_fixture(p) for p in paths]
+    Bn = 2048
+    idx = ((np.arange(Bn) * 7 + 3) % len(tubes)).astype(np.int32)
+    state = np.zeros((Bn, 6)); control = np.zeros((Bn, 3)); t0 = np.zeros(Bn); toff = np.zeros(Bn)
+    for k, t in enumerate(tubes):
+        sel = np.where(idx == k)[0]
+        s_, c_, t_, o_ = pkg.synthetic.config2_inputs(t, len(sel), seed=200 + k, s_range=None if t.s[-1] > 90 else (2.0, 0.4 * t.s[-1]))
+        state[sel], control[sel], t0[sel], toff[sel] = s_, c_, t_, o_
+    out = {}
+    for piped in (False, True):
+        mpc = pkg.BatchedTrajectoryTrackingMPC(tubes, Bn)
+        mpc.set_trajectory_index(idx)
+        mpc.set_pipeline(piped)
+        mpc.set_inputs(state, control, t0, time_offset=toff)
+        mpc.step_dev(); mpc.synchronize()
+        out[piped] = [np.concatenate([a.reshape(Bn, -1) for a in mpc.nodes()], axis=1), mpc.qp_data().copy(), mpc.get_next_control().copy(), mpc.solve_info()[0].copy()]
+        mpc.close()
+    assert np.mean(out[True][3] == pkg.SOLVED) > 0.99
+    for a, b in zip(out[False], out[True]):
+        assert np.array_equal(a, b, equal_nan=True)
