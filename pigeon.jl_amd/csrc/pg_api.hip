@@ -456,14 +456,17 @@ int pg_compute_linearization_nodes(pg_handle* h) {
     return launch_nodes(h, false);
 }
 // compute_time_steps! + compute_linearization_nodes! of pg_step_dev / pg_simulate_dev: the time grid rides in the projection kernel (one launch fewer)
-// the pipelined nodes + update_QP launch (k_nodes_linearize) serves the steps of pg_step_dev / pg_simulate_dev when: coupled formulation without the safety row (its
-// (M, b) and the re-filed launch order sit between the two phases), some instance is cold (an all-warm batch has no recurrence: k_nodes_warm), the batch is large
-// enough for the linearisation to need several rounds of wavefronts (below, the sum of the two kernels is the latency of the pipeline anyway) and small enough for
-// the nodes wavefronts to be resident at once (<= 256 of the 1024 SIMD slots), and the linearisation is not fused into the solve kernel
+// the pipelined nodes + update_QP launch (k_nodes_linearize) serves the steps of pg_step_dev / pg_simulate_dev when: coupled formulation, some instance is cold (an
+// all-warm batch has no recurrence: k_nodes_warm), the batch is large enough for the linearisation to need several rounds of wavefronts (below, the sum of the two
+// kernels is the latency of the pipeline anyway) and small enough for the nodes wavefronts to be resident at once (<= 256 of the 1024 SIMD slots), and the
+// linearisation is not fused into the solve kernel.  With a safety row, its (M, b) -- functions of the measured states only -- are computed BEFORE the launch and the
+// launch order is re-filed after it (k_order_hji needs the verdicts the recurrence files).
+static int launch_hji_rows_compute(pg_handle* h);
+static int launch_hji_order(pg_handle* h);
 static bool pipeline_applies(const pg_handle* h) {
     const DevCfg& C = h->dc;
     const bool fuse_wanted = h->fuse == 1;
-    return h->pipeline == 1 && C.formulation != PG_DECOUPLED && !h->has_hji && h->warm_B < h->B && h->B >= 2048 && h->B <= 16384 && C.Ns > 0 && C.Ns < C.N && !fuse_wanted;
+    return h->pipeline == 1 && C.formulation != PG_DECOUPLED && h->warm_B < h->B && h->B >= 2048 && h->B <= 16384 && C.Ns > 0 && C.Ns < C.N && !fuse_wanted;
 }
 static int launch_nodes(pg_handle* h, bool with_time_grid) {
     const int B = h->B;
@@ -492,6 +495,7 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
             hipLaunchKernelGGL(kern, dim3((unsigned)((nth + 255) / 256)), dim3(256), traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_sep, h->d_ts, h->d_prev_ts, h->d_solx,
                                h->d_nodes, F);
         } else if (pipelined) {
+            { int rc = launch_hji_rows_compute(h); if (rc) return rc; }      // (M, b) of the safety row: read by the lanes that linearise interval 0
             const int nbn = (B + 63) / 64, nbt = (B + 31) / 32;
             const size_t lds = traj_lds > 64 * 20 * sizeof(real) ? traj_lds : 64 * 20 * sizeof(real);
             auto kern = staged ? k_nodes_linearize<true> : k_nodes_linearize<false>;
@@ -504,7 +508,7 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
             for (int i = 1; i < h->dc.N - 2 && i < 64; i++)
                 if (i <= h->dc.Ns ? i % 3 == 0 : (i - h->dc.Ns) % 5 == 4) pub |= 1ull << i;
             hipLaunchKernelGGL(kern, dim3((unsigned)(nbn + nbt * h->dc.N)), block, lds, h->stream, h->dc, B, nbn, nzf, pub, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
-                               h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes, F, h->d_naux, h->d_progress, h->d_qp);
+                               h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes, F, h->d_naux, h->d_progress, h->d_Mb, h->d_qp);
             h->lin_done = true;
         } else {
             auto kern = staged ? k_nodes<true> : k_nodes<false>;
@@ -527,7 +531,9 @@ static int launch_hji_lookup(pg_handle* h, int B, const real* x7_dev, real* out8
     return PG_OK;
 }
 // the safety row of update_QP! (coupled_lat_long.jl:345-346): relative state, value / gradient look-up, (M, b) per instance
-static int launch_hji_rows(pg_handle* h) {
+// (two halves: the rows themselves read the measured states only and may run before the nodes -- the pipelined launch needs (M, b) when it linearises interval 0 --,
+// the re-filed launch order needs the verdicts the nodes kernel filed)
+static int launch_hji_rows_compute(pg_handle* h) {
     if (!h->has_hji) return PG_OK;
     const int B = h->B;
     hipLaunchKernelGGL(k_hji_relstate, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, h->d_state, h->d_other, h->d_x7);
@@ -535,6 +541,11 @@ static int launch_hji_rows(pg_handle* h) {
     int rc = launch_hji_lookup(h, B, h->d_x7, h->d_vg8); if (rc) return rc;
     hipLaunchKernelGGL(k_hji_constraint, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, h->d_x7, h->d_vg8, h->d_control, h->d_Mb);
     LAUNCH_CHECK(h);
+    return PG_OK;
+}
+static int launch_hji_order(pg_handle* h) {
+    if (!h->has_hji) return PG_OK;
+    const int B = h->B;
     if (h->dc.polish && h->order_B == B) {              // launch order again, now that the safety rows are known (k_order_hji)
         const size_t cap = (size_t)h->cfg.batch_capacity;
         OrderOut F{h->d_status, h->d_iters, h->d_polish, h->d_order, h->d_order + cap, h->d_order + cap + 2};
@@ -543,6 +554,10 @@ static int launch_hji_rows(pg_handle* h) {
         LAUNCH_CHECK(h);
     }
     return PG_OK;
+}
+static int launch_hji_rows(pg_handle* h) {
+    int rc = launch_hji_rows_compute(h); if (rc) return rc;
+    return launch_hji_order(h);
 }
 static int launch_linearize(pg_handle* h, int n) {
     // two lanes per (instance, interval) with four tangent directions each; small batches -- a handful of wavefronts whose duration is the latency of one lane --
@@ -614,6 +629,7 @@ static int update_and_solve(pg_handle* h, hipEvent_t after_update) {
     const bool fused = want && h->dc.formulation != PG_DECOUPLED && !h->solve_ring && 2 * h->dc.N <= 64 && !h->solve_quad;
     if (h->lin_done) {                   // the QP data of this step are already there (k_nodes_linearize)
         h->lin_done = false;
+        if ((rc = launch_hji_order(h))) return rc;
         if (after_update) HIPCHK(h, hipEventRecord(after_update, h->stream));
         return pg_solve(h);
     }

@@ -535,7 +535,8 @@ __global__ __launch_bounds__(64) void k_linearize(DevCfg C, int B, const real* _
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// compute_linearization_nodes! and update_QP! of a batch with cold instances as ONE launch (pg_step_dev / pg_simulate_dev, large batches without the safety row).
+// compute_linearization_nodes! and update_QP! of a batch with cold instances as ONE launch (pg_step_dev / pg_simulate_dev, large batches; the (M, b) of a safety row
+// are computed before it).
 // The cold seeding is a serial recurrence over the 31 nodes of an instance (lane = instance: 64 wavefronts at B = 4096, 0.18 ms of pure latency on 64 of the
 // 1024 SIMDs), and `linearize` of interval t reads nodes t and t + 1 only -- so the linearisation of the early intervals can run while the recurrence is still
 // on its way down the horizon.  Blocks [0, nb_nodes) run the nodes recurrence (the body of k_nodes) and publish their progress after every node; the blocks
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(64) void k_linearize(DevCfg C, int B, const real* _
 //    1.45); fp32 at 8192: 0.572 / 0.483 (0.555); B = 4096: 0.41 / 0.40 (0.53).
 template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_linearize(DevCfg C, int B, int nb_nodes, int nz_first, unsigned long long pub_mask, const real* __restrict__ state, const real* __restrict__ control,
                         const tdouble* __restrict__ toff, const int* __restrict__ solved, const real* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt,
-                        const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* nodes, OrderOut F, real* naux, int* progress, real* __restrict__ qp) {
+                        const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* nodes, OrderOut F, real* naux, int* progress, const real* __restrict__ hji_Mb, real* __restrict__ qp) {
     if ((int)blockIdx.x < nb_nodes) {
         nodes_body<STAGED, true>(C, B, (int)blockIdx.x, state, control, toff, solved, sep, ts, dt, prev_ts, prev_x, nodes, F, naux, progress, pub_mask);
         __threadfence();                                                  // (warm or mixed wavefronts publish once, here; every lane is back from the body)
@@ -605,8 +606,8 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_linearize(D
             }
         }
     }
-    if (t < C.Ns) linearize_lanes_at<3, 6>(C, b, t, g, live, rec, rec + 10, dt, nullptr, qp);
-    else linearize_lanes_at<4, 8>(C, b, t, g, live, rec, rec + 10, dt, nullptr, qp);
+    if (t < C.Ns) linearize_lanes_at<3, 6>(C, b, t, g, live, rec, rec + 10, dt, hji_Mb, qp);
+    else linearize_lanes_at<4, 8>(C, b, t, g, live, rec, rec + 10, dt, hji_Mb, qp);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -162,3 +162,39 @@ def test_value_slices_colours_and_zero_contour(pkg, oracle_mod, skidpad, precisi
                 assert abs(mpc.hji_lookup(np.array([x, y] + list(q[b, 2:])))[0][0]) <= (1e-9 if precision == "f64" else 1e-4)
     assert n_lines >= 3
     mpc.close()
+
+
+def test_pipelined_launch_with_the_safety_row(pkg, skidpad):
+    """pg_set_pipeline with an HJI grid installed: (M, b) are computed before the pipelined nodes + update_QP launch and the launch order is re-filed after it.
+    Same kernels on the same inputs.  fp64: the safety rows, the QP data and the controls are bit-identical to the launch-per-phase sequence.  fp32: the rows are
+    bit-identical, the QP data agree to fp32 rounding (the compiler contracts the fp32 tangent arithmetic differently inside the larger kernel), the controls to the
+    sensitivity of an fp32 solve to such rounding."""
+    knots, V, g = pkg.synthetic.hji_grid(dims=(7, 6, 5, 4, 4, 5, 4), seed=11)
+    n = 2048
+    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, n, seed=31)
+    other = pkg.synthetic.other_cars(state, seed=6)
+    for prec in ("f64", "f32"):
+        out = {}
+        for piped in (False, True):
+            mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, n, precision=prec, hji_eps=10.0)
+            mpc.set_hji_cache(knots, V, g)
+            mpc.set_pipeline(piped)
+            mpc.set_inputs(state, control, t0, other_car_state=other, time_offset=toff)
+            mpc.step_dev(); mpc.synchronize()
+            M, b, Vv = mpc.hji_constraint()
+            un2 = np.asarray(mpc.u_normalization, dtype=float)
+            out[piped] = [M.copy(), b.copy(), mpc.qp_data().copy(), mpc.get_next_control().copy(), mpc.solve_info()[0].copy(), mpc.solve_info()[1].copy()]
+            mpc.close()
+        assert np.sum(out[True][0] != 0.0) > 50                                   # rows are active
+        assert np.mean(out[True][4] == pkg.SOLVED) > 0.9
+        if prec == "f64":
+            for a, c in zip(out[False], out[True]):
+                assert np.array_equal(a, c, equal_nan=True)
+        else:
+            assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1])
+            qa, qc = out[False][2], out[True][2]
+            assert np.max(np.abs(qa - qc) / np.maximum(1.0, np.abs(qa))) < 5e-6
+            both = (out[False][4] == pkg.SOLVED) & (out[True][4] == pkg.SOLVED)
+            un = np.array([un2[0], un2[1], un2[1]])
+            err = np.abs(out[False][3][both] - out[True][3][both]) / un
+            assert np.median(err) < 1e-4 and err.max() < 2e-2, (np.median(err), err.max())
