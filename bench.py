@@ -410,7 +410,7 @@ def main():
         total = world * B * args.steps
         value = total / elapsed
         names = ["nodes(time_steps+project+nodes)", "update_qp(hji+linearize)", "solve(k_solve+extract)"]
-        # pg_set_pipeline (default for 2048..16384 cold instances without the safety row): nodes and update_QP are ONE launch (k_nodes_linearize) and the event between
+        # pg_set_pipeline (default for 2048..8192 instances with cold ones): nodes and update_QP are ONE launch (k_nodes_linearize) and the event between
         # the two phases falls behind it -- the first phase then holds both
         pipelined = float(ph[1]) < 0.02 and float(ph[0]) > 0.1
         if pipelined:

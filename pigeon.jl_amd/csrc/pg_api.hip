@@ -458,7 +458,7 @@ int pg_compute_linearization_nodes(pg_handle* h) {
 // compute_time_steps! + compute_linearization_nodes! of pg_step_dev / pg_simulate_dev: the time grid rides in the projection kernel (one launch fewer)
 // the pipelined nodes + update_QP launch (k_nodes_linearize) serves the steps of pg_step_dev / pg_simulate_dev when: coupled formulation, some instance is cold (an
 // all-warm batch has no recurrence: k_nodes_warm), the batch is large enough for the linearisation to need several rounds of wavefronts (below, the sum of the two
-// kernels is the latency of the pipeline anyway) and small enough for the nodes wavefronts to be resident at once (<= 256 of the 1024 SIMD slots), and the
+// kernels is the latency of the pipeline anyway) and small enough for it to pay and for the nodes wavefronts to be resident at once (<= 8192 instances = 128 of the 1024 SIMD slots; at 16384 the launch breaks even), and the
 // linearisation is not fused into the solve kernel.  With a safety row, its (M, b) -- functions of the measured states only -- are computed BEFORE the launch and the
 // launch order is re-filed after it (k_order_hji needs the verdicts the recurrence files).
 static int launch_hji_rows_compute(pg_handle* h);
@@ -466,7 +466,7 @@ static int launch_hji_order(pg_handle* h);
 static bool pipeline_applies(const pg_handle* h) {
     const DevCfg& C = h->dc;
     const bool fuse_wanted = h->fuse == 1;
-    return h->pipeline == 1 && C.formulation != PG_DECOUPLED && h->warm_B < h->B && h->B >= 2048 && h->B <= 16384 && C.Ns > 0 && C.Ns < C.N && !fuse_wanted;
+    return h->pipeline == 1 && C.formulation != PG_DECOUPLED && h->warm_B < h->B && h->B >= 2048 && h->B <= 8192 && C.Ns > 0 && C.Ns < C.N && !fuse_wanted;
 }
 static int launch_nodes(pg_handle* h, bool with_time_grid) {
     const int B = h->B;
