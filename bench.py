@@ -233,7 +233,7 @@ def main():
         one_step(cold=False)
     sync(); warm_elapsed = time.perf_counter() - tw
     # the same cold workload with the active-set guess OFF (every instance through the interior point; round-2-mid behaviour), as a reference for what the guess buys
-    ipm_only = None; fused_line = None
+    ipm_only = None; fused_line = None; per_phase_line = None
     if rank == 0 and world == 1 and not args.no_warm:
         m0 = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision=args.precision, cold_guess=0)
         m0.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -260,6 +260,17 @@ def main():
         fused_line = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": [float(v) for v in mpc.phase_ms()],
                       "config": "pg_set_fusion(1): the wave that solves an instance linearises it first (one kernel for update_QP! + solve!); off by default"}
         mpc.set_fusion(0)
+        # ... and with one launch per phase (pg_set_pipeline(0): nodes, update_QP!, solve as three kernels; the default pipelines the first two, bit-identical in fp64)
+        mpc.set_pipeline(0)
+        for _ in range(2):
+            mpc.reset(); mpc.step_dev(u_out.data_ptr())
+        torch.cuda.synchronize(); t_ = time.perf_counter()
+        for _ in range(args.steps):
+            mpc.reset(); mpc.step_dev(u_out.data_ptr())
+        torch.cuda.synchronize(); t_ = time.perf_counter() - t_
+        per_phase_line = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": [float(v) for v in mpc.phase_ms()],
+                          "config": "pg_set_pipeline(0): nodes (k_nodes), update_QP! (k_linearize_split) and solve as one launch each; the default runs the first two as one pipelined launch"}
+        mpc.set_pipeline(1)
         mpc.reset(); mpc.step_dev(u_out.data_ptr()); torch.cuda.synchronize()         # (leave the headline controller's outputs as the last thing in u_out)
     # a user-level way to more throughput: the same batch as two halves on two handles / two streams, submitted alternately -- the latency-bound nodes kernel of one
     # half (64 wavefronts on a 1024-SIMD part) runs under the throughput-bound kernels of the other.  Reported beside the headline, never as `value`.
@@ -467,6 +478,8 @@ def main():
         if two_streams is not None:
             line["two_half_batches_on_two_streams"] = two_streams
             line["fused_step"] = fused_line
+        if per_phase_line is not None:
+            line["launch_per_phase"] = per_phase_line
         if roll is not None:
             line["closed_loop_rollout"] = roll
         if hji is not None:
