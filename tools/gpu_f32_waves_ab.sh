@@ -9,9 +9,10 @@ import sys,json; d=json.loads(sys.stdin.read()); f=d['fp32']; w=f['without_hji']
 print('$1 config3', round(f['value']), [round(x,4) for x in f['phase_ms']], f['solved'], f.get('polished'), 'without_hji', (round(w['value']), [round(x,4) for x in w['phase_ms']]) if isinstance(w,dict) else w)"
   timeout -k 10 300 python $B --no-hji --no-f32 --precision f32 --batch 8192 > gpurun_out/bench_f32_8192_$1.log 2>&1
   tail -1 gpurun_out/bench_f32_8192_$1.log | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); print('$1 f32 8192', round(d['value']), [round(x,4) for x in d['phase_ms'].values()], d['solved'])"
+import sys,json; d=json.loads(sys.stdin.read()); print('$1 f32 8192', round(d['value']), [round(x,4) for x in d['phase_ms'].values()], d['solved'], d['ipm_iters_hist'], d['polish_rounds_hist'])"
 }
 run base
 cp pigeon.jl_amd/csrc/libpigeon_hip_f32.so /tmp/f32_w2.so && cp pigeon.jl_amd/csrc/libpigeon_hip_f32_w1.so pigeon.jl_amd/csrc/libpigeon_hip_f32.so
 run ext
+timeout -k 10 400 python -m pytest tests/test_gpu_f32.py -m gpu -x -q 2>&1 | tail -3
 cp /tmp/f32_w2.so pigeon.jl_amd/csrc/libpigeon_hip_f32.so
