@@ -189,19 +189,22 @@ PG_DEV real inv_fiala_tan3(real Fy, real three_over_Ca, real Fy_max) {
 template <class T>
 PG_DEV void lateral_forces(const DevVehicle& P, T af, T ar, T Fxf, T Fxr, T sd, T cd, T& Fyf, T& Fyr, T* Fxf_t_out = nullptr) {   // af, ar: TANGENTS of the slip angles
     const real W_b = P.m * P.G * P.b, W_a = P.m * P.G * P.a, invL = real(1.0) / P.L;
+    const real hL = P.h * invL, WbL = W_b * invL, WaL = W_a * invL;        // (forward-mode numbers: one multiplication per direction instead of two)
     Fyf = cst<T>(real(0.0));
     const T FxfC = Fxf * cd;                       // (formed once: the loop and the caller used to multiply it out four times; same association, same bits)
     T Fxt = FxfC;
     T Fx = FxfC + Fxr;
 #pragma unroll 1
     for (int i = 0; i < 3; i++) {
-        T Fzf = (W_b - P.h * Fx) * invL;
+        T Fzf;
+        if constexpr (is_dk<T>::value) Fzf = WbL - hL * Fx; else Fzf = (W_b - P.h * Fx) * invL;
         Fyf = fiala<T>(af, P.Caf, P.mu, Fxf, Fzf);
         Fxt = FxfC - Fyf * sd;                     // the longitudinal front force in the body frame at this load-transfer iterate
         Fx = Fxt + Fxr;
     }
     if (Fxf_t_out) *Fxf_t_out = Fxt;
-    T Fzr = (W_a + P.h * Fx) * invL;
+    T Fzr;
+    if constexpr (is_dk<T>::value) Fzr = WaL + hL * Fx; else Fzr = (W_a + P.h * Fx) * invL;
     Fyr = fiala<T>(ar, P.Car, P.mu, Fxr, Fzr);
 }
 
@@ -222,7 +225,7 @@ PG_DEV void actuate(const DevVehicle& P, T delta, T Fx, real Ux, T& d_out, T& Fx
 template <class T>
 PG_DEV void body_accel(const DevVehicle& P, T Ux, T Uy, T r, T delta, T Fxf, T Fxr, T& dUx, T& dUy, T& dr) {
     T sd, cd; sincos_(delta, sd, cd);
-    T taf, Fx_drag;
+    T taf, tar, Fx_drag;
     if constexpr (is_dk<T>::value) {
         // forward-mode numbers: tan(alpha_f) as ONE elementary function of (y = Uy + a r, Ux, delta) -- value and three partial derivatives in scalars, one
         // three-term combination per direction -- instead of carrying every direction through two quotients and the tangent-difference formula; likewise the drag
@@ -233,12 +236,15 @@ PG_DEV void body_accel(const DevVehicle& P, T Ux, T Uy, T r, T delta, T Fxf, T F
         const real dd = -(P.Cd1 + real(2.0) * P.Cd2 * val(Ux));
         Fx_drag.v = -P.Cd0 - val(Ux) * (P.Cd1 + P.Cd2 * val(Ux));
         PG_DK_LOOP_T(T) { taf.d[k] = c_y * (Uy.d[k] + P.a * r.d[k]) + c_u * Ux.d[k] + c_d * delta.d[k]; Fx_drag.d[k] = dd * Ux.d[k]; }
+        tar.v = (val(Uy) - P.b * val(r)) * iux;                                   // tan(atan2(Uy - b r, Ux)) with the reciprocal at hand
+        const real t_u = -tar.v * iux;
+        PG_DK_LOOP_T(T) tar.d[k] = iux * (Uy.d[k] - P.b * r.d[k]) + t_u * Ux.d[k];
     } else {
         T tf = (Uy + P.a * r) / Ux, td = sd / cd;
         taf = (tf - td) / (real(1.0) + tf * td);          // tan(atan2(Uy + a r, Ux) - delta)   (:118)
         Fx_drag = -P.Cd0 - Ux * (P.Cd1 + P.Cd2 * Ux);
+        tar = (Uy - P.b * r) / Ux;                 // tan(atan2(Uy - b r, Ux))           (:119)
     }
-    T tar = (Uy - P.b * r) / Ux;                   // tan(atan2(Uy - b r, Ux))           (:119)
     T Fyf, Fyr;
     T Fxf_t;
     lateral_forces<T>(P, taf, tar, Fxf, Fxr, sd, cd, Fyf, Fyr, &Fxf_t);
