@@ -19,6 +19,7 @@ struct pg_handle {
     int warm_B = 0;                  // instances [0, warm_B) are known to carry a previous solution (solved = true): set by pg_solve, cleared by pg_reset
     hipStream_t stream = nullptr;
     int pipeline = 1;                                         // pg_set_pipeline: 1 = nodes + update_QP of a large batch with cold instances as one pipelined launch (k_nodes_linearize), 0 = never
+    bool pipe_fault = false;                                  // PG_PIPE_FAULT=1: fault injection for the pipelined launch (its nodes blocks never publish)
     bool lin_done = false;                                    // this step's launch_nodes already linearised (update_and_solve skips update_QP)
     int* d_progress = nullptr;                                // [cap / 64 + 1] nodes completed per nodes wavefront (k_nodes_linearize)
     int fuse = 0;                                             // pg_step_dev / pg_simulate_dev: linearisation fused into the solve kernel (pg_set_fusion): 0 never (default), 1 always, 2 for all-warm batches
@@ -219,6 +220,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     h->ev_ok = true;
     { const char* e = getenv("PG_FUSE"); if (e && e[0] >= '0' && e[0] <= '2') h->fuse = e[0] - '0'; }
     { const char* e = getenv("PG_PIPELINE"); if (e && e[0] >= '0' && e[0] <= '1') h->pipeline = e[0] - '0'; }
+    { const char* e = getenv("PG_PIPE_FAULT"); h->pipe_fault = e && e[0] == '1'; }
     // horizons up to 32 intervals keep their dynamics blocks resident in LDS (one pass over the QP data); longer ones stream them through a 4-slot ring
     h->solve_ring = N > 32;
 #ifdef PG_EXPERIMENTAL_SOLVE4
@@ -505,8 +507,9 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
             // nodes after which the recurrence publishes its progress (each publication is a device-scope release, i.e. an L2 write-back): every third node of the
             // short horizon, every fifth of the long one (N = 30, Ns = 10: nodes 3, 6, 9, 14, 19, 24); the end of the recurrence always publishes
             unsigned long long pub = 0ull;
-            for (int i = 1; i < h->dc.N - 2 && i < 64; i++)
+            for (int i = 1; i < h->dc.N - 2 && i < 63; i++)
                 if (i <= h->dc.Ns ? i % 3 == 0 : (i - h->dc.Ns) % 5 == 4) pub |= 1ull << i;
+            if (h->pipe_fault) pub = 1ull << 63;                  // test hook: nothing is ever published (tests/test_gpu_api_contract.py)
             hipLaunchKernelGGL(kern, dim3((unsigned)(nbn + nbt * h->dc.N)), block, lds, h->stream, h->dc, B, nbn, nzf, pub, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
                                h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes, F, h->d_naux, h->d_progress, h->d_Mb, h->d_qp);
             h->lin_done = true;

@@ -558,7 +558,8 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_linearize(D
     if ((int)blockIdx.x < nb_nodes) {
         nodes_body<STAGED, true>(C, B, (int)blockIdx.x, state, control, toff, solved, sep, ts, dt, prev_ts, prev_x, nodes, F, naux, progress, pub_mask);
         __threadfence();                                                  // (warm or mixed wavefronts publish once, here; every lane is back from the body)
-        if (threadIdx.x == 0) __hip_atomic_store(progress + blockIdx.x, C.NN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (bit 63 of pub_mask = fault injection, PG_PIPE_FAULT=1 at pg_create: the recurrence never publishes, so that a test can watch every waiting wavefront give up)
+        if (threadIdx.x == 0 && !(pub_mask >> 63)) __hip_atomic_store(progress + blockIdx.x, C.NN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     extern __shared__ real sh_rec[];                                      // (the dynamic LDS of the launch: max(trajectory channels, 64 x 20 node-record entries))

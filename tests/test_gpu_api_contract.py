@@ -56,3 +56,24 @@ def test_reset_mask_restarts_only_the_masked_instances(pkg, skidpad):
     assert np.array_equal(qa[sel], qc[sel]) and np.array_equal(qa[~sel], qb[~sel])
     assert not np.array_equal(qb[sel], qc[sel])
     a.close(); b.close()
+
+
+def test_pipelined_launch_drains_when_the_recurrence_never_publishes(pkg, skidpad, monkeypatch):
+    """Fault injection for k_nodes_linearize (PG_PIPE_FAULT=1, read at pg_create): the nodes blocks never publish their progress.  Every waiting linearisation
+    wavefront must give up after its bounded number of polls, poison its share of the QP data and exit -- the launch drains, the step returns, every instance
+    is reported PG_NUMERICAL (never a stale or half-written QP solved as if nothing had happened), and the handle works again with the pipeline off."""
+    import time
+    B = 2048
+    monkeypatch.setenv("PG_PIPE_FAULT", "1")
+    mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, B)
+    monkeypatch.delenv("PG_PIPE_FAULT")
+    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B, seed=3)
+    t = time.perf_counter()
+    u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
+    elapsed = time.perf_counter() - t
+    assert np.all(status == pkg.NUMERICAL), np.bincount(status)
+    assert elapsed < 60.0, elapsed
+    mpc.set_pipeline(0); mpc.reset()
+    u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
+    assert np.all(status == pkg.SOLVED)
+    mpc.close()
