@@ -15,5 +15,5 @@ u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
 qs, us, ps = mpc.nodes(); sep = mpc.path_coordinates(); pol = mpc.polish_info(); st, it, act, mu = mpc.solve_info()
 nact = np.array([[bin(int(m)).count("1") for m in row] for row in act])
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-np.savez_compressed(os.path.join(ROOT, "gpurun_out", f"rounds_features_{name}.npz"), state=state, control=control, qs=qs, us=us, ps=ps, sep=sep, pol=pol, iters=it, nact=nact, u=u)
+np.savez_compressed(os.path.join(ROOT, "gpurun_out", f"rounds_features_{name}.npz"), state=state, control=control, qs=qs, us=us, ps=ps, sep=sep, pol=pol, iters=it, nact=nact, u=u, act=act)
 print("rounds hist", np.bincount(np.maximum(pol, 0)), "active rows mean", nact.sum(1).mean())
