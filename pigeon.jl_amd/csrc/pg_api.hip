@@ -42,6 +42,8 @@ struct pg_handle {
     hipEvent_t ev[4]; bool ev_ok = false; float phase_ms[3] = {0, 0, 0}; bool timing_valid = false;
     size_t solve_lds = 0; bool solve_ring = false;
     real* d_walls = nullptr;                                    // [cap][N][2] wall extension
+    char* d_in = nullptr; char* d_out = nullptr;             // the five input arrays / (u, status, iters) as ONE allocation each: a batch that fills the handle travels in one copy per direction
+    size_t in_bytes = 0, out_bytes = 0, in_dbl_off = 0;        // (layout by capacity: [state 6][control 3][other 4] real, then at in_dbl_off [t0][time_offset] double; [u 3] real, [status][iters] int)
     char* h_stage = nullptr; size_t stage_bytes = 0;            // pinned host staging of pg_set_inputs / pg_step (one stream synchronisation per call instead of one per array)
     real* d_ws4 = nullptr; bool solve_quad = false; size_t solve4_lds = 0;   // k_solve4 (four instances per wavefront)
 };
@@ -146,8 +148,8 @@ int pg_default_config_decoupled(pg_config* c) {
 }
 
 static void free_all(pg_handle* h) {
-    void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_state, h->d_control, h->d_t0, h->d_other, h->d_toff, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_u, h->d_mu, h->d_status, h->d_iters, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_order, h->d_naux, h->d_progress};
+    void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_in, h->d_out, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_order, h->d_naux, h->d_progress};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->ev_ok) for (int i = 0; i < 4; i++) (void)hipEventDestroy(h->ev[i]);
@@ -188,12 +190,15 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     C.polish = cfg->polish != 0; C.polish_rho = (real)cfg->polish_rho; C.polish_tol = (real)cfg->polish_tol; C.polish_ipm_tol = (real)cfg->polish_ipm_tol; C.warm_polish = cfg->warm_polish != 0; C.cold_guess = cfg->cold_guess > 0 ? cfg->cold_guess : 0;
     const size_t cap = (size_t)cfg->batch_capacity; const int N = C.N, NN = C.NN;
 #define ALLOC(ptr, count, type) do { if (hipMalloc((void**)&(ptr), (size_t)(count) * sizeof(type)) != hipSuccess) { g_create_error = "hipMalloc failed for " #ptr; free_all(h); delete h; return PG_ERR_HIP; } } while (0)
-    ALLOC(h->d_state, cap * 6, real); ALLOC(h->d_control, cap * 3, real); ALLOC(h->d_t0, cap, double); ALLOC(h->d_other, cap * 4, real); ALLOC(h->d_toff, cap, double);
+    h->in_dbl_off = (cap * 13 * sizeof(real) + 7) / 8 * 8; h->in_bytes = h->in_dbl_off + cap * 16; h->out_bytes = cap * (3 * sizeof(real) + 8);
+    ALLOC(h->d_in, h->in_bytes, char); ALLOC(h->d_out, h->out_bytes, char);
+    h->d_state = (real*)h->d_in; h->d_control = h->d_state + cap * 6; h->d_other = h->d_control + cap * 3; h->d_t0 = (double*)(h->d_in + h->in_dbl_off); h->d_toff = h->d_t0 + cap;
+    h->d_u = (real*)h->d_out; h->d_status = (int*)(h->d_u + cap * 3); h->d_iters = h->d_status + cap;
     ALLOC(h->d_solved, cap, int); ALLOC(h->d_mask, cap, uint8_t); ALLOC(h->d_ts, cap * NN, double); ALLOC(h->d_dt, cap * N, double); ALLOC(h->d_prev_ts, cap * NN, double);
     ALLOC(h->d_sep, cap * 4, real); ALLOC(h->d_nodes, cap * NN * 10, real); ALLOC(h->d_qp, cap * C.qp_len, real);
     ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
-    ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_u, cap * 3, real); ALLOC(h->d_mu, cap, real);
-    ALLOC(h->d_status, cap, int); ALLOC(h->d_iters, cap, int); ALLOC(h->d_polish, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_naux, cap * NN * 4, real); ALLOC(h->d_progress, cap / 64 + 2, int); ALLOC(h->d_active, cap * N, uint16_t);
+    ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_mu, cap, real);
+    ALLOC(h->d_polish, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_naux, cap * NN * 4, real); ALLOC(h->d_progress, cap / 64 + 2, int); ALLOC(h->d_active, cap * N, uint16_t);
 #ifdef PG_EXPERIMENTAL_SOLVE4
     { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (experimental/pg_solve4.hip)
     if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), real);
@@ -201,7 +206,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     if (cfg->walls) { ALLOC(h->d_walls, cap * N * 2, real); C.walls = 1; C.wall_weight = (real)cfg->wall_weight; C.wall_edges = h->d_walls; if (h->solve_quad) { g_create_error = "PG_SOLVER=quad does not carry the wall rows"; free_all(h); delete h; return PG_ERR_INVALID; } }
     ALLOC(h->d_pol_u2, cap * 2, real); ALLOC(h->d_pol_u, cap * 3, real); ALLOC(h->d_pol_src, cap, int);
 #undef ALLOC
-    h->stage_bytes = cap * (13 * sizeof(real) + 16);          // inputs: state 6 + control 3 + other 4 (real) + t0 + time_offset (double); outputs reuse the front of it
+    h->stage_bytes = h->in_bytes > h->out_bytes ? h->in_bytes : h->out_bytes;          // inputs: state 6 + control 3 + other 4 (real) + t0 + time_offset (double); outputs reuse the front of it
     if (hipHostMalloc((void**)&h->h_stage, h->stage_bytes, hipHostMallocDefault) != hipSuccess) { g_create_error = "hipHostMalloc failed for the staging buffer"; free_all(h); delete h; return PG_ERR_HIP; }
     // initial ts = 1..NN (model_predictive_control.jl:13), solved = false
     {
@@ -404,8 +409,20 @@ static int set_inputs(pg_handle* h, int32_t B, const void* state, const void* co
         // from there with asynchronous copies ordered before the kernels on the handle's stream: no synchronisation on the way in.  A previous call's
         // copies must have left the buffer first.
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        real* st = (real*)h->h_stage; real* ct = st + (size_t)B * 6; real* ot = ct + (size_t)B * 3; double* tt = (double*)(ot + (size_t)B * 4); double* ft = tt + B;
         const double* s_ = (const double*)state; const double* c_ = (const double*)control; const double* o_ = (const double*)other;
+        if (B == h->cfg.batch_capacity) {
+            // the batch fills the handle: the staging buffer takes the layout of the device block and ONE copy carries all five arrays (a single controller at
+            // 100 Hz -- B = capacity = 1 -- used to pay five copies and two memsets of a few bytes each per step)
+            real* st = (real*)h->h_stage; real* ct = st + (size_t)B * 6; real* ot = ct + (size_t)B * 3; double* tt = (double*)(h->h_stage + h->in_dbl_off); double* ft = tt + B;
+            for (size_t i = 0; i < (size_t)B * 6; i++) st[i] = (real)s_[i];
+            for (size_t i = 0; i < (size_t)B * 3; i++) ct[i] = (real)c_[i];
+            for (size_t i = 0; i < (size_t)B * 4; i++) ot[i] = o_ ? (real)o_[i] : real(0.0);
+            memcpy(tt, t0, (size_t)B * 8);
+            if (toff) memcpy(ft, toff, (size_t)B * 8); else memset(ft, 0xFF, (size_t)B * 8);      // all-ones bit pattern is a NaN: path-tracking mode
+            HIPCHK(h, hipMemcpyAsync(h->d_in, h->h_stage, h->in_bytes, kind, h->stream));
+            return PG_OK;
+        }
+        real* st = (real*)h->h_stage; real* ct = st + (size_t)B * 6; real* ot = ct + (size_t)B * 3; double* tt = (double*)(h->h_stage + ((size_t)B * 13 * sizeof(real) + 7) / 8 * 8); double* ft = tt + B;
         for (size_t i = 0; i < (size_t)B * 6; i++) st[i] = (real)s_[i];
         for (size_t i = 0; i < (size_t)B * 3; i++) ct[i] = (real)c_[i];
         if (o_) for (size_t i = 0; i < (size_t)B * 4; i++) ot[i] = (real)o_[i];
@@ -474,18 +491,18 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
     const int B = h->B;
     const bool pipelined = with_time_grid && pipeline_applies(h);
     h->lin_done = false;
+    const size_t cap = (size_t)h->cfg.batch_capacity;
+    const bool file = h->dc.formulation != PG_DECOUPLED && h->dc.polish;
+    int* const order_cnt = file ? h->d_order + cap : (int*)nullptr;            // the two counters of the launch order start from zero: the projection kernel clears them (no memset of its own)
     if (with_time_grid) hipLaunchKernelGGL(k_project<true>, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep, h->d_t0, h->d_ts, h->d_dt, h->d_prev_ts,
-                                           pipelined ? h->d_progress : (int*)nullptr, (B + 63) / 64);
+                                           pipelined ? h->d_progress : (int*)nullptr, (B + 63) / 64, order_cnt);
     else hipLaunchKernelGGL(k_project<false>, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep, (const double*)nullptr, (double*)nullptr, (double*)nullptr,
-                            (double*)nullptr, (int*)nullptr, 0);
+                            (double*)nullptr, (int*)nullptr, 0, order_cnt);
     LAUNCH_CHECK(h);
     const bool staged = h->dc.n_traj == 1 && h->traj_L <= 2048;
     const size_t traj_lds = staged ? (size_t)2 * h->traj_L * sizeof(real) : 0;
     const dim3 grid((B + 63) / 64), block(64);
-    const size_t cap = (size_t)h->cfg.batch_capacity;
-    const bool file = h->dc.formulation != PG_DECOUPLED && h->dc.polish;
     OrderOut F{h->d_status, h->d_iters, h->d_polish, file ? h->d_order : nullptr, h->d_order + cap, h->d_order + cap + 2};
-    if (file) HIPCHK(h, hipMemsetAsync(h->d_order + cap, 0, 2 * sizeof(int), h->stream));
     h->order_B = file ? B : 0;
     if (h->dc.formulation == PG_DECOUPLED) {
         auto kern = staged ? k_nodes_dec<true> : k_nodes_dec<false>;
@@ -753,9 +770,13 @@ int pg_step(pg_handle* h, int32_t B, const double* state, const double* control,
     // controls, status and iteration counts come back through the pinned staging buffer: three asynchronous copies behind k_solve on the handle's stream
     // (ordered even when the caller installed a non-blocking stream), ONE synchronisation, then the conversion into the caller's arrays
     real* us = (real*)h->h_stage; int* ss = (int*)(us + (size_t)B * 3); int* is = ss + B;
-    if (u_out) HIPCHK(h, hipMemcpyAsync(us, h->d_u, (size_t)B * 3 * sizeof(real), hipMemcpyDeviceToHost, h->stream));
-    if (status) HIPCHK(h, hipMemcpyAsync(ss, h->d_status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    if (iters) HIPCHK(h, hipMemcpyAsync(is, h->d_iters, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (B == h->cfg.batch_capacity) {          // (u, status, iters) are one block on the device: one copy
+        HIPCHK(h, hipMemcpyAsync(h->h_stage, h->d_out, h->out_bytes, hipMemcpyDeviceToHost, h->stream));
+    } else {
+        if (u_out) HIPCHK(h, hipMemcpyAsync(us, h->d_u, (size_t)B * 3 * sizeof(real), hipMemcpyDeviceToHost, h->stream));
+        if (status) HIPCHK(h, hipMemcpyAsync(ss, h->d_status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        if (iters) HIPCHK(h, hipMemcpyAsync(is, h->d_iters, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (u_out) for (size_t i = 0; i < (size_t)B * 3; i++) u_out[i] = (double)us[i];
     if (status) memcpy(status, ss, (size_t)B * sizeof(int));

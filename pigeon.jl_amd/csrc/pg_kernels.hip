@@ -114,9 +114,10 @@ PG_DEV void time_grid_lane(const DevCfg& C, int i, double t, double* T, double* 
 // writes the instance's time grid (lane = node): pg_step_dev launches time grid + projection as one kernel (TG = true; the fp32 purity check allows fp64
 // arithmetic in that instantiation only).
 template <bool TG> __global__ __launch_bounds__(256) void k_project(DevCfg C, int B, const real* __restrict__ state, real* __restrict__ sep, const double* __restrict__ t0, double* __restrict__ ts,
-                                                 double* __restrict__ dt, double* __restrict__ prev_ts, int* __restrict__ progress = nullptr, int n_progress = 0) {
+                                                 double* __restrict__ dt, double* __restrict__ prev_ts, int* __restrict__ progress = nullptr, int n_progress = 0, int* __restrict__ order_cnt = nullptr) {
     int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (progress && blockIdx.x == 0) { for (int i = threadIdx.x; i < n_progress; i += blockDim.x) progress[i] = 0; }      // (k_nodes_linearize of this step counts from 0)
+    if (order_cnt && blockIdx.x == 0 && threadIdx.x < 2) order_cnt[threadIdx.x] = 0;                                       // (the launch order the nodes kernel files: both counters from 0)
     if (wave >= B) return;
     if constexpr (TG) time_grid_lane(C, lane, t0[wave], ts + (size_t)wave * C.NN, dt + (size_t)wave * C.N, prev_ts + (size_t)wave * C.NN);
     const TrajView T = traj_of(C, wave);
