@@ -42,6 +42,11 @@ struct pg_handle {
     hipEvent_t ev[4]; bool ev_ok = false; float phase_ms[3] = {0, 0, 0}; bool timing_valid = false;
     size_t solve_lds = 0; bool solve_ring = false;
     real* d_walls = nullptr;                                    // [cap][N][2] wall extension
+    // hipGraph of a whole host-to-host warm step (pg_step of a small batch is launch-bound: one copy in, four kernels, one copy out; captured once, replayed while
+    // nothing that the launches depend on has changed -- `sig` is compared field by field before every replay)
+    struct StepGraph { hipGraph_t g = nullptr; hipGraphExec_t x = nullptr; hipStream_t own = nullptr; bool disabled = false; bool capturing = false;
+                       DevCfg dc; HjiView hv; int B = 0, fuse = 0, pipeline = 0, has_hji = 0, traj_L = 0; hipStream_t user = nullptr; } sg;
+    int graph_mode = 1;                                       // PG_GRAPH=0 at pg_create: never
     char* d_in = nullptr; char* d_out = nullptr;             // the five input arrays / (u, status, iters) as ONE allocation each: a batch that fills the handle travels in one copy per direction
     size_t in_bytes = 0, out_bytes = 0, in_dbl_off = 0;        // (layout by capacity: [state 6][control 3][other 4] real, then at in_dbl_off [t0][time_offset] double; [u 3] real, [status][iters] int)
     char* h_stage = nullptr; size_t stage_bytes = 0;            // pinned host staging of pg_set_inputs / pg_step (one stream synchronisation per call instead of one per array)
@@ -152,6 +157,9 @@ static void free_all(pg_handle* h) {
                     h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_order, h->d_naux, h->d_progress};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->sg.x) (void)hipGraphExecDestroy(h->sg.x);
+    if (h->sg.g) (void)hipGraphDestroy(h->sg.g);
+    if (h->sg.own) (void)hipStreamDestroy(h->sg.own);
     if (h->ev_ok) for (int i = 0; i < 4; i++) (void)hipEventDestroy(h->ev[i]);
 }
 
@@ -226,6 +234,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     { const char* e = getenv("PG_FUSE"); if (e && e[0] >= '0' && e[0] <= '2') h->fuse = e[0] - '0'; }
     { const char* e = getenv("PG_PIPELINE"); if (e && e[0] >= '0' && e[0] <= '1') h->pipeline = e[0] - '0'; }
     { const char* e = getenv("PG_PIPE_FAULT"); h->pipe_fault = e && e[0] == '1'; }
+    { const char* e = getenv("PG_GRAPH"); if (e && e[0] == '0') h->graph_mode = 0; }
     // horizons up to 32 intervals keep their dynamics blocks resident in LDS (one pass over the QP data); longer ones stream them through a 4-slot ring
     h->solve_ring = N > 32;
 #ifdef PG_EXPERIMENTAL_SOLVE4
@@ -396,6 +405,7 @@ int pg_reset(pg_handle* h, const uint8_t* mask) {
     return PG_OK;
 }
 
+static void stage_block(pg_handle* h, int32_t B, const double* s_, const double* c_, const double* t0, const double* o_, const double* toff);
 static int set_inputs(pg_handle* h, int32_t B, const void* state, const void* control, const double* t0, const void* other, const double* toff, bool host) {
     if (!h) return PG_ERR_INVALID;
     REQUIRE(h, B >= 1 && B <= h->cfg.batch_capacity, "batch size outside [1, batch_capacity]");
@@ -413,12 +423,7 @@ static int set_inputs(pg_handle* h, int32_t B, const void* state, const void* co
         if (B == h->cfg.batch_capacity) {
             // the batch fills the handle: the staging buffer takes the layout of the device block and ONE copy carries all five arrays (a single controller at
             // 100 Hz -- B = capacity = 1 -- used to pay five copies and two memsets of a few bytes each per step)
-            real* st = (real*)h->h_stage; real* ct = st + (size_t)B * 6; real* ot = ct + (size_t)B * 3; double* tt = (double*)(h->h_stage + h->in_dbl_off); double* ft = tt + B;
-            for (size_t i = 0; i < (size_t)B * 6; i++) st[i] = (real)s_[i];
-            for (size_t i = 0; i < (size_t)B * 3; i++) ct[i] = (real)c_[i];
-            for (size_t i = 0; i < (size_t)B * 4; i++) ot[i] = o_ ? (real)o_[i] : real(0.0);
-            memcpy(tt, t0, (size_t)B * 8);
-            if (toff) memcpy(ft, toff, (size_t)B * 8); else memset(ft, 0xFF, (size_t)B * 8);      // all-ones bit pattern is a NaN: path-tracking mode
+            stage_block(h, B, s_, c_, t0, o_, toff);
             HIPCHK(h, hipMemcpyAsync(h->d_in, h->h_stage, h->in_bytes, kind, h->stream));
             return PG_OK;
         }
@@ -727,13 +732,14 @@ int pg_get_next_control_hji(pg_handle* h, int32_t use_hji_policy, double* u_out,
 }
 int pg_step_dev(pg_handle* h, void* u_out_dev) {
     int rc = check_ready(h); if (rc) return rc;
-    HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    const bool ev = !h->sg.capturing;                             // (a step that is being captured into a graph carries no timing events)
+    if (ev) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     if ((rc = launch_nodes(h, true))) return rc;
-    HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-    if ((rc = update_and_solve(h, h->ev[2]))) return rc;       // (chunked: ev[2] marks the end of the LAST update_QP chunk; earlier solve chunks run under it)
+    if (ev) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    if ((rc = update_and_solve(h, ev ? h->ev[2] : nullptr))) return rc;       // (chunked: ev[2] marks the end of the LAST update_QP chunk; earlier solve chunks run under it)
     if ((rc = pg_get_next_control_dev(h, u_out_dev))) return rc;
-    HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
-    h->timing_valid = true;
+    if (ev) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+    h->timing_valid = ev;
     return PG_OK;
 }
 int pg_simulate_dev(pg_handle* h, int32_t steps, double dt, void* state_hist_dev_, void* control_hist_dev_) {
@@ -763,8 +769,74 @@ int pg_get_phase_ms(pg_handle* h, float out3[3]) {
     for (int i = 0; i < 3; i++) HIPCHK(h, hipEventElapsedTime(&out3[i], h->ev[i], h->ev[i + 1]));
     return PG_OK;
 }
+// the five input arrays in the staging buffer, in the layout of the device block (batch == capacity)
+static void stage_block(pg_handle* h, int32_t B, const double* s_, const double* c_, const double* t0, const double* o_, const double* toff) {
+    real* st = (real*)h->h_stage; real* ct = st + (size_t)B * 6; real* ot = ct + (size_t)B * 3; double* tt = (double*)(h->h_stage + h->in_dbl_off); double* ft = tt + B;
+    for (size_t i = 0; i < (size_t)B * 6; i++) st[i] = (real)s_[i];
+    for (size_t i = 0; i < (size_t)B * 3; i++) ct[i] = (real)c_[i];
+    for (size_t i = 0; i < (size_t)B * 4; i++) ot[i] = o_ ? (real)o_[i] : real(0.0);
+    memcpy(tt, t0, (size_t)B * 8);
+    if (toff) memcpy(ft, toff, (size_t)B * 8); else memset(ft, 0xFF, (size_t)B * 8);      // all-ones bit pattern is a NaN: path-tracking mode
+}
+// pg_step of a small warm batch as ONE graph launch.  Returns PG_OK with *done = true when the step ran through the graph; *done = false means "not eligible / not
+// possible": the caller takes the ordinary path.  Eligible: graphs on, the batch fills the handle (one copy per direction), <= 256 instances (beyond, the kernels
+// dominate the launches), every instance warm (the cold branch picks other kernels), nothing fused or chunked.
+static int step_by_graph(pg_handle* h, int32_t B, const double* state, const double* control, const double* t0, const double* other, const double* toff, bool* done) {
+    *done = false;
+    auto& G = h->sg;
+    if (!h->graph_mode || G.disabled || B != h->cfg.batch_capacity || B > 256 || h->B != B || h->warm_B < B || h->fuse != 0 || !h->d_traj) return PG_OK;
+    if (h->dc.n_traj > 1 && h->traj_idx_B < B) return PG_OK;
+    if (hipSetDevice(h->cfg.device) != hipSuccess) return PG_OK;
+    const bool same = G.x && G.B == B && G.user == h->stream && G.fuse == h->fuse && G.pipeline == h->pipeline && G.has_hji == (int)h->has_hji && G.traj_L == h->traj_L &&
+                      memcmp(&G.dc, &h->dc, sizeof(DevCfg)) == 0 && memcmp(&G.hv, &h->hv, sizeof(HjiView)) == 0;
+    hipStream_t run = h->stream ? h->stream : G.own;
+    if (!same) {
+        if (G.x) { (void)hipGraphExecDestroy(G.x); G.x = nullptr; }
+        if (G.g) { (void)hipGraphDestroy(G.g); G.g = nullptr; }
+        if (!h->stream && !G.own && hipStreamCreate(&G.own) != hipSuccess) { G.disabled = true; (void)hipGetLastError(); return PG_OK; }      // (a blocking stream: ordered against the null stream)
+        run = h->stream ? h->stream : G.own;
+        if (hipStreamSynchronize(h->stream) != hipSuccess) return PG_OK;
+        hipStream_t user = h->stream;
+        bool ok = hipStreamBeginCapture(run, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            h->stream = run; G.capturing = true;
+            ok = hipMemcpyAsync(h->d_in, h->h_stage, h->in_bytes, hipMemcpyHostToDevice, run) == hipSuccess && pg_step_dev(h, nullptr) == PG_OK &&
+                 hipMemcpyAsync(h->h_stage, h->d_out, h->out_bytes, hipMemcpyDeviceToHost, run) == hipSuccess;
+            h->stream = user; G.capturing = false;
+            hipGraph_t g = nullptr;
+            const bool ended = hipStreamEndCapture(run, &g) == hipSuccess && g != nullptr;
+            ok = ok && ended;
+            if (ok) { G.g = g; ok = hipGraphInstantiate(&G.x, G.g, nullptr, nullptr, 0) == hipSuccess; }
+            else if (g) (void)hipGraphDestroy(g);
+        }
+        if (!ok) {           // this runtime / this configuration cannot be captured: never again for this handle, the ordinary path takes over
+            if (G.x) { (void)hipGraphExecDestroy(G.x); G.x = nullptr; }
+            if (G.g) { (void)hipGraphDestroy(G.g); G.g = nullptr; }
+            G.disabled = true; (void)hipGetLastError();
+            return PG_OK;
+        }
+        G.dc = h->dc; G.hv = h->hv; G.B = B; G.user = user; G.fuse = h->fuse; G.pipeline = h->pipeline; G.has_hji = (int)h->has_hji; G.traj_L = h->traj_L;
+    } else if (hipStreamSynchronize(h->stream) != hipSuccess) return PG_OK;
+    stage_block(h, B, state, control, t0, other, toff);
+    HIPCHK(h, hipGraphLaunch(G.x, run));
+    HIPCHK(h, hipStreamSynchronize(run));
+    h->timing_valid = false;
+    *done = true;
+    return PG_OK;
+}
 int pg_step(pg_handle* h, int32_t B, const double* state, const double* control, const double* t0, const double* other, const double* toff,
             double* u_out, int32_t* status, int32_t* iters) {
+    if (h && state && control && t0) {
+        bool done = false;
+        int rc = step_by_graph(h, B, state, control, t0, other, toff, &done); if (rc) return rc;
+        if (done) {
+            const real* us = (const real*)h->h_stage; const int* ss = (const int*)(us + (size_t)B * 3); const int* is = ss + B;
+            if (u_out) for (size_t i = 0; i < (size_t)B * 3; i++) u_out[i] = (double)us[i];
+            if (status) memcpy(status, ss, (size_t)B * sizeof(int));
+            if (iters) memcpy(iters, is, (size_t)B * sizeof(int));
+            return PG_OK;
+        }
+    }
     int rc = pg_set_inputs(h, B, state, control, t0, other, toff); if (rc) return rc;
     if ((rc = pg_step_dev(h, nullptr))) return rc;
     // controls, status and iteration counts come back through the pinned staging buffer: three asynchronous copies behind k_solve on the handle's stream

@@ -77,3 +77,31 @@ def test_pipelined_launch_drains_when_the_recurrence_never_publishes(pkg, skidpa
     u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
     assert np.all(status == pkg.SOLVED)
     mpc.close()
+
+
+def test_graph_replay_of_small_warm_steps_changes_nothing(pkg, skidpad, monkeypatch):
+    """pg_step of a small batch that fills its handle is replayed from a hipGraph once every instance is warm (one copy in, the kernels of a warm step, one copy out).
+    The replayed steps must give the bits of the ordinary launches (PG_GRAPH=0), through a masked reset (cold instances: ordinary path for that step), a change of the
+    inputs' optional arrays and a re-installed trajectory (the graph is re-captured when anything its launches depend on has changed)."""
+    vail = pkg.load_path_fixture("vail")
+    out = {}
+    for graph in ("1", "0"):
+        monkeypatch.setenv("PG_GRAPH", graph)
+        B = 4
+        mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, B)
+        state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B, seed=9)
+        rec = []
+        for k in range(24):
+            if k == 8:
+                mpc.reset(np.array([1, 0, 0, 1], dtype=bool))
+            if k == 14:
+                mpc.set_trajectory(vail)
+                state, control, t0, toff = pkg.synthetic.config2_inputs(vail, B, seed=10)
+            u, st, it = mpc.step_(state, control, t0 + 0.01 * k, time_offset=None if 16 <= k < 20 else toff)
+            rec.append((u.copy(), st.copy(), it.copy()))
+            control = u.copy()
+        out[graph] = rec
+        mpc.close()
+    for (ua, sa, ia), (ub, sb, ib) in zip(out["1"], out["0"]):
+        assert np.array_equal(ua, ub) and np.array_equal(sa, sb) and np.array_equal(ia, ib)
+    assert all(np.all(s == pkg.SOLVED) for _, s, _ in out["1"][:14])
