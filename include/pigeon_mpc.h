@@ -182,10 +182,11 @@ int pg_get_next_control_hji(pg_handle* h, int32_t use_hji_policy, double* u_out,
 int pg_get_next_control_hji_dev(pg_handle* h, int32_t use_hji_policy, pg_real_dev* u_out_dev, int32_t* source_dev);
 
 /* all five for every instance: host buffers in, host buffers out (status/iters may be NULL).
- * A batch that fills the handle (B == batch_capacity) travels in one copy per direction; when it has at most 256 instances and every one of them is warm (the ROS
- * loop: one controller at 100 Hz), the whole step -- copy in, the kernels of a warm step, copy out -- is captured once into a hipGraph and replayed (re-captured
- * whenever something its launches depend on has changed; results identical to the ordinary launches; PG_GRAPH=0 at pg_create turns it off; pg_get_phase_ms has
- * no timing for replayed steps).  With no stream installed the graph runs on a blocking stream of its own, ordered against the null stream. */
+ * A batch that fills the handle (B == batch_capacity) travels in one copy per direction.  Opt-in (PG_GRAPH=1 at pg_create): when such a batch has at most 256
+ * instances and every one of them is warm, the whole step -- copy in, the kernels of a warm step, copy out -- is captured once into a hipGraph and replayed
+ * (re-captured whenever something its launches depend on has changed; results identical to the ordinary launches; pg_get_phase_ms has no timing for replayed
+ * steps; with no stream installed the graph runs on a blocking stream of its own, ordered against the null stream).  Measured: 2-7 % per step, against ~7 ms for
+ * every capture -- worth it for a long run on one path, not for a loop that re-installs its path every few steps; hence off by default. */
 int pg_step(pg_handle* h, int32_t B, const double* state, const double* control, const double* t0, const double* other_car,
             const double* time_offset, double* u_out, int32_t* status, int32_t* iters);
 /* the four compute phases + control extraction on the inputs last installed; nothing crosses PCIe.  u_out_dev may be NULL. */

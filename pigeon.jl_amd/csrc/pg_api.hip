@@ -46,7 +46,8 @@ struct pg_handle {
     // nothing that the launches depend on has changed -- `sig` is compared field by field before every replay)
     struct StepGraph { hipGraph_t g = nullptr; hipGraphExec_t x = nullptr; hipStream_t own = nullptr; bool disabled = false; bool capturing = false;
                        DevCfg dc; HjiView hv; int B = 0, fuse = 0, pipeline = 0, has_hji = 0, traj_L = 0; hipStream_t user = nullptr; } sg;
-    int graph_mode = 1;                                       // PG_GRAPH=0 at pg_create: never
+    int graph_mode = 0;                                       // PG_GRAPH=1 at pg_create turns it on.  OFF by default: capturing costs ~7 ms once and again whenever a launch parameter changes (a re-installed
+                                                              // path: every `path` message of the ROS loop), a jitter that a 100 Hz loop minds more than the 4-20 us per step the replay saves
     char* d_in = nullptr; char* d_out = nullptr;             // the five input arrays / (u, status, iters) as ONE allocation each: a batch that fills the handle travels in one copy per direction
     size_t in_bytes = 0, out_bytes = 0, in_dbl_off = 0;        // (layout by capacity: [state 6][control 3][other 4] real, then at in_dbl_off [t0][time_offset] double; [u 3] real, [status][iters] int)
     char* h_stage = nullptr; size_t stage_bytes = 0;            // pinned host staging of pg_set_inputs / pg_step (one stream synchronisation per call instead of one per array)
@@ -234,7 +235,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     { const char* e = getenv("PG_FUSE"); if (e && e[0] >= '0' && e[0] <= '2') h->fuse = e[0] - '0'; }
     { const char* e = getenv("PG_PIPELINE"); if (e && e[0] >= '0' && e[0] <= '1') h->pipeline = e[0] - '0'; }
     { const char* e = getenv("PG_PIPE_FAULT"); h->pipe_fault = e && e[0] == '1'; }
-    { const char* e = getenv("PG_GRAPH"); if (e && e[0] == '0') h->graph_mode = 0; }
+    { const char* e = getenv("PG_GRAPH"); if (e && (e[0] == '0' || e[0] == '1')) h->graph_mode = e[0] - '0'; }
     // horizons up to 32 intervals keep their dynamics blocks resident in LDS (one pass over the QP data); longer ones stream them through a 4-slot ring
     h->solve_ring = N > 32;
 #ifdef PG_EXPERIMENTAL_SOLVE4
