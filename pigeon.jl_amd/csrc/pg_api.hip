@@ -42,6 +42,7 @@ struct pg_handle {
     hipEvent_t ev[4]; bool ev_ok = false; float phase_ms[3] = {0, 0, 0}; bool timing_valid = false;
     size_t solve_lds = 0; bool solve_ring = false;
     real* d_walls = nullptr;                                    // [cap][N][2] wall extension
+    real* d_lat = nullptr;                                      // [cap][N][LATP] packed stage records of the lateral formulation (k_qp_dec -> k_solve_lat)
     // hipGraph of a whole host-to-host warm step (pg_step of a small batch is launch-bound: one copy in, four kernels, one copy out; captured once, replayed while
     // nothing that the launches depend on has changed -- `sig` is compared field by field before every replay)
     struct StepGraph { hipGraph_t g = nullptr; hipGraphExec_t x = nullptr; hipStream_t own = nullptr; bool disabled = false; bool capturing = false;
@@ -52,6 +53,7 @@ struct pg_handle {
     size_t in_bytes = 0, out_bytes = 0, in_dbl_off = 0;        // (layout by capacity: [state 6][control 3][other 4] real, then at in_dbl_off [t0][time_offset] double; [u 3] real, [status][iters] int)
     char* h_stage = nullptr; size_t stage_bytes = 0;            // pinned host staging of pg_set_inputs / pg_step (one stream synchronisation per call instead of one per array)
     real* d_ws4 = nullptr; bool solve_quad = false; size_t solve4_lds = 0;   // k_solve4 (four instances per wavefront)
+    bool solve_lat = false; size_t lat_lds = 0;               // lateral formulation: its own kernel k_solve_lat (PG_SOLVE_LAT=0 keeps the embedding in k_solve)
 };
 
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return PG_ERR_HIP; } } while (0)
@@ -155,7 +157,7 @@ int pg_default_config_decoupled(pg_config* c) {
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_in, h->d_out, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_order, h->d_naux, h->d_progress};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_order, h->d_naux, h->d_progress, h->d_lat};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->sg.x) (void)hipGraphExecDestroy(h->sg.x);
@@ -214,6 +216,9 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
 #endif
     if (cfg->walls) { ALLOC(h->d_walls, cap * N * 2, real); C.walls = 1; C.wall_weight = (real)cfg->wall_weight; C.wall_edges = h->d_walls; if (h->solve_quad) { g_create_error = "PG_SOLVER=quad does not carry the wall rows"; free_all(h); delete h; return PG_ERR_INVALID; } }
     ALLOC(h->d_pol_u2, cap * 2, real); ALLOC(h->d_pol_u, cap * 3, real); ALLOC(h->d_pol_src, cap, int);
+    // the lateral formulation has a solve kernel of its own (k_solve_lat: interior point, no polish); polish = 1 and PG_SOLVE_LAT=0 keep the embedding in k_solve
+    { const char* e = getenv("PG_SOLVE_LAT"); h->solve_lat = cfg->formulation == PG_DECOUPLED && !cfg->polish && !(e && e[0] == '0') && !h->solve_quad; }
+    if (h->solve_lat) { ALLOC(h->d_lat, cap * N * LATP, real); C.lat_pack = h->d_lat; }
 #undef ALLOC
     h->stage_bytes = h->in_bytes > h->out_bytes ? h->in_bytes : h->out_bytes;          // inputs: state 6 + control 3 + other 4 (real) + t0 + time_offset (double); outputs reuse the front of it
     if (hipHostMalloc((void**)&h->h_stage, h->stage_bytes, hipHostMallocDefault) != hipSuccess) { g_create_error = "hipHostMalloc failed for the staging buffer"; free_all(h); delete h; return PG_ERR_HIP; }
@@ -252,6 +257,14 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         (void)hipFuncSetAttribute((const void*)k_solve<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
         (void)hipFuncSetAttribute((const void*)k_solve<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
         (void)hipFuncSetAttribute((const void*)k_solve<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+    }
+    {
+        h->lat_lds = lat_lds_doubles(N) * sizeof(real);
+        if (h->solve_lat && h->lat_lds > 48 * 1024) {
+            const int ld = (int)h->lat_lds;
+            (void)hipFuncSetAttribute((const void*)k_solve_lat<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ld);
+            (void)hipFuncSetAttribute((const void*)k_solve_lat<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ld);
+        }
     }
     *out = h;
     return PG_OK;
@@ -621,11 +634,21 @@ int pg_update_qp(pg_handle* h) {
     return launch_linearize(h, B);
 }
 // k_solve over `n` instances on stream `st`: the whole batch in index order (order == nullptr) or the sub-range order[0..n) of the launch order
-static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n) {
+static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, unsigned long long* lat_prof = nullptr) {
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, order};
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) { hipLaunchKernelGGL((k_solve4<2, false>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, (unsigned long long*)nullptr); LAUNCH_CHECK(h); return PG_OK; }
 #endif
+    if (h->solve_lat) {      // lateral formulation: four instances per wavefront, always the whole batch in index order
+        const dim3 grid((unsigned)((h->B + 3) / 4));
+        const int slots = (h->dc.N + 15) / 16;
+#define PG_LAT_LAUNCH(NS, W) hipLaunchKernelGGL((k_solve_lat<NS, W>), grid, dim3(64), h->lat_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, lat_prof)
+        if (h->dc.walls) { if (slots == 1) PG_LAT_LAUNCH(1, true); else if (slots == 2) PG_LAT_LAUNCH(2, true); else if (slots == 3) PG_LAT_LAUNCH(3, true); else PG_LAT_LAUNCH(4, true); }
+        else { if (slots == 1) PG_LAT_LAUNCH(1, false); else if (slots == 2) PG_LAT_LAUNCH(2, false); else if (slots == 3) PG_LAT_LAUNCH(3, false); else PG_LAT_LAUNCH(4, false); }
+#undef PG_LAT_LAUNCH
+        LAUNCH_CHECK(h);
+        return PG_OK;
+    }
     if (h->solve_ring) hipLaunchKernelGGL((k_solve<false, true, false>), dim3(n), dim3(64), h->solve_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
     else hipLaunchKernelGGL((k_solve<false, false, false>), dim3(n), dim3(64), h->solve_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
     LAUNCH_CHECK(h);
@@ -681,6 +704,7 @@ int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     HIPCHK(h, hipMalloc((void**)&d, ((size_t)h->B * 6 + 1024) * 8));
     HIPCHK(h, hipMemset(d, 0, ((size_t)h->B * 6 + 1024) * 8));
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, nullptr};
+    if (h->solve_lat) { if ((rc = launch_solve(h, h->stream, nullptr, h->B, d))) { (void)hipFree(d); return rc; } } else
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) hipLaunchKernelGGL((k_solve4<2, true>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, d);
     else
@@ -894,7 +918,13 @@ int pg_get_qp(pg_handle* h, int32_t b0, int32_t n, double* out) {
 int pg_set_qp(pg_handle* h, int32_t b0, int32_t n, const double* in) {
     int rc = check_ready(h); if (rc) return rc;
     REQUIRE(h, in && b0 >= 0 && n >= 1 && b0 + n <= h->B, "pg_set_qp: range outside the batch");
-    return up(h, h->d_qp + (size_t)b0 * h->dc.qp_len, in, (size_t)n * h->dc.qp_len);
+    if ((rc = up(h, h->d_qp + (size_t)b0 * h->dc.qp_len, in, (size_t)n * h->dc.qp_len))) return rc;
+    if (h->solve_lat) {      // k_solve_lat reads the packed stage records: refresh them from the installed block
+        const long nt = (long)n * h->dc.N;
+        hipLaunchKernelGGL(k_lat_pack, dim3((unsigned)((nt + 127) / 128)), dim3(128), 0, h->stream, h->dc, b0, n, h->d_qp);
+        LAUNCH_CHECK(h);
+    }
+    return PG_OK;
 }
 int pg_get_solution(pg_handle* h, double* x, double* sigma) {
     int rc = check_ready(h); if (rc) return rc;

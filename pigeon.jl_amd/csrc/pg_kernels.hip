@@ -44,6 +44,7 @@ struct DevCfg {
     int walls;                    // build-defined extension: soft rows edge_R - sw <= e <= edge_L + sw, sw >= 0 at nodes 2..N+1 (decoupled formulation only)
     real wall_weight;           // linear penalty on sw (per second, like W_beta)
     real* wall_edges;           // [B][N][2] (edge_L, edge_R) at node k+1, written by k_nodes_dec, read by k_solve
+    real* lat_pack;             // lateral formulation: [B][N][LATP] packed stage records for k_solve_lat, written by k_qp_dec next to the QP block (nullptr: not wanted)
 };
 // the reference trajectory instance b tracks (mpc.trajectory of that controller)
 PG_DEV TrajView traj_of(const DevCfg& C, int b) {
@@ -59,6 +60,11 @@ PG_DEV TrajView traj_of(const DevCfg& C, int b) {
 // Stage block as k_solve keeps it in LDS (packed from the QP data on the way in): rows 0..5 of Abar = [A | B0+Bf] at a row stride of 9 doubles (odd stride: the 8 rows land on distinct LDS
 // banks, so the row-indexed reads of the Riccati passes are conflict-free), then Bbar = Bf (12) at SB_B, cbar = c (6) at SB_C.
 constexpr int SB = 72, SB_ROW = 9, SB_B = 54, SB_C = 66;
+
+// Packed stage record of the LATERAL formulation (k_qp_dec writes it, k_solve_lat streams it from L2: 16-byte aligned rows, one 64 B line per matrix row):
+//   [8 i + m], i < 4, m < 7: row i of [A | B0+Bf | Bf | c]  (= rows 0..3 of [Abar | Bbar | cbar]; m = 7 is a stored 0: the column lanes 7..15 of a row read)
+//   [32..39] H (4 x 2, row-major)   [40..43] G   [44] dmax  [45] dmin  [46] ddmax  [47] ddmin  [48] dt  [49..55] 0
+constexpr int LATP = 56;
 
 // offsets inside one instance's QP block (doubles); same order as pg_get_qp documents
 struct QpOff { int A, B0, Bf, c, H, G, dmin, dmax, fxmax, ddmin, ddmax, dt, qcurr, ucurr, M, b; };
@@ -808,6 +814,16 @@ __global__ __launch_bounds__(128) void k_qp_dec(DevCfg C, int B, const real* __r
     Q[o.fxmax + t] = real(1.0);                                           // inert Fx slot: 0 <= 1 is never active
     Q[o.ddmin + t] = -C.cp.deltadot_max * T; Q[o.ddmax + t] = C.cp.deltadot_max * T;
     Q[o.dt + t] = T;
+    if (C.lat_pack) {      // the same numbers once more, packed for k_solve_lat
+        real* Lp = C.lat_pack + ((size_t)b * C.N + t) * LATP;
+        for (int i = 0; i < 4; i++) {
+            for (int j = 0; j < 4; j++) Lp[8 * i + j] = Ad.a[4 * i + j];
+            Lp[8 * i + 4] = b0[i] + bf[i]; Lp[8 * i + 5] = bf[i]; Lp[8 * i + 6] = cd[i]; Lp[8 * i + 7] = real(0.0);
+            Lp[32 + 2 * i] = e.H[i][0]; Lp[33 + 2 * i] = e.H[i][1]; Lp[40 + i] = e.G[i];
+        }
+        Lp[44] = Q[o.dmax + t]; Lp[45] = Q[o.dmin + t]; Lp[46] = Q[o.ddmax + t]; Lp[47] = Q[o.ddmin + t]; Lp[48] = T;
+        for (int i = 49; i < LATP; i++) Lp[i] = real(0.0);
+    }
     if (t == 0) {
         Q[o.qcurr] = real(0.0); Q[o.qcurr + 1] = C.ux_dummy; for (int k = 0; k < 4; k++) Q[o.qcurr + 2 + k] = q[k];
         Q[o.ucurr] = n0[6]; Q[o.ucurr + 1] = real(0.0); Q[o.M] = real(0.0); Q[o.M + 1] = real(0.0); Q[o.b] = real(1.0);
@@ -2092,6 +2108,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         O.solved[b] = 1;      // model_predictive_control.jl:76: solved = true
     }
 }
+
+#include "pg_solve_lat.hip"         // the lateral formulation's own solve kernel (5-state stage, sixteen lanes per instance)
 
 #ifdef PG_EXPERIMENTAL_SOLVE4      // four instances per wavefront: a measured negative result, kept out of the shipped libraries
 #include "experimental/pg_solve4.hip"

@@ -1,0 +1,557 @@
+// k_solve_lat: solve! + get_next_control of the LATERAL tracking QP (decoupled_lat_long.jl:134-226,275-278) in its own 5-state stage form -- the dedicated kernel
+// of BASELINE configs[4] (B = 4096, N = 50, + the build-defined wall rows).  Included by pg_kernels.hip inside namespace pg.
+//
+// Stage form (exact; tools/lat_ipm_prototype.py is the numpy twin of this file):  x_k = (Uy, r, dpsi, e, delta)_k, v_k = delta_{k+1} - delta_k (the reference's d-delta
+// variables, :146),  x_{k+1} = Abar_k x_k + Bbar_k v_k + cbar_k  with  Abar = [A  B0+Bf; 0 1], Bbar = [Bf; 1], cbar = [c; 0];  x_0 = (q_curr, delta_curr) fixed (:150-151).
+// Rows of transition k (node k+1, input v_k), slack t >= 0 (local numbering; the bit of the 16-bit active mask pg_get_solve_info reports in brackets):
+//   0 [3]: dmax - delta    1 [4]: delta - dmin    2..5 [6..9]: G_i - H_i (Uy, r) + sigma_{1,1,2,2}    6 [10]: sigma_1    7 [11]: sigma_2    8 [12]: ddmax - v    9 [13]: v - ddmin
+//   walls: 10 [0]: edge_L - e + sw    11 [1]: e - edge_R + sw    12 [2]: sw
+// Same interior point as k_solve (Mehrotra predictor-corrector, every Newton step ONE equality-constrained LQ problem solved by a Riccati recursion: matrix pass once per
+// iteration, vector pass for the corrector, dynamics and slacks exact at every Newton point), but mapped for a 5 x 5 stage instead of being embedded in the 8 x 8 one:
+//
+//  * SIXTEEN lanes = one instance, four instances per wavefront (one DPP row each): 4096 instances = 1024 wavefronts = one per SIMD of the chip, a single round.
+//  * Stage-parallel work (barrier terms, slack elimination, Newton point, step rules): lane c of a row owns stages c, c + 16, ... (NSLOT of them); t and lambda of its rows
+//    live in its registers for the whole solve.
+//  * Serial passes: lane c holds COLUMN c of the stage matrices ([Abar | Bbar | cbar] = columns 0..6, P = columns 0..4, the vector recursion rides in column 6), loaded
+//    straight from the QP data in global memory (L2) one stage ahead -- no LDS copy of the dynamics.  Every product is a sequence of v_fmac_f64_dpp row_newbcast:k -- the
+//    broadcast of lane k's register to its row fused into the multiply-add (tools/probes/dpp_f64_probe.hip: 8.5 cycles against 22.5 for v_mov_b64_dpp + v_fma_f64, which is
+//    what the compiler emits for the builtin) -- so a stage's matrix recursion is ~90 instructions with NO LDS traffic and no cross-lane shuffles in the dependent chain.
+//    P is used from both orientations in M = P [Abar Bbar cbar] (M = (P + P')/2 X): the antisymmetric rounding error of the recursion never propagates (k_solve
+//    symmetrises through LDS every stage at N = 50).
+//  * The roll-out holds ROW i of [Abar | Bbar | cbar] in lane i and the gain row in lane 5: x_{k+1} = six fused multiply-adds per stage.
+//  * LDS per instance: 24 doubles per stage (stage cost terms that the roll-out result overwrites, gains, S^-1, P cbar) = 9.6 KB at N = 50: four wavefronts per CU.
+//
+// The DPP forms are inline assembly: hipcc does not pad their hazards (VALU write -> DPP read of the same register: 2 wait states; EXEC write -> DPP: 5), so every block opens
+// with s_nop 4 and the pass loops carry no divergent branch (predicated stores go to a dummy LDS slot).
+
+#ifdef PG_F32
+#define LAT_FMAC "v_fmac_f32_dpp"
+#define LAT_MOV "v_mov_b32"
+#else
+#define LAT_FMAC "v_fmac_f64_dpp"
+#define LAT_MOV "v_mov_b64"
+#endif
+#define LAT_DPP(acc, bsrc, x, lane) LAT_FMAC " %" #acc ", %" #bsrc ", %" #x " row_newbcast:" #lane " row_mask:0xf bank_mask:0xf\n\t"
+
+constexpr int LAT_REC = 12;     // stage -> serial: (yy, yr, rr, ee, dd, Rhat) [overwritten by the roll-out: x+_{k+1}[0..4], v+_k], qhat[5], rhat
+constexpr int LAT_TAB = 12;     // serial tables: K[5], kff, Sinv, P cbar [5]
+constexpr int LAT_STRIDE = LAT_REC + LAT_TAB;
+__host__ __device__ inline size_t lat_lds_doubles(int N) { return (size_t)4 * N * LAT_STRIDE + 64 + 8; }
+
+// broadcast of lane K of each 16-lane row (compiler builtin: hazards padded by hipcc; v_mov_b64_dpp row_newbcast)
+template <int K> PG_DEV real lat_bc(real v) {
+#ifdef PG_F32
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xF, 0xF, false));
+#else
+    return __longlong_as_double(__builtin_amdgcn_update_dpp((long long)0, __double_as_longlong(v), 0x150 + K, 0xF, 0xF, false));
+#endif
+}
+// all-reduce over the 16 lanes of a row (DPP butterflies: no LDS)
+PG_DEV real row_sum(real v) { v += dpp_move<0xB1>(v); v += dpp_move<0x4E>(v); v += dpp_move<0x124>(v); v += dpp_move<0x128>(v); return v; }
+PG_DEV real row_max(real v) { v = fmax(v, dpp_move<0xB1>(v)); v = fmax(v, dpp_move<0x4E>(v)); v = fmax(v, dpp_move<0x124>(v)); v = fmax(v, dpp_move<0x128>(v)); return v; }
+// reciprocal of the interior-point weights: hardware seed + ONE Newton step (~1e-14 relative in fp64; the Newton system only has to be consistent, see assemble)
+PG_DEV real lat_rcp(real x) {
+#ifdef PG_F32
+    return frcp(x);
+#else
+    double r = __builtin_amdgcn_rcp(x); double e = fma(-x, r, 1.0); return fma(r, e, r);
+#endif
+}
+
+// packed stage records from the embedded QP block (pg_set_qp installs QP data behind k_qp_dec's back): thread = (instance, stage)
+__global__ __launch_bounds__(128) void k_lat_pack(DevCfg C, int b0, int n, const real* __restrict__ qp) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)n * C.N) return;
+    const int b = b0 + (int)(gid / C.N), t = (int)(gid % C.N);
+    const QpOff o = qp_offsets(C.N);
+    const real* Q = qp + (size_t)b * C.qp_len;
+    real* Lp = C.lat_pack + ((size_t)b * C.N + t) * LATP;
+    for (int i = 0; i < 4; i++) {
+        for (int j = 0; j < 4; j++) Lp[8 * i + j] = Q[o.A + 36 * t + 6 * (2 + i) + 2 + j];
+        const real b0v = Q[o.B0 + 12 * t + 2 * (2 + i)], bfv = Q[o.Bf + 12 * t + 2 * (2 + i)];
+        Lp[8 * i + 4] = b0v + bfv; Lp[8 * i + 5] = bfv; Lp[8 * i + 6] = Q[o.c + 6 * t + 2 + i]; Lp[8 * i + 7] = real(0.0);
+        Lp[32 + 2 * i] = Q[o.H + 8 * t + 2 * i]; Lp[33 + 2 * i] = Q[o.H + 8 * t + 2 * i + 1]; Lp[40 + i] = Q[o.G + 4 * t + i];
+    }
+    Lp[44] = Q[o.dmax + t]; Lp[45] = Q[o.dmin + t]; Lp[46] = Q[o.ddmax + t]; Lp[47] = Q[o.ddmin + t]; Lp[48] = Q[o.dt + t];
+    for (int i = 49; i < LATP; i++) Lp[i] = real(0.0);
+}
+
+template <int NSLOT, bool WALLS>
+__global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real* __restrict__ qp, const real* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof) {
+    constexpr int NR = WALLS ? 13 : 10;
+    // diagnostic cycle counters (pg_debug_solve_cycles): 0 barrier terms, 1 matrix pass, 2 vector pass, 3 roll-outs, 4 Newton point / step rules, 5 everything else
+    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = prof ? clock64() : 0;
+    auto stamp = [&](int slot) { if (prof) { const unsigned long long now = clock64(); pc[slot] += now - tprev; tprev = now; } };
+    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    const int N = C.N, NN = C.NN;
+    const int b_raw = 4 * (int)blockIdx.x + g;
+    const bool valid = b_raw < B;
+    const int b = valid ? b_raw : B - 1;                 // (a ragged last wavefront solves the last instance again and stores nothing)
+    extern __shared__ real lds[];
+    real* const sI = lds + (size_t)g * N * LAT_STRIDE;   // this instance's region: rec[N][12] then tab[N][12]
+    real* const sRec = sI; real* const sTab = sI + (size_t)N * LAT_REC;
+    real* const sDum = lds + (size_t)4 * N * LAT_STRIDE; // [64] sink for predicated-off stores
+    real* const sZero = sDum + 64;                       // a stored 0
+    if (lane < 8) sZero[lane] = real(0.0);
+    const QpOff o = qp_offsets(N);
+    const real* const Q = qp + (size_t)b * C.qp_len;
+
+    // ---------------- addressing of the serial passes ----------------
+    // The stage matrices come from the packed records k_qp_dec wrote (LATP doubles per stage, L2-resident): [8 i + m] = row i of [A | B0+Bf | Bf | c], m = 7 a stored 0.
+    const real* const Lb = C.lat_pack + (size_t)b * N * LATP;
+    // column distribution (matrix + vector pass): lane c holds X[0..3][c] of [Abar | Bbar | cbar]; row 4 is the constant x4; lanes 7..15 read the zero column
+    const real* const colp = Lb + (c < 7 ? c : 7);
+    const real cx4 = (c == 4 || c == 5) ? real(1.0) : real(0.0);
+    // stage-cost column of lane c inside rec[k]: Qhat[i][c] for c < 5, qhat[i] for c == 6, else zero (a stored 0 with stride 0)
+    int qoff[5], qmul[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        int e = -1;
+        if (c == 0) e = i == 0 ? 0 : (i == 1 ? 1 : -1);
+        else if (c == 1) e = i == 0 ? 1 : (i == 1 ? 2 : -1);
+        else if (c == 3) e = i == 3 ? 3 : -1;
+        else if (c == 4) e = i == 4 ? 4 : -1;
+        else if (c == 6) e = 6 + i;
+        qoff[i] = e >= 0 ? (int)(sRec - sZero) + e : 0; qmul[i] = e >= 0 ? LAT_REC : 0;
+    }
+    const real cpsi = c == 2 ? real(2.0) * C.cp.Q_dpsi : real(0.0);      // Qhat[2][2] = 2 Q_dpsi dt_k is not stored: lane 2 forms it from dt_k
+    const int roff = c == 5 ? (int)(sRec - sZero) + 5 : (c == 6 ? (int)(sRec - sZero) + 11 : 0), rmul = (c == 5 || c == 6) ? LAT_REC : 0;      // Rhat (lane 5) / rhat (lane 6)
+    // table slot lane c writes after a stage of the matrix pass: K[c] (c < 5), kff (lane 6 -> slot 5), Sinv (lane 5 -> slot 6)
+    const int wslot = c < 5 ? c : (c == 6 ? 5 : (c == 5 ? 6 : -1));
+    const real m6 = c == 6 ? real(1.0) : real(0.0), m5lt = c < 5 ? real(1.0) : real(0.0);
+
+    // ---------------- Riccati matrix pass (+ the predictor's vector recursion in column 6) ----------------
+    // Software-pipelined by hand: the operands of stage k - 1 (global: the matrix column and dt; LDS: the stage-cost column, Rhat / rhat) are requested at the top of
+    // stage k and first touched at the top of stage k - 1, a whole stage of arithmetic (~900 cycles) later.
+    auto matrix_pass = [&]() {
+        real P[5], X[4], Xn[4], Qc[5], Qn[5], dtk, dtn, radd, raddn;
+        {   // P_N = Qhat_{N-1} (cost on node N), p_N = qhat_{N-1}
+            const real dtl = Lb[(size_t)(N - 1) * LATP + 48];
+#pragma unroll
+            for (int i = 0; i < 5; i++) P[i] = (sZero + qoff[i])[qmul[i] * (N - 1)];
+            P[2] += cpsi * dtl;
+        }
+        auto request = [&](int k, real* Xo, real* Qo, real& dto, real& ro) {      // operands of stage k (k < 0: stage 0 again, unused)
+            const int kk = k < 0 ? 0 : k, km = kk > 0 ? kk - 1 : 0;
+            const real* cp = colp + (size_t)kk * LATP;
+#pragma unroll
+            for (int i = 0; i < 4; i++) Xo[i] = cp[8 * i];
+            dto = Lb[(size_t)km * LATP + 48];                 // dt of stage k - 1: its cost sits on node k
+#pragma unroll
+            for (int i = 0; i < 5; i++) Qo[i] = (sZero + qoff[i])[qmul[i] * km];
+            ro = (sZero + roff)[rmul * kk];
+        };
+        request(N - 1, X, Qc, dtk, radd);
+#pragma unroll 1
+        for (int k = N - 1; k >= 0; k--) {
+            request(k - 1, Xn, Qn, dtn, raddn);
+            real Xh[5], M[5];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { Xh[i] = real(0.5) * X[i]; M[i] = real(0.0); }
+            Xh[4] = real(0.5) * cx4; M[4] = real(0.0);
+            // M[i][c] = sum_k 1/2 (P[i][k] + P[k][i]) X[k][c]:  bc_k(P[i]) = P[i][k],  bc_i(P[k]) = P[k][i]
+            asm volatile("s_nop 4\n\t"
+#define LAT_M1(k, xk) LAT_DPP(0, 5, xk, k) LAT_DPP(1, 6, xk, k) LAT_DPP(2, 7, xk, k) LAT_DPP(3, 8, xk, k) LAT_DPP(4, 9, xk, k)
+#define LAT_M2(pk, xk) LAT_DPP(0, pk, xk, 0) LAT_DPP(1, pk, xk, 1) LAT_DPP(2, pk, xk, 2) LAT_DPP(3, pk, xk, 3) LAT_DPP(4, pk, xk, 4)
+                         LAT_M1(0, 10) LAT_M2(5, 10) LAT_M1(1, 11) LAT_M2(6, 11) LAT_M1(2, 12) LAT_M2(7, 12) LAT_M1(3, 13) LAT_M2(8, 13) LAT_M1(4, 14) LAT_M2(9, 14)
+                         : "+v"(M[0]), "+v"(M[1]), "+v"(M[2]), "+v"(M[3]), "+v"(M[4])
+                         : "v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]), "v"(P[4]), "v"(Xh[0]), "v"(Xh[1]), "v"(Xh[2]), "v"(Xh[3]), "v"(Xh[4]));
+            // lane 6: M = P cbar (kept for the corrector's vector pass), then y = P cbar + p
+#pragma unroll
+            for (int i = 0; i < 5; i++) { *(c == 6 ? sTab + LAT_TAB * k + 7 + i : sDum + lane) = M[i]; M[i] = fma(m6, P[i], M[i]); }
+            // G[c] = sum_i Bbar[i] M[i][c]: lanes 0..4 F, lane 5 Bbar' P Bbar, lane 6 Bbar' y   (Bbar = column 5; its row 4 is 1)
+            real G0 = radd, G1 = M[4];
+            asm volatile("s_nop 4\n\t"
+                         LAT_DPP(0, 2, 6, 5) LAT_DPP(1, 3, 7, 5) LAT_DPP(0, 4, 8, 5) LAT_DPP(1, 5, 9, 5)
+                         : "+v"(G0), "+v"(G1)
+                         : "v"(X[0]), "v"(X[1]), "v"(X[2]), "v"(X[3]), "v"(M[0]), "v"(M[1]), "v"(M[2]), "v"(M[3]));
+            const real G = G0 + G1;                       // lane 5: S = Rhat + Bbar' P Bbar; lane 6: f = rhat + Bbar' y
+            const real Sinv = frcp(lat_bc<5>(G));
+            const real Kc = -G * Sinv;                    // lanes 0..4: K[c]; lane 6: kff
+            *(wslot >= 0 ? sTab + LAT_TAB * k + wslot : sDum + lane) = c == 5 ? Sinv : Kc;
+            // P_k[i][c] = Qhat[i][c] + sum_k Abar[k][i] M[k][c] + F[i] K[c]   (lane 6: p_k = qhat + Abar' y + F kff);  Abar[4][i] = (i == 4)
+            real Pn[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) Pn[i] = Qc[i];
+            Pn[2] += cpsi * dtk;
+            Pn[4] += M[4];                                // row 4 of Abar is e_4'
+            asm volatile("s_nop 4\n\t"
+#define LAT_P1(xk, mk) LAT_DPP(0, xk, mk, 0) LAT_DPP(1, xk, mk, 1) LAT_DPP(2, xk, mk, 2) LAT_DPP(3, xk, mk, 3) LAT_DPP(4, xk, mk, 4)
+                         LAT_P1(5, 9) LAT_P1(6, 10) LAT_P1(7, 11) LAT_P1(8, 12) LAT_P1(13, 14)
+                         : "+v"(Pn[0]), "+v"(Pn[1]), "+v"(Pn[2]), "+v"(Pn[3]), "+v"(Pn[4])
+                         : "v"(X[0]), "v"(X[1]), "v"(X[2]), "v"(X[3]), "v"(M[0]), "v"(M[1]), "v"(M[2]), "v"(M[3]), "v"(G), "v"(Kc));
+#pragma unroll
+            for (int i = 0; i < 5; i++) { P[i] = Pn[i]; Qc[i] = Qn[i]; }
+#pragma unroll
+            for (int i = 0; i < 4; i++) X[i] = Xn[i];
+            dtk = dtn; radd = raddn;
+        }
+    };
+
+    // ---------------- Riccati vector pass (corrector): p_k = qhat + Abar' y + K f,  y = P cbar + p,  f = rhat + Bbar' y,  kff = -Sinv f ----------------
+    // A stage is ~25 instructions here: the matrix columns are requested THREE stages ahead (L2 latency ~ several stages of this pass), the LDS operands one.
+    auto vector_pass = [&]() {
+        constexpr int D = 3;
+        real buf[D][4];
+        const int mcoff = c < 5 ? (int)(sTab - sZero) + 7 + c : 0, mcmul = c < 5 ? LAT_TAB : 0;       // P cbar [c]
+        const int koff = c < 5 ? (int)(sTab - sZero) + c : 0;                                        // K[c]
+        const int qvoff = c < 5 ? (int)(sRec - sZero) + 6 + c : 0, qvmul = c < 5 ? LAT_REC : 0;      // qhat[c]
+        real p = (sZero + qvoff)[qvmul * (N - 1)];
+        auto request = [&](int k, real* Xo) { const real* cp = colp + (size_t)(k < 0 ? 0 : k) * LATP;
+#pragma unroll
+            for (int i = 0; i < 4; i++) Xo[i] = cp[8 * i]; };
+        auto request_lds = [&](int k, real* o5) { const int kk = k < 0 ? 0 : k, km = kk > 0 ? kk - 1 : 0;
+            o5[0] = (sZero + mcoff)[mcmul * kk]; o5[1] = (sZero + koff)[mcmul * kk]; o5[2] = (sZero + qvoff)[qvmul * km]; o5[3] = sRec[LAT_REC * kk + 11]; o5[4] = sTab[LAT_TAB * kk + 6]; };
+#pragma unroll
+        for (int u = 0; u < D; u++) request(N - 1 - u, buf[u]);
+        real lo[5], ln[5];
+        request_lds(N - 1, lo);
+#pragma unroll 1
+        for (int k0 = N - 1; k0 >= 0; k0 -= D) {
+            // ONE basic block per D stages (stages below 0 of the last group run on stage 0's operands and store nothing): a buffer is re-requested only after the
+            // arithmetic that reads it, so the loads land in the registers they replace and nothing has to be copied (a copy would wait for the load it copies)
+#pragma unroll
+            for (int u = 0; u < D; u++) {
+                const int k = k0 - u;
+                request_lds(k - 1, ln);
+                const real y = lo[0] + p;              // lanes >= 5: 0
+                real acc = cx4 * lat_bc<4>(y);         // row 4 of columns 4, 5 is 1
+                asm volatile("s_nop 4\n\t"
+                             LAT_DPP(0, 1, 2, 0) LAT_DPP(0, 1, 3, 1) LAT_DPP(0, 1, 4, 2) LAT_DPP(0, 1, 5, 3)
+                             : "+v"(acc) : "v"(y), "v"(buf[u][0]), "v"(buf[u][1]), "v"(buf[u][2]), "v"(buf[u][3]));
+                request(k - D, buf[u]);
+                const real f = lo[3] + lat_bc<5>(acc); // lane 5's column is Bbar
+                *((c == 0 && k >= 0) ? sTab + LAT_TAB * (k < 0 ? 0 : k) + 5 : sDum + lane) = -lo[4] * f;
+                p = m5lt * (lo[2] + acc + lo[1] * f);
+#pragma unroll
+                for (int i = 0; i < 5; i++) lo[i] = ln[i];
+            }
+        }
+    };
+
+    // ---------------- roll-out: lane i < 4 holds row i of [A | B0+Bf | Bf | c], lane 4 the delta row, lane 5 the gain row (K | 0 | kff) ----------------
+    const int ri = c < 4 ? c : 0;
+    const real wA = c < 4 ? real(1.0) : real(0.0), wD = c == 4 ? real(1.0) : real(0.0);
+    const real x0c = c < 4 ? Q[o.qcurr + 2 + c] : (c == 4 ? Q[o.ucurr] : real(0.0));
+    auto forward_pass = [&](bool use_gain) {
+        constexpr int D = 3;
+        const bool isK = c == 5 && use_gain;          // (a select, not a multiplication by 0: the gain table holds nothing before the first matrix pass)
+        real xr = x0c;
+        const real2* const rowp = reinterpret_cast<const real2*>(Lb + 8 * ri);
+        const real2* const tabp = reinterpret_cast<const real2*>(sTab);
+        real2 buf[D][4], kt[3], ktn[3];
+        auto request = [&](int k, real2* o4) { const real2* rp = rowp + (size_t)(k < N ? k : N - 1) * (LATP / 2);
+#pragma unroll
+            for (int q = 0; q < 4; q++) o4[q] = rp[q]; };
+        auto request_lds = [&](int k, real2* o3) { const real2* tp = tabp + (LAT_TAB / 2) * (k < N ? k : N - 1);
+#pragma unroll
+            for (int q = 0; q < 3; q++) o3[q] = tp[q]; };
+#pragma unroll
+        for (int u = 0; u < D; u++) request(u, buf[u]);
+        request_lds(0, kt);
+#pragma unroll 1
+        for (int k0 = 0; k0 < N; k0 += D) {
+            // (one basic block per D stages, as in the vector pass; stages >= N of the last group run on the last stage's operands and store nothing)
+#pragma unroll
+            for (int u = 0; u < D; u++) {
+                const int k = k0 + u;
+                request_lds(k + 1, ktn);
+                real R[7];
+                R[0] = isK ? kt[0].x : wA * buf[u][0].x; R[1] = isK ? kt[0].y : wA * buf[u][0].y; R[2] = isK ? kt[1].x : wA * buf[u][1].x; R[3] = isK ? kt[1].y : wA * buf[u][1].y;
+                R[4] = isK ? kt[2].x : wA * buf[u][2].x + wD; R[5] = wA * buf[u][2].y + wD; R[6] = isK ? kt[2].y : wA * buf[u][3].x;
+                asm volatile("" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]), "+v"(R[5]), "+v"(R[6]));      // the row is formed BEFORE its buffer is re-requested
+                request(k + D, buf[u]);
+                real acc = R[6], xn;
+                asm volatile("s_nop 4\n\t"
+                             LAT_DPP(1, 2, 3, 0) LAT_DPP(1, 2, 4, 1) LAT_DPP(1, 2, 5, 2) LAT_DPP(1, 2, 6, 3) LAT_DPP(1, 2, 7, 4)
+                             "s_nop 1\n\t" LAT_MOV " %0, %1\n\t" LAT_DPP(0, 1, 8, 5)
+                             : "=&v"(xn), "+v"(acc) : "v"(xr), "v"(R[0]), "v"(R[1]), "v"(R[2]), "v"(R[3]), "v"(R[4]), "v"(R[5]));
+                xr = xn;                              // lanes 0..4: x_{k+1}; lane 5: v_k (its Bbar entry is 0)
+                *((c < 6 && k < N) ? sRec + LAT_REC * (k < N ? k : 0) + c : sDum + lane) = xn;
+#pragma unroll
+                for (int q = 0; q < 3; q++) kt[q] = ktn[q];
+            }
+        }
+    };
+
+    // ---------------- stage-parallel part ----------------
+    real T[NSLOT][NR], L[NSLOT][NR], CR[NSLOT][NR];        // slack, multiplier, second-order term (later: d-lambda) of this lane's rows
+    bool act[NSLOT];
+#pragma unroll
+    for (int j = 0; j < NSLOT; j++) act[j] = c + 16 * j < N;
+    struct StageC { real b[NR], h0[4], h1[4], dts; };
+    auto load_consts = [&](int j, StageC& S) {
+        int s = act[j] ? c + 16 * j : N - 1;
+        asm volatile("" : "+v"(s));        // opaque per call: these loads are invariant across the interior-point loop, and hoisted out of it they would sit in ~45 registers per slot
+        const real2* cp = reinterpret_cast<const real2*>(Lb + (size_t)s * LATP + 32);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const real2 h = cp[i]; S.h0[i] = h.x; S.h1[i] = h.y; }
+        const real2 g01 = cp[4], g23 = cp[5], dd = cp[6], rr = cp[7];
+        S.b[2] = g01.x; S.b[3] = g01.y; S.b[4] = g23.x; S.b[5] = g23.y;
+        S.b[0] = dd.x; S.b[1] = -dd.y; S.b[6] = real(0.0); S.b[7] = real(0.0); S.b[8] = rr.x; S.b[9] = -rr.y;
+        if constexpr (WALLS) { const real* w = C.wall_edges + ((size_t)b * N + s) * 2; S.b[10] = w[0]; S.b[11] = -w[1]; S.b[12] = real(0.0); }
+        S.dts = Lb[(size_t)s * LATP + 48];
+    };
+    auto slacks = [&](const StageC& S, const real* x, real v, real s1, real s2, real sw, real* out) {
+        out[0] = S.b[0] - x[4]; out[1] = x[4] + S.b[1];
+#pragma unroll
+        for (int i = 0; i < 4; i++) out[2 + i] = S.b[2 + i] - (S.h0[i] * x[0] + S.h1[i] * x[1]) + (i < 2 ? s1 : s2);
+        out[6] = s1; out[7] = s2; out[8] = S.b[8] - v; out[9] = v + S.b[9];
+        if constexpr (WALLS) { out[10] = S.b[10] - x[3] + sw; out[11] = S.b[11] + x[3] + sw; out[12] = sw; }
+    };
+    // elimination of the stage-local slacks (each is a leaf of the KKT graph): sigma_g = -(c_g' x + g_g) d_g
+    struct Elim { real c10, c11, g1, d1, c20, c21, g2, d2, ch, gh, dh; };
+    auto eliminate = [&](const StageC& S, const real* W, const real* ell, Elim& E) {
+        E.d1 = lat_rcp(W[2] + W[3] + W[6]); E.d2 = lat_rcp(W[4] + W[5] + W[7]);
+        E.c10 = -(W[2] * S.h0[0] + W[3] * S.h0[1]); E.c11 = -(W[2] * S.h1[0] + W[3] * S.h1[1]);
+        E.c20 = -(W[4] * S.h0[2] + W[5] * S.h0[3]); E.c21 = -(W[4] * S.h1[2] + W[5] * S.h1[3]);
+        E.g1 = C.cp.W_beta * S.dts - ell[2] - ell[3] - ell[6]; E.g2 = C.cp.W_r * S.dts - ell[4] - ell[5] - ell[7];
+        if constexpr (WALLS) { E.dh = lat_rcp(W[10] + W[11] + W[12]); E.ch = -(W[10] - W[11]); E.gh = C.wall_weight * S.dts - ell[10] - ell[11] - ell[12]; }
+        else { E.dh = real(0.0); E.ch = real(0.0); E.gh = real(0.0); }
+    };
+    // barrier weights of slot j at the current iterate: it = 1/t, W = lambda/t, ell = (sigma mu - corr)/t + lambda - W b
+    auto weights = [&](int j, const StageC& S, real sgmu, bool with_corr, real* it_, real* W, real* ell) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            it_[r] = lat_rcp(T[j][r]); W[r] = L[j][r] * it_[r];
+            ell[r] = (with_corr ? (sgmu - CR[j][r]) * it_[r] : real(0.0)) + L[j][r] - W[r] * S.b[r];
+        }
+    };
+    auto assemble = [&](int j, real sgmu, bool matrices) {
+        StageC S; load_consts(j, S);
+        real it_[NR], W[NR], ell[NR]; Elim E;
+        weights(j, S, sgmu, !matrices, it_, W, ell);
+        eliminate(S, W, ell, E);
+        real g0 = real(0.0), g1 = real(0.0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { g0 += S.h0[i] * ell[2 + i]; g1 += S.h1[i] * ell[2 + i]; }
+        if (act[j]) {
+            real* rec = sRec + LAT_REC * (c + 16 * j);
+            rec[6] = g0 - E.c10 * E.g1 * E.d1 - E.c20 * E.g2 * E.d2;
+            rec[7] = g1 - E.c11 * E.g1 * E.d1 - E.c21 * E.g2 * E.d2;
+            rec[8] = real(0.0);
+            if constexpr (WALLS) rec[9] = (ell[10] - ell[11]) - E.ch * E.gh * E.dh; else rec[9] = real(0.0);
+            rec[10] = ell[0] - ell[1];
+            rec[11] = ell[8] - ell[9];
+            if (matrices) {
+                real yy = real(0.0), yr = real(0.0), rr = real(0.0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) { yy += W[2 + i] * S.h0[i] * S.h0[i]; yr += W[2 + i] * S.h0[i] * S.h1[i]; rr += W[2 + i] * S.h1[i] * S.h1[i]; }
+                rec[0] = yy - E.c10 * E.c10 * E.d1 - E.c20 * E.c20 * E.d2;
+                rec[1] = yr - E.c10 * E.c11 * E.d1 - E.c20 * E.c21 * E.d2;
+                rec[2] = rr - E.c11 * E.c11 * E.d1 - E.c21 * E.c21 * E.d2;
+                rec[3] = real(2.0) * C.cp.Q_e * S.dts;
+                if constexpr (WALLS) rec[3] += W[10] + W[11] - E.ch * E.ch * E.dh;
+                rec[4] = real(2.0) * C.cp.R_delta * S.dts + W[0] + W[1];
+                rec[5] = real(2.0) * C.cp.R_ddelta * frcp(S.dts) + W[8] + W[9];
+            }
+        }
+    };
+    // Newton point of slot j from the roll-out (x+ of node s+1, v+ of transition s) -> eliminated slacks and the slack of every row
+    auto newton = [&](int j, const StageC& S, const Elim& E, real* xn, real& vn, real* sg3, real* tp) {
+        const real* rec = sRec + LAT_REC * (act[j] ? c + 16 * j : N - 1);
+#pragma unroll
+        for (int m = 0; m < 5; m++) xn[m] = rec[m];
+        vn = rec[5];
+        sg3[0] = -(E.c10 * xn[0] + E.c11 * xn[1] + E.g1) * E.d1;
+        sg3[1] = -(E.c20 * xn[0] + E.c21 * xn[1] + E.g2) * E.d2;
+        sg3[2] = WALLS ? -(E.ch * xn[3] + E.gh) * E.dh : real(0.0);
+        slacks(S, xn, vn, sg3[0], sg3[1], sg3[2], tp);
+    };
+
+    // ---------------- start: v = 0 roll-out (dynamics- and rate-feasible), soft-row slacks just feasible + 1, t = max(slack, tau), lambda = mu0 / t ----------------
+    __syncthreads();
+    forward_pass(false);
+    wave_sync();
+    stamp(3);
+    real rp0 = real(0.0);
+    // the damped iterate (x_{s+1}, sigma) of a stage is kept in the output buffers (read-modify-write once per iteration), not in registers
+    real* SXs[NSLOT]; real* SGs[NSLOT];
+#pragma unroll
+    for (int j = 0; j < NSLOT; j++) {
+        const int s = act[j] ? c + 16 * j : N - 1;
+        SXs[j] = O.sol_x + (size_t)b * NN * 8 + 8 * (s + 1); SGs[j] = O.sol_sigma + ((size_t)b * N + s) * 3;
+        StageC S; load_consts(j, S);
+        const real* rec = sRec + LAT_REC * s;
+        real xs[5], sl[NR];
+#pragma unroll
+        for (int m = 0; m < 5; m++) xs[m] = rec[m];
+        slacks(S, xs, real(0.0), real(0.0), real(0.0), real(0.0), sl);
+        const real sig0 = real(1.0), tau = real(1e-4);
+        const real s1 = fmax(real(0.0), -fmin(sl[2], sl[3])) + sig0, s2 = fmax(real(0.0), -fmin(sl[4], sl[5])) + sig0;
+        real sw = real(0.0);
+        if constexpr (WALLS) sw = fmax(real(0.0), -fmin(sl[10], sl[11])) + sig0;
+        slacks(S, xs, real(0.0), s1, s2, sw, sl);
+        if (act[j] && valid) {
+            SXs[j][0] = real(0.0); SXs[j][1] = C.ux_dummy; SXs[j][7] = real(0.0);      // the embedded layout pg_get_solution documents: (0, Ux slot, Uy, r, dpsi, e, delta, 0)
+#pragma unroll
+            for (int m = 0; m < 5; m++) SXs[j][2 + m] = xs[m];
+            SGs[j][0] = s1; SGs[j][1] = s2; SGs[j][2] = sw;
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const real tj = act[j] ? fmax(sl[r], tau) : real(1.0);
+            T[j][r] = tj; L[j][r] = act[j] ? C.ipm_mu0 / tj : real(1.0); CR[j][r] = real(0.0);      // (slots beyond the horizon: t = lambda = 1, never updated, never summed)
+            if (act[j]) rp0 = fmax(rp0, tj - sl[r]);
+        }
+    }
+    rp0 = row_max(rp0);
+    const real ntot = (real)(N * NR), intot = real(1.0) / ntot, tol = C.ipm_tol;
+    real mu = real(0.0), phi = real(1.0);
+    int status = PG_MAX_ITER, it = 0, good = 0;
+    bool done = false;
+    const int cap = C.ipm_max_iter;
+
+    while (true) {
+        {   // complementarity gap and the stopping rules (per instance = per row of lanes)
+            real ms = real(0.0);
+#pragma unroll
+            for (int j = 0; j < NSLOT; j++)
+#pragma unroll
+                for (int r = 0; r < NR; r++) ms += act[j] ? T[j][r] * L[j][r] : real(0.0);
+            const real mu_new = row_sum(ms) * intot;
+            if (!done) {
+                mu = mu_new;
+                if (it >= cap && !(cap >= 20 && good >= 3 && it < cap + 20)) done = true;                    // iteration cap (a converging attempt gets twenty more)
+                else if (!(mu == mu) || fabs(mu) > PG_BIG) { status = PG_NUMERICAL; done = true; }
+                else if (mu <= tol && phi * fmax(rp0, real(1.0)) <= tol) { status = PG_SOLVED; done = true; }
+            }
+        }
+        if (__all(done)) break;
+        stamp(5);
+        // ---- predictor: sigma = 0, no second-order term ----
+#pragma unroll
+        for (int j = 0; j < NSLOT; j++) { assemble(j, real(0.0), true); __builtin_amdgcn_sched_barrier(0); }
+        wave_sync();
+        stamp(0);
+        matrix_pass();
+        wave_sync();
+        stamp(1);
+        forward_pass(true);
+        wave_sync();
+        stamp(3);
+        real rmax = real(0.0), S2 = real(0.0);
+#pragma unroll
+        for (int j = 0; j < NSLOT; j++) {
+            StageC S; load_consts(j, S);
+            real it_[NR], W[NR], ell[NR], tp[NR], xn[5], vn, sg3[3]; Elim E;
+            weights(j, S, real(0.0), false, it_, W, ell);
+            eliminate(S, W, ell, E);
+            newton(j, S, E, xn, vn, sg3, tp);
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const real dt_ = tp[r] - T[j][r], dl_ = -W[r] * tp[r];
+                CR[j][r] = dt_ * dl_;
+                // step to the boundary: -dt/t = 1 - tp/t and, for the affine direction, -dl/lambda = tp/t
+                const real rho = tp[r] * it_[r];
+                rmax = fmax(rmax, act[j] ? fmax(real(1.0) - rho, rho) : real(0.0));
+                S2 += act[j] ? CR[j][r] : real(0.0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        rmax = row_max(rmax); S2 = row_sum(S2);
+        const real aaff = rmax > real(1.0) ? frcp(rmax) : real(1.0);
+        // rounding floor: once mu is within 1e4 x of the tolerance and the affine direction can no longer move, further iterations only add noise
+        if (!done && mu <= real(1e4) * tol && aaff < real(0.3) && phi * fmax(rp0, real(1.0)) <= tol) { status = PG_SOLVED; done = true; }
+        // sum (t + a dt)(lambda + a dl) = (1 - a) sum t lambda + a^2 sum dt dl   (t dl + lambda dt = -t lambda for the affine direction)
+        const real mu_aff = (real(1.0) - aaff) * mu + aaff * aaff * S2 * intot;
+        real sg = fmin(mu_aff * frcp(mu), real(1.0)); sg = sg * sg * sg;
+        const real sgmu = sg * mu;
+        stamp(4);
+        // ---- corrector ----
+#pragma unroll
+        for (int j = 0; j < NSLOT; j++) { assemble(j, sgmu, false); __builtin_amdgcn_sched_barrier(0); }
+        wave_sync();
+        stamp(0);
+        vector_pass();
+        wave_sync();
+        stamp(2);
+        forward_pass(true);
+        wave_sync();
+        stamp(3);
+        real T1 = real(0.0), T2 = real(0.0), SN[NSLOT][3];
+        rmax = real(0.0);
+#pragma unroll
+        for (int j = 0; j < NSLOT; j++) {
+            StageC S; load_consts(j, S);
+            real it_[NR], W[NR], ell[NR], tp[NR], xn[5], vn; Elim E;
+            weights(j, S, sgmu, true, it_, W, ell);
+            eliminate(S, W, ell, E);
+            newton(j, S, E, xn, vn, SN[j], tp);
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const real dt_ = tp[r] - T[j][r], dl_ = (sgmu - CR[j][r]) * it_[r] - W[r] * tp[r];
+                CR[j][r] = dl_;                            // (the second-order term has done its job: the slot now carries d-lambda to the update below)
+                const real rj = fmax(-dt_ * it_[r], -dl_ * lat_rcp(L[j][r]));
+                rmax = fmax(rmax, act[j] ? rj : real(0.0));
+                T1 += act[j] ? T[j][r] * dl_ + L[j][r] * dt_ : real(0.0);
+                T2 += act[j] ? dt_ * dl_ : real(0.0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        rmax = row_max(rmax); T1 = row_sum(T1); T2 = row_sum(T2);
+        const real alpha = rmax > real(0.995) ? real(0.995) * frcp(rmax) : real(1.0);
+        // rounding floor, second form: a step that would MULTIPLY mu near the tolerance is a Newton direction computed at a conditioning the arithmetic no longer
+        // carries -- the iterate at hand is as good as it gets
+        if (!done && mu <= (sizeof(real) == 8 ? real(1e5) : real(1e2)) * tol && phi * fmax(rp0, real(1.0)) <= tol) {
+            const real mnew = mu + (alpha * T1 + alpha * alpha * T2) * intot;
+            if (!(mnew <= real(4.0) * mu)) { status = PG_SOLVED; done = true; }
+        }
+        const real a = done ? real(0.0) : alpha;
+#pragma unroll
+        for (int j = 0; j < NSLOT; j++) {
+            StageC S; load_consts(j, S);
+            const real* rec = sRec + LAT_REC * (act[j] ? c + 16 * j : N - 1);
+            real xn[5], tp[NR];
+#pragma unroll
+            for (int m = 0; m < 5; m++) xn[m] = rec[m];
+            slacks(S, xn, rec[5], SN[j][0], SN[j][1], SN[j][2], tp);
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                T[j][r] += act[j] ? a * (tp[r] - T[j][r]) : real(0.0);
+                L[j][r] += act[j] ? a * CR[j][r] : real(0.0);
+            }
+            if (act[j] && valid && !done) {
+#pragma unroll
+                for (int m = 0; m < 5; m++) { const real cur = SXs[j][2 + m]; SXs[j][2 + m] = cur + a * (xn[m] - cur); }
+#pragma unroll
+                for (int m = 0; m < 3; m++) { const real cur = SGs[j][m]; SGs[j][m] = cur + a * (SN[j][m] - cur); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!done) {
+            phi *= (real(1.0) - alpha);
+            good = alpha > real(0.5) ? good + 1 : 0;
+            if (mu > real(1e8) * C.ipm_mu0) done = true;      // diverging: give up (PG_MAX_ITER)
+            it++;
+        }
+        wave_sync();
+        stamp(4);
+    }
+    stamp(5);
+    if (prof && valid && c == 0) for (int i = 0; i < 6; i++) prof[(size_t)b * 6 + i] = pc[i];
+
+    // ---------------- outputs ----------------
+    if (valid) {
+        real* SX = O.sol_x + (size_t)b * NN * 8;
+        if (c < 8) SX[c] = c == 1 ? C.ux_dummy : (c >= 2 && c < 6 ? Q[o.qcurr + c] : (c == 6 ? Q[o.ucurr] : real(0.0)));
+#pragma unroll
+        for (int j = 0; j < NSLOT; j++) {
+            if (!act[j]) continue;
+            // local row -> bit of the 16-bit active mask (the numbering of the embedded stage: pigeon_mpc.h)
+            constexpr int bit[13] = {3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 0, 1, 2};
+            unsigned mask = 0;
+#pragma unroll
+            for (int r = 0; r < NR; r++) if (L[j][r] > T[j][r]) mask |= 1u << bit[r];
+            O.active[(size_t)b * N + c + 16 * j] = (uint16_t)mask;
+        }
+        if (c == 0) {
+            // get_next_control (decoupled_lat_long.jl:275-278): delta of node 2 from the QP, Fx of the seeded node 2
+            const real d = SXs[0][6] * C.un0, Fx = nodes[((size_t)b * NN + 1) * 10 + 7];
+            real* U = O.u_out + (size_t)b * 3;
+            U[0] = d; U[1] = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac; U[2] = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
+            O.status[b] = status; O.iters[b] = it; O.mu[b] = mu; O.polish[b] = 0;
+            O.solved[b] = 1;      // model_predictive_control.jl:76: solved = true
+        }
+    }
+}

@@ -129,3 +129,94 @@ def test_walls_extension_matches_oracle_qp_with_wall_rows(pkg, oracle_mod, skidp
     assert np.max(xf[:, 1:, 5]) > -0.04                                                # ... and without it the optimum crosses e = -0.05
     with pytest.raises(pkg.PigeonError):
         pkg.BatchedTrajectoryTrackingMPC(tube, 4, walls=True)                         # coupled + walls is refused
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4] at FULL size, in the solver configuration the library ships (pg_default_config_decoupled): every instance against the oracle
+
+def unembed_qp(orc, row):
+    """Inverse of embed_sd: one row of pg_get_qp of a PG_DECOUPLED handle -> the oracle's lateral stage data."""
+    N = orc.N; o = 0
+    def take(n, shape):
+        nonlocal o
+        v = row[o:o + n].reshape(shape); o += n
+        return v
+    A = take(36 * N, (N, 6, 6)); B0 = take(12 * N, (N, 6, 2)); Bf = take(12 * N, (N, 6, 2)); c = take(6 * N, (N, 6))
+    H = take(8 * N, (N, 4, 2)); G = take(4 * N, (N, 4)); dmin = take(N, (N,)); dmax = take(N, (N,)); take(N, (N,)); ddmin = take(N, (N,)); ddmax = take(N, (N,)); dt = take(N, (N,))
+    qc = take(6, (6,)); uc = take(2, (2,))
+    return np.concatenate([A[:, 2:, 2:].ravel(), B0[:, 2:, 0].ravel(), Bf[:, 2:, 0].ravel(), c[:, 2:].ravel(), H.ravel(), G.ravel(), dmin, dmax, ddmin, ddmax, dt, qc[2:], [uc[0]]])
+
+
+def extend_with_walls(orc, qpc, edges, dt, Ww):
+    """Canonical lateral QP + the build-defined wall rows (columns n..n+N-1 = sw_k; rows m+3k: e - sw <= edge_L, m+3k+1: e + sw >= edge_R, m+3k+2: sw >= 0)."""
+    n, m, Nh = orc.n, orc.m, orc.N
+    A = sp.csc_matrix((qpc["Ax"], qpc["Ai"], qpc["Ap"]), shape=(m, n))
+    k = np.arange(Nh); col = 4 * (k + 1) + 3
+    rows = np.concatenate([3 * k, 3 * k, 3 * k + 1, 3 * k + 1, 3 * k + 2]); cols = np.concatenate([col, n + k, col, n + k, n + k])
+    vals = np.concatenate([np.ones(Nh), -np.ones(Nh), np.ones(Nh), np.ones(Nh), np.ones(Nh)])
+    W = sp.csc_matrix((vals, (rows, cols)), shape=(3 * Nh, n + Nh))
+    lw = np.full(3 * Nh, -1e20); uw = np.full(3 * Nh, 1e20)
+    uw[3 * k] = edges[:, 0]; lw[3 * k + 1] = edges[:, 1]; lw[3 * k + 2] = 0.0
+    Aw = sp.vstack([sp.hstack([A, sp.csc_matrix((m, Nh))]), W]).tocsc(); Aw.sort_indices()
+    return dict(Pd=np.concatenate([qpc["Pd"], np.zeros(Nh)]), q=np.concatenate([qpc["q"], Ww * dt]), Ap=Aw.indptr, Ai=Aw.indices, Ax=Aw.data,
+                l=np.concatenate([qpc["l"], lw]), u=np.concatenate([qpc["u"], uw])), Aw
+
+
+def check_lateral_batch_against_oracle(pkg, oracle_mod, tube, mpc, B, Ns, Nl, walls, Ww=1000.0, want_more=False):
+    """Every instance of the batch `mpc` just solved: exact optimum of ITS OWN QP data by the oracle (threaded).  Returns per instance
+    (|delta_2 - delta_2*|, relative objective gap, worst row violation, max |delta - delta*| over the horizon, oracle status,
+     oracle polish rounds (>= 1: a VERIFIED KKT point), max |e*| over the horizon, max sigma*)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    qp = mpc.qp_data(); x, sg = mpc.solution()
+    edges = mpc.wall_edges() if walls else None
+    nthr = min(16, len(os.sched_getaffinity(0)))
+    orcs = []
+    for _ in range(nthr):
+        o = oracle_mod.OracleDecoupled(N_short=Ns, N_long=Nl); o.set_trajectory(tube.data); orcs.append(o)
+
+    def work(w):
+        o = orcs[w]; out = []
+        for b in range(w, B, nthr):
+            sd = unembed_qp(o, qp[b]); qpc = o.assemble_qp(sd)
+            xg = np.concatenate([x[b, :, 2:6].ravel(), x[b, :, 6], sg[b, :, :2].ravel(), np.diff(x[b, :, 6])])
+            if walls:
+                S = o.unpack_sd(sd)
+                qpw, Ac = extend_with_walls(o, qpc, edges[b], S["dt"], Ww)
+                xe, ye, info = oracle_mod.solve_exact_generic(qpw)
+                xg = np.concatenate([xg, sg[b, :, 2]])
+            else:
+                qpw = qpc; Ac = sp.csc_matrix((qpc["Ax"], qpc["Ai"], qpc["Ap"]), shape=(o.m, o.n))
+                xe, ye, info = o.solve_exact(sd)
+            X = o.split_x(xe[:o.n])
+            obj = lambda v: 0.5 * np.dot(qpw["Pd"] * v, v) + np.dot(qpw["q"], v)
+            Axg = Ac @ xg
+            out.append((abs(x[b, 1, 6] - X["delta"][1]), (obj(xg) - obj(xe)) / (1.0 + abs(obj(xe))), max(np.max(qpw["l"] - Axg), np.max(Axg - qpw["u"])),
+                        float(np.max(np.abs(x[b, :, 6] - X["delta"]))), info["status"], info["polished"], float(np.max(np.abs(X["q"][:, 3]))), float(np.max(X["sigma"]))))
+        return out
+    with ThreadPoolExecutor(nthr) as ex:
+        parts = list(ex.map(work, range(nthr)))
+    res = np.zeros((B, 8))
+    for w, part in enumerate(parts):
+        res[w:B:nthr] = np.array(part)
+    return res
+
+
+@pytest.mark.parametrize("walls", [False, True])
+def test_config5_as_shipped_every_instance_against_the_oracle(pkg, oracle_mod, skidpad, walls):
+    """BASELINE configs[4]: B = 4096 lateral MPCs, N = 50 (N_short 10 + N_long 40), the bench's own batch (config2_inputs, seed 12345), solved with the
+    DEFAULT solver configuration of the library (whatever pg_default_config_decoupled ships) -- with the wall rows (the bench's configs[4] line) and
+    without (the reference's lateral QP as it stands).  Bar: the applied steering delta_2 within 1e-6 of the exact optimum of the same QP data for
+    EVERY instance, the objective within 1e-6 relative, every row of the canonical QP satisfied to 1e-8."""
+    B, Ns, Nl = 4096, 10, 40
+    mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, B, N_short=Ns, N_long=Nl, walls=walls)
+    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B)
+    u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
+    assert np.all(status == pkg.SOLVED), np.bincount(status)
+    res = check_lateral_batch_against_oracle(pkg, oracle_mod, skidpad, mpc, B, Ns, Nl, walls)
+    print(f"walls={walls}: max |d2-d2*| {res[:, 0].max():.2e} (median {np.median(res[:, 0]):.1e}), max objective gap {res[:, 1].max():.2e}, worst row violation {res[:, 2].max():.2e}, "
+          f"max |delta-delta*| over the horizon {res[:, 3].max():.2e}, iterations mean {iters.mean():.1f} max {iters.max()}")
+    assert np.all(res[:, 4] == 1)
+    assert res[:, 0].max() <= 1e-6, (res[:, 0].max(), int(np.argmax(res[:, 0])))
+    assert res[:, 1].max() <= 1e-6 and res[:, 2].max() <= 1e-8, (res[:, 1].max(), res[:, 2].max())
+    mpc.close()

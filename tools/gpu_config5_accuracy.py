@@ -1,0 +1,31 @@
+"""BASELINE configs[4] (B = 4096 lateral MPCs, N = 50), every instance against the oracle's exact optimum of the same QP data: per-instance table
+(error of the applied steering, objective gap, row violation, horizon error, oracle status / verification, iterations, mu, size of the optimum) saved to
+gpurun_out/config5_accuracy_<walls>.npz.  Usage (GPU box):  python tools/gpu_config5_accuracy.py [walls] [polish]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_pkg
+from test_gpu_decoupled import check_lateral_batch_against_oracle
+from oracle import oracle as om
+
+walls = len(sys.argv) > 1 and sys.argv[1] == "1"
+polish = None if len(sys.argv) <= 2 else sys.argv[2] == "1"
+pkg = load_pkg(); om.build()
+traj = pkg.load_path_fixture("skidpadoval")
+B, Ns, Nl = 4096, 10, 40
+mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=Ns, N_long=Nl, walls=walls, polish=polish)
+state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B)
+u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
+t = time.time()
+res = check_lateral_batch_against_oracle(pkg, om, traj, mpc, B, Ns, Nl, walls, want_more=True)
+x, sg = mpc.solution(); st, it, act, mu = mpc.solve_info()
+print(f"oracle sweep {time.time() - t:.1f} s; GPU status {np.bincount(status)}, iterations mean {iters.mean():.2f} max {iters.max()}")
+ok = res[:, 4] == 1
+print(f"oracle solved {int(ok.sum())}/{B}, verified KKT point (polished) {int((res[:, 5] >= 1).sum())}/{B}")
+for name, sel in [("all oracle-solved", ok), ("oracle verified", ok & (res[:, 5] >= 1)), ("|e*| <= 10 m", ok & (res[:, 6] <= 10.0)), ("|e*| > 10 m", ok & (res[:, 6] > 10.0))]:
+    if sel.sum():
+        e = res[sel, 0]
+        print(f"{name:22s} n={int(sel.sum()):5d}  |d2-d2*| max {e.max():.2e} p99 {np.percentile(e, 99):.2e} median {np.median(e):.1e}  > 1e-6: {int((e > 1e-6).sum())}   objective gap max {res[sel, 1].max():.2e}  horizon max {res[sel, 3].max():.2e}")
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+np.savez(os.path.join(ROOT, "gpurun_out", f"config5_accuracy_walls{int(walls)}_polish{polish}.npz"), res=res, status=status, iters=iters, mu=mu, d2=x[:, 1, 6])
