@@ -1,6 +1,12 @@
-"""numpy prototype of the algorithm of k_solve_lat (pigeon.jl_amd/csrc/pg_solve_lat.hip): Mehrotra predictor-corrector on the lateral tracking QP of
-decoupled_lat_long.jl:134-226 in its 5-state stage form.  NOT the oracle and not the product: the place where the kernel's arithmetic was worked out and where its
-start / stop rules were tuned (iteration counts do not depend on the hardware).  tests/test_lat_prototype.py checks it against the oracle's exact solve.
+"""TEST INFRASTRUCTURE (part of oracle/: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it).
+
+Stage-structured interior point for the lateral tracking QP of decoupled_lat_long.jl:134-226 in numpy: Mehrotra predictor-corrector in the 5-state stage form, every Newton
+step one Riccati recursion.  Two jobs: (1) it is the numpy twin in which the arithmetic of the product's k_solve_lat (pigeon.jl_amd/csrc/pg_solve_lat.hip) was worked out
+and its start / stop rules tuned (iteration counts do not depend on the hardware); (2) it is the oracle's SECOND exact method for this formulation: the sparse interior
+point of oracle/qp.hpp stalls on the few percent of N = 50 instances whose optimum leaves the linearisation by kilometres (saturated steering on an open-loop unstable
+horizon; the regularised KKT factorisation loses the dynamics rows), this recursion -- dynamics exact at every iterate -- does not.  Whatever it returns is only a
+CANDIDATE: OracleDecoupled.solve_exact_verified hands it to the canonical QP's active-set polish (oracle/qp.hpp: polish_from), which accepts nothing but a verified KKT
+point of the canonical (P, q, A, l, u).  tests/test_lat_ipm_numpy.py checks it against the sparse solver where both work.
 
 Stage form (exact): x_k = (Uy, r, dpsi, e, delta)_k, k = 0..N;  v_k = delta_{k+1} - delta_k (the reference's d-delta variables, :146);
   x_{k+1} = Abar_k x_k + Bbar_k v_k + cbar_k,  Abar = [A  B0+Bf; 0 1],  Bbar = [Bf; 1],  cbar = [c; 0],  x_0 = (q_curr, delta_curr) fixed (:150-151).
@@ -121,17 +127,31 @@ def eliminated_slacks(D, E, x):
     return s1, s2, sw
 
 
-def solve(D, tol=1e-12, mu0=100.0, max_iter=40, sig0=1.0, tau=1e-4, floor=True, verbose=False):
-    """Returns dict(x, v, s1, s2, sw, t, lam, iters, status, mu).  status 1 solved, 2 iteration cap, 4 numerical."""
+def solve(D, tol=1e-12, mu0=100.0, max_iter=40, sig0=1.0, tau=1e-4, floor=True, verbose=False, start="rollout", wls=1.0):
+    """Returns dict(x, v, s1, s2, sw, t, lam, iters, status, mu).  status 1 solved, 2 iteration cap, 4 numerical.
+    start: "rollout" = v = 0 roll-out (what the kernel does); "ls" = one Newton solve with every row replaced by a quadratic penalty of weight wls (closed-loop roll-out,
+    bounded on the open-loop unstable horizons), then a uniform shift that makes every slack >= 1."""
     N, NR = D["N"], D["NR"]
-    x, v = forward(D, None, None, use_gain=False)                      # v = 0 roll-out
     z = np.zeros(N)
-    sl = slacks(D, x, v, z, z, z)
-    s1 = np.maximum(0.0, -np.minimum(sl[:, 2], sl[:, 3])) + sig0; s2 = np.maximum(0.0, -np.minimum(sl[:, 4], sl[:, 5])) + sig0
-    sw = np.maximum(0.0, -np.minimum(sl[:, 10], sl[:, 11])) + sig0 if D["walls"] else z
-    sl = slacks(D, x, v, s1, s2, sw)
-    t = np.maximum(sl, tau); lam = mu0 / t
-    rp0 = float(np.max(t - sl)); phi = 1.0
+    if start == "rollout":
+        x, v = forward(D, None, None, use_gain=False)                      # v = 0 roll-out
+        sl = slacks(D, x, v, z, z, z)
+        s1 = np.maximum(0.0, -np.minimum(sl[:, 2], sl[:, 3])) + sig0; s2 = np.maximum(0.0, -np.minimum(sl[:, 4], sl[:, 5])) + sig0
+        sw = np.maximum(0.0, -np.minimum(sl[:, 10], sl[:, 11])) + sig0 if D["walls"] else z
+        sl = slacks(D, x, v, s1, s2, sw)
+        t = np.maximum(sl, tau); lam = mu0 / t
+        rp0 = float(np.max(t - sl))
+    else:
+        W = np.full((N, NR), wls); ell = W * 0.0 + wls * 1.0 - W * D["b"]       # lambda = t = 1: ell = lambda - W b
+        Qh, qh, Rh, rh, E = assemble(D, W, ell)
+        K, Si, Mc, kff = riccati_matrices(D, Qh, qh, Rh, rh)
+        x, v = forward(D, K, kff)
+        s1, s2, sw = eliminated_slacks(D, E, x)
+        sl = slacks(D, x, v, s1, s2, sw)
+        shift = max(0.0, 1.0 - float(sl.min()))
+        t = sl + shift; lam = mu0 / t
+        rp0 = shift
+    phi = 1.0
     ntot = N * NR
     status = 2; it = 0; good = 0; mu = 0.0
     while True:
@@ -182,3 +202,21 @@ def solve(D, tol=1e-12, mu0=100.0, max_iter=40, sig0=1.0, tau=1e-4, floor=True, 
             break
         it += 1
     return dict(x=x, v=v, s1=s1, s2=s2, sw=sw, t=t, lam=lam, iters=it, status=status, mu=mu)
+
+
+def canonical_candidate(D, r, Ns, walls=False):
+    """(x0, actv) for polish_from: the solver's answer `r` of stage data D in the variable and row order of the canonical lateral QP (oracle/mpc_decoupled.hpp =
+    the @constraint order of decoupled_lat_long.jl:146-203; with walls=True the N slack columns and 3N rows tests/test_gpu_decoupled.py::extend_with_walls appends)."""
+    N = D["N"]; Nn = N + 1
+    x0 = np.concatenate([r["x"][:, :4].ravel(), r["x"][:, 4], np.stack([r["s1"], r["s2"]], axis=1).ravel(), r["v"]] + ([r["sw"]] if walls else []))
+    m = 15 * N + 5
+    actv = np.zeros(m + (3 * N if walls else 0), dtype=np.int32)
+    on = r["lam"] > r["t"]
+    base = 2 * N + N + 5 + 4 * N
+    for k in range(N):
+        actv[2 * k] = on[k, 6]; actv[2 * k + 1] = on[k, 7]                     # vec(sigma) >= 0, column-major (:147)
+        b = base + 8 * k                                                        # per transition (:190-194): delta <= max, delta >= min, 4 envelope rows, d-delta <= max, >= min
+        actv[b] = on[k, 0]; actv[b + 1] = on[k, 1]; actv[b + 2:b + 6] = on[k, 2:6]; actv[b + 6] = on[k, 8]; actv[b + 7] = on[k, 9]
+        if walls:
+            actv[m + 3 * k] = on[k, 10]; actv[m + 3 * k + 1] = on[k, 11]; actv[m + 3 * k + 2] = on[k, 12]
+    return x0, actv

@@ -280,6 +280,59 @@ def solve_exact_generic(qp):
     return x, y, dict(iters=int(info[0]), status=int(info[1]), res_pri=info[2], res_dua=info[3], gap=info[4], polished=int(info[5]))
 
 
+def polish_generic(qp, x0, actv):
+    """Active-set polish of a canonical QP dict from the primal point x0 and the working set actv (int per row): (x, y, info); info["status"] == 1 and
+    info["polished"] >= 1 only for a VERIFIED KKT point (oracle/qp.hpp: polish_from)."""
+    L = lib()
+    n = len(qp["Pd"]); m = len(qp["l"])
+    x = np.zeros(n); y = np.zeros(m); info = np.zeros(6)
+    Ap = np.ascontiguousarray(qp["Ap"], dtype=np.int32); Ai = np.ascontiguousarray(qp["Ai"], dtype=np.int32); av = np.ascontiguousarray(actv, dtype=np.int32)
+    L.po_polish_generic(n, m, _d(_arr(qp["Pd"])), _d(_arr(qp["q"])), Ap.ctypes.data_as(c_ip), Ai.ctypes.data_as(c_ip), _d(_arr(qp["Ax"])),
+                        _d(_arr(qp["l"])), _d(_arr(qp["u"])), _d(_arr(x0, n)), av.ctypes.data_as(c_ip), _d(x), _d(y), _d(info))
+    return x, y, dict(iters=int(info[0]), status=int(info[1]), res_pri=info[2], res_dua=info[3], gap=info[4], polished=int(info[5]))
+
+
+def polish_lu(qp, x0, actv, rounds=10):
+    """The same active-set polish in scipy (sparse LU of the UNREGULARISED KKT matrix of the working set + iterative refinement): for the long-horizon QPs whose optimum
+    carries states of 1e4 -- vertices: as many active rows as variables -- where the regularised LDL' of qp.hpp's polish does not converge.  Accepts, like it, only a KKT
+    point of the full QP: every inactive row feasible and every active multiplier non-negative to 1e-9 of the problem's scale, KKT residual of the working set below
+    that too.  Returns (x, y, info)."""
+    import scipy.sparse as sp, scipy.sparse.linalg as spl
+    n = len(qp["Pd"]); m = len(qp["l"])
+    A = sp.csc_matrix((qp["Ax"], qp["Ai"], qp["Ap"]), shape=(m, n)).tocsr()
+    l, u = np.asarray(qp["l"]), np.asarray(qp["u"])
+    eq = l == u; lo = (l > -1e19) & ~eq; up = (u < 1e19) & ~eq; ineq = lo | up
+    bnd = np.where(eq | lo, l, u)
+    act = (np.asarray(actv) != 0) & ineq | eq
+    info = dict(iters=0, status=-2, res_pri=0.0, res_dua=0.0, gap=0.0, polished=0)
+    x = np.array(x0, dtype=float); y = np.zeros(m)
+    for rnd in range(rounds):
+        idx = np.where(act)[0]
+        Aa = A[idx]
+        K = sp.bmat([[sp.diags(qp["Pd"]), Aa.T], [Aa, None]], format="csc")
+        rhs = np.concatenate([-np.asarray(qp["q"]), bnd[idx]])
+        try:
+            lu = spl.splu((K + sp.diags(np.concatenate([np.full(n, 1e-12), np.full(len(idx), -1e-12)]))).tocsc())
+        except RuntimeError:
+            return x, y, info
+        sol = lu.solve(rhs)
+        for _ in range(8):
+            d = lu.solve(rhs - K @ sol); sol = sol + d
+            if np.max(np.abs(d)) <= 1e-15 * max(1.0, np.max(np.abs(sol))): break
+        x = sol[:n]; y = np.zeros(m); y[idx] = sol[n:]
+        Ax = A @ x
+        scale = 1.0 + max(np.max(np.abs(Ax)), np.max(np.abs(qp["Pd"] * x)), np.max(np.abs(A.T @ y)), np.max(np.abs(qp["q"])))
+        res = float(np.max(np.abs(rhs - K @ sol)))
+        t = np.where(lo, Ax - l, np.where(up, u - Ax, 0.0)); lam = np.where(lo, -y, np.where(up, y, 0.0))
+        drop = ineq & act & (lam < 0.0); add = ineq & ~act & (t < -1e-9 * scale)
+        info["res_dua"] = res
+        if not np.isfinite(res) or res > 1e-9 * scale: return x, y, info
+        if not drop.any() and not add.any():
+            info.update(status=1, polished=1 + rnd); return x, y, info
+        act = (act & ~drop) | add
+    return x, y, info
+
+
 def active_set(qp, x, y, tol=1e-7):
     """Index list of active inequality rows from an (x, y) pair of the canonical QP: +(i+1) upper-active, -(i+1) lower-active.
     Equality rows (l == u) are excluded.  A row is active when its multiplier exceeds `tol` in magnitude."""
@@ -356,6 +409,32 @@ class OracleDecoupled:
         x = np.zeros(self.n); y = np.zeros(self.m); info = np.zeros(6)
         self.L.pd_solve_exact(self.h, _d(_arr(sd, self.sd_len)), _d(x), _d(y), _d(info))
         return x, y, dict(iters=int(info[0]), status=int(info[1]), res_pri=info[2], res_dua=info[3], gap=info[4], polished=int(info[5]))
+
+    def solve_exact_verified(self, sd, qp=None, walls=None, wall_weight=1000.0):
+        """Exact optimum as a VERIFIED KKT point of the canonical QP: (x, y, info) with info["polished"] >= 1, or info["status"] != 1 when nothing verifies.
+        `qp`: the canonical dict to solve (default assemble_qp(sd); pass the wall-extended dict together with walls = edges[N, 2] of nodes 2..N+1).  First the sparse
+        interior point + polish of oracle/qp.hpp; where that does not end in a verified point (long horizons whose optimum diverges), the stage-structured interior
+        point of oracle/lat_ipm_numpy.py supplies the candidate and the same canonical polish verifies it."""
+        from . import lat_ipm_numpy as lp
+        if qp is None:
+            x, y, info = self.solve_exact(sd)
+            qp = None if (info["status"] == 1 and info["polished"] >= 1) else self.assemble_qp(sd)
+        else:
+            x, y, info = solve_exact_generic(qp)
+            if info["status"] == 1 and info["polished"] >= 1: qp = None
+        if qp is None:
+            info["method"] = "sparse"; return x, y, info
+        D = lp.stage_data(self.unpack_sd(sd), self.cp, walls=walls, wall_weight=wall_weight)
+        r = lp.solve(D)
+        x0, actv = lp.canonical_candidate(D, r, self.Ns, walls=walls is not None)
+        x2, y2, info2 = polish_generic(qp, x0, actv)
+        info2["method"] = "stage"; info2["iters"] = r["iters"]
+        if info2["status"] == 1: return x2, y2, info2
+        x2, y2, info2 = polish_lu(qp, x0, actv)
+        info2["method"] = "stage+lu"; info2["iters"] = r["iters"]
+        if info2["status"] == 1: return x2, y2, info2
+        info["method"] = "none"; info["status"] = info["status"] if info["status"] != 1 else -2
+        return x, y, info
 
     def step_batch(self, states6, controls3, t0, time_offsets=None, nthreads=1):
         """Whole lateral step per instance with the OSQP port (cold): (u [B,3], iters, status, wall seconds)."""

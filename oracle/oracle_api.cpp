@@ -313,6 +313,18 @@ int po_solve_exact_generic(int n, int m, const double* Pd, const double* q, cons
     info5[0] = R.iters; info5[1] = R.status; info5[2] = R.res_pri; info5[3] = R.res_dua; info5[4] = R.gap; info5[5] = R.polished;
     return st;
 }
+// Verification of a candidate answer of a canonical QP (any source): see polish_from in qp.hpp.  info5 as po_solve_exact_generic; status 1 only for a verified KKT point.
+int po_polish_generic(int n, int m, const double* Pd, const double* q, const int* Ap, const int* Ai, const double* Ax, const double* l, const double* u,
+                      const double* x0, const int* actv0, double* x, double* y, double* info5) {
+    QP qp; qp.n = n; qp.m = m; qp.Pd.assign(Pd, Pd + n); qp.q.assign(q, q + n); qp.Ap.assign(Ap, Ap + n + 1); qp.Ai.assign(Ai, Ai + Ap[n]); qp.Ax.assign(Ax, Ax + Ap[n]);
+    qp.l.assign(l, l + m); qp.u.assign(u, u + m);
+    KKTPattern K; K.build(n, m, qp.Ap, qp.Ai);
+    LDLNumeric ldl; ldl.init(&K.sym);
+    ExactResult R; int st = polish_from(qp, ldl, x0, actv0, R);
+    if ((int)R.x.size() == n) { std::memcpy(x, R.x.data(), n * 8); std::memcpy(y, R.y.data(), m * 8); }
+    info5[0] = R.iters; info5[1] = st; info5[2] = R.res_pri; info5[3] = R.res_dua; info5[4] = R.gap; info5[5] = R.polished;
+    return st;
+}
 void pd_update_qp(void* hv, const double* qs, const double* us, const double* ps, const double* dt, double* sd_flat) {
     DecoupledMPC m = ((HandleDec*)hv)->mpc; int Nn = m.N() + 1;
     m.TS.dt.assign(dt, dt + Nn - 1);

@@ -484,7 +484,12 @@ inline void polish_exact(const QP& qp, LDLNumeric& ldl, const std::vector<int>& 
     std::vector<double> xp(R.x), yp(m, 0.0), vals(n + m + qp.Ax.size()), res(n + m), Axv(m), Aty(n);
     for (size_t p = 0; p < qp.Ax.size(); p++) vals[n + m + p] = qp.Ax[p];
     for (int i = 0; i < m; i++) yp[i] = actv[i] ? R.y[i] : 0.0;
-    const double nq = vnorm_inf(qp.q.data(), n), nb = vnorm_inf(bnd.data(), m);
+    double nq = vnorm_inf(qp.q.data(), n), nb = vnorm_inf(bnd.data(), m);
+    {   // scale of the terms the residuals balance at the point handed over (see solve_exact)
+        A_mul(qp, qp.Ax.data(), xp.data(), Axv.data()); At_mul(qp, qp.Ax.data(), yp.data(), Aty.data());
+        nb = std::max(nb, vnorm_inf(Axv.data(), m));
+        for (int j = 0; j < n; j++) nq = std::max({nq, std::fabs(qp.Pd[j] * xp[j]), std::fabs(Aty[j])});
+    }
     const double ptol = 1e-9 * (1 + nb), reg = 1e-9;
     for (int round = 0; round < 8; round++) {
         for (int j = 0; j < n; j++) vals[j] = qp.Pd[j] + reg;
@@ -567,7 +572,7 @@ inline int solve_exact(const QP& qp, const KKTPattern& K, LDLNumeric& ldl, Exact
         for (int i = 0; i < m; i++) if (cls[i] == 1 || cls[i] == 2) { t[i] += st_; lam[i] += sl_; }
     }
     int nineq = 0; for (int i = 0; i < m; i++) if (cls[i] == 1 || cls[i] == 2) nineq++;
-    double nq = vnorm_inf(qp.q.data(), n), nb = vnorm_inf(bnd.data(), m);
+    double nq = vnorm_inf(qp.q.data(), n), nb = vnorm_inf(bnd.data(), m), sx_ = nb, sd_ = nq;
     int it; int status = -2;
     for (it = 0; it < max_iter; it++) {
         for (int i = 0; i < m; i++) y[i] = cls[i] == 1 ? -lam[i] : (cls[i] == 2 ? lam[i] : (cls[i] == 0 ? y[i] : 0.0));
@@ -584,7 +589,11 @@ inline int solve_exact(const QP& qp, const KKTPattern& K, LDLNumeric& ldl, Exact
         }
         mu /= std::max(nineq, 1);
         R.res_pri = rpn; R.res_dua = rdn; R.gap = mu;
-        if (rpn <= tol * (1 + nb) && rdn <= tol * (1 + nq) && mu <= tol_gap) { status = 1; break; }
+        // residuals relative to the size of the quantities they balance (OSQP's relative criterion): on the long lateral horizons the optimum can carry states of 1e4
+        // (a linearised model that diverges under saturated steering), and an absolute 1e-10 is then below the rounding of A x itself
+        sx_ = std::max({nb, vnorm_inf(Axv.data(), m)}); sd_ = nq;
+        for (int j = 0; j < n; j++) sd_ = std::max({sd_, std::fabs(qp.Pd[j] * x[j]), std::fabs(Aty[j])});
+        if (rpn <= tol * (1 + sx_) && rdn <= tol * (1 + sd_) && mu <= tol_gap) { status = 1; break; }
         for (int i = 0; i < m; i++) Dg[i] = (cls[i] == 0) ? eps_eq : (cls[i] == 3 ? 1e12 : t[i] / lam[i]);
         if (!factor()) { status = -10; break; }
         auto direction = [&](const std::vector<double>& rcv, std::vector<double>& odx, std::vector<double>& ody, std::vector<double>& odt, std::vector<double>& odl) {
@@ -620,7 +629,7 @@ inline int solve_exact(const QP& qp, const KKTPattern& K, LDLNumeric& ldl, Exact
         double sig = std::pow(std::min(mu_aff / mu, 1.0), 3.0);
         // keep complementarity from collapsing ahead of feasibility (the classic failure of infeasible-start methods): while the residuals are
         // still far above their tolerance relative to the gap, do not aim below a fifth of the current mu
-        if (rpn > tol * (1 + nb) || rdn > tol * (1 + nq)) sig = std::max(sig, 0.2);
+        if (rpn > tol * (1 + sx_) || rdn > tol * (1 + sd_)) sig = std::max(sig, 0.2);
         for (int i = 0; i < m; i++) rc[i] = sig * mu - t[i] * lam[i] - dt_aff[i] * dl_aff[i];
         direction(rc, dx, dy, dtv, dl);
         double a = std::min(1.0, 0.995 * steplen(dtv, dl));
@@ -628,7 +637,7 @@ inline int solve_exact(const QP& qp, const KKTPattern& K, LDLNumeric& ldl, Exact
         for (int i = 0; i < m; i++) { if (cls[i] == 0) y[i] += a * dy[i]; else if (cls[i] != 3) { t[i] += a * dtv[i]; lam[i] += a * dl[i]; } }
     }
     // rounding floor on ill-conditioned instances (long horizons with saturated steering): the gap stalls above tol_gap; residuals still hold
-    if (status == -2 && R.gap <= 1e-10 && R.res_pri <= tol * (1 + nb) && R.res_dua <= 1e3 * tol * (1 + nq)) status = 1;
+    if (status == -2 && R.gap <= 1e-10 && R.res_pri <= tol * (1 + sx_) && R.res_dua <= 1e3 * tol * (1 + sd_)) status = 1;
     for (int i = 0; i < m; i++) y[i] = cls[i] == 1 ? -lam[i] : (cls[i] == 2 ? lam[i] : (cls[i] == 0 ? y[i] : 0.0));
     R.x = x; R.y = y; R.iters = it; R.status = status; R.polished = 0;
     if (status == 1) {
@@ -637,6 +646,22 @@ inline int solve_exact(const QP& qp, const KKTPattern& K, LDLNumeric& ldl, Exact
         polish_exact(qp, ldl, cls, bnd, actv, R);
     }
     return status;
+}
+
+// Verification of a candidate answer from ANY source: polish from the primal point x0 and the working set actv0 (multipliers start at zero; the first KKT solve
+// finds them), accepted -- R.polished >= 1 -- only as a KKT point of the full QP (primal and dual feasible to 1e-9 of the problem's scale).
+inline int polish_from(const QP& qp, LDLNumeric& ldl, const double* x0, const int* actv0, ExactResult& R) {
+    const int n = qp.n, m = qp.m;
+    std::vector<int> cls(m); std::vector<double> bnd(m, 0.0); std::vector<char> actv(m, 0);
+    for (int i = 0; i < m; i++) {
+        bool hl = qp.l[i] > -QP_INF, hu = qp.u[i] < QP_INF;
+        if (hl && hu) { if (qp.u[i] - qp.l[i] > 1e-12) return R.status = -20; cls[i] = 0; bnd[i] = qp.l[i]; }
+        else if (hl) { cls[i] = 1; bnd[i] = qp.l[i]; } else if (hu) { cls[i] = 2; bnd[i] = qp.u[i]; } else cls[i] = 3;
+        actv[i] = cls[i] == 0 || ((cls[i] == 1 || cls[i] == 2) && actv0[i] != 0);
+    }
+    R.x.assign(x0, x0 + n); R.y.assign(m, 0.0); R.polished = 0; R.iters = 0; R.status = 1;
+    polish_exact(qp, ldl, cls, bnd, actv, R);
+    return R.polished >= 1 ? 1 : -2;
 }
 
 }  // namespace po
@@ -653,13 +678,15 @@ inline int solve_exact_robust(const QP& qp, const KKTPattern& K, LDLNumeric& ldl
     if (sa == 1) {
         R.x = admm.x; R.y = admm.y; R.iters = -admm.last_iters; R.status = 1; R.res_pri = admm.last_pri; R.res_dua = admm.last_dua; R.gap = 0.0; R.polished = 0;
         const int m = qp.m;
-        std::vector<int> cls(m); std::vector<double> bnd(m, 0.0); std::vector<char> actv(m, 0);
+        std::vector<int> cls(m); std::vector<double> bnd(m, 0.0); std::vector<char> actv(m, 0); bool two_sided = false;
         for (int i = 0; i < m; i++) {
             bool hl = qp.l[i] > -QP_INF, hu = qp.u[i] < QP_INF;
             cls[i] = (hl && hu) ? 0 : (hl ? 1 : (hu ? 2 : 3)); bnd[i] = hu && !hl ? qp.u[i] : (hl ? qp.l[i] : 0.0);
             actv[i] = cls[i] == 0 || (cls[i] != 3 && std::fabs(R.y[i]) > 1e-7);
+            // a genuinely two-sided row (l < u) is reached here only for QPs solve_exact refuses (-20): polish_exact would pin it at l and skip every check on it
+            if (hl && hu && qp.u[i] - qp.l[i] > 1e-12) two_sided = true;
         }
-        polish_exact(qp, ldl, cls, bnd, actv, R);
+        if (!two_sided) polish_exact(qp, ldl, cls, bnd, actv, R);
         return 1;
     }
     return st;

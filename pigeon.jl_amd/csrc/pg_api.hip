@@ -145,10 +145,10 @@ int pg_default_config_decoupled(pg_config* c) {
     U.Q_ds = 0.0; U.Q_dpsi = 1.0 / (d10 * d10); U.Q_e = 1.0; U.W_beta = 50 / d10; U.W_r = 50.0; U.W_HJI = 0.0; U.N_HJI = 0;
     U.R_delta = 0.0; U.R_ddelta = 0.01 / (d10 * d10); U.R_Fx = 0.0; U.R_dFx = 1.0;      // R_dFx only pins the inert Fx slot of the embedding
     c->formulation = PG_DECOUPLED;
-    // polish off by default here: the lateral QP's far horizon is weakly determined (degenerate rows), ~9 % of the N = 50 instances do not verify an active set,
-    // and what the polish improves there (the far-horizon steering, p99 error 4e-4 -> 6e-8) feeds nothing: this formulation has no warm start and only delta_2
-    // is applied, which the interior point already has to 1e-13 (median).  Measured: +8 % solve time (tools/gpu_dec_polish.py).  Set polish = 1 to have it.
-    c->polish = 0;
+    // polish ON (round 3; it used to be off here): with the interior point alone 5 (48 with the wall rows) of the 4096 N = 50 benchmark instances end 1e-6 .. 1e-4 from the
+    // exact optimum of their own QP data -- rows that are nearly degenerate, on horizons whose optimum leaves the linearisation by kilometres --; behind the polish of
+    // k_solve_lat every one of them is within 1.3e-7 (tests/test_gpu_decoupled.py::test_config5_as_shipped_every_instance_against_the_oracle)
+    c->polish = 1;
 #ifdef PG_F32
     c->ipm_tol = 1e-4;                               // the ill-conditioned 8 s lateral horizon stalls near 1e-4 in fp32 (tests/test_gpu_f32.py)
 #endif
@@ -216,8 +216,15 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
 #endif
     if (cfg->walls) { ALLOC(h->d_walls, cap * N * 2, real); C.walls = 1; C.wall_weight = (real)cfg->wall_weight; C.wall_edges = h->d_walls; if (h->solve_quad) { g_create_error = "PG_SOLVER=quad does not carry the wall rows"; free_all(h); delete h; return PG_ERR_INVALID; } }
     ALLOC(h->d_pol_u2, cap * 2, real); ALLOC(h->d_pol_u, cap * 3, real); ALLOC(h->d_pol_src, cap, int);
-    // the lateral formulation has a solve kernel of its own (k_solve_lat: interior point, no polish); polish = 1 and PG_SOLVE_LAT=0 keep the embedding in k_solve
-    { const char* e = getenv("PG_SOLVE_LAT"); h->solve_lat = cfg->formulation == PG_DECOUPLED && !cfg->polish && !(e && e[0] == '0') && !h->solve_quad; }
+    // The lateral formulation has a solve kernel of its own (k_solve_lat, pg_solve_lat.hip) for horizons beyond 20 intervals.  Shorter ones -- the reference's on-vehicle
+    // N_short = 5, N_long = 10 among them -- stay with the embedding in k_solve when the polish is on: its active-set rounds from the empty set serve a short lateral QP
+    // without any interior-point iteration (N = 15, 4096 instances: 0.12 ms against 0.37), an advantage that is gone at N = 30 (2.4 against 1.5 ms) and reversed at
+    // N = 50 (12.6 against 5.9).  PG_SOLVE_LAT=0 / 1 forces the choice.
+    {
+        const char* e = getenv("PG_SOLVE_LAT");
+        const bool want = (e && e[0] == '1') || (!(e && e[0] == '0') && !(cfg->polish && N <= 20));
+        h->solve_lat = cfg->formulation == PG_DECOUPLED && want && !h->solve_quad;
+    }
     if (h->solve_lat) { ALLOC(h->d_lat, cap * N * LATP, real); C.lat_pack = h->d_lat; }
 #undef ALLOC
     h->stage_bytes = h->in_bytes > h->out_bytes ? h->in_bytes : h->out_bytes;          // inputs: state 6 + control 3 + other 4 (real) + t0 + time_offset (double); outputs reuse the front of it

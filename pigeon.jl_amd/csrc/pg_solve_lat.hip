@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     constexpr int NR = WALLS ? 13 : 10;
     // diagnostic cycle counters (pg_debug_solve_cycles): 0 barrier terms, 1 matrix pass, 2 vector pass, 3 roll-outs, 4 Newton point / step rules, 5 everything else
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = prof ? clock64() : 0;
-    auto stamp = [&](int slot) { if (prof) { const unsigned long long now = clock64(); pc[slot] += now - tprev; tprev = now; } };
+    auto stamp = [&](int slot) __attribute__((always_inline)) { if (prof) { const unsigned long long now = clock64(); pc[slot] += now - tprev; tprev = now; } };
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
     const int N = C.N, NN = C.NN;
     const int b_raw = 4 * (int)blockIdx.x + g;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // ---------------- Riccati matrix pass (+ the predictor's vector recursion in column 6) ----------------
     // Software-pipelined by hand: the operands of stage k - 1 (global: the matrix column and dt; LDS: the stage-cost column, Rhat / rhat) are requested at the top of
     // stage k and first touched at the top of stage k - 1, a whole stage of arithmetic (~900 cycles) later.
-    auto matrix_pass = [&]() {
+    auto matrix_pass = [&]() __attribute__((always_inline)) {
         real P[5], X[4], Xn[4], Qc[5], Qn[5], dtk, dtn, radd, raddn;
         {   // P_N = Qhat_{N-1} (cost on node N), p_N = qhat_{N-1}
             const real dtl = Lb[(size_t)(N - 1) * LATP + 48];
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             for (int i = 0; i < 5; i++) P[i] = (sZero + qoff[i])[qmul[i] * (N - 1)];
             P[2] += cpsi * dtl;
         }
-        auto request = [&](int k, real* Xo, real* Qo, real& dto, real& ro) {      // operands of stage k (k < 0: stage 0 again, unused)
+        auto request = [&](int k, real* Xo, real* Qo, real& dto, real& ro) __attribute__((always_inline)) {      // operands of stage k (k < 0: stage 0 again, unused)
             const int kk = k < 0 ? 0 : k, km = kk > 0 ? kk - 1 : 0;
             const real* cp = colp + (size_t)kk * LATP;
 #pragma unroll
@@ -190,17 +190,17 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
 
     // ---------------- Riccati vector pass (corrector): p_k = qhat + Abar' y + K f,  y = P cbar + p,  f = rhat + Bbar' y,  kff = -Sinv f ----------------
     // A stage is ~25 instructions here: the matrix columns are requested THREE stages ahead (L2 latency ~ several stages of this pass), the LDS operands one.
-    auto vector_pass = [&]() {
+    auto vector_pass = [&]() __attribute__((always_inline)) {
         constexpr int D = 3;
         real buf[D][4];
         const int mcoff = c < 5 ? (int)(sTab - sZero) + 7 + c : 0, mcmul = c < 5 ? LAT_TAB : 0;       // P cbar [c]
         const int koff = c < 5 ? (int)(sTab - sZero) + c : 0;                                        // K[c]
         const int qvoff = c < 5 ? (int)(sRec - sZero) + 6 + c : 0, qvmul = c < 5 ? LAT_REC : 0;      // qhat[c]
         real p = (sZero + qvoff)[qvmul * (N - 1)];
-        auto request = [&](int k, real* Xo) { const real* cp = colp + (size_t)(k < 0 ? 0 : k) * LATP;
+        auto request = [&](int k, real* Xo) __attribute__((always_inline)) { const real* cp = colp + (size_t)(k < 0 ? 0 : k) * LATP;
 #pragma unroll
             for (int i = 0; i < 4; i++) Xo[i] = cp[8 * i]; };
-        auto request_lds = [&](int k, real* o5) { const int kk = k < 0 ? 0 : k, km = kk > 0 ? kk - 1 : 0;
+        auto request_lds = [&](int k, real* o5) __attribute__((always_inline)) { const int kk = k < 0 ? 0 : k, km = kk > 0 ? kk - 1 : 0;
             o5[0] = (sZero + mcoff)[mcmul * kk]; o5[1] = (sZero + koff)[mcmul * kk]; o5[2] = (sZero + qvoff)[qvmul * km]; o5[3] = sRec[LAT_REC * kk + 11]; o5[4] = sTab[LAT_TAB * kk + 6]; };
 #pragma unroll
         for (int u = 0; u < D; u++) request(N - 1 - u, buf[u]);
@@ -233,17 +233,17 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     const int ri = c < 4 ? c : 0;
     const real wA = c < 4 ? real(1.0) : real(0.0), wD = c == 4 ? real(1.0) : real(0.0);
     const real x0c = c < 4 ? Q[o.qcurr + 2 + c] : (c == 4 ? Q[o.ucurr] : real(0.0));
-    auto forward_pass = [&](bool use_gain) {
+    auto forward_pass = [&](bool use_gain) __attribute__((always_inline)) {
         constexpr int D = 3;
         const bool isK = c == 5 && use_gain;          // (a select, not a multiplication by 0: the gain table holds nothing before the first matrix pass)
         real xr = x0c;
         const real2* const rowp = reinterpret_cast<const real2*>(Lb + 8 * ri);
         const real2* const tabp = reinterpret_cast<const real2*>(sTab);
         real2 buf[D][4], kt[3], ktn[3];
-        auto request = [&](int k, real2* o4) { const real2* rp = rowp + (size_t)(k < N ? k : N - 1) * (LATP / 2);
+        auto request = [&](int k, real2* o4) __attribute__((always_inline)) { const real2* rp = rowp + (size_t)(k < N ? k : N - 1) * (LATP / 2);
 #pragma unroll
             for (int q = 0; q < 4; q++) o4[q] = rp[q]; };
-        auto request_lds = [&](int k, real2* o3) { const real2* tp = tabp + (LAT_TAB / 2) * (k < N ? k : N - 1);
+        auto request_lds = [&](int k, real2* o3) __attribute__((always_inline)) { const real2* tp = tabp + (LAT_TAB / 2) * (k < N ? k : N - 1);
 #pragma unroll
             for (int q = 0; q < 3; q++) o3[q] = tp[q]; };
 #pragma unroll
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
 #pragma unroll
     for (int j = 0; j < NSLOT; j++) act[j] = c + 16 * j < N;
     struct StageC { real b[NR], h0[4], h1[4], dts; };
-    auto load_consts = [&](int j, StageC& S) {
+    auto load_consts = [&](int j, StageC& S) __attribute__((always_inline)) {
         int s = act[j] ? c + 16 * j : N - 1;
         asm volatile("" : "+v"(s));        // opaque per call: these loads are invariant across the interior-point loop, and hoisted out of it they would sit in ~45 registers per slot
         const real2* cp = reinterpret_cast<const real2*>(Lb + (size_t)s * LATP + 32);
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         if constexpr (WALLS) { const real* w = C.wall_edges + ((size_t)b * N + s) * 2; S.b[10] = w[0]; S.b[11] = -w[1]; S.b[12] = real(0.0); }
         S.dts = Lb[(size_t)s * LATP + 48];
     };
-    auto slacks = [&](const StageC& S, const real* x, real v, real s1, real s2, real sw, real* out) {
+    auto slacks = [&](const StageC& S, const real* x, real v, real s1, real s2, real sw, real* out) __attribute__((always_inline)) {
         out[0] = S.b[0] - x[4]; out[1] = x[4] + S.b[1];
 #pragma unroll
         for (int i = 0; i < 4; i++) out[2 + i] = S.b[2 + i] - (S.h0[i] * x[0] + S.h1[i] * x[1]) + (i < 2 ? s1 : s2);
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     };
     // elimination of the stage-local slacks (each is a leaf of the KKT graph): sigma_g = -(c_g' x + g_g) d_g
     struct Elim { real c10, c11, g1, d1, c20, c21, g2, d2, ch, gh, dh; };
-    auto eliminate = [&](const StageC& S, const real* W, const real* ell, Elim& E) {
+    auto eliminate = [&](const StageC& S, const real* W, const real* ell, Elim& E) __attribute__((always_inline)) {
         E.d1 = lat_rcp(W[2] + W[3] + W[6]); E.d2 = lat_rcp(W[4] + W[5] + W[7]);
         E.c10 = -(W[2] * S.h0[0] + W[3] * S.h0[1]); E.c11 = -(W[2] * S.h1[0] + W[3] * S.h1[1]);
         E.c20 = -(W[4] * S.h0[2] + W[5] * S.h0[3]); E.c21 = -(W[4] * S.h1[2] + W[5] * S.h1[3]);
@@ -309,17 +309,61 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         if constexpr (WALLS) { E.dh = lat_rcp(W[10] + W[11] + W[12]); E.ch = -(W[10] - W[11]); E.gh = C.wall_weight * S.dts - ell[10] - ell[11] - ell[12]; }
         else { E.dh = real(0.0); E.ch = real(0.0); E.gh = real(0.0); }
     };
+    // Active-set polish (the OSQP-style polish of k_solve, without its cold-start rules: here it only ever follows a converged interior point).  pmode = 0 while the
+    // interior point of this instance runs, then the round of the polish; amask = the rows of a slot held as EQUALITIES through an augmented Lagrangian
+    // (-y t + rho/2 t^2: the shape of a barrier term with W = rho and constant multiplier part y - rho b), every other row absent; y lives in L.
+    int pmode = 0, pstat = 0, pchecks = 0; bool want_polish = false, skip_second = false, resume_ipm = false;
+    // working sets tried per polish: three at the hand-over tolerance (of the 3851 N = 50 + walls instances that verify, 2717 / 876 / 242 / 16 do so in round 1 / 2 / 3 / 4),
+    // two in the second attempt behind the resumed interior point (the slowest wavefront sets the kernel's time, and these are its instances)
+    const int LAT_POLISH_ROUNDS = 3;
+    unsigned amask[NSLOT], mask_ipm[NSLOT];
+#pragma unroll
+    for (int j = 0; j < NSLOT; j++) { amask[j] = 0u; mask_ipm[j] = 0u; }
+    const real rho = C.polish_rho, ptol = C.polish_tol;
     // barrier weights of slot j at the current iterate: it = 1/t, W = lambda/t, ell = (sigma mu - corr)/t + lambda - W b
-    auto weights = [&](int j, const StageC& S, real sgmu, bool with_corr, real* it_, real* W, real* ell) {
+    auto weights = [&](int j, const StageC& S, real sgmu, bool with_corr, real* it_, real* W, real* ell) __attribute__((always_inline)) {
+        if (pmode) {
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const bool a = (amask[j] >> r) & 1u;
+                it_[r] = real(1.0); W[r] = a ? rho : real(0.0); ell[r] = a ? L[j][r] - rho * S.b[r] : real(0.0);
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             it_[r] = lat_rcp(T[j][r]); W[r] = L[j][r] * it_[r];
             ell[r] = (with_corr ? (sgmu - CR[j][r]) * it_[r] : real(0.0)) + L[j][r] - W[r] * S.b[r];
         }
     };
-    auto assemble = [&](int j, real sgmu, bool matrices) {
+    // every stage-locally eliminated slack needs a pivot: a group without an active row gets its sigma >= 0 row, whose multiplier is then known (the linear cost of the slack)
+    auto polish_pivots = [&](int j, const StageC& S) __attribute__((always_inline)) {
+        if (!pmode) return;
+        if (!(amask[j] & 0x04Cu)) { amask[j] |= 1u << 6; L[j][6] = C.cp.W_beta * S.dts; }
+        if (!(amask[j] & 0x0B0u)) { amask[j] |= 1u << 7; L[j][7] = C.cp.W_r * S.dts; }
+        if constexpr (WALLS) { if (!(amask[j] & 0x1C00u)) { amask[j] |= 1u << 12; L[j][12] = C.wall_weight * S.dts; } }
+    };
+    // after a polish solve (tp = slacks at the new point): multiplier update of the held rows and the add / drop decisions of this slot.  Returns the next working set.
+    auto polish_rows = [&](int j, const real* tp, real ttol, bool& unsettled) __attribute__((always_inline)) -> unsigned {
+        unsigned add = 0u, drop = 0u;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const bool a = (amask[j] >> r) & 1u;
+            if (a) L[j][r] -= rho * tp[r];
+            if (act[j] && a && L[j][r] < real(0.0)) drop |= 1u << r;
+            if (act[j] && a && !(fabs(tp[r]) <= ttol)) unsettled = true;             // written so that a NaN never verifies
+            if (act[j] && !a && !(tp[r] >= -ptol)) add |= 1u << r;
+        }
+        // at most one NEW row per slack group and round, the more violated one (two rows that share a free slack pin a combination of the states hard)
+        if ((add & 0x00Cu) == 0x00Cu) add &= ~(tp[2] <= tp[3] ? (1u << 3) : (1u << 2));
+        if ((add & 0x030u) == 0x030u) add &= ~(tp[4] <= tp[5] ? (1u << 5) : (1u << 4));
+        if constexpr (WALLS) { if ((add & 0xC00u) == 0xC00u) add &= ~(tp[10] <= tp[11] ? (1u << 11) : (1u << 10)); }
+        return (amask[j] & ~drop) | add;
+    };
+    auto assemble = [&](int j, real sgmu, bool matrices) __attribute__((always_inline)) {
         StageC S; load_consts(j, S);
         real it_[NR], W[NR], ell[NR]; Elim E;
+        if (matrices) polish_pivots(j, S);
         weights(j, S, sgmu, !matrices, it_, W, ell);
         eliminate(S, W, ell, E);
         real g0 = real(0.0), g1 = real(0.0);
@@ -348,7 +392,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         }
     };
     // Newton point of slot j from the roll-out (x+ of node s+1, v+ of transition s) -> eliminated slacks and the slack of every row
-    auto newton = [&](int j, const StageC& S, const Elim& E, real* xn, real& vn, real* sg3, real* tp) {
+    auto newton = [&](int j, const StageC& S, const Elim& E, real* xn, real& vn, real* sg3, real* tp) __attribute__((always_inline)) {
         const real* rec = sRec + LAT_REC * (act[j] ? c + 16 * j : N - 1);
 #pragma unroll
         for (int m = 0; m < 5; m++) xn[m] = rec[m];
@@ -397,10 +441,55 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     }
     rp0 = row_max(rp0);
     const real ntot = (real)(N * NR), intot = real(1.0) / ntot, tol = C.ipm_tol;
+    // with the polish on, the interior point only has to get close enough for the active set to show (polish_ipm_tol); if the polish does not verify from there, the
+    // interior point resumes from the centred point (t, mu / t) and runs down to ipm_tol before the polish gets its second and last chance
+    real tol_cur = (C.polish && C.polish_ipm_tol > tol) ? C.polish_ipm_tol : tol;
     real mu = real(0.0), phi = real(1.0);
     int status = PG_MAX_ITER, it = 0, good = 0;
     bool done = false;
     const int cap = C.ipm_max_iter;
+
+    // the verdict of a polish solve for this instance, from the per-slot results of polish_rows: verified (the point is primal and dual feasible: a KKT point of the
+    // full QP, stored as the answer), refine (same set, held rows not yet at t = 0: the next solve starts from the updated multipliers), or a new working set.
+    // Returns true when the working set changed (the corrector half of this iteration then carries nothing for this instance: its vector pass has the old gains).
+    auto polish_decide = [&](const unsigned* nm, bool unsettled_, const real (*sn)[3]) __attribute__((always_inline)) -> bool {
+        real chg = real(0.0);
+#pragma unroll
+        for (int j = 0; j < NSLOT; j++) chg = fmax(chg, (act[j] && nm[j] != amask[j]) ? real(1.0) : real(0.0));
+        const bool changed = row_max(chg) > real(0.0), conv = !(row_max(unsettled_ ? real(1.0) : real(0.0)) > real(0.0));
+        pchecks++;
+        if (!changed && conv) {
+#pragma unroll
+            for (int j = 0; j < NSLOT; j++) if (act[j] && valid) {
+                const real* rec = sRec + LAT_REC * (c + 16 * j);
+#pragma unroll
+                for (int m = 0; m < 5; m++) SXs[j][2 + m] = rec[m];
+                SGs[j][0] = sn[j][0]; SGs[j][1] = sn[j][1]; SGs[j][2] = sn[j][2];
+            }
+            pstat = pmode; done = true;
+            return false;
+        }
+        if (changed) {
+#pragma unroll
+            for (int j = 0; j < NSLOT; j++) {
+                amask[j] = nm[j];
+#pragma unroll
+                for (int r = 0; r < NR; r++) L[j][r] = ((amask[j] >> r) & 1u) ? L[j][r] : real(0.0);
+            }
+            pmode++;
+        }
+        const int round_cap = tol_cur > tol ? LAT_POLISH_ROUNDS : LAT_POLISH_ROUNDS - 1;
+        if (pmode > round_cap || pchecks > 2 * round_cap + 1) {
+            pstat = -1;
+            // resume the interior point (takes effect at the top of the next iteration: the rest of this one still belongs to the polish), or -- second failure --
+            // nothing verified: the interior-point iterate stands.  (Both flags are assigned on both paths: "if (again) resume = true; else done = true" is folded by the
+            // optimiser into ONE store through a selected pointer into the lambda's capture block, which then -- with every captured variable -- lives in scratch memory:
+            // the kernel ran twice as long.)
+            const bool again = tol_cur > tol;
+            resume_ipm = again; done = done || !again;
+        }
+        return changed;
+    };
 
     while (true) {
         {   // complementarity gap and the stopping rules (per instance = per row of lanes)
@@ -410,11 +499,30 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
 #pragma unroll
                 for (int r = 0; r < NR; r++) ms += act[j] ? T[j][r] * L[j][r] : real(0.0);
             const real mu_new = row_sum(ms) * intot;
-            if (!done) {
+            if (resume_ipm) {       // the polish at the hand-over tolerance did not verify: the interior point resumes from the centred point (t, mu / t) -- t is untouched
+                                    // by the polish -- and goes all the way down before the polish gets its second and last chance
+                resume_ipm = false; tol_cur = tol; pmode = 0; status = PG_MAX_ITER;
+#pragma unroll
+                for (int j = 0; j < NSLOT; j++)
+#pragma unroll
+                    for (int r = 0; r < NR; r++) L[j][r] = act[j] ? mu * lat_rcp(T[j][r]) : real(1.0);
+            } else if (!done && !pmode && !want_polish) {
                 mu = mu_new;
                 if (it >= cap && !(cap >= 20 && good >= 3 && it < cap + 20)) done = true;                    // iteration cap (a converging attempt gets twenty more)
                 else if (!(mu == mu) || fabs(mu) > PG_BIG) { status = PG_NUMERICAL; done = true; }
-                else if (mu <= tol && phi * fmax(rp0, real(1.0)) <= tol) { status = PG_SOLVED; done = true; }
+                else if (mu <= tol_cur && phi * fmax(rp0, real(1.0)) <= tol_cur) { status = PG_SOLVED; if (C.polish) want_polish = true; else done = true; }
+            }
+            if (want_polish) {      // the interior point has converged: the rows with lambda > t are handed to the polish as its first working set, with their multipliers
+                want_polish = false; pmode = 1; pchecks = 0; status = PG_SOLVED;
+#pragma unroll
+                for (int j = 0; j < NSLOT; j++) {
+                    unsigned mk = 0u;
+#pragma unroll
+                    for (int r = 0; r < NR; r++) if (act[j] && L[j][r] > T[j][r]) mk |= 1u << r;
+                    amask[j] = mk; mask_ipm[j] = mk;
+#pragma unroll
+                    for (int r = 0; r < NR; r++) L[j][r] = ((mk >> r) & 1u) ? L[j][r] : real(0.0);
+                }
             }
         }
         if (__all(done)) break;
@@ -430,7 +538,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         forward_pass(true);
         wave_sync();
         stamp(3);
-        real rmax = real(0.0), S2 = real(0.0);
+        real rmax = real(0.0), S2 = real(0.0), SNp[NSLOT][3]; unsigned nmask[NSLOT]; bool unsettled = false;
 #pragma unroll
         for (int j = 0; j < NSLOT; j++) {
             StageC S; load_consts(j, S);
@@ -438,21 +546,26 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             weights(j, S, real(0.0), false, it_, W, ell);
             eliminate(S, W, ell, E);
             newton(j, S, E, xn, vn, sg3, tp);
+            if (pmode) { SNp[j][0] = sg3[0]; SNp[j][1] = sg3[1]; SNp[j][2] = sg3[2]; nmask[j] = polish_rows(j, tp, real(0.01) * ptol, unsettled); }
+            else {
 #pragma unroll
-            for (int r = 0; r < NR; r++) {
-                const real dt_ = tp[r] - T[j][r], dl_ = -W[r] * tp[r];
-                CR[j][r] = dt_ * dl_;
-                // step to the boundary: -dt/t = 1 - tp/t and, for the affine direction, -dl/lambda = tp/t
-                const real rho = tp[r] * it_[r];
-                rmax = fmax(rmax, act[j] ? fmax(real(1.0) - rho, rho) : real(0.0));
-                S2 += act[j] ? CR[j][r] : real(0.0);
+                for (int r = 0; r < NR; r++) {
+                    const real dt_ = tp[r] - T[j][r], dl_ = -W[r] * tp[r];
+                    CR[j][r] = dt_ * dl_;
+                    // step to the boundary: -dt/t = 1 - tp/t and, for the affine direction, -dl/lambda = tp/t
+                    const real rho_ = tp[r] * it_[r];
+                    rmax = fmax(rmax, act[j] ? fmax(real(1.0) - rho_, rho_) : real(0.0));
+                    S2 += act[j] ? CR[j][r] : real(0.0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        skip_second = false;
+        if (pmode && !done) skip_second = polish_decide(nmask, unsettled, SNp);
         rmax = row_max(rmax); S2 = row_sum(S2);
         const real aaff = rmax > real(1.0) ? frcp(rmax) : real(1.0);
         // rounding floor: once mu is within 1e4 x of the tolerance and the affine direction can no longer move, further iterations only add noise
-        if (!done && mu <= real(1e4) * tol && aaff < real(0.3) && phi * fmax(rp0, real(1.0)) <= tol) { status = PG_SOLVED; done = true; }
+        if (!done && !pmode && mu <= real(1e4) * tol && aaff < real(0.3) && phi * fmax(rp0, real(1.0)) <= tol) { status = PG_SOLVED; if (C.polish) want_polish = true; else done = true; }
         // sum (t + a dt)(lambda + a dl) = (1 - a) sum t lambda + a^2 sum dt dl   (t dl + lambda dt = -t lambda for the affine direction)
         const real mu_aff = (real(1.0) - aaff) * mu + aaff * aaff * S2 * intot;
         real sg = fmin(mu_aff * frcp(mu), real(1.0)); sg = sg * sg * sg;
@@ -470,7 +583,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         wave_sync();
         stamp(3);
         real T1 = real(0.0), T2 = real(0.0), SN[NSLOT][3];
-        rmax = real(0.0);
+        rmax = real(0.0); unsettled = false;
 #pragma unroll
         for (int j = 0; j < NSLOT; j++) {
             StageC S; load_consts(j, S);
@@ -478,26 +591,31 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             weights(j, S, sgmu, true, it_, W, ell);
             eliminate(S, W, ell, E);
             newton(j, S, E, xn, vn, SN[j], tp);
+            if (pmode) { if (!skip_second && !resume_ipm) nmask[j] = polish_rows(j, tp, ptol, unsettled); }
+            else {
 #pragma unroll
-            for (int r = 0; r < NR; r++) {
-                const real dt_ = tp[r] - T[j][r], dl_ = (sgmu - CR[j][r]) * it_[r] - W[r] * tp[r];
-                CR[j][r] = dl_;                            // (the second-order term has done its job: the slot now carries d-lambda to the update below)
-                const real rj = fmax(-dt_ * it_[r], -dl_ * lat_rcp(L[j][r]));
-                rmax = fmax(rmax, act[j] ? rj : real(0.0));
-                T1 += act[j] ? T[j][r] * dl_ + L[j][r] * dt_ : real(0.0);
-                T2 += act[j] ? dt_ * dl_ : real(0.0);
+                for (int r = 0; r < NR; r++) {
+                    const real dt_ = tp[r] - T[j][r], dl_ = (sgmu - CR[j][r]) * it_[r] - W[r] * tp[r];
+                    CR[j][r] = dl_;                            // (the second-order term has done its job: the slot now carries d-lambda to the update below)
+                    const real rj = fmax(-dt_ * it_[r], -dl_ * lat_rcp(L[j][r]));
+                    rmax = fmax(rmax, act[j] ? rj : real(0.0));
+                    T1 += act[j] ? T[j][r] * dl_ + L[j][r] * dt_ : real(0.0);
+                    T2 += act[j] ? dt_ * dl_ : real(0.0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (pmode && !done && !skip_second && !resume_ipm) (void)polish_decide(nmask, unsettled, SN);
         rmax = row_max(rmax); T1 = row_sum(T1); T2 = row_sum(T2);
         const real alpha = rmax > real(0.995) ? real(0.995) * frcp(rmax) : real(1.0);
         // rounding floor, second form: a step that would MULTIPLY mu near the tolerance is a Newton direction computed at a conditioning the arithmetic no longer
         // carries -- the iterate at hand is as good as it gets
-        if (!done && mu <= (sizeof(real) == 8 ? real(1e5) : real(1e2)) * tol && phi * fmax(rp0, real(1.0)) <= tol) {
+        if (!done && !pmode && !want_polish && mu <= (sizeof(real) == 8 ? real(1e5) : real(1e2)) * tol && phi * fmax(rp0, real(1.0)) <= tol) {
             const real mnew = mu + (alpha * T1 + alpha * alpha * T2) * intot;
-            if (!(mnew <= real(4.0) * mu)) { status = PG_SOLVED; done = true; }
+            if (!(mnew <= real(4.0) * mu)) { status = PG_SOLVED; if (C.polish) want_polish = true; else done = true; }
         }
-        const real a = done ? real(0.0) : alpha;
+        const bool ipm_on = !done && !pmode && !want_polish;
+        const real a = ipm_on ? alpha : real(0.0);
 #pragma unroll
         for (int j = 0; j < NSLOT; j++) {
             StageC S; load_consts(j, S);
@@ -508,10 +626,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             slacks(S, xn, rec[5], SN[j][0], SN[j][1], SN[j][2], tp);
 #pragma unroll
             for (int r = 0; r < NR; r++) {
-                T[j][r] += act[j] ? a * (tp[r] - T[j][r]) : real(0.0);
-                L[j][r] += act[j] ? a * CR[j][r] : real(0.0);
+                T[j][r] += (act[j] && ipm_on) ? a * (tp[r] - T[j][r]) : real(0.0);       // (a select, not a * 0: an instance in its polish has no meaningful tp here)
+                L[j][r] += (act[j] && ipm_on) ? a * CR[j][r] : real(0.0);
             }
-            if (act[j] && valid && !done) {
+            if (act[j] && valid && ipm_on) {
 #pragma unroll
                 for (int m = 0; m < 5; m++) { const real cur = SXs[j][2 + m]; SXs[j][2 + m] = cur + a * (xn[m] - cur); }
 #pragma unroll
@@ -519,7 +637,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!done) {
+        if (ipm_on) {
             phi *= (real(1.0) - alpha);
             good = alpha > real(0.5) ? good + 1 : 0;
             if (mu > real(1e8) * C.ipm_mu0) done = true;      // diverging: give up (PG_MAX_ITER)
@@ -542,7 +660,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             constexpr int bit[13] = {3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 0, 1, 2};
             unsigned mask = 0;
 #pragma unroll
-            for (int r = 0; r < NR; r++) if (L[j][r] > T[j][r]) mask |= 1u << bit[r];
+            for (int r = 0; r < NR; r++) {
+                const bool on = pstat > 0 ? ((amask[j] >> r) & 1u) : (pmode ? ((mask_ipm[j] >> r) & 1u) : (L[j][r] > T[j][r]));      // the polish's verified set / the interior point's at hand-over
+                if (on) mask |= 1u << bit[r];
+            }
             O.active[(size_t)b * N + c + 16 * j] = (uint16_t)mask;
         }
         if (c == 0) {
@@ -550,7 +671,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             const real d = SXs[0][6] * C.un0, Fx = nodes[((size_t)b * NN + 1) * 10 + 7];
             real* U = O.u_out + (size_t)b * 3;
             U[0] = d; U[1] = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac; U[2] = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
-            O.status[b] = status; O.iters[b] = it; O.mu[b] = mu; O.polish[b] = 0;
+            O.status[b] = status; O.iters[b] = it; O.mu[b] = mu; O.polish[b] = pstat;
             O.solved[b] = 1;      // model_predictive_control.jl:76: solved = true
         }
     }

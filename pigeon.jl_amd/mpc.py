@@ -45,7 +45,7 @@ class BatchedTrajectoryTrackingMPC:
         (self.lib.pg_default_config if formulation == "coupled" else self.lib.pg_default_config_decoupled)(C.byref(cfg))
         # solver tolerances default to the library's own (they depend on its arithmetic type: pg_default_config*)
         ipm_tol = cfg.ipm_tol if ipm_tol is None else ipm_tol
-        if polish is not None:                    # None: the library's default for the formulation (on for coupled, off for decoupled)
+        if polish is not None:                    # None: the library's default (on for both formulations)
             cfg.polish = int(bool(polish))
         if polish_rho is not None:
             cfg.polish_rho = float(polish_rho)

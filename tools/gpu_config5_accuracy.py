@@ -20,7 +20,8 @@ u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
 t = time.time()
 res = check_lateral_batch_against_oracle(pkg, om, traj, mpc, B, Ns, Nl, walls, want_more=True)
 x, sg = mpc.solution(); st, it, act, mu = mpc.solve_info()
-print(f"oracle sweep {time.time() - t:.1f} s; GPU status {np.bincount(status)}, iterations mean {iters.mean():.2f} max {iters.max()}")
+pol = mpc.polish_info()
+print(f"oracle sweep {time.time() - t:.1f} s; GPU status {np.bincount(status)}, iterations mean {iters.mean():.2f} max {iters.max()}, polish verified {int((pol >= 1).sum())}/{B} (rounds {np.bincount(pol[pol >= 1])}), failed {int((pol < 0).sum())}")
 ok = res[:, 4] == 1
 print(f"oracle solved {int(ok.sum())}/{B}, verified KKT point (polished) {int((res[:, 5] >= 1).sum())}/{B}")
 for name, sel in [("all oracle-solved", ok), ("oracle verified", ok & (res[:, 5] >= 1)), ("|e*| <= 10 m", ok & (res[:, 6] <= 10.0)), ("|e*| > 10 m", ok & (res[:, 6] > 10.0))]:
