@@ -226,7 +226,7 @@ def main():
         one_step(); torch.cuda.synchronize(); ph.append(mpc.phase_ms())
     ph = np.mean(np.array(ph), axis=0)
     st, it, act, mu = mpc.solve_info(); pol = mpc.polish_info()
-    ok = int((st == pkg.SOLVED).sum())
+    ok = int(pkg.is_solved(st).sum())
     # warm steps (second and later consecutive steps on the same inputs: warm nodes + warm start of the active set): reported as an extra, not as `value`
     sync(); tw = time.perf_counter()
     for _ in range(0 if args.no_warm else args.steps):
@@ -246,7 +246,7 @@ def main():
         torch.cuda.synchronize(); t_ = time.perf_counter() - t_
         st0_, it0_, _, _ = m0.solve_info(); p0_ = m0.polish_info()
         ipm_only = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": [float(v) for v in m0.phase_ms()],
-                    "solved": f"{int((st0_ == pkg.SOLVED).sum())}/{B}", "ipm_iters_mean": float(np.mean(it0_)), "polish_rounds_hist": hist(p0_),
+                    "solved": f"{int(pkg.is_solved(st0_).sum())}/{B}", "ipm_iters_mean": float(np.mean(it0_)), "polish_rounds_hist": hist(p0_),
                     "config": "pg_config.cold_guess = 0: Mehrotra interior point to mu <= 3e-6 + active-set polish for every instance"}
         m0.close()
         # ... and with update_QP! fused into the solve kernel (pg_set_fusion(1), off by default: SURVEY 7.1 step 6; bit-identical results)
@@ -290,7 +290,7 @@ def main():
         for _ in range(args.steps):
             for m2, _s in hs: m2.reset(); m2.step_dev()
         torch.cuda.synchronize(); t_ = time.perf_counter() - t_
-        ok2 = sum(int((m2.solve_info()[0] == pkg.SOLVED).sum()) for m2, _s in hs)
+        ok2 = sum(int(pkg.is_solved(m2.solve_info()[0]).sum()) for m2, _s in hs)
         two_streams = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "solved": f"{ok2}/{B}",
                        "config": f"the same {B} cold instances as 2 x {B // 2} on two handles and two HIP streams, steps submitted alternately, one synchronisation at the end"}
         for m2, _s in hs: m2.close()
@@ -309,7 +309,7 @@ def main():
             mr.simulate_(4); torch.cuda.synchronize(); tr_ = time.perf_counter()
             mr.simulate_(40); torch.cuda.synchronize(); tr_ = time.perf_counter() - tr_
             str_, itr_, _, _ = mr.solve_info()
-            roll["warm_start_of_active_set" if warm else "without_it"] = {"value": B * 40 / tr_, "unit": "solves/s", "ms_per_step": 1e3 * tr_ / 40, "solved_last_step": f"{int((str_ == pkg.SOLVED).sum())}/{B}",
+            roll["warm_start_of_active_set" if warm else "without_it"] = {"value": B * 40 / tr_, "unit": "solves/s", "ms_per_step": 1e3 * tr_ / 40, "solved_last_step": f"{int(pkg.is_solved(str_).sum())}/{B}",
                                                                           "ipm_iters_mean_last_step": float(np.mean(itr_)), "served_by_warm_polish_alone": int((itr_ == 0).sum())}
             mr.close()
 
@@ -328,7 +328,7 @@ def main():
             torch.cuda.synchronize(); td = time.perf_counter() - td
             std, itd, _, _ = mpc_d.solve_info(); pd_ = mpc_d.polish_info()
             r = {"value": B * args.steps / td, "unit": "solves/s", "ms_per_step": 1e3 * td / args.steps, "phase_ms": [float(v) for v in mpc_d.phase_ms()],
-                 "solved": f"{int((std == pkg.SOLVED).sum())}/{B}", "ipm_iters_mean": float(np.mean(itd)), "polished": f"{int((pd_ >= 1).sum())}/{B}"}
+                 "solved": f"{int(pkg.is_solved(std).sum())}/{B}", "ipm_iters_mean": float(np.mean(itd)), "verified_by_polish": f"{int((pd_ >= 1).sum())}/{B}"}
             mpc_d.close()
             return r
         dec = {"workload": f"configs[4]: Batch={B} decoupled MPC, N=50 + both_walls (soft rows edge_R - sw <= e <= edge_L + sw from the tube's edge channels: a build-defined "
@@ -404,7 +404,7 @@ def main():
             torch.cuda.synchronize(); t_ = time.perf_counter() - t_
             st_, it_, _, _ = m32.solve_info(); p_ = m32.polish_info()
             return {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": [float(v) for v in m32.phase_ms()],
-                    "solved": f"{int((st_ == pkg.SOLVED).sum())}/{B}", "ipm_iters_mean": float(np.mean(it_)), "polished": f"{int((p_ >= 1).sum())}/{B}"}
+                    "solved": f"{int(pkg.is_solved(st_).sum())}/{B}", "ipm_iters_mean": float(np.mean(it_)), "verified_by_polish": f"{int((p_ >= 1).sum())}/{B}"}
 
         plain = run32(False)
         f32 = {"workload": f"configs[2]: Batch={B} coupled MPC + HJI safety constraint (13x13x9x9x9x9x9 float32 grid), N=30, fp32, cold", "dtype": "f32",

@@ -49,7 +49,11 @@ enum pg_solve_status {
     PG_SOLVED = 1,
     PG_MAX_ITER = 2,            /* iteration cap reached before the tolerances were met */
     PG_NUMERICAL = 3,           /* NaN/Inf met in the data or the iterates (e.g. the H4 hazard: other-car speed 0) */
-    PG_INFEASIBLE_X0 = 4        /* a hard bound on the fixed first node is violated (Ux_1 outside [V_min,V_max], Fx_1 < Fx_min) */
+    PG_INFEASIBLE_X0 = 4,       /* a hard bound on the fixed first node is violated (Ux_1 outside [V_min,V_max], Fx_1 < Fx_min) */
+    PG_SOLVED_UNVERIFIED = 5    /* (polish on) the interior point met its tolerances but NO active-set round verified a KKT point (pg_get_polish_info = -1): the control is
+                                 * the interior-point iterate at its rounding floor -- within 1e-6 of the optimum on every tracking batch tested, up to 2e-3 off in the wide
+                                 * random regime of tests/test_gpu_fuzz.py.  A caller that treats it like PG_SOLVED gets round-2 behaviour; with polish = 0 the interior
+                                 * point's own convergence is all there is and the status stays PG_SOLVED */
 };
 
 /* vehicle dictionary: src/vehicles.jl:1-59; field sets of src/vehicle_dynamics.jl:7-29,272-292 */
@@ -215,6 +219,11 @@ int pg_set_fusion(pg_handle* h, int32_t mode);
  * functions on the same arguments: nodes and QP data are bit-identical in fp64; in the fp32 library the nodes are, the QP data agree to fp32 rounding.
  * mode 1 = on where it applies (default; PG_PIPELINE=0/1 at pg_create overrides), 0 = never.  The compute calls invoked one by one are never pipelined. */
 int pg_set_pipeline(pg_handle* h, int32_t mode);
+/* The wavefronts of that launch that linearise an interval WAIT for the wavefronts that seed its nodes.  The wait is bounded (20 ms of wall-clock time); a wavefront
+ * that gives up -- the seeding wavefronts not resident before it: a dispatch order the launch does not control, a debugger, a time-sliced or counter-serialised run --
+ * raises a device flag, and the launch-per-phase kernels queued behind the pipelined launch (predicated on that flag) redo update_QP! for the batch: such a step is
+ * late, not wrong, and nothing is reported to the caller but this cumulative count of wavefronts that gave up (synchronises the handle's stream). */
+int pg_get_pipeline_fallbacks(pg_handle* h, int64_t* count);
 int pg_synchronize(pg_handle* h);
 
 /* ---- read-backs for parity tests and logging (host pointers, any may be NULL) ---------------------------------- */

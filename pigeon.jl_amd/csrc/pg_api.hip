@@ -209,7 +209,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_sep, cap * 4, real); ALLOC(h->d_nodes, cap * NN * 10, real); ALLOC(h->d_qp, cap * C.qp_len, real);
     ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
     ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_mu, cap, real);
-    ALLOC(h->d_polish, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_naux, cap * NN * 4, real); ALLOC(h->d_progress, cap / 64 + 2, int); ALLOC(h->d_active, cap * N, uint16_t);
+    ALLOC(h->d_polish, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_naux, cap * NN * 4, real); ALLOC(h->d_progress, cap / 64 + 6, int); ALLOC(h->d_active, cap * N, uint16_t);
 #ifdef PG_EXPERIMENTAL_SOLVE4
     { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (experimental/pg_solve4.hip)
     if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), real);
@@ -237,6 +237,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         (void)hipMemcpy(h->d_prev_ts, ts.data(), ts.size() * 8, hipMemcpyHostToDevice);
         (void)hipMemcpy(h->d_dt, dt.data(), dt.size() * 8, hipMemcpyHostToDevice);
         (void)hipMemset(h->d_solved, 0, cap * sizeof(int));
+        (void)hipMemset(h->d_progress, 0, (cap / 64 + 6) * sizeof(int));
         (void)hipMemset(h->d_status, 0, cap * sizeof(int));
         (void)hipMemset(h->d_other, 0, cap * 4 * sizeof(real));
         (void)hipMemset(h->d_solx, 0, cap * NN * 8 * sizeof(real));
@@ -302,6 +303,14 @@ int pg_qp_len(const pg_handle* h) { return h ? h->dc.qp_len : PG_ERR_INVALID; }
 int pg_set_stream(pg_handle* h, void* s) { if (!h) return PG_ERR_INVALID; h->stream = (hipStream_t)s; return PG_OK; }
 int pg_set_pipeline(pg_handle* h, int32_t mode) { if (!h || mode < 0 || mode > 1) return PG_ERR_INVALID; h->pipeline = mode; return PG_OK; }
 int pg_set_fusion(pg_handle* h, int32_t mode) { if (!h || mode < 0 || mode > 2) return PG_ERR_INVALID; h->fuse = mode; return PG_OK; }
+int pg_get_pipeline_fallbacks(pg_handle* h, int64_t* count) {
+    if (!h || !count) return PG_ERR_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int v = 0;
+    HIPCHK(h, hipMemcpy(&v, h->d_progress + (size_t)h->cfg.batch_capacity / 64 + 5, sizeof(int), hipMemcpyDeviceToHost));
+    *count = v;
+    return PG_OK;
+}
 int pg_synchronize(pg_handle* h) { if (!h) return PG_ERR_INVALID; HIPCHK(h, hipStreamSynchronize(h->stream)); return PG_OK; }
 
 // install a library: channels[n_traj][10][Lmax] (t, s, V, A, E, N, psi, kappa, edge_L, edge_R), L[k] valid nodes of trajectory k
@@ -521,7 +530,7 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
     const bool file = h->dc.formulation != PG_DECOUPLED && h->dc.polish;
     int* const order_cnt = file ? h->d_order + cap : (int*)nullptr;            // the two counters of the launch order start from zero: the projection kernel clears them (no memset of its own)
     if (with_time_grid) hipLaunchKernelGGL(k_project<true>, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep, h->d_t0, h->d_ts, h->d_dt, h->d_prev_ts,
-                                           pipelined ? h->d_progress : (int*)nullptr, (B + 63) / 64, order_cnt);
+                                           pipelined ? h->d_progress : (int*)nullptr, (B + 63) / 64 + 1, order_cnt);      // (+ 1: the fault word of the pipelined launch)
     else hipLaunchKernelGGL(k_project<false>, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep, (const double*)nullptr, (double*)nullptr, (double*)nullptr,
                             (double*)nullptr, (int*)nullptr, 0, order_cnt);
     LAUNCH_CHECK(h);
@@ -554,7 +563,19 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
                 if (i <= h->dc.Ns ? i % 3 == 0 : (i - h->dc.Ns) % 5 == 4) pub |= 1ull << i;
             if (h->pipe_fault) pub = 1ull << 63;                  // test hook: nothing is ever published (tests/test_gpu_api_contract.py)
             hipLaunchKernelGGL(kern, dim3((unsigned)(nbn + nbt * h->dc.N)), block, lds, h->stream, h->dc, B, nbn, nzf, pub, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
-                               h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes, F, h->d_naux, h->d_progress, h->d_Mb, h->d_qp);
+                               h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes, F, h->d_naux, h->d_progress, h->d_Mb, h->d_qp, h->d_progress + nbn, h->d_progress + cap / 64 + 5);
+            LAUNCH_CHECK(h);
+            // repair, queued unconditionally and predicated on the device: if any waiting wavefront of the launch above gave up (its fault word, zeroed by the
+            // projection kernel of the step), the deferred angles and update_QP! of the WHOLE batch run launch per phase -- the same kernels on the same nodes, so the QP
+            // data are the ones the pipeline would have written.  When nothing gave up the two launches return at once (~3 us together).
+            {
+                const int* flt = h->d_progress + nbn;
+                const long nn = (long)B * h->dc.NN;
+                hipLaunchKernelGGL(k_nodes_angles, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_naux, h->d_nodes, flt);
+                const long nz = (long)B * h->dc.Ns * 2, nr = (long)B * (h->dc.N - h->dc.Ns) * 2;
+                const int nbz = (int)((nz + 63) / 64), nbr = (int)((nr + 63) / 64);
+                hipLaunchKernelGGL(k_linearize_split, dim3((unsigned)(nbz + nbr)), dim3(64), 0, h->stream, h->dc, B, nbz, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp, flt);
+            }
             h->lin_done = true;
         } else {
             auto kern = staged ? k_nodes<true> : k_nodes<false>;

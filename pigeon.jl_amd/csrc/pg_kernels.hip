@@ -317,7 +317,8 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
 // The angles k_nodes deferred (steady_state(.., defer = true)): delta = atan2(y, x) - atan(t) of every seeded node and beta = atan(tb) of the long ones -- the same
 // expressions on the same arguments, evaluated with lane = (instance, node) instead of inside the serial chain of the instance (three inverse tangents per node were a
 // fifth of that chain's instructions).
-__global__ __launch_bounds__(256) void k_nodes_angles(DevCfg C, int B, const real* __restrict__ naux, real* __restrict__ nodes) {
+__global__ __launch_bounds__(256) void k_nodes_angles(DevCfg C, int B, const real* __restrict__ naux, real* __restrict__ nodes, const int* __restrict__ only_if = nullptr) {
+    if (only_if && *only_if == 0) return;                         // (repair launch behind k_nodes_linearize: runs only when a waiting wavefront of that launch gave up)
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)B * C.NN) return;
     const real* ax = naux + (size_t)gid * 4;
@@ -518,7 +519,8 @@ PG_DEV void linearize_pair(const DevCfg& C, int b, int t, int g, bool live, cons
 // the large-batch form: the Ns zero-order-hold intervals of every instance with three directions per lane (ND = 6), the N - Ns ramp intervals with four (ND = 8);
 // blocks [0, nb_zoh) take the first group -- a wavefront runs one of the two instruction streams, 8 instead of 10 dynamics "units" per short interval
 __global__ __launch_bounds__(64) void k_linearize_split(DevCfg C, int B, int nb_zoh, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb,
-                                                        real* __restrict__ qp) {
+                                                        real* __restrict__ qp, const int* __restrict__ only_if = nullptr) {
+    if (only_if && *only_if == 0) return;                         // (repair launch behind k_nodes_linearize, see there)
     const bool zoh = (int)blockIdx.x < nb_zoh;
     const int nint = zoh ? C.Ns : C.N - C.Ns;                      // intervals of this group per instance
     long gid = (long)(zoh ? blockIdx.x : blockIdx.x - nb_zoh) * blockDim.x + threadIdx.x;
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(64) void k_linearize(DevCfg C, int B, const real* _
 //    1.45); fp32 at 8192: 0.572 / 0.483 (0.555); B = 4096: 0.41 / 0.40 (0.53).
 template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_linearize(DevCfg C, int B, int nb_nodes, int nz_first, unsigned long long pub_mask, const real* __restrict__ state, const real* __restrict__ control,
                         const tdouble* __restrict__ toff, const int* __restrict__ solved, const real* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt,
-                        const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* nodes, OrderOut F, real* naux, int* progress, const real* __restrict__ hji_Mb, real* __restrict__ qp) {
+                        const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* nodes, OrderOut F, real* naux, int* progress, const real* __restrict__ hji_Mb, real* __restrict__ qp, int* fault, int* fault_total) {
     if ((int)blockIdx.x < nb_nodes) {
         nodes_body<STAGED, true>(C, B, (int)blockIdx.x, state, control, toff, solved, sep, ts, dt, prev_ts, prev_x, nodes, F, naux, progress, pub_mask);
         __threadfence();                                                  // (warm or mixed wavefronts publish once, here; every lane is back from the body)
@@ -583,14 +585,19 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_linearize(D
     {
         const int* flag = progress + ((grp * 32) >> 6);                     // (the nodes wavefront of these 32 instances)
         const int need = t + 2;                                             // nodes 0 .. t + 1
-        int spins = 0; bool gave_up = false;
+        // The wait is bounded in WALL-CLOCK time (s_memrealtime: 100 MHz whatever the shader clock does): 20 ms -- a hundred times the whole recurrence.  A wavefront that
+        // gives up (the nodes blocks not resident before it: a dispatch order this launch does not control; a debugger, a time-sliced or serialised profiler run)
+        // raises `fault` and leaves; every other waiting wavefront then leaves at once as well, and the host has queued, behind this launch, the ordinary
+        // k_nodes_angles + k_linearize_split over the whole batch, predicated on that word: the step is late, never wrong.
+        const unsigned long long t_give_up = wall_clock64() + 2000000ull;
+        bool gave_up = false;
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
             __builtin_amdgcn_s_sleep(16);
-            if (++spins > 200000) { gave_up = true; break; }
+            if (__hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() > t_give_up) { gave_up = true; break; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (gave_up) {
-            if (live && g == 0) { real* Q = qp + (size_t)b * C.qp_len + qp_offsets(C.N).c + 6 * t; for (int i = 0; i < 6; i++) Q[i] = NAN; }
+            if (lane == 0) { __hip_atomic_fetch_add(fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_add(fault_total, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             return;
         }
     }
@@ -2081,7 +2088,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     it = it_total;
     stamp(0);
     if (PROF && lane == 0) { for (int i = 0; i < 6; i++) prof[(size_t)b * 6 + i] = pc[i]; }
-    if (status == PG_SOLVED) {
+    if (status == PG_SOLVED && C.polish && pstat < 0) status = PG_SOLVED_UNVERIFIED;      // an interior-point iterate no active-set round could verify (pigeon_mpc.h)
+    if (status == PG_SOLVED || status == PG_SOLVED_UNVERIFIED) {
         real Ux0 = sx0[1], Fx0 = sx0[7];
         if (Ux0 < C.cp.V_min || Ux0 > C.cp.V_max || Fx0 < C.fxmin_n) status = PG_INFEASIBLE_X0;
     }

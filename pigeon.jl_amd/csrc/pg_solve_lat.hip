@@ -671,7 +671,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             const real d = SXs[0][6] * C.un0, Fx = nodes[((size_t)b * NN + 1) * 10 + 7];
             real* U = O.u_out + (size_t)b * 3;
             U[0] = d; U[1] = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac; U[2] = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
-            O.status[b] = status; O.iters[b] = it; O.mu[b] = mu; O.polish[b] = pstat;
+            O.status[b] = (status == PG_SOLVED && C.polish && pstat < 0) ? PG_SOLVED_UNVERIFIED : status; O.iters[b] = it; O.mu[b] = mu; O.polish[b] = pstat;
             O.solved[b] = 1;      // model_predictive_control.jl:76: solved = true
         }
     }

@@ -16,7 +16,14 @@ from .vehicles import X1, CoupledControlParams, DecoupledControlParams
 
 c_dp = C.POINTER(C.c_double)
 
-SOLVED, MAX_ITER, NUMERICAL, INFEASIBLE_X0 = 1, 2, 3, 4
+SOLVED, MAX_ITER, NUMERICAL, INFEASIBLE_X0, SOLVED_UNVERIFIED = 1, 2, 3, 4, 5
+
+
+def is_solved(status):
+    """True where the solver returned an answer that met its tolerances: PG_SOLVED (with the polish on: a VERIFIED KKT point) or PG_SOLVED_UNVERIFIED (the
+    interior-point iterate no active-set round could verify; include/pigeon_mpc.h)."""
+    status = np.asarray(status)
+    return (status == SOLVED) | (status == SOLVED_UNVERIFIED)
 
 
 def _p(a, ctype=c_dp):
@@ -243,6 +250,12 @@ class BatchedTrajectoryTrackingMPC:
     def set_pipeline(self, mode):
         """Pipelined nodes + update_QP launch for large batches with cold instances (include/pigeon_mpc.h pg_set_pipeline): True / 1 where it applies (default), False / 0 never."""
         self._chk(self.lib.pg_set_pipeline(self.h, int(mode)), "pg_set_pipeline")
+
+    def pipeline_fallbacks(self):
+        """Cumulative number of waiting wavefronts of the pipelined nodes + update_QP launch that gave up (the step was then redone launch per phase)."""
+        n = C.c_int64(0)
+        self._chk(self.lib.pg_get_pipeline_fallbacks(self.h, C.byref(n)), "pg_get_pipeline_fallbacks")
+        return int(n.value)
 
     def phase_ms(self):
         out = (C.c_float * 3)()

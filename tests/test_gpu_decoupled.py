@@ -25,7 +25,7 @@ def test_decoupled_matches_oracle(pkg, oracle_mod, skidpad, Ns, Nl):
     assert (orc.n, orc.m) == ((245, 455) if Nl == 20 else (405, 755))
     state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B, seed=31, traj_mode=(Nl == 20))
     u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
-    assert np.all(status == 1), status
+    assert np.all(pkg.is_solved(status)), status      # (PG_SOLVED_UNVERIFIED: instances whose polish did not verify keep the interior-point iterate; compared below like the rest)
     qs, us, ps = mpc.nodes(); qp = mpc.qp_data(); x, sg = mpc.solution(); st, it, act, mu = mpc.solve_info()
     worst = 0.0
     for b in range(B):
@@ -84,7 +84,7 @@ def test_walls_extension_matches_oracle_qp_with_wall_rows(pkg, oracle_mod, skidp
     free = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), tube, B, N_short=Ns, N_long=Nl)
     u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
     uf, stf, _ = free.step_(state, control, t0, time_offset=toff)
-    assert np.all(status == 1), np.bincount(status)
+    assert np.all(pkg.is_solved(status)), np.bincount(status)
     x, sg = mpc.solution(); st, it, act, mu = mpc.solve_info(); edges = mpc.wall_edges(); xf, _ = free.solution()
     orc = oracle_mod.OracleDecoupled(N_short=Ns, N_long=Nl); orc.set_trajectory(tube.data)
     n, m, Nh = orc.n, orc.m, orc.N
@@ -217,7 +217,8 @@ def test_config5_as_shipped_every_instance_against_the_oracle(pkg, oracle_mod, s
     mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, B, N_short=Ns, N_long=Nl, walls=walls)
     state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B)
     u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
-    assert np.all(status == pkg.SOLVED), np.bincount(status)
+    assert np.all(pkg.is_solved(status)), np.bincount(status)
+    assert np.array_equal(status == pkg.SOLVED, mpc.polish_info() >= 1)             # PG_SOLVED = a verified KKT point, PG_SOLVED_UNVERIFIED = the interior-point iterate
     res = check_lateral_batch_against_oracle(pkg, oracle_mod, skidpad, mpc, B, Ns, Nl, walls)
     pol = mpc.polish_info()
     print(f"walls={walls}: max |d2-d2*| {res[:, 0].max():.2e} (median {np.median(res[:, 0]):.1e}), max objective gap {res[:, 1].max():.2e}, worst row violation {res[:, 2].max():.2e}, "

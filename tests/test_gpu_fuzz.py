@@ -34,13 +34,15 @@ def test_wide_random_inputs(pkg, oracle_mod, path, seed):
     for step in range(2):                                   # cold step, then a warm step from the plant-advanced state (warm start of the active set)
         u, st, it = mpc.step_(state, control, t0, time_offset=toff)
         qp = mpc.qp_data(); x, _ = mpc.solution(); pol = mpc.polish_info()
-        ok = st == pkg.SOLVED
+        ok = pkg.is_solved(st)
+        # status honesty: PG_SOLVED is returned for VERIFIED KKT points only; an interior-point iterate no polish round verified is PG_SOLVED_UNVERIFIED
+        assert np.array_equal(st[ok] == pkg.SOLVED, pol[ok] >= 1)
         assert np.mean(ok) > 0.7, (path, step, np.bincount(st))
         assert np.all(np.isfinite(u[ok])) and np.all(np.isfinite(x[ok]))
         # PG_NUMERICAL with finite inputs is legitimate in exactly one situation, and the reference shares it: the explicit RK4 of `linearize` is unstable at low
         # speed (|lambda h| > 2.78 below ~2 m/s) and overflows when the warm nodes come from a wild previous solution -- the QP data are then 1e40+
         num = st == pkg.NUMERICAL
-        assert np.all((st == pkg.SOLVED) | (st == pkg.MAX_ITER) | (st == pkg.INFEASIBLE_X0) | num), np.bincount(st)
+        assert np.all((st == pkg.SOLVED) | (st == pkg.SOLVED_UNVERIFIED) | (st == pkg.MAX_ITER) | (st == pkg.INFEASIBLE_X0) | num), np.bincount(st)
         assert num.sum() <= 4 and all(not np.all(np.isfinite(qp[b])) or np.max(np.abs(qp[b])) > 1e10 for b in np.flatnonzero(num)), (path, step, int(num.sum()))
         worst, worst_unverified, n_bad = 0.0, 0.0, 0
         idx = rng.choice(B, 192, replace=False)
