@@ -37,6 +37,25 @@ def solve_flops(N, ipm_iters, polish_rounds):
     return 6000.0 + per_iter * ipm_iters + per_polish * polish_rounds
 
 
+def kernel_source_sha16():
+    """Content hash of the device sources (what profiles/traffic.json was measured on is recorded with the same function by tools/summarize_profiles.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("pg_kernels.hip", "pg_solve_lat.hip", "pg_device.hpp", "pg_api.hip"):
+        h.update(open(os.path.join(ROOT, "pigeon.jl_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def mfma_util(tr, dom, pipelined):
+    """Matrix-core utilisation of the dominant kernel from the committed PMC pass (profiles/traffic.json, written by tools/summarize_profiles.py): busy cycles of the MFMA
+    pipe over the kernel's busy cycles, and the fp64 MFMA flop rate against the 78.6 TFLOP/s dense fp64 matrix peak.  None when the counters were not collected."""
+    if not tr:
+        return None
+    kern = {0: "k_nodes_linearize" if pipelined else "k_nodes", 1: "k_linearize", 2: "k_solve"}[dom]
+    hit = [v for k, v in tr.get("kernels", {}).items() if kern in k and "mfma" in v]
+    return hit[0]["mfma"] if hit else None
+
+
 def usable_cores():
     """Host threads this process may really use: the scheduler affinity, capped by the cgroup CPU quota (cpu.max) when one is set."""
     n = len(os.sched_getaffinity(0))
@@ -91,8 +110,34 @@ def cpu_baseline(pkg, traj, mpc, state, control, t0, toff, precision, local):
         _, itd, std, secsd = od.step_batch(state[:nd], control[:nd], t0[:nd], toff[:nd], nthreads=cores)
         out["decoupled_n50"] = {"value": nd / secsd, "unit": "solves/s", "cores": cores, "sample": f"{nd} cold instances", "osqp_iters_mean": float(np.mean(itd)),
                                 "osqp_hit_max_iter": int(np.sum(std != 1))}
+        # ... and the checker for the bench's decoupled_n50 line: the GPU's applied steering of a sample of the SAME batch, default solver configuration, with the wall
+        # rows (the configs[4] line) and without, against a VERIFIED KKT point of the canonical QP built from the GPU's own QP data (OracleDecoupled.solve_exact_verified)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_gpu_decoupled import unembed_qp, extend_with_walls
+        nsd = 128
+        acc = {}
+        for walls in (True, False):
+            g = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, nsd, N_short=10, N_long=40, device=local, precision=precision, walls=walls)
+            ud, stdg, _ = g.step_(state[:nsd], control[:nsd], t0[:nsd], time_offset=toff[:nsd])
+            qpd = g.qp_data(); xd, _ = g.solution(); edges = g.wall_edges() if walls else None; pold = g.polish_info()
+            errs, nver = [], 0
+            for b in range(nsd):
+                sd = unembed_qp(od, qpd[b])
+                if walls:
+                    qpw, _ = extend_with_walls(od, od.assemble_qp(sd), edges[b], od.unpack_sd(sd)["dt"], g.wall_weight)
+                    xe, ye, info = od.solve_exact_verified(sd, qp=qpw, walls=edges[b], wall_weight=g.wall_weight)
+                else:
+                    xe, ye, info = od.solve_exact_verified(sd)
+                if info["status"] == 1 and info["polished"] >= 1:
+                    nver += 1; errs.append(abs(xd[b, 1, 6] - od.split_x(xe[:od.n])["delta"][1]))
+            acc["with_walls" if walls else "without_walls"] = {"instances": nsd, "oracle_verified_kkt_points": nver, "max_abs_applied_steering_error_rad": float(np.max(errs)),
+                                                               "median": float(np.median(errs)), "gpu_verified_by_polish": f"{int((pold >= 1).sum())}/{nsd}",
+                                                               "gpu_solved": f"{int(pkg.is_solved(stdg).sum())}/{nsd}"}
+            g.close()
+        out["decoupled_n50"]["accuracy"] = dict(acc, against="exact optimum of the same QP data as a verified KKT point of the canonical lateral QP (fp64 oracle); every one of "
+                                                "the 4096 instances <= 1e-6 is asserted by tests/test_gpu_decoupled.py::test_config5_as_shipped_every_instance_against_the_oracle")
     except Exception as e:          # never let a secondary object cost the headline
-        out["decoupled_n50"] = {"error": repr(e)}
+        out.setdefault("decoupled_n50", {})["error"] = repr(e)
 
     # ---- BASELINE config 1: ONE controller, cold step then 100 closed-loop steps (simulate semantics, 10 ms period), pg_step host->host
     #      latency on the GPU beside the CPU port's step time; x0 = path pose at s = 20 m, e = 0.3 m, dpsi = 0.05 rad, Ux = V_path ----
@@ -215,10 +260,16 @@ def main():
     torch.cuda.synchronize()
     sync()
     elapsed = time.perf_counter() - t_begin
+    rank_ms = None
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        # a scaling run is the timed loop, the gather check and ONE JSON line: every secondary object below is skipped when world > 1 (rank 0 would otherwise build
+        # HJI tables, decoupled and fp32 handles while the other ranks wait in the barrier)
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(t.item()) for t in every]
+        elapsed = max(per_rank)
+        rank_ms = {"min": 1e3 * min(per_rank) / args.steps, "max": 1e3 * max(per_rank) / args.steps}
 
     # per-phase device time (HIP events recorded by pg_step_dev on the launch stream): mean over a few extra steps outside the timed region
     ph = []
@@ -300,7 +351,7 @@ def main():
     # closed-loop rollouts resident on the device (pg_simulate_dev = simulate of model_predictive_control.jl:80-100 for the whole batch): per step the
     # four compute phases + the plant's RK4 step; warm branch of the nodes and warm start of the active set (vs the same loop with that warm start off)
     roll = None
-    if rank == 0 and not args.no_rollout:
+    if rank == 0 and world == 1 and not args.no_rollout:
         roll = {"workload": f"{B} controllers in closed loop on the device, 40 steps of 10 ms after 4 warm-up steps (skidpadoval, config-2 initial states), {args.precision}"}
         for warm in (True, False):
             mr = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision=args.precision, warm_polish=warm)
@@ -315,7 +366,7 @@ def main():
 
     # BASELINE config 5: decoupled (lateral) MPC, N = 50 (N_short = 10, N_long = 40), same batch, cold every step (that formulation has no warm branch)
     dec = None
-    if rank == 0 and not args.no_decoupled:
+    if rank == 0 and world == 1 and not args.no_decoupled:
         def run_dec(walls, polish=None):
             mpc_d = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, device=local, precision=args.precision, walls=walls, polish=polish)
             mpc_d.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -335,11 +386,13 @@ def main():
                            f"extension, the reference snapshot has no wall constraint), {args.precision}"}
         dec.update(run_dec(True))
         dec["without_walls"] = run_dec(False)            # the reference's own lateral QP (decoupled_lat_long.jl as it stands)
-        dec["without_walls_with_polish"] = run_dec(False, polish=True)      # optional for this formulation (off by default: pg_default_config_decoupled)
+        dec["without_walls_interior_point_only"] = run_dec(False, polish=False)      # (polish = 0, the round-2 default: 5 of these 4096 instances end 1e-6 .. 1e-5 from the optimum)
+        dec["accuracy"] = "measured in this run: cpu_baseline.decoupled_n50.accuracy (sample of 128 against verified KKT points, with and without the wall rows)"
+        dec["solver"] = "k_solve_lat: Mehrotra interior point on the 5-state stage form (sixteen lanes per instance) to mu <= 3e-6, active-set polish (verified KKT point), interior point resumed to 1e-12 where the polish does not verify"
 
     # HJI value/gradient lookup (the bandwidth-bound kernel of the path): 2^20 random in-grid relative states against the config-3 grid
     hji = None
-    if rank == 0 and not args.no_hji:
+    if rank == 0 and world == 1 and not args.no_hji:
         import ctypes as C
 
         def lookup_rate(knots, Vg, gg, label):
@@ -386,7 +439,7 @@ def main():
 
     # BASELINE config 3: coupled MPC + HJI safety constraint on the precomputed 7-D grid, fp32 (libpigeon_hip_f32.so: same translation unit, real = float)
     f32 = None
-    if rank == 0 and not args.no_f32 and args.precision == "f64":
+    if rank == 0 and world == 1 and not args.no_f32 and args.precision == "f64":
         m32 = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision="f32")
         m32.set_stream(torch.cuda.current_stream().cuda_stream)
         other = pkg.synthetic.other_cars(state, seed=777)
@@ -431,9 +484,12 @@ def main():
         dom_ms = float(ph[dom])
         bytes_per_solve = BYTES_PER_SOLVE_COLD_FP64 if args.precision == "f64" else 68        # 112 B fp64; fp32 = 9 floats + t0 (double) in, 3 floats + status + iters out
         achieved = B * bytes_per_solve / (dom_ms * 1e-3) / 1e9
-        traffic = None; traffic_src = None
+        traffic = None; traffic_src = None; traffic_stale = None; tr = None
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            # the counters were taken with a particular build: traffic.json records the hash of the kernel sources it was taken at (tools/summarize_profiles.py), and the
+            # line says so when the sources have changed since (the GPU box has no .git: a content hash, not a commit)
+            traffic_stale = tr.get("kernel_source_sha16") != kernel_source_sha16()
             kern = {0: "k_nodes_linearize" if pipelined else "k_nodes", 1: "k_linearize", 2: "k_solve"}[dom]                  # the kernel that makes up the dominant phase (no HJI row in the headline run)
             hit = [v for k, v in tr.get("kernels", {}).items() if kern in k]
             traffic = hit[0]["hbm_bytes_per_launch"] if hit else tr.get("hbm_bytes_per_launch"); traffic_src = (hit[0] if hit else tr).get("source")
@@ -465,11 +521,12 @@ def main():
                                  "Mehrotra interior point to mu <= " + ("3e-6" if args.precision == "f64" else "1e-4") + ", then active-set polish (verified KKT point)",
                        "accuracy": "measured in this run: cpu_baseline.accuracy (sample of 256); every one of the 4096 instances <= 1e-6 is asserted by tests/test_gpu_full_size.py (measured max 5e-11)"},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": dom_ms, "valu": valu, "valu_linearize": valu_lin,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale, "avg_launch_ms": dom_ms, "mfma": mfma_util(tr, dom, pipelined), "valu": valu, "valu_linearize": valu_lin,
                          "note": f"algorithmic HBM bytes are {bytes_per_solve} B/solve (SURVEY 8d): the step is VALU/LDS/latency bound by construction, not HBM bound; see roofline.valu and hji_lookup"},
             "phase_ms": {n: float(v) for n, v in zip(names, ph)},
             "warm_value": None if args.no_warm else world * B * args.steps / warm_elapsed,
-            "solved": f"{ok}/{B}", "gather_ok": gather_ok, "ipm_iters_mean": float(np.mean(it)), "ipm_iters_max": int(np.max(it)), "ipm_iters_hist": hist(it),
+            "solved": f"{ok}/{B}", "gather_ok": gather_ok, "ranks": world if world == 1 else dist.get_world_size(), "collective": None if world == 1 else ("rccl" if args.backend == "nccl" else "gloo"),
+            "per_rank_ms_per_step": rank_ms, "ipm_iters_mean": float(np.mean(it)), "ipm_iters_max": int(np.max(it)), "ipm_iters_hist": hist(it),
             "polish_rounds_hist": hist(pol), "polish_note": "k >= 1: verified in round k; 0: not run; -1: not verified (interior-point iterate at 1e-12 kept)",
             "served_by_active_set_guess_alone": int((it == 0).sum()),
         }

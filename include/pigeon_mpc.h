@@ -204,7 +204,8 @@ int pg_simulate_dev(pg_handle* h, int32_t steps, double dt, pg_real_dev* state_h
 /* current device-resident inputs: state [B][6], control [B][3], t0 [B] (host pointers, any may be NULL) */
 int pg_get_state(pg_handle* h, double* state, double* control, double* t0);
 
-/* stream to launch on (hipStream_t as void*); NULL = the null stream */
+/* stream to launch on (hipStream_t as void*); NULL = the null stream.  pg_set_inputs and pg_step are ASYNCHRONOUS on the handle's stream (copies from / into one pinned
+ * staging buffer, synchronised at the next entry that needs it): switching streams first waits for whatever is still queued on the old one. */
 int pg_set_stream(pg_handle* h, void* hip_stream);
 /* Fused step: pg_step / pg_step_dev / pg_simulate_dev can run update_QP! and solve! of the coupled formulation (N <= 32) in ONE kernel -- the wavefront that
  * solves an instance linearises it first (same device functions: results are bit-identical either way; the QP data are still written and pg_get_qp reads them).

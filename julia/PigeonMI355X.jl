@@ -214,6 +214,18 @@ function set_pipeline!(mpc::BatchedTrajectoryTrackingMPC, mode::Integer)
     check(mpc, ccall(sym(mpc, :pg_set_pipeline), Cint, (Ptr{Cvoid}, Int32), mpc.handle, Int32(mode)), "pg_set_pipeline")
 end
 
+"number of waiting wavefronts of the pipelined launch that gave up so far (each such step was redone launch per phase: late, not wrong; pg_get_pipeline_fallbacks)"
+function pipeline_fallbacks(mpc::BatchedTrajectoryTrackingMPC)
+    n = Ref{Int64}(0)
+    check(mpc, ccall(sym(mpc, :pg_get_pipeline_fallbacks), Cint, (Ptr{Cvoid}, Ptr{Int64}), mpc.handle, n), "pg_get_pipeline_fallbacks")
+    n[]
+end
+
+# per-instance solver status words (include/pigeon_mpc.h: pg_solve_status).  With the polish on, PG_SOLVED is a VERIFIED KKT point of the QP; PG_SOLVED_UNVERIFIED is the
+# interior-point iterate no active-set round could verify (a caller that treats it like PG_SOLVED gets the behaviour of earlier versions)
+const PG_SOLVED = Int32(1); const PG_MAX_ITER = Int32(2); const PG_NUMERICAL = Int32(3); const PG_INFEASIBLE_X0 = Int32(4); const PG_SOLVED_UNVERIFIED = Int32(5)
+is_solved(status::Integer) = status == PG_SOLVED || status == PG_SOLVED_UNVERIFIED
+
 "update_HJI_values_marker! / update_HJI_contour_marker! (src/rviz.jl:23-40,60-69) for a batch of relative states q (7 x B): V at every (x, y) knot pair of grid
 dimensions 1, 2 and the zero-level crossings on the grid edges (NaN = none)"
 function hji_value_slice(mpc::BatchedTrajectoryTrackingMPC, q::Matrix{Float64})

@@ -45,6 +45,8 @@ def load_library(precision="f64"):
     if precision in _libs:
         return _libs[precision]
     path = LIB_PATH if precision == "f64" else LIB_PATH_F32
+    # A/B runs of an experimental build select it here (PIGEON_HIP_LIB / PIGEON_HIP_LIB_F32 = path of the .so) instead of copying it over the shipped library
+    path = os.environ.get("PIGEON_HIP_LIB" if precision == "f64" else "PIGEON_HIP_LIB_F32", path)
     if not os.path.exists(path):
         raise PigeonError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)")
     try:

@@ -256,10 +256,14 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
 #endif
     h->solve_lds = (size_t)((h->solve_ring ? 4 : N) * SB + 10 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 72 + 100 + 8 + 64 + 2) * sizeof(real);
     if (h->solve_lds > 160 * 1024) { g_create_error = "horizon too long for LDS staging"; free_all(h); delete h; return PG_ERR_INVALID; }
-    static size_t lds_attr_max = 48 * 1024;      // hipFuncSetAttribute is process-global: a later handle with a shorter horizon must not lower the limit of an earlier one
-    if (h->solve_lds > lds_attr_max)
+    // hipFuncSetAttribute applies to the CURRENT DEVICE's copy of a kernel, and a later handle with a shorter horizon must not lower the limit an earlier handle of the same
+    // device relies on: the largest size asked for so far is kept per device ordinal
+    static size_t lds_attr_max[64] = {0};
+    const int dev_slot = cfg->device < 64 ? cfg->device : 63;
+    if (lds_attr_max[dev_slot] < 48 * 1024) lds_attr_max[dev_slot] = 48 * 1024;
+    if (h->solve_lds > lds_attr_max[dev_slot])
     {
-        lds_attr_max = h->solve_lds;
+        lds_attr_max[dev_slot] = h->solve_lds;
         (void)hipFuncSetAttribute((const void*)k_solve<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
         (void)hipFuncSetAttribute((const void*)k_solve<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
         (void)hipFuncSetAttribute((const void*)k_solve<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
@@ -268,8 +272,9 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     }
     {
         h->lat_lds = lat_lds_doubles(N) * sizeof(real);
-        if (h->solve_lat && h->lat_lds > 48 * 1024) {
-            const int ld = (int)h->lat_lds;
+        static size_t lat_attr_max[64] = {0};
+        if (h->solve_lat && h->lat_lds > 48 * 1024 && h->lat_lds > lat_attr_max[dev_slot]) {
+            const int ld = (int)h->lat_lds; lat_attr_max[dev_slot] = h->lat_lds;
             (void)hipFuncSetAttribute((const void*)k_solve_lat<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ld);
             (void)hipFuncSetAttribute((const void*)k_solve_lat<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ld);
         }
@@ -300,7 +305,14 @@ int pg_abi_layout(int32_t* out, int32_t n) {
     return cnt;
 }
 int pg_qp_len(const pg_handle* h) { return h ? h->dc.qp_len : PG_ERR_INVALID; }
-int pg_set_stream(pg_handle* h, void* s) { if (!h) return PG_ERR_INVALID; h->stream = (hipStream_t)s; return PG_OK; }
+int pg_set_stream(pg_handle* h, void* s) {
+    if (!h) return PG_ERR_INVALID;
+    // pg_set_inputs / pg_step leave asynchronous copies from (and into) the ONE pinned staging buffer queued on the old stream: they must have landed before kernels on
+    // the new stream read the inputs or the next call overwrites the buffer
+    if ((hipStream_t)s != h->stream) { (void)hipSetDevice(h->cfg.device); HIPCHK(h, hipStreamSynchronize(h->stream)); }
+    h->stream = (hipStream_t)s;
+    return PG_OK;
+}
 int pg_set_pipeline(pg_handle* h, int32_t mode) { if (!h || mode < 0 || mode > 1) return PG_ERR_INVALID; h->pipeline = mode; return PG_OK; }
 int pg_set_fusion(pg_handle* h, int32_t mode) { if (!h || mode < 0 || mode > 2) return PG_ERR_INVALID; h->fuse = mode; return PG_OK; }
 int pg_get_pipeline_fallbacks(pg_handle* h, int64_t* count) {
@@ -868,7 +880,8 @@ static int step_by_graph(pg_handle* h, int32_t B, const double* state, const dou
             G.disabled = true; (void)hipGetLastError();
             return PG_OK;
         }
-        G.dc = h->dc; G.hv = h->hv; G.B = B; G.user = user; G.fuse = h->fuse; G.pipeline = h->pipeline; G.has_hji = (int)h->has_hji; G.traj_L = h->traj_L;
+        memcpy(&G.dc, &h->dc, sizeof(DevCfg)); memcpy(&G.hv, &h->hv, sizeof(HjiView)); G.B = B;      // (byte copies: the signature is compared with memcmp, padding included)
+         G.user = user; G.fuse = h->fuse; G.pipeline = h->pipeline; G.has_hji = (int)h->has_hji; G.traj_L = h->traj_L;
     } else if (hipStreamSynchronize(h->stream) != hipSuccess) return PG_OK;
     stage_block(h, B, state, control, t0, other, toff);
     HIPCHK(h, hipGraphLaunch(G.x, run));

@@ -11,8 +11,10 @@ print('$1 config3', round(f['value']), [round(x,4) for x in f['phase_ms']], f['s
   tail -1 gpurun_out/bench_f32_8192_$1.log | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); print('$1 f32 8192', round(d['value']), [round(x,4) for x in d['phase_ms'].values()], d['solved'], d['ipm_iters_hist'], d['polish_rounds_hist'])"
 }
+set -e
 run base
-cp pigeon.jl_amd/csrc/libpigeon_hip_f32.so /tmp/f32_w2.so && cp pigeon.jl_amd/csrc/libpigeon_hip_f32_w1.so pigeon.jl_amd/csrc/libpigeon_hip_f32.so
+test -f pigeon.jl_amd/csrc/libpigeon_hip_f32_w1.so      # (nothing to compare against otherwise)
+export PIGEON_HIP_LIB_F32=$PWD/pigeon.jl_amd/csrc/libpigeon_hip_f32_w1.so      # selected, never copied over the shipped library (pigeon.jl_amd/_lib.py)
 run ext
 timeout -k 10 400 python -m pytest tests/test_gpu_f32.py -m gpu -x -q 2>&1 | tail -3
-cp /tmp/f32_w2.so pigeon.jl_amd/csrc/libpigeon_hip_f32.so
+unset PIGEON_HIP_LIB_F32

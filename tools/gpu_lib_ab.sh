@@ -11,10 +11,10 @@ print('$1', round(d['value']), [round(x,4) for x in d['phase_ms'].values()], d['
   if [ "$PG_AB_FULL" = "1" ]; then timeout -k 10 300 python tools/gpu_all_paths_probe.py 2>&1 | grep -v amdgpu.ids | tail -9; fi
 }
 run base
-cp pigeon.jl_amd/csrc/libpigeon_hip.so /tmp/base.so
+# (the alternative build is SELECTED through PIGEON_HIP_LIB -- pigeon.jl_amd/_lib.py --, never copied over the shipped library: a timeout in between used to leave it there)
 for v in pigeon.jl_amd/csrc/libpigeon_hip_rg*.so; do
-  cp $v pigeon.jl_amd/csrc/libpigeon_hip.so
+  export PIGEON_HIP_LIB=$PWD/$v
   run $(basename $v .so)
   if [ "$PG_AB_FULL" = "1" ]; then timeout -k 10 400 python -m pytest tests/test_gpu_full_size.py tests/test_gpu_fuzz.py tests/test_gpu_edge_cases.py -m gpu -x -q 2>&1 | tail -3; fi
 done
-cp /tmp/base.so pigeon.jl_amd/csrc/libpigeon_hip.so
+unset PIGEON_HIP_LIB

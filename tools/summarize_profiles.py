@@ -1,13 +1,17 @@
-"""Condense gpurun_out/prof (written by tools/gpu_profile.sh on the GPU box) into profiles/<tag>/ and profiles/traffic.json.
+"""Condense gpurun_out/prof (written by tools/gpu_profile.sh on the GPU box, PART = 1, 2, 3) into profiles/<tag>/ and profiles/traffic.json.
 
-usage: python tools/summarize_profiles.py r01_final
-  kernel_stats.csv  : rocprofv3 --kernel-trace --stats summary, copied as is
-  pmc_summary.json  : per-kernel per-launch means of every counter collected in the separate --pmc passes
-  ../traffic.json   : HBM bytes per launch of the dominant kernel, (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction,
-                      MI355X_MICROARCH.md HBM section); bench.py reports it as roofline.traffic
+usage: python tools/summarize_profiles.py r03_final
+  kernel_stats*.csv : rocprofv3 --kernel-trace --stats summaries, copied as they are: kernel_stats.csv = the cold fp64 headline; _dec = + config 5 (lateral N = 50 with the
+                      wall rows: k_nodes_dec, k_qp_dec, k_solve_lat); _roll = + the closed-loop rollout (k_nodes_warm, k_advance, warm k_solve); _c3 = the fp32 library
+                      alone (its headline, the HJI lookups, config 3 with the safety row); _f32 = fp32 at 8192 per GPU (config 4's share)
+  pmc_summary.json  : per-kernel per-launch means of every counter collected in the separate --pmc passes, one section per pass group ("headline", "dec", "f32")
+  ../traffic.json   : HBM bytes per launch of the dominant kernels, (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md HBM section),
+                      matrix-core utilisation where the counters were collected, and the hash of the kernel sources the counters were taken at
+                      (bench.py reports traffic_stale: true when the sources have changed since)
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
@@ -20,56 +24,82 @@ src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
-ks = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
-assert len(ks) == 1, ks
-shutil.copy(ks[0], os.path.join(dst, "kernel_stats.csv"))
-ks32 = glob.glob(os.path.join(src, "stats_f32", "*", "*_kernel_stats.csv"))
-if len(ks32) == 1:
-    shutil.copy(ks32[0], os.path.join(dst, "kernel_stats_f32.csv"))
-
 
 def short(name):
-    name = name.replace("void ", "")
-    return name.split("(")[0]
+    return name.replace("void ", "").split("(")[0]
 
 
-acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
-for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
-    for row in csv.DictReader(open(f)):
-        k = short(row["Kernel_Name"])
-        if not k.startswith("pg::"):
-            continue
-        a = acc[k][row["Counter_Name"]]
-        a[0] += float(row["Counter_Value"]); a[1] += 1
-summary = {k: {c: {"launches": v[1], "mean_per_launch": v[0] / v[1]} for c, v in cs.items()} for k, cs in acc.items()}
+stats = {}
+for d, out in (("stats", "kernel_stats.csv"), ("stats_dec", "kernel_stats_dec.csv"), ("stats_roll", "kernel_stats_roll.csv"), ("stats_c3", "kernel_stats_c3.csv"),
+               ("stats_f32", "kernel_stats_f32.csv")):
+    ks = glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv"))
+    if len(ks) == 1:
+        shutil.copy(ks[0], os.path.join(dst, out))
+        stats[d] = list(csv.DictReader(open(ks[0])))
+assert "stats" in stats, "PART=1 of tools/gpu_profile.sh has not run"
+
+groups = {"headline": ["pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_mfma", "pmc_tcc"], "hji": ["pmc_fetch_hji", "pmc_write_hji"],
+          "dec": ["pmc_fetch_dec", "pmc_write_dec", "pmc_sq_dec"], "f32": ["pmc_fetch_f32", "pmc_write_f32", "pmc_sq_f32", "pmc_mfma_f32"]}
+summary = {}
+for g, dirs in groups.items():
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for d in dirs:
+        for f in glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")):
+            for row in csv.DictReader(open(f)):
+                k = short(row["Kernel_Name"])
+                if not k.startswith("pg::"):
+                    continue
+                a = acc[k][row["Counter_Name"]]
+                a[0] += float(row["Counter_Value"]); a[1] += 1
+    if acc:
+        summary[g] = {k: {c: {"launches": v[1], "mean_per_launch": v[0] / v[1]} for c, v in cs.items()} for k, cs in acc.items()}
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
 
-# HBM bytes per launch of the dominant kernel (k_solve) and of the bandwidth-bound one (k_hji_lookup)
-rows = list(csv.DictReader(open(ks[0])))
+
+def kernel_source_sha16():
+    h = hashlib.sha256()
+    for f in ("pg_kernels.hip", "pg_solve_lat.hip", "pg_device.hpp", "pg_api.hip"):
+        h.update(open(os.path.join(ROOT, "pigeon.jl_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
-def traffic_of(match):
+def entry(group, stats_key, match):
+    rows = stats.get(stats_key, [])
     cand = [r for r in rows if match in r["Name"]]
+    S = summary.get(group, {})
     if not cand:
         return None
     dom = max(cand, key=lambda r: float(r["TotalDurationNs"]))
     dk = short(dom["Name"])
-    if dk not in summary or "FETCH_SIZE" not in summary[dk]:
+    if dk not in S or "FETCH_SIZE" not in S[dk] or "WRITE_SIZE" not in S[dk]:
         return None
-    fs = summary[dk]["FETCH_SIZE"]["mean_per_launch"]; ws = summary[dk]["WRITE_SIZE"]["mean_per_launch"]
-    return dk, {"hbm_bytes_per_launch": (2 * fs + ws) * 1024, "fetch_size_kib": fs, "write_size_kib": ws, "avg_launch_ns_rocprof": float(dom["AverageNs"]),
-                "source": f"profiles/{tag}/pmc_summary.json"}
+    c = {k: v["mean_per_launch"] for k, v in S[dk].items()}
+    e = {"hbm_bytes_per_launch": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024, "fetch_size_kib": c["FETCH_SIZE"], "write_size_kib": c["WRITE_SIZE"],
+         "avg_launch_ns_rocprof": float(dom["AverageNs"]), "source": f"profiles/{tag}/pmc_summary.json [{group}]"}
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
+        # busy cycles of the matrix pipe over the busy cycles of the kernel's shader engines; fp64 MFMA flops (512 per MOPS unit: MI355X_MICROARCH.md) against the dense fp64 peak
+        secs = float(dom["AverageNs"]) * 1e-9
+        mops64 = c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)
+        e["mfma"] = {"busy_cycles_per_launch": c["SQ_VALU_MFMA_BUSY_CYCLES"], "sq_busy_cycles_per_launch": c["SQ_BUSY_CYCLES"],
+                     "busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(c["SQ_BUSY_CYCLES"], 1.0), "mfma_instructions_per_launch": c.get("SQ_INSTS_MFMA"),
+                     "mops_f64_per_launch": mops64, "tflops_f64_executed": mops64 * 512 / secs / 1e12, "peak_tflops_f64_matrix": 78.6,
+                     "frac_of_peak": mops64 * 512 / secs / 1e12 / 78.6, "source": f"profiles/{tag}/pmc_summary.json [{group}]"}
+    return dk, e
 
 
 out = {"formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction for wide coalesced reads, MI355X_MICROARCH.md HBM section; separate --pmc passes)",
-       "workload": "bench.py B=4096 coupled fp64 cold (k_solve); 2^20 lookups on the 13x13x9^5 grid (k_hji_lookup)", "kernels": {}}
-for m in ("pg::k_solve", "pg::k_hji_lookup", "pg::k_linearize", "pg::k_nodes"):
-    t = traffic_of(m)
+       "workload": "bench.py B=4096 coupled fp64 cold (k_solve, k_nodes_linearize); 2^20 lookups on the 13x13x9^5 grid (k_hji_lookup); config 5 = lateral N = 50 + walls (k_solve_lat)",
+       "kernel_source_sha16": kernel_source_sha16(), "kernels": {}}
+for group, sk, m in (("headline", "stats", "pg::k_solve<"), ("hji", "stats", "pg::k_hji_lookup"), ("headline", "stats", "pg::k_linearize"), ("headline", "stats", "pg::k_nodes"),
+                     ("dec", "stats_dec", "pg::k_solve_lat"), ("dec", "stats_dec", "pg::k_qp_dec")):
+    t = entry(group, sk, m)
     if t:
         out["kernels"][t[0]] = t[1]
-        if m == "pg::k_solve":
-            out.update({"kernel": t[0], **t[1]})
+        if m == "pg::k_solve<":
+            out.update({"kernel": t[0], **{k: v for k, v in t[1].items() if k != "mfma"}})
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
-for r in rows[:8]:
-    print(f"{short(r['Name'])[:60]:60s} calls {r['Calls']:>4s} avg {float(r['AverageNs'])/1e3:9.1f} us  {r['Percentage']:>6s} %")
-print(json.dumps({k: {c: round(v['mean_per_launch']) for c, v in cs.items()} for k, cs in summary.items() if 'k_solve' in k or 'lookup' in k}, indent=1))
+for sk, rows in stats.items():
+    print("==", sk)
+    for r in rows[:8]:
+        print(f"{short(r['Name'])[:60]:60s} calls {r['Calls']:>4s} avg {float(r['AverageNs'])/1e3:9.1f} us  {r['Percentage']:>6s} %")
+print(json.dumps({k: v.get("mfma") for k, v in out["kernels"].items()}, indent=1))
