@@ -583,10 +583,11 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
             {
                 const int* flt = h->d_progress + nbn;
                 const long nn = (long)B * h->dc.NN;
-                hipLaunchKernelGGL(k_nodes_angles, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_naux, h->d_nodes, flt);
-                const long nz = (long)B * h->dc.Ns * 2, nr = (long)B * (h->dc.N - h->dc.Ns) * 2;
+                (void)nn;
+                hipLaunchKernelGGL(k_nodes_angles, dim3(64), dim3(256), 0, h->stream, h->dc, B, h->d_naux, h->d_nodes, flt);               // (small grids, striding over the work:
+                const long nz = (long)B * h->dc.Ns * 2, nr = (long)B * (h->dc.N - h->dc.Ns) * 2;                                               //  an empty launch is cheap)
                 const int nbz = (int)((nz + 63) / 64), nbr = (int)((nr + 63) / 64);
-                hipLaunchKernelGGL(k_linearize_split, dim3((unsigned)(nbz + nbr)), dim3(64), 0, h->stream, h->dc, B, nbz, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp, flt);
+                hipLaunchKernelGGL(k_linearize_split, dim3(512), dim3(64), 0, h->stream, h->dc, B, nbz, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp, flt, nbz + nbr);
             }
             h->lin_done = true;
         } else {

@@ -319,13 +319,14 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes(DevCfg C, i
 // fifth of that chain's instructions).
 __global__ __launch_bounds__(256) void k_nodes_angles(DevCfg C, int B, const real* __restrict__ naux, real* __restrict__ nodes, const int* __restrict__ only_if = nullptr) {
     if (only_if && *only_if == 0) return;                         // (repair launch behind k_nodes_linearize: runs only when a waiting wavefront of that launch gave up)
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long)B * C.NN) return;
-    const real* ax = naux + (size_t)gid * 4;
-    if (ax[0] != ax[0]) return;                                   // measured node / warm instance: nothing deferred
-    real* nd = nodes + (size_t)gid * 10;
-    nd[6] = atan2(ax[0], ax[1]) - atan(ax[2]);
-    if (ax[3] == ax[3]) nd[4] = -atan(ax[3]);
+    // (grid-stride: the ordinary launch has one thread per node; the repair launch is a small grid -- an empty launch then costs ~2 us instead of 4.6)
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < (long)B * C.NN; gid += (long)gridDim.x * blockDim.x) {
+        const real* ax = naux + (size_t)gid * 4;
+        if (ax[0] != ax[0]) continue;                             // measured node / warm instance: nothing deferred
+        real* nd = nodes + (size_t)gid * 10;
+        nd[6] = atan2(ax[0], ax[1]) - atan(ax[2]);
+        if (ax[3] == ax[3]) nd[4] = -atan(ax[3]);
+    }
 }
 // Warm branch of compute_linearization_nodes! (coupled_lat_long.jl:82-102) for a batch in which EVERY instance has a previous solution (closed loop after the
 // first step): the 31 nodes of an instance are independent of each other there -- node i interpolates the previous solution at ts[i] and looks the reference up at
@@ -519,18 +520,21 @@ PG_DEV void linearize_pair(const DevCfg& C, int b, int t, int g, bool live, cons
 // the large-batch form: the Ns zero-order-hold intervals of every instance with three directions per lane (ND = 6), the N - Ns ramp intervals with four (ND = 8);
 // blocks [0, nb_zoh) take the first group -- a wavefront runs one of the two instruction streams, 8 instead of 10 dynamics "units" per short interval
 __global__ __launch_bounds__(64) void k_linearize_split(DevCfg C, int B, int nb_zoh, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb,
-                                                        real* __restrict__ qp, const int* __restrict__ only_if = nullptr) {
+                                                        real* __restrict__ qp, const int* __restrict__ only_if = nullptr, int nb_total = 0) {
     if (only_if && *only_if == 0) return;                         // (repair launch behind k_nodes_linearize, see there)
-    const bool zoh = (int)blockIdx.x < nb_zoh;
-    const int nint = zoh ? C.Ns : C.N - C.Ns;                      // intervals of this group per instance
-    long gid = (long)(zoh ? blockIdx.x : blockIdx.x - nb_zoh) * blockDim.x + threadIdx.x;
-    const long per = (long)nint * 2;
-    const bool live = gid < (long)B * per;
-    if (!live) gid = (long)B * per - 2 + (gid & 1);
-    const int b = (int)(gid / per); const int rem = (int)(gid - (long)b * per);
-    const int t = (zoh ? 0 : C.Ns) + (rem >> 1), g = rem & 1;
-    if (zoh) linearize_lanes<3, 6>(C, b, t, g, live, nodes, dt, hji_Mb, qp);
-    else linearize_lanes<4, 8>(C, b, t, g, live, nodes, dt, hji_Mb, qp);
+    // (block-stride over the nb_total blocks of work when launched as a small repair grid; the ordinary launch -- nb_total = 0 -- has one block per block of work)
+    for (int blk = (int)blockIdx.x; blk < (nb_total ? nb_total : (int)gridDim.x); blk += (int)gridDim.x) {
+        const bool zoh = blk < nb_zoh;
+        const int nint = zoh ? C.Ns : C.N - C.Ns;                      // intervals of this group per instance
+        long gid = (long)(zoh ? blk : blk - nb_zoh) * blockDim.x + threadIdx.x;
+        const long per = (long)nint * 2;
+        const bool live = gid < (long)B * per;
+        if (!live) gid = (long)B * per - 2 + (gid & 1);
+        const int b = (int)(gid / per); const int rem = (int)(gid - (long)b * per);
+        const int t = (zoh ? 0 : C.Ns) + (rem >> 1), g = rem & 1;
+        if (zoh) linearize_lanes<3, 6>(C, b, t, g, live, nodes, dt, hji_Mb, qp);
+        else linearize_lanes<4, 8>(C, b, t, g, live, nodes, dt, hji_Mb, qp);
+    }
 }
 template <int K>
 __global__ __launch_bounds__(64) void k_linearize(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb, real* __restrict__ qp) {

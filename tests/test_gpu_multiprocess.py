@@ -59,3 +59,34 @@ def test_bench_launches_its_own_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["solved"] == "512/512"
     assert d["gather_ok"] is True
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 512) < 1e-6 * 2 * 512          # value = all ranks' solves / max-over-ranks time
+
+
+def test_config4_workload_line_over_two_ranks():
+    """BASELINE configs[3] through the bench's own launcher in its test mode: fp32, 8192 instances per rank, two ranks (gloo: both on the GPU present).  The line names
+    that configuration, carries the whole-job rate over the max-over-ranks time and the per-rank times, and -- a scaling run being the timed loop, the gather check and
+    one JSON line -- none of the secondary objects rank 0 would otherwise build while the other ranks wait."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--batch", "8192",
+                        "--precision", "f32"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dtype"] == "f32" and d["ranks"] == 2 and d["collective"] == "gloo" and d["gather_ok"] is True
+    assert d["config"]["workload"].startswith("configs[3]: Batch=16384 coupled MPC, N=30, fp32, sharded 8192/GPU x2")
+    assert d["solved"] == "8192/8192"
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 8192) < 1e-6 * 2 * 8192
+    assert d["per_rank_ms_per_step"]["min"] <= d["per_rank_ms_per_step"]["max"] == pytest.approx(d["ms_per_step"])
+    for k in ("closed_loop_rollout", "hji_lookup", "decoupled_n50", "fp32", "cpu_baseline", "interior_point_only", "two_half_batches_on_two_streams"):
+        assert k not in d, k
+
+
+def test_rccl_gather_when_two_gpus_are_present():
+    """The product's collective: RCCL all_gather of the controls (backend nccl), one rank per GPU.  Runs wherever at least two GPUs are visible (the 1-GPU test box skips)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "nccl", "--steps", "3", "--warmup", "1", "--batch", "1024"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["collective"] == "rccl" and d["ranks"] == 2 and d["gather_ok"] is True and d["solved"] == "1024/1024"

@@ -77,11 +77,11 @@ def entry(group, stats_key, match):
     e = {"hbm_bytes_per_launch": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024, "fetch_size_kib": c["FETCH_SIZE"], "write_size_kib": c["WRITE_SIZE"],
          "avg_launch_ns_rocprof": float(dom["AverageNs"]), "source": f"profiles/{tag}/pmc_summary.json [{group}]"}
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
-        # busy cycles of the matrix pipe over the busy cycles of the kernel's shader engines; fp64 MFMA flops (512 per MOPS unit: MI355X_MICROARCH.md) against the dense fp64 peak
+        # busy cycles of the matrix pipe (summed over SIMDs) over 1024 SIMDs x the launch at 2.4 GHz; fp64 MFMA flops (512 per MOPS unit: MI355X_MICROARCH.md) against the dense fp64 peak
         secs = float(dom["AverageNs"]) * 1e-9
         mops64 = c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)
         e["mfma"] = {"busy_cycles_per_launch": c["SQ_VALU_MFMA_BUSY_CYCLES"], "sq_busy_cycles_per_launch": c["SQ_BUSY_CYCLES"],
-                     "busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(c["SQ_BUSY_CYCLES"], 1.0), "mfma_instructions_per_launch": c.get("SQ_INSTS_MFMA"),
+                     "busy_frac_of_simd_time": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * secs * 2.4e9), "mfma_instructions_per_launch": c.get("SQ_INSTS_MFMA"),
                      "mops_f64_per_launch": mops64, "tflops_f64_executed": mops64 * 512 / secs / 1e12, "peak_tflops_f64_matrix": 78.6,
                      "frac_of_peak": mops64 * 512 / secs / 1e12 / 78.6, "source": f"profiles/{tag}/pmc_summary.json [{group}]"}
     return dk, e
