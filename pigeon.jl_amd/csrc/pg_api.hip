@@ -42,6 +42,7 @@ struct pg_handle {
     hipEvent_t ev[4]; bool ev_ok = false; float phase_ms[3] = {0, 0, 0}; bool timing_valid = false;
     size_t solve_lds = 0; bool solve_ring = false;
     real* d_walls = nullptr;                                    // [cap][N][2] wall extension
+    char* d_lat_ws = nullptr; bool lat_mem = false;            // k_solve_lat's workspace for horizons beyond 32 intervals (PG_LAT_MEM=1: at every horizon)
     real* d_lat = nullptr;                                      // [cap][N][LATP] packed stage records of the lateral formulation (k_qp_dec -> k_solve_lat)
     // hipGraph of a whole host-to-host warm step (pg_step of a small batch is launch-bound: one copy in, four kernels, one copy out; captured once, replayed while
     // nothing that the launches depend on has changed -- `sig` is compared field by field before every replay)
@@ -157,7 +158,7 @@ int pg_default_config_decoupled(pg_config* c) {
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_in, h->d_out, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_order, h->d_naux, h->d_progress, h->d_lat};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_order, h->d_naux, h->d_progress, h->d_lat, h->d_lat_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->sg.x) (void)hipGraphExecDestroy(h->sg.x);
@@ -225,7 +226,13 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         const bool want = (e && e[0] == '1') || (!(e && e[0] == '0') && !(cfg->polish && N <= 20));
         h->solve_lat = cfg->formulation == PG_DECOUPLED && want && !h->solve_quad;
     }
-    if (h->solve_lat) { ALLOC(h->d_lat, cap * N * LATP, real); C.lat_pack = h->d_lat; }
+    if (h->solve_lat) {
+        ALLOC(h->d_lat, cap * N * LATP, real); C.lat_pack = h->d_lat;
+        { const char* k = getenv("PG_LAT_MU0_COST"); C.lat_mu0_cost = (real)(k ? atof(k) : 10.0); }
+        const char* e = getenv("PG_LAT_MEM");
+        h->lat_mem = N > 32 || (e && e[0] == '1');
+        if (h->lat_mem) { ALLOC(h->d_lat_ws, lat_ws_bytes(cap), char); C.lat_ws = h->d_lat_ws; }
+    }
 #undef ALLOC
     h->stage_bytes = h->in_bytes > h->out_bytes ? h->in_bytes : h->out_bytes;          // inputs: state 6 + control 3 + other 4 (real) + t0 + time_offset (double); outputs reuse the front of it
     if (hipHostMalloc((void**)&h->h_stage, h->stage_bytes, hipHostMallocDefault) != hipSuccess) { g_create_error = "hipHostMalloc failed for the staging buffer"; free_all(h); delete h; return PG_ERR_HIP; }
@@ -275,8 +282,8 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         static size_t lat_attr_max[64] = {0};
         if (h->solve_lat && h->lat_lds > 48 * 1024 && h->lat_lds > lat_attr_max[dev_slot]) {
             const int ld = (int)h->lat_lds; lat_attr_max[dev_slot] = h->lat_lds;
-            (void)hipFuncSetAttribute((const void*)k_solve_lat<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ld);
-            (void)hipFuncSetAttribute((const void*)k_solve_lat<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ld);
+            (void)hipFuncSetAttribute((const void*)k_solve_lat<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ld);
+            (void)hipFuncSetAttribute((const void*)k_solve_lat<1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ld);
         }
     }
     *out = h;
@@ -683,9 +690,9 @@ static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, u
     if (h->solve_lat) {      // lateral formulation: four instances per wavefront, always the whole batch in index order
         const dim3 grid((unsigned)((h->B + 3) / 4));
         const int slots = (h->dc.N + 15) / 16;
-#define PG_LAT_LAUNCH(NS, W) hipLaunchKernelGGL((k_solve_lat<NS, W>), grid, dim3(64), h->lat_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, lat_prof)
-        if (h->dc.walls) { if (slots == 1) PG_LAT_LAUNCH(1, true); else if (slots == 2) PG_LAT_LAUNCH(2, true); else if (slots == 3) PG_LAT_LAUNCH(3, true); else PG_LAT_LAUNCH(4, true); }
-        else { if (slots == 1) PG_LAT_LAUNCH(1, false); else if (slots == 2) PG_LAT_LAUNCH(2, false); else if (slots == 3) PG_LAT_LAUNCH(3, false); else PG_LAT_LAUNCH(4, false); }
+#define PG_LAT_LAUNCH(NS, W, M) hipLaunchKernelGGL((k_solve_lat<NS, W, M>), grid, dim3(64), h->lat_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, lat_prof)
+        if (h->dc.walls) { if (h->lat_mem) PG_LAT_LAUNCH(1, true, true); else if (slots == 1) PG_LAT_LAUNCH(1, true, false); else PG_LAT_LAUNCH(2, true, false); }
+        else { if (h->lat_mem) PG_LAT_LAUNCH(1, false, true); else if (slots == 1) PG_LAT_LAUNCH(1, false, false); else PG_LAT_LAUNCH(2, false, false); }
 #undef PG_LAT_LAUNCH
         LAUNCH_CHECK(h);
         return PG_OK;

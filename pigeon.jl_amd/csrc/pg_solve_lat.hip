@@ -37,6 +37,10 @@ constexpr int LAT_REC = 12;     // stage -> serial: (yy, yr, rr, ee, dd, Rhat) [
 constexpr int LAT_TAB = 12;     // serial tables: K[5], kff, Sinv, P cbar [5]
 constexpr int LAT_STRIDE = LAT_REC + LAT_TAB;
 __host__ __device__ inline size_t lat_lds_doubles(int N) { return (size_t)4 * N * LAT_STRIDE + 64 + 8; }
+// horizons beyond 32 intervals keep the per-row interior-point state in a global workspace (see "stage-parallel part"): bytes per 16-stage slot of one wavefront
+// (13 rows x 64 lanes x (t, lambda) + 7 x 64 x 2 second-order terms + 64 x 4 eliminated slacks + 64 x 16 B of working-set words, fp64), four slots per wavefront
+constexpr size_t LAT_WS_SLOT_BYTES = 23552;
+__host__ __device__ inline size_t lat_ws_bytes(int B) { return (size_t)((B + 3) / 4) * 4 * LAT_WS_SLOT_BYTES; }
 
 // broadcast of lane K of each 16-lane row (compiler builtin: hazards padded by hipcc; v_mov_b64_dpp row_newbcast)
 template <int K> PG_DEV real lat_bc(real v) {
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(128) void k_lat_pack(DevCfg C, int b0, int n, const
     for (int i = 49; i < LATP; i++) Lp[i] = real(0.0);
 }
 
-template <int NSLOT, bool WALLS>
+template <int NSLOT, bool WALLS, bool MEM>
 __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real* __restrict__ qp, const real* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof) {
     constexpr int NR = WALLS ? 13 : 10;
     // diagnostic cycle counters (pg_debug_solve_cycles): 0 barrier terms, 1 matrix pass, 2 vector pass, 3 roll-outs, 4 Newton point / step rules, 5 everything else
@@ -275,13 +279,106 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     };
 
     // ---------------- stage-parallel part ----------------
-    real T[NSLOT][NR], L[NSLOT][NR], CR[NSLOT][NR];        // slack, multiplier, second-order term (later: d-lambda) of this lane's rows
-    bool act[NSLOT];
+    // Home of the per-row state (slack t, multiplier lambda, second-order term / d-lambda) of this lane's rows:
+    //   MEM = false: registers, for the whole solve (NSLOT <= 2: 10 or 13 rows x 3 x NSLOT doubles per lane fit next to the serial passes);
+    //   MEM = true : a per-wavefront workspace in global memory (C.lat_ws), one slot at a time through registers, the slot loop ROLLED.  At N = 50 (four slots, the
+    //                last one two stages deep) the register file cannot hold 156 doubles per lane next to the passes: the compiler's own spilling cost 40 % of an iteration
+    //                (serialised scratch reloads at one wavefront per SIMD; 24 k instructions of unrolled slot code against a 64 KB instruction cache).  The explicit home
+    //                is read with 16-byte loads issued back to back at the top of a slot visit, (t, lambda) pairs interleaved, the lanes of a wavefront contiguous.
+    constexpr int NP = (NR + 1) / 2;
+    constexpr size_t WS_TL = (size_t)NR * 64 * 2 * sizeof(real), WS_CR = (size_t)NP * 64 * 2 * sizeof(real), WS_SN = (size_t)64 * 4 * sizeof(real), WS_META = (size_t)64 * 16;
+    constexpr size_t WS_SLOT = WS_TL + WS_CR + WS_SN + WS_META;
+    static_assert(WS_SLOT <= LAT_WS_SLOT_BYTES, "workspace slot");
+    const int nslot = MEM ? (N + 15) >> 4 : NSLOT;
+    constexpr int NREG = MEM ? 1 : NSLOT;
+    real T[NREG][NR], L[NREG][NR], CR[NREG][NR];
+    unsigned amask[NREG], mask_ipm[NREG], nmask[NREG]; real SN[NREG][3];
+    char* const wsw = MEM ? C.lat_ws + (size_t)blockIdx.x * 4 * LAT_WS_SLOT_BYTES : nullptr;
+    auto for_slots = [&](auto&& body) __attribute__((always_inline)) {
+        if constexpr (MEM) {
+#pragma unroll 1
+            for (int j = 0; j < nslot; j++) body(j);
+        } else {
 #pragma unroll
-    for (int j = 0; j < NSLOT; j++) act[j] = c + 16 * j < N;
+            for (int j = 0; j < NSLOT; j++) { body(j); __builtin_amdgcn_sched_barrier(0); }
+        }
+    };
+    auto get_tl = [&](int j, real* Tl, real* Ll) __attribute__((always_inline)) {
+        if constexpr (MEM) {
+            const real2* p = reinterpret_cast<const real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES) + lane;
+#pragma unroll
+            for (int r = 0; r < NR; r++) { const real2 v = p[64 * r]; Tl[r] = v.x; Ll[r] = v.y; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NR; r++) { Tl[r] = T[j][r]; Ll[r] = L[j][r]; }
+        }
+    };
+    auto put_tl = [&](int j, const real* Tl, const real* Ll) __attribute__((always_inline)) {
+        if constexpr (MEM) {
+            real2* p = reinterpret_cast<real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES) + lane;
+#pragma unroll
+            for (int r = 0; r < NR; r++) { real2 v; v.x = Tl[r]; v.y = Ll[r]; p[64 * r] = v; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NR; r++) { T[j][r] = Tl[r]; L[j][r] = Ll[r]; }
+        }
+    };
+    auto get_cr = [&](int j, real* Cl) __attribute__((always_inline)) {
+        if constexpr (MEM) {
+            const real2* p = reinterpret_cast<const real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL) + lane;
+#pragma unroll
+            for (int q = 0; q < NP; q++) { const real2 v = p[64 * q]; Cl[2 * q] = v.x; if (2 * q + 1 < NR) Cl[2 * q + 1] = v.y; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NR; r++) Cl[r] = CR[j][r];
+        }
+    };
+    auto put_cr = [&](int j, const real* Cl) __attribute__((always_inline)) {
+        if constexpr (MEM) {
+            real2* p = reinterpret_cast<real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL) + lane;
+#pragma unroll
+            for (int q = 0; q < NP; q++) { real2 v; v.x = Cl[2 * q]; v.y = 2 * q + 1 < NR ? Cl[2 * q + 1] : real(0.0); p[64 * q] = v; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NR; r++) CR[j][r] = Cl[r];
+        }
+    };
+    auto get_sn = [&](int j, real* s3) __attribute__((always_inline)) {
+        if constexpr (MEM) {
+            const real2* p = reinterpret_cast<const real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL + WS_CR) + 2 * lane;
+            const real2 a = p[0], b_ = p[1]; s3[0] = a.x; s3[1] = a.y; s3[2] = b_.x;
+        } else { s3[0] = SN[j][0]; s3[1] = SN[j][1]; s3[2] = SN[j][2]; }
+    };
+    auto put_sn = [&](int j, const real* s3) __attribute__((always_inline)) {
+        if constexpr (MEM) {
+            real2* p = reinterpret_cast<real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL + WS_CR) + 2 * lane;
+            real2 a, b_; a.x = s3[0]; a.y = s3[1]; b_.x = s3[2]; b_.y = real(0.0); p[0] = a; p[1] = b_;
+        } else { SN[j][0] = s3[0]; SN[j][1] = s3[1]; SN[j][2] = s3[2]; }
+    };
+    // working set of the polish, the interior point's set at the hand-over, the set the last polish solve proposes
+    struct Meta { unsigned am, mi, nm; };
+    auto get_meta = [&](int j) __attribute__((always_inline)) -> Meta {
+        Meta m;
+        if constexpr (MEM) { const uint4 v = *(reinterpret_cast<const uint4*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL + WS_CR + WS_SN) + lane); m.am = v.x; m.mi = v.y; m.nm = v.z; }
+        else { m.am = amask[j]; m.mi = mask_ipm[j]; m.nm = nmask[j]; }
+        return m;
+    };
+    auto get_meta_if = [&](int j, bool wanted) __attribute__((always_inline)) -> Meta {      // (the interior point never looks at the sets: no load while it runs)
+        Meta m; m.am = 0u; m.mi = 0u; m.nm = 0u;
+        if (wanted) m = get_meta(j);
+        return m;
+    };
+    auto put_meta = [&](int j, const Meta& m) __attribute__((always_inline)) {
+        if constexpr (MEM) { uint4 v; v.x = m.am; v.y = m.mi; v.z = m.nm; v.w = 0u; *(reinterpret_cast<uint4*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL + WS_CR + WS_SN) + lane) = v; }
+        else { amask[j] = m.am; mask_ipm[j] = m.mi; nmask[j] = m.nm; }
+    };
+    auto is_act = [&](int j) __attribute__((always_inline)) { return c + 16 * j < N; };
+    auto sx_of = [&](int j) __attribute__((always_inline)) { const int s = is_act(j) ? c + 16 * j : N - 1; return O.sol_x + (size_t)b * NN * 8 + 8 * (s + 1); };
+    auto sg_of = [&](int j) __attribute__((always_inline)) { const int s = is_act(j) ? c + 16 * j : N - 1; return O.sol_sigma + ((size_t)b * N + s) * 3; };
+
     struct StageC { real b[NR], h0[4], h1[4], dts; };
     auto load_consts = [&](int j, StageC& S) __attribute__((always_inline)) {
-        int s = act[j] ? c + 16 * j : N - 1;
+        int s = is_act(j) ? c + 16 * j : N - 1;
         asm volatile("" : "+v"(s));        // opaque per call: these loads are invariant across the interior-point loop, and hoisted out of it they would sit in ~45 registers per slot
         const real2* cp = reinterpret_cast<const real2*>(Lb + (size_t)s * LATP + 32);
 #pragma unroll
@@ -291,6 +388,35 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         S.b[0] = dd.x; S.b[1] = -dd.y; S.b[6] = real(0.0); S.b[7] = real(0.0); S.b[8] = rr.x; S.b[9] = -rr.y;
         if constexpr (WALLS) { const real* w = C.wall_edges + ((size_t)b * N + s) * 2; S.b[10] = w[0]; S.b[11] = -w[1]; S.b[12] = real(0.0); }
         S.dts = Lb[(size_t)s * LATP + 48];
+    };
+    int pmode = 0, pstat = 0, pchecks = 0; bool want_polish = false, skip_second = false, resume_ipm = false;
+    // what a slot visit reads before it computes: stage constants, (t, lambda), second-order term / d-lambda, working-set words, eliminated slacks
+    struct In { StageC S; real Tl[NR], Ll[NR], Cl[NR]; Meta mt; real s3[3]; };
+    constexpr int F_TL = 1, F_CR = 2, F_META = 4, F_SN = 8;
+    auto fetch = [&](int j, In& in, int what) __attribute__((always_inline)) {
+        load_consts(j, in.S);
+        if (what & F_TL) get_tl(j, in.Tl, in.Ll);
+        if (what & F_CR) get_cr(j, in.Cl);
+        if (what & F_SN) get_sn(j, in.s3);
+        in.mt = get_meta_if(j, (what & F_META) && pmode != 0);
+    };
+    // one pass over the slots.  MEM: software-pipelined by hand -- the loads of slot j + 1 are in flight while slot j computes (one wavefront per SIMD: nothing else
+    // hides the ~2 us of a workspace read); a visit only ever stores to its OWN slot, so the early loads cannot pass a store they depend on.
+    auto piped = [&](int what, auto&& compute) __attribute__((always_inline)) {
+        if constexpr (MEM) {
+            In cur; fetch(0, cur, what);
+#pragma unroll 1
+            for (int j = 0; j < nslot; j++) {
+                In nxt;
+                if (j + 1 < nslot) fetch(j + 1, nxt, what);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(j, cur);
+                cur = nxt;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NSLOT; j++) { In cur; fetch(j, cur, what); compute(j, cur); __builtin_amdgcn_sched_barrier(0); }
+        }
     };
     auto slacks = [&](const StageC& S, const real* x, real v, real s1, real s2, real sw, real* out) __attribute__((always_inline)) {
         out[0] = S.b[0] - x[4]; out[1] = x[4] + S.b[1];
@@ -312,64 +438,62 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // Active-set polish (the OSQP-style polish of k_solve, without its cold-start rules: here it only ever follows a converged interior point).  pmode = 0 while the
     // interior point of this instance runs, then the round of the polish; amask = the rows of a slot held as EQUALITIES through an augmented Lagrangian
     // (-y t + rho/2 t^2: the shape of a barrier term with W = rho and constant multiplier part y - rho b), every other row absent; y lives in L.
-    int pmode = 0, pstat = 0, pchecks = 0; bool want_polish = false, skip_second = false, resume_ipm = false;
     // working sets tried per polish: three at the hand-over tolerance (of the 3851 N = 50 + walls instances that verify, 2717 / 876 / 242 / 16 do so in round 1 / 2 / 3 / 4),
     // two in the second attempt behind the resumed interior point (the slowest wavefront sets the kernel's time, and these are its instances)
     const int LAT_POLISH_ROUNDS = 3;
-    unsigned amask[NSLOT], mask_ipm[NSLOT];
-#pragma unroll
-    for (int j = 0; j < NSLOT; j++) { amask[j] = 0u; mask_ipm[j] = 0u; }
     const real rho = C.polish_rho, ptol = C.polish_tol;
-    // barrier weights of slot j at the current iterate: it = 1/t, W = lambda/t, ell = (sigma mu - corr)/t + lambda - W b
-    auto weights = [&](int j, const StageC& S, real sgmu, bool with_corr, real* it_, real* W, real* ell) __attribute__((always_inline)) {
+    // barrier weights of a slot at the current iterate: it = 1/t, W = lambda/t, ell = (sigma mu - corr)/t + lambda - W b
+    auto weights = [&](unsigned am, const real* Tl, const real* Ll, const real* Cl, const StageC& S, real sgmu, bool with_corr, real* it_, real* W, real* ell) __attribute__((always_inline)) {
         if (pmode) {
 #pragma unroll
             for (int r = 0; r < NR; r++) {
-                const bool a = (amask[j] >> r) & 1u;
-                it_[r] = real(1.0); W[r] = a ? rho : real(0.0); ell[r] = a ? L[j][r] - rho * S.b[r] : real(0.0);
+                const bool a = (am >> r) & 1u;
+                it_[r] = real(1.0); W[r] = a ? rho : real(0.0); ell[r] = a ? Ll[r] - rho * S.b[r] : real(0.0);
             }
             return;
         }
 #pragma unroll
         for (int r = 0; r < NR; r++) {
-            it_[r] = lat_rcp(T[j][r]); W[r] = L[j][r] * it_[r];
-            ell[r] = (with_corr ? (sgmu - CR[j][r]) * it_[r] : real(0.0)) + L[j][r] - W[r] * S.b[r];
+            it_[r] = lat_rcp(Tl[r]); W[r] = Ll[r] * it_[r];
+            ell[r] = (with_corr ? (sgmu - Cl[r]) * it_[r] : real(0.0)) + Ll[r] - W[r] * S.b[r];
         }
     };
     // every stage-locally eliminated slack needs a pivot: a group without an active row gets its sigma >= 0 row, whose multiplier is then known (the linear cost of the slack)
-    auto polish_pivots = [&](int j, const StageC& S) __attribute__((always_inline)) {
-        if (!pmode) return;
-        if (!(amask[j] & 0x04Cu)) { amask[j] |= 1u << 6; L[j][6] = C.cp.W_beta * S.dts; }
-        if (!(amask[j] & 0x0B0u)) { amask[j] |= 1u << 7; L[j][7] = C.cp.W_r * S.dts; }
-        if constexpr (WALLS) { if (!(amask[j] & 0x1C00u)) { amask[j] |= 1u << 12; L[j][12] = C.wall_weight * S.dts; } }
+    auto polish_pivots = [&](unsigned& am, real* Ll, const StageC& S) __attribute__((always_inline)) -> bool {
+        bool touched = false;
+        if (!(am & 0x04Cu)) { am |= 1u << 6; Ll[6] = C.cp.W_beta * S.dts; touched = true; }
+        if (!(am & 0x0B0u)) { am |= 1u << 7; Ll[7] = C.cp.W_r * S.dts; touched = true; }
+        if constexpr (WALLS) { if (!(am & 0x1C00u)) { am |= 1u << 12; Ll[12] = C.wall_weight * S.dts; touched = true; } }
+        return touched;
     };
     // after a polish solve (tp = slacks at the new point): multiplier update of the held rows and the add / drop decisions of this slot.  Returns the next working set.
-    auto polish_rows = [&](int j, const real* tp, real ttol, bool& unsettled) __attribute__((always_inline)) -> unsigned {
+    auto polish_rows = [&](bool actj, unsigned am, real* Ll, const real* tp, real ttol, bool& unsettled) __attribute__((always_inline)) -> unsigned {
         unsigned add = 0u, drop = 0u;
 #pragma unroll
         for (int r = 0; r < NR; r++) {
-            const bool a = (amask[j] >> r) & 1u;
-            if (a) L[j][r] -= rho * tp[r];
-            if (act[j] && a && L[j][r] < real(0.0)) drop |= 1u << r;
-            if (act[j] && a && !(fabs(tp[r]) <= ttol)) unsettled = true;             // written so that a NaN never verifies
-            if (act[j] && !a && !(tp[r] >= -ptol)) add |= 1u << r;
+            const bool a = (am >> r) & 1u;
+            if (a) Ll[r] -= rho * tp[r];
+            if (actj && a && Ll[r] < real(0.0)) drop |= 1u << r;
+            if (actj && a && !(fabs(tp[r]) <= ttol)) unsettled = true;             // written so that a NaN never verifies
+            if (actj && !a && !(tp[r] >= -ptol)) add |= 1u << r;
         }
         // at most one NEW row per slack group and round, the more violated one (two rows that share a free slack pin a combination of the states hard)
         if ((add & 0x00Cu) == 0x00Cu) add &= ~(tp[2] <= tp[3] ? (1u << 3) : (1u << 2));
         if ((add & 0x030u) == 0x030u) add &= ~(tp[4] <= tp[5] ? (1u << 5) : (1u << 4));
         if constexpr (WALLS) { if ((add & 0xC00u) == 0xC00u) add &= ~(tp[10] <= tp[11] ? (1u << 11) : (1u << 10)); }
-        return (amask[j] & ~drop) | add;
+        return (am & ~drop) | add;
     };
-    auto assemble = [&](int j, real sgmu, bool matrices) __attribute__((always_inline)) {
-        StageC S; load_consts(j, S);
+    // barrier terms of slot j -> stage cost of the Riccati passes (rec[0..5] the matrices, rec[6..11] the vectors)
+    auto assemble = [&](int j, In& in, real sgmu, bool matrices) __attribute__((always_inline)) {
+        StageC& S = in.S; real* const Tl = in.Tl; real* const Ll = in.Ll; real* const Cl = in.Cl; Meta& mt = in.mt;
         real it_[NR], W[NR], ell[NR]; Elim E;
-        if (matrices) polish_pivots(j, S);
-        weights(j, S, sgmu, !matrices, it_, W, ell);
+        if (matrices && pmode) { if (polish_pivots(mt.am, Ll, S)) { put_meta(j, mt); put_tl(j, Tl, Ll); } }
+        weights(mt.am, Tl, Ll, Cl, S, sgmu, !matrices, it_, W, ell);
         eliminate(S, W, ell, E);
         real g0 = real(0.0), g1 = real(0.0);
 #pragma unroll
         for (int i = 0; i < 4; i++) { g0 += S.h0[i] * ell[2 + i]; g1 += S.h1[i] * ell[2 + i]; }
-        if (act[j]) {
+        if (is_act(j)) {
             real* rec = sRec + LAT_REC * (c + 16 * j);
             rec[6] = g0 - E.c10 * E.g1 * E.d1 - E.c20 * E.g2 * E.d2;
             rec[7] = g1 - E.c11 * E.g1 * E.d1 - E.c21 * E.g2 * E.d2;
@@ -393,7 +517,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     };
     // Newton point of slot j from the roll-out (x+ of node s+1, v+ of transition s) -> eliminated slacks and the slack of every row
     auto newton = [&](int j, const StageC& S, const Elim& E, real* xn, real& vn, real* sg3, real* tp) __attribute__((always_inline)) {
-        const real* rec = sRec + LAT_REC * (act[j] ? c + 16 * j : N - 1);
+        const real* rec = sRec + LAT_REC * (is_act(j) ? c + 16 * j : N - 1);
 #pragma unroll
         for (int m = 0; m < 5; m++) xn[m] = rec[m];
         vn = rec[5];
@@ -408,13 +532,13 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     forward_pass(false);
     wave_sync();
     stamp(3);
-    real rp0 = real(0.0);
+    real rp0 = real(0.0), j0 = real(0.0);
+    real ms_next = real(0.0);       // sum t lambda over this lane's rows at the iterate just stored (the complementarity gap of the next loop top)
     // the damped iterate (x_{s+1}, sigma) of a stage is kept in the output buffers (read-modify-write once per iteration), not in registers
-    real* SXs[NSLOT]; real* SGs[NSLOT];
-#pragma unroll
-    for (int j = 0; j < NSLOT; j++) {
-        const int s = act[j] ? c + 16 * j : N - 1;
-        SXs[j] = O.sol_x + (size_t)b * NN * 8 + 8 * (s + 1); SGs[j] = O.sol_sigma + ((size_t)b * N + s) * 3;
+    for_slots([&](int j) __attribute__((always_inline)) {
+        const bool actj = is_act(j);
+        const int s = actj ? c + 16 * j : N - 1;
+        real* const SXj = sx_of(j); real* const SGj = sg_of(j);
         StageC S; load_consts(j, S);
         const real* rec = sRec + LAT_REC * s;
         real xs[5], sl[NR];
@@ -426,21 +550,40 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         real sw = real(0.0);
         if constexpr (WALLS) sw = fmax(real(0.0), -fmin(sl[10], sl[11])) + sig0;
         slacks(S, xs, real(0.0), s1, s2, sw, sl);
-        if (act[j] && valid) {
-            SXs[j][0] = real(0.0); SXs[j][1] = C.ux_dummy; SXs[j][7] = real(0.0);      // the embedded layout pg_get_solution documents: (0, Ux slot, Uy, r, dpsi, e, delta, 0)
+        if (actj && valid) {
+            SXj[0] = real(0.0); SXj[1] = C.ux_dummy; SXj[7] = real(0.0);      // the embedded layout pg_get_solution documents: (0, Ux slot, Uy, r, dpsi, e, delta, 0)
 #pragma unroll
-            for (int m = 0; m < 5; m++) SXs[j][2 + m] = xs[m];
-            SGs[j][0] = s1; SGs[j][1] = s2; SGs[j][2] = sw;
+            for (int m = 0; m < 5; m++) SXj[2 + m] = xs[m];
+            SGj[0] = s1; SGj[1] = s2; SGj[2] = sw;
         }
+        // cost of the starting point (tracking terms on node s + 1, the linear penalties of the soft-row slacks): it sets the scale of the first barrier parameter below
+        if (actj) {
+            j0 += real(0.5) * S.dts * (real(2.0) * C.cp.Q_dpsi * xs[2] * xs[2] + real(2.0) * C.cp.Q_e * xs[3] * xs[3] + real(2.0) * C.cp.R_delta * xs[4] * xs[4])
+                  + S.dts * (C.cp.W_beta * s1 + C.cp.W_r * s2 + (WALLS ? C.wall_weight * sw : real(0.0)));
+        }
+        real Tl[NR], Ll[NR], Cl[NR];
 #pragma unroll
         for (int r = 0; r < NR; r++) {
-            const real tj = act[j] ? fmax(sl[r], tau) : real(1.0);
-            T[j][r] = tj; L[j][r] = act[j] ? C.ipm_mu0 / tj : real(1.0); CR[j][r] = real(0.0);      // (slots beyond the horizon: t = lambda = 1, never updated, never summed)
-            if (act[j]) rp0 = fmax(rp0, tj - sl[r]);
+            const real tj = actj ? fmax(sl[r], tau) : real(1.0);
+            Tl[r] = tj; Ll[r] = real(1.0); Cl[r] = real(0.0);      // (slots beyond the horizon: t = lambda = 1, never updated, never summed)
+            if (actj) rp0 = fmax(rp0, tj - sl[r]);
         }
-    }
+        put_tl(j, Tl, Ll); put_cr(j, Cl);
+        Meta m0; m0.am = 0u; m0.mi = 0u; m0.nm = 0u; put_meta(j, m0);
+    });
     rp0 = row_max(rp0);
     const real ntot = (real)(N * NR), intot = real(1.0) / ntot, tol = C.ipm_tol;
+    // First barrier parameter: ipm_mu0, raised to lat_mu0_cost (10) x (cost of the starting point per row).  The v = 0 roll-out of an open-loop unstable 8 s horizon can start
+    // kilometres off the path; from mu = 100 such an instance spends ~12 iterations with step lengths of a few per cent while mu climbs by itself to ~1e5, and it is these
+    // instances (one in twenty) that set the kernel's time.  With the scaled start the slowest of the N = 50 batch needs 16 iterations to the hand-over instead of 27
+    // and the mean drops from 9.8 to 9.0 (oracle/lat_ipm_numpy.py carries the same rule).
+    const real mu0i = fmax(C.ipm_mu0, C.lat_mu0_cost * row_sum(j0) * intot);
+    for_slots([&](int j) __attribute__((always_inline)) {
+        real Tl[NR], Ll[NR]; get_tl(j, Tl, Ll);
+#pragma unroll
+        for (int r = 0; r < NR; r++) { Ll[r] = is_act(j) ? mu0i * lat_rcp(Tl[r]) : real(1.0); ms_next += is_act(j) ? Tl[r] * Ll[r] : real(0.0); }
+        put_tl(j, Tl, Ll);
+    });
     // with the polish on, the interior point only has to get close enough for the active set to show (polish_ipm_tol); if the polish does not verify from there, the
     // interior point resumes from the centred point (t, mu / t) and runs down to ipm_tol before the polish gets its second and last chance
     real tol_cur = (C.polish && C.polish_ipm_tol > tol) ? C.polish_ipm_tol : tol;
@@ -449,33 +592,37 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     bool done = false;
     const int cap = C.ipm_max_iter;
 
-    // the verdict of a polish solve for this instance, from the per-slot results of polish_rows: verified (the point is primal and dual feasible: a KKT point of the
-    // full QP, stored as the answer), refine (same set, held rows not yet at t = 0: the next solve starts from the updated multipliers), or a new working set.
+    // the verdict of a polish solve for this instance, from the per-slot results of polish_rows (the proposed sets are in the slots' meta words, the eliminated slacks
+    // of the solve in their sn words): verified (the point is primal and dual feasible: a KKT point of the full QP, stored as the answer), refine (same set, held rows
+    // not yet at t = 0: the next solve starts from the updated multipliers), or a new working set.
     // Returns true when the working set changed (the corrector half of this iteration then carries nothing for this instance: its vector pass has the old gains).
-    auto polish_decide = [&](const unsigned* nm, bool unsettled_, const real (*sn)[3]) __attribute__((always_inline)) -> bool {
+    auto polish_decide = [&](bool unsettled_) __attribute__((always_inline)) -> bool {
         real chg = real(0.0);
-#pragma unroll
-        for (int j = 0; j < NSLOT; j++) chg = fmax(chg, (act[j] && nm[j] != amask[j]) ? real(1.0) : real(0.0));
+        for_slots([&](int j) __attribute__((always_inline)) { const Meta m = get_meta(j); chg = fmax(chg, (is_act(j) && m.nm != m.am) ? real(1.0) : real(0.0)); });
         const bool changed = row_max(chg) > real(0.0), conv = !(row_max(unsettled_ ? real(1.0) : real(0.0)) > real(0.0));
         pchecks++;
         if (!changed && conv) {
+            for_slots([&](int j) __attribute__((always_inline)) {
+                if (is_act(j) && valid) {
+                    const real* rec = sRec + LAT_REC * (c + 16 * j);
+                    real* const SXj = sx_of(j); real* const SGj = sg_of(j);
+                    real s3[3]; get_sn(j, s3);
 #pragma unroll
-            for (int j = 0; j < NSLOT; j++) if (act[j] && valid) {
-                const real* rec = sRec + LAT_REC * (c + 16 * j);
-#pragma unroll
-                for (int m = 0; m < 5; m++) SXs[j][2 + m] = rec[m];
-                SGs[j][0] = sn[j][0]; SGs[j][1] = sn[j][1]; SGs[j][2] = sn[j][2];
-            }
+                    for (int m = 0; m < 5; m++) SXj[2 + m] = rec[m];
+                    SGj[0] = s3[0]; SGj[1] = s3[1]; SGj[2] = s3[2];
+                }
+            });
             pstat = pmode; done = true;
             return false;
         }
         if (changed) {
+            for_slots([&](int j) __attribute__((always_inline)) {
+                Meta m = get_meta(j); m.am = m.nm; put_meta(j, m);
+                real Tl[NR], Ll[NR]; get_tl(j, Tl, Ll);
 #pragma unroll
-            for (int j = 0; j < NSLOT; j++) {
-                amask[j] = nm[j];
-#pragma unroll
-                for (int r = 0; r < NR; r++) L[j][r] = ((amask[j] >> r) & 1u) ? L[j][r] : real(0.0);
-            }
+                for (int r = 0; r < NR; r++) Ll[r] = ((m.am >> r) & 1u) ? Ll[r] : real(0.0);
+                put_tl(j, Tl, Ll);
+            });
             pmode++;
         }
         const int round_cap = tol_cur > tol ? LAT_POLISH_ROUNDS : LAT_POLISH_ROUNDS - 1;
@@ -493,19 +640,16 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
 
     while (true) {
         {   // complementarity gap and the stopping rules (per instance = per row of lanes)
-            real ms = real(0.0);
-#pragma unroll
-            for (int j = 0; j < NSLOT; j++)
-#pragma unroll
-                for (int r = 0; r < NR; r++) ms += act[j] ? T[j][r] * L[j][r] : real(0.0);
-            const real mu_new = row_sum(ms) * intot;
-            if (resume_ipm) {       // the polish at the hand-over tolerance did not verify: the interior point resumes from the centred point (t, mu / t) -- t is untouched
-                                    // by the polish -- and goes all the way down before the polish gets its second and last chance
+            const real mu_new = row_sum(ms_next) * intot;
+            if (resume_ipm) {       // the polish at the hand-over tolerance did not verify: the interior point resumes where it stopped (t is untouched by the polish,
+                                    // lambda was set aside) and goes all the way down before the polish gets its second and last chance
                 resume_ipm = false; tol_cur = tol; pmode = 0; status = PG_MAX_ITER;
+                for_slots([&](int j) __attribute__((always_inline)) {
+                    real Tl[NR], Ll[NR], Cl[NR]; get_tl(j, Tl, Ll); get_cr(j, Cl);
 #pragma unroll
-                for (int j = 0; j < NSLOT; j++)
-#pragma unroll
-                    for (int r = 0; r < NR; r++) L[j][r] = act[j] ? mu * lat_rcp(T[j][r]) : real(1.0);
+                    for (int r = 0; r < NR; r++) Ll[r] = is_act(j) ? Cl[r] : real(1.0);
+                    put_tl(j, Tl, Ll);
+                });
             } else if (!done && !pmode && !want_polish) {
                 mu = mu_new;
                 if (it >= cap && !(cap >= 20 && good >= 3 && it < cap + 20)) done = true;                    // iteration cap (a converging attempt gets twenty more)
@@ -514,22 +658,23 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             }
             if (want_polish) {      // the interior point has converged: the rows with lambda > t are handed to the polish as its first working set, with their multipliers
                 want_polish = false; pmode = 1; pchecks = 0; status = PG_SOLVED;
-#pragma unroll
-                for (int j = 0; j < NSLOT; j++) {
+                for_slots([&](int j) __attribute__((always_inline)) {
+                    real Tl[NR], Ll[NR]; get_tl(j, Tl, Ll);
                     unsigned mk = 0u;
 #pragma unroll
-                    for (int r = 0; r < NR; r++) if (act[j] && L[j][r] > T[j][r]) mk |= 1u << r;
-                    amask[j] = mk; mask_ipm[j] = mk;
+                    for (int r = 0; r < NR; r++) if (is_act(j) && Ll[r] > Tl[r]) mk |= 1u << r;
+                    put_cr(j, Ll);          // the interior point's multipliers wait in the (idle) second-order slot: a polish that does not verify hands them back
 #pragma unroll
-                    for (int r = 0; r < NR; r++) L[j][r] = ((mk >> r) & 1u) ? L[j][r] : real(0.0);
-                }
+                    for (int r = 0; r < NR; r++) Ll[r] = ((mk >> r) & 1u) ? Ll[r] : real(0.0);
+                    put_tl(j, Tl, Ll);
+                    Meta m; m.am = mk; m.mi = mk; m.nm = mk; put_meta(j, m);
+                });
             }
         }
         if (__all(done)) break;
         stamp(5);
         // ---- predictor: sigma = 0, no second-order term ----
-#pragma unroll
-        for (int j = 0; j < NSLOT; j++) { assemble(j, real(0.0), true); __builtin_amdgcn_sched_barrier(0); }
+        piped(F_TL | F_META, [&](int j, In& in) __attribute__((always_inline)) { assemble(j, in, real(0.0), true); });
         wave_sync();
         stamp(0);
         matrix_pass();
@@ -538,30 +683,29 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         forward_pass(true);
         wave_sync();
         stamp(3);
-        real rmax = real(0.0), S2 = real(0.0), SNp[NSLOT][3]; unsigned nmask[NSLOT]; bool unsettled = false;
-#pragma unroll
-        for (int j = 0; j < NSLOT; j++) {
-            StageC S; load_consts(j, S);
+        real rmax = real(0.0), S2 = real(0.0); bool unsettled = false;
+        piped(F_TL | F_META, [&](int j, In& in) __attribute__((always_inline)) {
+            StageC& S = in.S; real* const Tl = in.Tl; real* const Ll = in.Ll; real* const Cl = in.Cl; Meta& mt = in.mt;
             real it_[NR], W[NR], ell[NR], tp[NR], xn[5], vn, sg3[3]; Elim E;
-            weights(j, S, real(0.0), false, it_, W, ell);
+            weights(mt.am, Tl, Ll, Cl, S, real(0.0), false, it_, W, ell);
             eliminate(S, W, ell, E);
             newton(j, S, E, xn, vn, sg3, tp);
-            if (pmode) { SNp[j][0] = sg3[0]; SNp[j][1] = sg3[1]; SNp[j][2] = sg3[2]; nmask[j] = polish_rows(j, tp, real(0.01) * ptol, unsettled); }
+            if (pmode) { put_sn(j, sg3); mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, real(0.01) * ptol, unsettled); put_meta(j, mt); put_tl(j, Tl, Ll); }
             else {
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    const real dt_ = tp[r] - T[j][r], dl_ = -W[r] * tp[r];
-                    CR[j][r] = dt_ * dl_;
+                    const real dt_ = tp[r] - Tl[r], dl_ = -W[r] * tp[r];
+                    Cl[r] = dt_ * dl_;
                     // step to the boundary: -dt/t = 1 - tp/t and, for the affine direction, -dl/lambda = tp/t
                     const real rho_ = tp[r] * it_[r];
-                    rmax = fmax(rmax, act[j] ? fmax(real(1.0) - rho_, rho_) : real(0.0));
-                    S2 += act[j] ? CR[j][r] : real(0.0);
+                    rmax = fmax(rmax, is_act(j) ? fmax(real(1.0) - rho_, rho_) : real(0.0));
+                    S2 += is_act(j) ? Cl[r] : real(0.0);
                 }
+                put_cr(j, Cl);
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        });
         skip_second = false;
-        if (pmode && !done) skip_second = polish_decide(nmask, unsettled, SNp);
+        if (pmode && !done) skip_second = polish_decide(unsettled);
         rmax = row_max(rmax); S2 = row_sum(S2);
         const real aaff = rmax > real(1.0) ? frcp(rmax) : real(1.0);
         // rounding floor: once mu is within 1e4 x of the tolerance and the affine direction can no longer move, further iterations only add noise
@@ -572,8 +716,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         const real sgmu = sg * mu;
         stamp(4);
         // ---- corrector ----
-#pragma unroll
-        for (int j = 0; j < NSLOT; j++) { assemble(j, sgmu, false); __builtin_amdgcn_sched_barrier(0); }
+        piped(F_TL | F_CR | F_META, [&](int j, In& in) __attribute__((always_inline)) { assemble(j, in, sgmu, false); });
         wave_sync();
         stamp(0);
         vector_pass();
@@ -582,30 +725,30 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         forward_pass(true);
         wave_sync();
         stamp(3);
-        real T1 = real(0.0), T2 = real(0.0), SN[NSLOT][3];
+        real T1 = real(0.0), T2 = real(0.0);
         rmax = real(0.0); unsettled = false;
-#pragma unroll
-        for (int j = 0; j < NSLOT; j++) {
-            StageC S; load_consts(j, S);
-            real it_[NR], W[NR], ell[NR], tp[NR], xn[5], vn; Elim E;
-            weights(j, S, sgmu, true, it_, W, ell);
+        piped(F_TL | F_CR | F_META, [&](int j, In& in) __attribute__((always_inline)) {
+            StageC& S = in.S; real* const Tl = in.Tl; real* const Ll = in.Ll; real* const Cl = in.Cl; Meta& mt = in.mt;
+            real it_[NR], W[NR], ell[NR], tp[NR], xn[5], vn, sg3[3]; Elim E;
+            weights(mt.am, Tl, Ll, Cl, S, sgmu, true, it_, W, ell);
             eliminate(S, W, ell, E);
-            newton(j, S, E, xn, vn, SN[j], tp);
-            if (pmode) { if (!skip_second && !resume_ipm) nmask[j] = polish_rows(j, tp, ptol, unsettled); }
+            newton(j, S, E, xn, vn, sg3, tp);
+            put_sn(j, sg3);
+            if (pmode) { if (!skip_second && !resume_ipm) { mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, ptol, unsettled); put_meta(j, mt); put_tl(j, Tl, Ll); } }
             else {
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    const real dt_ = tp[r] - T[j][r], dl_ = (sgmu - CR[j][r]) * it_[r] - W[r] * tp[r];
-                    CR[j][r] = dl_;                            // (the second-order term has done its job: the slot now carries d-lambda to the update below)
-                    const real rj = fmax(-dt_ * it_[r], -dl_ * lat_rcp(L[j][r]));
-                    rmax = fmax(rmax, act[j] ? rj : real(0.0));
-                    T1 += act[j] ? T[j][r] * dl_ + L[j][r] * dt_ : real(0.0);
-                    T2 += act[j] ? dt_ * dl_ : real(0.0);
+                    const real dt_ = tp[r] - Tl[r], dl_ = (sgmu - Cl[r]) * it_[r] - W[r] * tp[r];
+                    Cl[r] = dl_;                            // (the second-order term has done its job: the slot now carries d-lambda to the update below)
+                    const real rj = fmax(-dt_ * it_[r], -dl_ * lat_rcp(Ll[r]));
+                    rmax = fmax(rmax, is_act(j) ? rj : real(0.0));
+                    T1 += is_act(j) ? Tl[r] * dl_ + Ll[r] * dt_ : real(0.0);
+                    T2 += is_act(j) ? dt_ * dl_ : real(0.0);
                 }
+                put_cr(j, Cl);
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (pmode && !done && !skip_second && !resume_ipm) (void)polish_decide(nmask, unsettled, SN);
+        });
+        if (pmode && !done && !skip_second && !resume_ipm) (void)polish_decide(unsettled);
         rmax = row_max(rmax); T1 = row_sum(T1); T2 = row_sum(T2);
         const real alpha = rmax > real(0.995) ? real(0.995) * frcp(rmax) : real(1.0);
         // rounding floor, second form: a step that would MULTIPLY mu near the tolerance is a Newton direction computed at a conditioning the arithmetic no longer
@@ -616,31 +759,34 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         }
         const bool ipm_on = !done && !pmode && !want_polish;
         const real a = ipm_on ? alpha : real(0.0);
-#pragma unroll
-        for (int j = 0; j < NSLOT; j++) {
-            StageC S; load_consts(j, S);
-            const real* rec = sRec + LAT_REC * (act[j] ? c + 16 * j : N - 1);
+        ms_next = real(0.0);
+        piped(F_TL | F_CR | F_SN, [&](int j, In& in) __attribute__((always_inline)) {
+            const bool actj = is_act(j);
+            StageC& S = in.S; real* const Tl = in.Tl; real* const Ll = in.Ll; real* const Cl = in.Cl; real* const s3 = in.s3;
+            const real* rec = sRec + LAT_REC * (actj ? c + 16 * j : N - 1);
             real xn[5], tp[NR];
 #pragma unroll
             for (int m = 0; m < 5; m++) xn[m] = rec[m];
-            slacks(S, xn, rec[5], SN[j][0], SN[j][1], SN[j][2], tp);
+            slacks(S, xn, rec[5], s3[0], s3[1], s3[2], tp);
 #pragma unroll
             for (int r = 0; r < NR; r++) {
-                T[j][r] += (act[j] && ipm_on) ? a * (tp[r] - T[j][r]) : real(0.0);       // (a select, not a * 0: an instance in its polish has no meaningful tp here)
-                L[j][r] += (act[j] && ipm_on) ? a * CR[j][r] : real(0.0);
+                Tl[r] += (actj && ipm_on) ? a * (tp[r] - Tl[r]) : real(0.0);       // (a select, not a * 0: an instance in its polish has no meaningful tp here)
+                Ll[r] += (actj && ipm_on) ? a * Cl[r] : real(0.0);
+                ms_next += actj ? Tl[r] * Ll[r] : real(0.0);
             }
-            if (act[j] && valid && ipm_on) {
+            if (ipm_on) put_tl(j, Tl, Ll);
+            if (actj && valid && ipm_on) {
+                real* const SXj = sx_of(j); real* const SGj = sg_of(j);
 #pragma unroll
-                for (int m = 0; m < 5; m++) { const real cur = SXs[j][2 + m]; SXs[j][2 + m] = cur + a * (xn[m] - cur); }
+                for (int m = 0; m < 5; m++) { const real cur = SXj[2 + m]; SXj[2 + m] = cur + a * (xn[m] - cur); }
 #pragma unroll
-                for (int m = 0; m < 3; m++) { const real cur = SGs[j][m]; SGs[j][m] = cur + a * (SN[j][m] - cur); }
+                for (int m = 0; m < 3; m++) { const real cur = SGj[m]; SGj[m] = cur + a * (s3[m] - cur); }
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        });
         if (ipm_on) {
             phi *= (real(1.0) - alpha);
             good = alpha > real(0.5) ? good + 1 : 0;
-            if (mu > real(1e8) * C.ipm_mu0) done = true;      // diverging: give up (PG_MAX_ITER)
+            if (mu > real(1e8) * mu0i) done = true;           // diverging: give up (PG_MAX_ITER)
             it++;
         }
         wave_sync();
@@ -653,22 +799,24 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     if (valid) {
         real* SX = O.sol_x + (size_t)b * NN * 8;
         if (c < 8) SX[c] = c == 1 ? C.ux_dummy : (c >= 2 && c < 6 ? Q[o.qcurr + c] : (c == 6 ? Q[o.ucurr] : real(0.0)));
+        for_slots([&](int j) __attribute__((always_inline)) {
+            if (is_act(j)) {
+                // local row -> bit of the 16-bit active mask (the numbering of the embedded stage: pigeon_mpc.h)
+                constexpr int bit[13] = {3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 0, 1, 2};
+                real Tl[NR], Ll[NR]; get_tl(j, Tl, Ll);
+                const Meta m = get_meta(j);
+                unsigned mask = 0;
 #pragma unroll
-        for (int j = 0; j < NSLOT; j++) {
-            if (!act[j]) continue;
-            // local row -> bit of the 16-bit active mask (the numbering of the embedded stage: pigeon_mpc.h)
-            constexpr int bit[13] = {3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 0, 1, 2};
-            unsigned mask = 0;
-#pragma unroll
-            for (int r = 0; r < NR; r++) {
-                const bool on = pstat > 0 ? ((amask[j] >> r) & 1u) : (pmode ? ((mask_ipm[j] >> r) & 1u) : (L[j][r] > T[j][r]));      // the polish's verified set / the interior point's at hand-over
-                if (on) mask |= 1u << bit[r];
+                for (int r = 0; r < NR; r++) {
+                    const bool on = pstat > 0 ? ((m.am >> r) & 1u) : (pmode ? ((m.mi >> r) & 1u) : (Ll[r] > Tl[r]));      // the polish's verified set / the interior point's at hand-over
+                    if (on) mask |= 1u << bit[r];
+                }
+                O.active[(size_t)b * N + c + 16 * j] = (uint16_t)mask;
             }
-            O.active[(size_t)b * N + c + 16 * j] = (uint16_t)mask;
-        }
+        });
         if (c == 0) {
             // get_next_control (decoupled_lat_long.jl:275-278): delta of node 2 from the QP, Fx of the seeded node 2
-            const real d = SXs[0][6] * C.un0, Fx = nodes[((size_t)b * NN + 1) * 10 + 7];
+            const real d = (O.sol_x + (size_t)b * NN * 8 + 8)[6] * C.un0, Fx = nodes[((size_t)b * NN + 1) * 10 + 7];
             real* U = O.u_out + (size_t)b * 3;
             U[0] = d; U[1] = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac; U[2] = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
             O.status[b] = (status == PG_SOLVED && C.polish && pstat < 0) ? PG_SOLVED_UNVERIFIED : status; O.iters[b] = it; O.mu[b] = mu; O.polish[b] = pstat;

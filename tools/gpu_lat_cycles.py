@@ -24,3 +24,14 @@ print(f"N = {10 + Nl}, walls = {int(walls)}: iterations mean {it.mean():.2f}, pe
 for i, n in enumerate(names):
     print(f"{n:36s} {w[:, i].mean():12.0f} cycles  {100 * w[:, i].mean() / tot.mean():5.1f} %   per wavefront-iteration {w[:, i].sum() / wave_it.sum():10.0f}")
 print(f"{'total':36s} {tot.mean():12.0f}                  per wavefront-iteration {tot.sum() / wave_it.sum():10.0f}")
+
+pol = mpc.polish_info()
+import collections
+print("iterations histogram (instances):", sorted(collections.Counter(it.tolist()).items()))
+print("polish info histogram:", sorted(collections.Counter(np.asarray(pol).tolist()).items()), " status:", sorted(collections.Counter(np.asarray(st).tolist()).items()))
+order = np.argsort(-tot)[:12]
+print("slowest wavefronts: cycles, iterations of their 4 instances, polish info")
+for wv in order:
+    print(f"  {tot[wv]:10.0f}  {it.reshape(-1, 4)[wv].tolist()}  {np.asarray(pol).reshape(-1, 4)[wv].tolist()}")
+q = np.percentile(tot, [50, 90, 99, 100])
+print("cycles per wavefront: median %.0f  p90 %.0f  p99 %.0f  max %.0f" % tuple(q))
