@@ -229,6 +229,8 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     if (h->solve_lat) {
         ALLOC(h->d_lat, cap * N * LATP, real); C.lat_pack = h->d_lat;
         { const char* k = getenv("PG_LAT_MU0_COST"); C.lat_mu0_cost = (real)(k ? atof(k) : 10.0); }
+        { const char* k = getenv("PG_LAT_POLISH2"); C.lat_polish2 = k ? atoi(k) : 1; }
+        { const char* k = getenv("PG_LAT_FAR_COST"); C.lat_far_cost = (real)(k ? atof(k) : 3e4); }
         const char* e = getenv("PG_LAT_MEM");
         h->lat_mem = N > 32 || (e && e[0] == '1');
         if (h->lat_mem) { ALLOC(h->d_lat_ws, lat_ws_bytes(cap), char); C.lat_ws = h->d_lat_ws; }

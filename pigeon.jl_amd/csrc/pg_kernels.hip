@@ -44,6 +44,8 @@ struct DevCfg {
     int walls;                    // build-defined extension: soft rows edge_R - sw <= e <= edge_L + sw, sw >= 0 at nodes 2..N+1 (decoupled formulation only)
     real wall_weight;           // linear penalty on sw (per second, like W_beta)
     real* wall_edges;           // [B][N][2] (edge_L, edge_R) at node k+1, written by k_nodes_dec, read by k_solve
+    int lat_polish2;            // k_solve_lat: the polish gets a second chance behind the resumed interior point
+    real lat_far_cost;          // k_solve_lat: starting cost per row beyond which the early hand-over to the polish is not tried
     real lat_mu0_cost;          // k_solve_lat: first barrier parameter = max(ipm_mu0, lat_mu0_cost x cost of the starting point per row)
     char* lat_ws;               // lateral formulation, horizons beyond 32 intervals: k_solve_lat's per-wavefront workspace (lat_ws_bytes(B); nullptr: not wanted)
     real* lat_pack;             // lateral formulation: [B][N][LATP] packed stage records for k_solve_lat, written by k_qp_dec next to the QP block (nullptr: not wanted)

@@ -25,6 +25,7 @@ if [ "$PART" = "2" ]; then
   pmc pmc_fetch_dec "FETCH_SIZE" "$DEC"
   pmc pmc_write_dec "WRITE_SIZE" "$DEC"
   pmc pmc_sq_dec "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT" "$DEC"
+  pmc pmc_sq2_dec "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_INSTS_FLAT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS" "$DEC"
   ROLL="bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-decoupled --no-f32 --no-warm --no-hji"            # + closed loop: k_nodes_warm, k_advance, warm k_solve
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_roll -- python3 $ROLL > $OUT/bench_stats_roll.log 2>&1
   C3="bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-decoupled --no-rollout --no-warm --precision f32"   # the fp32 library alone: its headline, the HJI lookups, config 3 (+ HJI row)
