@@ -641,12 +641,13 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         return changed;
     };
 
+    bool need_a1 = true;
     while (true) {
         {   // complementarity gap and the stopping rules (per instance = per row of lanes)
             const real mu_new = row_sum(ms_next) * intot;
             if (resume_ipm) {       // the polish at the hand-over tolerance did not verify: the interior point resumes where it stopped (t is untouched by the polish,
                                     // lambda was set aside) and goes all the way down before the polish gets its second and last chance
-                resume_ipm = false; tol_cur = tol; pmode = 0; status = PG_MAX_ITER;
+                resume_ipm = false; tol_cur = tol; pmode = 0; status = PG_MAX_ITER; need_a1 = true;
                 for_slots([&](int j) __attribute__((always_inline)) {
                     real Tl[NR], Ll[NR], Cl[NR]; get_tl(j, Tl, Ll); get_cr(j, Cl);
 #pragma unroll
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
                 else if (mu <= tol_cur && phi * fmax(rp0, real(1.0)) <= tol_cur) { status = PG_SOLVED; if (C.polish && (tol_cur > tol || C.lat_polish2)) want_polish = true; else done = true; }
             }
             if (want_polish) {      // the interior point has converged: the rows with lambda > t are handed to the polish as its first working set, with their multipliers
-                want_polish = false; pmode = 1; pchecks = 0; status = PG_SOLVED;
+                want_polish = false; pmode = 1; pchecks = 0; status = PG_SOLVED; need_a1 = true;
                 for_slots([&](int j) __attribute__((always_inline)) {
                     real Tl[NR], Ll[NR]; get_tl(j, Tl, Ll);
                     unsigned mk = 0u;
@@ -677,7 +678,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         if (__all(done)) break;
         stamp(5);
         // ---- predictor: sigma = 0, no second-order term ----
-        piped(F_TL | F_META, [&](int j, In& in) __attribute__((always_inline)) { assemble(j, in, real(0.0), true); });
+        // (its barrier terms were assembled by the update pass of the previous iteration, which had t and lambda in its registers anyway; only the first iteration and
+        // an instance whose mode has just changed -- hand-over to the polish, resumed interior point -- assemble here)
+        if (need_a1) piped(F_TL | F_META, [&](int j, In& in) __attribute__((always_inline)) { assemble(j, in, real(0.0), true); });
+        need_a1 = false;
         wave_sync();
         stamp(0);
         matrix_pass();
@@ -763,7 +767,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         const bool ipm_on = !done && !pmode && !want_polish;
         const real a = ipm_on ? alpha : real(0.0);
         ms_next = real(0.0);
-        piped(F_TL | F_CR | F_SN, [&](int j, In& in) __attribute__((always_inline)) {
+        piped(F_TL | F_CR | F_SN | F_META, [&](int j, In& in) __attribute__((always_inline)) {
             const bool actj = is_act(j);
             StageC& S = in.S; real* const Tl = in.Tl; real* const Ll = in.Ll; real* const Cl = in.Cl; real* const s3 = in.s3;
             const real* rec = sRec + LAT_REC * (actj ? c + 16 * j : N - 1);
@@ -785,6 +789,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
 #pragma unroll
                 for (int m = 0; m < 3; m++) { const real cur = SGj[m]; SGj[m] = cur + a * (s3[m] - cur); }
             }
+            assemble(j, in, real(0.0), true);       // the next predictor's barrier terms at the iterate just formed (its roll-out results in rec[0..5] have been read above)
         });
         if (ipm_on) {
             phi *= (real(1.0) - alpha);

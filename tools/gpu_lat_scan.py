@@ -19,5 +19,5 @@ for walls in (False, True):
     ms = np.min(np.array(ms), axis=0)
     print(f"knobs {dict((k, v) for k, v in os.environ.items() if k.startswith('PG_'))} walls {int(walls)}: solve {ms[2]:.3f} ms (step {ms.sum():.3f}), iterations mean {it.mean():.2f} p99 {np.percentile(it, 99):.0f} max {it.max()}, "
           f"per wavefront {it.reshape(-1, 4).max(1).mean():.2f}, verified {int((pol >= 1).sum())}, status {np.bincount(st, minlength=6).tolist()}", flush=True)
-    np.savez(os.path.join(ROOT, 'gpurun_out', f'lat_scan_walls{int(walls)}.npz'), it=it, pol=pol, st=st, mu=mu)
+    np.savez(os.path.join(ROOT, 'gpurun_out', f'lat_scan_walls{int(walls)}.npz'), it=it, pol=pol, st=st, mu=mu, **({'edges': mpc.wall_edges()} if walls else {}))
     mpc.close()
