@@ -1211,6 +1211,9 @@ PG_DEV void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef PG_SETTLE_PASSES
+#define PG_SETTLE_PASSES 4
+#endif
 template <bool PROF, bool RING, bool FUSE>
 __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, int B, real* qp, const real* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof,
                                                                           const tdouble* __restrict__ dt_grid, const real* __restrict__ hji_Mb) {
@@ -1410,7 +1413,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     real it_[NROW];                    // 1 / t_j, refreshed once per interior-point iteration
     // Polish state (see the loop below): pmode = 0 while the interior point runs, then the round number of the active-set polish;
     // amask = this stage's rows currently held active.
-    int pmode = 0, pstat = 0; unsigned amask = 0, mask_ipm = 0, amask_1ago = 0xFFFFFFFFu, amask_2ago = 0xFFFFFFFFu; bool polish_gave_up = false, cycle_broken = false;
+    int pmode = 0, pstat = 0; unsigned amask = 0, mask_ipm = 0, amask_1ago = 0xFFFFFFFFu, amask_2ago = 0xFFFFFFFFu; bool polish_gave_up = false, cycle_broken = false, settle_used = false; int settle_left = 0;
     const real rho = C.polish_rho, ptol = C.polish_tol, dtol = real(1000.0) * C.polish_tol;      // dtol: largest correction of the last refinement pass a verified point may have had
     auto assemble = [&](real sigmu, bool matrices) {
         real W[NROW], ell[NROW];
@@ -1725,7 +1728,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     bool warm_attempt = false, from_prev = false;          // warm_attempt: a polish without an interior point in front (attempts -2, -1); from_prev: attempt -2
     for (int attempt = warm ? -2 : (guess ? -1 : 0); attempt < 2; attempt++) {
     if (attempt == -1 && !guess) continue;
-    rp0 = real(0.0); phi = real(1.0); pmode = 0; pstat = 0; polish_gave_up = false; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu; cycle_broken = false; good_steps = 0;
+    rp0 = real(0.0); phi = real(1.0); pmode = 0; pstat = 0; polish_gave_up = false; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu; cycle_broken = false; settle_used = false; settle_left = 0; good_steps = 0;
     warm_attempt = attempt < 0; from_prev = attempt == -2;
     if (attempt < 0) {
         amask = (act && from_prev) ? (unsigned)O.active[(size_t)b * N + s] : 0u; mask_ipm = amask;
@@ -1847,6 +1850,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             last_tmax = wave_max(tmx);
             last_nchg = (int)wave_sum(real(__popc(add | drop)));
         }
+        // settling (see the cycle rule below): the working set stays as it is until its held rows are at t = 0, i.e. until the multiplier estimates have converged
+        if (settle_left > 0) { if (!conv) { settle_left--; return 1; } settle_left = 0; }
         if (!changed && conv) {
             if (act) {
 #pragma unroll
@@ -1888,6 +1893,14 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             if (wall_on && (tog & (1u << 2))) nx = (nx | (1u << 2)) & ~0x0003u;
             if (__any(nx != next)) { cycle_broken = true; next = nx; }
         }
+        // A -> B -> C -> A with the held rows still far from t = 0 (fp32 at rho = 1e3: |t| ~ 1e-3 against polish_tol 1e-4) is a cycle of DECISIONS TAKEN ON UNCONVERGED
+        // MULTIPLIERS -- one or two weakly active rows toggle on the sign of an estimate that is still moving.  Once per polish the set is kept for up to
+        // PG_SETTLE_PASSES refinement passes (vector pass + correction roll-out each) and the decisions are taken again from settled multipliers; the alternative is the
+        // interior point (7 iterations of two passes each, which for the ~7 such instances of a cold fp32 batch of 4096 was the duration of the whole launch).
+        if ((cycle || stalled) && !settle_used && !(last_tmax <= ttol)) {      // (stalled: the only violated rows are ones the set cannot take -- the same unsettled estimates)
+            settle_used = true; settle_left = PG_SETTLE_PASSES; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu;
+            return 1;
+        }
         amask_2ago = amask_1ago; amask_1ago = amask;
         if (cycle || stalled) return 3;
         amask = next;
@@ -1902,7 +1915,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         if (warm_attempt) { pstat = 0; status = PG_MAX_ITER; return true; }      // warm guess did not verify: on to the cold start
         pstat = -1;
         if (!(tol_cur > C.ipm_tol)) { polish_gave_up = true; return true; }
-        tol_cur = C.ipm_tol; pmode = 0; status = PG_MAX_ITER; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu; cycle_broken = false;
+        tol_cur = C.ipm_tol; pmode = 0; status = PG_MAX_ITER; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu; cycle_broken = false; settle_used = false; settle_left = 0;
 #pragma unroll
         for (int j = 0; j < NROW; j++) R.lam[j] = (act && j < nrows) ? mu * frcp(R.t[j]) : real(0.0);
         return false;
