@@ -1181,6 +1181,13 @@ PG_DEV real wave_sum(real v) {
     return v;
 }
 
+// inclusive prefix sum over the lanes of a wave
+PG_DEV real wave_prefix_sum(real v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const real o = __shfl_up(v, d); v += lane >= d ? o : real(0.0); }
+    return v;
+}
+
 // broadcast of lane `src` (compile-time constant) to the whole wave through SGPRs: no LDS, no barrier
 PG_DEV real rl(real v, int src) {
 #ifdef PG_F32
@@ -1725,6 +1732,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     // change together) and the add / drop iteration turns over dozens of rows per round -- the interior point needs its usual 8 iterations there
     const bool guess = C.polish && C.cold_guess > 0 && !(C.has_hji && M0 * sx0[6] + M1 * sx0[7] + Q[o.b] < real(0.0));
     int last_nchg = 0, good_steps = 0; real last_tmax = real(0.0); bool refine_only = false;
+    int dbg_stage = -1, dbg_bit = -1, dbg_nadd = 0, dbg_ndrop = 0;      // diagnostic build: first stage / row that joined the set in the last check, rows added / dropped
     bool warm_attempt = false, from_prev = false;          // warm_attempt: a polish without an interior point in front (attempts -2, -1); from_prev: attempt -2
     for (int attempt = warm ? -2 : (guess ? -1 : 0); attempt < 2; attempt++) {
     if (attempt == -1 && !guess) continue;
@@ -1842,6 +1850,13 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             if (wall_on && (addf & 0x0003u) == 0x0003u) addf &= ~(tp[0] <= tp[1] ? 2u : 1u);
             add = addf;
         }
+        if constexpr (PROF) {
+            const unsigned long long bl = __ballot(add != 0u);
+            dbg_stage = bl ? __ffsll((long long)bl) - 1 : -1;
+            const unsigned a0 = __shfl(add, dbg_stage < 0 ? 0 : dbg_stage);
+            dbg_bit = a0 ? __ffs((int)a0) - 1 : -1;
+            dbg_nadd = (int)wave_sum(real(__popc(add))); dbg_ndrop = (int)wave_sum(real(__popc(drop)));
+        }
         const bool stalled = changed && !__any((add | drop) != 0u);      // only rows that cannot be active are violated (then another row is too: not expected)
         {   // progress of the set iteration, for the round cap and the bail-out below
             real tmx = real(0.0);
@@ -1929,7 +1944,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
 #pragma unroll
             for (int j = 0; j < NROW; j++) if (act && ((amask >> j) & 1u)) { mx = fmax(mx, fabs(tp[j])); cnt += real(1.0); }
             mx = wave_max(mx); cnt = wave_sum(cnt);
-            if (lane == 0 && ptr_n < 128) { real* tr = reinterpret_cast<real*>(prof + (size_t)B * 6) + 4 * (128 + ptr_n); tr[0] = real(100 * (attempt + 2) + pmode); tr[1] = real(pc); tr[2] = cnt; tr[3] = mx; }
+            if (lane == 0 && ptr_n < 128) { real* tr = reinterpret_cast<real*>(prof + (size_t)B * 6) + 4 * (128 + ptr_n); tr[0] = real(100 * (attempt + 2) + pmode); tr[1] = real(pc + 100 * dbg_nadd + 10000 * dbg_ndrop); tr[2] = cnt + real(1000 * (dbg_stage + 1) + 100000 * (dbg_bit + 1)); tr[3] = mx; }
             ptr_n++;
         }
     };

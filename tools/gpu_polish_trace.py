@@ -33,4 +33,6 @@ for k in range(128):
     if tr[k].any(): print(f"  {k:3d}  mu {tr[k, 0]:.3e}  aaff {tr[k, 1]:.3f}  sigma {tr[k, 2]:.3e}  alpha {tr[k, 3]:.3f}")
 print("polish checks ((attempt + 2) * 100 + pass [attempt -2 = previous set, -1 = empty set, 0 / 1 = after the interior point], outcome [0 verified, 1 refine, 2 set changed, 3 cycle; +10 = after a refinement], rows in the set, max |t| over them):")
 for k in range(128, 256):
-    if tr[k].any(): print(f"  {int(tr[k, 0]):4d}  outcome {int(tr[k, 1]):2d}  rows {int(tr[k, 2]):3d}  max|t| {tr[k, 3]:.3e}")
+    if tr[k].any():
+        o = int(tr[k, 1]); r = int(tr[k, 2])
+        print(f"  {int(tr[k, 0]):4d}  outcome {o % 100:2d}  rows {r % 1000:3d}  max|t| {tr[k, 3]:.3e}   added {o // 100 % 100} dropped {o // 10000} rows; first added: stage {r // 1000 % 100 - 1} row bit {r // 100000 - 1}")
