@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec (
 FP64_VALU_PEAK_TF = 78.6                  # MI355X fp64 vector peak (256 CUs x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz); fp32: 157.3
 BYTES_PER_SOLVE_COLD_FP64 = 112           # state 6 + control 3 + t0 in, control 3 + status + iters out
 
-# Algorithmic FLOPs of k_solve per instance (FMA = 2; derivation term by term in DESIGN.md 6): stage-structured interior point with n = 8 states,
+# Algorithmic FLOPs of k_solve per instance (FMA = 2; derivation term by term in EXPERIMENTS.md 6): stage-structured interior point with n = 8 states,
 # m = 2 inputs, 16 rows per stage.  Per stage: matrix pass 2480 (P [A B c] 1080, B'PB + B'PA 250, S^-1 and K 80, Q + A'PA + F'K 1070),
 # one vector pass 180, one roll-out 160, one half-iteration of stage work (assemble + Newton point + step rule) 400.
 def solve_flops(N, ipm_iters, polish_rounds):
@@ -506,7 +506,7 @@ def main():
         peak_lin = FP64_VALU_PEAK_TF if args.precision == "f64" else 2 * FP64_VALU_PEAK_TF
         valu_lin = {"bound": "valu-" + args.precision, "kernel": "k_nodes_linearize" if pipelined else "k_linearize", "algorithmic_flops_per_launch": lin_fl, "achieved": lin_fl / (lin_ms * 1e-3) / 1e12, "peak": peak_lin,
                     "unit": "TFLOP/s", "frac": lin_fl / (lin_ms * 1e-3) / 1e12 / peak_lin, "avg_launch_ms": lin_ms,
-                    "source": "flop model of the forward-mode RK4 linearisation (DESIGN.md 6); time live (HIP events: " + ("the nodes + update_qp phase -- projection, the nodes recurrence and the linearisation running under it" if pipelined else "the update_qp phase") + ", no HJI row in the headline run)"}
+                    "source": "flop model of the forward-mode RK4 linearisation (EXPERIMENTS.md 6); time live (HIP events: " + ("the nodes + update_qp phase -- projection, the nodes recurrence and the linearisation running under it" if pipelined else "the update_qp phase") + ", no HJI row in the headline run)"}
         # secondary roofline of the dominant kernel: ALGORITHMIC flops (model above x the iteration counts of THIS run) against the fp64 / fp32 vector peak --
         # the resource class that binds (the step moves 112 B per solve through HBM, so its HBM fraction is ~1e-5 by construction)
         rounds = np.where(pol > 0, pol, np.where(pol < 0, 6, 0))
@@ -514,7 +514,7 @@ def main():
         peak_tf = FP64_VALU_PEAK_TF if args.precision == "f64" else 2 * FP64_VALU_PEAK_TF
         valu = {"bound": "valu-" + args.precision, "kernel": "k_solve", "algorithmic_flops_per_launch": fl, "flops_per_solve_mean": fl / B, "achieved": fl / (float(ph[2]) * 1e-3) / 1e12,
                 "peak": peak_tf, "unit": "TFLOP/s", "frac": fl / (float(ph[2]) * 1e-3) / 1e12 / peak_tf, "avg_launch_ms": float(ph[2]),
-                "source": "flop model of the stage-structured interior point (bench.py solve_flops, DESIGN.md 6) x live iteration / polish-round counts; time live (HIP events)"}
+                "source": "flop model of the stage-structured interior point (bench.py solve_flops, EXPERIMENTS.md 6) x live iteration / polish-round counts; time live (HIP events)"}
         line = {
             "metric": "MPC QP solves/sec (N=30 coupled, X1 model)", "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -210,7 +210,7 @@ int pg_set_stream(pg_handle* h, void* hip_stream);
 /* Fused step: pg_step / pg_step_dev / pg_simulate_dev can run update_QP! and solve! of the coupled formulation (N <= 32) in ONE kernel -- the wavefront that
  * solves an instance linearises it first (same device functions: results are bit-identical either way; the QP data are still written and pg_get_qp reads them).
  * mode 0 = never (default; PG_FUSE=0/1/2 at pg_create overrides), 1 = always, 2 = for batches of >= 1024 instances in which every instance is warm (closed loop).
- * Measured on MI355X: +7 % on the cold benchmark batch (skidpadoval), -5..-8 % on the other paths and in closed loop -- it pays only where a few
+ * Measured on MI355X: +7 % on the cold benchmark batch (skidpadoval), -5..-8 % on the other paths and in closed loop (EXPERIMENTS.md 4.1) -- it pays only where a few
  * slow instances dominate the solve kernel.  The four compute calls invoked one by one are never fused. */
 int pg_set_fusion(pg_handle* h, int32_t mode);
 /* Pipelined nodes + update_QP (build-defined; no counterpart in the reference): for batches of 2048..8192 instances with cold instances, coupled formulation,

@@ -127,8 +127,9 @@ def eliminated_slacks(D, E, x):
     return s1, s2, sw
 
 
-def solve(D, tol=1e-12, mu0=100.0, max_iter=40, sig0=1.0, tau=1e-4, floor=True, verbose=False, start="rollout", wls=1.0):
+def solve(D, tol=1e-12, mu0=100.0, max_iter=40, sig0=1.0, tau=1e-4, floor=True, verbose=False, start="rollout", wls=1.0, mu0_cost=10.0):
     """Returns dict(x, v, s1, s2, sw, t, lam, iters, status, mu).  status 1 solved, 2 iteration cap, 4 numerical.
+    mu0_cost: the first barrier parameter is max(mu0, mu0_cost x cost of the starting point per row) as in k_solve_lat (0: mu0 as given).
     start: "rollout" = v = 0 roll-out (what the kernel does); "ls" = one Newton solve with every row replaced by a quadratic penalty of weight wls (closed-loop roll-out,
     bounded on the open-loop unstable horizons), then a uniform shift that makes every slack >= 1."""
     N, NR = D["N"], D["NR"]
@@ -139,6 +140,9 @@ def solve(D, tol=1e-12, mu0=100.0, max_iter=40, sig0=1.0, tau=1e-4, floor=True, 
         s1 = np.maximum(0.0, -np.minimum(sl[:, 2], sl[:, 3])) + sig0; s2 = np.maximum(0.0, -np.minimum(sl[:, 4], sl[:, 5])) + sig0
         sw = np.maximum(0.0, -np.minimum(sl[:, 10], sl[:, 11])) + sig0 if D["walls"] else z
         sl = slacks(D, x, v, s1, s2, sw)
+        xn = x[1:]
+        j0 = 0.5 * float(np.sum(D["Qpsi"] * xn[:, 2] ** 2 + D["Qe"] * xn[:, 3] ** 2 + D["Qd"] * xn[:, 4] ** 2)) + float(np.sum(D["wb"] * s1 + D["wr"] * s2 + (D["ww"] * sw if D["walls"] else 0.0)))
+        mu0 = max(mu0, mu0_cost * j0 / (N * NR))
         t = np.maximum(sl, tau); lam = mu0 / t
         rp0 = float(np.max(t - sl))
     else:

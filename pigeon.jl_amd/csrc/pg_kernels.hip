@@ -380,7 +380,7 @@ template <bool STAGED> __global__ __launch_bounds__(256) void k_nodes_warm(DevCf
 // ------------------------------------------------------------------------------------------------------------------
 // update_QP! of the coupled formulation (coupled_lat_long.jl:315-368) in ONE kernel: `linearize` of every interval + c + u-normalisation (:335-353), the
 // stability envelope and the bounds (:354-367), q_curr/u_curr (:332-333) and the safety row (:345-346).
-// linearize = RK4 (nsub sub-steps) of VehicleModel{TrackingBicycleModel} on forward-mode numbers (third-party LinearDynamicsModels; restated in DESIGN.md 2).
+// linearize = RK4 (nsub sub-steps) of VehicleModel{TrackingBicycleModel} on forward-mode numbers (third-party LinearDynamicsModels; restated in EXPERIMENTS.md 2).
 // TWO lanes per (instance, interval), four tangent directions each (DK<4>): lane 0 carries d/d(Ux, Uy, r, dpsi), lane 1 d/d(u0[0], u0[1], uf[0], uf[1]).
 // The tracking model does not read ds or e (vehicle_dynamics.jl:159-183: neither appears on the right-hand side), so dPhi/d(ds) = e_0 and dPhi/d(e) = e_5
 // EXACTLY -- those two columns of A are written as constants instead of being integrated (round 1 propagated all ten tangents in five lanes of two, i.e.
@@ -2155,7 +2155,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
 
 #include "pg_solve_lat.hip"         // the lateral formulation's own solve kernel (5-state stage, sixteen lanes per instance)
 
-#ifdef PG_EXPERIMENTAL_SOLVE4      // four instances per wavefront: a measured negative result, kept out of the shipped libraries
+#ifdef PG_EXPERIMENTAL_SOLVE4      // four instances per wavefront: a measured negative result (EXPERIMENTS.md 4.1), kept out of the shipped libraries
 #include "experimental/pg_solve4.hip"
 #endif
 

@@ -124,7 +124,7 @@ def test_walls_extension_matches_oracle_qp_with_wall_rows(pkg, oracle_mod, skidp
         tight = {+(i + 1) for i in range(len(Axg)) if qpw["u"][i] - Axg[i] < 1e-6} | {-(i + 1) for i in range(len(Axg)) if Axg[i] - qpw["l"][i] < 1e-6}
         assert strong <= G <= tight, (b, sorted(strong - G, key=abs)[:5], sorted(G - tight, key=abs)[:5])
         n_active += sum(1 for k in range(Nh) if int(act[b][k]) & 1)
-    assert worst < 2e-5, worst          # (N = 50 with binding walls: a third of the instances stop at the rounding floor mu ~ 1e-10)
+    assert worst < 2e-5, worst          # (N = 50 with binding walls: a third of the instances stop at the rounding floor mu ~ 1e-10, see EXPERIMENTS.md 4.3)
     assert n_active > 5 * B                                                            # the wall really binds
     assert np.max(xf[:, 1:, 5]) > -0.04                                                # ... and without it the optimum crosses e = -0.05
     with pytest.raises(pkg.PigeonError):

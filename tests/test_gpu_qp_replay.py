@@ -1,5 +1,5 @@
 """pg_set_qp: QP data installed by hand are solved exactly like the ones update_QP! writes; and a recorded QP of the wide-random stress regime on which the
-absolute solve of the active-set polish is limited by the conditioning of its penalty (why the corrector is a refinement step)."""
+absolute solve of the active-set polish is limited by the conditioning of its penalty (EXPERIMENTS.md 4.1: why the corrector is a refinement step)."""
 import os
 import numpy as np
 import pytest

@@ -1,6 +1,6 @@
 """Writes tests/golden/onvehicle_cases.npz: the oracle's outputs (time grid, path coordinates, nodes, refreshed QP data, exact controls, active-set lists) for the cases
 of tests/onvehicle_cases.py -- the reference's own dry-run configuration (Pigeon.jl:34-58) and the construction knobs no other test turns.  The oracle is the CPU
-restatement (parity unpinned: DESIGN.md 5); the file pins ITS outputs against drift and gives the GPU tests fixed vectors.   python tools/make_onvehicle_golden.py"""
+restatement (parity unpinned: EXPERIMENTS.md 5); the file pins ITS outputs against drift and gives the GPU tests fixed vectors.   python tools/make_onvehicle_golden.py"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
