@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_pkg
 pkg = load_pkg()
 traj = pkg.load_path_fixture("skidpadoval")
-B = 4096
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 for walls in (False, True):
     mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, walls=walls)
     state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B)
@@ -18,6 +18,6 @@ for walls in (False, True):
     st, it, act, mu = mpc.solve_info(); pol = mpc.polish_info()
     ms = np.min(np.array(ms), axis=0)
     print(f"knobs {dict((k, v) for k, v in os.environ.items() if k.startswith('PG_'))} walls {int(walls)}: solve {ms[2]:.3f} ms (step {ms.sum():.3f}), iterations mean {it.mean():.2f} p99 {np.percentile(it, 99):.0f} max {it.max()}, "
-          f"per wavefront {it.reshape(-1, 4).max(1).mean():.2f}, verified {int((pol >= 1).sum())}, status {np.bincount(st, minlength=6).tolist()}", flush=True)
+          f"per wavefront {it[:B // 4 * 4].reshape(-1, 4).max(1).mean():.2f}, verified {int((pol >= 1).sum())}, status {np.bincount(st, minlength=6).tolist()}", flush=True)
     np.savez(os.path.join(ROOT, 'gpurun_out', f'lat_scan_walls{int(walls)}.npz'), it=it, pol=pol, st=st, mu=mu, **({'edges': mpc.wall_edges()} if walls else {}))
     mpc.close()

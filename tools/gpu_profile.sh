@@ -15,6 +15,8 @@ if [ "$PART" = "1" ]; then
   pmc pmc_sq "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT" "$HEAD"
   pmc pmc_mfma "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" "$HEAD"
   pmc pmc_sq2 "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_INSTS_FLAT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS" "$HEAD"
+  pmc pmc_wr "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_WRITE_sum TCC_WRITE_SECTORS_sum" "$HEAD"               # what k_solve's 45 MB of write-back are made of
+  pmc pmc_wb "TCC_NORMAL_WRITEBACK_sum TCC_ALL_TC_OP_WB_WRITEBACK_sum TCC_WRITEBACK_sum TCC_EA0_WR_UNCACHED_32B_sum" "$HEAD"
   pmc pmc_tcc "TCC_HIT_sum TCC_MISS_sum" "bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-decoupled --no-f32 --no-rollout --no-warm"
   pmc pmc_fetch_hji "FETCH_SIZE" "bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-decoupled --no-f32 --no-rollout --no-warm"
   pmc pmc_write_hji "WRITE_SIZE" "bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-decoupled --no-f32 --no-rollout --no-warm"

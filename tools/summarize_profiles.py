@@ -38,7 +38,7 @@ for d, out in (("stats", "kernel_stats.csv"), ("stats_dec", "kernel_stats_dec.cs
         stats[d] = list(csv.DictReader(open(ks[0])))
 assert "stats" in stats, "PART=1 of tools/gpu_profile.sh has not run"
 
-groups = {"headline": ["pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_mfma", "pmc_tcc"], "hji": ["pmc_fetch_hji", "pmc_write_hji"],
+groups = {"headline": ["pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_mfma", "pmc_tcc", "pmc_wr", "pmc_wb"], "hji": ["pmc_fetch_hji", "pmc_write_hji"],
           "dec": ["pmc_fetch_dec", "pmc_write_dec", "pmc_sq_dec", "pmc_sq2_dec"], "f32": ["pmc_fetch_f32", "pmc_write_f32", "pmc_sq_f32", "pmc_mfma_f32"]}
 summary = {}
 for g, dirs in groups.items():
