@@ -421,7 +421,7 @@ def main():
                  "setup_s": setup_s, "device_table_bytes": int(table_bytes)}
             mpc.clear_hji_cache()
             return r
-        hji = lookup_rate(*pkg.synthetic.hji_grid_large(), "13x13x9x9x9x9x9 float32 (V, gradV), 10 M nodes; device layout: one contiguous 4 KiB cell record per lookup (41 GB table, capacity traded for line efficiency)")
+        hji = lookup_rate(*pkg.synthetic.hji_grid_large(), "13x13x9x9x9x9x9 float32 (V, gradV), 10 M nodes; device layout: one contiguous 4 KiB cell record per lookup (19 GB table: 4.7 M cells, capacity traded for line efficiency)")
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]["pg::k_hji_lookup<7>"]
             hji["traffic"] = tr["hbm_bytes_per_launch"]; hji["traffic_source"] = tr["source"]

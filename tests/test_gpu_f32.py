@@ -123,7 +123,7 @@ def test_f32_decoupled_n50(pkg, skidpad):
 
 
 def test_config3_full_size_grid_and_batch(pkg, oracle_mod, skidpad):
-    """BASELINE configs[2] as stated: B = 4096, fp32, HJI safety row on the 13x13x9x9x9x9x9 grid (10 M nodes, 41 GB of cell records on the device),
+    """BASELINE configs[2] as stated: B = 4096, fp32, HJI safety row on the 13x13x9x9x9x9x9 grid (10 M nodes, 19 GB of cell records on the device),
     default HJI_eps = 0.05.  Every instance solves; the rows that are active (V <= eps) and a sample of the others are compared with the oracle."""
     n = 4096
     knots, V, g = pkg.synthetic.hji_grid_large()
