@@ -33,6 +33,12 @@
 #endif
 #define LAT_DPP(acc, bsrc, x, lane) LAT_FMAC " %" #acc ", %" #bsrc ", %" #x " row_newbcast:" #lane " row_mask:0xf bank_mask:0xf\n\t"
 
+#ifndef LAT_PREFETCH_V
+#define LAT_PREFETCH_V 3        // stages of matrix columns in flight in the vector pass
+#endif
+#ifndef LAT_PREFETCH_F
+#define LAT_PREFETCH_F 3        // stages of matrix rows in flight in the roll-out
+#endif
 constexpr int LAT_REC = 12;     // stage -> serial: (yy, yr, rr, ee, dd, Rhat) [overwritten by the roll-out: x+_{k+1}[0..4], v+_k], qhat[5], rhat
 constexpr int LAT_TAB = 12;     // serial tables: K[5], kff, Sinv, P cbar [5]
 constexpr int LAT_STRIDE = LAT_REC + LAT_TAB;
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // ---------------- Riccati vector pass (corrector): p_k = qhat + Abar' y + K f,  y = P cbar + p,  f = rhat + Bbar' y,  kff = -Sinv f ----------------
     // A stage is ~25 instructions here: the matrix columns are requested THREE stages ahead (L2 latency ~ several stages of this pass), the LDS operands one.
     auto vector_pass = [&]() __attribute__((always_inline)) {
-        constexpr int D = 3;
+        constexpr int D = LAT_PREFETCH_V;
         real buf[D][4];
         const int mcoff = c < 5 ? (int)(sTab - sZero) + 7 + c : 0, mcmul = c < 5 ? LAT_TAB : 0;       // P cbar [c]
         const int koff = c < 5 ? (int)(sTab - sZero) + c : 0;                                        // K[c]
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     const real wA = c < 4 ? real(1.0) : real(0.0), wD = c == 4 ? real(1.0) : real(0.0);
     const real x0c = c < 4 ? Q[o.qcurr + 2 + c] : (c == 4 ? Q[o.ucurr] : real(0.0));
     auto forward_pass = [&](bool use_gain) __attribute__((always_inline)) {
-        constexpr int D = 3;
+        constexpr int D = LAT_PREFETCH_F;
         const bool isK = c == 5 && use_gain;          // (a select, not a multiplication by 0: the gain table holds nothing before the first matrix pass)
         real xr = x0c;
         const real2* const rowp = reinterpret_cast<const real2*>(Lb + 8 * ri);
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // ---------------- stage-parallel part ----------------
     // Home of the per-row state (slack t, multiplier lambda, second-order term / d-lambda) of this lane's rows:
     //   MEM = false: registers, for the whole solve (NSLOT <= 2: 10 or 13 rows x 3 x NSLOT doubles per lane fit next to the serial passes);
-    //   MEM = true : a per-wavefront workspace in global memory (C.lat_ws), one slot at a time through registers, the slot loop ROLLED.  At N = 50 (four slots, the
+    //   MEM = true : a per-wavefront workspace in global memory (C.lat_ws), one slot at a time through registers, the slot loop ROLLED (no prefetch of the next slot: see `piped`).  At N = 50 (four slots, the
     //                last one two stages deep) the register file cannot hold 156 doubles per lane next to the passes: the compiler's own spilling cost 40 % of an iteration
     //                (serialised scratch reloads at one wavefront per SIMD; 24 k instructions of unrolled slot code against a 64 KB instruction cache).  The explicit home
     //                is read with 16-byte loads issued back to back at the top of a slot visit, (t, lambda) pairs interleaved, the lanes of a wavefront contiguous.
@@ -400,19 +406,13 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         if (what & F_SN) get_sn(j, in.s3);
         in.mt = get_meta_if(j, (what & F_META) && pmode != 0);
     };
-    // one pass over the slots.  MEM: software-pipelined by hand -- the loads of slot j + 1 are in flight while slot j computes (one wavefront per SIMD: nothing else
-    // hides the ~2 us of a workspace read); a visit only ever stores to its OWN slot, so the early loads cannot pass a store they depend on.
+    // one pass over the slots (MEM: rolled; the loads of a visit are issued back to back at its top.  Requesting slot j + 1 while slot j computes was measured:
+    // barrier terms 48 k -> 40 k cycles per iteration, Newton point unchanged, and the 62-double copy of the prefetched operands per visit ate the gain:
+    // 2.46 / 3.42 ms with it, 2.36 / 3.45 ms without)
     auto piped = [&](int what, auto&& compute) __attribute__((always_inline)) {
         if constexpr (MEM) {
-            In cur; fetch(0, cur, what);
 #pragma unroll 1
-            for (int j = 0; j < nslot; j++) {
-                In nxt;
-                if (j + 1 < nslot) fetch(j + 1, nxt, what);
-                __builtin_amdgcn_sched_barrier(0);
-                compute(j, cur);
-                cur = nxt;
-            }
+            for (int j = 0; j < nslot; j++) { In cur; fetch(j, cur, what); compute(j, cur); }
         } else {
 #pragma unroll
             for (int j = 0; j < NSLOT; j++) { In cur; fetch(j, cur, what); compute(j, cur); __builtin_amdgcn_sched_barrier(0); }
@@ -699,15 +699,17 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             newton(j, S, E, xn, vn, sg3, tp);
             if (pmode) { put_sn(j, sg3); mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, real(0.01) * ptol, unsettled); put_meta(j, mt); put_tl(j, Tl, Ll); }
             else {
+                real rm = real(0.0), s2 = real(0.0);      // (one select per visit, not per row: a wavefront at one wave per SIMD pays for every instruction it issues)
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
                     const real dt_ = tp[r] - Tl[r], dl_ = -W[r] * tp[r];
                     Cl[r] = dt_ * dl_;
                     // step to the boundary: -dt/t = 1 - tp/t and, for the affine direction, -dl/lambda = tp/t
                     const real rho_ = tp[r] * it_[r];
-                    rmax = fmax(rmax, is_act(j) ? fmax(real(1.0) - rho_, rho_) : real(0.0));
-                    S2 += is_act(j) ? Cl[r] : real(0.0);
+                    rm = fmax(rm, fmax(real(1.0) - rho_, rho_));
+                    s2 += Cl[r];
                 }
+                rmax = fmax(rmax, is_act(j) ? rm : real(0.0)); S2 += is_act(j) ? s2 : real(0.0);
                 put_cr(j, Cl);
             }
         });
@@ -743,15 +745,16 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             put_sn(j, sg3);
             if (pmode) { if (!skip_second && !resume_ipm) { mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, ptol, unsettled); put_meta(j, mt); put_tl(j, Tl, Ll); } }
             else {
+                real rm = real(0.0), t1 = real(0.0), t2 = real(0.0);
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
                     const real dt_ = tp[r] - Tl[r], dl_ = (sgmu - Cl[r]) * it_[r] - W[r] * tp[r];
                     Cl[r] = dl_;                            // (the second-order term has done its job: the slot now carries d-lambda to the update below)
-                    const real rj = fmax(-dt_ * it_[r], -dl_ * lat_rcp(Ll[r]));
-                    rmax = fmax(rmax, is_act(j) ? rj : real(0.0));
-                    T1 += is_act(j) ? Tl[r] * dl_ + Ll[r] * dt_ : real(0.0);
-                    T2 += is_act(j) ? dt_ * dl_ : real(0.0);
+                    rm = fmax(rm, fmax(-dt_ * it_[r], -dl_ * lat_rcp(Ll[r])));
+                    t1 += Tl[r] * dl_ + Ll[r] * dt_;
+                    t2 += dt_ * dl_;
                 }
+                rmax = fmax(rmax, is_act(j) ? rm : real(0.0)); T1 += is_act(j) ? t1 : real(0.0); T2 += is_act(j) ? t2 : real(0.0);
                 put_cr(j, Cl);
             }
         });
@@ -775,12 +778,14 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
 #pragma unroll
             for (int m = 0; m < 5; m++) xn[m] = rec[m];
             slacks(S, xn, rec[5], s3[0], s3[1], s3[2], tp);
+            real ms = real(0.0);
 #pragma unroll
             for (int r = 0; r < NR; r++) {
                 Tl[r] += (actj && ipm_on) ? a * (tp[r] - Tl[r]) : real(0.0);       // (a select, not a * 0: an instance in its polish has no meaningful tp here)
                 Ll[r] += (actj && ipm_on) ? a * Cl[r] : real(0.0);
-                ms_next += actj ? Tl[r] * Ll[r] : real(0.0);
+                ms += Tl[r] * Ll[r];
             }
+            ms_next += actj ? ms : real(0.0);
             if (ipm_on) put_tl(j, Tl, Ll);
             if (actj && valid && ipm_on) {
                 real* const SXj = sx_of(j); real* const SGj = sg_of(j);
