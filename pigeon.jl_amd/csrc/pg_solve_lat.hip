@@ -515,6 +515,31 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             }
         }
     };
+    // The vector part of a stage's barrier terms (what the vector pass reads: rec[6], [7], [9], [10], [11]) is LINEAR in ell, and the corrector's
+    // ell = (sigma mu - corr) / t + lambda - W b is affine in sigma mu, which is only known after the reduction over the predictor's Newton point.  The pass that forms
+    // that point therefore leaves BOTH parts in the stage record -- the constant one in rec[6..11], the coefficient of sigma mu in rec[0..4] (the roll-out result it has
+    // just read) -- and a five-multiply-add touch of the record replaces a whole second assembly pass over the row state (round 3: 2.37 -> ... ms at N = 50).
+    auto vec_terms = [&](const StageC& S, const Elim& E, const real* ell, bool with_const, real* out) __attribute__((always_inline)) {
+        real g0 = real(0.0), g1 = real(0.0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { g0 += S.h0[i] * ell[2 + i]; g1 += S.h1[i] * ell[2 + i]; }
+        const real G1 = (with_const ? C.cp.W_beta * S.dts : real(0.0)) - ell[2] - ell[3] - ell[6], G2 = (with_const ? C.cp.W_r * S.dts : real(0.0)) - ell[4] - ell[5] - ell[7];
+        out[0] = g0 - E.c10 * G1 * E.d1 - E.c20 * G2 * E.d2;
+        out[1] = g1 - E.c11 * G1 * E.d1 - E.c21 * G2 * E.d2;
+        if constexpr (WALLS) out[2] = (ell[10] - ell[11]) - E.ch * ((with_const ? C.wall_weight * S.dts : real(0.0)) - ell[10] - ell[11] - ell[12]) * E.dh; else out[2] = real(0.0);
+        out[3] = ell[0] - ell[1];
+        out[4] = ell[8] - ell[9];
+    };
+    auto put_vec = [&](int j, const real* qa, const real* qb) __attribute__((always_inline)) {
+        if (is_act(j)) {
+            real* rec = sRec + LAT_REC * (c + 16 * j);
+            rec[6] = qa[0]; rec[7] = qa[1]; rec[8] = real(0.0); rec[9] = qa[2]; rec[10] = qa[3]; rec[11] = qa[4];
+            if (!pmode) {       // (a polish has no sigma mu part, and its verdict may still want the point in rec[0..4]: polish_decide stores it as the answer)
+#pragma unroll
+                for (int i = 0; i < 5; i++) rec[i] = qb[i];
+            }
+        }
+    };
     // Newton point of slot j from the roll-out (x+ of node s+1, v+ of transition s) -> eliminated slacks and the slack of every row
     auto newton = [&](int j, const StageC& S, const Elim& E, real* xn, real& vn, real* sg3, real* tp) __attribute__((always_inline)) {
         const real* rec = sRec + LAT_REC * (is_act(j) ? c + 16 * j : N - 1);
@@ -697,7 +722,15 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             weights(mt.am, Tl, Ll, Cl, S, real(0.0), false, it_, W, ell);
             eliminate(S, W, ell, E);
             newton(j, S, E, xn, vn, sg3, tp);
-            if (pmode) { put_sn(j, sg3); mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, real(0.01) * ptol, unsettled); put_meta(j, mt); put_tl(j, Tl, Ll); }
+            real qa[5], qb[5];
+            if (pmode) {
+                put_sn(j, sg3); mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, real(0.01) * ptol, unsettled); put_meta(j, mt); put_tl(j, Tl, Ll);
+                // the refinement solve behind this one: same set, the multipliers just updated (no sigma mu in a polish)
+                weights(mt.am, Tl, Ll, Cl, S, real(0.0), false, it_, W, ell);
+                vec_terms(S, E, ell, true, qa);
+#pragma unroll
+                for (int i = 0; i < 5; i++) qb[i] = real(0.0);
+            }
             else {
                 real rm = real(0.0), s2 = real(0.0);      // (one select per visit, not per row: a wavefront at one wave per SIMD pays for every instruction it issues)
 #pragma unroll
@@ -711,7 +744,13 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
                 }
                 rmax = fmax(rmax, is_act(j) ? rm : real(0.0)); S2 += is_act(j) ? s2 : real(0.0);
                 put_cr(j, Cl);
+                // the corrector's vector terms: ell = (ell at sigma mu = 0) + sigma mu / t
+#pragma unroll
+                for (int r = 0; r < NR; r++) ell[r] = ell[r] - Cl[r] * it_[r];
+                vec_terms(S, E, ell, true, qa);
+                vec_terms(S, E, it_, false, qb);
             }
+            put_vec(j, qa, qb);
         });
         skip_second = false;
         if (pmode && !done) skip_second = polish_decide(unsettled);
@@ -725,7 +764,14 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         const real sgmu = sg * mu;
         stamp(4);
         // ---- corrector ----
-        piped(F_TL | F_CR | F_META, [&](int j, In& in) __attribute__((always_inline)) { assemble(j, in, sgmu, false); });
+        for_slots([&](int j) __attribute__((always_inline)) {
+            if (is_act(j)) {
+                real* rec = sRec + LAT_REC * (c + 16 * j);
+                constexpr int dst[5] = {6, 7, 9, 10, 11};
+#pragma unroll
+                for (int i = 0; i < 5; i++) { const real v = rec[dst[i]], w = rec[i]; rec[dst[i]] = pmode ? v : fma(sgmu, w, v); }      // (a select: sigma mu of an instance in its polish is not a number)
+            }
+        });
         wave_sync();
         stamp(0);
         vector_pass();
