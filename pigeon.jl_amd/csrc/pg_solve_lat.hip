@@ -518,7 +518,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // The vector part of a stage's barrier terms (what the vector pass reads: rec[6], [7], [9], [10], [11]) is LINEAR in ell, and the corrector's
     // ell = (sigma mu - corr) / t + lambda - W b is affine in sigma mu, which is only known after the reduction over the predictor's Newton point.  The pass that forms
     // that point therefore leaves BOTH parts in the stage record -- the constant one in rec[6..11], the coefficient of sigma mu in rec[0..4] (the roll-out result it has
-    // just read) -- and a five-multiply-add touch of the record replaces a whole second assembly pass over the row state (round 3: 2.37 -> ... ms at N = 50).
+    // just read) -- and a five-multiply-add touch of the record replaces a whole second assembly pass over the row state (N = 50: 2.37 -> 2.19 ms, 3.45 -> 3.12 ms with walls).
     auto vec_terms = [&](const StageC& S, const Elim& E, const real* ell, bool with_const, real* out) __attribute__((always_inline)) {
         real g0 = real(0.0), g1 = real(0.0);
 #pragma unroll
