@@ -519,6 +519,9 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // ell = (sigma mu - corr) / t + lambda - W b is affine in sigma mu, which is only known after the reduction over the predictor's Newton point.  The pass that forms
     // that point therefore leaves BOTH parts in the stage record -- the constant one in rec[6..11], the coefficient of sigma mu in rec[0..4] (the roll-out result it has
     // just read) -- and a five-multiply-add touch of the record replaces a whole second assembly pass over the row state (N = 50: 2.37 -> 2.19 ms, 3.45 -> 3.12 ms with walls).
+    // (fp64 only: split this way, sigma mu / t and -corr / t are rounded separately although they nearly cancel close to the solution -- harmless at 1e-16, but in fp32
+    // three more of 512 N = 50 instances missed their tolerance; the fp32 build keeps the separate assembly pass)
+    constexpr bool SPLIT_CORR = sizeof(real) == 8;
     auto vec_terms = [&](const StageC& S, const Elim& E, const real* ell, bool with_const, real* out) __attribute__((always_inline)) {
         real g0 = real(0.0), g1 = real(0.0);
 #pragma unroll
@@ -725,11 +728,12 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             real qa[5], qb[5];
             if (pmode) {
                 put_sn(j, sg3); mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, real(0.01) * ptol, unsettled); put_meta(j, mt); put_tl(j, Tl, Ll);
-                // the refinement solve behind this one: same set, the multipliers just updated (no sigma mu in a polish)
-                weights(mt.am, Tl, Ll, Cl, S, real(0.0), false, it_, W, ell);
-                vec_terms(S, E, ell, true, qa);
+                if constexpr (SPLIT_CORR) {      // the refinement solve behind this one: same set, the multipliers just updated (no sigma mu in a polish)
+                    weights(mt.am, Tl, Ll, Cl, S, real(0.0), false, it_, W, ell);
+                    vec_terms(S, E, ell, true, qa);
 #pragma unroll
-                for (int i = 0; i < 5; i++) qb[i] = real(0.0);
+                    for (int i = 0; i < 5; i++) qb[i] = real(0.0);
+                }
             }
             else {
                 real rm = real(0.0), s2 = real(0.0);      // (one select per visit, not per row: a wavefront at one wave per SIMD pays for every instruction it issues)
@@ -744,13 +748,14 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
                 }
                 rmax = fmax(rmax, is_act(j) ? rm : real(0.0)); S2 += is_act(j) ? s2 : real(0.0);
                 put_cr(j, Cl);
-                // the corrector's vector terms: ell = (ell at sigma mu = 0) + sigma mu / t
+                if constexpr (SPLIT_CORR) {      // the corrector's vector terms: ell = (ell at sigma mu = 0) + sigma mu / t
 #pragma unroll
-                for (int r = 0; r < NR; r++) ell[r] = ell[r] - Cl[r] * it_[r];
-                vec_terms(S, E, ell, true, qa);
-                vec_terms(S, E, it_, false, qb);
+                    for (int r = 0; r < NR; r++) ell[r] = ell[r] - Cl[r] * it_[r];
+                    vec_terms(S, E, ell, true, qa);
+                    vec_terms(S, E, it_, false, qb);
+                }
             }
-            put_vec(j, qa, qb);
+            if constexpr (SPLIT_CORR) put_vec(j, qa, qb);
         });
         skip_second = false;
         if (pmode && !done) skip_second = polish_decide(unsettled);
@@ -764,7 +769,8 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         const real sgmu = sg * mu;
         stamp(4);
         // ---- corrector ----
-        for_slots([&](int j) __attribute__((always_inline)) {
+        if constexpr (!SPLIT_CORR) piped(F_TL | F_CR | F_META, [&](int j, In& in) __attribute__((always_inline)) { assemble(j, in, sgmu, false); });
+        else for_slots([&](int j) __attribute__((always_inline)) {
             if (is_act(j)) {
                 real* rec = sRec + LAT_REC * (c + 16 * j);
                 constexpr int dst[5] = {6, 7, 9, 10, 11};
