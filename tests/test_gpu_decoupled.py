@@ -236,3 +236,33 @@ def test_config5_as_shipped_every_instance_against_the_oracle(pkg, oracle_mod, s
     print(f"walls={walls}: interior point alone vs default: {int((d > 1e-6).sum())} instances differ by more than 1e-6 in delta_2 (max {d.max():.1e}, 99.9th percentile {np.percentile(d, 99.9):.1e})")
     assert np.percentile(d, 95) < 1e-6 and d.max() < 1e-3
     ipm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,walls,path", [(1, False, "skidpadoval"), (5, True, "skidpadoval"), (1021, True, "EastPaddock"), (130, False, "vail")])
+def test_lateral_kernel_on_ragged_batches_matches_the_embedding(pkg, B, walls, path):
+    """k_solve_lat (four instances per wavefront, the per-row state of N = 50 in its global workspace) against the embedding of the same QP in k_solve
+    (PG_SOLVE_LAT=0, one wavefront per instance) on batch sizes that leave the last wavefront ragged and on other paths than the benchmark's: two
+    different kernels, the same verified KKT point wherever both verify."""
+    import os
+    traj = pkg.load_path_fixture(path)
+    state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=3)
+    out = {}
+    for lat in ("1", "0"):
+        os.environ["PG_SOLVE_LAT"] = lat
+        try:
+            mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, walls=walls)
+        finally:
+            os.environ.pop("PG_SOLVE_LAT", None)
+        u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
+        x, sg = mpc.solution()
+        out[lat] = (u.copy(), status.copy(), x.copy(), mpc.polish_info().copy())
+        mpc.close()
+    (ua, sa, xa, pa), (ue, se, xe, pe) = out["1"], out["0"]
+    assert np.all(pkg.is_solved(sa)), np.bincount(sa)
+    both = (pa >= 1) & (pe >= 1)
+    assert both.sum() >= max(1, int(0.8 * B)), (int(both.sum()), B)
+    assert np.max(np.abs(xa[both, 1, 6] - xe[both, 1, 6])) <= 1e-7                    # applied steering: both are verified KKT points of the same QP data
+    assert np.max(np.abs(ua[both] - ue[both])) <= 1e-6 * max(1.0, np.max(np.abs(ue[both])))
+    solved_e = pkg.is_solved(se)
+    assert np.max(np.abs(xa[solved_e, 1, 6] - xe[solved_e, 1, 6])) <= 1e-5            # interior-point iterates of either kernel where a polish did not verify
