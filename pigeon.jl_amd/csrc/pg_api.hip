@@ -751,18 +751,20 @@ static int update_and_solve(pg_handle* h, hipEvent_t after_update) {
 int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     int rc = check_ready(h); if (rc) return rc;
     unsigned long long* d = nullptr;
-    HIPCHK(h, hipMalloc((void**)&d, ((size_t)h->B * 6 + 1024) * 8));
-    HIPCHK(h, hipMemset(d, 0, ((size_t)h->B * 6 + 1024) * 8));
-    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, nullptr};
+    HIPCHK(h, hipMalloc((void**)&d, ((size_t)h->B * 9 + 1024) * 8));
+    HIPCHK(h, hipMemset(d, 0, ((size_t)h->B * 9 + 1024) * 8));
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam,
+               (h->dc.polish && h->order_B == h->B) ? h->d_order : nullptr};            // (the launch order pg_solve would use: the timeline is the product's)
     if (h->solve_lat) { if ((rc = launch_solve(h, h->stream, nullptr, h->B, d))) { (void)hipFree(d); return rc; } } else
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) hipLaunchKernelGGL((k_solve4<2, true>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, d);
     else
 #endif
     if (h->solve_ring) hipLaunchKernelGGL((k_solve<true, true, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, d, h->d_dt, h->d_Mb);
+    else if (getenv("PG_DEBUG_TIMELINE")) hipLaunchKernelGGL((k_solve<false, false, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, d, h->d_dt, h->d_Mb);      // the product's kernel: timeline only
     else hipLaunchKernelGGL((k_solve<true, false, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, d, h->d_dt, h->d_Mb);
     LAUNCH_CHECK(h);
-    HIPCHK(h, hipMemcpy(out, d, ((size_t)h->B * 6 + 1024) * 8, hipMemcpyDeviceToHost));      // out: [B][6] cycles + 1024-double trace of PG_DEBUG_INSTANCE
+    HIPCHK(h, hipMemcpy(out, d, ((size_t)h->B * 9 + 1024) * 8, hipMemcpyDeviceToHost));      // out: [B][6] cycles + 1024-double trace of PG_DEBUG_INSTANCE + [B][3] timeline (k_solve: entry, exit on the 100 MHz wall clock, HW_ID | XCC_ID << 32)
     (void)hipFree(d);
     return PG_OK;
 }

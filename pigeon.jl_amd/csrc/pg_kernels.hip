@@ -1218,6 +1218,11 @@ PG_DEV void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifdef PG_TIMELINE        // diagnostic build (make EXTRA=-DPG_TIMELINE): the product's k_solve also records its per-wavefront timeline (costs ~100 B of scratch per lane)
+#define PG_TL true
+#else
+#define PG_TL PROF
+#endif
 #ifndef PG_SETTLE_PASSES
 #define PG_SETTLE_PASSES 4
 #endif
@@ -1227,6 +1232,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int slot) { if (PROF) { unsigned long long now = clock64(); pc[slot] += now - tprev; tprev = now; } };
     if (PROF) tprev = clock64();
+    const unsigned long long t_entry = (PG_TL && prof) ? wall_clock64() : 0ull;
     // Launch order: workgroup i solves instance order_in[i] when an order is supplied (filed by the nodes kernels, likely stragglers first: see OrderOut)
     const int b = O.order_in ? O.order_in[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;
     const int N = C.N, NN = C.NN;
@@ -2123,7 +2129,13 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     }   // attempts
     it = it_total;
     stamp(0);
-    if (PROF && lane == 0) { for (int i = 0; i < 6; i++) prof[(size_t)b * 6 + i] = pc[i]; }
+    if (PG_TL && prof && lane == 0) {      // (the timeline also from the product's kernel in a -DPG_TIMELINE build: pg_debug_solve_cycles with PG_DEBUG_TIMELINE=1)
+        if constexpr (PROF) for (int i = 0; i < 6; i++) prof[(size_t)b * 6 + i] = pc[i];
+        // timeline record behind the trace region: wall clock (100 MHz) at entry and here, and where the wavefront ran (HW_ID | XCC_ID << 32)
+        unsigned long long* tl = prof + (size_t)B * 6 + 1024 + (size_t)b * 3;
+        tl[0] = t_entry; tl[1] = wall_clock64();
+        tl[2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (31 << 11)) << 32);
+    }
     if (status == PG_SOLVED && C.polish && pstat < 0) status = PG_SOLVED_UNVERIFIED;      // an interior-point iterate no active-set round could verify (pigeon_mpc.h)
     if (status == PG_SOLVED || status == PG_SOLVED_UNVERIFIED) {
         real Ux0 = sx0[1], Fx0 = sx0[7];

@@ -22,7 +22,7 @@ if step > 1:
 st0, it0, act0, _ = mpc.solve_info(); ps0 = mpc.polish_info()
 print(f"before step {step}: instance {inst} status {st0[inst]} iters {it0[inst]} polish {ps0[inst]} active rows {sum(bin(int(m)).count('1') for m in act0[inst])}")
 mpc.compute_time_steps_(); mpc.compute_linearization_nodes_(); mpc.update_QP_()
-out = np.zeros(B * 6 + 1024, dtype=np.uint64)
+out = np.zeros(B * 9 + 1024, dtype=np.uint64)
 rc = mpc.lib.pg_debug_solve_cycles(mpc.h, out.ctypes.data_as(C.c_void_p)); assert rc == 0
 tr = out[B * 6:].view(np.float64 if mpc.precision == 'f64' else np.float32).reshape(-1, 4)[:256]
 st, it, act, mu = mpc.solve_info(); ps = mpc.polish_info()

@@ -1,4 +1,7 @@
-"""Diagnostic: per-phase shader cycles inside k_solve (diagnostic kernel build with s_memtime stamps; shares, not run time)."""
+"""Diagnostic: per-phase shader cycles inside k_solve (diagnostic kernel build with s_memtime stamps; shares, not run time), then the per-SIMD timeline of a COLD
+launch in the product's launch order: wavefront lifetimes by rounds, gaps between consecutive wavefronts of a SIMD, when the SIMDs run out of work, when the long
+instances start.  The timeline of the diagnostic kernel is stretched by its stamps (575 against 403 us); for the product's own kernel build the library with
+`make EXTRA=-DPG_TIMELINE`, point PIGEON_HIP_LIB at it and set PG_DEBUG_TIMELINE=1."""
 import ctypes as C, sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +12,7 @@ traj = pkg.load_path_fixture("skidpadoval")
 mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B)
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345)
 mpc.step_(state, control, t0, time_offset=toff)
-out = np.zeros(B * 6 + 1024, dtype=np.uint64)
+out = np.zeros(B * 9 + 1024, dtype=np.uint64)
 rc = mpc.lib.pg_debug_solve_cycles(mpc.h, out.ctypes.data_as(C.c_void_p)); assert rc == 0
 out = out[:B * 6].reshape(B, 6)
 st, it, act, mu = mpc.solve_info()
@@ -20,3 +23,37 @@ tot = out.sum(1).astype(float)
 print("iters mean", it.mean(), "cycles/solve mean", tot.mean())
 for i, n in enumerate(names):
     print(f"{n:24s} {out[:, i].mean():12.0f} cycles  {100 * out[:, i].mean() / tot.mean():5.1f} %   per iteration {out[:, i].mean() / it.mean():10.0f}")
+
+# ---- timeline of the launch (k_solve only): per SIMD the wavefronts it ran, their entry / exit on the 100 MHz wall clock, the gaps between them
+# (a fresh handle, phases called one by one, the diagnostic solve in place of solve!: a COLD launch, in index order -- the figures above are those of the warm re-solve)
+mpc2 = pkg.BatchedTrajectoryTrackingMPC(traj, B)
+mpc2.set_inputs(state, control, t0, time_offset=toff)
+mpc2.compute_time_steps_(); mpc2.compute_linearization_nodes_(); mpc2.update_QP_()
+raw = np.zeros(B * 9 + 1024, dtype=np.uint64)
+rc = mpc2.lib.pg_debug_solve_cycles(mpc2.h, raw.ctypes.data_as(C.c_void_p)); assert rc == 0
+mpc = mpc2
+cyc = raw[:B * 6].reshape(B, 6).astype(float)
+print("cold launch: cycles per instance mean %.0f: " % cyc.sum(1).mean() + ", ".join(f"{n} {cyc[:, i].mean():.0f}" for i, n in enumerate(names)))
+tl = raw[B * 6 + 1024:].reshape(B, 3)
+if tl[:, 1].any():
+    t0_ = tl[:, 0].min(); ent = (tl[:, 0] - t0_).astype(float) / 100.0; ext = (tl[:, 1] - t0_).astype(float) / 100.0          # microseconds
+    hw = tl[:, 2] & np.uint64(0xFFFFFFFF); xcc = (tl[:, 2] >> np.uint64(32)) & np.uint64(0xF)
+    simd = (hw >> np.uint64(4)) & np.uint64(3); cu = (hw >> np.uint64(8)) & np.uint64(15); sh = (hw >> np.uint64(12)) & np.uint64(1); se = (hw >> np.uint64(13)) & np.uint64(7)
+    slot = (((xcc * np.uint64(8) + se) * np.uint64(2) + sh) * np.uint64(16) + cu) * np.uint64(4) + simd
+    pol = mpc.polish_info()
+    print(f"launch: first entry 0, last entry {ent.max():.1f} us, last exit {ext.max():.1f} us; wavefront lifetime mean {np.mean(ext - ent):.1f} us (min {np.min(ext - ent):.1f}, max {np.max(ext - ent):.1f}); distinct SIMDs seen {len(np.unique(slot))}")
+    busy = []; gaps = []; nper = []
+    for sl_ in np.unique(slot):
+        m = np.where(slot == sl_)[0]; o_ = m[np.argsort(ent[m])]
+        busy.append(np.sum(ext[o_] - ent[o_])); nper.append(len(o_))
+        gaps += list(ent[o_][1:] - ext[o_][:-1])
+    busy = np.array(busy); gaps = np.array(gaps)
+    print(f"per SIMD: wavefronts {np.mean(nper):.2f} (min {np.min(nper)}, max {np.max(nper)}); busy {busy.mean():.1f} us of {ext.max():.1f} ({100 * busy.mean() / ext.max():.0f} %); gap between consecutive wavefronts on a SIMD: median {np.median(gaps):.2f} us, mean {gaps.mean():.2f}, p99 {np.percentile(gaps, 99):.2f}")
+    print("lifetime by rounds:", {int(r): round(float(np.mean((ext - ent)[pol == r])), 1) for r in np.unique(pol)})
+    fin = np.sort(np.array([ext[slot == s_].max() for s_ in np.unique(slot)]))
+    print(f"time at which a SIMD runs out of work: p10 {np.percentile(fin, 10):.0f}  median {np.median(fin):.0f}  p90 {np.percentile(fin, 90):.0f}  max {fin.max():.0f} us")
+    for thr in (4, 6, 8):
+        m = pol >= thr
+        if m.any(): print(f"instances with >= {thr} rounds: {int(m.sum())}; entry time median {np.median(ent[m]):.0f} us, p90 {np.percentile(ent[m], 90):.0f}, max {ent[m].max():.0f}; exit max {ext[m].max():.0f}")
+    last = np.argsort(-ext)[:8]
+    print("last wavefronts to finish (exit us, entry us, rounds):", [(round(float(ext[i])), round(float(ent[i])), int(pol[i])) for i in last])
