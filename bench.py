@@ -112,8 +112,7 @@ def cpu_baseline(pkg, traj, mpc, state, control, t0, toff, precision, local):
                                 "osqp_hit_max_iter": int(np.sum(std != 1))}
         # ... and the checker for the bench's decoupled_n50 line: the GPU's applied steering of a sample of the SAME batch, default solver configuration, with the wall
         # rows (the configs[4] line) and without, against a VERIFIED KKT point of the canonical QP built from the GPU's own QP data (OracleDecoupled.solve_exact_verified)
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from test_gpu_decoupled import unembed_qp, extend_with_walls
+        unembed_qp, extend_with_walls = orc_mod.unembed_qp, orc_mod.extend_with_walls
         nsd = 128
         acc = {}
         for walls in (True, False):
@@ -130,8 +129,8 @@ def cpu_baseline(pkg, traj, mpc, state, control, t0, toff, precision, local):
                     xe, ye, info = od.solve_exact_verified(sd)
                 if info["status"] == 1 and info["polished"] >= 1:
                     nver += 1; errs.append(abs(xd[b, 1, 6] - od.split_x(xe[:od.n])["delta"][1]))
-            acc["with_walls" if walls else "without_walls"] = {"instances": nsd, "oracle_verified_kkt_points": nver, "max_abs_applied_steering_error_rad": float(np.max(errs)),
-                                                               "median": float(np.median(errs)), "gpu_verified_by_polish": f"{int((pold >= 1).sum())}/{nsd}",
+            acc["with_walls" if walls else "without_walls"] = {"instances": nsd, "oracle_verified_kkt_points": nver, "max_abs_applied_steering_error_rad": float(np.max(errs)) if errs else None,
+                                                               "median": float(np.median(errs)) if errs else None, "gpu_verified_by_polish": f"{int((pold >= 1).sum())}/{nsd}",
                                                                "gpu_solved": f"{int(pkg.is_solved(stdg).sum())}/{nsd}"}
             g.close()
         out["decoupled_n50"]["accuracy"] = dict(acc, against="exact optimum of the same QP data as a verified KKT point of the canonical lateral QP (fp64 oracle); every one of "

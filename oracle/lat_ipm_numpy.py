@@ -210,7 +210,7 @@ def solve(D, tol=1e-12, mu0=100.0, max_iter=40, sig0=1.0, tau=1e-4, floor=True, 
 
 def canonical_candidate(D, r, Ns, walls=False):
     """(x0, actv) for polish_from: the solver's answer `r` of stage data D in the variable and row order of the canonical lateral QP (oracle/mpc_decoupled.hpp =
-    the @constraint order of decoupled_lat_long.jl:146-203; with walls=True the N slack columns and 3N rows tests/test_gpu_decoupled.py::extend_with_walls appends)."""
+    the @constraint order of decoupled_lat_long.jl:146-203; with walls=True the N slack columns and 3N rows oracle.extend_with_walls appends)."""
     N = D["N"]; Nn = N + 1
     x0 = np.concatenate([r["x"][:, :4].ravel(), r["x"][:, 4], np.stack([r["s1"], r["s2"]], axis=1).ravel(), r["v"]] + ([r["sw"]] if walls else []))
     m = 15 * N + 5

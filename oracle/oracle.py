@@ -10,6 +10,7 @@ import os
 import subprocess
 
 import numpy as np
+import scipy.sparse as sp
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -460,3 +461,43 @@ class OracleDecoupled:
 
     def next_control(self, delta, Fx_seed):
         o = np.zeros(3); self.L.pd_next_control(self.h, C.c_double(delta), C.c_double(Fx_seed), _d(o)); return o
+
+
+# ---- glue between the lateral oracle and the product's embedded QP layout (pg_get_qp of a PG_DECOUPLED handle); used by tests/ and by bench.py's accuracy block ----
+
+def embed_sd(orc, sd, ux_dummy=8.0):
+    """Oracle stage data of the lateral QP -> the embedded coupled layout pg_get_qp returns for PG_DECOUPLED handles."""
+    S = orc.unpack_sd(sd); N = orc.N
+    A = np.zeros((N, 6, 6)); A[:, 0, 0] = 1; A[:, 1, 1] = 1; A[:, 2:, 2:] = S["A"]
+    B0 = np.zeros((N, 6, 2)); B0[:, 2:, 0] = S["B0"]; Bf = np.zeros((N, 6, 2)); Bf[:, 2:, 0] = S["Bf"]
+    c = np.zeros((N, 6)); c[:, 2:] = S["c"]
+    return np.concatenate([A.ravel(), B0.ravel(), Bf.ravel(), c.ravel(), S["H"].ravel(), S["G"].ravel(), S["dmin"], S["dmax"], np.ones(N), S["ddmin"], S["ddmax"],
+                           S["dt"], [0.0, ux_dummy], S["q_curr"], [S["d_curr"], 0.0], [0.0, 0.0], [1.0]])
+
+
+def unembed_qp(orc, row):
+    """Inverse of embed_sd: one row of pg_get_qp of a PG_DECOUPLED handle -> the oracle's lateral stage data."""
+    N = orc.N; o = 0
+    def take(n, shape):
+        nonlocal o
+        v = row[o:o + n].reshape(shape); o += n
+        return v
+    A = take(36 * N, (N, 6, 6)); B0 = take(12 * N, (N, 6, 2)); Bf = take(12 * N, (N, 6, 2)); c = take(6 * N, (N, 6))
+    H = take(8 * N, (N, 4, 2)); G = take(4 * N, (N, 4)); dmin = take(N, (N,)); dmax = take(N, (N,)); take(N, (N,)); ddmin = take(N, (N,)); ddmax = take(N, (N,)); dt = take(N, (N,))
+    qc = take(6, (6,)); uc = take(2, (2,))
+    return np.concatenate([A[:, 2:, 2:].ravel(), B0[:, 2:, 0].ravel(), Bf[:, 2:, 0].ravel(), c[:, 2:].ravel(), H.ravel(), G.ravel(), dmin, dmax, ddmin, ddmax, dt, qc[2:], [uc[0]]])
+
+
+def extend_with_walls(orc, qpc, edges, dt, Ww):
+    """Canonical lateral QP + the build-defined wall rows (columns n..n+N-1 = sw_k; rows m+3k: e - sw <= edge_L, m+3k+1: e + sw >= edge_R, m+3k+2: sw >= 0)."""
+    n, m, Nh = orc.n, orc.m, orc.N
+    A = sp.csc_matrix((qpc["Ax"], qpc["Ai"], qpc["Ap"]), shape=(m, n))
+    k = np.arange(Nh); col = 4 * (k + 1) + 3
+    rows = np.concatenate([3 * k, 3 * k, 3 * k + 1, 3 * k + 1, 3 * k + 2]); cols = np.concatenate([col, n + k, col, n + k, n + k])
+    vals = np.concatenate([np.ones(Nh), -np.ones(Nh), np.ones(Nh), np.ones(Nh), np.ones(Nh)])
+    W = sp.csc_matrix((vals, (rows, cols)), shape=(3 * Nh, n + Nh))
+    lw = np.full(3 * Nh, -1e20); uw = np.full(3 * Nh, 1e20)
+    uw[3 * k] = edges[:, 0]; lw[3 * k + 1] = edges[:, 1]; lw[3 * k + 2] = 0.0
+    Aw = sp.vstack([sp.hstack([A, sp.csc_matrix((m, Nh))]), W]).tocsc(); Aw.sort_indices()
+    return dict(Pd=np.concatenate([qpc["Pd"], np.zeros(Nh)]), q=np.concatenate([qpc["q"], Ww * dt]), Ap=Aw.indptr, Ai=Aw.indices, Ax=Aw.data,
+                l=np.concatenate([qpc["l"], lw]), u=np.concatenate([qpc["u"], uw])), Aw

@@ -34,6 +34,7 @@ struct pg_handle {
     real *d_x7 = nullptr, *d_vg8 = nullptr, *d_Mb = nullptr;
     real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     real* d_lam = nullptr;                                      // [cap][N][16] multipliers of the last solve (warm start of the polish)
+    int* d_wfail = nullptr;                                     // [cap] back-off of k_solve_lat's warm attempts
     int* d_order = nullptr; int order_B = 0;  // [cap] + 2 counters: launch order filed by the nodes kernels of the current step (likely slow instances first); order_B = batch it is valid for
     real *d_pol_u2 = nullptr, *d_pol_u = nullptr; int* d_pol_src = nullptr;   // HJI fallback policy (HJI_computation.jl:133-158)
     int *d_status = nullptr, *d_iters = nullptr, *d_polish = nullptr; uint16_t* d_active = nullptr;
@@ -158,7 +159,7 @@ int pg_default_config_decoupled(pg_config* c) {
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_in, h->d_out, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_order, h->d_naux, h->d_progress, h->d_lat, h->d_lat_ws};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_wfail, h->d_order, h->d_naux, h->d_progress, h->d_lat, h->d_lat_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->sg.x) (void)hipGraphExecDestroy(h->sg.x);
@@ -210,7 +211,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_sep, cap * 4, real); ALLOC(h->d_nodes, cap * NN * 10, real); ALLOC(h->d_qp, cap * C.qp_len, real);
     ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
     ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_mu, cap, real);
-    ALLOC(h->d_polish, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_naux, cap * NN * 4, real); ALLOC(h->d_progress, cap / 64 + 6, int); ALLOC(h->d_active, cap * N, uint16_t);
+    ALLOC(h->d_polish, cap, int); ALLOC(h->d_wfail, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_naux, cap * NN * 4, real); ALLOC(h->d_progress, cap / 64 + 6, int); ALLOC(h->d_active, cap * N, uint16_t);
 #ifdef PG_EXPERIMENTAL_SOLVE4
     { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (experimental/pg_solve4.hip)
     if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), real);
@@ -231,6 +232,12 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         { const char* k = getenv("PG_LAT_MU0_COST"); C.lat_mu0_cost = (real)(k ? atof(k) : 10.0); }
         { const char* k = getenv("PG_LAT_POLISH2"); C.lat_polish2 = k ? atoi(k) : 1; }
         { const char* k = getenv("PG_LAT_FAR_COST"); C.lat_far_cost = (real)(k ? atof(k) : 3e4); }
+        { const char* k = getenv("PG_LAT_RHO_SCALE"); const double v = k ? atof(k) : (sizeof(real) == 8 ? 1e3 : 1.0); C.lat_rho_scale = (real)((v > 0.0 && v < 1e12) ? v : 1.0); }
+        { const char* k = getenv("PG_LAT_SETTLE"); C.lat_settle = k ? atoi(k) : 0; }
+        { const char* k = getenv("PG_LAT_WARM_ROUNDS"); C.lat_warm_rounds = k ? atoi(k) : 4; if (C.lat_warm_rounds < 0) C.lat_warm_rounds = 0; }
+        { const char* k = getenv("PG_LAT_WIPM"); C.lat_wipm = k ? atoi(k) : 0; }
+        { const char* k = getenv("PG_LAT_WMU"); C.lat_wmu = (real)(k ? atof(k) : 1e-2); }
+        { const char* k = getenv("PG_LAT_WTAU"); C.lat_wtau = (real)(k ? atof(k) : 1e-4); }
         const char* e = getenv("PG_LAT_MEM");
         h->lat_mem = N > 32 || (e && e[0] == '1');
         if (h->lat_mem) { ALLOC(h->d_lat_ws, lat_ws_bytes(cap), char); C.lat_ws = h->d_lat_ws; }
@@ -248,6 +255,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         (void)hipMemset(h->d_solved, 0, cap * sizeof(int));
         (void)hipMemset(h->d_progress, 0, (cap / 64 + 6) * sizeof(int));
         (void)hipMemset(h->d_status, 0, cap * sizeof(int));
+        (void)hipMemset(h->d_wfail, 0, cap * sizeof(int));
         (void)hipMemset(h->d_other, 0, cap * 4 * sizeof(real));
         (void)hipMemset(h->d_solx, 0, cap * NN * 8 * sizeof(real));
         if (hipDeviceSynchronize() != hipSuccess) { g_create_error = "initial fills failed"; free_all(h); delete h; return PG_ERR_HIP; }   // hipMemset may return before the fill has run
@@ -437,9 +445,9 @@ int pg_set_hji_grid(pg_handle* h, const int32_t dims[7], const float* knots_conc
     return PG_OK;
 }
 
-__global__ void k_reset(int B, const uint8_t* mask, int* solved) {
+__global__ void k_reset(int B, const uint8_t* mask, int* solved, int* wfail) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B && (!mask || mask[b])) solved[b] = 0;
+    if (b < B && (!mask || mask[b])) { solved[b] = 0; wfail[b] = 0; }
 }
 
 int pg_reset(pg_handle* h, const uint8_t* mask) {
@@ -447,10 +455,10 @@ int pg_reset(pg_handle* h, const uint8_t* mask) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int cap = h->cfg.batch_capacity;
     h->warm_B = 0; h->order_B = 0;
-    if (!mask) { HIPCHK(h, hipMemsetAsync(h->d_solved, 0, (size_t)cap * sizeof(int), h->stream)); return PG_OK; }
+    if (!mask) { HIPCHK(h, hipMemsetAsync(h->d_solved, 0, (size_t)cap * sizeof(int), h->stream)); HIPCHK(h, hipMemsetAsync(h->d_wfail, 0, (size_t)cap * sizeof(int), h->stream)); return PG_OK; }
     REQUIRE(h, h->B > 0, "pg_reset with a mask needs inputs installed (B known)");
     HIPCHK(h, hipMemcpyAsync(h->d_mask, mask, h->B, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_reset, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, h->B, h->d_mask, h->d_solved);
+    hipLaunchKernelGGL(k_reset, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, h->B, h->d_mask, h->d_solved, h->d_wfail);
     LAUNCH_CHECK(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));            // the caller may reuse `mask`
     return PG_OK;
@@ -685,7 +693,7 @@ int pg_update_qp(pg_handle* h) {
 }
 // k_solve over `n` instances on stream `st`: the whole batch in index order (order == nullptr) or the sub-range order[0..n) of the launch order
 static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, unsigned long long* lat_prof = nullptr) {
-    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, order};
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, order, h->d_wfail};
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) { hipLaunchKernelGGL((k_solve4<2, false>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, (unsigned long long*)nullptr); LAUNCH_CHECK(h); return PG_OK; }
 #endif
@@ -740,7 +748,7 @@ static int update_and_solve(pg_handle* h, hipEvent_t after_update) {
     if ((rc = launch_hji_rows(h))) return rc;
     if (after_update) HIPCHK(h, hipEventRecord(after_update, h->stream));
     const bool use_order = h->dc.polish && h->order_B == h->B;
-    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, use_order ? h->d_order : nullptr};
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, use_order ? h->d_order : nullptr, h->d_wfail};
     hipLaunchKernelGGL((k_solve<false, false, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
     LAUNCH_CHECK(h);
     if (h->B > h->warm_B) h->warm_B = h->B;
@@ -754,7 +762,7 @@ int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     HIPCHK(h, hipMalloc((void**)&d, ((size_t)h->B * 9 + 1024) * 8));
     HIPCHK(h, hipMemset(d, 0, ((size_t)h->B * 9 + 1024) * 8));
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam,
-               (h->dc.polish && h->order_B == h->B) ? h->d_order : nullptr};            // (the launch order pg_solve would use: the timeline is the product's)
+               (h->dc.polish && h->order_B == h->B) ? h->d_order : nullptr, h->d_wfail};            // (the launch order pg_solve would use: the timeline is the product's)
     if (h->solve_lat) { if ((rc = launch_solve(h, h->stream, nullptr, h->B, d))) { (void)hipFree(d); return rc; } } else
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) hipLaunchKernelGGL((k_solve4<2, true>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, d);

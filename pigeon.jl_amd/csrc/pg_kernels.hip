@@ -47,6 +47,10 @@ struct DevCfg {
     int lat_polish2;            // k_solve_lat: the polish gets a second chance behind the resumed interior point
     real lat_far_cost;          // k_solve_lat: starting cost per row beyond which the early hand-over to the polish is not tried
     real lat_mu0_cost;          // k_solve_lat: first barrier parameter = max(ipm_mu0, lat_mu0_cost x cost of the starting point per row)
+    real lat_rho_scale;         // k_solve_lat: penalty of the held rows = polish_rho x this (see pg_solve_lat.hip)
+    int lat_settle;             // k_solve_lat: working-set decisions wait for settled multipliers (0 never, 1 warm attempts, 2 every polish)
+    int lat_wipm; real lat_wmu, lat_wtau;      // k_solve_lat: interior point of a warm instance starts from the previous solution (floors of t lambda and of t)
+    int lat_warm_rounds;        // k_solve_lat: working sets a warm attempt (previous step's set and multipliers) may try before the cold start takes over
     char* lat_ws;               // lateral formulation, horizons beyond 32 intervals: k_solve_lat's per-wavefront workspace (lat_ws_bytes(B); nullptr: not wanted)
     real* lat_pack;             // lateral formulation: [B][N][LATP] packed stage records for k_solve_lat, written by k_qp_dec next to the QP block (nullptr: not wanted)
 };
@@ -1152,7 +1156,7 @@ __global__ __launch_bounds__(64) void k_hji_policy(DevCfg C, int B, int use_poli
 //   6..9: H_i [Uy;r] - sigma_{i/2} <= G_i     10: sigma1 >= 0   11: sigma2 >= 0    12: d_delta <= ddmax   13: d_delta >= ddmin
 //   14: M u + b + sigma_HJI >= 0              15: sigma_HJI >= 0        (14,15 only for nodes 1 .. min(N_HJI,Ns)-1)
 struct SolveOut { real* sol_x; real* sol_sigma; real* u_out; int* status; int* iters; uint16_t* active; real* mu; int* solved; int* polish; real* lam;
-                  const int* order_in; };
+                  const int* order_in; int* wfail; };      // wfail: k_solve_lat's back-off word per instance (nullptr: none)
 
 #define NROW 16
 #define PG_POLISH_ROUNDS 6      // active-set rounds of the polish before it gives up

@@ -441,7 +441,12 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // working sets tried per polish: three at the hand-over tolerance (of the 3851 N = 50 + walls instances that verify, 2717 / 876 / 242 / 16 do so in round 1 / 2 / 3 / 4),
     // two in the second attempt behind the resumed interior point (the slowest wavefront sets the kernel's time, and these are its instances)
     const int LAT_POLISH_ROUNDS = 3;
-    const real rho = C.polish_rho, ptol = C.polish_tol;
+    // Penalty of the held rows: polish_rho x lat_rho_scale (fp64: 1e3, i.e. 1e10 at the default 1e7).  A held rate or steering-bound row pins the input of its stage, and
+    // the multiplier iteration lambda <- lambda - rho t contracts by S / (S + rho) per pass, S = Rhat + Bbar' P Bbar the curvature of the cost-to-go in that input -- on the
+    // open-loop unstable 8 s horizon P grows like exp(2 lambda T), S reaches 1e9..1e12, and at rho = 1e7 the multipliers of such rows stall: 6-7 % of the N = 50 batch ended
+    // unverified for that reason alone (PG_RHO sweep, EXPERIMENTS 10.1: unverified 248 / 111 / 53 / 11 of 4096 at 1e7 / 1e9 / 1e10 / 1e11; accuracy against the oracle
+    // unchanged up to 1e10, 3x worse with walls at 1e11).  The embedding in k_solve keeps polish_rho as it is (its refinement solves for a correction; tuned at 1e7).
+    const real rho = C.polish_rho * C.lat_rho_scale, ptol = C.polish_tol;
     // barrier weights of a slot at the current iterate: it = 1/t, W = lambda/t, ell = (sigma mu - corr)/t + lambda - W b
     auto weights = [&](unsigned am, const real* Tl, const real* Ll, const real* Cl, const StageC& S, real sgmu, bool with_corr, real* it_, real* W, real* ell) __attribute__((always_inline)) {
         if (pmode) {
@@ -561,6 +566,12 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     wave_sync();
     stamp(3);
     real rp0 = real(0.0), j0 = real(0.0);
+    constexpr int lat_bit[13] = {3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 0, 1, 2};      // local row -> bit of the 16-bit active mask (the numbering of the embedded stage: pigeon_mpc.h)
+    // an instance whose previous step ended in a solved QP (see "warm start" below)
+    const bool warm = C.polish && C.warm_polish && O.solved[b] != 0 && (O.status[b] == PG_SOLVED || O.status[b] == PG_SOLVED_UNVERIFIED);
+    // ... whose interior point, should it be needed, starts from the PREVIOUS solution instead of the v = 0 roll-out: slacks of the previous primal point against the new
+    // rows, floored at lat_wtau; multipliers the previous ones, floored at lat_wmu / t (every product t lambda >= lat_wmu: a centred neighbourhood of the old optimum)
+    const bool wipm = warm && C.lat_wipm != 0;
     real ms_next = real(0.0);       // sum t lambda over this lane's rows at the iterate just stored (the complementarity gap of the next loop top)
     // the damped iterate (x_{s+1}, sigma) of a stage is kept in the output buffers (read-modify-write once per iteration), not in registers
     for_slots([&](int j) __attribute__((always_inline)) {
@@ -571,13 +582,14 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         const real* rec = sRec + LAT_REC * s;
         real xs[5], sl[NR];
 #pragma unroll
-        for (int m = 0; m < 5; m++) xs[m] = rec[m];
-        slacks(S, xs, real(0.0), real(0.0), real(0.0), real(0.0), sl);
-        const real sig0 = real(1.0), tau = real(1e-4);
-        const real s1 = fmax(real(0.0), -fmin(sl[2], sl[3])) + sig0, s2 = fmax(real(0.0), -fmin(sl[4], sl[5])) + sig0;
+        for (int m = 0; m < 5; m++) xs[m] = wipm ? SXj[2 + m] : rec[m];
+        const real vst = wipm ? xs[4] - (SXj - 8)[6] : real(0.0);
+        slacks(S, xs, vst, real(0.0), real(0.0), real(0.0), sl);
+        const real sig0 = wipm ? C.lat_wtau : real(1.0), tau = wipm ? C.lat_wtau : real(1e-4);
+        const real s1 = fmax(wipm ? SGj[0] : real(0.0), fmax(real(0.0), -fmin(sl[2], sl[3])) + sig0), s2 = fmax(wipm ? SGj[1] : real(0.0), fmax(real(0.0), -fmin(sl[4], sl[5])) + sig0);
         real sw = real(0.0);
-        if constexpr (WALLS) sw = fmax(real(0.0), -fmin(sl[10], sl[11])) + sig0;
-        slacks(S, xs, real(0.0), s1, s2, sw, sl);
+        if constexpr (WALLS) sw = fmax(wipm ? SGj[2] : real(0.0), fmax(real(0.0), -fmin(sl[10], sl[11])) + sig0);
+        slacks(S, xs, vst, s1, s2, sw, sl);
         if (actj && valid) {
             SXj[0] = real(0.0); SXj[1] = C.ux_dummy; SXj[7] = real(0.0);      // the embedded layout pg_get_solution documents: (0, Ux slot, Uy, r, dpsi, e, delta, 0)
 #pragma unroll
@@ -605,13 +617,18 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // kilometres off the path; from mu = 100 such an instance spends ~12 iterations with step lengths of a few per cent while mu climbs by itself to ~1e5, and it is these
     // instances (one in twenty) that set the kernel's time.  With the scaled start the slowest of the N = 50 batch needs 16 iterations to the hand-over instead of 27
     // and the mean drops from 9.8 to 9.0 (oracle/lat_ipm_numpy.py carries the same rule).
-    const real mu0i = fmax(C.ipm_mu0, C.lat_mu0_cost * row_sum(j0) * intot);
+    real mu0i = fmax(C.ipm_mu0, C.lat_mu0_cost * row_sum(j0) * intot);
     for_slots([&](int j) __attribute__((always_inline)) {
         real Tl[NR], Ll[NR]; get_tl(j, Tl, Ll);
+        const real* Lp = O.lam + ((size_t)b * N + (is_act(j) ? c + 16 * j : N - 1)) * 16;
 #pragma unroll
-        for (int r = 0; r < NR; r++) { Ll[r] = is_act(j) ? mu0i * lat_rcp(Tl[r]) : real(1.0); ms_next += is_act(j) ? Tl[r] * Ll[r] : real(0.0); }
+        for (int r = 0; r < NR; r++) {
+            const real lw = wipm ? fmax(fmax(Lp[r], real(0.0)), C.lat_wmu * lat_rcp(Tl[r])) : mu0i * lat_rcp(Tl[r]);
+            Ll[r] = is_act(j) ? lw : real(1.0); ms_next += is_act(j) ? Tl[r] * Ll[r] : real(0.0);
+        }
         put_tl(j, Tl, Ll);
     });
+    if (wipm) mu0i = row_sum(ms_next) * intot;
     // with the polish on, the interior point only has to get close enough for the active set to show (polish_ipm_tol); if the polish does not verify from there, the
     // interior point resumes from the centred point (t, mu / t) and runs down to ipm_tol before the polish gets its second and last chance
     // (an instance that starts further than lat_far_cost per row from its optimum's neighbourhood -- the open-loop roll-out of an unstable horizon, kilometres off the
@@ -622,15 +639,53 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     int status = PG_MAX_ITER, it = 0, good = 0;
     bool done = false;
     const int cap = C.ipm_max_iter;
+    // Warm start of the ACTIVE SET (the reference runs the lateral QP with OSQP's WarmStart = true, decoupled_lat_long.jl:139, inside the same 100 Hz loop as the coupled
+    // one, Pigeon.jl:34 / model_predictive_control.jl:80-100).  An instance whose previous step ended in a solved QP first tries the polish from that step's working set
+    // and multipliers on the NEW QP data: a verified round IS the exact optimum of the new QP whatever the guess was.  The cold start above has been prepared anyway (its
+    // multipliers wait in the second-order slot, where a hand-over to the polish would put them): a warm attempt that does not verify within lat_warm_rounds working sets
+    // resumes as the cold interior point, exactly as a failed first polish resumes the interior point it interrupted.
+    // Back-off: the instances a warm attempt does not serve are mostly the same ones from step to step (far horizons whose working set turns over by a dozen rows per
+    // 10 ms), and a failed attempt costs its rounds ON TOP of the cold solve -- in a kernel that ends with its slowest instance.  An instance whose attempt failed skips the
+    // next 1, 3, 7, 15, 31 attempts (level in bits 8.., remaining skips in bits 0..7 of wfail[b]); a verified attempt clears the word.
+    const int wf = O.wfail ? O.wfail[b] : 0;
+    bool warm_try = warm && C.lat_warm_rounds > 0 && (wf & 0xFF) == 0;
+    bool warm_failed = false;
+    const bool warm_tried = warm_try;
+    const real tol_cold = tol_cur;
+    if (warm_try) {
+        for_slots([&](int j) __attribute__((always_inline)) {
+            real Tl[NR], Ll[NR]; get_tl(j, Tl, Ll);
+            put_cr(j, Ll);
+            const int s = is_act(j) ? c + 16 * j : N - 1;
+            const unsigned pm = is_act(j) ? (unsigned)O.active[(size_t)b * N + s] : 0u;
+            const real* Lp = O.lam + ((size_t)b * N + s) * 16;
+            unsigned mk = 0u;
+#pragma unroll
+            for (int r = 0; r < NR; r++) { const bool a = (pm >> lat_bit[r]) & 1u; mk |= a ? (1u << r) : 0u; Ll[r] = a ? Lp[r] : real(0.0); }
+            put_tl(j, Tl, Ll);
+            Meta m; m.am = mk; m.mi = mk; m.nm = mk; put_meta(j, m);
+        });
+        pmode = 1; pchecks = 0; status = PG_SOLVED;
+    }
 
     // the verdict of a polish solve for this instance, from the per-slot results of polish_rows (the proposed sets are in the slots' meta words, the eliminated slacks
     // of the solve in their sn words): verified (the point is primal and dual feasible: a KKT point of the full QP, stored as the answer), refine (same set, held rows
     // not yet at t = 0: the next solve starts from the updated multipliers), or a new working set.
     // Returns true when the working set changed (the corrector half of this iteration then carries nothing for this instance: its vector pass has the old gains).
-    auto polish_decide = [&](bool unsettled_) __attribute__((always_inline)) -> bool {
-        real chg = real(0.0);
-        for_slots([&](int j) __attribute__((always_inline)) { const Meta m = get_meta(j); chg = fmax(chg, (is_act(j) && m.nm != m.am) ? real(1.0) : real(0.0)); });
-        const bool changed = row_max(chg) > real(0.0), conv = !(row_max(unsettled_ ? real(1.0) : real(0.0)) > real(0.0));
+    unsigned long long dbg_tr0 = 0ull, dbg_tr1 = 0ull; int dbg_n = 0;      // diagnostic launch (prof != nullptr): one record per polish verdict of this instance
+    auto polish_decide = [&](bool unsettled_, bool second_half) __attribute__((always_inline)) -> bool {
+        real chg = real(0.0), nch = real(0.0);
+        for_slots([&](int j) __attribute__((always_inline)) { const Meta m = get_meta(j); chg = fmax(chg, (is_act(j) && m.nm != m.am) ? real(1.0) : real(0.0)); if (prof) nch += is_act(j) ? (real)__popc(m.nm ^ m.am) : real(0.0); });
+        const bool conv = !(row_max(unsettled_ ? real(1.0) : real(0.0)) > real(0.0));
+        // decisions wait for settled multipliers (lat_settle: 1 = warm attempts, 2 = every polish): on an open-loop unstable horizon a held row that is still 1e-5 off its
+        // bound moves the far end of the trajectory by metres, and the rows that then LOOK violated send the working set off (traces: 1 -> 15 -> 90 rows changing per round)
+        const bool changed = row_max(chg) > real(0.0) && (conv || !(C.lat_settle == 2 || (C.lat_settle == 1 && warm_try)));
+        if (prof) {      // nibble: changed | settled << 1 | warm attempt << 2 | second half << 3; byte: rows that change
+            const int nc = (int)fmin(row_sum(nch), real(255.0));
+            if (dbg_n < 16) dbg_tr0 |= (unsigned long long)((changed ? 1 : 0) | (conv ? 2 : 0) | (warm_try ? 4 : 0) | (second_half ? 8 : 0)) << (4 * dbg_n);
+            if (dbg_n < 8) dbg_tr1 |= (unsigned long long)nc << (8 * dbg_n);
+            dbg_n++;
+        }
         pchecks++;
         if (!changed && conv) {
             for_slots([&](int j) __attribute__((always_inline)) {
@@ -656,14 +711,14 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             });
             pmode++;
         }
-        const int round_cap = tol_cur > tol ? LAT_POLISH_ROUNDS : LAT_POLISH_ROUNDS - 1;
+        const int round_cap = warm_try ? C.lat_warm_rounds : (tol_cur > tol ? LAT_POLISH_ROUNDS : LAT_POLISH_ROUNDS - 1);
         if (pmode > round_cap || pchecks > 2 * round_cap + 1) {
             pstat = -1;
             // resume the interior point (takes effect at the top of the next iteration: the rest of this one still belongs to the polish), or -- second failure --
             // nothing verified: the interior-point iterate stands.  (Both flags are assigned on both paths: "if (again) resume = true; else done = true" is folded by the
             // optimiser into ONE store through a selected pointer into the lambda's capture block, which then -- with every captured variable -- lives in scratch memory:
             // the kernel ran twice as long.)
-            const bool again = tol_cur > tol;
+            const bool again = warm_try || tol_cur > tol;      // (a warm attempt that did not verify: on to the cold start)
             resume_ipm = again; done = done || !again;
         }
         return changed;
@@ -675,13 +730,16 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             const real mu_new = row_sum(ms_next) * intot;
             if (resume_ipm) {       // the polish at the hand-over tolerance did not verify: the interior point resumes where it stopped (t is untouched by the polish,
                                     // lambda was set aside) and goes all the way down before the polish gets its second and last chance
-                resume_ipm = false; tol_cur = tol; pmode = 0; status = PG_MAX_ITER; need_a1 = true;
+                // (or the warm attempt did not verify: the cold start prepared before it takes over, at the tolerance a cold instance starts with)
+                resume_ipm = false; tol_cur = warm_try ? tol_cold : tol; pstat = warm_try ? 0 : pstat; warm_failed = warm_failed || warm_try; warm_try = false; pmode = 0; status = PG_MAX_ITER; need_a1 = true;
+                real msr = real(0.0);
                 for_slots([&](int j) __attribute__((always_inline)) {
                     real Tl[NR], Ll[NR], Cl[NR]; get_tl(j, Tl, Ll); get_cr(j, Cl);
 #pragma unroll
-                    for (int r = 0; r < NR; r++) Ll[r] = is_act(j) ? Cl[r] : real(1.0);
+                    for (int r = 0; r < NR; r++) { Ll[r] = is_act(j) ? Cl[r] : real(1.0); msr += is_act(j) ? Tl[r] * Ll[r] : real(0.0); }
                     put_tl(j, Tl, Ll);
                 });
+                mu = row_sum(msr) * intot;
             } else if (!done && !pmode && !want_polish) {
                 mu = mu_new;
                 if (it >= cap && !(cap >= 20 && good >= 3 && it < cap + 20)) done = true;                    // iteration cap (a converging attempt gets twenty more)
@@ -758,7 +816,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             if constexpr (SPLIT_CORR) put_vec(j, qa, qb);
         });
         skip_second = false;
-        if (pmode && !done) skip_second = polish_decide(unsettled);
+        if (pmode && !done) skip_second = polish_decide(unsettled, false);
         rmax = row_max(rmax); S2 = row_sum(S2);
         const real aaff = rmax > real(1.0) ? frcp(rmax) : real(1.0);
         // rounding floor: once mu is within 1e4 x of the tolerance and the affine direction can no longer move, further iterations only add noise
@@ -810,7 +868,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
                 put_cr(j, Cl);
             }
         });
-        if (pmode && !done && !skip_second && !resume_ipm) (void)polish_decide(unsettled);
+        if (pmode && !done && !skip_second && !resume_ipm) (void)polish_decide(unsettled, true);
         rmax = row_max(rmax); T1 = row_sum(T1); T2 = row_sum(T2);
         const real alpha = rmax > real(0.995) ? real(0.995) * frcp(rmax) : real(1.0);
         // rounding floor, second form: a step that would MULTIPLY mu near the tolerance is a Newton direction computed at a conditioning the arithmetic no longer
@@ -859,6 +917,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     }
     stamp(5);
     if (prof && valid && c == 0) for (int i = 0; i < 6; i++) prof[(size_t)b * 6 + i] = pc[i];
+    if (prof && valid && c == 0) { unsigned long long* tl = prof + (size_t)B * 6 + 1024 + (size_t)b * 3; tl[0] = dbg_tr0; tl[1] = dbg_tr1; tl[2] = (unsigned long long)dbg_n; }      // (the [B][3] region k_solve uses for its timeline)
 
     // ---------------- outputs ----------------
     if (valid) {
@@ -866,15 +925,16 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         if (c < 8) SX[c] = c == 1 ? C.ux_dummy : (c >= 2 && c < 6 ? Q[o.qcurr + c] : (c == 6 ? Q[o.ucurr] : real(0.0)));
         for_slots([&](int j) __attribute__((always_inline)) {
             if (is_act(j)) {
-                // local row -> bit of the 16-bit active mask (the numbering of the embedded stage: pigeon_mpc.h)
-                constexpr int bit[13] = {3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 0, 1, 2};
-                real Tl[NR], Ll[NR]; get_tl(j, Tl, Ll);
+                real Tl[NR], Ll[NR], Cl[NR]; get_tl(j, Tl, Ll); get_cr(j, Cl);
                 const Meta m = get_meta(j);
                 unsigned mask = 0;
+                real* const Lst = O.lam + ((size_t)b * N + c + 16 * j) * 16;
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
                     const bool on = pstat > 0 ? ((m.am >> r) & 1u) : (pmode ? ((m.mi >> r) & 1u) : (Ll[r] > Tl[r]));      // the polish's verified set / the interior point's at hand-over
-                    if (on) mask |= 1u << bit[r];
+                    if (on) mask |= 1u << lat_bit[r];
+                    // multipliers for the next step's warm attempt: the verified set's, else the interior point's (set aside in the second-order slot at the hand-over)
+                    Lst[r] = pstat > 0 ? Ll[r] : (pmode ? Cl[r] : Ll[r]);
                 }
                 O.active[(size_t)b * N + c + 16 * j] = (uint16_t)mask;
             }
@@ -886,6 +946,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             U[0] = d; U[1] = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac; U[2] = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
             O.status[b] = (status == PG_SOLVED && C.polish && pstat < 0) ? PG_SOLVED_UNVERIFIED : status; O.iters[b] = it; O.mu[b] = mu; O.polish[b] = pstat;
             O.solved[b] = 1;      // model_predictive_control.jl:76: solved = true
+            if (O.wfail) {
+                const int lvl = (wf >> 8) & 0xFF, nl = lvl < 5 ? lvl + 1 : 5;
+                O.wfail[b] = !warm ? 0 : (warm_tried ? (warm_failed ? ((nl << 8) | ((1 << nl) - 1)) : 0) : ((lvl << 8) | (((wf & 0xFF) > 0 ? (wf & 0xFF) - 1 : 0))));
+            }
         }
     }
 }

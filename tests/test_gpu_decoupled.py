@@ -6,20 +6,10 @@ import scipy.sparse as sp
 pytestmark = pytest.mark.gpu
 
 
-def embed_sd(orc, sd, ux_dummy=8.0):
-    """Oracle stage data of the lateral QP -> the embedded coupled layout pg_get_qp returns for PG_DECOUPLED handles."""
-    S = orc.unpack_sd(sd); N = orc.N
-    A = np.zeros((N, 6, 6)); A[:, 0, 0] = 1; A[:, 1, 1] = 1; A[:, 2:, 2:] = S["A"]
-    B0 = np.zeros((N, 6, 2)); B0[:, 2:, 0] = S["B0"]; Bf = np.zeros((N, 6, 2)); Bf[:, 2:, 0] = S["Bf"]
-    c = np.zeros((N, 6)); c[:, 2:] = S["c"]
-    return np.concatenate([A.ravel(), B0.ravel(), Bf.ravel(), c.ravel(), S["H"].ravel(), S["G"].ravel(), S["dmin"], S["dmax"], np.ones(N), S["ddmin"], S["ddmax"],
-                           S["dt"], [0.0, ux_dummy], S["q_curr"], [S["d_curr"], 0.0], [0.0, 0.0], [1.0]])
-
-
 @pytest.mark.parametrize("Ns,Nl", [(10, 20), (10, 40)])
 def test_decoupled_matches_oracle(pkg, oracle_mod, skidpad, Ns, Nl):
     B = 64
-    mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, B, N_short=Ns, N_long=Nl, polish=True)      # (off by default for this formulation: see pg_default_config_decoupled)
+    mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, B, N_short=Ns, N_long=Nl, polish=True)
     assert np.array_equal(mpc.u_normalization, [1.0, 1.0])
     orc = oracle_mod.OracleDecoupled(N_short=Ns, N_long=Nl); orc.set_trajectory(skidpad.data)
     assert (orc.n, orc.m) == ((245, 455) if Nl == 20 else (405, 755))
@@ -34,7 +24,7 @@ def test_decoupled_matches_oracle(pkg, oracle_mod, skidpad, Ns, Nl):
         assert np.max(np.abs(qs[b, :, 2:] - oq)) < 1e-9 and np.max(np.abs(us[b] - ou)) <= 1e-9 * max(1, np.max(np.abs(ou)))
         assert np.max(np.abs(qs[b, :, 1] - op[:, 0])) < 1e-9 and np.max(np.abs(ps[b, :, 1] - op[:, 1])) < 1e-12      # Ux parameter, kappa
         sd = orc.update_qp(oq, ou, op, dt)
-        ref = embed_sd(orc, sd)
+        ref = oracle_mod.embed_sd(orc, sd)
         assert np.max(np.abs(qp[b] - ref) / np.maximum(1.0, np.abs(ref))) < 1e-8, b
         xe, ye, info = orc.solve_exact(sd); X = orc.split_x(xe)
         assert info["status"] == 1
@@ -134,34 +124,6 @@ def test_walls_extension_matches_oracle_qp_with_wall_rows(pkg, oracle_mod, skidp
 # ------------------------------------------------------------------------------------------------------------------
 # BASELINE configs[4] at FULL size, in the solver configuration the library ships (pg_default_config_decoupled): every instance against the oracle
 
-def unembed_qp(orc, row):
-    """Inverse of embed_sd: one row of pg_get_qp of a PG_DECOUPLED handle -> the oracle's lateral stage data."""
-    N = orc.N; o = 0
-    def take(n, shape):
-        nonlocal o
-        v = row[o:o + n].reshape(shape); o += n
-        return v
-    A = take(36 * N, (N, 6, 6)); B0 = take(12 * N, (N, 6, 2)); Bf = take(12 * N, (N, 6, 2)); c = take(6 * N, (N, 6))
-    H = take(8 * N, (N, 4, 2)); G = take(4 * N, (N, 4)); dmin = take(N, (N,)); dmax = take(N, (N,)); take(N, (N,)); ddmin = take(N, (N,)); ddmax = take(N, (N,)); dt = take(N, (N,))
-    qc = take(6, (6,)); uc = take(2, (2,))
-    return np.concatenate([A[:, 2:, 2:].ravel(), B0[:, 2:, 0].ravel(), Bf[:, 2:, 0].ravel(), c[:, 2:].ravel(), H.ravel(), G.ravel(), dmin, dmax, ddmin, ddmax, dt, qc[2:], [uc[0]]])
-
-
-def extend_with_walls(orc, qpc, edges, dt, Ww):
-    """Canonical lateral QP + the build-defined wall rows (columns n..n+N-1 = sw_k; rows m+3k: e - sw <= edge_L, m+3k+1: e + sw >= edge_R, m+3k+2: sw >= 0)."""
-    n, m, Nh = orc.n, orc.m, orc.N
-    A = sp.csc_matrix((qpc["Ax"], qpc["Ai"], qpc["Ap"]), shape=(m, n))
-    k = np.arange(Nh); col = 4 * (k + 1) + 3
-    rows = np.concatenate([3 * k, 3 * k, 3 * k + 1, 3 * k + 1, 3 * k + 2]); cols = np.concatenate([col, n + k, col, n + k, n + k])
-    vals = np.concatenate([np.ones(Nh), -np.ones(Nh), np.ones(Nh), np.ones(Nh), np.ones(Nh)])
-    W = sp.csc_matrix((vals, (rows, cols)), shape=(3 * Nh, n + Nh))
-    lw = np.full(3 * Nh, -1e20); uw = np.full(3 * Nh, 1e20)
-    uw[3 * k] = edges[:, 0]; lw[3 * k + 1] = edges[:, 1]; lw[3 * k + 2] = 0.0
-    Aw = sp.vstack([sp.hstack([A, sp.csc_matrix((m, Nh))]), W]).tocsc(); Aw.sort_indices()
-    return dict(Pd=np.concatenate([qpc["Pd"], np.zeros(Nh)]), q=np.concatenate([qpc["q"], Ww * dt]), Ap=Aw.indptr, Ai=Aw.indices, Ax=Aw.data,
-                l=np.concatenate([qpc["l"], lw]), u=np.concatenate([qpc["u"], uw])), Aw
-
-
 def check_lateral_batch_against_oracle(pkg, oracle_mod, tube, mpc, B, Ns, Nl, walls, Ww=1000.0, want_more=False):
     """Every instance of the batch `mpc` just solved: exact optimum of ITS OWN QP data by the oracle (threaded), as a VERIFIED KKT point of the canonical QP
     (OracleDecoupled.solve_exact_verified).  Returns per instance (|delta_2 - delta_2*|, relative objective gap, worst row violation relative to 1 + |A x|_inf, max |delta - delta*| over the
@@ -178,11 +140,11 @@ def check_lateral_batch_against_oracle(pkg, oracle_mod, tube, mpc, B, Ns, Nl, wa
     def work(w):
         o = orcs[w]; out = []
         for b in range(w, B, nthr):
-            sd = unembed_qp(o, qp[b]); qpc = o.assemble_qp(sd)
+            sd = oracle_mod.unembed_qp(o, qp[b]); qpc = o.assemble_qp(sd)
             xg = np.concatenate([x[b, :, 2:6].ravel(), x[b, :, 6], sg[b, :, :2].ravel(), np.diff(x[b, :, 6])])
             if walls:
                 S = o.unpack_sd(sd)
-                qpw, Ac = extend_with_walls(o, qpc, edges[b], S["dt"], Ww)
+                qpw, Ac = oracle_mod.extend_with_walls(o, qpc, edges[b], S["dt"], Ww)
                 xe, ye, info = o.solve_exact_verified(sd, qp=qpw, walls=edges[b], wall_weight=Ww)
                 xg = np.concatenate([xg, sg[b, :, 2]])
             else:

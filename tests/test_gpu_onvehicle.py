@@ -55,12 +55,11 @@ def test_case_matches_the_committed_oracle_vectors(pkg, golden, name):
             mine = set(mpc.canonical_active_set(b, act[b], qp[b])); theirs = set(G["act"][b, 1:1 + G["act"][b, 0]].tolist())
             assert len(mine ^ theirs) <= 2, (b, sorted(mine ^ theirs, key=abs))           # (rows with a multiplier of ~1e-6 in the oracle's solution fall on either side)
     else:
-        from test_gpu_decoupled import embed_sd
         from oracle import oracle as om      # (only its layout helpers: nothing is solved here)
         o = om.OracleDecoupled(**kw)
         assert rel(qs[:, :, 2:6], G["qs"]) < 1e-9 and np.max(np.abs(us - G["us"]) / np.maximum(1.0, np.abs(G["us"]))) < 1e-9
         for b in range(oc.B):
-            ref = embed_sd(o, G["sd"][b])
+            ref = om.embed_sd(o, G["sd"][b])
             assert rel(qp[b], ref) < 1e-8, b
         assert np.max(np.abs(u[:, 0] - G["u"][:, 0])) < 1e-6 and rel(u[:, 1:], G["u"][:, 1:]) < 1e-9
     if name.startswith("singleton"):

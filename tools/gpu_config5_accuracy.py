@@ -14,9 +14,11 @@ polish = None if len(sys.argv) <= 2 else sys.argv[2] == "1"
 pkg = load_pkg(); om.build()
 traj = pkg.load_path_fixture("skidpadoval")
 B, Ns, Nl = 4096, 10, 40
-mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=Ns, N_long=Nl, walls=walls, polish=polish)
+rho = float(os.environ['PG_RHO']) if 'PG_RHO' in os.environ else None          # PG_RHO: polish penalty (default: the library's)
+mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=Ns, N_long=Nl, walls=walls, polish=polish, polish_rho=rho)
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B)
 u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
+print(f"walls={walls} rho={rho} phases {np.round(mpc.phase_ms(), 3)}", flush=True)
 t = time.time()
 res = check_lateral_batch_against_oracle(pkg, om, traj, mpc, B, Ns, Nl, walls, want_more=True)
 x, sg = mpc.solution(); st, it, act, mu = mpc.solve_info()
