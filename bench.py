@@ -363,7 +363,7 @@ def main():
                                                                           "ipm_iters_mean_last_step": float(np.mean(itr_)), "served_by_warm_polish_alone": int((itr_ == 0).sum())}
             mr.close()
 
-    # BASELINE config 5: decoupled (lateral) MPC, N = 50 (N_short = 10, N_long = 40), same batch, cold every step (that formulation has no warm branch)
+    # BASELINE config 5: decoupled (lateral) MPC, N = 50 (N_short = 10, N_long = 40), same batch, cold every step (pg_reset before each: the nodes of that formulation have no warm branch, its solver does)
     dec = None
     if rank == 0 and world == 1 and not args.no_decoupled:
         def run_dec(walls, polish=None):
@@ -371,10 +371,10 @@ def main():
             mpc_d.set_stream(torch.cuda.current_stream().cuda_stream)
             mpc_d.set_inputs_dev(B, d_state.data_ptr(), d_control.data_ptr(), d_t0.data_ptr(), None, d_toff.data_ptr())
             for _ in range(2):
-                mpc_d.step_dev(u_out.data_ptr())
+                mpc_d.reset(); mpc_d.step_dev(u_out.data_ptr())
             torch.cuda.synchronize(); td = time.perf_counter()
             for _ in range(args.steps):
-                mpc_d.step_dev(u_out.data_ptr())
+                mpc_d.reset(); mpc_d.step_dev(u_out.data_ptr())          # (reset: solved = false -- every timed step is a COLD step; k_solve_lat warm-starts otherwise)
             torch.cuda.synchronize(); td = time.perf_counter() - td
             std, itd, _, _ = mpc_d.solve_info(); pd_ = mpc_d.polish_info()
             r = {"value": B * args.steps / td, "unit": "solves/s", "ms_per_step": 1e3 * td / args.steps, "phase_ms": [float(v) for v in mpc_d.phase_ms()],
@@ -388,6 +388,28 @@ def main():
         dec["without_walls_interior_point_only"] = run_dec(False, polish=False)      # (polish = 0, the round-2 default: 5 of these 4096 instances end 1e-6 .. 1e-5 from the optimum)
         dec["accuracy"] = "measured in this run: cpu_baseline.decoupled_n50.accuracy (sample of 128 against verified KKT points, with and without the wall rows)"
         dec["solver"] = "k_solve_lat: Mehrotra interior point on the 5-state stage form (sixteen lanes per instance) to mu <= 3e-6, active-set polish (verified KKT point), interior point resumed to 1e-12 where the polish does not verify"
+
+        # ... and in CLOSED LOOP on the device (pg_simulate_dev; the reference runs the lateral QP with OSQP's WarmStart = true in the same loop as the coupled one,
+        # decoupled_lat_long.jl:139, Pigeon.jl:34): k_solve_lat's warm start of the active set against the same loop without it, on the benchmark batch (random starts:
+        # k_solve_lat ends with its slowest instance, and the instances a warm attempt does not serve set the time of the launch) and on a settled loop
+        def run_loop(path, walls, burn, warm):
+            tj = pkg.load_path_fixture(path)
+            s_, c_, t_, o_ = pkg.synthetic.config2_inputs(tj, B, seed=12345)
+            ml = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), tj, B, N_short=10, N_long=40, device=local, precision=args.precision, walls=walls, warm_polish=warm)
+            ml.set_stream(torch.cuda.current_stream().cuda_stream)
+            ml.set_inputs(s_, c_, t_, time_offset=o_)
+            ml.simulate_(burn); torch.cuda.synchronize(); tl = time.perf_counter()
+            ml.simulate_(40); torch.cuda.synchronize(); tl = time.perf_counter() - tl
+            stl, itl, _, _ = ml.solve_info(); pl = ml.polish_info()
+            ml.step_dev(); torch.cuda.synchronize(); phl = ml.phase_ms()           # (one more step on the last inputs, for its phase times)
+            r = {"value": B * 40 / tl, "unit": "solves/s", "ms_per_step": 1e3 * tl / 40, "solved_last_step": f"{int(pkg.is_solved(stl).sum())}/{B}",
+                 "verified_last_step": f"{int((pl >= 1).sum())}/{B}", "served_by_warm_attempt_alone_last_step": int((itl == 0).sum()), "ipm_iters_mean_last_step": float(np.mean(itl))}
+            ml.close()
+            return r
+        dec["closed_loop"] = {"workload": f"{B} lateral controllers (N = 50) in closed loop on the device, 40 steps of 10 ms behind a burn-in; per step: time grid + projection, k_nodes_dec, k_qp_dec, k_solve_lat, plant RK4",
+                              "benchmark_batch_walls": {"burn_in_steps": 4, "warm_start_of_active_set": run_loop("skidpadoval", True, 4, True), "without_it": run_loop("skidpadoval", True, 4, False)},
+                              "settled_loop_EastPaddock": {"burn_in_steps": 100, "warm_start_of_active_set": run_loop("EastPaddock", False, 100, True), "without_it": run_loop("EastPaddock", False, 100, False)},
+                              "accuracy": "every instance of a warm step <= 1e-6 of the exact optimum of its own QP data: tests/test_gpu_decoupled_closed_loop.py (B = 4096, both loops)"}
 
     # HJI value/gradient lookup (the bandwidth-bound kernel of the path): 2^20 random in-grid relative states against the config-3 grid
     hji = None
