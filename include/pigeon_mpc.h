@@ -55,6 +55,11 @@ enum pg_solve_status {
                                  * random regime of tests/test_gpu_fuzz.py.  A caller that treats it like PG_SOLVED gets round-2 behaviour; with polish = 0 the interior
                                  * point's own convergence is all there is and the status stays PG_SOLVED */
 };
+/* "the solver returned an answer that met its tolerances" (verified or not): what a caller that used to test status == PG_SOLVED most likely means, e.g. the `solved`
+ * decision of the ROS loop (src/ros_integration.jl:127-147).  With the polish on, ~1 % of the N = 50 lateral benchmark instances end PG_SOLVED_UNVERIFIED.
+ * (The warm start of the next step accepts both in k_solve_lat; k_solve, the coupled solver, starts an unverified instance cold: its multipliers at hand-over
+ * belong to a working set that did not verify.) */
+#define PG_IS_SOLVED(st) ((st) == PG_SOLVED || (st) == PG_SOLVED_UNVERIFIED)
 
 /* vehicle dictionary: src/vehicles.jl:1-59; field sets of src/vehicle_dynamics.jl:7-29,272-292 */
 typedef struct pg_vehicle {
@@ -93,17 +98,18 @@ typedef struct pg_config {
                                      * cost  wall_weight * dt_t * sw_t  (soft, like the stability-envelope rows of :193-211); 0 (default) = the reference's QP */
     int32_t _pad2;
     double wall_weight;             /* linear penalty on the wall slack per second (default 1000) */
-    int32_t polish;                 /* 1 (default for the coupled formulation; 0 for the decoupled one, see pg_default_config_decoupled): after the interior point has converged, an active-set polish (OSQP's `polish`, off in the reference's settings,
+    int32_t polish;                 /* 1 (default, both formulations): after the interior point has converged, an active-set polish (OSQP's `polish`, off in the reference's settings,
                                      * src/coupled_lat_long.jl:201-203) solves the equality-constrained problem on the detected active set with the same Riccati passes
                                      * and verifies primal/dual feasibility; removes the sqrt(mu) error of nearly degenerate rows.  0 = interior-point iterate as is */
     int32_t _pad3;
-    double polish_rho;              /* penalty on the active rows inside the polish solves (default 1e7 in the fp64 library, 1e3 in the fp32 one) */
+    double polish_rho;              /* penalty on the active rows inside the polish solves (default 1e7 in the fp64 library, 1e3 in the fp32 one; k_solve_lat, the lateral formulation's kernel for
+                                     * horizons beyond 20 intervals, multiplies it by 1e3 in fp64: see pg_solve_lat.hip) */
     double polish_tol;              /* feasibility tolerance of the polish verification (default 1e-9 / 1e-4) */
     double polish_ipm_tol;          /* with polish = 1 the interior point first stops at this (looser) tolerance and hands over to the polish (default 3e-6 / 1e-4);
                                      * if the polish cannot verify an active set from there (or the sets cycle), the interior point resumes down to ipm_tol and the polish
                                      * gets a second and last chance; if that fails too the interior-point iterate is the answer, exactly as with polish = 0.
                                      * Values <= ipm_tol disable the early hand-over */
-    int32_t warm_polish;            /* 1 (default): an instance whose previous step ended in a solved QP (solved flag set, status PG_SOLVED) first tries the polish from that
+    int32_t warm_polish;            /* 1 (default): an instance whose previous step ended in a solved QP (solved flag set, status PG_SOLVED -- the lateral kernel also accepts PG_SOLVED_UNVERIFIED) first tries the polish from that
                                      * step's active set and multipliers on the new QP data -- the counterpart of the reference's OSQP warm start
                                      * (src/coupled_lat_long.jl:218).  A verified round is the exact optimum of the new QP (iters = 0 then); otherwise the interior point runs
                                      * as for a cold instance.  Ignored when polish = 0 */
@@ -127,7 +133,8 @@ int pg_default_config(pg_config* cfg);
 /* DecoupledTrajectoryTrackingMPC(vehicle, trajectory; ...) defaults: src/decoupled_lat_long.jl:18-33.  The lateral formulation uses the
  * fields V_min, V_max, k_V, k_s, deltadot_max, Q_dpsi, Q_e, W_beta, W_r, R_delta, R_ddelta of pg_control_params; delta is NOT normalised
  * (pg_get_u_normalization returns (1,1)); pg_get_next_control returns delta from the QP and Fx from the seeded node 2 (:275-278).
- * The warm branch does not exist in this formulation (:52-104 always re-seeds), and the HJI row is not part of it. */
+ * The warm branch of the NODES does not exist in this formulation (:52-104 always re-seeds); the solver warm-starts (WarmStart = true, :139: pg_config.warm_polish).
+ * The HJI row is not part of it. */
 int pg_default_config_decoupled(pg_config* cfg);
 
 /* CoupledTrajectoryTrackingMPC(vehicle, trajectory; ...)  src/coupled_lat_long.jl:42-60 (trajectory installed separately) */

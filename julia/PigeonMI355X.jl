@@ -110,7 +110,7 @@ _vehicle(v::Dict{Symbol,Float64}) = PgVehicle((v[k] for k in (:G, :m, :Izz, :L, 
 "CoupledTrajectoryTrackingMPC(vehicle, trajectory; ...) for a batch of B (src/coupled_lat_long.jl:42-60)"
 function BatchedTrajectoryTrackingMPC(vehicle::Dict{Symbol,Float64}, trajectory::TrajectoryTube{Float64}, B::Integer;
                                       control_params=CoupledControlParams(), N_short=10, N_long=20, dt_short=0.01, dt_long=0.2,
-                                      use_correction_step=true, device=0, precision::Symbol=:f64, polish=true, cold_guess=nothing)
+                                      use_correction_step=true, device=0, precision::Symbol=:f64, polish=nothing, warm_polish=nothing, cold_guess=nothing)
     L = lib(precision)
     cfg = Ref{PgConfig}()
     ccall(Libdl.dlsym(L, :pg_default_config), Cint, (Ref{PgConfig},), cfg)          # solver tolerances default to the library's own (they depend on its arithmetic type)
@@ -118,15 +118,15 @@ function BatchedTrajectoryTrackingMPC(vehicle::Dict{Symbol,Float64}, trajectory:
     U = control_params
     cp = PgControlParams(U.V_min, U.V_max, U.k_V, U.k_s, U.δ̇_max, U.Q_Δs, U.Q_Δψ, U.Q_e, U.W_β, U.W_r, U.W_HJI, U.R_δ, U.R_Δδ, U.R_Fx, U.R_ΔFx, U.N_HJI, 0)
     _create(PgConfig(_vehicle(vehicle), cp, N_short, N_long, dt_short, dt_long, use_correction_step, c.rk4_substeps, c.hji_eps, B, device,
-                     c.ipm_max_iter, 0, c.ipm_tol, c.ipm_mu0, 0, 0, c.wall_weight, polish, 0, c.polish_rho, c.polish_tol, c.polish_ipm_tol, c.warm_polish,
-                     cold_guess === nothing ? c.cold_guess : Int32(cold_guess)), L, trajectory, B)
+                     c.ipm_max_iter, 0, c.ipm_tol, c.ipm_mu0, 0, 0, c.wall_weight, polish === nothing ? c.polish : Int32(polish), 0, c.polish_rho, c.polish_tol, c.polish_ipm_tol,
+                     warm_polish === nothing ? c.warm_polish : Int32(warm_polish), cold_guess === nothing ? c.cold_guess : Int32(cold_guess)), L, trajectory, B)
 end
 
 "DecoupledTrajectoryTrackingMPC(vehicle, trajectory; ...) for a batch of B (src/decoupled_lat_long.jl:32-50).  `walls = true` adds the build-defined soft corridor rows
 edge_R - sw <= e <= edge_L + sw from the tube's edge channels (the reference snapshot carries the edges but no constraint reads them, README.md:54)."
 function BatchedDecoupledTrajectoryTrackingMPC(vehicle::Dict{Symbol,Float64}, trajectory::TrajectoryTube{Float64}, B::Integer;
                                                control_params=Pigeon.DecoupledControlParams(), N_short=10, N_long=20, dt_short=0.01, dt_long=0.2,
-                                               use_correction_step=true, device=0, precision::Symbol=:f64, walls=false, wall_weight=1000.0, polish=false)
+                                               use_correction_step=true, device=0, precision::Symbol=:f64, walls=false, wall_weight=1000.0, polish=nothing, warm_polish=nothing)
     L = lib(precision)
     cfg = Ref{PgConfig}()
     ccall(Libdl.dlsym(L, :pg_default_config_decoupled), Cint, (Ref{PgConfig},), cfg)
@@ -134,7 +134,8 @@ function BatchedDecoupledTrajectoryTrackingMPC(vehicle::Dict{Symbol,Float64}, tr
     U = control_params                                # the lateral formulation has no Q_Δs / R_Fx / R_ΔFx / W_HJI / N_HJI: those slots keep the library's defaults
     cp = PgControlParams(U.V_min, U.V_max, U.k_V, U.k_s, U.δ̇_max, d.Q_ds, U.Q_Δψ, U.Q_e, U.W_β, U.W_r, d.W_HJI, U.R_δ, U.R_Δδ, d.R_Fx, d.R_dFx, d.N_HJI, 0)
     _create(PgConfig(_vehicle(vehicle), cp, N_short, N_long, dt_short, dt_long, use_correction_step, c.rk4_substeps, c.hji_eps, B, device,
-                     c.ipm_max_iter, 1, c.ipm_tol, c.ipm_mu0, walls, 0, wall_weight, polish, 0, c.polish_rho, c.polish_tol, c.polish_ipm_tol, c.warm_polish, c.cold_guess), L, trajectory, B)
+                     c.ipm_max_iter, 1, c.ipm_tol, c.ipm_mu0, walls, 0, wall_weight, polish === nothing ? c.polish : Int32(polish), 0, c.polish_rho, c.polish_tol, c.polish_ipm_tol,
+                     warm_polish === nothing ? c.warm_polish : Int32(warm_polish), c.cold_guess), L, trajectory, B)
 end
 
 "mpc.trajectory = latest_trajectory[] (src/ros_integration.jl:53)"

@@ -22,6 +22,7 @@ struct pg_handle {
     bool pipe_fault = false;                                  // PG_PIPE_FAULT=1: fault injection for the pipelined launch (its nodes blocks never publish)
     bool lin_done = false;                                    // this step's launch_nodes already linearised (update_and_solve skips update_QP)
     int* d_progress = nullptr;                                // [cap / 64 + 1] nodes completed per nodes wavefront (k_nodes_linearize)
+    int64_t fallback_total = 0; int fallback_seen = 0;        // pg_get_pipeline_fallbacks: 64-bit total kept on the host, last value of the device's 32-bit word
     int fuse = 0;                                             // pg_step_dev / pg_simulate_dev: linearisation fused into the solve kernel (pg_set_fusion): 0 never (default), 1 always, 2 for all-warm batches
     std::string err;
     // device buffers
@@ -229,15 +230,16 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     }
     if (h->solve_lat) {
         ALLOC(h->d_lat, cap * N * LATP, real); C.lat_pack = h->d_lat;
-        { const char* k = getenv("PG_LAT_MU0_COST"); C.lat_mu0_cost = (real)(k ? atof(k) : 10.0); }
-        { const char* k = getenv("PG_LAT_POLISH2"); C.lat_polish2 = k ? atoi(k) : 1; }
-        { const char* k = getenv("PG_LAT_FAR_COST"); C.lat_far_cost = (real)(k ? atof(k) : 3e4); }
+        // tuning knobs of k_solve_lat (diagnostics; a value that is not a positive finite number keeps the default)
+        auto env_pos = [](const char* name, double dflt) { const char* k = getenv(name); if (!k) return dflt; const double v = atof(k); return (v > 0.0 && v < 1e300) ? v : dflt; };
+        C.lat_mu0_cost = (real)env_pos("PG_LAT_MU0_COST", 10.0);
+        { const char* k = getenv("PG_LAT_POLISH2"); C.lat_polish2 = k ? (atoi(k) != 0) : 1; }
+        C.lat_far_cost = (real)env_pos("PG_LAT_FAR_COST", 3e4);
         { const char* k = getenv("PG_LAT_RHO_SCALE"); const double v = k ? atof(k) : (sizeof(real) == 8 ? 1e3 : 1.0); C.lat_rho_scale = (real)((v > 0.0 && v < 1e12) ? v : 1.0); }
         { const char* k = getenv("PG_LAT_SETTLE"); C.lat_settle = k ? atoi(k) : 0; }
         { const char* k = getenv("PG_LAT_WARM_ROUNDS"); C.lat_warm_rounds = k ? atoi(k) : 4; if (C.lat_warm_rounds < 0) C.lat_warm_rounds = 0; }
         { const char* k = getenv("PG_LAT_WIPM"); C.lat_wipm = k ? atoi(k) : 0; }
-        { const char* k = getenv("PG_LAT_WMU"); C.lat_wmu = (real)(k ? atof(k) : 1e-2); }
-        { const char* k = getenv("PG_LAT_WTAU"); C.lat_wtau = (real)(k ? atof(k) : 1e-4); }
+        C.lat_wmu = (real)env_pos("PG_LAT_WMU", 1e-2); C.lat_wtau = (real)env_pos("PG_LAT_WTAU", 1e-4);
         const char* e = getenv("PG_LAT_MEM");
         h->lat_mem = N > 32 || (e && e[0] == '1');
         if (h->lat_mem) { ALLOC(h->d_lat_ws, lat_ws_bytes(cap), char); C.lat_ws = h->d_lat_ws; }
@@ -287,15 +289,9 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         (void)hipFuncSetAttribute((const void*)k_solve<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
         (void)hipFuncSetAttribute((const void*)k_solve<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
     }
-    {
-        h->lat_lds = lat_lds_doubles(N) * sizeof(real);
-        static size_t lat_attr_max[64] = {0};
-        if (h->solve_lat && h->lat_lds > 48 * 1024 && h->lat_lds > lat_attr_max[dev_slot]) {
-            const int ld = (int)h->lat_lds; lat_attr_max[dev_slot] = h->lat_lds;
-            (void)hipFuncSetAttribute((const void*)k_solve_lat<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ld);
-            (void)hipFuncSetAttribute((const void*)k_solve_lat<1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ld);
-        }
-    }
+    h->lat_lds = lat_lds_doubles(N) * sizeof(real);
+    // (N + 1 <= 64 nodes: at most 4 x 63 x 24 doubles + 72 = 48,960 B, below the 64 KB a launch may ask for without raising the function attribute)
+    if (h->solve_lat && h->lat_lds > 64 * 1024) { g_create_error = "horizon too long for k_solve_lat's LDS staging"; free_all(h); delete h; return PG_ERR_INVALID; }
     *out = h;
     return PG_OK;
 }
@@ -334,10 +330,15 @@ int pg_set_pipeline(pg_handle* h, int32_t mode) { if (!h || mode < 0 || mode > 1
 int pg_set_fusion(pg_handle* h, int32_t mode) { if (!h || mode < 0 || mode > 2) return PG_ERR_INVALID; h->fuse = mode; return PG_OK; }
 int pg_get_pipeline_fallbacks(pg_handle* h, int64_t* count) {
     if (!h || !count) return PG_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->cfg.device));                 // (a multi-GPU process: the copy below must not depend on whichever device happens to be current)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     int v = 0;
     HIPCHK(h, hipMemcpy(&v, h->d_progress + (size_t)h->cfg.batch_capacity / 64 + 5, sizeof(int), hipMemcpyDeviceToHost));
-    *count = v;
+    // the device word is a 32-bit counter of waiting wavefronts that gave up: the host keeps the 64-bit total and folds the device word into it (a wrap of the 32-bit
+    // word between two calls would need 2^31 fall-backs -- at one per 20 ms wait, more than a year of nothing but fall-backs)
+    h->fallback_total += (int64_t)(uint32_t)((uint32_t)v - (uint32_t)h->fallback_seen);
+    h->fallback_seen = v;
+    *count = h->fallback_total;
     return PG_OK;
 }
 int pg_synchronize(pg_handle* h) { if (!h) return PG_ERR_INVALID; HIPCHK(h, hipStreamSynchronize(h->stream)); return PG_OK; }

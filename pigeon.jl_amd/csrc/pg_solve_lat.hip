@@ -1,7 +1,7 @@
 // k_solve_lat: solve! + get_next_control of the LATERAL tracking QP (decoupled_lat_long.jl:134-226,275-278) in its own 5-state stage form -- the dedicated kernel
 // of BASELINE configs[4] (B = 4096, N = 50, + the build-defined wall rows).  Included by pg_kernels.hip inside namespace pg.
 //
-// Stage form (exact; tools/lat_ipm_prototype.py is the numpy twin of this file):  x_k = (Uy, r, dpsi, e, delta)_k, v_k = delta_{k+1} - delta_k (the reference's d-delta
+// Stage form (exact; oracle/lat_ipm_numpy.py is the numpy twin of this file's interior point):  x_k = (Uy, r, dpsi, e, delta)_k, v_k = delta_{k+1} - delta_k (the reference's d-delta
 // variables, :146),  x_{k+1} = Abar_k x_k + Bbar_k v_k + cbar_k  with  Abar = [A  B0+Bf; 0 1], Bbar = [Bf; 1], cbar = [c; 0];  x_0 = (q_curr, delta_curr) fixed (:150-151).
 // Rows of transition k (node k+1, input v_k), slack t >= 0 (local numbering; the bit of the 16-bit active mask pg_get_solve_info reports in brackets):
 //   0 [3]: dmax - delta    1 [4]: delta - dmin    2..5 [6..9]: G_i - H_i (Uy, r) + sigma_{1,1,2,2}    6 [10]: sigma_1    7 [11]: sigma_2    8 [12]: ddmax - v    9 [13]: v - ddmin
@@ -742,9 +742,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
                 mu = row_sum(msr) * intot;
             } else if (!done && !pmode && !want_polish) {
                 mu = mu_new;
-                if (it >= cap && !(cap >= 20 && good >= 3 && it < cap + 20)) done = true;                    // iteration cap (a converging attempt gets twenty more)
-                else if (!(mu == mu) || fabs(mu) > PG_BIG) { status = PG_NUMERICAL; done = true; }
+                // (convergence is tested BEFORE the cap: an instance that meets its tolerances exactly at the cap is solved, not PG_MAX_ITER)
+                if (!(mu == mu) || fabs(mu) > PG_BIG) { status = PG_NUMERICAL; done = true; }
                 else if (mu <= tol_cur && phi * fmax(rp0, real(1.0)) <= tol_cur) { status = PG_SOLVED; if (C.polish && (tol_cur > tol || C.lat_polish2)) want_polish = true; else done = true; }
+                else if (it >= cap && !(cap >= 20 && good >= 3 && it < cap + 20)) done = true;               // iteration cap (a converging attempt gets twenty more)
             }
             if (want_polish) {      // the interior point has converged: the rows with lambda > t are handed to the polish as its first working set, with their multipliers
                 want_polish = false; pmode = 1; pchecks = 0; status = PG_SOLVED; need_a1 = true;

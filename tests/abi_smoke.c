@@ -54,7 +54,7 @@ int main(void) {
     /* second step 10 ms later: the warm branch (solved = true inside the handle) */
     double u2[6]; t0[0] += 0.01; t0[1] += 0.01;
     rc = pg_step(h, 2, state, u, t0, NULL, toff, u2, st, it);
-    CHECK(rc == PG_OK && st[0] == PG_SOLVED && st[1] == PG_SOLVED, "warm pg_step: rc %d status %d %d", rc, st[0], st[1]);
+    CHECK(rc == PG_OK && PG_IS_SOLVED(st[0]) && PG_IS_SOLVED(st[1]), "warm pg_step: rc %d status %d %d", rc, st[0], st[1]);
     CHECK(fabs(u2[0] - u[0]) < 0.05, "warm step jumps: %g -> %g", u[0], u2[0]);
     CHECK(pg_step(h, 3, state, control, t0, NULL, toff, u, st, it) == PG_ERR_INVALID, "B > batch_capacity must be rejected");
     CHECK(pg_destroy(h) == PG_OK, "pg_destroy");

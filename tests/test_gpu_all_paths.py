@@ -43,9 +43,9 @@ def test_path_sweep(pkg, oracle_mod, path, traj_mode):
     # gives up on is one the oracle's exact solver cannot solve either.
     stress = path.startswith("raw:")
     if stress:
-        assert np.mean(status == 1) > 0.3, (path, np.bincount(status))
+        assert np.mean(status == pkg.SOLVED) > 0.3, (path, np.bincount(status))
     else:
-        assert np.all(status == 1), (path, np.bincount(status))
+        assert np.all(status == pkg.SOLVED), (path, np.bincount(status))
     qs, us, ps = mpc.nodes(); qp = mpc.qp_data(); x, _ = mpc.solution(); _, _, act, _ = mpc.solve_info()
     n_unsolved_checked = 0
     for b in range(0, B, 48 if not stress else 16):
@@ -84,9 +84,9 @@ def test_path_sweep(pkg, oracle_mod, path, traj_mode):
         state2[b] = orc.plant_step(state[b], control[b], 0.01)
     u2, status2, _ = mpc.step_(state2, u, t0 + 0.01, time_offset=toff)
     if not stress:
-        assert np.all(status2[sel] == 1)
+        assert np.all(status2[sel] == pkg.SOLVED)
     qp2 = mpc.qp_data(); x2, _ = mpc.solution()
-    for b in [b for b in sel if status2[b] == 1][:3]:
+    for b in [b for b in sel if status2[b] == pkg.SOLVED][:3]:
         xe, ye, info = orc.solve_exact(qp2[b])
         assert rel_inf(x2[b, 1, 6:], orc.split_x(xe)["u"][1]) < 1e-6, (path, b, "warm")
     mpc.close()

@@ -28,7 +28,7 @@ def test_call_order_and_argument_checks(pkg, skidpad):
         m.wall_edges()
     # a valid step still works after the rejected calls, and a smaller batch than the capacity is fine
     u, status, iters = m.step_(state[:5], control[:5], t0[:5], time_offset=toff[:5])
-    assert u.shape == (5, 3) and np.all(status == 1)
+    assert u.shape == (5, 3) and np.all(status == pkg.SOLVED)
     cfg = _lib.pg_config(); lib.pg_default_config(C.byref(cfg))
     h = C.c_void_p()
     cfg.N_short, cfg.N_long = 10, 60                                                     # 71 nodes > 64

@@ -42,7 +42,7 @@ def test_f32_step_against_f64_library(pair):
     m64, m32, state, control, t0, toff = pair
     u64, st64, _ = m64.step_(state, control, t0, time_offset=toff)
     u32, st32, it32 = m32.step_(state, control, t0, time_offset=toff)
-    assert np.all(st64 == 1) and np.all((st32 == 1) | (st32 == 5))            # (5 = PG_SOLVED_UNVERIFIED: an fp32 instance whose polish did not verify)
+    assert np.all(st64 == pkg.SOLVED) and np.all((st32 == pkg.SOLVED) | (st32 == pkg.SOLVED_UNVERIFIED))            # (5 = PG_SOLVED_UNVERIFIED: an fp32 instance whose polish did not verify)
     assert np.array_equal(m64.time_steps()[0], m32.time_steps()[0]) and np.array_equal(m64.time_steps()[1], m32.time_steps()[1])
     un = np.array([m64.u_normalization[0], m64.u_normalization[1], m64.u_normalization[1]])
     err = np.max(np.abs(u32 - u64) / un, axis=1)

@@ -120,11 +120,11 @@ def test_golden_cases_on_gpu(pkg):
         mpc = pkg.BatchedTrajectoryTrackingMPC(traj, 6)
         un = np.array([mpc.u_normalization[0], mpc.u_normalization[1], mpc.u_normalization[1]])
         u1, st, _ = mpc.step_(G[f"{path}_state"], G[f"{path}_control"], G[f"{path}_t0"], time_offset=G[f"{path}_toff"])
-        assert np.all(st == 1)
+        assert np.all(st == pkg.SOLVED)
         assert np.max(np.abs(mpc.qp_data() - G[f"{path}_qp1"]) / np.maximum(1.0, np.abs(G[f"{path}_qp1"]))) < 1e-8
         assert np.max(np.abs(u1 - G[f"{path}_u1"]) / un) < 1e-6
         u2, st, _ = mpc.step_(G[f"{path}_state2"], G[f"{path}_u1"], G[f"{path}_t0"] + 0.01, time_offset=G[f"{path}_toff"])
-        assert np.all(st == 1)
+        assert np.all(st == pkg.SOLVED)
         assert np.max(np.abs(u2 - G[f"{path}_u2"]) / un) < 1e-6
 
 
@@ -135,7 +135,7 @@ def test_ragged_and_tiny_batches(pkg, skidpad):
     ub, st, _ = big.step_(state, control, t0, time_offset=toff)
     one = pkg.BatchedTrajectoryTrackingMPC(skidpad, 1)
     u1, st1, _ = one.step_(state[:1], control[:1], t0[:1], time_offset=toff[:1])
-    assert st1[0] == 1 and np.array_equal(u1[0], ub[0])
+    assert st1[0] == pkg.SOLVED and np.array_equal(u1[0], ub[0])
     part = pkg.BatchedTrajectoryTrackingMPC(skidpad, 70)
     up, stp, _ = part.step_(state[:37], control[:37], t0[:37], time_offset=toff[:37])
     assert np.array_equal(up, ub[:37])
@@ -158,12 +158,12 @@ def test_closed_loop_on_device_matches_oracle(pkg, oracle_mod, skidpad):
         assert np.max(np.abs(qh[k] - q) / np.maximum(1.0, np.abs(q))) < 1e-5, k
         assert np.max(np.abs(uh[k] - u) / un) < 1e-5, k
         unext, _, it, st, _ = orc.step_batch(q, u, tt, time_offsets=toff, solver=0)
-        assert np.all(st == 1)
+        assert np.all(st == pkg.SOLVED)
         q = np.stack([orc.plant_step(q[b], u[b], 0.01) for b in range(Bc)])
         u = unext; tt = tt + 0.01
     assert np.max(np.abs(s - q) / np.maximum(1.0, np.abs(q))) < 1e-5 and np.max(np.abs(c - u) / un) < 1e-5 and np.allclose(t, tt)
     st, it, act, mu = mpc.solve_info()
-    assert np.all(st == 1)
+    assert np.all(st == pkg.SOLVED)
 
 
 def test_warm_start_of_the_active_set_is_exact_and_mostly_sufficient(pkg, skidpad):

@@ -63,7 +63,7 @@ def test_constraint_rows_and_solve_with_hji(pkg, oracle_mod, skidpad, grid):
             assert abs(Vv[i] - Vo) <= 1e-12 * max(1, abs(Vo))
             assert np.max(np.abs(M[i] - Mo)) <= 1e-9 * max(1.0, np.max(np.abs(Mo))) and abs(b[i] - bo) <= 1e-9 * max(1.0, abs(bo)), i
     assert nact >= B // 2
-    assert np.all(status == 1), status
+    assert np.all(status == pkg.SOLVED), status
     qp = mpc.qp_data(); x, sg = mpc.solution(); st, it, act, mu = mpc.solve_info()
     worst = 0.0
     for i in range(B):
@@ -102,7 +102,7 @@ def test_hji_fallback_policy(pkg, oracle_mod, skidpad, grid):
     toff[::5] = np.nan                                               # path-tracking mode never hands over (tracking_mode != :traj)
     other = pkg.synthetic.other_cars(state, seed=9)
     u_mpc, status, _ = mpc.step_(state, control, t0, other_car_state=other, time_offset=toff)
-    assert np.all(status == 1)
+    assert np.all(status == pkg.SOLVED)
     u_on, src_on, u2 = mpc.get_next_control_hji(True)
     u_off, src_off, _ = mpc.get_next_control_hji(False)
     P = mpc.vehicle

@@ -80,7 +80,7 @@ def test_solve_matches_exact_optimum(setup, oracle_mod):
     mpc, orc, state, control, t0, toff = setup
     mpc.reset()
     u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
-    assert np.all(status == 1), status
+    assert np.all(status == pkg.SOLVED), status
     qp = mpc.qp_data()
     x, sg = mpc.solution()
     st, it, act, mu = mpc.solve_info()
@@ -110,7 +110,7 @@ def test_warm_second_step(setup):
     # advance the plant with the OLD control (simulate semantics, model_predictive_control.jl:94-95) using the oracle's plant model
     state2 = np.stack([orc.plant_step(state[b], control[b], 0.01) for b in range(B_SMALL)])
     u2, status2, _ = mpc.step_(state2, u1, t0 + 0.01, time_offset=toff)
-    assert np.all(status2 == 1)
+    assert np.all(status2 == pkg.SOLVED)
     qs, us, ps = mpc.nodes()
     qp = mpc.qp_data()
     x2, _ = mpc.solution()
@@ -134,7 +134,7 @@ def test_gpu_against_the_independent_numpy_spec(pkg):
     state, control, t0, toff = pkg.synthetic.config2_inputs(traj, n, seed=404, s_range=(5.0, 30.0))
     mpc = pkg.BatchedTrajectoryTrackingMPC(traj, n)
     u, st, _ = mpc.step_(state, control, t0, time_offset=toff)
-    assert np.all(st == 1)
+    assert np.all(st == pkg.SOLVED)
     ts_g, dt_g, _ = mpc.time_steps(); qs_g, us_g, ps_g = mpc.nodes(); qp_g = mpc.qp_data(); x_g, _ = mpc.solution()
     P, U, T = S.X1(), S.coupled_control_params(), S.Trajectory(traj.data)
     for b in range(n):

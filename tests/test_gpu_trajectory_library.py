@@ -47,7 +47,7 @@ def test_library_step_matches_single_trajectory_oracles(pkg, oracle_mod, library
     mpc = pkg.BatchedTrajectoryTrackingMPC(tubes, B)
     mpc.set_trajectory_index(idx)
     u, status, _ = mpc.step_(state, control, t0, time_offset=toff)
-    assert np.all(status == 1), status
+    assert np.all(status == pkg.SOLVED), status
     sep = mpc.path_coordinates(); qs, us, ps = mpc.nodes(); qp = mpc.qp_data(); x, _ = mpc.solution()
     for b in range(B):
         orc = orcs[idx[b]]
@@ -87,7 +87,7 @@ def test_long_tube_unstaged_nodes_kernel(pkg, oracle_mod, library):
     state, control, t0, toff = pkg.synthetic.config2_inputs(dense, n, seed=5)
     mpc = pkg.BatchedTrajectoryTrackingMPC(dense, n)
     u, status, _ = mpc.step_(state, control, t0, time_offset=toff)
-    assert np.all(status == 1)
+    assert np.all(status == pkg.SOLVED)
     qs, us, ps = mpc.nodes()
     orc = make_oracle(oracle_mod, dense)
     for b in range(n):
