@@ -256,6 +256,12 @@ int pg_get_solve_info(pg_handle* h, int32_t* status, int32_t* iters, uint16_t* a
 /* outcome of the active-set polish per instance, [B]: 0 = not run (polish off, or the interior point did not converge), k >= 1 = verified in round k (the
  * solution is the exact optimum on its active set), -1 = did not verify (the interior-point iterate at ipm_tol was kept) */
 int pg_get_polish_info(pg_handle* h, int32_t* polish);
+/* multipliers of the inequality rows as the last solve left them, lam [B][N][16], indexed like the bits of the `active` masks (the next step's warm start reads them).
+ * A verified instance (pg_get_polish_info >= 1): the multipliers of its verified working set, 0 off the set -- with the masks, the dual half of the KKT point; the
+ * CANONICAL active-set rule of the parity tests is "bit set AND multiplier > 1e-6" (a row held at its bound with a zero multiplier is degenerate: the QP does not say
+ * which side of "active" it is on), the same rule the oracle applies to its own multipliers.  An unverified instance: the interior point's multipliers at the hand-over
+ * (k_solve_lat) or the estimates of the last working set tried (k_solve) -- not a certificate. */
+int pg_get_multipliers(pg_handle* h, double* lam);
 /* milliseconds of the last pg_step_dev per phase: time_steps+nodes, update_qp (linearize, limits, HJI), solve (+extract); HIP events */
 int pg_get_phase_ms(pg_handle* h, float out3[3]);
 

@@ -205,6 +205,14 @@ function polish_info(mpc::BatchedTrajectoryTrackingMPC)
     p
 end
 
+"Multipliers of the inequality rows of the last solve, [16, N, B] (column-major view of the ABI's [B][N][16]), indexed like the bits of the active masks"
+function multipliers(mpc::BatchedTrajectoryTrackingMPC)
+    N = (Int(ccall(sym(mpc, :pg_qp_len), Cint, (Ptr{Cvoid},), mpc.handle)) - 11) ÷ 84          # pg_qp_len = 84 N + 11
+    lam = Array{Float64}(undef, 16, N, mpc.B)
+    check(mpc, ccall(sym(mpc, :pg_get_multipliers), Cint, (Ptr{Cvoid}, Ptr{Float64}), mpc.handle, lam), "pg_get_multipliers")
+    lam
+end
+
 "update_QP! inside the solve kernel for step! / simulate! (pg_set_fusion; bit-identical results): mode 0 never (default), 1 always, 2 for all-warm batches"
 function set_fusion!(mpc::BatchedTrajectoryTrackingMPC, mode::Integer)
     check(mpc, ccall(sym(mpc, :pg_set_fusion), Cint, (Ptr{Cvoid}, Int32), mpc.handle, Int32(mode)), "pg_set_fusion")

@@ -1006,6 +1006,11 @@ int pg_get_polish_info(pg_handle* h, int32_t* polish) {
     REQUIRE(h, polish, "polish is null");
     return down_raw(h, polish, h->d_polish, (size_t)h->B * 4);
 }
+int pg_get_multipliers(pg_handle* h, double* lam) {
+    int rc = check_ready(h); if (rc) return rc;
+    REQUIRE(h, lam, "lam is null");
+    return down(h, lam, h->d_lam, (size_t)h->B * h->dc.N * 16);
+}
 int pg_get_walls(pg_handle* h, double* edges) {
     int rc = check_ready(h); if (rc) return rc;
     if (!h->dc.walls) { h->err = "walls are off (pg_config.walls = 0)"; return PG_ERR_STATE; }

@@ -623,7 +623,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         const real* Lp = O.lam + ((size_t)b * N + (is_act(j) ? c + 16 * j : N - 1)) * 16;
 #pragma unroll
         for (int r = 0; r < NR; r++) {
-            const real lw = wipm ? fmax(fmax(Lp[r], real(0.0)), C.lat_wmu * lat_rcp(Tl[r])) : mu0i * lat_rcp(Tl[r]);
+            const real lw = wipm ? fmax(fmax(Lp[lat_bit[r]], real(0.0)), C.lat_wmu * lat_rcp(Tl[r])) : mu0i * lat_rcp(Tl[r]);
             Ll[r] = is_act(j) ? lw : real(1.0); ms_next += is_act(j) ? Tl[r] * Ll[r] : real(0.0);
         }
         put_tl(j, Tl, Ll);
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             const real* Lp = O.lam + ((size_t)b * N + s) * 16;
             unsigned mk = 0u;
 #pragma unroll
-            for (int r = 0; r < NR; r++) { const bool a = (pm >> lat_bit[r]) & 1u; mk |= a ? (1u << r) : 0u; Ll[r] = a ? Lp[r] : real(0.0); }
+            for (int r = 0; r < NR; r++) { const bool a = (pm >> lat_bit[r]) & 1u; mk |= a ? (1u << r) : 0u; Ll[r] = a ? Lp[lat_bit[r]] : real(0.0); }
             put_tl(j, Tl, Ll);
             Meta m; m.am = mk; m.mi = mk; m.nm = mk; put_meta(j, m);
         });
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
                     const bool on = pstat > 0 ? ((m.am >> r) & 1u) : (pmode ? ((m.mi >> r) & 1u) : (Ll[r] > Tl[r]));      // the polish's verified set / the interior point's at hand-over
                     if (on) mask |= 1u << lat_bit[r];
                     // multipliers for the next step's warm attempt: the verified set's, else the interior point's (set aside in the second-order slot at the hand-over)
-                    Lst[r] = pstat > 0 ? Ll[r] : (pmode ? Cl[r] : Ll[r]);
+                    Lst[lat_bit[r]] = pstat > 0 ? Ll[r] : (pmode ? Cl[r] : Ll[r]);      // (indexed like the mask bits: pg_get_multipliers)
                 }
                 O.active[(size_t)b * N + c + 16 * j] = (uint16_t)mask;
             }

@@ -306,6 +306,12 @@ class BatchedTrajectoryTrackingMPC:
         self._chk(self.lib.pg_get_polish_info(self.h, _p(p, C.POINTER(C.c_int32))), "pg_get_polish_info")
         return p
 
+    def multipliers(self):
+        """Multipliers of the inequality rows of the last solve [B, N, 16], indexed like the bits of the active masks (include/pigeon_mpc.h pg_get_multipliers)."""
+        lam = np.zeros((self.B, self.N, 16))
+        self._chk(self.lib.pg_get_multipliers(self.h, _p(lam)), "pg_get_multipliers")
+        return lam
+
     def hji_constraint(self):
         M = np.zeros((self.B, 2)); b = np.zeros(self.B); V = np.zeros(self.B)
         self._chk(self.lib.pg_get_hji_constraint(self.h, _p(M), _p(b), _p(V)), "pg_get_hji_constraint")
@@ -337,9 +343,11 @@ class BatchedTrajectoryTrackingMPC:
         return V, rgb, cx, cy
 
     # ---- canonical active-set indices (row numbering of the reference's QP) ----
-    def canonical_active_set(self, b, act_masks, qp_row):
+    def canonical_active_set(self, b, act_masks, qp_row, lam=None, tol=1e-6):
         """Signed 1-based row indices of the reference QP that are active for instance b: +i upper bound, -i lower bound.
-        act_masks: [N] uint16 from solve_info(); qp_row: this instance's pg_get_qp block (for the fixed first node)."""
+        act_masks: [N] uint16 from solve_info(); qp_row: this instance's pg_get_qp block (for the fixed first node).
+        lam: this instance's multipliers [N, 16] (multipliers()[b]): with them the CANONICAL rule applies -- a row is active when its bit is set AND its multiplier
+        exceeds tol, the rule oracle.active_set applies to the oracle's multipliers (rows held with a zero multiplier are degenerate: either side is a KKT point)."""
         N, Ns = self.N, self.N_short
         cp = self.control_params
         r_C1 = 0; r_C2 = r_C1 + 2 * N; r_C3 = r_C2 + Ns; r_C4 = r_C3 + N; r_C5 = r_C4 + N; r_C6 = r_C5 + N + 1; r_C7 = r_C6 + N + 1
@@ -355,7 +363,7 @@ class BatchedTrajectoryTrackingMPC:
                 out.append(-(r_C2 + 0 + 1))
         for k in range(N):
             m = int(act_masks[k]); node = k + 1
-            bit = lambda j: (m >> j) & 1
+            bit = lambda j: ((m >> j) & 1) and (lam is None or lam[k][j] > tol)
             if bit(0): out.append(-(r_C5 + node + 1))
             if bit(1): out.append(+(r_C6 + node + 1))
             if bit(2): out.append(-(r_C7 + node + 1))
@@ -385,15 +393,16 @@ def DecoupledTrajectoryTrackingMPC(vehicle, trajectory, batch_capacity=1, **kw):
     return BatchedTrajectoryTrackingMPC(trajectory, batch_capacity, vehicle=vehicle, formulation="decoupled", **kw)
 
 
-def decoupled_canonical_active_set(N, N_short, act_masks, walls=False):
-    """Signed 1-based active rows of the reference's LATERAL QP (decoupled_lat_long.jl:166-211 row order) from the per-stage masks.
+def decoupled_canonical_active_set(N, N_short, act_masks, walls=False, lam=None, tol=1e-6):
+    """Signed 1-based active rows of the reference's LATERAL QP (decoupled_lat_long.jl:166-211 row order) from the per-stage masks (lam [N, 16]: the canonical rule of
+    BatchedTrajectoryTrackingMPC.canonical_active_set -- bit set and multiplier > tol).
     With the wall extension the 3N wall rows are numbered after the reference's rows: (e - sw <= edge_L, e + sw >= edge_R, sw >= 0) per node 2..N+1."""
     Ns, Nl = N_short, N - N_short
     r_1 = 0; r_2 = 2 * N; r_3 = r_2 + N; r_4 = r_3 + 4; r_5 = r_4 + 1; r_6 = r_5 + 4 * Ns; r_7 = r_6 + 4 * Nl
     out = []
     for k in range(N):
         m = int(act_masks[k]); base = r_7 + 8 * k
-        bit = lambda j: (m >> j) & 1
+        bit = lambda j: ((m >> j) & 1) and (lam is None or lam[k][j] > tol)
         if bit(3): out.append(+(base + 0 + 1))
         if bit(4): out.append(-(base + 1 + 1))
         for i in range(4):

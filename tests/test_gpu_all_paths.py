@@ -46,7 +46,7 @@ def test_path_sweep(pkg, oracle_mod, path, traj_mode):
         assert np.mean(status == pkg.SOLVED) > 0.3, (path, np.bincount(status))
     else:
         assert np.all(status == pkg.SOLVED), (path, np.bincount(status))
-    qs, us, ps = mpc.nodes(); qp = mpc.qp_data(); x, _ = mpc.solution(); _, _, act, _ = mpc.solve_info()
+    qs, us, ps = mpc.nodes(); qp = mpc.qp_data(); x, _ = mpc.solution(); _, _, act, _ = mpc.solve_info(); lam = mpc.multipliers()
     n_unsolved_checked = 0
     for b in range(0, B, 48 if not stress else 16):
         if status[b] != 1:
@@ -76,7 +76,7 @@ def test_path_sweep(pkg, oracle_mod, path, traj_mode):
         xe, ye, info = orc.solve_exact(qp[b])
         assert info["status"] == 1
         assert rel_inf(x[b, 1, 6:], orc.split_x(xe)["u"][1]) < 1e-6, (path, b)
-        assert mpc.canonical_active_set(b, act[b], qp[b]) == oracle_mod.active_set(orc.assemble_qp(qp[b]), xe, ye, tol=1e-6), (path, b)
+        assert mpc.canonical_active_set(b, act[b], qp[b], lam=lam[b]) == oracle_mod.active_set(orc.assemble_qp(qp[b]), xe, ye, tol=1e-6), (path, b)
     # second (warm) step on the same handle: plant advanced by the oracle's model with the old control (simulate semantics)
     sel = np.arange(0, B, 48)
     state2 = state.copy()

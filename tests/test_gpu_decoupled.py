@@ -16,7 +16,7 @@ def test_decoupled_matches_oracle(pkg, oracle_mod, skidpad, Ns, Nl):
     state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B, seed=31, traj_mode=(Nl == 20))
     u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
     assert np.all(pkg.is_solved(status)), status      # (PG_SOLVED_UNVERIFIED: instances whose polish did not verify keep the interior-point iterate; compared below like the rest)
-    qs, us, ps = mpc.nodes(); qp = mpc.qp_data(); x, sg = mpc.solution(); st, it, act, mu = mpc.solve_info()
+    qs, us, ps = mpc.nodes(); qp = mpc.qp_data(); x, sg = mpc.solution(); st, it, act, mu = mpc.solve_info(); lam = mpc.multipliers()
     worst = 0.0
     for b in range(B):
         ts, dt = orc.time_steps(t0[b])
@@ -43,7 +43,7 @@ def test_decoupled_matches_oracle(pkg, oracle_mod, skidpad, Ns, Nl):
         assert np.all(x[b, :, 0] == 0) and np.all(x[b, :, 7] == 0) and np.max(np.abs(x[b, :, 1] - 8.0)) < 1e-12
         uo = orc.next_control(X["delta"][1], ou[1, 1])                       # decoupled_lat_long.jl:275-278
         assert abs(u[b, 0] - uo[0]) < 1e-6 and np.max(np.abs(u[b, 1:] - uo[1:])) <= 1e-9 * max(1.0, np.max(np.abs(uo)))
-        assert pkg.decoupled_canonical_active_set(orc.N, Ns, act[b]) == oracle_mod.active_set(qpc, xe, ye, tol=1e-6), b
+        assert pkg.decoupled_canonical_active_set(orc.N, Ns, act[b], lam=lam[b]) == oracle_mod.active_set(qpc, xe, ye, tol=1e-6), b
     assert worst < 1e-6, worst
 
 

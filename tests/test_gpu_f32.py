@@ -38,7 +38,7 @@ def test_precision_bits(pkg):
     assert pkg.load_library("f64").pg_precision_bits() == 64 and pkg.load_library("f32").pg_precision_bits() == 32
 
 
-def test_f32_step_against_f64_library(pair):
+def test_f32_step_against_f64_library(pair, pkg):
     m64, m32, state, control, t0, toff = pair
     u64, st64, _ = m64.step_(state, control, t0, time_offset=toff)
     u32, st32, it32 = m32.step_(state, control, t0, time_offset=toff)
@@ -122,6 +122,31 @@ def test_f32_decoupled_n50(pkg, skidpad):
     d64.close(); d32.close()
 
 
+@pytest.mark.parametrize("walls", [False, True])
+def test_f32_config5_full_size_every_instance_against_the_oracle(pkg, oracle_mod, skidpad, walls):
+    """BASELINE configs[4] in fp32 ("fp64 and fp32"): B = 4096 lateral MPCs, N = 50, with and without the wall rows, the fp32 library's answer for EVERY
+    instance against the ORACLE's exact optimum (a verified KKT point of the canonical QP, fp64) of the fp32 library's OWN QP data -- not against the fp64 library.
+    The bars state what single precision delivers on an open-loop unstable 8 s horizon (a Riccati recursion whose cost-to-go spans twelve decades), measured in
+    round 4 (tools/gpu_config5_accuracy.py with PG_PREC=f32): at least 99.5 % of the instances solve (about 15 of 4096 stop at the iteration cap, at most a few end
+    PG_NUMERICAL), and over the solved ones the applied steering is within 1e-2 rad of the optimum (measured 6.0e-3 / 3.5e-3), 99th percentile within 3e-3 (1.2e-3 /
+    1.7e-3), median within 2e-5 (9e-7 / 5e-6).  fp64 is the precision this configuration should be run in (every instance <= 1e-6: tests/test_gpu_decoupled.py)."""
+    from test_gpu_decoupled import check_lateral_batch_against_oracle
+    B, Ns, Nl = 4096, 10, 40
+    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B)
+    state, control = f32_round(state), f32_round(control)
+    d32 = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, B, N_short=Ns, N_long=Nl, precision="f32", walls=walls)
+    u, status, iters = d32.step_(state, control, t0, time_offset=toff)
+    ok = pkg.is_solved(status)
+    assert np.mean(ok) >= 0.995 and np.sum(status == pkg.NUMERICAL) <= 4, np.bincount(status)
+    res = check_lateral_batch_against_oracle(pkg, oracle_mod, skidpad, d32, B, Ns, Nl, walls)
+    assert np.all(res[:, 4] == 1) and np.all(res[:, 5] >= 1)                      # the oracle's side: a verified KKT point of every instance's (fp32-rounded) QP data
+    e = res[ok, 0]
+    print(f"fp32 config 5 walls={walls}: solved {int(ok.sum())}/{B} (status {np.bincount(status)}), |d2-d2*| max {e.max():.2e} p99 {np.percentile(e, 99):.2e} median {np.median(e):.1e}, "
+          f"iterations mean {iters.mean():.1f} max {iters.max()}")
+    assert e.max() <= 1e-2 and np.percentile(e, 99) <= 3e-3 and np.median(e) <= 2e-5, (e.max(), np.percentile(e, 99), np.median(e))
+    d32.close()
+
+
 def test_config3_full_size_grid_and_batch(pkg, oracle_mod, skidpad):
     """BASELINE configs[2] as stated: B = 4096, fp32, HJI safety row on the 13x13x9x9x9x9x9 grid (10 M nodes, 19 GB of cell records on the device),
     default HJI_eps = 0.05.  Every instance solves; the rows that are active (V <= eps) and a sample of the others are compared with the oracle."""
@@ -146,12 +171,27 @@ def test_config3_full_size_grid_and_batch(pkg, oracle_mod, skidpad):
         assert abs(Vv[i] - Vo) <= 5e-5 * max(1, abs(Vo)), i
         if abs(Vo - 0.05) > 1e-4:                                                       # (a value within fp32 rounding of eps may fall on either side)
             assert np.max(np.abs(M[i] - Mo)) <= 3e-3 * max(1.0, np.max(np.abs(Mo))) and abs(b[i] - bo) <= 3e-3 * max(1.0, abs(bo)), i
+    # solve accuracy: EVERY one of the 4096 instances against the exact optimum of its own QP data (threaded oracle, as for config 2 in fp64)
+    import os
+    from concurrent.futures import ThreadPoolExecutor
     x, sg = m32.solution(); qp = m32.qp_data()
-    errs = []
-    for i in list(np.flatnonzero(active)[:24]) + list(range(0, n, 256)):
-        xe, ye, info = orc.solve_exact(qp[i])
-        errs.append(np.max(np.abs(x[i, 1, 6:] - orc.split_x(xe)["u"][1])))
-    assert np.max(errs) <= 1e-3, np.max(errs)
+    nthr = min(16, len(os.sched_getaffinity(0)))
+    orcs = [make_oracle(oracle_mod, skidpad) for _ in range(nthr)]
+
+    def work(w):
+        o = orcs[w]; out = []
+        for i in range(w, n, nthr):
+            xe, ye, info = o.solve_exact(qp[i])
+            out.append((float(np.max(np.abs(x[i, 1, 6:] - o.split_x(xe)["u"][1]))), info["status"]))
+        return out
+    with ThreadPoolExecutor(nthr) as ex:
+        parts = list(ex.map(work, range(nthr)))
+    errs = np.zeros(n); ost = np.zeros(n, int)
+    for w, part in enumerate(parts):
+        errs[w:n:nthr] = [p[0] for p in part]; ost[w:n:nthr] = [p[1] for p in part]
+    assert np.all(ost == 1)
+    print(f"config 3, every instance: max |u2-u2*| (normalised) {errs.max():.2e}, p99 {np.percentile(errs, 99):.2e}, median {np.median(errs):.1e}; over the {int(active.sum())} instances with an active safety row: {errs[active].max():.2e}")
+    assert errs.max() <= 1e-3 and np.median(errs) <= 1e-5, (errs.max(), np.median(errs))
     m32.close()
 
 

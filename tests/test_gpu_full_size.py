@@ -78,13 +78,13 @@ def test_accuracy_of_every_instance_of_the_batch(run, oracle_mod, skidpad, pkg):
       * applied control and every control of the horizon <= 1e-6 (measured: 5e-11 / 4e-9, through the active-set rounds as through the interior point -- the active-set polish removed the sqrt(mu) tail that left
         3 of 4096 instances at 1e-6..3e-6 in round 1);
       * whole primal solution (states) <= 1e-6 relative;
-      * the signed canonical active-set list identical to the oracle's, except on rows that are degenerate in the oracle's own solution
-        (|multiplier| <= 1e-6 there: which side of "active" such a row falls on is not defined by the QP);
+      * the signed canonical active-set list IDENTICAL to the oracle's for every instance, under one rule applied on both sides: a row is active when its multiplier
+        exceeds 1e-6 (a row at its bound with a zero multiplier is degenerate -- the QP does not define which side of "active" it falls on; pg_get_multipliers);
       * every instance polished (verified KKT point), none fell back to the interior-point iterate."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as om
     mpc, state, control, t0, toff, u, status, iters = run
-    qp = mpc.qp_data(); x, _ = mpc.solution(); _, _, act, _ = mpc.solve_info(); pol = mpc.polish_info()
+    qp = mpc.qp_data(); x, _ = mpc.solution(); _, _, act, _ = mpc.solve_info(); pol = mpc.polish_info(); lam = mpc.multipliers()
     assert np.all(pol >= 1), np.bincount(pol + 1)
     nthr = min(16, len(os.sched_getaffinity(0)))
     orcs = [make_oracle(oracle_mod, skidpad) for _ in range(nthr)]
@@ -97,19 +97,21 @@ def test_accuracy_of_every_instance_of_the_batch(run, oracle_mod, skidpad, pkg):
             e_u2 = float(np.max(np.abs(x[b, 1, 6:] - X["u"][1]))); e_u = float(np.max(np.abs(x[b, :, 6:] - X["u"])))
             e_q = float(np.max(np.abs(x[b, :, :6] - X["q"]) / np.maximum(1.0, np.abs(X["q"]))))
             Q = o.assemble_qp(qp[b])
-            mine = set(mpc.canonical_active_set(b, act[b], qp[b])); theirs = set(om.active_set(Q, xe, ye, tol=1e-6))
+            # ONE rule on both sides: a row is active when its multiplier exceeds 1e-6 (mine: bit of the verified working set AND multiplier; theirs: multiplier)
+            mine = set(mpc.canonical_active_set(b, act[b], qp[b], lam=lam[b])); theirs = set(om.active_set(Q, xe, ye, tol=1e-6))
             diff = mine ^ theirs
-            bad = [i for i in diff if abs(ye[abs(i) - 1]) > 1e-4]          # a disagreement on a row the oracle holds with a real multiplier
-            out.append((e_u2, e_u, e_q, len(bad), len(diff)))
+            # (a multiplier within 1e-9 of the threshold itself may fall on either side of it: not counted, reported)
+            near = [i for i in diff if abs(abs(ye[abs(i) - 1]) - 1e-6) <= 1e-9]
+            out.append((e_u2, e_u, e_q, len(diff) - len(near), len(near)))
         return out
     with ThreadPoolExecutor(nthr) as ex:
         res = np.array(sum(ex.map(work, range(nthr)), []))
     assert res.shape == (B, 5)
     assert res[:, 0].max() <= 1e-6 and res[:, 1].max() <= 1e-6 and res[:, 2].max() <= 1e-6, res.max(axis=0)
     assert np.median(res[:, 0]) <= 1e-11
-    assert res[:, 3].sum() == 0, int(res[:, 3].sum())
-    assert np.mean(res[:, 4] == 0) >= 0.98                            # and the lists are IDENTICAL for (nearly) all instances
-    print(f"max |u2-u2*| {res[:, 0].max():.2e}, max |u-u*| {res[:, 1].max():.2e}, max rel |q-q*| {res[:, 2].max():.2e}, identical active-set lists {int((res[:, 4] == 0).sum())}/{B}")
+    print(f"max |u2-u2*| {res[:, 0].max():.2e}, max |u-u*| {res[:, 1].max():.2e}, max rel |q-q*| {res[:, 2].max():.2e}, identical active-set lists {int((res[:, 3] == 0).sum())}/{B}"
+          f" (rows whose multiplier sits within 1e-9 of the 1e-6 threshold: {int(res[:, 4].sum())})")
+    assert res[:, 3].sum() == 0, (int(res[:, 3].sum()), np.flatnonzero(res[:, 3])[:8])          # the signed index lists are IDENTICAL for every one of the 4096 instances
 
 
 def test_golden_cases_on_gpu(pkg):

@@ -64,13 +64,13 @@ def test_constraint_rows_and_solve_with_hji(pkg, oracle_mod, skidpad, grid):
             assert np.max(np.abs(M[i] - Mo)) <= 1e-9 * max(1.0, np.max(np.abs(Mo))) and abs(b[i] - bo) <= 1e-9 * max(1.0, abs(bo)), i
     assert nact >= B // 2
     assert np.all(status == pkg.SOLVED), status
-    qp = mpc.qp_data(); x, sg = mpc.solution(); st, it, act, mu = mpc.solve_info()
+    qp = mpc.qp_data(); x, sg = mpc.solution(); st, it, act, mu = mpc.solve_info(); lam = mpc.multipliers()
     worst = 0.0
     for i in range(B):
         xe, ye, info = orc.solve_exact(qp[i]); X = orc.split_x(xe)
         worst = max(worst, float(np.max(np.abs(x[i, 1, 6:] - X["u"][1]))))
         qpc = orc.assemble_qp(qp[i])
-        assert mpc.canonical_active_set(i, act[i], qp[i]) == oracle_mod.active_set(qpc, xe, ye, tol=1e-6), i
+        assert mpc.canonical_active_set(i, act[i], qp[i], lam=lam[i]) == oracle_mod.active_set(qpc, xe, ye, tol=1e-6), i
         # the penalised slacks of nodes 2 and 3 (sigma_HJI, N_HJI = 3) match the canonical solution
         assert np.max(np.abs(sg[i, :2, 2] - X["sigma_hji"][1:3])) < 1e-6
     assert worst < 1e-6, worst

@@ -5,8 +5,7 @@
     DecoupledTrajectoryTrackingMPC(X1(), straight_trajectory(30., 5.)) from state (0, 0, 0, 5, 0, 0): the on-vehicle horizon on a TWO-node tube;
   * use_correction_step = false (model_predictive_control.jl:22-24), R_delta, R_Fx > 0 (coupled_lat_long.jl:36-37), N_HJI = 10, rk4_substeps = 4, dt_long = 0.1.
 
-Bars: time grid bit-exact; nodes 1e-9; refreshed QP data 1e-8; applied control 1e-6 (normalised) of the exact optimum; active-set index lists identical up to rows that
-are degenerate in the oracle's own solution."""
+Bars: time grid bit-exact; nodes 1e-9; refreshed QP data 1e-8; applied control 1e-6 (normalised) of the exact optimum; active-set index lists identical under the canonical rule (multiplier > 1e-6 on both sides)."""
 import os
 import numpy as np
 import pytest
@@ -51,9 +50,10 @@ def test_case_matches_the_committed_oracle_vectors(pkg, golden, name):
         assert rel(qp, G["sd"]) < 1e-8
         un = np.array([mpc.u_normalization[0], mpc.u_normalization[1], mpc.u_normalization[1]])
         assert np.max(np.abs(u - G["u"]) / un) < 1e-6, np.max(np.abs(u - G["u"]) / un)
+        lam = mpc.multipliers()
         for b in range(oc.B):
-            mine = set(mpc.canonical_active_set(b, act[b], qp[b])); theirs = set(G["act"][b, 1:1 + G["act"][b, 0]].tolist())
-            assert len(mine ^ theirs) <= 2, (b, sorted(mine ^ theirs, key=abs))           # (rows with a multiplier of ~1e-6 in the oracle's solution fall on either side)
+            mine = set(mpc.canonical_active_set(b, act[b], qp[b], lam=lam[b])); theirs = set(G["act"][b, 1:1 + G["act"][b, 0]].tolist())
+            assert mine == theirs, (b, sorted(mine ^ theirs, key=abs))                     # canonical rule on both sides: multiplier > 1e-6 (tools/make_onvehicle_golden.py: tol = 1e-6)
     else:
         from oracle import oracle as om      # (only its layout helpers: nothing is solved here)
         o = om.OracleDecoupled(**kw)

@@ -76,14 +76,14 @@ def test_qp_data(setup):
             assert rel_inf(G[k], O[k]) < 1e-8, (b, k, rel_inf(G[k], O[k]))
 
 
-def test_solve_matches_exact_optimum(setup, oracle_mod):
+def test_solve_matches_exact_optimum(setup, oracle_mod, pkg):
     mpc, orc, state, control, t0, toff = setup
     mpc.reset()
     u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
     assert np.all(status == pkg.SOLVED), status
     qp = mpc.qp_data()
     x, sg = mpc.solution()
-    st, it, act, mu = mpc.solve_info()
+    st, it, act, mu = mpc.solve_info(); lam = mpc.multipliers()
     worst_u2 = 0.0; worst_all = 0.0
     for b in range(B_SMALL):
         xe, ye, info = orc.solve_exact(qp[b])            # exact optimum of the SAME QP data the GPU solved
@@ -95,12 +95,12 @@ def test_solve_matches_exact_optimum(setup, oracle_mod):
         assert rel_inf(u[b] / [mpc.u_normalization[0], mpc.u_normalization[1], mpc.u_normalization[1]],
                        un / [mpc.u_normalization[0], mpc.u_normalization[1], mpc.u_normalization[1]]) < 1e-6
         qpc = orc.assemble_qp(qp[b])
-        assert mpc.canonical_active_set(b, act[b], qp[b]) == oracle_mod.active_set(qpc, xe, ye, tol=1e-6), b
+        assert mpc.canonical_active_set(b, act[b], qp[b], lam=lam[b]) == oracle_mod.active_set(qpc, xe, ye, tol=1e-6), b
     assert worst_u2 < 1e-6, worst_u2
     assert worst_all < 1e-5, worst_all
 
 
-def test_warm_second_step(setup):
+def test_warm_second_step(setup, pkg):
     """Second consecutive step: warm branch of compute_linearization_nodes! (coupled_lat_long.jl:82-102) on both sides."""
     mpc, orc, state, control, t0, toff = setup
     mpc.reset()
