@@ -267,6 +267,125 @@ PG_DEV void tracking_rhs(const DevVehicle& P, const T q[6], T u0, T u1, real pV,
     out[4] = q[3] - vs * pK;
     out[5] = q[1] * s + q[2] * c;
 }
+// ---- the same right-hand side with its LOCAL JACOBIAN in scalar arithmetic (k_linearize since round 4) ----
+// `linearize` needs d(flow map)/d(q, u0, uf): 8 tangent directions through 40 evaluations of the dynamics per interval.  Rounds 1-3 carried every direction through
+// every operation of the right-hand side (forward-mode numbers DK<K>, ~120 fp64 operations per direction and evaluation, and 5-vectors for every intermediate: the
+// kernel ran at 360 registers).  The right-hand side has only FIVE inputs that matter to its three non-trivial outputs -- (Ux, Uy, r, delta, Fx) -> (Ux', Uy', r') --
+// and the other three outputs are kinematics of (Ux, Uy, dpsi, r).  So: value and the 3 x 5 + 9 partial derivatives ONCE per evaluation, in scalars (~190 operations
+// on top of the ~150 of the value; the chain rule runs over the six quantities the tire forces actually see -- tan(alpha_f), tan(alpha_r), Fxf, Fxr, sin delta,
+// cos delta -- through the three load-transfer iterations), then every direction is a 3 x 5 and three 1 x 3 products (~25 operations).  Same function, same
+// derivatives; the rounding differs from the forward-mode evaluation by a few ulp.
+struct TrackJac {
+    real f[6];        // the right-hand side (ds', Ux', Uy', r', dpsi', e')
+    real a0[3];       // d ds'  / d(Ux, Uy, dpsi)
+    real a4[3];       // d dpsi'/ d(Ux, Uy, dpsi)      (d dpsi'/dr = 1)
+    real a5[3];       // d e'   / d(Ux, Uy, dpsi)
+    real b[3][5];     // d(Ux', Uy', r') / d(Ux, Uy, r, delta, Fx)
+};
+// tire force with its three partial derivatives (the forward-mode branch of fiala<T> above, as a scalar function)
+PG_DEV void fiala_s(real ta, real Ca, real mu, real fx, real Fz, real& Fy, real& g_t, real& g_x, real& g_z) {
+    const real fm = mu * Fz;
+    if (fabs(fx) >= fm) { Fy = real(0.0); g_t = real(0.0); g_x = real(0.0); g_z = real(0.0); return; }
+    const real w = fm * fm - fx * fx, z = pg_rsqrt(w);
+    const real rho = fabs(ta * z) * (Ca * (real(1.0) / real(3.0)));
+    real g_w;
+    if (rho <= real(1.0)) {
+        const real cat = Ca * ta, omr = real(1.0) - rho;
+        Fy = -cat * (omr + rho * rho * (real(1.0) / real(3.0)));
+        g_t = -Ca * omr * omr;
+        g_w = cat * (rho * (real(2.0) / real(3.0)) - real(1.0)) * rho * (real(0.5) * z * z);
+    } else {
+        const real sg = sgn(ta);
+        Fy = -(w * z) * sg; g_t = real(0.0); g_w = real(-0.5) * z * sg;
+    }
+    g_z = g_w * (real(2.0) * fm * mu); g_x = g_w * (real(-2.0) * fx);
+}
+// VehicleModel{TrackingBicycleModel} (vehicle_dynamics.jl:310-315 over :159-183, actuator limits :293-298, tire model :35-76) at q = (ds, Ux, Uy, r, dpsi, e),
+// u = (delta, Fx), p = (V, kappa): value and Jacobian
+PG_DEV void tracking_jac(const DevVehicle& P, const real q[6], real u0, real u1, real pV, real pK, TrackJac& J) {
+    const real Ux = q[1], Uy = q[2], r = q[3];
+    // apply_control_limits + longitudinal_tire_forces: a clamped input has no derivative (the limits see Ux by value, :295)
+    const real dlt = u0 > P.delta_max ? P.delta_max : (u0 < -P.delta_max ? -P.delta_max : u0);
+    const real ddl = (u0 > P.delta_max || u0 < -P.delta_max) ? real(0.0) : real(1.0);
+    const real cap = jmin(P.Fx_max, P.Px_max / Ux);
+    real fxc = u1, dfx = real(1.0);
+    if (cap < fxc) { fxc = cap; dfx = real(0.0); }
+    if (P.Fx_min > fxc) { fxc = P.Fx_min; dfx = real(0.0); }
+    const real ff = fxc > real(0.0) ? P.fwd_frac : P.fwb_frac, fr = fxc > real(0.0) ? P.rwd_frac : P.rwb_frac;
+    const real Xf = fxc * ff, Xr = fxc * fr;
+    // kinematic rows
+    real s, c; pg_sincos(q[4], &s, &c);
+    const real vs = Ux * c - Uy * s, w5 = Ux * s + Uy * c;
+    J.f[0] = vs - pV; J.f[4] = r - vs * pK; J.f[5] = w5;
+    J.a0[0] = c; J.a0[1] = -s; J.a0[2] = -w5;
+    J.a4[0] = -pK * c; J.a4[1] = pK * s; J.a4[2] = pK * w5;
+    J.a5[0] = s; J.a5[1] = c; J.a5[2] = vs;
+    // slip angles (tangents), drag
+    real sd, cd; pg_sincos(dlt, &sd, &cd);
+    const real iux = frcp(Ux), yv = Uy + P.a * r, tfv = yv * iux, tdv = sd * frcp(cd);
+    const real iden = frcp(real(1.0) + tfv * tdv), id2 = iden * iden;
+    const real c_y = (real(1.0) + tdv * tdv) * id2 * iux, c_u = -c_y * tfv, c_d = -(real(1.0) + tfv * tfv) * id2 * (real(1.0) + tdv * tdv);
+    const real taf = (tfv - tdv) * iden;
+    const real dd = -(P.Cd1 + real(2.0) * P.Cd2 * Ux), Fdrag = -P.Cd0 - Ux * (P.Cd1 + P.Cd2 * Ux);
+    const real tar = (Uy - P.b * r) * iux, t_u = -tar * iux;
+    // lateral forces (:64-76): three load-transfer iterations on the front axle, then the rear.  Gradients over L = (taf, Xf, Xr, sd, cd), as five scalars each.
+    const real W_b = P.m * P.G * P.b, W_a = P.m * P.G * P.a, invL = real(1.0) / P.L;
+    const real hL = P.h * invL, WbL = W_b * invL, WaL = W_a * invL;
+    const real FxfC = Xf * cd;
+    real Fx = FxfC + Xr, Fxt = FxfC, Fyf = real(0.0);
+    real dX[5] = {real(0.0), cd, real(1.0), real(0.0), Xf};        // d Fx
+    real dT[5] = {real(0.0), cd, real(0.0), real(0.0), Xf};        // d Fxt
+    real dY[5] = {real(0.0), real(0.0), real(0.0), real(0.0), real(0.0)};      // d Fyf
+#pragma unroll 1
+    for (int i = 0; i < 3; i++) {
+        const real Fzf = WbL - hL * Fx;
+        real g_t, g_x, g_z;
+        fiala_s(taf, P.Caf, P.mu, Xf, Fzf, Fyf, g_t, g_x, g_z);
+        const real gz = -g_z * hL;
+#pragma unroll
+        for (int k = 0; k < 5; k++) dY[k] = gz * dX[k];
+        dY[0] += g_t; dY[1] += g_x;
+        Fxt = FxfC - Fyf * sd;
+        dT[0] = -sd * dY[0]; dT[1] = cd - sd * dY[1]; dT[2] = -sd * dY[2]; dT[3] = -sd * dY[3] - Fyf; dT[4] = Xf - sd * dY[4];
+        Fx = Fxt + Xr;
+#pragma unroll
+        for (int k = 0; k < 5; k++) dX[k] = dT[k];
+        dX[2] += real(1.0);
+    }
+    const real Fzr = WaL + hL * Fx;
+    real Fyr, h_t, h_x, h_z;
+    fiala_s(tar, P.Car, P.mu, Xr, Fzr, Fyr, h_t, h_x, h_z);
+    const real hz = h_z * hL;
+    real dR[5];                                                     // d Fyr over L (its own slip angle: h_t)
+#pragma unroll
+    for (int k = 0; k < 5; k++) dR[k] = hz * dX[k];
+    dR[2] += h_x;
+    const real Fyf_t = Fyf * cd + Xf * sd;
+    real dF[5];                                                     // d Fyf_t
+#pragma unroll
+    for (int k = 0; k < 5; k++) dF[k] = cd * dY[k];
+    dF[1] += sd; dF[3] += Xf; dF[4] += Fyf;
+    const real invm = real(1.0) / P.m, invI = real(1.0) / P.Izz;
+    J.f[1] = (Fxt + Xr + Fdrag) * invm + r * Uy;
+    J.f[2] = (Fyf_t + Fyr) * invm - r * Ux;
+    J.f[3] = (P.a * Fyf_t - P.b * Fyr) * invI;
+    // gradients of the three accelerations over L (+ the rear slip angle), then the chain to (Ux, Uy, r, delta, Fx):
+    //   taf: (c_u, c_y, a c_y, c_d) ; tar: (t_u, 1/Ux, -b/Ux, 0) ; sd, cd: (0, 0, 0, cd, -sd) ; Xf, Xr: Fx through the brake / drive split
+    real g1[5], g2[5], g3[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { g1[k] = invm * dT[k]; g2[k] = invm * (dF[k] + dR[k]); g3[k] = invI * (P.a * dF[k] - P.b * dR[k]); }
+    g1[2] += invm;
+    const real r2 = invm * h_t, r3 = -invI * P.b * h_t;               // d(Uy', r') / d tar
+    const real acy = P.a * c_y, biux = P.b * iux;
+    J.b[0][0] = g1[0] * c_u + invm * dd;  J.b[0][1] = g1[0] * c_y + r;   J.b[0][2] = g1[0] * acy + Uy;
+    J.b[1][0] = g2[0] * c_u + r2 * t_u - r; J.b[1][1] = g2[0] * c_y + r2 * iux; J.b[1][2] = g2[0] * acy - r2 * biux - Ux;
+    J.b[2][0] = g3[0] * c_u + r3 * t_u;   J.b[2][1] = g3[0] * c_y + r3 * iux; J.b[2][2] = g3[0] * acy - r3 * biux;
+    const real dsd = cd * ddl, dcd = -sd * ddl, dta = c_d * ddl, dxf = ff * dfx, dxr = fr * dfx;
+    J.b[0][3] = g1[0] * dta + g1[3] * dsd + g1[4] * dcd;  J.b[0][4] = g1[1] * dxf + g1[2] * dxr;
+    J.b[1][3] = g2[0] * dta + g2[3] * dsd + g2[4] * dcd;  J.b[1][4] = g2[1] * dxf + g2[2] * dxr;
+    J.b[2][3] = g3[0] * dta + g3[3] * dsd + g3[4] * dcd;  J.b[2][4] = g3[1] * dxf + g3[2] * dxr;
+}
+
 // VehicleModel{BicycleModel}: vehicle_dynamics.jl:310-314 over :111-135; only the components the hot path reads (dUx,dUy,dr)
 template <class T>
 PG_DEV void world_body_rhs(const DevVehicle& P, real Ux, real Uy, real r, T u0, T u1, T& dUx, T& dUy, T& dr) {

@@ -401,48 +401,75 @@ template <bool STAGED> __global__ __launch_bounds__(256) void k_nodes_warm(DevCf
 template <int K, int ND = 8>
 PG_DEV void linearize_lanes_at(const DevCfg& C, int b, int t, int g, bool live, const real* __restrict__ n0, const real* __restrict__ n1, const tdouble* __restrict__ dt,
                                const real* __restrict__ hji_Mb, real* __restrict__ qp) {
-    typedef DK<K> DT;
     constexpr int G = ND / K;
     const bool ramp = ND == 8 && t >= C.Ns;
     const real h_total = dt[(size_t)b * C.N + t];
-    DT x[6];
+    // value of the state and its K tangent directions (direction j = g K + d: j < 4 seeds component j + 1; 4, 5: u0; 6, 7: uf)
+    struct XD { real v, d[K]; };
+    XD x[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
-        x[k] = DT(n0[k]);
+        x[k].v = n0[k];
 #pragma unroll
-        for (int d = 0; d < K; d++) x[k].d[d] = (g * K + d < 4 && g * K + d + 1 == k) ? real(1.0) : real(0.0);          // (directions 0..3 seed components 1..4)
+        for (int d = 0; d < K; d++) x[k].d[d] = (g * K + d < 4 && g * K + d + 1 == k) ? real(1.0) : real(0.0);
     }
-    DT u0a(n0[6]), u0b(n0[7]), ufa(ramp ? n1[6] : n0[6]), ufb(ramp ? n1[7] : n0[7]);
+    const real u0a = n0[6], u0b = n0[7], ufa = ramp ? n1[6] : n0[6], ufb = ramp ? n1[7] : n0[7];
+    // tangents of the interpolated control u(tau) = u0 + (uf - u0) w: direction 4 / 5 carries (1 - w) on delta / Fx, direction 6 / 7 carries w
+    real s0a[K], s0b[K], sfa[K], sfb[K];
 #pragma unroll
     for (int d = 0; d < K; d++) {
         const int j = g * K + d;
-        u0a.d[d] = j == 4 ? real(1.0) : real(0.0); u0b.d[d] = j == 5 ? real(1.0) : real(0.0); ufa.d[d] = j == 6 ? real(1.0) : real(0.0); ufb.d[d] = j == 7 ? real(1.0) : real(0.0);
+        s0a[d] = j == 4 ? real(1.0) : real(0.0); s0b[d] = j == 5 ? real(1.0) : real(0.0); sfa[d] = j == 6 ? real(1.0) : real(0.0); sfb[d] = j == 7 ? real(1.0) : real(0.0);
     }
     const real pV0 = n0[8], pK0 = n0[9], pV1 = ramp ? n1[8] : n0[8], pK1 = ramp ? n1[9] : n0[9];
     const int nsub = C.nsub; const real h = h_total / nsub;
-    auto rhs = [&](const DT* xx, real tau, DT* out) {
-        real w = ramp ? tau / h_total : real(0.0);
-        DT ua = u0a + (ufa - u0a) * w, ub = u0b + (ufb - u0b) * w;
-        tracking_rhs<DT>(C.veh, xx, ua, ub, pV0 + (pV1 - pV0) * w, pK0 + (pK1 - pK0) * w, out);
-    };
 #pragma unroll 1
     for (int i = 0; i < nsub; i++) {
         const real t0 = i * h;
-        DT kk[6], xx[6], acc[6];
+        XD xx[6], acc[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) { xx[k] = x[k]; acc[k] = DT(real(0.0)); }
-        // classical RK4 written as one rolled stage loop (one instance of the dynamics in the instruction stream, fewer live registers)
+        for (int k = 0; k < 6; k++) {
+            xx[k] = x[k]; acc[k].v = real(0.0);
+#pragma unroll
+            for (int d = 0; d < K; d++) acc[k].d[d] = real(0.0);
+        }
+        // classical RK4 as one rolled stage loop.  Per stage: the right-hand side and its local Jacobian ONCE (scalars: tracking_jac), then every direction is a handful
+        // of multiply-adds -- k.d = J (xx.d, du) -- in an order that does not depend on K: the Jacobians are bit-identical whatever the lane arrangement
 #pragma unroll 1
         for (int st = 0; st < 4; st++) {
             const real cst_ = st == 0 ? real(0.0) : (st == 3 ? real(1.0) : real(0.5));        // stage time fraction
             const real wgt = (st == 0 || st == 3) ? real(1.0) : real(2.0);              // quadrature weight (x h/6)
-            const real nxt = st == 2 ? real(1.0) : real(0.5);                           // coefficient of k in the NEXT stage's evaluation point
-            rhs(xx, t0 + cst_ * h, kk);
+            const real nxt = (st == 2 ? real(1.0) : real(0.5)) * h;                     // coefficient of k in the NEXT stage's evaluation point
+            const real w = ramp ? (t0 + cst_ * h) / h_total : real(0.0);
+            const real ua = u0a + (ufa - u0a) * w, ub = u0b + (ufb - u0b) * w;
+            real qv[6];
 #pragma unroll
-            for (int k = 0; k < 6; k++) { acc[k] = acc[k] + kk[k] * wgt; xx[k] = x[k] + kk[k] * (nxt * h); }
+            for (int k = 0; k < 6; k++) qv[k] = xx[k].v;
+            TrackJac J;
+            tracking_jac(C.veh, qv, ua, ub, pV0 + (pV1 - pV0) * w, pK0 + (pK1 - pK0) * w, J);
+#pragma unroll
+            for (int k = 0; k < 6; k++) { acc[k].v = acc[k].v + J.f[k] * wgt; xx[k].v = x[k].v + J.f[k] * nxt; }
+#pragma unroll
+            for (int d = 0; d < K; d++) {
+                const real tU = xx[1].d[d], tY = xx[2].d[d], tR = xx[3].d[d], tP = xx[4].d[d];
+                const real da = s0a[d] + (sfa[d] - s0a[d]) * w, db = s0b[d] + (sfb[d] - s0b[d]) * w;
+                real kd[6];
+                kd[0] = J.a0[0] * tU + J.a0[1] * tY + J.a0[2] * tP;
+#pragma unroll
+                for (int m = 0; m < 3; m++) kd[1 + m] = J.b[m][0] * tU + J.b[m][1] * tY + J.b[m][2] * tR + J.b[m][3] * da + J.b[m][4] * db;
+                kd[4] = tR + J.a4[0] * tU + J.a4[1] * tY + J.a4[2] * tP;
+                kd[5] = J.a5[0] * tU + J.a5[1] * tY + J.a5[2] * tP;
+#pragma unroll
+                for (int k = 0; k < 6; k++) { acc[k].d[d] = acc[k].d[d] + kd[k] * wgt; xx[k].d[d] = x[k].d[d] + kd[k] * nxt; }
+            }
         }
+        const real h6 = h / real(6.0);
 #pragma unroll
-        for (int k = 0; k < 6; k++) x[k] = x[k] + acc[k] * (h / real(6.0));
+        for (int k = 0; k < 6; k++) {
+            x[k].v = x[k].v + acc[k].v * h6;
+#pragma unroll
+            for (int d = 0; d < K; d++) x[k].d[d] = x[k].d[d] + acc[k].d[d] * h6;
+        }
     }
     // this lane's share of c_i = Phi_i - A_i. q - B0_i. u0 - Bf_i. uf   (raw, un-normalised Jacobians: coupled_lat_long.jl:336-353)
     // The eight products d_j coef_j are rounded one by one, brought to the group's first lane and summed THERE in one fixed order, so that c -- like the Jacobians --
