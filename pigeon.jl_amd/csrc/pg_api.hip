@@ -36,6 +36,7 @@ struct pg_handle {
     real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     real* d_lam = nullptr;                                      // [cap][N][16] multipliers of the last solve (warm start of the polish)
     int* d_wfail = nullptr;                                     // [cap] back-off of k_solve_lat's warm attempts
+    int* d_todo = nullptr; int split_solve = 1;                 // [cap + 1] instances the rounds-only k_solve leaves to the full kernel + their count; PG_SOLVE_SPLIT=0: one kernel as before
     int* d_order = nullptr; int order_B = 0;  // [cap] + 2 counters: launch order filed by the nodes kernels of the current step (likely slow instances first); order_B = batch it is valid for
     real *d_pol_u2 = nullptr, *d_pol_u = nullptr; int* d_pol_src = nullptr;   // HJI fallback policy (HJI_computation.jl:133-158)
     int *d_status = nullptr, *d_iters = nullptr, *d_polish = nullptr; uint16_t* d_active = nullptr;
@@ -160,7 +161,7 @@ int pg_default_config_decoupled(pg_config* c) {
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_in, h->d_out, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_wfail, h->d_order, h->d_naux, h->d_progress, h->d_lat, h->d_lat_ws};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_wfail, h->d_todo, h->d_order, h->d_naux, h->d_progress, h->d_lat, h->d_lat_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->sg.x) (void)hipGraphExecDestroy(h->sg.x);
@@ -212,7 +213,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_sep, cap * 4, real); ALLOC(h->d_nodes, cap * NN * 10, real); ALLOC(h->d_qp, cap * C.qp_len, real);
     ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
     ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_mu, cap, real);
-    ALLOC(h->d_polish, cap, int); ALLOC(h->d_wfail, cap, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_naux, cap * NN * 4, real); ALLOC(h->d_progress, cap / 64 + 6, int); ALLOC(h->d_active, cap * N, uint16_t);
+    ALLOC(h->d_polish, cap, int); ALLOC(h->d_wfail, cap, int); ALLOC(h->d_todo, cap + 1, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_naux, cap * NN * 4, real); ALLOC(h->d_progress, cap / 64 + 6, int); ALLOC(h->d_active, cap * N, uint16_t);
 #ifdef PG_EXPERIMENTAL_SOLVE4
     { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (experimental/pg_solve4.hip)
     if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), real);
@@ -264,6 +265,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     }
     for (int i = 0; i < 4; i++) if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_create_error = "hipEventCreate failed"; free_all(h); delete h; return PG_ERR_HIP; }
     h->ev_ok = true;
+    { const char* e = getenv("PG_SOLVE_SPLIT"); if (e && (e[0] == '0' || e[0] == '1')) h->split_solve = e[0] - '0'; }
     { const char* e = getenv("PG_FUSE"); if (e && e[0] >= '0' && e[0] <= '2') h->fuse = e[0] - '0'; }
     { const char* e = getenv("PG_PIPELINE"); if (e && e[0] >= '0' && e[0] <= '1') h->pipeline = e[0] - '0'; }
     { const char* e = getenv("PG_PIPE_FAULT"); h->pipe_fault = e && e[0] == '1'; }
@@ -284,6 +286,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     {
         lds_attr_max[dev_slot] = h->solve_lds;
         (void)hipFuncSetAttribute((const void*)k_solve<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+        (void)hipFuncSetAttribute((const void*)k_solve<false, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
         (void)hipFuncSetAttribute((const void*)k_solve<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
         (void)hipFuncSetAttribute((const void*)k_solve<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
         (void)hipFuncSetAttribute((const void*)k_solve<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
@@ -694,7 +697,7 @@ int pg_update_qp(pg_handle* h) {
 }
 // k_solve over `n` instances on stream `st`: the whole batch in index order (order == nullptr) or the sub-range order[0..n) of the launch order
 static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, unsigned long long* lat_prof = nullptr) {
-    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, order, h->d_wfail};
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, order, h->d_wfail, nullptr, nullptr, nullptr, nullptr};
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) { hipLaunchKernelGGL((k_solve4<2, false>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, (unsigned long long*)nullptr); LAUNCH_CHECK(h); return PG_OK; }
 #endif
@@ -709,6 +712,19 @@ static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, u
         return PG_OK;
     }
     if (h->solve_ring) hipLaunchKernelGGL((k_solve<false, true, false>), dim3(n), dim3(64), h->solve_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
+    else if (h->split_solve && h->dc.polish && (h->dc.cold_guess > 0 || h->dc.warm_polish) && !h->has_hji) {
+        // Two launches: the rounds-only instantiation (334 registers, no scratch: the interior point's state and code are not in it) serves the instances an active-set
+        // attempt verifies -- all of them on the tracking batches --; what it leaves (SolveOut::todo) goes through the full kernel in list mode, its 4096 blocks
+        // returning at once when the list is empty.  Not with a safety row installed: there the instances whose row is violated NEED the interior point (9-17 % of config
+        // 3), and in one kernel they start first (launch order) instead of after everyone else.
+        const size_t cap = (size_t)h->cfg.batch_capacity;
+        HIPCHK(h, hipMemsetAsync(h->d_todo + cap, 0, sizeof(int), st));
+        O.todo = h->d_todo; O.n_todo = h->d_todo + cap;
+        hipLaunchKernelGGL((k_solve<false, false, false, false>), dim3(n), dim3(64), h->solve_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
+        LAUNCH_CHECK(h);
+        SolveOut O2 = O; O2.order_in = nullptr; O2.todo = nullptr; O2.n_todo = nullptr; O2.list = h->d_todo; O2.n_list = h->d_todo + cap;
+        hipLaunchKernelGGL((k_solve<false, false, false, true>), dim3(n), dim3(64), h->solve_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O2, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
+    }
     else hipLaunchKernelGGL((k_solve<false, false, false>), dim3(n), dim3(64), h->solve_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
     LAUNCH_CHECK(h);
     return PG_OK;
@@ -749,7 +765,7 @@ static int update_and_solve(pg_handle* h, hipEvent_t after_update) {
     if ((rc = launch_hji_rows(h))) return rc;
     if (after_update) HIPCHK(h, hipEventRecord(after_update, h->stream));
     const bool use_order = h->dc.polish && h->order_B == h->B;
-    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, use_order ? h->d_order : nullptr, h->d_wfail};
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, use_order ? h->d_order : nullptr, h->d_wfail, nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL((k_solve<false, false, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
     LAUNCH_CHECK(h);
     if (h->B > h->warm_B) h->warm_B = h->B;
@@ -763,7 +779,7 @@ int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     HIPCHK(h, hipMalloc((void**)&d, ((size_t)h->B * 9 + 1024) * 8));
     HIPCHK(h, hipMemset(d, 0, ((size_t)h->B * 9 + 1024) * 8));
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam,
-               (h->dc.polish && h->order_B == h->B) ? h->d_order : nullptr, h->d_wfail};            // (the launch order pg_solve would use: the timeline is the product's)
+               (h->dc.polish && h->order_B == h->B) ? h->d_order : nullptr, h->d_wfail, nullptr, nullptr, nullptr, nullptr};            // (the launch order pg_solve would use: the timeline is the product's)
     if (h->solve_lat) { if ((rc = launch_solve(h, h->stream, nullptr, h->B, d))) { (void)hipFree(d); return rc; } } else
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) hipLaunchKernelGGL((k_solve4<2, true>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, d);

@@ -1183,7 +1183,9 @@ __global__ __launch_bounds__(64) void k_hji_policy(DevCfg C, int B, int use_poli
 //   6..9: H_i [Uy;r] - sigma_{i/2} <= G_i     10: sigma1 >= 0   11: sigma2 >= 0    12: d_delta <= ddmax   13: d_delta >= ddmin
 //   14: M u + b + sigma_HJI >= 0              15: sigma_HJI >= 0        (14,15 only for nodes 1 .. min(N_HJI,Ns)-1)
 struct SolveOut { real* sol_x; real* sol_sigma; real* u_out; int* status; int* iters; uint16_t* active; real* mu; int* solved; int* polish; real* lam;
-                  const int* order_in; int* wfail; };      // wfail: k_solve_lat's back-off word per instance (nullptr: none)
+                  const int* order_in; int* wfail;         // wfail: k_solve_lat's back-off word per instance (nullptr: none)
+                  int* todo; int* n_todo;                  // rounds-only k_solve: instances left for the full kernel, and how many
+                  const int* list; const int* n_list; };   // full k_solve in list mode: the instances to solve (interior point at once), and how many
 
 #define NROW 16
 #define PG_POLISH_ROUNDS 6      // active-set rounds of the polish before it gives up
@@ -1257,7 +1259,10 @@ PG_DEV void wave_sync() {
 #ifndef PG_SETTLE_PASSES
 #define PG_SETTLE_PASSES 4
 #endif
-template <bool PROF, bool RING, bool FUSE>
+// IPM = false: the ROUNDS-ONLY instantiation (round 4): the active-set attempts (previous step's set, empty set) and nothing else -- no interior-point state (t, corr,
+// 1/t), no Mehrotra code, no second start.  An instance its rounds do not serve is appended to SolveOut::todo and left untouched; the host launches the full kernel
+// over that list behind it (SolveOut::list / n_list: block i solves list[i], blocks beyond *n_list return at once, the attempts already made are skipped).
+template <bool PROF, bool RING, bool FUSE, bool IPM = true>
 __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, int B, real* qp, const real* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof,
                                                                           const tdouble* __restrict__ dt_grid, const real* __restrict__ hji_Mb) {
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -1265,7 +1270,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     if (PROF) tprev = clock64();
     const unsigned long long t_entry = (PG_TL && prof) ? wall_clock64() : 0ull;
     // Launch order: workgroup i solves instance order_in[i] when an order is supplied (filed by the nodes kernels, likely stragglers first: see OrderOut)
-    const int b = O.order_in ? O.order_in[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;
+    if (O.n_list && (int)blockIdx.x >= *O.n_list) return;      // list mode: nothing left for this block
+    const int b = O.n_list ? O.list[blockIdx.x] : (O.order_in ? O.order_in[blockIdx.x] : (int)blockIdx.x), lane = threadIdx.x;
     const int N = C.N, NN = C.NN;
     // FUSE: update_QP! of this instance first, by the wave that is about to solve it -- lane pair (2t, 2t+1) linearises interval t (2N <= 64; lanes beyond 2N mirror
     // the last interval and store nothing).  The QP data go to memory exactly as k_linearize writes them (pg_get_qp reads them; the solve below reads them back
@@ -1461,7 +1467,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     const real rho = C.polish_rho, ptol = C.polish_tol, dtol = real(1000.0) * C.polish_tol;      // dtol: largest correction of the last refinement pass a verified point may have had
     auto assemble = [&](real sigmu, bool matrices) {
         real W[NROW], ell[NROW];
-        if (pmode) {
+        if (!IPM || pmode) {
             // polish: active rows are equalities enforced by the augmented Lagrangian  -y t(z) + rho/2 t(z)^2  (y lives in R.lam), inactive rows are absent.
             // Same shape as the barrier terms: W = rho, constant part of the multiplier = y - rho b.
 #pragma unroll
@@ -1470,7 +1476,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
                 W[j] = a ? rho : real(0.0);
                 ell[j] = a ? R.lam[j] - rho * bb[j] : real(0.0);
             }
-        } else {
+        } else if constexpr (IPM) {
 #pragma unroll
             for (int j = 0; j < NROW; j++) {
                 bool on = j < nrows;
@@ -1771,14 +1777,14 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     int last_nchg = 0, good_steps = 0; real last_tmax = real(0.0); bool refine_only = false;
     int dbg_stage = -1, dbg_bit = -1, dbg_nadd = 0, dbg_ndrop = 0;      // diagnostic build: first stage / row that joined the set in the last check, rows added / dropped
     bool warm_attempt = false, from_prev = false;          // warm_attempt: a polish without an interior point in front (attempts -2, -1); from_prev: attempt -2
-    for (int attempt = warm ? -2 : (guess ? -1 : 0); attempt < 2; attempt++) {
+    for (int attempt = O.n_list ? 0 : (warm ? -2 : (guess ? -1 : 0)); attempt < (IPM ? 2 : 0); attempt++) {
     if (attempt == -1 && !guess) continue;
     rp0 = real(0.0); phi = real(1.0); pmode = 0; pstat = 0; polish_gave_up = false; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu; cycle_broken = false; settle_used = false; settle_left = 0; good_steps = 0;
     warm_attempt = attempt < 0; from_prev = attempt == -2;
-    if (attempt < 0) {
+    if (!IPM || attempt < 0) {
         amask = (act && from_prev) ? (unsigned)O.active[(size_t)b * N + s] : 0u; mask_ipm = amask;
 #pragma unroll
-        for (int j = 0; j < NROW; j++) { R.t[j] = real(1.0); R.corr[j] = real(0.0); R.lam[j] = (act && from_prev && ((amask >> j) & 1u)) ? Lst[j] : real(0.0); }
+        for (int j = 0; j < NROW; j++) { if constexpr (IPM) { R.t[j] = real(1.0); R.corr[j] = real(0.0); } R.lam[j] = (act && from_prev && ((amask >> j) & 1u)) ? Lst[j] : real(0.0); }
         pmode = 1; mu = real(0.0);
     } else if (attempt == 0) {
         // ---- first attempt: v = 0 roll-out (dynamics- and rate-feasible), sigma just feasible; t = max(slack, tau); lambda = mu0 / t ----
@@ -1964,7 +1970,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     // there, the interior point resumes from the centred point (t, mu / t) and runs down to ipm_tol before the polish gets its second and last chance
     real tol_cur = (C.polish && C.polish_ipm_tol > C.ipm_tol) ? C.polish_ipm_tol : C.ipm_tol;
     auto polish_failed = [&]() -> bool {          // true: give up (keep the interior-point iterate); false: the interior point resumes
-        if (warm_attempt) { pstat = 0; status = PG_MAX_ITER; return true; }      // warm guess did not verify: on to the cold start
+        if (!IPM || warm_attempt) { pstat = 0; status = PG_MAX_ITER; return true; }      // warm guess did not verify: on to the cold start
         pstat = -1;
         if (!(tol_cur > C.ipm_tol)) { polish_gave_up = true; return true; }
         tol_cur = C.ipm_tol; pmode = 0; status = PG_MAX_ITER; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu; cycle_broken = false; settle_used = false; settle_left = 0;
@@ -1987,7 +1993,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     };
     it = 0;
     while (true) {
-        if (!pmode) {
+        if (IPM && !pmode) {
             // (an attempt that is converging at its cap -- three steps in a row longer than one half -- gets twenty more iterations (caps of 20 and more: not the test settings that force the second start): the alternative is a second start
             // from scratch; long lateral horizons with wall rows spend 25-30 iterations on tiny steps before the iteration takes off)
             if (it >= iter_cap && !(iter_cap >= 20 && good_steps >= 3 && it < iter_cap + 20)) break;
@@ -2035,7 +2041,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         forward(std::true_type{});
         stamp(4);
         newton_point(tp);
-        if (!pmode) {
+        if (IPM && !pmode) {
             // step to the boundary: alpha_max = 1 / max_j( -dt_j / t_j, -dl_j / lam_j )  (only rows that move towards the boundary are positive)
             real rmax = real(0.0);
 #pragma unroll
@@ -2103,7 +2109,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         forward(std::true_type{}, dlt);
         stamp(4);
         newton_point(tp, dlt);
-        if (!pmode) {
+        if (IPM && !pmode) {
             real rmax = real(0.0);
 #pragma unroll
             for (int j = 0; j < NROW; j++) {
@@ -2167,6 +2173,12 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         tl[0] = t_entry; tl[1] = wall_clock64();
         tl[2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (31 << 11)) << 32);
     }
+    if constexpr (!IPM) {
+        if (status != PG_SOLVED) {      // not served by the rounds: left for the full kernel (nothing of this instance's outputs or warm-start state has been touched)
+            if (lane == 0) O.todo[atomicAdd(O.n_todo, 1)] = b;
+            return;
+        }
+    }
     if (status == PG_SOLVED && C.polish && pstat < 0) status = PG_SOLVED_UNVERIFIED;      // an interior-point iterate no active-set round could verify (pigeon_mpc.h)
     if (status == PG_SOLVED || status == PG_SOLVED_UNVERIFIED) {
         real Ux0 = sx0[1], Fx0 = sx0[7];
@@ -2177,8 +2189,10 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     if (lane < 8) SX[lane] = sx0[lane];
     if (act) {
         unsigned mask = 0;
+        if constexpr (IPM) {
 #pragma unroll
-        for (int j = 0; j < NROW; j++) if (j < nrows && R.lam[j] > R.t[j]) mask |= (1u << j);
+            for (int j = 0; j < NROW; j++) if (j < nrows && R.lam[j] > R.t[j]) mask |= (1u << j);
+        }
         if (pstat > 0) mask = amask;                               // the polish's verified set
         else if (pmode) mask = mask_ipm;                           // polish ended unverified with the multipliers overwritten: the interior point's set at hand-over
         O.active[(size_t)b * N + s] = (uint16_t)mask;
