@@ -237,6 +237,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         { const char* k = getenv("PG_LAT_POLISH2"); C.lat_polish2 = k ? (atoi(k) != 0) : 1; }
         C.lat_far_cost = (real)env_pos("PG_LAT_FAR_COST", 3e4);
         { const char* k = getenv("PG_LAT_RHO_SCALE"); const double v = k ? atof(k) : (sizeof(real) == 8 ? 1e3 : 1.0); C.lat_rho_scale = (real)((v > 0.0 && v < 1e12) ? v : 1.0); }
+        { const char* k = getenv("PG_LAT_POLISH_ROUNDS"); C.lat_polish_rounds = k ? atoi(k) : 3; if (C.lat_polish_rounds < 2) C.lat_polish_rounds = 2; }
         { const char* k = getenv("PG_LAT_SETTLE"); C.lat_settle = k ? atoi(k) : 0; }
         { const char* k = getenv("PG_LAT_WARM_ROUNDS"); C.lat_warm_rounds = k ? atoi(k) : 4; if (C.lat_warm_rounds < 0) C.lat_warm_rounds = 0; }
         { const char* k = getenv("PG_LAT_WIPM"); C.lat_wipm = k ? atoi(k) : 0; }
@@ -265,6 +266,8 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     }
     for (int i = 0; i < 4; i++) if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_create_error = "hipEventCreate failed"; free_all(h); delete h; return PG_ERR_HIP; }
     h->ev_ok = true;
+    { const char* e = getenv("PG_HJI_SEED"); C.hji_seed = e ? atoi(e) : 0; }
+    { const char* e = getenv("PG_HJI_ROUNDS"); C.hji_rounds = e ? atoi(e) : 0; }
     { const char* e = getenv("PG_SOLVE_SPLIT"); if (e && (e[0] == '0' || e[0] == '1')) h->split_solve = e[0] - '0'; }
     { const char* e = getenv("PG_FUSE"); if (e && e[0] >= '0' && e[0] <= '2') h->fuse = e[0] - '0'; }
     { const char* e = getenv("PG_PIPELINE"); if (e && e[0] >= '0' && e[0] <= '1') h->pipeline = e[0] - '0'; }

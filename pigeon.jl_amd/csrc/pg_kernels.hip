@@ -33,6 +33,8 @@ struct DevCfg {
     real ipm_tol, ipm_mu0;
     int polish;                   // active-set polish after the interior point (k_solve): 0 off, 1 on
     real polish_rho, polish_tol;  // penalty of the active rows in the polish solves; feasibility tolerance of its verification
+    int hji_rounds;               // k_solve: working sets such a seeded attempt may try (0: the cold-guess cap and its extension)
+    int hji_seed;                 // k_solve: rounds of an instance whose safety row is violated at the current control start from a seeded working set (0: interior point, as before)
     int cold_guess;               // > 0: a COLD instance first tries the polish from the empty active set (unconstrained LQ optimum + add/drop rounds), at most this many rounds
     int warm_polish;              // instances with a previous solution first try the polish from its active set and multipliers (no interior point if it verifies)
     real polish_ipm_tol;          // interior-point tolerance at which the polish is first attempted (>= ipm_tol; a polish that fails there resumes the interior point down to ipm_tol)
@@ -48,6 +50,7 @@ struct DevCfg {
     real lat_far_cost;          // k_solve_lat: starting cost per row beyond which the early hand-over to the polish is not tried
     real lat_mu0_cost;          // k_solve_lat: first barrier parameter = max(ipm_mu0, lat_mu0_cost x cost of the starting point per row)
     real lat_rho_scale;         // k_solve_lat: penalty of the held rows = polish_rho x this (see pg_solve_lat.hip)
+    int lat_polish_rounds;      // k_solve_lat: working sets a polish may try at the hand-over tolerance (one fewer behind the resumed interior point)
     int lat_settle;             // k_solve_lat: working-set decisions wait for settled multipliers (0 never, 1 warm attempts, 2 every polish)
     int lat_wipm; real lat_wmu, lat_wtau;      // k_solve_lat: interior point of a warm instance starts from the previous solution (floors of t lambda and of t)
     int lat_warm_rounds;        // k_solve_lat: working sets a warm attempt (previous step's set and multipliers) may try before the cold start takes over
@@ -1773,7 +1776,11 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     // attempt -1: the polish from the EMPTY set (cold instances, and warm ones whose previous set did not verify).  Not where the safety row is violated at the
     // current control: its weight (W_HJI) then overrides the tracking cost, the optimum is close to bang-bang (rate rows of both signs, force bounds, soft rows all
     // change together) and the add / drop iteration turns over dozens of rows per round -- the interior point needs its usual 8 iterations there
-    const bool guess = C.polish && C.cold_guess > 0 && !(C.has_hji && M0 * sx0[6] + M1 * sx0[7] + Q[o.b] < real(0.0));
+    const bool hji_hot = C.has_hji && M0 * sx0[6] + M1 * sx0[7] + Q[o.b] < real(0.0);
+    // hji_seed (PG_HJI_SEED, experiment of round 4): a violated safety row does NOT send the instance to the interior point; its rounds start from a SEEDED working set
+    // instead of the empty one -- the row held at its two stages with its slack free (an exact penalty: the multiplier of such a row IS the linear cost W_HJI of its slack)
+    // and, with hji_seed = 2, the steering-rate row of those stages in the direction that relieves it
+    const bool guess = C.polish && C.cold_guess > 0 && (!hji_hot || C.hji_seed > 0);
     int last_nchg = 0, good_steps = 0; real last_tmax = real(0.0); bool refine_only = false;
     int dbg_stage = -1, dbg_bit = -1, dbg_nadd = 0, dbg_ndrop = 0;      // diagnostic build: first stage / row that joined the set in the last check, rows added / dropped
     bool warm_attempt = false, from_prev = false;          // warm_attempt: a polish without an interior point in front (attempts -2, -1); from_prev: attempt -2
@@ -1785,6 +1792,25 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         amask = (act && from_prev) ? (unsigned)O.active[(size_t)b * N + s] : 0u; mask_ipm = amask;
 #pragma unroll
         for (int j = 0; j < NROW; j++) { if constexpr (IPM) { R.t[j] = real(1.0); R.corr[j] = real(0.0); } R.lam[j] = (act && from_prev && ((amask >> j) & 1u)) ? Lst[j] : real(0.0); }
+        if (attempt == -1 && hji_hot && hji_on) {
+            // can the violation be removed at node 2 at all?  What M u can gain there: the steering at its rate limit and Fx up to its bound (Fx has no rate limit, only a
+            // quadratic cost on its change).  If yes the row ends up MET with its slack at zero (row and sigma >= 0 both held, the steering rate limit of the first stage
+            // usually with them: steering is the cheap actuator); if not, the row stays violated at the exact-penalty multiplier W_HJI, Fx sits on its bound and the
+            // steering runs at its rate limit over both stages (the two patterns cover 370 of the 380 violated rows of config 3: tools/gpu_config3_probe.py PG_C3_DUMP=1)
+            const real viol = -(M0 * sx0[6] + M1 * sx0[7] + Q[o.b]);
+            const real reach = fabs(M0) * rl(M0 > real(0.0) ? bb[12] : bb[13], 0) + (M1 > real(0.0) ? M1 * (rl(bb[5], 0) - sx0[7]) : -M1 * (sx0[7] + rl(bb[2], 0)));
+            const bool removable = C.hji_seed >= 4 && viol < reach;
+            const unsigned rate_bit = (M0 > real(0.0)) ? (1u << 12) : (1u << 13);
+            if (removable) {
+                amask |= (1u << 14) | (1u << 15); R.lam[14] = real(0.5) * wh; R.lam[15] = real(0.5) * wh;
+                if (s == 0) amask |= rate_bit;
+            } else {
+                amask |= 1u << 14; R.lam[14] = wh;
+                if (C.hji_seed >= 2) amask |= rate_bit;
+                if (C.hji_seed >= 3) amask |= (M1 > real(0.0)) ? (1u << 5) : (1u << 2);      // ... and the force bound the row pushes Fx against
+            }
+            mask_ipm = amask;
+        }
         pmode = 1; mu = real(0.0);
     } else if (attempt == 0) {
         // ---- first attempt: v = 0 roll-out (dynamics- and rate-feasible), sigma just feasible; t = max(slack, tau); lambda = mu0 / t ----
@@ -1849,7 +1875,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     const int round_cap = attempt == -1 ? C.cold_guess : PG_POLISH_ROUNDS;
     // a set that moves by a row or two per round on a nearly feasible point is a ramp being extended or released one stage at a time (the multiplier of the next row
     // only changes sign once the previous one has left): it gets there, and eight more 25 us rounds are far cheaper than the interior point they avoid
-    auto over_cap = [&](int pass) { return pass > round_cap + (((warm_attempt || sizeof(real) == 8) && last_tmax < real(1.0)) ? (last_nchg <= 2 ? (sizeof(real) == 8 ? 16 : 8) : (last_nchg <= PG_PROGRESS_ROWS ? 8 : 0)) : 0); };      // (also for the warm attempt: a fall-back to the cold start costs ten rounds, and the slowest instance sets the kernel time)
+    // (a seeded attempt on a violated safety row -- hji_seed -- either verifies within a few working sets or not at all: its cap is hji_rounds, without the extension)
+    auto over_cap = [&](int pass) { if (attempt == -1 && hji_hot && C.hji_rounds > 0) return pass > C.hji_rounds; return pass > round_cap + (((warm_attempt || sizeof(real) == 8) && last_tmax < real(1.0)) ? (last_nchg <= 2 ? (sizeof(real) == 8 ? 16 : 8) : (last_nchg <= PG_PROGRESS_ROWS ? 8 : 0)) : 0); };      // (also for the warm attempt: a fall-back to the cold start costs ten rounds, and the slowest instance sets the kernel time)
     // Active-set polish (OSQP-style, on the stage-structured problem).  The interior point approaches nearly degenerate rows (slack and multiplier both ~ sqrt(mu))
     // like sqrt(mu), so its iterate can sit 1e-6 away from the optimum at any tolerance fp64 rounding allows.  Once it has converged, the rows with
     // lambda > t are held as EQUALITIES (augmented Lagrangian with penalty rho, multiplier estimates y = lambda), every other row is dropped, and the

@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // (-y t + rho/2 t^2: the shape of a barrier term with W = rho and constant multiplier part y - rho b), every other row absent; y lives in L.
     // working sets tried per polish: three at the hand-over tolerance (of the 3851 N = 50 + walls instances that verify, 2717 / 876 / 242 / 16 do so in round 1 / 2 / 3 / 4),
     // two in the second attempt behind the resumed interior point (the slowest wavefront sets the kernel's time, and these are its instances)
-    const int LAT_POLISH_ROUNDS = 3;
+    const int LAT_POLISH_ROUNDS = C.lat_polish_rounds;
     // Penalty of the held rows: polish_rho x lat_rho_scale (fp64: 1e3, i.e. 1e10 at the default 1e7).  A held rate or steering-bound row pins the input of its stage, and
     // the multiplier iteration lambda <- lambda - rho t contracts by S / (S + rho) per pass, S = Rhat + Bbar' P Bbar the curvature of the cost-to-go in that input -- on the
     // open-loop unstable 8 s horizon P grows like exp(2 lambda T), S reaches 1e9..1e12, and at rho = 1e7 the multipliers of such rows stall: 6-7 % of the N = 50 batch ended

@@ -16,11 +16,11 @@ traj = pkg.load_path_fixture("skidpadoval")
 B, Ns, Nl = 4096, 10, 40
 rho = float(os.environ['PG_RHO']) if 'PG_RHO' in os.environ else None          # PG_RHO: polish penalty (default: the library's)
 prec = os.environ.get('PG_PREC', 'f64')                                         # PG_PREC=f32: the fp32 library against the oracle's exact optimum of ITS OWN (fp32-rounded) QP data
-mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=Ns, N_long=Nl, walls=walls, polish=polish, polish_rho=rho, precision=prec)
+mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=Ns, N_long=Nl, walls=walls, polish=polish, polish_rho=rho, precision=prec, polish_ipm_tol=float(os.environ['PG_PIT']) if 'PG_PIT' in os.environ else None)
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B)
 if prec == 'f32': state, control = state.astype(np.float32).astype(np.float64), control.astype(np.float32).astype(np.float64)
 u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
-print(f"precision={prec} walls={walls} rho={rho} phases {np.round(mpc.phase_ms(), 3)}", flush=True)
+print(f"precision={prec} walls={walls} rho={rho} far={os.environ.get('PG_LAT_FAR_COST')} pit={os.environ.get('PG_PIT')} phases {np.round(mpc.phase_ms(), 3)}", flush=True)
 t = time.time()
 res = check_lateral_batch_against_oracle(pkg, om, traj, mpc, B, Ns, Nl, walls, want_more=True)
 x, sg = mpc.solution(); st, it, act, mu = mpc.solve_info()
