@@ -1328,17 +1328,19 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     // prime(k0, dir): block k0 lands in the ring, block k0+dir is in flight.  step(k, dir) at the top of stage k: block k+dir lands, k+2dir takes off.
     auto ring_prime = [&](int k0, int dir) { if (RING) { ring_load(k0); ring_put(k0); ring_load(k0 + dir); } };
     auto ring_step = [&](int k, int dir) { if (RING) { ring_put(k + dir); ring_load(k + 2 * dir); } };
-    if (!RING) {      // short horizons: every stage block is read from HBM exactly once and stays in LDS (SB N doubles = 17.3 KB at N = 30)
-        for (int k0 = 0; k0 < N; k0 += 6) {      // six stages in flight per lane
-            real v0[6], v1[6];
+    // short horizons: every stage block is read from HBM exactly once and stays in LDS (SB N doubles = 17.3 KB at N = 30).  ALL the loads of the prologue -- the N stage
+    // blocks (two values per lane and stage), the fixed first node, the per-stage constants below -- are issued as ONE batch before anything waits for any of them
+    // (round 4; rounds 1-3 filled the LDS in batches of six stages, each a round trip to the memory side, and loaded the rest in three more dependent round trips)
+    constexpr int NFILL = RING ? 1 : 32;
+    real fill0[NFILL], fill1[NFILL];
+    if (!RING) {
 #pragma unroll
-            for (int u = 0; u < 6; u++) { const int kk = k0 + u < N ? k0 + u : N - 1; v0[u] = Q[src0 + sstr * kk]; v1[u] = Q[src1 + 12 * kk]; }
-#pragma unroll
-            for (int u = 0; u < 6; u++) if (k0 + u < N) { ring_v0 = v0[u]; ring_v1 = v1[u]; ring_put(k0 + u); }
-        }
+        for (int u = 0; u < NFILL; u++) { const int kk = u < N ? u : N - 1; fill0[u] = Q[src0 + sstr * kk]; fill1[u] = Q[src1 + 12 * kk]; }
     }
+    const real x0_fill = lane < 6 ? Q[o.qcurr + lane] : Q[o.ucurr + (lane < 8 ? lane - 6 : 0)];
+    const int prev_solved = O.solved[b], prev_status = O.status[b];      // (the warm-start test further down: loaded with the batch, not in a round trip of its own)
+    const real hji_b = Q[o.b];
     if (lane < 2) sZero[lane] = real(0.0);
-    if (lane < 8) sx0[lane] = lane < 6 ? Q[o.qcurr + lane] : Q[o.ucurr + lane - 6];
 
     // ---- per-stage constants in the registers of lane s (stage s = transition s, node s+1) ----
     const bool act = lane < N;
@@ -1359,6 +1361,15 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     if (wall_on) { const real* w = C.wall_edges + ((size_t)b * N + s) * 2; bb[0] = w[0]; bb[1] = -w[1]; bb[2] = real(0.0); }
     const real ww = C.wall_weight * dts;
     const real Qd5 = real(2.0) * C.cp.Q_e * dts;
+    if (!RING) {      // (the loads issued at the top have had the whole constant set-up to arrive)
+#pragma unroll
+        for (int u = 0; u < NFILL; u++) {
+            real* slot = ring_slot(u < N ? u : N - 1);
+            *(((mvA || mvB || mvC) && u < N) ? slot + dst0 : sDum + lane) = mvB ? fill0[u] + fill1[u] : fill0[u];
+            *((mvB && u < N) ? slot + dst1 : sDum + lane) = fill1[u];
+        }
+    }
+    if (lane < 8) sx0[lane] = x0_fill;
     if (act) {   // entries of the stage cost that never change
         real* Qo = sQ + 10 * (s + 1);
         Qo[0] = real(2.0) * C.cp.Q_ds * dts; Qo[4] = real(2.0) * C.cp.Q_dpsi * dts; Qo[5] = real(2.0) * C.cp.Q_e * dts;
@@ -1772,11 +1783,11 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
     // (attempt -1): in closed loop the set rarely changes from one 10 ms step to the next, and a verified round IS the exact optimum of the new QP whatever the
     // guess was, so nothing is lost in accuracy; if the rounds do not verify, the interior point runs as for a cold instance.
     real* const Lst = O.lam + ((size_t)b * N + s) * NROW;
-    const bool warm = C.polish && C.warm_polish && O.solved[b] != 0 && O.status[b] == PG_SOLVED;
+    const bool warm = C.polish && C.warm_polish && prev_solved != 0 && prev_status == PG_SOLVED;
     // attempt -1: the polish from the EMPTY set (cold instances, and warm ones whose previous set did not verify).  Not where the safety row is violated at the
     // current control: its weight (W_HJI) then overrides the tracking cost, the optimum is close to bang-bang (rate rows of both signs, force bounds, soft rows all
     // change together) and the add / drop iteration turns over dozens of rows per round -- the interior point needs its usual 8 iterations there
-    const bool hji_hot = C.has_hji && M0 * sx0[6] + M1 * sx0[7] + Q[o.b] < real(0.0);
+    const bool hji_hot = C.has_hji && M0 * sx0[6] + M1 * sx0[7] + hji_b < real(0.0);
     // hji_seed (PG_HJI_SEED, experiment of round 4): a violated safety row does NOT send the instance to the interior point; its rounds start from a SEEDED working set
     // instead of the empty one -- the row held at its two stages with its slack free (an exact penalty: the multiplier of such a row IS the linear cost W_HJI of its slack)
     // and, with hji_seed = 2, the steering-rate row of those stages in the direction that relieves it
@@ -1797,7 +1808,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
             // quadratic cost on its change).  If yes the row ends up MET with its slack at zero (row and sigma >= 0 both held, the steering rate limit of the first stage
             // usually with them: steering is the cheap actuator); if not, the row stays violated at the exact-penalty multiplier W_HJI, Fx sits on its bound and the
             // steering runs at its rate limit over both stages (the two patterns cover 370 of the 380 violated rows of config 3: tools/gpu_config3_probe.py PG_C3_DUMP=1)
-            const real viol = -(M0 * sx0[6] + M1 * sx0[7] + Q[o.b]);
+            const real viol = -(M0 * sx0[6] + M1 * sx0[7] + hji_b);
             const real reach = fabs(M0) * rl(M0 > real(0.0) ? bb[12] : bb[13], 0) + (M1 > real(0.0) ? M1 * (rl(bb[5], 0) - sx0[7]) : -M1 * (sx0[7] + rl(bb[2], 0)));
             const bool removable = C.hji_seed >= 4 && viol < reach;
             const unsigned rate_bit = (M0 > real(0.0)) ? (1u << 12) : (1u << 13);
