@@ -243,7 +243,9 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         { const char* k = getenv("PG_LAT_WIPM"); C.lat_wipm = k ? atoi(k) : 0; }
         C.lat_wmu = (real)env_pos("PG_LAT_WMU", 1e-2); C.lat_wtau = (real)env_pos("PG_LAT_WTAU", 1e-4);
         const char* e = getenv("PG_LAT_MEM");
-        h->lat_mem = N > 32 || (e && e[0] == '1');
+        // (round 4: with the wall rows the two-slot register variant spills 720 B per lane since the warm start was added -- 1.57 ms at N = 30 against 1.36 ms through the
+        // workspace; without them the registers still win, 0.94 against 1.01 ms)
+        h->lat_mem = N > 32 || (cfg->walls && N > 16) || (e && e[0] == '1');
         if (h->lat_mem) { ALLOC(h->d_lat_ws, lat_ws_bytes(cap), char); C.lat_ws = h->d_lat_ws; }
     }
 #undef ALLOC

@@ -300,6 +300,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     real T[NREG][NR], L[NREG][NR], CR[NREG][NR];
     unsigned amask[NREG], mask_ipm[NREG], nmask[NREG]; real SN[NREG][3];
     char* const wsw = MEM ? C.lat_ws + (size_t)blockIdx.x * 4 * LAT_WS_SLOT_BYTES : nullptr;
+    auto is_act = [&](int j) __attribute__((always_inline)) { return c + 16 * j < N; };
     auto for_slots = [&](auto&& body) __attribute__((always_inline)) {
         if constexpr (MEM) {
 #pragma unroll 1
@@ -311,9 +312,16 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     };
     auto get_tl = [&](int j, real* Tl, real* Ll) __attribute__((always_inline)) {
         if constexpr (MEM) {
+            // (lanes whose stage lies beyond the horizon -- 14 of the 16 lanes of the last slot at N = 50 -- carry t = lambda = 1 and touch no memory: a fifth of the
+            // workspace traffic of the kernel was theirs)
             const real2* p = reinterpret_cast<const real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES) + lane;
+            if (is_act(j)) {
 #pragma unroll
-            for (int r = 0; r < NR; r++) { const real2 v = p[64 * r]; Tl[r] = v.x; Ll[r] = v.y; }
+                for (int r = 0; r < NR; r++) { const real2 v = p[64 * r]; Tl[r] = v.x; Ll[r] = v.y; }
+            } else {
+#pragma unroll
+                for (int r = 0; r < NR; r++) { Tl[r] = real(1.0); Ll[r] = real(1.0); }
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < NR; r++) { Tl[r] = T[j][r]; Ll[r] = L[j][r]; }
@@ -322,8 +330,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     auto put_tl = [&](int j, const real* Tl, const real* Ll) __attribute__((always_inline)) {
         if constexpr (MEM) {
             real2* p = reinterpret_cast<real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES) + lane;
+            if (is_act(j)) {
 #pragma unroll
-            for (int r = 0; r < NR; r++) { real2 v; v.x = Tl[r]; v.y = Ll[r]; p[64 * r] = v; }
+                for (int r = 0; r < NR; r++) { real2 v; v.x = Tl[r]; v.y = Ll[r]; p[64 * r] = v; }
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < NR; r++) { T[j][r] = Tl[r]; L[j][r] = Ll[r]; }
@@ -332,8 +342,13 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     auto get_cr = [&](int j, real* Cl) __attribute__((always_inline)) {
         if constexpr (MEM) {
             const real2* p = reinterpret_cast<const real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL) + lane;
+            if (is_act(j)) {
 #pragma unroll
-            for (int q = 0; q < NP; q++) { const real2 v = p[64 * q]; Cl[2 * q] = v.x; if (2 * q + 1 < NR) Cl[2 * q + 1] = v.y; }
+                for (int q = 0; q < NP; q++) { const real2 v = p[64 * q]; Cl[2 * q] = v.x; if (2 * q + 1 < NR) Cl[2 * q + 1] = v.y; }
+            } else {
+#pragma unroll
+                for (int r = 0; r < NR; r++) Cl[r] = real(0.0);
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < NR; r++) Cl[r] = CR[j][r];
@@ -342,8 +357,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     auto put_cr = [&](int j, const real* Cl) __attribute__((always_inline)) {
         if constexpr (MEM) {
             real2* p = reinterpret_cast<real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL) + lane;
+            if (is_act(j)) {
 #pragma unroll
-            for (int q = 0; q < NP; q++) { real2 v; v.x = Cl[2 * q]; v.y = 2 * q + 1 < NR ? Cl[2 * q + 1] : real(0.0); p[64 * q] = v; }
+                for (int q = 0; q < NP; q++) { real2 v; v.x = Cl[2 * q]; v.y = 2 * q + 1 < NR ? Cl[2 * q + 1] : real(0.0); p[64 * q] = v; }
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < NR; r++) CR[j][r] = Cl[r];
@@ -352,20 +369,21 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     auto get_sn = [&](int j, real* s3) __attribute__((always_inline)) {
         if constexpr (MEM) {
             const real2* p = reinterpret_cast<const real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL + WS_CR) + 2 * lane;
-            const real2 a = p[0], b_ = p[1]; s3[0] = a.x; s3[1] = a.y; s3[2] = b_.x;
+            if (is_act(j)) { const real2 a = p[0], b_ = p[1]; s3[0] = a.x; s3[1] = a.y; s3[2] = b_.x; }
+            else { s3[0] = real(0.0); s3[1] = real(0.0); s3[2] = real(0.0); }
         } else { s3[0] = SN[j][0]; s3[1] = SN[j][1]; s3[2] = SN[j][2]; }
     };
     auto put_sn = [&](int j, const real* s3) __attribute__((always_inline)) {
         if constexpr (MEM) {
             real2* p = reinterpret_cast<real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL + WS_CR) + 2 * lane;
-            real2 a, b_; a.x = s3[0]; a.y = s3[1]; b_.x = s3[2]; b_.y = real(0.0); p[0] = a; p[1] = b_;
+            if (is_act(j)) { real2 a, b_; a.x = s3[0]; a.y = s3[1]; b_.x = s3[2]; b_.y = real(0.0); p[0] = a; p[1] = b_; }
         } else { SN[j][0] = s3[0]; SN[j][1] = s3[1]; SN[j][2] = s3[2]; }
     };
     // working set of the polish, the interior point's set at the hand-over, the set the last polish solve proposes
     struct Meta { unsigned am, mi, nm; };
     auto get_meta = [&](int j) __attribute__((always_inline)) -> Meta {
         Meta m;
-        if constexpr (MEM) { const uint4 v = *(reinterpret_cast<const uint4*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL + WS_CR + WS_SN) + lane); m.am = v.x; m.mi = v.y; m.nm = v.z; }
+        if constexpr (MEM) { m.am = 0u; m.mi = 0u; m.nm = 0u; if (is_act(j)) { const uint4 v = *(reinterpret_cast<const uint4*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL + WS_CR + WS_SN) + lane); m.am = v.x; m.mi = v.y; m.nm = v.z; } }
         else { m.am = amask[j]; m.mi = mask_ipm[j]; m.nm = nmask[j]; }
         return m;
     };
@@ -375,10 +393,9 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         return m;
     };
     auto put_meta = [&](int j, const Meta& m) __attribute__((always_inline)) {
-        if constexpr (MEM) { uint4 v; v.x = m.am; v.y = m.mi; v.z = m.nm; v.w = 0u; *(reinterpret_cast<uint4*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL + WS_CR + WS_SN) + lane) = v; }
+        if constexpr (MEM) { if (is_act(j)) { uint4 v; v.x = m.am; v.y = m.mi; v.z = m.nm; v.w = 0u; *(reinterpret_cast<uint4*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL + WS_CR + WS_SN) + lane) = v; } }
         else { amask[j] = m.am; mask_ipm[j] = m.mi; nmask[j] = m.nm; }
     };
-    auto is_act = [&](int j) __attribute__((always_inline)) { return c + 16 * j < N; };
     auto sx_of = [&](int j) __attribute__((always_inline)) { const int s = is_act(j) ? c + 16 * j : N - 1; return O.sol_x + (size_t)b * NN * 8 + 8 * (s + 1); };
     auto sg_of = [&](int j) __attribute__((always_inline)) { const int s = is_act(j) ? c + 16 * j : N - 1; return O.sol_sigma + ((size_t)b * N + s) * 3; };
 

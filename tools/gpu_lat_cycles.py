@@ -11,7 +11,8 @@ walls = len(sys.argv) > 3 and sys.argv[3] == "1"
 traj = pkg.load_path_fixture("skidpadoval")
 mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=Nl, walls=walls)
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B)
-mpc.step_(state, control, t0, time_offset=toff)
+mpc.set_inputs(state, control, t0, time_offset=toff)
+mpc.compute_time_steps_(); mpc.compute_linearization_nodes_(); mpc.update_QP_()      # (no solve yet: the diagnostic launch below is the COLD solve; k_solve_lat warm-starts otherwise)
 out = np.zeros(B * 9 + 1024, dtype=np.uint64)
 rc = mpc.lib.pg_debug_solve_cycles(mpc.h, out.ctypes.data_as(C.c_void_p)); assert rc == 0
 out = out[:B * 6].reshape(B, 6).astype(float)
