@@ -46,6 +46,34 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
+# Algorithmic FLOPs of k_solve_lat per instance and pass through its loop (an interior-point iteration or a polish round; FMA = 2), 5-state stage, NR rows per stage:
+# matrix pass 2 x (P [A B c] 175 + B'M 35 + Q + A'M + F'K 175 + gains 15) = 800, vector pass 2 x 45 = 90, two roll-outs 2 x 2 x 42 = 170, and the three stage-parallel
+# passes (barrier terms and slack elimination, Newton point and slacks, step rules and update): ~70 flops per row and pass.
+def lat_flops(N, NR, passes):
+    return passes * N * (800.0 + 90.0 + 170.0 + 3 * 70.0 * NR)
+
+
+def roofline_of(tr, kernel_match, ms, units, bytes_per_unit, flops, precision, note=None):
+    """`roofline` object of a secondary benchmark line: HBM fraction from the algorithmic bytes and the live duration; counter traffic, VALU issue fraction (SQ_INSTS_VALU x 4
+    cycles over the SIMD time of the launch) and the rocprof duration spread from the committed PMC / stats passes (profiles/traffic.json); flop-model fraction of the vector peak."""
+    achieved = units * bytes_per_unit / (ms * 1e-3) / 1e9
+    peak_tf = FP64_VALU_PEAK_TF if precision == "f64" else 2 * FP64_VALU_PEAK_TF
+    r = {"bound": "hbm", "kernel": kernel_match, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "avg_launch_ms": ms,
+         "algorithmic_bytes_per_launch": units * bytes_per_unit, "traffic": None,
+         "valu": {"bound": "valu-" + precision, "algorithmic_flops_per_launch": flops, "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+                  "frac": flops / (ms * 1e-3) / 1e12 / peak_tf}}
+    hit = [v for k, v in (tr or {}).get("kernels", {}).items() if kernel_match in k]
+    if hit:
+        e = hit[0]
+        r["traffic"] = e.get("hbm_bytes_per_launch"); r["traffic_source"] = e.get("source")
+        for k in ("valu_issue_frac", "valu_insts_per_launch", "avg_launch_ns_rocprof", "min_launch_ns_rocprof", "max_launch_ns_rocprof", "stddev_launch_ns_rocprof", "launches_rocprof"):
+            if k in e:
+                r[k] = e[k]
+    if note:
+        r["note"] = note
+    return r
+
+
 def mfma_util(tr, dom, pipelined):
     """Matrix-core utilisation of the dominant kernel from the committed PMC pass (profiles/traffic.json, written by tools/summarize_profiles.py): busy cycles of the MFMA
     pipe over the kernel's busy cycles, and the fp64 MFMA flop rate against the 78.6 TFLOP/s dense fp64 matrix peak.  None when the counters were not collected."""
@@ -220,6 +248,10 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     B = args.batch
+    try:
+        TR = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        TR = None
     traj = pkg.load_path_fixture("skidpadoval")
     mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision=args.precision)
     npdt = np.float64 if args.precision == "f64" else np.float32; tdt = torch.float64 if args.precision == "f64" else torch.float32
@@ -377,8 +409,15 @@ def main():
                 mpc_d.reset(); mpc_d.step_dev(u_out.data_ptr())          # (reset: solved = false -- every timed step is a COLD step; k_solve_lat warm-starts otherwise)
             torch.cuda.synchronize(); td = time.perf_counter() - td
             std, itd, _, _ = mpc_d.solve_info(); pd_ = mpc_d.polish_info()
-            r = {"value": B * args.steps / td, "unit": "solves/s", "ms_per_step": 1e3 * td / args.steps, "phase_ms": [float(v) for v in mpc_d.phase_ms()],
-                 "solved": f"{int(pkg.is_solved(std).sum())}/{B}", "ipm_iters_mean": float(np.mean(itd)), "verified_by_polish": f"{int((pd_ >= 1).sum())}/{B}"}
+            phd = [float(v) for v in mpc_d.phase_ms()]
+            r = {"value": B * args.steps / td, "unit": "solves/s", "ms_per_step": 1e3 * td / args.steps, "phase_ms": phd,
+                 "solved": f"{int(pkg.is_solved(std).sum())}/{B}", "ipm_iters_mean": float(np.mean(itd)), "ipm_iters_max": int(np.max(itd)), "verified_by_polish": f"{int((pd_ >= 1).sum())}/{B}"}
+            # roofline of the dominant kernel (k_solve_lat): the launch runs as long as its slowest instance -- passes through the loop = interior-point iterations + polish rounds
+            passes = itd.astype(np.float64) + np.where(pd_ > 0, pd_, 3) + 1.0
+            r["roofline"] = roofline_of(TR, "k_solve_lat<1, true, true>" if walls else "k_solve_lat<1, false, true>", phd[2], B, BYTES_PER_SOLVE_COLD_FP64 if args.precision == "f64" else 68,
+                                        float(np.sum(lat_flops(50, 13 if walls else 10, passes))), args.precision,
+                                        note="k_solve_lat is bound by the dependent fp64 chains of its slowest instance (one wavefront per SIMD, every wavefront resident): the HBM fraction is ~1e-5 by "
+                                             "construction; `traffic` is what the per-wavefront workspace and the packed stage records move through the memory side (L2 / Infinity Cache, not HBM-served)")
             mpc_d.close()
             return r
         dec = {"workload": f"configs[4]: Batch={B} decoupled MPC, N=50 + both_walls (soft rows edge_R - sw <= e <= edge_L + sw from the tube's edge channels: a build-defined "
@@ -406,10 +445,11 @@ def main():
                  "verified_last_step": f"{int((pl >= 1).sum())}/{B}", "served_by_warm_attempt_alone_last_step": int((itl == 0).sum()), "ipm_iters_mean_last_step": float(np.mean(itl))}
             ml.close()
             return r
-        dec["closed_loop"] = {"workload": f"{B} lateral controllers (N = 50) in closed loop on the device, 40 steps of 10 ms behind a burn-in; per step: time grid + projection, k_nodes_dec, k_qp_dec, k_solve_lat, plant RK4",
-                              "benchmark_batch_walls": {"burn_in_steps": 4, "warm_start_of_active_set": run_loop("skidpadoval", True, 4, True), "without_it": run_loop("skidpadoval", True, 4, False)},
-                              "settled_loop_EastPaddock": {"burn_in_steps": 100, "warm_start_of_active_set": run_loop("EastPaddock", False, 100, True), "without_it": run_loop("EastPaddock", False, 100, False)},
-                              "accuracy": "every instance of a warm step <= 1e-6 of the exact optimum of its own QP data: tests/test_gpu_decoupled_closed_loop.py (B = 4096, both loops)"}
+        if not args.no_rollout:
+          dec["closed_loop"] = {"workload": f"{B} lateral controllers (N = 50) in closed loop on the device, 40 steps of 10 ms behind a burn-in; per step: time grid + projection, k_nodes_dec, k_qp_dec, k_solve_lat, plant RK4",
+                                "benchmark_batch_walls": {"burn_in_steps": 4, "warm_start_of_active_set": run_loop("skidpadoval", True, 4, True), "without_it": run_loop("skidpadoval", True, 4, False)},
+                                "settled_loop_EastPaddock": {"burn_in_steps": 100, "warm_start_of_active_set": run_loop("EastPaddock", False, 100, True), "without_it": run_loop("EastPaddock", False, 100, False)},
+                                "accuracy": "every instance of a warm step <= 1e-6 of the exact optimum of its own QP data: tests/test_gpu_decoupled_closed_loop.py (B = 4096, both loops)"}
 
     # HJI value/gradient lookup (the bandwidth-bound kernel of the path): 2^20 random in-grid relative states against the config-3 grid
     hji = None
@@ -468,6 +508,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_f32 and args.precision == "f64":
         m32 = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision="f32")
         m32.set_stream(torch.cuda.current_stream().cuda_stream)
+        TR32 = {"kernels": (TR or {}).get("kernels_f32", {})}
         other = pkg.synthetic.other_cars(state, seed=777)
         f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
         s32, c32, o32 = f(state), f(control), f(other)
@@ -481,9 +522,12 @@ def main():
             for _ in range(args.steps):
                 m32.reset(); m32.step_dev(u32.data_ptr())
             torch.cuda.synchronize(); t_ = time.perf_counter() - t_
-            st_, it_, _, _ = m32.solve_info(); p_ = m32.polish_info()
-            return {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": [float(v) for v in m32.phase_ms()],
-                    "solved": f"{int(pkg.is_solved(st_).sum())}/{B}", "ipm_iters_mean": float(np.mean(it_)), "verified_by_polish": f"{int((p_ >= 1).sum())}/{B}"}
+            st_, it_, _, _ = m32.solve_info(); p_ = m32.polish_info(); ph32 = [float(v) for v in m32.phase_ms()]
+            rounds32 = np.where(p_ > 0, p_, np.where(p_ < 0, 6, 0))
+            return {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": ph32,
+                    "solved": f"{int(pkg.is_solved(st_).sum())}/{B}", "ipm_iters_mean": float(np.mean(it_)), "ipm_iters_hist": hist(it_), "verified_by_polish": f"{int((p_ >= 1).sum())}/{B}",
+                    "roofline": roofline_of(TR32, "k_solve<", ph32[2], B, 68 + (16 + 4096 if with_hji else 0), float(np.sum(solve_flops(m32.N, it_.astype(np.float64), rounds32.astype(np.float64)))), "f32",
+                                            note="solve phase of the fp32 library (k_solve, two waves per SIMD); bytes per solve: 68 (SURVEY 8d, fp32) + other car 16 B + one 4 KiB cell record with the safety row")}
 
         plain = run32(False)
         f32 = {"workload": f"configs[2]: Batch={B} coupled MPC + HJI safety constraint (13x13x9x9x9x9x9 float32 grid), N=30, fp32, cold", "dtype": "f32",
@@ -530,7 +574,7 @@ def main():
         dom_ms = float(ph[dom])
         bytes_per_solve = BYTES_PER_SOLVE_COLD_FP64 if args.precision == "f64" else 68        # 112 B fp64; fp32 = 9 floats + t0 (double) in, 3 floats + status + iters out
         achieved = B * bytes_per_solve / (dom_ms * 1e-3) / 1e9
-        traffic = None; traffic_src = None; traffic_stale = None; tr = None
+        traffic = None; traffic_src = None; traffic_stale = None; tr = None; dom_extra = {}
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             # the counters were taken with a particular build: traffic.json records the hash of the kernel sources it was taken at (tools/summarize_profiles.py), and the
@@ -539,6 +583,7 @@ def main():
             kern = {0: "k_nodes_linearize" if pipelined else "k_nodes", 1: "k_linearize", 2: "k_solve"}[dom]                  # the kernel that makes up the dominant phase (no HJI row in the headline run)
             hit = [v for k, v in tr.get("kernels", {}).items() if kern in k]
             traffic = hit[0]["hbm_bytes_per_launch"] if hit else tr.get("hbm_bytes_per_launch"); traffic_src = (hit[0] if hit else tr).get("source")
+            dom_extra = {k: hit[0][k] for k in ("valu_issue_frac", "valu_insts_per_launch", "avg_launch_ns_rocprof", "min_launch_ns_rocprof", "max_launch_ns_rocprof", "stddev_launch_ns_rocprof") if hit and k in hit[0]}
         except Exception:
             pass
         # k_linearize is throughput-bound on the fp64 vector unit: 40 dynamics evaluations per interval x (130 value + 260 per tangent direction) flops -- eight
@@ -557,7 +602,7 @@ def main():
                 "peak": peak_tf, "unit": "TFLOP/s", "frac": fl / (float(ph[2]) * 1e-3) / 1e12 / peak_tf, "avg_launch_ms": float(ph[2]),
                 "source": "flop model of the stage-structured interior point (bench.py solve_flops, EXPERIMENTS.md 6) x live iteration / polish-round counts; time live (HIP events)"}
         line = {
-            "metric": "MPC QP solves/sec (N=30 coupled, X1 model)", "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+            "metric": "MPC QP solves/sec (N=30 coupled, X1 model)", "kernel_source_sha16": kernel_source_sha16(), "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": (f"configs[1]: Batch={B}/GPU coupled MPC, N=30 (N_short=10, N_long=20), X1, randomised x0 along skidpadoval, cold start, HJI inactive, fp64" if args.precision == "f64"
@@ -567,7 +612,7 @@ def main():
                                  "Mehrotra interior point to mu <= " + ("3e-6" if args.precision == "f64" else "1e-4") + ", then active-set polish (verified KKT point)",
                        "accuracy": "measured in this run: cpu_baseline.accuracy (sample of 256); every one of the 4096 instances <= 1e-6 is asserted by tests/test_gpu_full_size.py (measured max 5e-11)"},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale, "avg_launch_ms": dom_ms, "mfma": mfma_util(tr, dom, pipelined), "valu": valu, "valu_linearize": valu_lin,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale, "avg_launch_ms": dom_ms, **dom_extra, "mfma": mfma_util(tr, dom, pipelined), "valu": valu, "valu_linearize": valu_lin,
                          "note": f"algorithmic HBM bytes are {bytes_per_solve} B/solve (SURVEY 8d): the step is VALU/LDS/latency bound by construction, not HBM bound; see roofline.valu and hji_lookup"},
             "phase_ms": {n: float(v) for n, v in zip(names, ph)},
             "warm_value": None if args.no_warm else world * B * args.steps / warm_elapsed,

@@ -32,6 +32,11 @@ if [ "$PART" = "2" ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_roll -- python3 $ROLL > $OUT/bench_stats_roll.log 2>&1
   C3="bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-decoupled --no-rollout --no-warm --precision f32"   # the fp32 library alone: its headline, the HJI lookups, config 3 (+ HJI row)
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -- python3 $C3 > $OUT/bench_stats_c3.log 2>&1
+  pmc pmc_fetch_c3 "FETCH_SIZE" "$C3"
+  pmc pmc_write_c3 "WRITE_SIZE" "$C3"
+  pmc pmc_sq_c3 "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT" "$C3"
+  DECLOOP="bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-f32 --no-warm --no-hji"                        # + the lateral closed loops (warm k_solve_lat, k_advance)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_decloop -- python3 $DECLOOP > $OUT/bench_stats_decloop.log 2>&1
 fi
 if [ "$PART" = "3" ]; then
   F32="bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-decoupled --no-hji --no-rollout --no-warm --precision f32 --batch 8192"      # config 4's per-GPU share

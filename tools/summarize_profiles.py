@@ -31,7 +31,7 @@ def short(name):
 
 stats = {}
 for d, out in (("stats", "kernel_stats.csv"), ("stats_dec", "kernel_stats_dec.csv"), ("stats_roll", "kernel_stats_roll.csv"), ("stats_c3", "kernel_stats_c3.csv"),
-               ("stats_f32", "kernel_stats_f32.csv")):
+               ("stats_f32", "kernel_stats_f32.csv"), ("stats_decloop", "kernel_stats_decloop.csv")):
     ks = glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv"))
     if len(ks) == 1:
         shutil.copy(ks[0], os.path.join(dst, out))
@@ -39,7 +39,8 @@ for d, out in (("stats", "kernel_stats.csv"), ("stats_dec", "kernel_stats_dec.cs
 assert "stats" in stats, "PART=1 of tools/gpu_profile.sh has not run"
 
 groups = {"headline": ["pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_mfma", "pmc_tcc", "pmc_wr", "pmc_wb"], "hji": ["pmc_fetch_hji", "pmc_write_hji"],
-          "dec": ["pmc_fetch_dec", "pmc_write_dec", "pmc_sq_dec", "pmc_sq2_dec"], "f32": ["pmc_fetch_f32", "pmc_write_f32", "pmc_sq_f32", "pmc_mfma_f32"]}
+          "dec": ["pmc_fetch_dec", "pmc_write_dec", "pmc_sq_dec", "pmc_sq2_dec"], "f32": ["pmc_fetch_f32", "pmc_write_f32", "pmc_sq_f32", "pmc_mfma_f32"],
+          "c3": ["pmc_fetch_c3", "pmc_write_c3", "pmc_sq_c3"]}
 summary = {}
 for g, dirs in groups.items():
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
@@ -57,10 +58,16 @@ json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1, s
 
 
 def kernel_source_sha16():
-    h = hashlib.sha256()
-    for f in ("pg_kernels.hip", "pg_solve_lat.hip", "pg_device.hpp", "pg_api.hip"):
-        h.update(open(os.path.join(ROOT, "pigeon.jl_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+    """The hash of the kernel sources the counters were TAKEN at: bench.py prints it into its JSON line, and the profile's own bench log (gpurun_out/prof/bench_stats.log)
+    carries that line -- the stamp is the collection's, not whatever the tree holds when this script runs.  Fallback (logs of an older bench.py): the tree's hash."""
+    try:
+        line = [l for l in open(os.path.join(src, "bench_stats.log")).read().splitlines() if l.startswith("{")][-1]
+        return json.loads(line)["kernel_source_sha16"]
+    except Exception:
+        h = hashlib.sha256()
+        for f in ("pg_kernels.hip", "pg_solve_lat.hip", "pg_device.hpp", "pg_api.hip"):
+            h.update(open(os.path.join(ROOT, "pigeon.jl_amd", "csrc", f), "rb").read())
+        return h.hexdigest()[:16]
 
 
 def entry(group, stats_key, match):
@@ -75,7 +82,16 @@ def entry(group, stats_key, match):
         return None
     c = {k: v["mean_per_launch"] for k, v in S[dk].items()}
     e = {"hbm_bytes_per_launch": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024, "fetch_size_kib": c["FETCH_SIZE"], "write_size_kib": c["WRITE_SIZE"],
-         "avg_launch_ns_rocprof": float(dom["AverageNs"]), "source": f"profiles/{tag}/pmc_summary.json [{group}]"}
+         "avg_launch_ns_rocprof": float(dom["AverageNs"]), "min_launch_ns_rocprof": float(dom["MinNs"]), "max_launch_ns_rocprof": float(dom["MaxNs"]),
+         "stddev_launch_ns_rocprof": float(dom.get("StdDev", 0.0) or 0.0), "launches_rocprof": int(dom["Calls"]), "source": f"profiles/{tag}/pmc_summary.json [{group}]"}
+    if "SQ_INSTS_VALU" in c:
+        # issue fraction: every VALU wave-instruction occupies its SIMD for 4 cycles (64 lanes on 16), 1024 SIMDs at 2.4 GHz over the launch
+        e["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
+        e["valu_issue_frac"] = c["SQ_INSTS_VALU"] * 4 / (1024 * float(dom["AverageNs"]) * 1e-9 * 2.4e9)
+        for k_, n_ in (("SQ_INSTS_LDS", "lds_insts_per_launch"), ("SQ_INSTS_SALU", "salu_insts_per_launch"), ("SQ_INSTS_VMEM_RD", "vmem_rd_insts_per_launch"), ("SQ_INSTS_VMEM_WR", "vmem_wr_insts_per_launch"),
+                       ("SQ_ACTIVE_INST_VALU", "active_inst_valu"), ("SQ_WAVE_CYCLES", "wave_cycles"), ("SQ_WAVES", "waves")):
+            if k_ in c:
+                e[n_] = c[k_]
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
         # busy cycles of the matrix pipe (summed over SIMDs) over 1024 SIMDs x the launch at 2.4 GHz; fp64 MFMA flops (512 per MOPS unit: MI355X_MICROARCH.md) against the dense fp64 peak
         secs = float(dom["AverageNs"]) * 1e-9
@@ -90,13 +106,20 @@ def entry(group, stats_key, match):
 out = {"formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction for wide coalesced reads, MI355X_MICROARCH.md HBM section; separate --pmc passes)",
        "workload": "bench.py B=4096 coupled fp64 cold (k_solve, k_nodes_linearize); 2^20 lookups on the 13x13x9^5 grid (k_hji_lookup); config 5 = lateral N = 50 + walls (k_solve_lat)",
        "kernel_source_sha16": kernel_source_sha16(), "kernels": {}}
-for group, sk, m in (("headline", "stats", "pg::k_solve<"), ("hji", "stats", "pg::k_hji_lookup"), ("headline", "stats", "pg::k_linearize"), ("headline", "stats", "pg::k_nodes"),
-                     ("dec", "stats_dec", "pg::k_solve_lat"), ("dec", "stats_dec", "pg::k_qp_dec")):
+for group, sk, m in (("headline", "stats", "pg::k_solve<false, false, false, false>"), ("headline", "stats", "pg::k_solve<false, false, false, true>"), ("hji", "stats", "pg::k_hji_lookup"),
+                     ("headline", "stats", "pg::k_linearize"), ("headline", "stats", "pg::k_nodes"),
+                     ("dec", "stats_dec", "pg::k_solve_lat<1, true, true>"), ("dec", "stats_dec", "pg::k_solve_lat<1, false, true>"), ("dec", "stats_dec", "pg::k_qp_dec"), ("dec", "stats_dec", "pg::k_nodes_dec")):
     t = entry(group, sk, m)
     if t:
         out["kernels"][t[0]] = t[1]
-        if m == "pg::k_solve<":
+        if m == "pg::k_solve<false, false, false, false>":
             out.update({"kernel": t[0], **{k: v for k, v in t[1].items() if k != "mfma"}})
+# the fp32 library's kernels (same names): config 3 (4096 + safety row: group "c3") first, config 4's share (8192: group "f32") for what c3 does not carry
+out["kernels_f32"] = {}
+for group, sk, m in (("c3", "stats_c3", "pg::k_solve<"), ("c3", "stats_c3", "pg::k_nodes"), ("c3", "stats_c3", "pg::k_hji_lookup"), ("f32", "stats_f32", "pg::k_solve<"), ("f32", "stats_f32", "pg::k_nodes")):
+    t = entry(group, sk, m)
+    if t and t[0] not in out["kernels_f32"]:
+        out["kernels_f32"][t[0]] = dict(t[1], workload="config 3 (B = 4096, fp32, safety row)" if group == "c3" else "fp32 at 8192 per GPU (config 4's share)")
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 for sk, rows in stats.items():
     print("==", sk)
