@@ -482,25 +482,25 @@ def main():
                  "setup_s": setup_s, "device_table_bytes": int(table_bytes)}
             mpc.clear_hji_cache()
             return r
-        hji = lookup_rate(*pkg.synthetic.hji_grid_large(), "13x13x9x9x9x9x9 float32 (V, gradV), 10 M nodes; device layout: one contiguous 4 KiB cell record per lookup (19 GB table: 4.7 M cells, capacity traded for line efficiency)")
+        hji = lookup_rate(*pkg.synthetic.hji_grid_large(), "13x13x9x9x9x9x9 float32 (V, gradV), 10 M nodes; device layout (default since round 4): sixteen 256 B cell records per lookup, each read 256 contiguous bytes per instruction and lane group (1.9 GB table = 6 x the node table)")
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]["pg::k_hji_lookup<7>"]
+            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]["pg::k_hji_lookup<3>"]
             hji["traffic"] = tr["hbm_bytes_per_launch"]; hji["traffic_source"] = tr["source"]
         except Exception:
             hji["traffic"] = None
-        # the two smaller device layouts pg_set_hji_grid falls back to when HBM is short (1 KiB records: 10 GB table; 256 B records: 2.6 GB), same grid -- far beyond
-        # the 256 MiB Infinity Cache in every layout (PG_HJI_CELL_DIMS is the library's test hook for forcing one)
+        # the two larger device layouts (PG_HJI_CELL_DIMS: 1 KiB records, 6 GB table; 4 KiB records, the default of rounds 1-3, 19 GB), same grid -- far beyond the 256 MiB
+        # Infinity Cache in every layout
         fb = {}
-        for cd, lbl in ((5, "1 KiB cell records (4 per lookup)"), (3, "256 B cell records (16 per lookup)")):
+        for cd, lbl in ((5, "1 KiB cell records (4 per lookup)"), (7, "4 KiB cell records (1 per lookup)")):
             os.environ["PG_HJI_CELL_DIMS"] = str(cd)
             try:
                 r = lookup_rate(*pkg.synthetic.hji_grid_large(), lbl)
                 fb[lbl] = {k: r[k] for k in ("lookups_per_s", "avg_launch_ms", "achieved", "frac", "setup_s", "device_table_bytes")}
             finally:
                 os.environ.pop("PG_HJI_CELL_DIMS", None)
-        hji["fallback_layouts"] = fb
+        hji["other_layouts"] = fb
         # SURVEY 8(d) secondary number: a FOUR-dimensional value grid (BASELINE.json says "4D": relative position, heading, other-car speed) run through the
-        # same 7-D kernel with the three remaining dimensions collapsed to two knots each -- every lookup still gathers one 4 KiB record
+        # same 7-D kernel with the three remaining dimensions collapsed to two knots each -- every lookup still gathers its 4096 B of corner data
         hji["grid_4d"] = lookup_rate(*pkg.synthetic.hji_grid_large(dims=(49, 49, 25, 2, 2, 25, 2)), "4-D grid 49x49x25x25 embedded as 49x49x25x2x2x25x2 (three collapsed dimensions), 12 M nodes")
 
     # BASELINE config 3: coupled MPC + HJI safety constraint on the precomputed 7-D grid, fp32 (libpigeon_hip_f32.so: same translation unit, real = float)
@@ -527,7 +527,7 @@ def main():
             return {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": ph32,
                     "solved": f"{int(pkg.is_solved(st_).sum())}/{B}", "ipm_iters_mean": float(np.mean(it_)), "ipm_iters_hist": hist(it_), "verified_by_polish": f"{int((p_ >= 1).sum())}/{B}",
                     "roofline": roofline_of(TR32, "k_solve<", ph32[2], B, 68 + (16 + 4096 if with_hji else 0), float(np.sum(solve_flops(m32.N, it_.astype(np.float64), rounds32.astype(np.float64)))), "f32",
-                                            note="solve phase of the fp32 library (k_solve, two waves per SIMD); bytes per solve: 68 (SURVEY 8d, fp32) + other car 16 B + one 4 KiB cell record with the safety row")}
+                                            note="solve phase of the fp32 library (k_solve, two waves per SIMD); bytes per solve: 68 (SURVEY 8d, fp32) + other car 16 B + 4096 B of corner records with the safety row")}
 
         plain = run32(False)
         f32 = {"workload": f"configs[2]: Batch={B} coupled MPC + HJI safety constraint (13x13x9x9x9x9x9 float32 grid), N=30, fp32, cold", "dtype": "f32",

@@ -436,9 +436,12 @@ int pg_set_hji_grid(pg_handle* h, const int32_t dims[7], const float* knots_conc
     // cell records (8 corners of dims 1..3 contiguous): built on the device from the compact node records, which are then released
     size_t free_b = 0, total_b = 0;
     HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
-    int cd = 7; long ncell = 0;
-    if (const char* e = getenv("PG_HJI_CELL_DIMS")) { int v = atoi(e); if (v == 3 || v == 5 || v == 7) cd = v; }     // test hook: force a smaller record
-    for (;; cd -= 2) {        // largest cell record (4 KiB / 1 KiB / 256 B) whose table fits a quarter of the free HBM
+    // Device layout: 256 B cell records (cdims = 3: sixteen per lookup; 6 x the node table -- 1.9 GB for the 13 x 13 x 9^5 grid).  Since the lookup reads every record 256
+    // contiguous bytes per instruction and lane group (round 4), the three layouts stream at the same rate -- 0.77 / 0.76 / 0.69-0.74 of the HBM peak for 256 B / 1 KiB /
+    // 4 KiB records -- so the smallest table is the default (rounds 1-3: 4 KiB records, 19.3 GB).  PG_HJI_CELL_DIMS = 5 / 7 selects the larger records (bench, tests).
+    int cd = 3; long ncell = 0;
+    if (const char* e = getenv("PG_HJI_CELL_DIMS")) { int v = atoi(e); if (v == 3 || v == 5 || v == 7) cd = v; }
+    for (;; cd -= 2) {        // (a larger record asked for must fit a quarter of the free HBM)
         long cs = 1; ncell = 1;
         for (int d = 0; d < 7; d++) { int ext = d < cd ? dims[d] - 1 : dims[d]; h->hv.cstride[d] = cs; cs *= ext; ncell *= ext; }
         if (cd == 3 || ((size_t)ncell << cd) * 32 <= free_b / 4) break;

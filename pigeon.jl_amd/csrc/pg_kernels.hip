@@ -966,17 +966,27 @@ __global__ __launch_bounds__(256) void k_hji_lookup(HjiView Hv, int B, const rea
     real acc[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) acc[c] = real(0.0);
-    if (inb && CD == 7) {
-        // cdims = 7: ONE 4 KiB record holds all 128 corners of the lookup, ordered by the corner bits.  Lane g reads the float4s
-        // 16 j + g (j = 0..15): every load instruction of the 16-lane group covers 256 contiguous bytes.  float4 f belongs to node f/2
-        // (half f & 1), so the lane always sees the same channel half (g & 1) of nodes 8 j + (g >> 1): bits b1..b3 = g >> 1, b4..b7 = j.
+    if (inb) {
+        // The 128 corners of a lookup are 256 float4s -- corner bits (b1..b7), two float4s (channels 0..3, 4..7) per corner -- held as ONE 4 KiB record (cdims = 7),
+        // FOUR 1 KiB records (cdims = 5: corner bits b6, b7 pick the record) or SIXTEEN 256 B records (cdims = 3: b4..b7 pick it), each ordered by its own corner bits.
+        // In every layout lane g reads float4 number 16 j + g of the lookup (j = 0..15): a load instruction of the 16-lane group covers 256 CONTIGUOUS bytes of one
+        // record, and the lane always sees the same channel half (g & 1) of corners b1..b3 = g >> 1, b4..b7 = j.
+        // (Round 4: the two smaller layouts used to give every lane a record (cdims = 3) or a 64 B chunk of each record (cdims = 5) of its own -- 64 / 32 different cache
+        // lines per load instruction.  They ran at 0.47 / 0.53 of the HBM peak; tools/probes/random_read_probe.hip shows that 256 B random records, read 256 B per
+        // instruction and group, stream at the same 0.69-0.73 as 4 KiB ones: the layouts were bound by their address pattern, not by the memory.)
+        constexpr int ROWS = 1 << (CD - 3);           // float4 rows of sixteen per record: 16, 4, 1
         long cell = 0;
 #pragma unroll
         for (int d = 0; d < 7; d++) cell += (long)idx[d] * Hv.cstride[d];
-        const float4* p = reinterpret_cast<const float4*>(Hv.cells + cell * 1024) + g;
         float4 r[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) r[j] = p[16 * j];
+        for (int j = 0; j < 16; j++) {
+            const int c = j / ROWS, jr = j % ROWS;        // record of the lookup (corner bits of dims CD+1..7), row inside it
+            long rec = cell;
+#pragma unroll
+            for (int d = CD; d < 7; d++) rec += (long)((c >> (d - CD)) & 1) * Hv.cstride[d];
+            r[j] = (reinterpret_cast<const float4*>(Hv.cells + rec * (8 << CD)) + 16 * jr + g)[0];
+        }
         const int lb = g >> 1;
         const real wlo = ((lb & 1) ? w[0] : (real(1.0) - w[0])) * ((lb & 2) ? w[1] : (real(1.0) - w[1])) * ((lb & 4) ? w[2] : (real(1.0) - w[2]));
         // tensor-product weights of dims 4..7 built as a tree (30 products instead of 80)
@@ -994,70 +1004,15 @@ __global__ __launch_bounds__(256) void k_hji_lookup(HjiView Hv, int B, const rea
             acc[0] += wj * (real)r[j].x; acc[1] += wj * (real)r[j].y; acc[2] += wj * (real)r[j].z; acc[3] += wj * (real)r[j].w;
         }
     }
-    if (CD == 7) {
-        // sum over the 8 lanes with the same channel half (same lane parity): xor 2 inside the quad, then rotations by 4 and 8 across quads
+    // sum over the 8 lanes with the same channel half (same lane parity): xor 2 inside the quad, then rotations by 4 and 8 across quads
 #pragma unroll
-        for (int c = 0; c < 4; c++) { real v = acc[c]; v = dpp_add(v, 1); v = dpp_add(v, 4); v = dpp_add(v, 5); acc[c] = v; }
-        if (live && g < 8) {      // lanes 0,2,4,6 hold channels 0..3, lanes 1,3,5,7 channels 4..7: lane g stores channel g
-            const int c = g >> 1;  // after the butterflies every even lane has the same sums, every odd lane too
-            real o = (c == 0) ? acc[0] : (c == 1 ? acc[1] : (c == 2 ? acc[2] : acc[3]));
-            // channel index = 4 * (g & 1) + (g >> 1)
-            int ch = 4 * (g & 1) + c;
-            if (!inb) o = (ch == 0) ? INFINITY : real(0.0);
-            out8[(size_t)look * 8 + ch] = o;
-        }
-        return;
-    }
-    if (inb && CD == 5) {
-        // cdims = 5: lane g owns the corner bits of dims 2..5 = the 64 B chunk g (dim-1 pair) of a 1 KiB record; 4 records for dims 6,7
-        long cell = 0; real wt = real(1.0);
-#pragma unroll
-        for (int d = 0; d < 5; d++) cell += (long)idx[d] * Hv.cstride[d];
-#pragma unroll
-        for (int d = 1; d < 5; d++) { int bit = (g >> (d - 1)) & 1; wt *= bit ? w[d] : (real(1.0) - w[d]); }
-        float4 r[4][4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            long rec = cell + (long)(idx[5] + (c & 1)) * Hv.cstride[5] + (long)(idx[6] + (c >> 1)) * Hv.cstride[6];
-            const float4* p = reinterpret_cast<const float4*>(Hv.cells + rec * 256) + 4 * g;
-            r[c][0] = p[0]; r[c][1] = p[1]; r[c][2] = p[2]; r[c][3] = p[3];
-        }
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            real wc = wt * ((c & 1) ? w[5] : (real(1.0) - w[5])) * ((c >> 1) ? w[6] : (real(1.0) - w[6]));
-            real wa = wc * (real(1.0) - w[0]), wb = wc * w[0];
-            acc[0] += wa * (real)r[c][0].x + wb * (real)r[c][2].x; acc[1] += wa * (real)r[c][0].y + wb * (real)r[c][2].y;
-            acc[2] += wa * (real)r[c][0].z + wb * (real)r[c][2].z; acc[3] += wa * (real)r[c][0].w + wb * (real)r[c][2].w;
-            acc[4] += wa * (real)r[c][1].x + wb * (real)r[c][3].x; acc[5] += wa * (real)r[c][1].y + wb * (real)r[c][3].y;
-            acc[6] += wa * (real)r[c][1].z + wb * (real)r[c][3].z; acc[7] += wa * (real)r[c][1].w + wb * (real)r[c][3].w;
-        }
-    }
-    if (inb && CD == 3) {
-        // cdims = 3: this lane's cell record: cell (idx1, idx2, idx3) at the corner of dims 4..7 selected by the lane bits
-        long cell = (long)idx[0] * Hv.cstride[0] + (long)idx[1] * Hv.cstride[1] + (long)idx[2] * Hv.cstride[2];
-        real wt = real(1.0);
-#pragma unroll
-        for (int d = 3; d < 7; d++) { int bit = (g >> (d - 3)) & 1; wt *= bit ? w[d] : (real(1.0) - w[d]); cell += (long)(idx[d] + bit) * Hv.cstride[d]; }
-        const float4* p = reinterpret_cast<const float4*>(Hv.cells + cell * 64);
-        float4 r[16];
-#pragma unroll
-        for (int c = 0; c < 16; c++) r[c] = p[c];  // 256 contiguous bytes: issue everything before the first use
-#pragma unroll
-        for (int c = 0; c < 8; c++) {              // corner c of the cell: bits (b1, b2, b3)
-            real wc = wt * ((c & 1) ? w[0] : (real(1.0) - w[0])) * ((c & 2) ? w[1] : (real(1.0) - w[1])) * ((c & 4) ? w[2] : (real(1.0) - w[2]));
-            acc[0] += wc * (real)r[2 * c].x; acc[1] += wc * (real)r[2 * c].y; acc[2] += wc * (real)r[2 * c].z; acc[3] += wc * (real)r[2 * c].w;
-            acc[4] += wc * (real)r[2 * c + 1].x; acc[5] += wc * (real)r[2 * c + 1].y; acc[6] += wc * (real)r[2 * c + 1].z; acc[7] += wc * (real)r[2 * c + 1].w;
-        }
-    }
-    // reduction over the 16 lanes of the row (out-of-bounds groups reduce zeros)
-#pragma unroll
-    for (int c = 0; c < 8; c++) { real v = acc[c]; v = dpp_add(v, 0); v = dpp_add(v, 1); v = dpp_add(v, 2); v = dpp_add(v, 3); acc[c] = v; }
-    if (live && g < 8) {
-        real o = acc[0];
-#pragma unroll
-        for (int c = 1; c < 8; c++) o = (g == c) ? acc[c] : o;
-        if (!inb) o = (g == 0) ? INFINITY : real(0.0);
-        out8[(size_t)look * 8 + g] = o;
+    for (int c = 0; c < 4; c++) { real v = acc[c]; v = dpp_add(v, 1); v = dpp_add(v, 4); v = dpp_add(v, 5); acc[c] = v; }
+    if (live && g < 8) {      // lanes 0,2,4,6 hold channels 0..3, lanes 1,3,5,7 channels 4..7: lane g stores channel 4 (g & 1) + (g >> 1)
+        const int c = g >> 1;  // after the butterflies every even lane has the same sums, every odd lane too
+        real o = (c == 0) ? acc[0] : (c == 1 ? acc[1] : (c == 2 ? acc[2] : acc[3]));
+        const int ch = 4 * (g & 1) + c;
+        if (!inb) o = (ch == 0) ? INFINITY : real(0.0);
+        out8[(size_t)look * 8 + ch] = o;
     }
 }
 

@@ -148,7 +148,7 @@ def test_f32_config5_full_size_every_instance_against_the_oracle(pkg, oracle_mod
 
 
 def test_config3_full_size_grid_and_batch(pkg, oracle_mod, skidpad):
-    """BASELINE configs[2] as stated: B = 4096, fp32, HJI safety row on the 13x13x9x9x9x9x9 grid (10 M nodes, 19 GB of cell records on the device),
+    """BASELINE configs[2] as stated: B = 4096, fp32, HJI safety row on the 13x13x9x9x9x9x9 grid (10 M nodes; 1.9 GB of 256 B cell records on the device),
     default HJI_eps = 0.05.  Every instance solves; the rows that are active (V <= eps) and a sample of the others are compared with the oracle."""
     n = 4096
     knots, V, g = pkg.synthetic.hji_grid_large()

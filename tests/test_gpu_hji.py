@@ -16,7 +16,7 @@ def grid(pkg):
 
 @pytest.mark.parametrize("cell_dims", [7, 5, 3])
 def test_lookup_matches_oracle(pkg, oracle_mod, skidpad, grid, cell_dims, monkeypatch):
-    """All three device layouts (4 KiB / 1 KiB / 256 B cell records; chosen by free memory in production) against the oracle."""
+    """All three device layouts (256 B cell records = the default, 1 KiB, 4 KiB: PG_HJI_CELL_DIMS) against the oracle."""
     monkeypatch.setenv("PG_HJI_CELL_DIMS", str(cell_dims))
     knots, V, g = grid
     mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, 8)

@@ -106,7 +106,7 @@ def entry(group, stats_key, match):
 out = {"formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction for wide coalesced reads, MI355X_MICROARCH.md HBM section; separate --pmc passes)",
        "workload": "bench.py B=4096 coupled fp64 cold (k_solve, k_nodes_linearize); 2^20 lookups on the 13x13x9^5 grid (k_hji_lookup); config 5 = lateral N = 50 + walls (k_solve_lat)",
        "kernel_source_sha16": kernel_source_sha16(), "kernels": {}}
-for group, sk, m in (("headline", "stats", "pg::k_solve<false, false, false, false>"), ("headline", "stats", "pg::k_solve<false, false, false, true>"), ("hji", "stats", "pg::k_hji_lookup"),
+for group, sk, m in (("headline", "stats", "pg::k_solve<false, false, false, false>"), ("headline", "stats", "pg::k_solve<false, false, false, true>"), ("hji", "stats", "pg::k_hji_lookup<3>"), ("hji", "stats", "pg::k_hji_lookup<5>"), ("hji", "stats", "pg::k_hji_lookup<7>"),
                      ("headline", "stats", "pg::k_linearize"), ("headline", "stats", "pg::k_nodes"),
                      ("dec", "stats_dec", "pg::k_solve_lat<1, true, true>"), ("dec", "stats_dec", "pg::k_solve_lat<1, false, true>"), ("dec", "stats_dec", "pg::k_qp_dec"), ("dec", "stats_dec", "pg::k_nodes_dec")):
     t = entry(group, sk, m)
