@@ -36,7 +36,8 @@ struct pg_handle {
     real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     real* d_lam = nullptr;                                      // [cap][N][16] multipliers of the last solve (warm start of the polish)
     int* d_wfail = nullptr;                                     // [cap] back-off of k_solve_lat's warm attempts
-    int* d_todo = nullptr; int split_solve = 1;                 // [cap + 1] instances the rounds-only k_solve leaves to the full kernel + their count; PG_SOLVE_SPLIT=0: one kernel as before
+    int* d_todo = nullptr; int split_solve = 1; volatile int* h_todo = nullptr;      // h_todo: pinned copy of the previous launch's count (queued behind it, read -- never waited for -- by the next)
+    int* d_todo_unused = nullptr;                 // [cap + 1] instances the rounds-only k_solve leaves to the full kernel + their count; PG_SOLVE_SPLIT=0: one kernel as before
     int* d_order = nullptr; int order_B = 0;  // [cap] + 2 counters: launch order filed by the nodes kernels of the current step (likely slow instances first); order_B = batch it is valid for
     real *d_pol_u2 = nullptr, *d_pol_u = nullptr; int* d_pol_src = nullptr;   // HJI fallback policy (HJI_computation.jl:133-158)
     int *d_status = nullptr, *d_iters = nullptr, *d_polish = nullptr; uint16_t* d_active = nullptr;
@@ -164,6 +165,7 @@ static void free_all(pg_handle* h) {
                     h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_wfail, h->d_todo, h->d_order, h->d_naux, h->d_progress, h->d_lat, h->d_lat_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->h_todo) (void)hipHostFree((void*)h->h_todo);
     if (h->sg.x) (void)hipGraphExecDestroy(h->sg.x);
     if (h->sg.g) (void)hipGraphDestroy(h->sg.g);
     if (h->sg.own) (void)hipStreamDestroy(h->sg.own);
@@ -250,6 +252,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     }
 #undef ALLOC
     h->stage_bytes = h->in_bytes > h->out_bytes ? h->in_bytes : h->out_bytes;          // inputs: state 6 + control 3 + other 4 (real) + t0 + time_offset (double); outputs reuse the front of it
+    { int* p_ = nullptr; if (hipHostMalloc((void**)&p_, sizeof(int), hipHostMallocDefault) != hipSuccess) { g_create_error = "hipHostMalloc failed for the to-do count"; free_all(h); delete h; return PG_ERR_HIP; } *p_ = 0; h->h_todo = p_; }
     if (hipHostMalloc((void**)&h->h_stage, h->stage_bytes, hipHostMallocDefault) != hipSuccess) { g_create_error = "hipHostMalloc failed for the staging buffer"; free_all(h); delete h; return PG_ERR_HIP; }
     // initial ts = 1..NN (model_predictive_control.jl:13), solved = false
     {
@@ -720,11 +723,14 @@ static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, u
         return PG_OK;
     }
     if (h->solve_ring) hipLaunchKernelGGL((k_solve<false, true, false>), dim3(n), dim3(64), h->solve_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
-    else if (h->split_solve && h->dc.polish && (h->dc.cold_guess > 0 || h->dc.warm_polish) && !h->has_hji) {
+    else if (h->split_solve && h->dc.polish && (h->dc.cold_guess > 0 || h->dc.warm_polish) && !h->has_hji && *h->h_todo == 0 && !h->sg.capturing) {
         // Two launches: the rounds-only instantiation (334 registers, no scratch: the interior point's state and code are not in it) serves the instances an active-set
         // attempt verifies -- all of them on the tracking batches --; what it leaves (SolveOut::todo) goes through the full kernel in list mode, its 4096 blocks
         // returning at once when the list is empty.  Not with a safety row installed: there the instances whose row is violated NEED the interior point (9-17 % of config
-        // 3), and in one kernel they start first (launch order) instead of after everyone else.
+        // 3), and in one kernel they start first (launch order) instead of after everyone else.  For the same reason the split is dropped as soon as a launch of this
+        // handle has left something on the list (its count travels to pinned memory behind the launch; the next launch reads whatever has arrived, without waiting): an
+        // instance that needs the interior point then runs it right behind its rounds, under the rest of the batch, instead of after it (`vail`, two such instances of 4096:
+        // 1.38 ms per cold step split, 1.07 ms in one kernel).  The single launch counts its interior-point instances the same way, so the split returns when they are gone.
         const size_t cap = (size_t)h->cfg.batch_capacity;
         HIPCHK(h, hipMemsetAsync(h->d_todo + cap, 0, sizeof(int), st));
         O.todo = h->d_todo; O.n_todo = h->d_todo + cap;
@@ -732,8 +738,15 @@ static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, u
         LAUNCH_CHECK(h);
         SolveOut O2 = O; O2.order_in = nullptr; O2.todo = nullptr; O2.n_todo = nullptr; O2.list = h->d_todo; O2.n_list = h->d_todo + cap;
         hipLaunchKernelGGL((k_solve<false, false, false, true>), dim3(n), dim3(64), h->solve_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O2, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
+        HIPCHK(h, hipMemcpyAsync((void*)h->h_todo, h->d_todo + cap, sizeof(int), hipMemcpyDeviceToHost, st));
     }
-    else hipLaunchKernelGGL((k_solve<false, false, false>), dim3(n), dim3(64), h->solve_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
+    else {
+        const bool count = h->split_solve && !h->has_hji && !h->sg.capturing;      // (the count decides whether the NEXT launch may split again)
+        const size_t cap = (size_t)h->cfg.batch_capacity;
+        if (count) { HIPCHK(h, hipMemsetAsync(h->d_todo + cap, 0, sizeof(int), st)); O.n_todo = h->d_todo + cap; }
+        hipLaunchKernelGGL((k_solve<false, false, false>), dim3(n), dim3(64), h->solve_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
+        if (count) HIPCHK(h, hipMemcpyAsync((void*)h->h_todo, h->d_todo + cap, sizeof(int), hipMemcpyDeviceToHost, st));
+    }
     LAUNCH_CHECK(h);
     return PG_OK;
 }

@@ -1779,6 +1779,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, in
         }
         pmode = 1; mu = real(0.0);
     } else if (attempt == 0) {
+        if (!O.n_list && O.n_todo && lane == 0) atomicAdd(O.n_todo, 1);      // (one-kernel launch: count the instances that need the interior point -- the host's choice between the split and the single launch)
         // ---- first attempt: v = 0 roll-out (dynamics- and rate-feasible), sigma just feasible; t = max(slack, tau); lambda = mu0 / t ----
         forward(std::false_type{});
         real xs[8];
