@@ -257,4 +257,45 @@ function step!(mpc::BatchedTrajectoryTrackingMPC, t0::AbstractVector{Float64})
 end
 const MPC! = step!
 
+# ---- multi-GPU (SURVEY 8e): the batch shards by instance, one handle per device, no data-path collective --------------------------------------------------------
+# One Julia process drives every GPU of the node through its own handle (pg_config.device); the step of every shard is queued asynchronously (pg_set_inputs +
+# pg_step_dev return once the work is on the device's stream) before any result is waited for, and the gather of the B x 3 controls is the concatenation of the shards'
+# host read-backs -- the ROS publishers want them in host memory anyway.  (bench.py's one-process-per-GPU harness gathers on the devices with RCCL instead.)
+"Instances [lo, hi] (1-based, inclusive) of shard `g` of `G`: contiguous blocks, the remainder spread over the first shards (pigeon.jl_amd/sharding.py: shard_range)"
+function shard_range(B::Integer, G::Integer, g::Integer)
+    base, rem = divrem(B, G)
+    lo = (g - 1) * base + min(g - 1, rem)
+    lo + 1, lo + base + (g <= rem ? 1 : 0)
+end
+
+struct ShardedTrajectoryTrackingMPC
+    shards::Vector{BatchedTrajectoryTrackingMPC}
+    ranges::Vector{UnitRange{Int}}
+    B::Int
+end
+
+"B controllers spread over `devices` (device ordinals); `make(B_g, device)` builds one shard, e.g. (b, d) -> BatchedTrajectoryTrackingMPC(X1(), traj, b; device = d)"
+function ShardedTrajectoryTrackingMPC(make::Function, B::Integer, devices::AbstractVector{<:Integer})
+    G = length(devices)
+    ranges = [UnitRange(shard_range(B, G, g)...) for g in 1:G]
+    ShardedTrajectoryTrackingMPC([make(length(ranges[g]), devices[g]) for g in 1:G], ranges, B)
+end
+
+"All five calls for every instance on every GPU: states / controls / t0 are the full-batch vectors; returns (u, status, iters) of the full batch"
+function step!(s::ShardedTrajectoryTrackingMPC, current_state::Vector{BicycleState{Float64}}, current_control::Vector{BicycleControl{Float64}}, t0::Vector{Float64})
+    for (mpc, r) in zip(s.shards, s.ranges)          # queue every shard's step first ...
+        mpc.current_state .= view(current_state, r); mpc.current_control .= view(current_control, r); mpc.t .= view(t0, r)
+        check(mpc, ccall(sym(mpc, :pg_set_inputs), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                                mpc.handle, mpc.B, mpc.current_state, mpc.current_control, mpc.t, mpc.other_car_state, mpc.time_offset), "pg_set_inputs")
+        check(mpc, ccall(sym(mpc, :pg_step_dev), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), mpc.handle, C_NULL), "pg_step_dev")
+    end
+    u = Vector{BicycleControl{Float64}}(undef, s.B); status = Vector{Int32}(undef, s.B); iters = Vector{Int32}(undef, s.B)
+    for (mpc, r) in zip(s.shards, s.ranges)          # ... then gather: each read-back waits for its own device only
+        ug = get_next_control(mpc); st = Vector{Int32}(undef, mpc.B); it = Vector{Int32}(undef, mpc.B)
+        check(mpc, ccall(sym(mpc, :pg_get_solve_info), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{UInt16}, Ptr{Float64}), mpc.handle, st, it, C_NULL, C_NULL), "pg_get_solve_info")
+        u[r] .= ug; status[r] .= st; iters[r] .= it
+    end
+    u, status, iters
+end
+
 end # module
