@@ -526,7 +526,7 @@ def main():
             rounds32 = np.where(p_ > 0, p_, np.where(p_ < 0, 6, 0))
             return {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": ph32,
                     "solved": f"{int(pkg.is_solved(st_).sum())}/{B}", "ipm_iters_mean": float(np.mean(it_)), "ipm_iters_hist": hist(it_), "verified_by_polish": f"{int((p_ >= 1).sum())}/{B}",
-                    "roofline": roofline_of(TR32, "k_solve<", ph32[2], B, 68 + (16 + 4096 if with_hji else 0), float(np.sum(solve_flops(m32.N, it_.astype(np.float64), rounds32.astype(np.float64)))), "f32",
+                    "roofline": roofline_of(TR32, "k_solve<false, false, false, true>" if with_hji else "k_solve<false, false, false, false>", ph32[2], B, 68 + (16 + 4096 if with_hji else 0), float(np.sum(solve_flops(m32.N, it_.astype(np.float64), rounds32.astype(np.float64)))), "f32",
                                             note="solve phase of the fp32 library (k_solve, two waves per SIMD); bytes per solve: 68 (SURVEY 8d, fp32) + other car 16 B + 4096 B of corner records with the safety row")}
 
         plain = run32(False)

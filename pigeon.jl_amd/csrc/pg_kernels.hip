@@ -1193,9 +1193,11 @@ PG_DEV real rl(real v, int src) {
 #ifndef PG_F32_WAVES
 #define PG_F32_WAVES 2          // (-DPG_F32_WAVES=1 builds the fp32 kernel for one wave per SIMD: the experiment that isolates the occupancy effect)
 #endif
-#define PG_SOLVE_WAVES(RING) PG_F32_WAVES
+// (round 4: two for the rounds-only instantiation only.  The full kernel -- interior point included -- needs 700 B of scratch per lane inside 256 registers; at one wave per
+//  SIMD it has none, and the launches that use it are the ones whose duration is an interior-point instance: config 3, 0.680 -> 0.639 ms)
+#define PG_SOLVE_WAVES(RING, IPM) ((IPM) ? 1 : PG_F32_WAVES)
 #else
-#define PG_SOLVE_WAVES(RING) 1          // (the ring variant used to ask for two waves per SIMD: its LDS footprint, 30 KB at N = 50, allows five waves per CU, i.e. one per
+#define PG_SOLVE_WAVES(RING, IPM) 1     // (the ring variant used to ask for two waves per SIMD: its LDS footprint, 30 KB at N = 50, allows five waves per CU, i.e. one per
                                         // SIMD anyway, and the 256-VGPR budget cost it 452 spilled registers: 8.3 -> 6.9 ms on the N = 50 lateral batch.  A deeper register
                                         // prefetch of the stage blocks, 2 / 4 / 6 loads in flight instead of one, was measured on top: 7.4 / 7.6 / 7.8 ms -- not load-bound)
 #endif
@@ -1221,7 +1223,7 @@ PG_DEV void wave_sync() {
 // 1/t), no Mehrotra code, no second start.  An instance its rounds do not serve is appended to SolveOut::todo and left untouched; the host launches the full kernel
 // over that list behind it (SolveOut::list / n_list: block i solves list[i], blocks beyond *n_list return at once, the attempts already made are skipped).
 template <bool PROF, bool RING, bool FUSE, bool IPM = true>
-__global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING)) void k_solve(DevCfg C, int B, real* qp, const real* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof,
+__global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg C, int B, real* qp, const real* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof,
                                                                           const tdouble* __restrict__ dt_grid, const real* __restrict__ hji_Mb) {
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int slot) { if (PROF) { unsigned long long now = clock64(); pc[slot] += now - tprev; tprev = now; } };

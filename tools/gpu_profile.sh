@@ -1,6 +1,6 @@
 # rocprofv3 runs for profiles/ (kernel stats, then PMC passes in their own runs: gpurun refuses --pmc together with the trace domains).  PART = 1 | 2 | 3 (a gpurun
 # call is capped at 20 minutes): 1 = the cold fp64 headline (stats + HBM + SQ + matrix-core counters), 2 = config 5 (lateral N = 50 + walls), config 3 (fp32 + HJI row) and
-# the closed-loop rollout (stats; HBM and matrix-core counters for config 5), 3 = the fp32 library's counters.   usage: PART=1 bash tools/gpu_profile.sh
+# the closed-loop rollouts (stats; HBM and SQ counters for configs 5 and 3), 3 = the fp32 library at 8192 per GPU (config 4's share).   usage: PART=1 bash tools/gpu_profile.sh
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 PART=${PART:-1}
@@ -18,6 +18,7 @@ if [ "$PART" = "1" ]; then
   pmc pmc_wr "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_WRITE_sum TCC_WRITE_SECTORS_sum" "$HEAD"               # what k_solve's 45 MB of write-back are made of
   pmc pmc_wb "TCC_NORMAL_WRITEBACK_sum TCC_ALL_TC_OP_WB_WRITEBACK_sum TCC_WRITEBACK_sum TCC_EA0_WR_UNCACHED_32B_sum" "$HEAD"
   pmc pmc_tcc "TCC_HIT_sum TCC_MISS_sum" "bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-decoupled --no-f32 --no-rollout --no-warm"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_hji -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-decoupled --no-f32 --no-rollout --no-warm > $OUT/bench_stats_hji.log 2>&1      # + the HJI lookups (three layouts)
   pmc pmc_fetch_hji "FETCH_SIZE" "bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-decoupled --no-f32 --no-rollout --no-warm"
   pmc pmc_write_hji "WRITE_SIZE" "bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-decoupled --no-f32 --no-rollout --no-warm"
 fi
@@ -30,7 +31,7 @@ if [ "$PART" = "2" ]; then
   pmc pmc_sq2_dec "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_INSTS_FLAT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS" "$DEC"
   ROLL="bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-decoupled --no-f32 --no-warm --no-hji"            # + closed loop: k_nodes_warm, k_advance, warm k_solve
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_roll -- python3 $ROLL > $OUT/bench_stats_roll.log 2>&1
-  C3="bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-decoupled --no-rollout --no-warm --precision f32"   # the fp32 library alone: its headline, the HJI lookups, config 3 (+ HJI row)
+  C3="tools/gpu_config3_probe.py f32"   # config 3 alone: the fp32 library, B = 4096, safety row on the 13 x 13 x 9^5 grid, five cold steps (every k_solve launch of the trace is a config-3 launch)
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -- python3 $C3 > $OUT/bench_stats_c3.log 2>&1
   pmc pmc_fetch_c3 "FETCH_SIZE" "$C3"
   pmc pmc_write_c3 "WRITE_SIZE" "$C3"

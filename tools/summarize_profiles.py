@@ -2,8 +2,8 @@
 
 usage: python tools/summarize_profiles.py r03_final
   kernel_stats*.csv : rocprofv3 --kernel-trace --stats summaries, copied as they are: kernel_stats.csv = the cold fp64 headline; _dec = + config 5 (lateral N = 50 with the
-                      wall rows: k_nodes_dec, k_qp_dec, k_solve_lat); _roll = + the closed-loop rollout (k_nodes_warm, k_advance, warm k_solve); _c3 = the fp32 library
-                      alone (its headline, the HJI lookups, config 3 with the safety row); _f32 = fp32 at 8192 per GPU (config 4's share)
+                      wall rows: k_nodes_dec, k_qp_dec, k_solve_lat); _roll = + the closed-loop rollout (k_nodes_warm, k_advance, warm k_solve); _c3 = config 3 alone (tools/gpu_config3_probe.py f32: fp32 library, safety row,
+                      five cold steps); _f32 = fp32 at 8192 per GPU (config 4's share)
   pmc_summary.json  : per-kernel per-launch means of every counter collected in the separate --pmc passes, one section per pass group ("headline", "dec", "f32")
   ../traffic.json   : HBM bytes per launch of the dominant kernels, (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md HBM section),
                       matrix-core utilisation where the counters were collected, and the hash of the kernel sources the counters were taken at
@@ -31,7 +31,7 @@ def short(name):
 
 stats = {}
 for d, out in (("stats", "kernel_stats.csv"), ("stats_dec", "kernel_stats_dec.csv"), ("stats_roll", "kernel_stats_roll.csv"), ("stats_c3", "kernel_stats_c3.csv"),
-               ("stats_f32", "kernel_stats_f32.csv"), ("stats_decloop", "kernel_stats_decloop.csv")):
+               ("stats_f32", "kernel_stats_f32.csv"), ("stats_decloop", "kernel_stats_decloop.csv"), ("stats_hji", "kernel_stats_hji.csv")):
     ks = glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv"))
     if len(ks) == 1:
         shutil.copy(ks[0], os.path.join(dst, out))
@@ -106,7 +106,7 @@ def entry(group, stats_key, match):
 out = {"formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction for wide coalesced reads, MI355X_MICROARCH.md HBM section; separate --pmc passes)",
        "workload": "bench.py B=4096 coupled fp64 cold (k_solve, k_nodes_linearize); 2^20 lookups on the 13x13x9^5 grid (k_hji_lookup); config 5 = lateral N = 50 + walls (k_solve_lat)",
        "kernel_source_sha16": kernel_source_sha16(), "kernels": {}}
-for group, sk, m in (("headline", "stats", "pg::k_solve<false, false, false, false>"), ("headline", "stats", "pg::k_solve<false, false, false, true>"), ("hji", "stats", "pg::k_hji_lookup<3>"), ("hji", "stats", "pg::k_hji_lookup<5>"), ("hji", "stats", "pg::k_hji_lookup<7>"),
+for group, sk, m in (("headline", "stats", "pg::k_solve<false, false, false, false>"), ("headline", "stats", "pg::k_solve<false, false, false, true>"), ("hji", "stats_hji", "pg::k_hji_lookup<3>"), ("hji", "stats_hji", "pg::k_hji_lookup<5>"), ("hji", "stats_hji", "pg::k_hji_lookup<7>"),
                      ("headline", "stats", "pg::k_linearize"), ("headline", "stats", "pg::k_nodes"),
                      ("dec", "stats_dec", "pg::k_solve_lat<1, true, true>"), ("dec", "stats_dec", "pg::k_solve_lat<1, false, true>"), ("dec", "stats_dec", "pg::k_qp_dec"), ("dec", "stats_dec", "pg::k_nodes_dec")):
     t = entry(group, sk, m)
@@ -116,7 +116,7 @@ for group, sk, m in (("headline", "stats", "pg::k_solve<false, false, false, fal
             out.update({"kernel": t[0], **{k: v for k, v in t[1].items() if k != "mfma"}})
 # the fp32 library's kernels (same names): config 3 (4096 + safety row: group "c3") first, config 4's share (8192: group "f32") for what c3 does not carry
 out["kernels_f32"] = {}
-for group, sk, m in (("c3", "stats_c3", "pg::k_solve<"), ("c3", "stats_c3", "pg::k_nodes"), ("c3", "stats_c3", "pg::k_hji_lookup"), ("f32", "stats_f32", "pg::k_solve<"), ("f32", "stats_f32", "pg::k_nodes")):
+for group, sk, m in (("c3", "stats_c3", "pg::k_solve<false, false, false, true>"), ("c3", "stats_c3", "pg::k_nodes"), ("c3", "stats_c3", "pg::k_hji_lookup"), ("f32", "stats_f32", "pg::k_solve<false, false, false, false>"), ("f32", "stats_f32", "pg::k_nodes")):
     t = entry(group, sk, m)
     if t and t[0] not in out["kernels_f32"]:
         out["kernels_f32"][t[0]] = dict(t[1], workload="config 3 (B = 4096, fp32, safety row)" if group == "c3" else "fp32 at 8192 per GPU (config 4's share)")
