@@ -127,7 +127,7 @@ def eliminated_slacks(D, E, x):
     return s1, s2, sw
 
 
-def solve(D, tol=1e-12, mu0=100.0, max_iter=40, sig0=1.0, tau=1e-4, floor=True, verbose=False, start="rollout", wls=1.0, mu0_cost=10.0):
+def solve(D, tol=1e-12, mu0=100.0, max_iter=40, sig0=1.0, tau=1e-4, floor=True, verbose=False, start="rollout", wls=1.0, mu0_cost=10.0, split_steps=False):
     """Returns dict(x, v, s1, s2, sw, t, lam, iters, status, mu).  status 1 solved, 2 iteration cap, 4 numerical.
     mu0_cost: the first barrier parameter is max(mu0, mu0_cost x cost of the starting point per row) as in k_solve_lat (0: mu0 as given).
     start: "rollout" = v = 0 roll-out (what the kernel does); "ls" = one Newton solve with every row replaced by a quadratic penalty of weight wls (closed-loop roll-out,
@@ -192,16 +192,20 @@ def solve(D, tol=1e-12, mu0=100.0, max_iter=40, sig0=1.0, tau=1e-4, floor=True, 
         dt_ = tp - t; dl_ = (sg * mu - corr) * it_ - W * tp
         rmax = float(np.max(np.maximum(-dt_ * it_, -dl_ / lam)))
         alpha = 0.995 / rmax if rmax > 0.995 else 1.0
+        alpha_d = alpha
+        if split_steps:          # (experiment of round 4: the slacks and the multipliers each go to 0.995 of their OWN boundary)
+            rp = float(np.max(-dt_ * it_)); rd = float(np.max(-dl_ / lam))
+            alpha = 0.995 / rp if rp > 0.995 else 1.0; alpha_d = 0.995 / rd if rd > 0.995 else 1.0
         if floor and mu <= 1e5 * tol and phi * max(rp0, 1.0) <= tol:
-            mnew = float(np.sum((t + alpha * dt_) * (lam + alpha * dl_))) / ntot
+            mnew = float(np.sum((t + alpha * dt_) * (lam + alpha_d * dl_))) / ntot
             if not (mnew <= 4.0 * mu):
                 status = 1; break
-        t = t + alpha * dt_; lam = lam + alpha * dl_
+        t = t + alpha * dt_; lam = lam + alpha_d * dl_
         x = x + alpha * (xn - x); v = v + alpha * (vn - v); s1 = s1 + alpha * (n1 - s1); s2 = s2 + alpha * (n2 - s2); sw = sw + alpha * (nw - sw)
         phi *= (1.0 - alpha)
         good = good + 1 if alpha > 0.5 else 0
         if verbose:
-            print(f"it {it:3d} mu {mu:.3e} aaff {aaff:.3f} sg {sg:.2e} alpha {alpha:.3f} phi {phi:.1e}")
+            print(f"it {it:3d} mu {mu:.3e} aaff {aaff:.3f} sg {sg:.2e} alpha {alpha:.3f} alpha_d {alpha_d:.3f} phi {phi:.1e}")
         if mu > 1e8 * mu0:
             break
         it += 1

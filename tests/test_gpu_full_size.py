@@ -294,3 +294,31 @@ def test_pipelined_launch_with_a_trajectory_library(pkg):
     assert np.mean(out[True][3] == pkg.SOLVED) > 0.99
     for a, b in zip(out[False], out[True]):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_split_solve_launch_gives_the_same_answers(pkg, skidpad, monkeypatch):
+    """k_solve as two launches (the rounds-only instantiation, then the full kernel in list mode over what it left: the default without a safety row) against the single
+    kernel (PG_SOLVE_SPLIT=0), on the benchmark batch and on `vail` (two of whose 4096 cold instances need the interior point: the list-mode launch does real work there,
+    and the next launch of that handle drops the split by itself): same status, same interior-point iteration counts, controls of two verified KKT points of the same QP."""
+    B = 4096
+    un = np.array([0.314159, 16793.7, 16793.7])
+    for path in ("skidpadoval", "vail"):
+        traj = pkg.load_path_fixture(path)
+        kw = dict(s_range=(2.0, 0.4 * float(traj.s[-1]))) if float(traj.s[-1]) <= 100 else {}
+        state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345, **kw)
+        out = {}
+        for split in ("1", "0"):
+            monkeypatch.setenv("PG_SOLVE_SPLIT", split)
+            mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B)
+            u1, st1, it1 = mpc.step_(state, control, t0, time_offset=toff)
+            mpc.reset()
+            u2, st2, it2 = mpc.step_(state, control, t0, time_offset=toff)          # (after a launch that left work: the split handle has switched to the single kernel)
+            out[split] = (u1, st1, it1, u2, st2, it2, mpc.polish_info().copy())
+            mpc.close()
+        a, b = out["1"], out["0"]
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5]), path
+        assert np.all(pkg.is_solved(a[1]))
+        both = (a[6] >= 1) & (b[6] >= 1)
+        assert np.max(np.abs(a[0][both] - b[0][both]) / un) < 1e-8 and np.max(np.abs(a[3][both] - b[3][both]) / un) < 1e-8, path
+        if path == "vail":
+            assert (a[2] > 0).sum() >= 1          # the list-mode launch had something to do
