@@ -36,7 +36,7 @@ struct pg_handle {
     real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     real* d_lam = nullptr;                                      // [cap][N][16] multipliers of the last solve (warm start of the polish)
     int* d_wfail = nullptr;                                     // [cap] back-off of k_solve_lat's warm attempts
-    int* d_todo = nullptr; int split_solve = 1; volatile int* h_todo = nullptr;      // h_todo: pinned copy of the previous launch's count (queued behind it, read -- never waited for -- by the next)
+    int* d_todo = nullptr; int split_solve = 1, split_lat = 1; volatile int* h_todo = nullptr;      // h_todo: pinned copy of the previous launch's count (queued behind it, read -- never waited for -- by the next)
     int* d_todo_unused = nullptr;                 // [cap + 1] instances the rounds-only k_solve leaves to the full kernel + their count; PG_SOLVE_SPLIT=0: one kernel as before
     int* d_order = nullptr; int order_B = 0;  // [cap] + 2 counters: launch order filed by the nodes kernels of the current step (likely slow instances first); order_B = batch it is valid for
     real *d_pol_u2 = nullptr, *d_pol_u = nullptr; int* d_pol_src = nullptr;   // HJI fallback policy (HJI_computation.jl:133-158)
@@ -241,7 +241,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         { const char* k = getenv("PG_LAT_RHO_SCALE"); const double v = k ? atof(k) : (sizeof(real) == 8 ? 1e3 : 1.0); C.lat_rho_scale = (real)((v > 0.0 && v < 1e12) ? v : 1.0); }
         { const char* k = getenv("PG_LAT_POLISH_ROUNDS"); C.lat_polish_rounds = k ? atoi(k) : 3; if (C.lat_polish_rounds < 2) C.lat_polish_rounds = 2; }
         { const char* k = getenv("PG_LAT_SETTLE"); C.lat_settle = k ? atoi(k) : 0; }
-        { const char* k = getenv("PG_LAT_WARM_ROUNDS"); C.lat_warm_rounds = k ? atoi(k) : 4; if (C.lat_warm_rounds < 0) C.lat_warm_rounds = 0; }
+        { const char* k = getenv("PG_LAT_WARM_ROUNDS"); C.lat_warm_rounds = k ? atoi(k) : 2;      /* (2 since the two-launch warm step: an attempt that needs a third working set is cheaper to hand to the cold list: 2.03 -> 1.95 ms, 2.9 -> 2.7 with walls) */ if (C.lat_warm_rounds < 0) C.lat_warm_rounds = 0; }
         { const char* k = getenv("PG_LAT_WIPM"); C.lat_wipm = k ? atoi(k) : 0; }
         C.lat_wmu = (real)env_pos("PG_LAT_WMU", 1e-2); C.lat_wtau = (real)env_pos("PG_LAT_WTAU", 1e-4);
         const char* e = getenv("PG_LAT_MEM");
@@ -273,6 +273,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     h->ev_ok = true;
     { const char* e = getenv("PG_HJI_SEED"); C.hji_seed = e ? atoi(e) : 0; }
     { const char* e = getenv("PG_HJI_ROUNDS"); C.hji_rounds = e ? atoi(e) : 0; }
+    { const char* e = getenv("PG_LAT_SPLIT"); if (e && (e[0] == '0' || e[0] == '1')) h->split_lat = e[0] - '0'; }
     { const char* e = getenv("PG_SOLVE_SPLIT"); if (e && (e[0] == '0' || e[0] == '1')) h->split_solve = e[0] - '0'; }
     { const char* e = getenv("PG_FUSE"); if (e && e[0] >= '0' && e[0] <= '2') h->fuse = e[0] - '0'; }
     { const char* e = getenv("PG_PIPELINE"); if (e && e[0] >= '0' && e[0] <= '1') h->pipeline = e[0] - '0'; }
@@ -716,8 +717,22 @@ static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, u
         const dim3 grid((unsigned)((h->B + 3) / 4));
         const int slots = (h->dc.N + 15) / 16;
 #define PG_LAT_LAUNCH(NS, W, M) hipLaunchKernelGGL((k_solve_lat<NS, W, M>), grid, dim3(64), h->lat_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, lat_prof)
-        if (h->dc.walls) { if (h->lat_mem) PG_LAT_LAUNCH(1, true, true); else if (slots == 1) PG_LAT_LAUNCH(1, true, false); else PG_LAT_LAUNCH(2, true, false); }
-        else { if (h->lat_mem) PG_LAT_LAUNCH(1, false, true); else if (slots == 1) PG_LAT_LAUNCH(1, false, false); else PG_LAT_LAUNCH(2, false, false); }
+#define PG_LAT_LAUNCH_ANY() do { \
+        if (h->dc.walls) { if (h->lat_mem) PG_LAT_LAUNCH(1, true, true); else if (slots == 1) PG_LAT_LAUNCH(1, true, false); else PG_LAT_LAUNCH(2, true, false); } \
+        else { if (h->lat_mem) PG_LAT_LAUNCH(1, false, true); else if (slots == 1) PG_LAT_LAUNCH(1, false, false); else PG_LAT_LAUNCH(2, false, false); } } while (0)
+        // A batch in which every instance carries a previous solution (a closed loop after its first step) is solved in TWO launches: the warm attempts, then -- over the
+        // list the first launch leaves -- the cold solves of what they did not serve, packed four per wavefront again (see k_solve_lat).  PG_LAT_SPLIT=0: one launch.
+        const bool two = h->split_lat && h->dc.polish && h->dc.warm_polish && h->dc.lat_warm_rounds > 0 && h->warm_B >= h->B && !lat_prof && !h->sg.capturing;
+        if (two) {
+            const size_t cap = (size_t)h->cfg.batch_capacity;
+            HIPCHK(h, hipMemsetAsync(h->d_todo + cap, 0, sizeof(int), st));
+            O.todo = h->d_todo; O.n_todo = h->d_todo + cap;
+            PG_LAT_LAUNCH_ANY();
+            LAUNCH_CHECK(h);
+            O.todo = nullptr; O.n_todo = nullptr; O.list = h->d_todo; O.n_list = h->d_todo + cap;
+        }
+        PG_LAT_LAUNCH_ANY();
+#undef PG_LAT_LAUNCH_ANY
 #undef PG_LAT_LAUNCH
         LAUNCH_CHECK(h);
         return PG_OK;

@@ -94,7 +94,14 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     auto stamp = [&](int slot) __attribute__((always_inline)) { if (prof) { const unsigned long long now = clock64(); pc[slot] += now - tprev; tprev = now; } };
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
     const int N = C.N, NN = C.NN;
-    const int b_raw = 4 * (int)blockIdx.x + g;
+    // Two launches per WARM step (round 4, SolveOut::todo / list): the first runs the warm attempts only and appends what they do not serve (and the instances that are
+    // cold or backing off) to a list; the second solves that list cold, four instances per wavefront again -- 150 wavefronts instead of the 600 that would otherwise
+    // stay alive for one unserved instance each, i.e. one per CU instead of two or three: a pass through the loop costs 61-80 us there against 110 us with four per CU.
+    const bool listm = O.n_list != nullptr, defer = O.todo != nullptr;
+    const int n_list = listm ? *O.n_list : B;
+    if (listm && 4 * (int)blockIdx.x >= n_list) return;          // (uniform over the block; nothing has been touched yet)
+    const int idx_raw = 4 * (int)blockIdx.x + g;
+    const int b_raw = listm ? (idx_raw < n_list ? O.list[idx_raw] : B) : idx_raw;
     const bool valid = b_raw < B;
     const int b = valid ? b_raw : B - 1;                 // (a ragged last wavefront solves the last instance again and stores nothing)
     extern __shared__ real lds[];
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     const bool warm = C.polish && C.warm_polish && O.solved[b] != 0 && (O.status[b] == PG_SOLVED || O.status[b] == PG_SOLVED_UNVERIFIED);
     // ... whose interior point, should it be needed, starts from the PREVIOUS solution instead of the v = 0 roll-out: slacks of the previous primal point against the new
     // rows, floored at lat_wtau; multipliers the previous ones, floored at lat_wmu / t (every product t lambda >= lat_wmu: a centred neighbourhood of the old optimum)
-    const bool wipm = warm && C.lat_wipm != 0;
+    const bool wipm = warm && C.lat_wipm != 0 && O.n_list == nullptr;
     real ms_next = real(0.0);       // sum t lambda over this lane's rows at the iterate just stored (the complementarity gap of the next loop top)
     // the damped iterate (x_{s+1}, sigma) of a stage is kept in the output buffers (read-modify-write once per iteration), not in registers
     for_slots([&](int j) __attribute__((always_inline)) {
@@ -665,8 +672,8 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // 10 ms), and a failed attempt costs its rounds ON TOP of the cold solve -- in a kernel that ends with its slowest instance.  An instance whose attempt failed skips the
     // next 1, 3, 7, 15, 31 attempts (level in bits 8.., remaining skips in bits 0..7 of wfail[b]); a verified attempt clears the word.
     const int wf = O.wfail ? O.wfail[b] : 0;
-    bool warm_try = warm && C.lat_warm_rounds > 0 && (wf & 0xFF) == 0;
-    bool warm_failed = false;
+    bool warm_try = warm && C.lat_warm_rounds > 0 && (wf & 0xFF) == 0 && !listm;
+    bool warm_failed = false, deferred = false;
     const bool warm_tried = warm_try;
     const real tol_cold = tol_cur;
     if (warm_try) {
@@ -684,6 +691,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         });
         pmode = 1; pchecks = 0; status = PG_SOLVED;
     }
+    if (defer && !warm_try) { deferred = true; done = true; }      // (first of two launches: this instance has no warm attempt to make -- cold, or backing off: the second launch solves it)
 
     // the verdict of a polish solve for this instance, from the per-slot results of polish_rows (the proposed sets are in the slots' meta words, the eliminated slacks
     // of the solve in their sn words): verified (the point is primal and dual feasible: a KKT point of the full QP, stored as the answer), refine (same set, held rows
@@ -735,8 +743,9 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             // nothing verified: the interior-point iterate stands.  (Both flags are assigned on both paths: "if (again) resume = true; else done = true" is folded by the
             // optimiser into ONE store through a selected pointer into the lambda's capture block, which then -- with every captured variable -- lives in scratch memory:
             // the kernel ran twice as long.)
-            const bool again = warm_try || tol_cur > tol;      // (a warm attempt that did not verify: on to the cold start)
-            resume_ipm = again; done = done || !again;
+            const bool wdefer = warm_try && defer;             // (first of two launches: a warm attempt that did not verify leaves the instance to the second one)
+            const bool again = !wdefer && (warm_try || tol_cur > tol);      // (one launch: a warm attempt that did not verify goes on to the cold start)
+            resume_ipm = again; done = done || !again; deferred = deferred || wdefer; warm_failed = warm_failed || wdefer;
         }
         return changed;
     };
@@ -938,7 +947,14 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     if (prof && valid && c == 0) { unsigned long long* tl = prof + (size_t)B * 6 + 1024 + (size_t)b * 3; tl[0] = dbg_tr0; tl[1] = dbg_tr1; tl[2] = (unsigned long long)dbg_n; }      // (the [B][3] region k_solve uses for its timeline)
 
     // ---------------- outputs ----------------
-    if (valid) {
+    if (valid && c == 0) {
+        if (deferred) O.todo[atomicAdd(O.n_todo, 1)] = b;
+        if (O.wfail && !listm) {        // (the back-off word belongs to the launch that makes -- or skips -- the warm attempt)
+            const int lvl = (wf >> 8) & 0xFF, nl = lvl < 5 ? lvl + 1 : 5;
+            O.wfail[b] = !warm ? 0 : (warm_tried ? (warm_failed ? ((nl << 8) | ((1 << nl) - 1)) : 0) : ((lvl << 8) | (((wf & 0xFF) > 0 ? (wf & 0xFF) - 1 : 0))));
+        }
+    }
+    if (valid && !deferred) {
         real* SX = O.sol_x + (size_t)b * NN * 8;
         if (c < 8) SX[c] = c == 1 ? C.ux_dummy : (c >= 2 && c < 6 ? Q[o.qcurr + c] : (c == 6 ? Q[o.ucurr] : real(0.0)));
         for_slots([&](int j) __attribute__((always_inline)) {
@@ -964,10 +980,6 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             U[0] = d; U[1] = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac; U[2] = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
             O.status[b] = (status == PG_SOLVED && C.polish && pstat < 0) ? PG_SOLVED_UNVERIFIED : status; O.iters[b] = it; O.mu[b] = mu; O.polish[b] = pstat;
             O.solved[b] = 1;      // model_predictive_control.jl:76: solved = true
-            if (O.wfail) {
-                const int lvl = (wf >> 8) & 0xFF, nl = lvl < 5 ? lvl + 1 : 5;
-                O.wfail[b] = !warm ? 0 : (warm_tried ? (warm_failed ? ((nl << 8) | ((1 << nl) - 1)) : 0) : ((lvl << 8) | (((wf & 0xFF) > 0 ? (wf & 0xFF) - 1 : 0))));
-            }
         }
     }
 }
