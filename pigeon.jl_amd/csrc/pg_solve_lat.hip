@@ -700,13 +700,14 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     unsigned long long dbg_tr0 = 0ull, dbg_tr1 = 0ull; int dbg_n = 0;      // diagnostic launch (prof != nullptr): one record per polish verdict of this instance
     auto polish_decide = [&](bool unsettled_, bool second_half) __attribute__((always_inline)) -> bool {
         real chg = real(0.0), nch = real(0.0);
-        for_slots([&](int j) __attribute__((always_inline)) { const Meta m = get_meta(j); chg = fmax(chg, (is_act(j) && m.nm != m.am) ? real(1.0) : real(0.0)); if (prof) nch += is_act(j) ? (real)__popc(m.nm ^ m.am) : real(0.0); });
+        for_slots([&](int j) __attribute__((always_inline)) { const Meta m = get_meta(j); chg = fmax(chg, (is_act(j) && m.nm != m.am) ? real(1.0) : real(0.0)); nch += is_act(j) ? (real)__popc(m.nm ^ m.am) : real(0.0); });
+        const real nchg = row_sum(nch);          // rows that enter or leave the working set in this verdict
         const bool conv = !(row_max(unsettled_ ? real(1.0) : real(0.0)) > real(0.0));
         // decisions wait for settled multipliers (lat_settle: 1 = warm attempts, 2 = every polish): on an open-loop unstable horizon a held row that is still 1e-5 off its
         // bound moves the far end of the trajectory by metres, and the rows that then LOOK violated send the working set off (traces: 1 -> 15 -> 90 rows changing per round)
         const bool changed = row_max(chg) > real(0.0) && (conv || !(C.lat_settle == 2 || (C.lat_settle == 1 && warm_try)));
         if (prof) {      // nibble: changed | settled << 1 | warm attempt << 2 | second half << 3; byte: rows that change
-            const int nc = (int)fmin(row_sum(nch), real(255.0));
+            const int nc = (int)fmin(nchg, real(255.0));
             if (dbg_n < 16) dbg_tr0 |= (unsigned long long)((changed ? 1 : 0) | (conv ? 2 : 0) | (warm_try ? 4 : 0) | (second_half ? 8 : 0)) << (4 * dbg_n);
             if (dbg_n < 8) dbg_tr1 |= (unsigned long long)nc << (8 * dbg_n);
             dbg_n++;
@@ -736,7 +737,9 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             });
             pmode++;
         }
-        const int round_cap = warm_try ? C.lat_warm_rounds : (tol_cur > tol ? LAT_POLISH_ROUNDS : LAT_POLISH_ROUNDS - 1);
+        // (a warm attempt: lat_warm_rounds working sets, two more while the set moves by a row or two per round -- a settled loop whose set shifts by one stage gets there,
+        //  and ONE instance that does not costs the launch a cold solve; an attempt that turns over a dozen rows is on its way out and is left to the cold list at once)
+        const int round_cap = warm_try ? C.lat_warm_rounds + (nchg <= real(2.0) ? 2 : 0) : (tol_cur > tol ? LAT_POLISH_ROUNDS : LAT_POLISH_ROUNDS - 1);
         if (pmode > round_cap || pchecks > 2 * round_cap + 1) {
             pstat = -1;
             // resume the interior point (takes effect at the top of the next iteration: the rest of this one still belongs to the polish), or -- second failure --
