@@ -678,7 +678,8 @@ static int launch_linearize(pg_handle* h, int n) {
 #ifdef PG_F32
     const int G = 2;         // (fp32: the compiler contracts the tangent arithmetic differently in the K = 1, 2 instantiations -- results would depend on the batch size)
 #else
-    const int G = n <= 256 ? 8 : (n <= 512 ? 4 : 2);        // bit-identical across K in fp64 (tests/test_gpu_multiprocess.py steps 1024 = 2 x 512, 1001 = 501 + 500, 400 = 2 x 200)
+    static const int g_env = getenv("PG_LIN_G") ? atoi(getenv("PG_LIN_G")) : 0;       // (diagnostic: force the lane arrangement)
+    const int G = (g_env == 2 || g_env == 4 || g_env == 8) ? g_env : n <= 256 ? 8 : (n <= 512 ? 4 : 2);        // bit-identical across K in fp64 (tests/test_gpu_multiprocess.py steps 1024 = 2 x 512, 1001 = 501 + 500, 400 = 2 x 200)
 #endif
     if (G == 2 && h->dc.Ns > 0 && h->dc.Ns < h->dc.N) {     // large batches: short-horizon intervals with three directions per lane (k_linearize_split)
         const long nz = (long)n * h->dc.Ns * 2, nr = (long)n * (h->dc.N - h->dc.Ns) * 2;

@@ -574,8 +574,11 @@ __global__ __launch_bounds__(64) void k_linearize_split(DevCfg C, int B, int nb_
         else linearize_lanes<4, 8>(C, b, t, g, live, nodes, dt, hji_Mb, qp);
     }
 }
+#ifndef PG_LIN_WAVES
+#define PG_LIN_WAVES 1
+#endif
 template <int K>
-__global__ __launch_bounds__(64) void k_linearize(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb, real* __restrict__ qp) {
+__global__ __launch_bounds__(64, PG_LIN_WAVES) void k_linearize(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb, real* __restrict__ qp) {
     constexpr int G = 8 / K;
     long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long per = (long)C.N * G;
