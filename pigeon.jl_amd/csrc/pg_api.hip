@@ -36,6 +36,8 @@ struct pg_handle {
     real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     real* d_lam = nullptr;                                      // [cap][N][16] multipliers of the last solve (warm start of the polish)
     int* d_wfail = nullptr;                                     // [cap] back-off of k_solve_lat's warm attempts
+    int lin_lpi = 1;                                          // lanes per (instance, interval) of the large-batch linearisation (k_linearize_split / k_nodes_linearize): one lane with all eight
+                                                              // directions (PG_LIN_LPI=2: the lane pair of rounds 1-3, for A/B runs; same bits in fp64, rounding-level differences in fp32)
     int* d_todo = nullptr; int split_solve = 1, split_lat = 1; volatile int* h_todo = nullptr;      // h_todo: pinned copy of the previous launch's count (queued behind it, read -- never waited for -- by the next)
     int* d_todo_unused = nullptr;                 // [cap + 1] instances the rounds-only k_solve leaves to the full kernel + their count; PG_SOLVE_SPLIT=0: one kernel as before
     int* d_order = nullptr; int order_B = 0;  // [cap] + 2 counters: launch order filed by the nodes kernels of the current step (likely slow instances first); order_B = batch it is valid for
@@ -273,6 +275,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     h->ev_ok = true;
     { const char* e = getenv("PG_HJI_SEED"); C.hji_seed = e ? atoi(e) : 0; }
     { const char* e = getenv("PG_HJI_ROUNDS"); C.hji_rounds = e ? atoi(e) : 0; }
+    { const char* e = getenv("PG_LIN_LPI"); if (e && (e[0] == '1' || e[0] == '2') && !e[1]) h->lin_lpi = e[0] - '0'; }
     { const char* e = getenv("PG_LAT_SPLIT"); if (e && (e[0] == '0' || e[0] == '1')) h->split_lat = e[0] - '0'; }
     { const char* e = getenv("PG_SOLVE_SPLIT"); if (e && (e[0] == '0' || e[0] == '1')) h->split_solve = e[0] - '0'; }
     { const char* e = getenv("PG_FUSE"); if (e && e[0] >= '0' && e[0] <= '2') h->fuse = e[0] - '0'; }
@@ -595,9 +598,10 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
                                h->d_nodes, F);
         } else if (pipelined) {
             { int rc = launch_hji_rows_compute(h); if (rc) return rc; }      // (M, b) of the safety row: read by the lanes that linearise interval 0
-            const int nbn = (B + 63) / 64, nbt = (B + 31) / 32;
+            const int lpi = h->lin_lpi, ipb = 64 / lpi;
+            const int nbn = (B + 63) / 64, nbt = (B + ipb - 1) / ipb;
             const size_t lds = traj_lds > 64 * 20 * sizeof(real) ? traj_lds : 64 * 20 * sizeof(real);
-            auto kern = staged ? k_nodes_linearize<true> : k_nodes_linearize<false>;
+            auto kern = lpi == 1 ? (staged ? k_nodes_linearize<true, 1> : k_nodes_linearize<false, 1>) : (staged ? k_nodes_linearize<true, 2> : k_nodes_linearize<false, 2>);
             int nzf = (1024 - nbn + nbt - 1) / nbt;               // short-horizon intervals that go first: one wavefront for every SIMD the recurrence leaves free
             if (nzf > h->dc.Ns) nzf = h->dc.Ns;
             if (nzf < 1) nzf = 1;
@@ -618,9 +622,10 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
                 const long nn = (long)B * h->dc.NN;
                 (void)nn;
                 hipLaunchKernelGGL(k_nodes_angles, dim3(64), dim3(256), 0, h->stream, h->dc, B, h->d_naux, h->d_nodes, flt);               // (small grids, striding over the work:
-                const long nz = (long)B * h->dc.Ns * 2, nr = (long)B * (h->dc.N - h->dc.Ns) * 2;                                               //  an empty launch is cheap)
+                const long nz = (long)B * h->dc.Ns * lpi, nr = (long)B * (h->dc.N - h->dc.Ns) * lpi;                                           //  an empty launch is cheap)
                 const int nbz = (int)((nz + 63) / 64), nbr = (int)((nr + 63) / 64);
-                hipLaunchKernelGGL(k_linearize_split, dim3(512), dim3(64), 0, h->stream, h->dc, B, nbz, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp, flt, nbz + nbr);
+                auto ksplit = lpi == 1 ? k_linearize_split<1> : k_linearize_split<2>;
+                hipLaunchKernelGGL(ksplit, dim3(512), dim3(64), 0, h->stream, h->dc, B, nbz, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp, flt, nbz + nbr);
             }
             h->lin_done = true;
         } else {
@@ -672,25 +677,33 @@ static int launch_hji_rows(pg_handle* h) {
     int rc = launch_hji_rows_compute(h); if (rc) return rc;
     return launch_hji_order(h);
 }
+#define PG_LIN_PAIR_MAX 1024
 static int launch_linearize(pg_handle* h, int n) {
     // two lanes per (instance, interval) with four tangent directions each; small batches -- a handful of wavefronts whose duration is the latency of one lane --
     // spread the eight directions over four or eight lanes instead (same arithmetic per direction)
-#ifdef PG_F32
-    const int G = 2;         // (fp32: the compiler contracts the tangent arithmetic differently in the K = 1, 2 instantiations -- results would depend on the batch size)
-#else
+    // Large batches (several rounds of wavefronts): ONE lane per interval with all eight directions (k_linearize_split<1>) -- the fewest instructions per interval.
+    // While every lane pair is resident at once (n <= 1024: 2 x 29 x 1024 / 64 = 928 wavefronts on 1024 SIMDs) the pair is the shorter chain.
     static const int g_env = getenv("PG_LIN_G") ? atoi(getenv("PG_LIN_G")) : 0;       // (diagnostic: force the lane arrangement)
-    const int G = (g_env == 2 || g_env == 4 || g_env == 8) ? g_env : n <= 256 ? 8 : (n <= 512 ? 4 : 2);        // bit-identical across K in fp64 (tests/test_gpu_multiprocess.py steps 1024 = 2 x 512, 1001 = 501 + 500, 400 = 2 x 200)
+#ifdef PG_F32
+    const int G_small = 2;   // (fp32: the instantiations differ at rounding level -- the compiler contracts them differently --, so only the two classes n <= 1024 / above exist:
+                             //  shards and whole batch agree bit for bit when they fall in the same class)
+#else
+    const int G_small = n <= 256 ? 8 : (n <= 512 ? 4 : 2);
 #endif
-    if (G == 2 && h->dc.Ns > 0 && h->dc.Ns < h->dc.N) {     // large batches: short-horizon intervals with three directions per lane (k_linearize_split)
-        const long nz = (long)n * h->dc.Ns * 2, nr = (long)n * (h->dc.N - h->dc.Ns) * 2;
+    // fp64: bit-identical across K (tests/test_gpu_multiprocess.py steps 1024 = 2 x 512, 1001 = 501 + 500, 400 = 2 x 200; tests/test_gpu_full_size.py 4096 against 4 x 1024)
+    const int G = (g_env == 1 || g_env == 2 || g_env == 4 || g_env == 8) ? g_env : ((n <= PG_LIN_PAIR_MAX || h->lin_lpi == 2) ? G_small : 1);
+    if (G <= 2 && h->dc.Ns > 0 && h->dc.Ns < h->dc.N) {     // short-horizon intervals without the two uf directions (k_linearize_split)
+        const long nz = (long)n * h->dc.Ns * G, nr = (long)n * (h->dc.N - h->dc.Ns) * G;
         const int nbz = (int)((nz + 63) / 64), nbr = (int)((nr + 63) / 64);
-        hipLaunchKernelGGL(k_linearize_split, dim3((unsigned)(nbz + nbr)), dim3(64), 0, h->stream, h->dc, n, nbz, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp);
+        auto ksplit = G == 1 ? k_linearize_split<1> : k_linearize_split<2>;
+        hipLaunchKernelGGL(ksplit, dim3((unsigned)(nbz + nbr)), dim3(64), 0, h->stream, h->dc, n, nbz, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp, (const int*)nullptr, 0);
         LAUNCH_CHECK(h);
         return PG_OK;
     }
     const long nl = (long)n * h->dc.N * G;
     const dim3 grid((unsigned)((nl + 63) / 64)), block(64);
-    if (G == 8) hipLaunchKernelGGL(k_linearize<1>, grid, block, 0, h->stream, h->dc, n, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp);
+    if (G == 1) hipLaunchKernelGGL(k_linearize<8>, grid, block, 0, h->stream, h->dc, n, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp);
+    else if (G == 8) hipLaunchKernelGGL(k_linearize<1>, grid, block, 0, h->stream, h->dc, n, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp);
     else if (G == 4) hipLaunchKernelGGL(k_linearize<2>, grid, block, 0, h->stream, h->dc, n, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp);
     else hipLaunchKernelGGL(k_linearize<4>, grid, block, 0, h->stream, h->dc, n, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp);
     LAUNCH_CHECK(h);

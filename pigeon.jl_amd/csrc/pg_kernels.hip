@@ -555,8 +555,14 @@ PG_DEV void linearize_pair(const DevCfg& C, int b, int t, int g, bool live, cons
                            real* __restrict__ qp) {
     linearize_lanes<4>(C, b, t, g, live, nodes, dt, hji_Mb, qp);
 }
-// the large-batch form: the Ns zero-order-hold intervals of every instance with three directions per lane (ND = 6), the N - Ns ramp intervals with four (ND = 8);
-// blocks [0, nb_zoh) take the first group -- a wavefront runs one of the two instruction streams, 8 instead of 10 dynamics "units" per short interval
+// the large-batch form: the Ns zero-order-hold intervals of every instance with six directions (ND = 6), the N - Ns ramp intervals with eight (ND = 8);
+// blocks [0, nb_zoh) take the first group -- a wavefront runs one of the two instruction streams.  LPI = lanes per (instance, interval):
+//   1 (round 4): ONE lane carries all the directions.  The scalar part of a lane (value, local Jacobian, RK4 of the state) costs as much as six directions, and a
+//     lane pair pays it twice; one lane holds 468 registers (212 of them AGPRs the compiler moves through) and still issues 30 % fewer instructions per interval:
+//     update_QP! of 4096 instances 0.343 -> 0.251 ms, the same bits (EXPERIMENTS.md 10.4 -- the paper argument against it, "two AGPR moves per access", was wrong).
+//     fp32: 0.281 -> 0.160 ms.
+//   2: the lane pair of rounds 1-3 (three / four directions per lane); batches of <= 1024 instances, where every pair is resident at once and the pair is the shorter chain.
+template <int LPI>
 __global__ __launch_bounds__(64) void k_linearize_split(DevCfg C, int B, int nb_zoh, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb,
                                                         real* __restrict__ qp, const int* __restrict__ only_if = nullptr, int nb_total = 0) {
     if (only_if && *only_if == 0) return;                         // (repair launch behind k_nodes_linearize, see there)
@@ -565,13 +571,13 @@ __global__ __launch_bounds__(64) void k_linearize_split(DevCfg C, int B, int nb_
         const bool zoh = blk < nb_zoh;
         const int nint = zoh ? C.Ns : C.N - C.Ns;                      // intervals of this group per instance
         long gid = (long)(zoh ? blk : blk - nb_zoh) * blockDim.x + threadIdx.x;
-        const long per = (long)nint * 2;
+        const long per = (long)nint * LPI;
         const bool live = gid < (long)B * per;
-        if (!live) gid = (long)B * per - 2 + (gid & 1);
+        if (!live) gid = (long)B * per - LPI + (gid & (LPI - 1));
         const int b = (int)(gid / per); const int rem = (int)(gid - (long)b * per);
-        const int t = (zoh ? 0 : C.Ns) + (rem >> 1), g = rem & 1;
-        if (zoh) linearize_lanes<3, 6>(C, b, t, g, live, nodes, dt, hji_Mb, qp);
-        else linearize_lanes<4, 8>(C, b, t, g, live, nodes, dt, hji_Mb, qp);
+        const int t = (zoh ? 0 : C.Ns) + rem / LPI, g = rem % LPI;
+        if (zoh) linearize_lanes<6 / LPI, 6>(C, b, t, g, live, nodes, dt, hji_Mb, qp);
+        else linearize_lanes<8 / LPI, 8>(C, b, t, g, live, nodes, dt, hji_Mb, qp);
     }
 }
 #ifndef PG_LIN_WAVES
@@ -594,8 +600,8 @@ __global__ __launch_bounds__(64, PG_LIN_WAVES) void k_linearize(DevCfg C, int B,
 // The cold seeding is a serial recurrence over the 31 nodes of an instance (lane = instance: 64 wavefronts at B = 4096, 0.18 ms of pure latency on 64 of the
 // 1024 SIMDs), and `linearize` of interval t reads nodes t and t + 1 only -- so the linearisation of the early intervals can run while the recurrence is still
 // on its way down the horizon.  Blocks [0, nb_nodes) run the nodes recurrence (the body of k_nodes) and publish their progress after every node; the blocks
-// behind them are the linearisation in INTERVAL-major order (block = 32 instances x 2 lanes of one interval t; t < Ns: three directions per lane, else four --
-// the two instruction streams of k_linearize_split) and wait until nodes t, t + 1 of their 32 instances are published.  The same device functions on the same
+// behind them are the linearisation in INTERVAL-major order (block = 64 / LPI instances x LPI lanes of one interval t; t < Ns: six directions, else eight --
+// the two instruction streams of k_linearize_split<LPI>) and wait until nodes t, t + 1 of their instances are published.  The same device functions on the same
 // arguments as the two-launch sequence: bit-identical nodes and QP data.
 //  * Forward progress: workgroups are dispatched in index order, so the nodes blocks are resident before any waiting block (nb_nodes <= 256 of 1024 SIMD slots is
 //    required by the host); they never wait for anything.  A waiting wavefront sleeps between polls and gives up after ~0.1 s: it then poisons its share of the
@@ -606,7 +612,7 @@ __global__ __launch_bounds__(64, PG_LIN_WAVES) void k_linearize(DevCfg C, int B,
 //    writes the dirty lines of the XCD's L2 back -- including the QP data the linearisation wavefronts of that XCD are in the middle of writing -- so the recurrence
 //    publishes after a few chosen nodes (`pub_mask`), not after every node: measured, B = 16384: 1.595 ms with 30 publications per wavefront, 1.434 with 6 (two launches:
 //    1.45); fp32 at 8192: 0.572 / 0.483 (0.555); B = 4096: 0.41 / 0.40 (0.53).
-template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_linearize(DevCfg C, int B, int nb_nodes, int nz_first, unsigned long long pub_mask, const real* __restrict__ state, const real* __restrict__ control,
+template <bool STAGED, int LPI> __global__ __launch_bounds__(64) void k_nodes_linearize(DevCfg C, int B, int nb_nodes, int nz_first, unsigned long long pub_mask, const real* __restrict__ state, const real* __restrict__ control,
                         const tdouble* __restrict__ toff, const int* __restrict__ solved, const real* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt,
                         const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* nodes, OrderOut F, real* naux, int* progress, const real* __restrict__ hji_Mb, real* __restrict__ qp, int* fault, int* fault_total) {
     if ((int)blockIdx.x < nb_nodes) {
@@ -617,18 +623,21 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_linearize(D
         return;
     }
     extern __shared__ real sh_rec[];                                      // (the dynamic LDS of the launch: max(trajectory channels, 64 x 20 node-record entries))
-    // a block = one interval t of 32 instances, two lanes each.  Order of the intervals: the first nz_first intervals of the short horizon (enough wavefronts to
+    // a block = one interval t of 64 / LPI instances, LPI lanes each.  Order of the intervals: the first nz_first intervals of the short horizon (enough wavefronts to
     // fill the machine while the recurrence is still in the short horizon), then the ramp intervals of the long horizon, and the remaining short-horizon
     // intervals LAST -- the launch ends with its cheapest wavefronts (0.408 -> 0.399 ms; grouping several intervals of an instance in a wavefront: no difference)
-    const int w = (int)blockIdx.x - nb_nodes, nbt = (B + 31) >> 5;
+    // (measured and dropped, EXPERIMENTS.md 10.4: lane pairs for the LAST ramp intervals -- the shorter chain behind the recurrence's last publication -- and for the FIRST
+    // short-horizon intervals -- more wavefronts while most SIMDs are still idle: 0.337 -> 0.351 / 0.343 ms.  One lane per interval everywhere.)
+    constexpr int IPB = 64 / LPI;                                         // instances per block
+    const int w = (int)blockIdx.x - nb_nodes, nbt = (B + IPB - 1) / IPB;
     int t = w / nbt; const int grp = w - t * nbt;
     if (t >= nz_first) t = t < nz_first + (C.N - C.Ns) ? t - nz_first + C.Ns : t - (C.N - C.Ns);
-    const int lane = (int)threadIdx.x, g = lane & 1;
-    int b = grp * 32 + (lane >> 1);
+    const int lane = (int)threadIdx.x, g = lane % LPI;
+    int b = grp * IPB + lane / LPI;
     const bool live = b < B;
     if (!live) b = B - 1;
     {
-        const int* flag = progress + ((grp * 32) >> 6);                     // (the nodes wavefront of these 32 instances)
+        const int* flag = progress + ((grp * IPB) >> 6);                    // (the nodes wavefront of these instances)
         const int need = t + 2;                                             // nodes 0 .. t + 1
         // The wait is bounded in WALL-CLOCK time (s_memrealtime: 100 MHz whatever the shader clock does): 20 ms -- a hundred times the whole recurrence.  A wavefront that
         // gives up (the nodes blocks not resident before it: a dispatch order this launch does not control; a debugger, a time-sliced or serialised profiler run)
@@ -662,12 +671,12 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_linearize(D
             rec[16] = atan2(y1, x1) - atan(t1);
             if (t == C.N - 1) {
                 if (b1 == b1) rec[14] = -atan(b1);
-                if (live && g == 1) { real* nd = nodes + ((size_t)b * C.NN + t + 1) * 10; nd[6] = rec[16]; nd[4] = rec[14]; }
+                if (live && g == LPI - 1) { real* nd = nodes + ((size_t)b * C.NN + t + 1) * 10; nd[6] = rec[16]; nd[4] = rec[14]; }
             }
         }
     }
-    if (t < C.Ns) linearize_lanes_at<3, 6>(C, b, t, g, live, rec, rec + 10, dt, hji_Mb, qp);
-    else linearize_lanes_at<4, 8>(C, b, t, g, live, rec, rec + 10, dt, hji_Mb, qp);
+    if (t < C.Ns) linearize_lanes_at<6 / LPI, 6>(C, b, t, g, live, rec, rec + 10, dt, hji_Mb, qp);
+    else linearize_lanes_at<8 / LPI, 8>(C, b, t, g, live, rec, rec + 10, dt, hji_Mb, qp);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -8,7 +8,8 @@ from __graft_entry__ import _load_pkg
 pkg = _load_pkg()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 traj = pkg.load_path_fixture("skidpadoval")
-mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B)
+prec = os.environ.get("PREC", "f64")
+mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, precision=prec)
 mpc.set_stream(torch.cuda.current_stream().cuda_stream)
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345, traj_mode=True)
 mpc.set_inputs(state, control, t0, time_offset=toff)
