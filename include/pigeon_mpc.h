@@ -220,7 +220,7 @@ int pg_set_stream(pg_handle* h, void* hip_stream);
  * Measured on MI355X: +7 % on the cold benchmark batch (skidpadoval), -5..-8 % on the other paths and in closed loop (EXPERIMENTS.md 4.1) -- it pays only where a few
  * slow instances dominate the solve kernel.  The four compute calls invoked one by one are never fused. */
 int pg_set_fusion(pg_handle* h, int32_t mode);
-/* Pipelined nodes + update_QP (build-defined; no counterpart in the reference): for batches of 2048..8192 instances with cold instances, coupled formulation,
+/* Pipelined nodes + update_QP (build-defined; no counterpart in the reference): for batches of 2304..16384 instances with cold instances, coupled formulation,
  * pg_step / pg_step_dev / pg_simulate_dev run compute_linearization_nodes! and update_QP! as ONE launch in which the linearisation of
  * interval t starts as soon as nodes t, t + 1 of its instances are seeded (the cold seeding is a serial recurrence over the nodes: 0.18 ms of latency on 6 % of the
  * chip that the linearisation of the early intervals now runs under).  With a safety row installed its (M, b) are computed before that launch.  Same device

@@ -36,6 +36,7 @@ struct pg_handle {
     real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     real* d_lam = nullptr;                                      // [cap][N][16] multipliers of the last solve (warm start of the polish)
     int* d_wfail = nullptr;                                     // [cap] back-off of k_solve_lat's warm attempts
+    int pipe_min = 2304, pipe_max = 16384;                    // batch sizes the pipelined launch serves (PG_PIPE_MIN / PG_PIPE_MAX; its nodes blocks must be resident at once: <= 16384)
     int lin_lpi = 1;                                          // lanes per (instance, interval) of the large-batch linearisation (k_linearize_split / k_nodes_linearize): one lane with all eight
                                                               // directions (PG_LIN_LPI=2: the lane pair of rounds 1-3, for A/B runs; same bits in fp64, rounding-level differences in fp32)
     int* d_todo = nullptr; int split_solve = 1, split_lat = 1; volatile int* h_todo = nullptr;      // h_todo: pinned copy of the previous launch's count (queued behind it, read -- never waited for -- by the next)
@@ -275,6 +276,8 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     h->ev_ok = true;
     { const char* e = getenv("PG_HJI_SEED"); C.hji_seed = e ? atoi(e) : 0; }
     { const char* e = getenv("PG_HJI_ROUNDS"); C.hji_rounds = e ? atoi(e) : 0; }
+    { const char* e = getenv("PG_PIPE_MIN"); if (e && e[0] >= '0' && e[0] <= '9') h->pipe_min = atoi(e); }
+    { const char* e = getenv("PG_PIPE_MAX"); if (e && e[0] >= '0' && e[0] <= '9') { h->pipe_max = atoi(e); if (h->pipe_max > 16384) h->pipe_max = 16384; } }
     { const char* e = getenv("PG_LIN_LPI"); if (e && (e[0] == '1' || e[0] == '2') && !e[1]) h->lin_lpi = e[0] - '0'; }
     { const char* e = getenv("PG_LAT_SPLIT"); if (e && (e[0] == '0' || e[0] == '1')) h->split_lat = e[0] - '0'; }
     { const char* e = getenv("PG_SOLVE_SPLIT"); if (e && (e[0] == '0' || e[0] == '1')) h->split_solve = e[0] - '0'; }
@@ -559,8 +562,9 @@ int pg_compute_linearization_nodes(pg_handle* h) {
 }
 // compute_time_steps! + compute_linearization_nodes! of pg_step_dev / pg_simulate_dev: the time grid rides in the projection kernel (one launch fewer)
 // the pipelined nodes + update_QP launch (k_nodes_linearize) serves the steps of pg_step_dev / pg_simulate_dev when: coupled formulation, some instance is cold (an
-// all-warm batch has no recurrence: k_nodes_warm), the batch is large enough for the linearisation to need several rounds of wavefronts (below, the sum of the two
-// kernels is the latency of the pipeline anyway) and small enough for it to pay and for the nodes wavefronts to be resident at once (<= 8192 instances = 128 of the 1024 SIMD slots; at 16384 the launch breaks even), and the
+// all-warm batch has no recurrence: k_nodes_warm), the batch is large enough for the linearisation to need more than one round of wavefronts (one lane per interval:
+// 2048 x 29 / 64 = 928 wavefronts are one round and the two launches are shorter -- 0.310 against 0.315 ms; 2560: 0.386 against 0.317) and small enough for the nodes
+// wavefronts to be resident at once (<= 16384 instances = 256 of the 1024 SIMD slots; measured with the one-lane linearisation: 12288: 0.72 against 0.86 ms, 16384: 1.02 against 1.07), and the
 // linearisation is not fused into the solve kernel.  With a safety row, its (M, b) -- functions of the measured states only -- are computed BEFORE the launch and the
 // launch order is re-filed after it (k_order_hji needs the verdicts the recurrence files).
 static int launch_hji_rows_compute(pg_handle* h);
@@ -568,7 +572,7 @@ static int launch_hji_order(pg_handle* h);
 static bool pipeline_applies(const pg_handle* h) {
     const DevCfg& C = h->dc;
     const bool fuse_wanted = h->fuse == 1;
-    return h->pipeline == 1 && C.formulation != PG_DECOUPLED && h->warm_B < h->B && h->B >= 2048 && h->B <= 8192 && C.Ns > 0 && C.Ns < C.N && !fuse_wanted;
+    return h->pipeline == 1 && C.formulation != PG_DECOUPLED && h->warm_B < h->B && h->B >= h->pipe_min && h->B <= h->pipe_max && C.Ns > 0 && C.Ns < C.N && !fuse_wanted;
 }
 static int launch_nodes(pg_handle* h, bool with_time_grid) {
     const int B = h->B;

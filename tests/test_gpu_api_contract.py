@@ -64,7 +64,7 @@ def test_pipelined_launch_recovers_when_the_recurrence_never_publishes(pkg, skid
     predicated on the device's fault word, redo update_QP! for the batch: the step returns the SAME controls, QP data and statuses as a step with the pipeline off
     (VERDICT r2 weak 6 / ADVICE r2: a slow step, never wrong-status answers), and the fall-back is counted."""
     import time
-    B = 2048
+    B = 2560            # (the pipelined launch serves 2304 .. 16384 instances)
     state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B, seed=3)
     ref = pkg.BatchedTrajectoryTrackingMPC(skidpad, B); ref.set_pipeline(0)
     u0, st0, it0 = ref.step_(state, control, t0, time_offset=toff)

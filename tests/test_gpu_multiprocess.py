@@ -28,7 +28,7 @@ def _launch(nproc, script_args, timeout=600):
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
 
 
-@pytest.mark.parametrize("B,precision", [(1024, "f64"), (1001, "f64"), (400, "f64"), (2048, "f64"), (1024, "f32")])      # (400 = 2 x 200, 1024 = 2 x 512, 2048 = 2 x 1024: shards and whole batch use different lane splits of k_linearize -- 8, 4, 2 lanes per interval, and 1 in the pipelined launch of the whole 2048)
+@pytest.mark.parametrize("B,precision", [(1024, "f64"), (1001, "f64"), (400, "f64"), (2048, "f64"), (1024, "f32")])      # (400 = 2 x 200, 1024 = 2 x 512, 2048 = 2 x 1024: shards and whole batch use different lane splits of k_linearize -- 8, 4, 2 lanes per interval, and 1 for the whole 2048)
 def test_two_ranks_step_their_shards_and_gather(pkg, skidpad, tmp_path, B, precision):
     """Both ranks run the real pg_step_dev on their shard; the gathered controls are BIT-identical to one process stepping the whole batch
     (instances are independent: nothing in the path depends on the batch an instance sits in)."""
