@@ -593,7 +593,10 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
     h->order_B = file ? B : 0;
     if (h->dc.formulation == PG_DECOUPLED) {
         auto kern = staged ? k_nodes_dec<true> : k_nodes_dec<false>;
-        hipLaunchKernelGGL(kern, grid, block, traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_sep, h->d_ts, h->d_dt, h->d_nodes);
+        hipLaunchKernelGGL(kern, grid, block, traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_sep, h->d_ts, h->d_dt, h->d_nodes, h->d_naux);
+        LAUNCH_CHECK(h);
+        const long nn = (long)B * h->dc.NN;
+        hipLaunchKernelGGL(k_nodes_angles, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_naux, h->d_nodes, (const int*)nullptr);
     } else {
         if (h->warm_B >= B) {           // every instance takes the warm branch: lane = (instance, node)
             auto kern = staged ? k_nodes_warm<true> : k_nodes_warm<false>;

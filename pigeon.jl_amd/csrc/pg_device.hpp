@@ -557,7 +557,8 @@ PG_DEV TrajS traj_at_s(const TrajView& T, real sq) {
 // traj[sq] and traj(tq).s of one node in ONE loop: the two binary searches (arclength channel, time channel) advance in lockstep so that their dependent
 // LDS / L2 probes overlap, and searchsortedlast on the arclength channel is derived from searchsortedfirst (the knots are strictly increasing: at most
 // one equals sq) instead of being searched again.  Same results as traj_at_s + traj_s_at_time.
-PG_DEV void traj_lookup2(const TrajView& T, real sq, real tq, TrajS& o, real& s_at_t) {
+// (j_out, w_out: knot and weight of the interp_by_s channels at sq -- psi and kappa here, edge_L / edge_R for the caller: traj_edges_at_s at the same arclength)
+PG_DEV void traj_lookup2(const TrajView& T, real sq, real tq, TrajS& o, real& s_at_t, int* j_out = nullptr, real* w_out = nullptr) {
     int lo_s = 0, hi_s = T.L, lo_t = 0, hi_t = T.L;
     while (lo_s < hi_s || lo_t < hi_t) {
         const int ms = (lo_s + hi_s) >> 1, mt = (lo_t + hi_t) >> 1;
@@ -582,6 +583,7 @@ PG_DEV void traj_lookup2(const TrajView& T, real sq, real tq, TrajS& o, real& s_
     const real w = (sq - T.s[j]) / (T.s[j + 1] - T.s[j]);
     o.psi = T.psi[j] + w * (T.psi[j + 1] - T.psi[j]);
     o.kappa = T.kappa[j] + w * (T.kappa[j + 1] - T.kappa[j]);
+    if (j_out) { *j_out = j; *w_out = w; }
 }
 // edge_L, edge_R channels of interp_by_s at arclength sq (trajectories.jl:32-35): read only by the build-defined wall rows
 PG_DEV void traj_edges_at_s(const TrajView& T, real sq, real& eL, real& eR) {

@@ -722,7 +722,10 @@ __global__ __launch_bounds__(64) void k_advance(DevCfg C, int B, tdouble dtp, re
 // decoupled from the rest, the optimum of the embedded problem restricted to the live slots IS the lateral optimum).
 // Node record (10 doubles): (0, Ux parameter, Uy, r, dpsi, e, delta, Fx, 0, kappa).
 template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg C, int B, const real* __restrict__ state, const real* __restrict__ control, const tdouble* __restrict__ toff,
-                                                  const real* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt, real* __restrict__ nodes) {
+                                                  const real* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt, real* __restrict__ nodes, real* __restrict__ naux) {
+    // One serial chain per instance (lane = instance), 51 nodes at N = 50: latency is its whole cost.  As in k_nodes: the arclength and time channels are searched in ONE
+    // lockstep loop per node (traj_lookup2; the wall edges reuse its knot), and the three inverse tangents of a seeded node -- they feed nothing in the chain -- are left to
+    // k_nodes_angles (lane = (instance, node)), launched behind this kernel: the same expressions on the same arguments, bit-identical nodes (round 4: 0.36 -> see DESIGN.md).
     extern __shared__ real sh_traj[];
     TrajView T = C.traj;
     if constexpr (STAGED) {                                 // single shared trajectory; compile-time so the searches compile to ds_read, not flat loads
@@ -752,27 +755,33 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg 
 #pragma unroll 1
     for (int i = 0; i < C.NN; i++) {
         real tau = (i == C.NN - 1) ? DT[i - 1] : DT[i];
-        TrajS tj = traj_at_s(T, s);
-        real A_des = tj.A + C.cp.k_V * (tj.V - V) / tau + (traj_mode ? C.cp.k_s * (traj_s_at_time(T, TS[i]) - s) / tau / tau : real(0.0));   // :76
+        TrajS tj; real s_ref; int jk; real wk;
+        traj_lookup2(T, s, TS[i], tj, s_ref, &jk, &wk);
+        real A_des = tj.A + C.cp.k_V * (tj.V - V) / tau + (traj_mode ? C.cp.k_s * (s_ref - s) / tau / tau : real(0.0));   // :76
         A_des = jmin(jmax(A_des, (C.cp.V_min - V) / tau), (C.cp.V_max - V) / tau);
         NodeRec r; real A;
+        real* ax = naux + ((size_t)b * C.NN + i) * 4;
         r.q0 = real(0.0); r.pV = real(0.0); r.pK = tj.kappa;
         if (i == 0) {
             r.q1 = Ux0; r.q2 = Uy0; r.q3 = r0; r.q4 = adiff(psi0, tj.psi); r.q5 = e0; r.u0 = d0; r.u1 = Fxf0 + Fxr0;      // :79-81
             real dUx, dUy, dr;
             world_body_rhs<real>(P, Ux0, Uy0, r0, d0, Fxf0 + Fxr0, dUx, dUy, dr);                                          // :82
-            real sb, cb; pg_sincos(beta0, &sb, &cb);
-            A = (dUx - r0 * Uy0) * cb + (dUy + r0 * Ux0) * sb;                                                               // :83
+            A = (dUx - r0 * Uy0) * cb0 + (dUy + r0 * Ux0) * sb0;                                                             // :83
+            ax[0] = NAN;                                                                                                     // the measured state: nothing deferred
         } else {
             const bool shortp = i <= C.Ns;
             Steady est = steady_state(P, V, A_des, tj.kappa, shortp ? 1 : 4, shortp ? r0 : V * tj.kappa, shortp ? beta0 : real(0.0), shortp ? sb0 : real(0.0), shortp ? cb0 : real(1.0),
-                                      shortp ? d0 : real(0.0), shortp ? sd0 : real(0.0), shortp ? cd0 : real(1.0), shortp ? Fyf0 : real(0.0));
+                                      shortp ? d0 : real(0.0), shortp ? sd0 : real(0.0), shortp ? cd0 : real(1.0), shortp ? Fyf0 : real(0.0), true);
             r.q1 = est.Ux;
-            r.q2 = shortp ? Uy0 : est.Uy; r.q3 = shortp ? r0 : est.r; r.q4 = shortp ? adiff(psi0, tj.psi) : -est.beta; r.q5 = shortp ? e0 : real(0.0);   // :85,92
-            r.u0 = est.delta; r.u1 = est.Fx; A = est.A;
+            r.q2 = shortp ? Uy0 : est.Uy; r.q3 = shortp ? r0 : est.r; r.q4 = shortp ? adiff(psi0, tj.psi) : -est.beta; r.q5 = shortp ? e0 : real(0.0);   // :85,92 (long nodes: q4 = -beta by k_nodes_angles)
+            r.u0 = real(0.0); r.u1 = est.Fx; A = est.A;                                                                      // (u0 = delta by k_nodes_angles)
+            ax[0] = est.ang_y; ax[1] = est.ang_x; ax[2] = est.ang_t; ax[3] = (!shortp && est.beta_is_tan) ? est.tb : NAN;
         }
         put_node(ND, i, r);
-        if (C.walls && i >= 1) { real eL, eR; traj_edges_at_s(T, s, eL, eR); real* w = C.wall_edges + ((size_t)b * C.N + i - 1) * 2; w[0] = eL; w[1] = eR; }
+        if (C.walls && i >= 1) {                                                        // traj_edges_at_s(T, s): the knot and weight of the lookup above
+            real* w = C.wall_edges + ((size_t)b * C.N + i - 1) * 2;
+            w[0] = T.edge_L[jk] + wk * (T.edge_L[jk + 1] - T.edge_L[jk]); w[1] = T.edge_R[jk] + wk * (T.edge_R[jk + 1] - T.edge_R[jk]);
+        }
         V = V + A * tau;
         s = s + V * tau + A * tau * tau * real(0.5);
     }
