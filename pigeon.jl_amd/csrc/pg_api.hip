@@ -275,6 +275,8 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     for (int i = 0; i < 4; i++) if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_create_error = "hipEventCreate failed"; free_all(h); delete h; return PG_ERR_HIP; }
     h->ev_ok = true;
     { const char* e = getenv("PG_HJI_SEED"); C.hji_seed = e ? atoi(e) : 0; }
+    { const char* e = getenv("PG_CLIP_GUESS"); C.clip_guess = e ? atoi(e) : 1; }
+    { const char* e = getenv("PG_WARM_TRIVIAL_COLD"); C.warm_trivial_cold = e ? atoi(e) : 1; }
     { const char* e = getenv("PG_HJI_ROUNDS"); C.hji_rounds = e ? atoi(e) : 0; }
     { const char* e = getenv("PG_PIPE_MIN"); if (e && e[0] >= '0' && e[0] <= '9') h->pipe_min = atoi(e); }
     { const char* e = getenv("PG_PIPE_MAX"); if (e && e[0] >= '0' && e[0] <= '9') { h->pipe_max = atoi(e); if (h->pipe_max > 16384) h->pipe_max = 16384; } }

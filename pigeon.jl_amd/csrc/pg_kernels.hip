@@ -34,6 +34,8 @@ struct DevCfg {
     int polish;                   // active-set polish after the interior point (k_solve): 0 off, 1 on
     real polish_rho, polish_tol;  // penalty of the active rows in the polish solves; feasibility tolerance of its verification
     int hji_rounds;               // k_solve: working sets such a seeded attempt may try (0: the cold-guess cap and its extension)
+    int warm_trivial_cold;        // k_solve: a warm instance whose previous working set was empty starts like a cold one (PG_WARM_TRIVIAL_COLD, default 1)
+    int clip_guess;               // k_solve, cold instances: the first roll-out clips the steering rate at its limits and the clipped transitions are the first working set (PG_CLIP_GUESS, default 1)
     int hji_seed;                 // k_solve: rounds of an instance whose safety row is violated at the current control start from a seeded working set (0: interior point, as before)
     int cold_guess;               // > 0: a COLD instance first tries the polish from the empty active set (unconstrained LQ optimum + add/drop rounds), at most this many rounds
     int warm_polish;              // instances with a previous solution first try the polish from its active set and multipliers (no interior point if it verifies)
@@ -1404,6 +1406,14 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     // Lane roles inside each 16-lane row (rows mirror each other): lanes 0..5 own the six dynamics rows of Abar, lanes 6, 7 the two input states, lanes 8, 9 the two
     // rows of the gain K -- every lane does ONE 8-term dot product against the broadcast state and the two inputs come back through SGPRs (round 1 had all eight
     // component lanes evaluate both gain rows as well: 24 FMAs and 29 LDS reads per lane and stage, now 10 and 11).
+    // Working-set guess of a cold instance (round 4).  The verified sets of a cold batch are runs of steering-rate rows from the first transition (7 rows for the instances that
+    // used to take two rounds, 10 for three, 13-15 beyond: the rounds followed the length of the run, one row per round past the second).  The roll-out of the FIRST round --
+    // empty set: the unconstrained optimum -- therefore applies the gains with the steering rate clipped at its limits: the lag of the held transitions feeds back through
+    // the gains and the later transitions saturate as they will in the optimum.  Nothing clipped: the point is the unconstrained optimum and verifies as before (half of the
+    // batch).  Otherwise the point is not a KKT candidate; its clipped transitions are the first working set (no multiplier update, no drops in that check).
+    // Headline batch: rounds 1 / 2 / 3 / 4+ 2105 / 714 / 928 / 349 -> 2105 / 1552 / 372 / 67 instances (mean 1.97 -> 1.62), k_solve 0.386 -> 0.334 ms.  Measured and dropped:
+    // clipping in every round (11 instances end in the interior point), clipping at the steering stops as well (fp64: 3-round instances 372 -> 418, 4+ 67 -> 21, same time; fp32: more 9-12 round instances, 0.34 -> 0.43 ms; and the code alone costs 4 % in the roll-out).  PG_CLIP_GUESS=0: off.
+    bool clip_now = false, clip_used = false, clip_off = false; unsigned clip_mask = 0u;
     auto forward = [&](auto use_gain_t, bool delta = false) {      // delta: the roll-out of a CORRECTION (starts at 0, no affine term: see the polish refinement)
         constexpr bool use_gain = decltype(use_gain_t)::value;
         const int f16 = lane & 15;
@@ -1431,7 +1441,12 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             for (int m = 0; m < 8; m += 2) { d0 += rw[m] * xm[m]; d1 += rw[m + 1] * xm[m + 1]; }
             real d = d0 + d1;
             if (!use_gain) d = isK ? real(0.0) : d;            // v = 0 roll-out of the first start
-            const real v0 = rl(d, 8), v1 = rl(d, 9);
+            real v0 = rl(d, 8); const real v1 = rl(d, 9);
+            if (clip_now) {        // (wave-uniform; first round of a cold instance) saturated roll-out: the gain of the unconstrained problem, the steering rate held inside its limits
+                const real hi = rl(bb[12], k), lo = -rl(bb[13], k);
+                if (v0 > hi) { v0 = hi; if (lane == k) clip_mask |= 1u << 12; }
+                else if (v0 < lo) { v0 = lo; if (lane == k) clip_mask |= 1u << 13; }
+            }
             const real xr = d + (bf0 * v0 + bf1 * v1);
             // arithmetic blend instead of ?: so that the compiler keeps the LDS reads above unconditional (a branch here serialises them)
             const real xn = w_lo * xr + w_6 * (xm[6] + v0) + w_7 * (xm[7] + v1);
@@ -1761,7 +1776,13 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     // (attempt -1): in closed loop the set rarely changes from one 10 ms step to the next, and a verified round IS the exact optimum of the new QP whatever the
     // guess was, so nothing is lost in accuracy; if the rounds do not verify, the interior point runs as for a cold instance.
     real* const Lst = O.lam + ((size_t)b * N + s) * NROW;
-    const bool warm = C.polish && C.warm_polish && prev_solved != 0 && prev_status == PG_SOLVED;
+    bool warm = C.polish && C.warm_polish && prev_solved != 0 && prev_status == PG_SOLVED;
+    // ... unless the previous set holds nothing but the pivots of the eliminated slacks: that IS the empty set, which attempt -1 starts from as well -- with the clipped
+    // roll-out's guess should the new optimum have rows after all (closed loop of the headline batch, 40 steps: 6.38 -> see EXPERIMENTS.md 10.9)
+    if (warm && C.clip_guess != 0 && C.warm_trivial_cold != 0) {
+        const unsigned piv = (1u << 10) | (1u << 11) | (hji_on ? (1u << 15) : 0u) | (wall_on ? (1u << 2) : 0u);
+        if (!__any(act && (((unsigned)O.active[(size_t)b * N + s]) & ~piv) != 0u)) warm = false;
+    }
     // attempt -1: the polish from the EMPTY set (cold instances, and warm ones whose previous set did not verify).  Not where the safety row is violated at the
     // current control: its weight (W_HJI) then overrides the tracking cost, the optimum is close to bang-bang (rate rows of both signs, force bounds, soft rows all
     // change together) and the add / drop iteration turns over dozens of rows per round -- the interior point needs its usual 8 iterations there
@@ -1887,11 +1908,14 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     // stored, pstat set), 1 = same set but the active rows are not yet at t = 0 within `ttol` (refine), 2 = the active set changed, 3 = the sets cycle.
     auto polish_check = [&](const real* tp, real ttol, real dmax = real(0.0)) -> int {
         unsigned add = 0, drop = 0; bool settled = !(dmax > dtol);
+        // (a roll-out that clipped the steering rate is not the optimum of its working set: no multiplier update, no drops -- its clipped transitions join the set)
+        const bool clipped = __any(clip_mask != 0u);
+        if (clipped) { add = act ? (clip_mask & ~amask) : 0u; settled = false; clip_used = true; }
 #pragma unroll
         for (int j = 0; j < NROW; j++) {
             const bool on = act && j < nrows, a = (amask >> j) & 1u;
-            if (a) R.lam[j] -= rho * tp[j];
-            if (on && a && R.lam[j] < real(0.0)) drop |= 1u << j;
+            if (a && !clipped) R.lam[j] -= rho * tp[j];
+            if (on && a && !clipped && R.lam[j] < real(0.0)) drop |= 1u << j;
             if (on && a && !(fabs(tp[j]) <= ttol)) settled = false;            // written so that a NaN never verifies
             if (on && !a && !(tp[j] >= -ptol)) add |= 1u << j;
         }
@@ -2055,7 +2079,9 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
         stamp(1);
         riccati_matrices();                // matrix recursion + the predictor's vector recursion
         stamp(2);
+        clip_mask = 0u; clip_now = C.clip_guess != 0 && !clip_off && attempt == -1 && pmode == 1 && !hji_hot;
         forward(std::true_type{});
+        clip_now = false;
         stamp(4);
         newton_point(tp);
         if (IPM && !pmode) {
@@ -2180,6 +2206,9 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     }
     it_total += it;
     if (status == PG_SOLVED || status == PG_NUMERICAL) break;
+    // a cold attempt that started from the clipped roll-out's set and did not verify is repeated once from the plain empty set (the rounds of rounds 2-3: one fp32
+    // instance of 4096 needs it -- and the launch lasts as long as an instance that falls through to the interior point)
+    if (attempt == -1 && clip_used && !clip_off) { clip_off = true; attempt = -2; }
     }   // attempts
     it = it_total;
     stamp(0);
