@@ -35,6 +35,7 @@ struct DevCfg {
     real polish_rho, polish_tol;  // penalty of the active rows in the polish solves; feasibility tolerance of its verification
     int hji_rounds;               // k_solve: working sets such a seeded attempt may try (0: the cold-guess cap and its extension)
     int warm_trivial_cold;        // k_solve: a warm instance whose previous working set was empty starts like a cold one (PG_WARM_TRIVIAL_COLD, default 1)
+    int ck_riccati;               // k_solve (rounds-only instantiation): restart the matrix recursion of a round at its checkpoint when the working set allows (PG_CK_RICCATI, default 1)
     int clip_guess;               // k_solve, cold instances: the first roll-out clips the steering rate at its limits and the clipped transitions are the first working set (PG_CLIP_GUESS, default 1)
     int hji_seed;                 // k_solve: rounds of an instance whose safety row is violated at the current control start from a seeded working set (0: interior point, as before)
     int cold_guess;               // > 0: a COLD instance first tries the polish from the empty active set (unconstrained LQ optimum + add/drop rounds), at most this many rounds
@@ -1285,6 +1286,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     real* sx0 = sMT + 99 + 1;              // [8]
     real* sDum = sx0 + 8;              // [64] sink for predicated-off stores (keeps the pass loops branch-free)
     real* sZero = sDum + 64;           // [2]  a stored 0.0 (off-pattern entries of Qhat)
+    real* skf_ck = sZero + 2;          // [N][2] the predictor's feed-forward terms as the matrix pass left them (skf itself is rewritten by every vector pass): restored when the recursion restarts at its checkpoint
 
     const QpOff o = qp_offsets(N);
     const real* Q = qp + (size_t)b * C.qp_len;
@@ -1590,11 +1592,25 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
         f0 = __hiloint2double((int)th[0], (int)tl[0]); f1 = __hiloint2double((int)th[1], (int)tl[1]);
     };
 #endif
+    // Checkpoint of the recursion (rounds of the active-set polish, rounds-only instantiation, N <= 32): (P, p) after stage ck_k, two registers per lane.  The stage costs
+    // of a round differ from the previous round's only where the working set does, and the sets of a cold batch are runs of rows from the first transition (stage <= 14
+    // of 30): while no stage lane >= ck_k - 1 holds anything but its slack pivots -- now and when the checkpoint was taken -- the recursion restarts there (the gains and the
+    // Mc of the stages behind it are still in LDS).  The pivots' multipliers are their known values (they move at rounding level once the refinement passes run).
+    real ck_V0 = real(0.0), ck_V1 = real(0.0); int ck_top = 1 << 20;      // ck_top: highest stage with a non-pivot row when the checkpoint was taken (1 << 20: none taken)
+    const int ck_k = ((N >> 1) + 3) & ~3;
+    bool ck_restart = false;
     auto riccati_matrices = [&]() {
-        real V0 = abase[0][amul[0] * N], V1 = abase[1][amul[1] * N];          // terminal: P_N = Qhat_N, p_N = qhat_N (operand layout; the vector lives in column 10)
+        const bool restart = (!IPM && !RING) && ck_restart;
+        real V0 = restart ? ck_V0 : abase[0][amul[0] * N], V1 = restart ? ck_V1 : abase[1][amul[1] * N];          // terminal: P_N = Qhat_N, p_N = qhat_N (operand layout; the vector lives in column 10)
         ring_prime(N - 1, -1);
+        if (restart) { const int i = 2 * ck_k + lane; if (i < 2 * N) skf[i] = skf_ck[i]; }      // (2 (N - ck_k) <= 64 values)
+        // two segments of the same rolled loop: stages N-1 .. ck_k (skipped on a restart), then ck_k-1 .. 0; the checkpoint is taken between them
+        const int nseg = (!IPM && !RING) ? 2 : 1;
 #pragma unroll 1
-        for (int k = N - 1; k >= 0; k--) {
+        for (int seg = restart ? 1 : 0; seg < nseg; seg++) {
+        const int k_hi = (nseg == 2 && seg == 1) ? ck_k - 1 : N - 1, k_lo = (nseg == 2 && seg == 0) ? ck_k : 0;
+#pragma unroll 1
+        for (int k = k_hi; k >= k_lo; k--) {
             ring_step(k, -1);
             const real* Xk = ring_slot(k);
             // stage constants: none of these reads depends on the recursion
@@ -1643,7 +1659,12 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
                 wave_sync();
             }
         }
+        if (nseg == 2 && seg == 0) { ck_V0 = V0; ck_V1 = V1; }
+        }
         __syncthreads();
+        if constexpr (!IPM && !RING) {      // (the feed-forward terms of the stages behind the checkpoint, as this pass left them: off the serial loop)
+            if (!restart) { const int i = 2 * ck_k + lane; if (i < 2 * N) skf_ck[i] = skf[i]; }
+        }
     };
 #undef PG_MFMA
 #else
@@ -2077,7 +2098,21 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
         assemble(real(0.0), true);
         __syncthreads();
         stamp(1);
-        riccati_matrices();                // matrix recursion + the predictor's vector recursion
+        {
+            bool restart = false;
+            if constexpr (!IPM && !RING) {
+                if (C.ck_riccati != 0) {
+                    const unsigned piv = (1u << 10) | (1u << 11) | (hji_on ? (1u << 15) : 0u) | (wall_on ? (1u << 2) : 0u);
+                    const unsigned long long held = __ballot(act && (amask & ~piv) != 0u);
+                    const int top = held ? 63 - __builtin_clzll(held) : -1;
+                    restart = top < ck_k - 1 && ck_top < ck_k - 1;      // (the rows of stage lane s sit on node s + 1: P_{ck_k} holds those of lane ck_k - 1)
+                    if (!restart) ck_top = top;
+                }
+            }
+            ck_restart = restart;
+            riccati_matrices();                // matrix recursion + the predictor's vector recursion
+            ck_restart = false;
+        }
         stamp(2);
         clip_mask = 0u; clip_now = C.clip_guess != 0 && !clip_off && attempt == -1 && pmode == 1 && !hji_hot;
         forward(std::true_type{});
