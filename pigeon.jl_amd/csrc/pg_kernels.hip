@@ -1598,14 +1598,17 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     // Mc of the stages behind it are still in LDS).  The pivots' multipliers are their known values (they move at rounding level once the refinement passes run).
     real ck_V0 = real(0.0), ck_V1 = real(0.0); int ck_top = 1 << 20;      // ck_top: highest stage with a non-pivot row when the checkpoint was taken (1 << 20: none taken)
     const int ck_k = ((N >> 1) + 3) & ~3;
+    // (fp64 only: in fp32 the pivots' multipliers drift by 1e-7 per refinement pass, the checkpoint goes stale, and 75 of 8192 instances of the config-4 batch ended in the
+    //  interior point)
+    constexpr bool CKPT = !IPM && !RING && sizeof(real) == 8;
     bool ck_restart = false;
     auto riccati_matrices = [&]() {
-        const bool restart = (!IPM && !RING) && ck_restart;
+        const bool restart = CKPT && ck_restart;
         real V0 = restart ? ck_V0 : abase[0][amul[0] * N], V1 = restart ? ck_V1 : abase[1][amul[1] * N];          // terminal: P_N = Qhat_N, p_N = qhat_N (operand layout; the vector lives in column 10)
         ring_prime(N - 1, -1);
         if (restart) { const int i = 2 * ck_k + lane; if (i < 2 * N) skf[i] = skf_ck[i]; }      // (2 (N - ck_k) <= 64 values)
         // two segments of the same rolled loop: stages N-1 .. ck_k (skipped on a restart), then ck_k-1 .. 0; the checkpoint is taken between them
-        const int nseg = (!IPM && !RING) ? 2 : 1;
+        const int nseg = CKPT ? 2 : 1;
 #pragma unroll 1
         for (int seg = restart ? 1 : 0; seg < nseg; seg++) {
         const int k_hi = (nseg == 2 && seg == 1) ? ck_k - 1 : N - 1, k_lo = (nseg == 2 && seg == 0) ? ck_k : 0;
@@ -1662,7 +1665,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
         if (nseg == 2 && seg == 0) { ck_V0 = V0; ck_V1 = V1; }
         }
         __syncthreads();
-        if constexpr (!IPM && !RING) {      // (the feed-forward terms of the stages behind the checkpoint, as this pass left them: off the serial loop)
+        if constexpr (CKPT) {      // (the feed-forward terms of the stages behind the checkpoint, as this pass left them: off the serial loop)
             if (!restart) { const int i = 2 * ck_k + lane; if (i < 2 * N) skf_ck[i] = skf[i]; }
         }
     };
@@ -2100,7 +2103,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
         stamp(1);
         {
             bool restart = false;
-            if constexpr (!IPM && !RING) {
+            if constexpr (CKPT) {
                 if (C.ck_riccati != 0) {
                     const unsigned piv = (1u << 10) | (1u << 11) | (hji_on ? (1u << 15) : 0u) | (wall_on ? (1u << 2) : 0u);
                     const unsigned long long held = __ballot(act && (amask & ~piv) != 0u);
