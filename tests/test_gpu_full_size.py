@@ -322,3 +322,38 @@ def test_split_solve_launch_gives_the_same_answers(pkg, skidpad, monkeypatch):
         assert np.max(np.abs(a[0][both] - b[0][both]) / un) < 1e-8 and np.max(np.abs(a[3][both] - b[3][both]) / un) < 1e-8, path
         if path == "vail":
             assert (a[2] > 0).sum() >= 1          # the list-mode launch had something to do
+
+
+@pytest.mark.gpu
+def test_round4_guess_checkpoint_and_lane_arrangement_change_nothing(pkg, skidpad, monkeypatch):
+    """Round 4's three changes to the headline path, each against its switch, on the benchmark batch (B = 4096, cold):
+    (i) PG_LIN_LPI: one lane per (instance, interval) with all eight tangent directions against the lane pair -- the QP data bit for bit (fp64);
+    (ii) PG_CK_RICCATI: the matrix recursion of a round restarted at its checkpoint -- controls, primal solution and statuses bit for bit;
+    (iii) PG_CLIP_GUESS: the rounds of a cold instance started from the clipped roll-out's working set against the plain empty set -- two routes to verified KKT
+    points of the same QP: every instance solved without an interior-point iteration both ways, controls within 1e-8, the canonical active sets identical."""
+    B = 4096
+    un = np.array([0.314159, 16793.7, 16793.7])
+    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B, seed=12345, traj_mode=True)
+
+    def run(**env):
+        for k, v in env.items(): monkeypatch.setenv(k, v)
+        m = pkg.BatchedTrajectoryTrackingMPC(skidpad, B)
+        u, st, it = m.step_(state, control, t0, time_offset=toff)
+        _, _, act, _ = m.solve_info()
+        r = dict(u=u, st=st, it=it, x=m.solution()[0], qp=m.qp_data(), act=act, lam=m.multipliers(), pol=m.polish_info().copy())
+        m.close()
+        for k in env: monkeypatch.delenv(k)
+        return r
+
+    ref = run()
+    assert np.all(ref["st"] == pkg.SOLVED) and np.all(ref["it"] == 0) and np.all(ref["pol"] >= 1)
+    pair = run(PG_LIN_LPI="2")
+    assert np.array_equal(pair["qp"], ref["qp"]) and np.array_equal(pair["u"], ref["u"])
+    nock = run(PG_CK_RICCATI="0")
+    assert np.array_equal(nock["u"], ref["u"]) and np.array_equal(nock["x"], ref["x"]) and np.array_equal(nock["st"], ref["st"]) and np.array_equal(nock["pol"], ref["pol"])
+    plain = run(PG_CLIP_GUESS="0")
+    assert np.all(plain["st"] == pkg.SOLVED) and np.all(plain["it"] == 0)
+    assert np.max(np.abs(plain["u"] - ref["u"]) / un) < 1e-8
+    can = lambda r: ((r["act"][:, :, None].astype(np.uint32) >> np.arange(16)[None, None, :]) & 1).astype(bool) & (r["lam"] > 1e-6)
+    assert np.array_equal(can(plain), can(ref))
+    assert ref["pol"].mean() < plain["pol"].mean() - 0.2            # (1.62 against 1.97 rounds per instance)
