@@ -376,6 +376,29 @@ def main():
         two_streams = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "solved": f"{ok2}/{B}",
                        "config": f"the same {B} cold instances as 2 x {B // 2} on two handles and two HIP streams, steps submitted alternately, one synchronisation at the end"}
         for m2, _s in hs: m2.close()
+    # ... and two WHOLE batches in flight on one GPU (two handles, two streams, steps submitted alternately): the nodes + update_QP launch of one batch runs on the SIMDs
+    # the solve launch of the other leaves idle (its tail) and vice versa.  Twice the instances per GPU -- not the benchmark's configuration: reported beside it.
+    two_batches = None
+    if rank == 0 and world == 1 and not args.no_warm and B >= 2048:
+        hs = []
+        for k in range(2):
+            m2 = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision=args.precision)
+            st2 = torch.cuda.Stream(device=dev)
+            m2.set_stream(st2.cuda_stream)
+            s2, c2, t2, o2 = pkg.synthetic.config2_inputs(traj, B, seed=777 + k, traj_mode=True)
+            m2.set_inputs(s2, c2, t2, time_offset=o2)
+            hs.append((m2, st2))
+        for _ in range(2):
+            for m2, _s in hs: m2.reset(); m2.step_dev()
+        torch.cuda.synchronize(); t_ = time.perf_counter()
+        for _ in range(args.steps):
+            for m2, _s in hs: m2.reset(); m2.step_dev()
+        torch.cuda.synchronize(); t_ = time.perf_counter() - t_
+        ok2 = sum(int(pkg.is_solved(m2.solve_info()[0]).sum()) for m2, _s in hs)
+        two_batches = {"value": 2 * B * args.steps / t_, "unit": "solves/s", "ms_per_pair_of_steps": 1e3 * t_ / args.steps, "solved": f"{ok2}/{2 * B}",
+                       "config": f"two independent batches of {B} cold instances on two handles and two HIP streams, steps submitted alternately, one synchronisation at the end "
+                                 f"({2 * B} instances in flight per GPU: not the benchmark's configuration)"}
+        for m2, _s in hs: m2.close()
     # the gathered controls hold every rank's shard: this rank's block equals its own output
     gather_ok = True if world == 1 else bool(torch.equal(gathered[rank * B:(rank + 1) * B], u_out) and torch.isfinite(gathered).all().item())
 
@@ -625,6 +648,8 @@ def main():
             line["interior_point_only"] = ipm_only
         if two_streams is not None:
             line["two_half_batches_on_two_streams"] = two_streams
+        if two_batches is not None:
+            line["two_batches_on_two_streams"] = two_batches
             line["fused_step"] = fused_line
         if per_phase_line is not None:
             line["launch_per_phase"] = per_phase_line
