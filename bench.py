@@ -101,6 +101,122 @@ def hist(a):
     return {str(int(k)): int(n) for k, n in zip(v, c)}
 
 
+def host_cpu_model():
+    """Model name of the host CPU (the cores the `cpu_baseline` ran on)."""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return None
+
+
+def oracle_build_flags():
+    """Compiler and flags the CPU baseline (oracle/liboracle.so) was built with: read from oracle/Makefile, the recipe build() runs."""
+    try:
+        txt = open(os.path.join(ROOT, "oracle", "Makefile")).read()
+        cxx = [ln.split("?=", 1)[1].strip() for ln in txt.splitlines() if ln.startswith("CXX ?=")]
+        fl = [ln.split("?=", 1)[1].strip() for ln in txt.splitlines() if ln.startswith("CXXFLAGS ?=")]
+        return (cxx[0] if cxx else "g++") + " " + (fl[0] if fl else "")
+    except Exception:
+        return None
+
+
+def pg_environment():
+    """PG_* / PIGEON_* variables set in this process (diagnostic switches of a -DPG_DIAG build, library overrides): a run with any of them is not the shipped configuration."""
+    return sorted(f"{k}={v}" for k, v in os.environ.items() if k.startswith("PG_") or k.startswith("PIGEON_"))
+
+
+def _r(x, sig=5):
+    """Round floats to `sig` significant digits (the compact line); everything else unchanged."""
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{sig}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+COMPACT_LIMIT = 4096
+
+
+def compact_line(full):
+    """The LAST stdout line of bench.py: the contract keys only, strict JSON, <= 4 KB (the driver keeps an 8 KB tail of stdout: round 4's 20 KB line came back `parsed: null`).
+    `full` is the whole record (written to bench_full.json).  Pure function of `full`: tests/test_abi_and_host.py runs it on canned records."""
+    g = full.get
+    rf = full.get("roofline") or {}
+    roof = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "avg_launch_ms") if k in rf}
+    if rf.get("kernels"):
+        roof["kernels"] = rf["kernels"]
+    if rf.get("hji_lookup"):
+        roof["hji_lookup"] = rf["hji_lookup"]
+    cb = full.get("cpu_baseline")
+    cpu = None
+    if cb:
+        cpu = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "value_1thread", "cpu_model", "flags") if k in cb}
+        cpu["sample"] = str(cb.get("sample", ""))[:160]
+        acc = cb.get("accuracy") or {}
+        if acc:
+            cpu["gpu_vs_oracle_max_abs_applied_control_error"] = acc.get("max_abs_applied_control_error")
+            cpu["identical_active_set_lists"] = acc.get("identical_active_set_lists")
+    cfg = full.get("config") or {}
+    line = {"metric": g("metric"), "value": g("value"), "unit": g("unit"), "n_gpus": g("n_gpus"), "steps": g("steps"), "warmup": g("warmup"), "ms_per_step": g("ms_per_step"),
+            "higher_is_better": True, "scaling": g("scaling"), "vs_baseline": g("vs_baseline"), "dtype": g("dtype"), "data": g("data"),
+            "config": {k: (str(cfg[k])[:200] if isinstance(cfg[k], str) else cfg[k]) for k in ("workload", "batch_per_gpu", "parallelism") if k in cfg},
+            "solved": g("solved"), "roofline": roof}
+    if cpu is not None:
+        line["cpu_baseline"] = cpu
+    for k in ("phase_ms_short", "pipeline_fallbacks", "env", "kernel_source_sha16", "ranks", "collective", "per_rank_ms_per_step", "gather_ok", "secondary"):
+        if full.get(k) is not None:
+            line[k] = full[k]
+    line["full_record"] = "bench_full.json"
+    line = _r(line)
+    txt = json.dumps(line, allow_nan=False)
+    # never past the limit: drop the optional keys in order of least importance (the contract keys always fit)
+    for k in ("secondary", "phase_ms_short", "kernel_source_sha16", "env"):
+        if len(txt) <= COMPACT_LIMIT:
+            break
+        line.pop(k, None)
+        txt = json.dumps(line, allow_nan=False)
+    if len(txt) > COMPACT_LIMIT and "kernels" in line["roofline"]:
+        line["roofline"].pop("kernels"); txt = json.dumps(line, allow_nan=False)
+    return txt
+
+
+def _json_safe(x):
+    """NaN / Inf -> null (strict JSON), numpy scalars -> Python."""
+    if isinstance(x, dict):
+        return {str(k): _json_safe(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_json_safe(v) for v in x]
+    if isinstance(x, (np.floating, float)):
+        x = float(x)
+        return x if x == x and abs(x) != float("inf") else None
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    if isinstance(x, (np.bool_,)):
+        return bool(x)
+    return x
+
+
+def emit(full):
+    """Write the whole record to bench_full.json (+ gpurun_out/ when that scratch directory exists, so that a gpurun call brings it home) and print the compact line LAST on stdout."""
+    full = _json_safe(full)
+    blob = json.dumps(full, allow_nan=False)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_full.json"), "w") as f:
+                    f.write(blob + "\n")
+        except OSError:
+            pass
+    print(compact_line(full), flush=True)
+
+
 def cpu_baseline(pkg, traj, mpc, state, control, t0, toff, precision, local):
     """The reference ALGORITHM (OSQP-form ADMM with sparse LDL', default settings) on the host cores: oracle 'port'.
     Only this leg may touch oracle/: as the timed CPU baseline, and as the CHECKER of the GPU numbers (accuracy sample, config 1)."""
@@ -115,7 +231,7 @@ def cpu_baseline(pkg, traj, mpc, state, control, t0, toff, precision, local):
     out = {"value": nall / secs, "unit": "solves/s", "cores": cores, "kind": "port",
            "sample": f"{nall} cold instances of the same workload on {cores} host threads (OSQP-port ADMM, eps 1e-3, mean {float(np.mean(it)):.0f} iterations); "
                      f"1 thread: {n1 / secs1:.1f} solves/s on {n1} instances",
-           "value_1thread": n1 / secs1, "osqp_iters_hist": hist(it),
+           "value_1thread": n1 / secs1, "cpu_model": host_cpu_model(), "flags": oracle_build_flags(), "osqp_iters_hist": hist(it),
            "note": "Julia reference not run (no Julia toolchain; third-party sources absent): C++ restatement of the same algorithm"}
 
     # ---- checker: measured accuracy of the GPU batch against the exact optimum of the same QP data (sample of the headline batch) ----
@@ -259,24 +375,44 @@ def main():
     dev = torch.device("cuda", local)
     d_state = torch.from_numpy(state.astype(npdt)).to(dev); d_control = torch.from_numpy(control.astype(npdt)).to(dev)
     d_t0 = torch.from_numpy(t0).to(dev); d_toff = torch.from_numpy(toff).to(dev)            # absolute time is double in both builds
-    u_out = torch.zeros(B, 3, dtype=tdt, device=dev)
-    gathered = torch.zeros(world * B, 3, dtype=tdt, device=dev) if world > 1 else None
-    mpc.set_stream(torch.cuda.current_stream().cuda_stream)
+    # controls of a step and their gather are DOUBLE-BUFFERED (N > 1): the all_gather of step i runs on a stream of its own under the kernels of step i + 1 (the
+    # collective moves 96 KB per rank over xGMI: latency, which the next step hides); a buffer is reused only after the gather that read it has finished
+    u_bufs = [torch.zeros(B, 3, dtype=tdt, device=dev) for _ in range(2 if world > 1 else 1)]
+    g_bufs = [torch.zeros(world * B, 3, dtype=tdt, device=dev) for _ in range(2)] if world > 1 else None
+    u_out = u_bufs[0]; gathered = g_bufs[0] if world > 1 else None
+    main_stream = torch.cuda.current_stream()
+    comm_stream = torch.cuda.Stream(device=dev) if (world > 1 and args.backend == "nccl") else None
+    ev_done = [torch.cuda.Event() for _ in range(2)]; ev_free = [torch.cuda.Event() for _ in range(2)]; used = [False, False]
+    step_no = [0]
+    mpc.set_stream(main_stream.cuda_stream)
     mpc.set_inputs_dev(B, d_state.data_ptr(), d_control.data_ptr(), d_t0.data_ptr(), None, d_toff.data_ptr())
 
     def one_step(cold=True):
+        nonlocal u_out, gathered
+        k = step_no[0] & 1 if world > 1 else 0
+        step_no[0] += 1
+        u_out = u_bufs[k]
         if cold:
             mpc.reset()                                   # solved = false for every instance (hipMemsetAsync on the same stream)
+        if comm_stream is not None and used[k]:
+            main_stream.wait_event(ev_free[k])            # the gather of step i - 2 has read this buffer
         mpc.step_dev(u_out.data_ptr())
         if world > 1:
+            gathered = g_bufs[k]
             if args.backend == "nccl":
-                dist.all_gather_into_tensor(gathered, u_out)  # RCCL over xGMI: the only collective on the path
+                ev_done[k].record(main_stream)
+                comm_stream.wait_event(ev_done[k])
+                with torch.cuda.stream(comm_stream):
+                    dist.all_gather_into_tensor(gathered, u_out)  # RCCL over xGMI: the only collective on the path
+                    ev_free[k].record(comm_stream)
+                used[k] = True
             else:
                 g_host = torch.empty(world * B, 3, dtype=tdt)
                 dist.all_gather_into_tensor(g_host, u_out.cpu())
                 gathered.copy_(g_host)
 
     def sync():
+        torch.cuda.synchronize()                          # (every stream of the device: the last gathers on the communication stream included)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -399,6 +535,28 @@ def main():
                        "config": f"two independent batches of {B} cold instances on two handles and two HIP streams, steps submitted alternately, one synchronisation at the end "
                                  f"({2 * B} instances in flight per GPU: not the benchmark's configuration)"}
         for m2, _s in hs: m2.close()
+    # SURVEY 8(d), config 2 "repeat for vail" and "a second run with time_offset = NaN (path mode; coupled_lat_long.jl:115)": the same cold step on the reference's
+    # other long test path and on the benchmark path with every instance in path-tracking mode -- two short secondary numbers
+    variants = None
+    if rank == 0 and world == 1 and not args.no_warm:
+        variants = {}
+        for key, path, tmode in (("vail", "vail", True), ("path_mode", "skidpadoval", False)):
+            tj = pkg.load_path_fixture(path)
+            mv = pkg.BatchedTrajectoryTrackingMPC(tj, B, device=local, precision=args.precision)
+            mv.set_stream(torch.cuda.current_stream().cuda_stream)
+            sv, cv, tv, ov = pkg.synthetic.config2_inputs(tj, B, seed=12345, traj_mode=tmode)
+            mv.set_inputs(sv, cv, tv, time_offset=ov)
+            for _ in range(3):
+                mv.reset(); mv.step_dev()
+            torch.cuda.synchronize(); t_ = time.perf_counter()
+            for _ in range(args.steps):
+                mv.reset(); mv.step_dev()
+            torch.cuda.synchronize(); t_ = time.perf_counter() - t_
+            stv, itv, _, _ = mv.solve_info(); pv = mv.polish_info()
+            variants[key] = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": [float(v) for v in mv.phase_ms()],
+                             "solved": f"{int(pkg.is_solved(stv).sum())}/{B}", "interior_point_instances": int((itv > 0).sum()), "polish_rounds_hist": hist(pv),
+                             "workload": f"configs[1] on {path}, " + ("trajectory mode (time_offset = 0)" if tmode else "PATH mode (time_offset = NaN: V, A from the speed profile at s; coupled_lat_long.jl:115)")}
+            mv.close()
     # the gathered controls hold every rank's shard: this rank's block equals its own output
     gather_ok = True if world == 1 else bool(torch.equal(gathered[rank * B:(rank + 1) * B], u_out) and torch.isfinite(gathered).all().item())
 
@@ -492,14 +650,20 @@ def main():
                 look()
             torch.cuda.synchronize()
             reps = 20
-            ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)     # the handle launches on torch's current stream (set_stream above)
-            ev0.record()
-            for _ in range(reps):
-                look()
-            ev1.record(); torch.cuda.synchronize()
-            ms = ev0.elapsed_time(ev1) / reps
+            # ONE event pair per launch (the handle launches on torch's current stream, set_stream above): the average LAUNCH DURATION, the quantity rocprofv3 --stats
+            # reports for the kernel.  (Round 4 timed 20 back-to-back launches with one pair: the tail of a launch overlaps the ramp of the next and the figure came
+            # out above every single launch of the committed trace.)  The back-to-back rate is kept beside it.
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for e0, e1 in evs:
+                e0.record(); look(); e1.record()
+            torch.cuda.synchronize()
+            per = np.array([e0.elapsed_time(e1) for e0, e1 in evs])
+            b2b = evs[0][0].elapsed_time(evs[-1][1]) / reps
+            ms = float(per.mean())
             gbs = nq * 4096 / (ms * 1e-3) / 1e9
-            r = {"lookups_per_s": nq / (ms * 1e-3), "avg_launch_ms": ms, "algorithmic_bytes_per_lookup": 4096, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            r = {"lookups_per_s": nq / (ms * 1e-3), "avg_launch_ms": ms, "min_launch_ms": float(per.min()), "max_launch_ms": float(per.max()), "back_to_back_ms_per_launch": float(b2b),
+                 "timing": f"HIP events around each of {reps} launches (mean); back_to_back = first start to last stop / {reps}",
+                 "algorithmic_bytes_per_lookup": 4096, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": gbs / HBM_PEAK_GBS, "bound": "hbm", "grid": label, "lookups": nq, "finite": bool(torch.isfinite(out8).all().item()),
                  # pg_set_hji_grid: host re-pack + upload + cell-record build, once per grid (wall clock of the call), and the device memory the installed table holds
                  "setup_s": setup_s, "device_table_bytes": int(table_bytes)}
@@ -509,18 +673,20 @@ def main():
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]["pg::k_hji_lookup<3>"]
             hji["traffic"] = tr["hbm_bytes_per_launch"]; hji["traffic_source"] = tr["source"]
+            for k in ("avg_launch_ns_rocprof", "min_launch_ns_rocprof", "max_launch_ns_rocprof"):
+                hji[k] = tr.get(k)
         except Exception:
             hji["traffic"] = None
-        # the two larger device layouts (PG_HJI_CELL_DIMS: 1 KiB records, 6 GB table; 4 KiB records, the default of rounds 1-3, 19 GB), same grid -- far beyond the 256 MiB
+        # the two larger device layouts (option "hji_cell_dims": 1 KiB records, 6 GB table; 4 KiB records, the default of rounds 1-3, 19 GB), same grid -- far beyond the 256 MiB
         # Infinity Cache in every layout
         fb = {}
         for cd, lbl in ((5, "1 KiB cell records (4 per lookup)"), (7, "4 KiB cell records (1 per lookup)")):
-            os.environ["PG_HJI_CELL_DIMS"] = str(cd)
+            mpc.set_option("hji_cell_dims", cd)
             try:
                 r = lookup_rate(*pkg.synthetic.hji_grid_large(), lbl)
-                fb[lbl] = {k: r[k] for k in ("lookups_per_s", "avg_launch_ms", "achieved", "frac", "setup_s", "device_table_bytes")}
+                fb[lbl] = {k: r[k] for k in ("lookups_per_s", "avg_launch_ms", "min_launch_ms", "max_launch_ms", "achieved", "frac", "setup_s", "device_table_bytes")}
             finally:
-                os.environ.pop("PG_HJI_CELL_DIMS", None)
+                mpc.set_option("hji_cell_dims", 3)
         hji["other_layouts"] = fb
         # SURVEY 8(d) secondary number: a FOUR-dimensional value grid (BASELINE.json says "4D": relative position, heading, other-car speed) run through the
         # same 7-D kernel with the three remaining dimensions collapsed to two knots each -- every lookup still gathers its 4096 B of corner data
@@ -624,6 +790,25 @@ def main():
         valu = {"bound": "valu-" + args.precision, "kernel": "k_solve", "algorithmic_flops_per_launch": fl, "flops_per_solve_mean": fl / B, "achieved": fl / (float(ph[2]) * 1e-3) / 1e12,
                 "peak": peak_tf, "unit": "TFLOP/s", "frac": fl / (float(ph[2]) * 1e-3) / 1e12 / peak_tf, "avg_launch_ms": float(ph[2]),
                 "source": "flop model of the stage-structured interior point (bench.py solve_flops, EXPERIMENTS.md 6) x live iteration / polish-round counts; time live (HIP events)"}
+        # the two kernels that make up the step (nodes + update_QP! launch, solve launch), each with what the committed counter passes say about it: the headline `roofline`
+        # names the longer one and lists BOTH (their phases are within a few per cent of each other and swap places from run to run)
+        def kernel_entry(name, match, ms, flop_obj):
+            e = {"kernel": name, "avg_launch_ms": ms, "hbm_frac": B * bytes_per_solve / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "valu_flop_frac": flop_obj["frac"]}
+            hit_ = [v for k, v in (tr or {}).get("kernels" if args.precision == "f64" else "kernels_f32", {}).items() if match in k]
+            if hit_:
+                h_ = hit_[0]
+                e["traffic"] = h_.get("hbm_bytes_per_launch"); e["valu_issue_frac"] = h_.get("valu_issue_frac"); e["avg_launch_ms_rocprof"] = (h_.get("avg_launch_ns_rocprof") or 0) * 1e-6 or None
+                m_ = h_.get("mfma")
+                if isinstance(m_, dict):
+                    e["mfma_busy_frac"] = m_.get("busy_frac_of_simd_time"); e["mfma_flop_frac"] = m_.get("frac_of_peak")
+            return e
+        lin_match = ("k_nodes_linearize" if pipelined else "k_linearize")
+        kernels = [kernel_entry("k_solve", "k_solve<false, false, false, false>", float(ph[2]), valu), kernel_entry(lin_match, lin_match, lin_ms, valu_lin)]
+        kernels.sort(key=lambda e: -e["avg_launch_ms"])
+        try:
+            fallbacks = int(mpc.pipeline_fallbacks())
+        except Exception:
+            fallbacks = None
         line = {
             "metric": "MPC QP solves/sec (N=30 coupled, X1 model)", "kernel_source_sha16": kernel_source_sha16(), "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -635,9 +820,12 @@ def main():
                                  "Mehrotra interior point to mu <= " + ("3e-6" if args.precision == "f64" else "1e-4") + ", then active-set polish (verified KKT point)",
                        "accuracy": "measured in this run: cpu_baseline.accuracy (sample of 256); every one of the 4096 instances <= 1e-6 is asserted by tests/test_gpu_full_size.py (measured max 5e-11)"},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale, "avg_launch_ms": dom_ms, **dom_extra, "mfma": mfma_util(tr, dom, pipelined), "valu": valu, "valu_linearize": valu_lin,
-                         "note": f"algorithmic HBM bytes are {bytes_per_solve} B/solve (SURVEY 8d): the step is VALU/LDS/latency bound by construction, not HBM bound; see roofline.valu and hji_lookup"},
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale, "avg_launch_ms": dom_ms, **dom_extra, "mfma": mfma_util(tr, 2, pipelined), "valu": valu, "valu_linearize": valu_lin,
+                         "kernels": kernels,
+                         "note": f"algorithmic HBM bytes are {bytes_per_solve} B/solve (SURVEY 8d): the step is VALU/LDS/latency bound by construction, not HBM bound; see roofline.kernels (valu_flop_frac, valu_issue_frac, mfma_busy_frac) and roofline.hji_lookup (the bandwidth-bound kernel of the path)"},
             "phase_ms": {n: float(v) for n, v in zip(names, ph)},
+            "phase_ms_short": {"nodes+update_qp" if pipelined else "nodes": float(ph[0]), "update_qp": float(ph[1]), "solve": float(ph[2])},
+            "pipeline_fallbacks": fallbacks, "env": pg_environment(),
             "warm_value": None if args.no_warm else world * B * args.steps / warm_elapsed,
             "solved": f"{ok}/{B}", "gather_ok": gather_ok, "ranks": world if world == 1 else dist.get_world_size(), "collective": None if world == 1 else ("rccl" if args.backend == "nccl" else "gloo"),
             "per_rank_ms_per_step": rank_ms, "ipm_iters_mean": float(np.mean(it)), "ipm_iters_max": int(np.max(it)), "ipm_iters_hist": hist(it),
@@ -650,20 +838,36 @@ def main():
             line["two_half_batches_on_two_streams"] = two_streams
         if two_batches is not None:
             line["two_batches_on_two_streams"] = two_batches
+        if fused_line is not None:
             line["fused_step"] = fused_line
         if per_phase_line is not None:
             line["launch_per_phase"] = per_phase_line
         if roll is not None:
             line["closed_loop_rollout"] = roll
+        if variants is not None:
+            line["config2_variants"] = variants
         if hji is not None:
             line["hji_lookup"] = hji
+            line["roofline"]["hji_lookup"] = {k: hji.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "min_launch_ms", "max_launch_ms", "traffic")}
+            line["roofline"]["hji_lookup"]["algorithmic_bytes_per_launch"] = hji["lookups"] * 4096
         if dec is not None:
             line["decoupled_n50"] = dec
         if f32 is not None:
             line["fp32"] = f32
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, traj, mpc, state, control, t0, toff, args.precision, local)
-        print(json.dumps(line), flush=True)
+        # headline numbers of the other BASELINE configs, for the compact line (everything else about them: bench_full.json)
+        sec = {"warm_solves_per_s": line["warm_value"]}
+        if f32 is not None:
+            sec["config3_f32_hji_solves_per_s"] = f32.get("value"); sec["f32_cold_solves_per_s"] = f32["without_hji"]["value"]
+        if dec is not None:
+            sec["config5_n50_walls_solves_per_s"] = dec.get("value"); sec["config5_n50_solves_per_s"] = dec["without_walls"]["value"]; sec["config5_verified"] = dec.get("verified_by_polish")
+        if roll is not None:
+            sec["closed_loop_solves_per_s"] = roll["warm_start_of_active_set"]["value"]
+        if variants is not None:
+            sec["config2_vail_solves_per_s"] = variants["vail"]["value"]; sec["config2_path_mode_solves_per_s"] = variants["path_mode"]["value"]
+        line["secondary"] = {k: v for k, v in sec.items() if v is not None}
+        emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

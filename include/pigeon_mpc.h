@@ -193,7 +193,7 @@ int pg_get_next_control_hji(pg_handle* h, int32_t use_hji_policy, double* u_out,
 int pg_get_next_control_hji_dev(pg_handle* h, int32_t use_hji_policy, pg_real_dev* u_out_dev, int32_t* source_dev);
 
 /* all five for every instance: host buffers in, host buffers out (status/iters may be NULL).
- * A batch that fills the handle (B == batch_capacity) travels in one copy per direction.  Opt-in (PG_GRAPH=1 at pg_create): when such a batch has at most 256
+ * A batch that fills the handle (B == batch_capacity) travels in one copy per direction.  Opt-in (pg_set_option "graph" = 1): when such a batch has at most 256
  * instances and every one of them is warm, the whole step -- copy in, the kernels of a warm step, copy out -- is captured once into a hipGraph and replayed
  * (re-captured whenever something its launches depend on has changed; results identical to the ordinary launches; pg_get_phase_ms has no timing for replayed
  * steps; with no stream installed the graph runs on a blocking stream of its own, ordered against the null stream).  Measured: 2-7 % per step, against ~7 ms for
@@ -216,7 +216,7 @@ int pg_get_state(pg_handle* h, double* state, double* control, double* t0);
 int pg_set_stream(pg_handle* h, void* hip_stream);
 /* Fused step: pg_step / pg_step_dev / pg_simulate_dev can run update_QP! and solve! of the coupled formulation (N <= 32) in ONE kernel -- the wavefront that
  * solves an instance linearises it first (same device functions: results are bit-identical either way; the QP data are still written and pg_get_qp reads them).
- * mode 0 = never (default; PG_FUSE=0/1/2 at pg_create overrides), 1 = always, 2 = for batches of >= 1024 instances in which every instance is warm (closed loop).
+ * mode 0 = never (default), 1 = always, 2 = for batches of >= 1024 instances in which every instance is warm (closed loop).
  * Measured on MI355X: +7 % on the cold benchmark batch (skidpadoval), -5..-8 % on the other paths and in closed loop (EXPERIMENTS.md 4.1) -- it pays only where a few
  * slow instances dominate the solve kernel.  The four compute calls invoked one by one are never fused. */
 int pg_set_fusion(pg_handle* h, int32_t mode);
@@ -225,7 +225,7 @@ int pg_set_fusion(pg_handle* h, int32_t mode);
  * interval t starts as soon as nodes t, t + 1 of its instances are seeded (the cold seeding is a serial recurrence over the nodes: 0.18 ms of latency on 6 % of the
  * chip that the linearisation of the early intervals now runs under).  With a safety row installed its (M, b) are computed before that launch.  Same device
  * functions on the same arguments: nodes and QP data are bit-identical in fp64; in the fp32 library the nodes are, the QP data agree to fp32 rounding.
- * mode 1 = on where it applies (default; PG_PIPELINE=0/1 at pg_create overrides), 0 = never.  The compute calls invoked one by one are never pipelined. */
+ * mode 1 = on where it applies (default), 0 = never.  The compute calls invoked one by one are never pipelined. */
 int pg_set_pipeline(pg_handle* h, int32_t mode);
 /* The wavefronts of that launch that linearise an interval WAIT for the wavefronts that seed its nodes.  The wait is bounded (20 ms of wall-clock time); a wavefront
  * that gives up -- the seeding wavefronts not resident before it: a dispatch order the launch does not control, a debugger, a time-sliced or counter-serialised run --
@@ -233,6 +233,33 @@ int pg_set_pipeline(pg_handle* h, int32_t mode);
  * late, not wrong, and nothing is reported to the caller but this cumulative count of wavefronts that gave up (synchronises the handle's stream). */
 int pg_get_pipeline_fallbacks(pg_handle* h, int64_t* count);
 int pg_synchronize(pg_handle* h);
+
+/* Build-defined options of a handle, by name (no counterpart in the reference; every one has a default under which the library behaves as documented above).  The library
+ * reads NOTHING from the process environment: what a handle does depends on its pg_config and on the options set here.  Unknown name, read-only name or a value out of
+ * range: PG_ERR_INVALID.  Integer options take integral values.  Options take effect at the next launch (hji_cell_dims: at the next pg_set_hji_grid).
+ *   coupled solve kernel (k_solve):
+ *     "solve_split" 0/1 (1)      rounds-only kernel + list-mode full kernel instead of one kernel (never with a safety row installed)
+ *     "clip_guess" 0/1 (1)       first roll-out of a cold instance clips the steering rate; the clipped transitions are its first working set
+ *     "ck_riccati" 0/1 (1)       the matrix recursion of a later round restarts at a checkpoint behind the rows that changed (fp64)
+ *     "warm_trivial_cold" 0/1 (1)  a warm instance whose previous working set was empty starts like a cold one
+ *     "hji_seed" 0..4 (0), "hji_rounds" 0..64 (0)   seeded working sets for instances whose safety row is violated at the current control (experiment, off)
+ *   launch shape:
+ *     "pipe_min" (2304), "pipe_max" (16384, at most)  batch sizes the pipelined nodes + update_QP launch serves (pg_set_pipeline)
+ *     "lin_lanes" 1/2 (1)        lanes per (instance, interval) of the large-batch linearisation
+ *     "graph" 0/1 (0)            pg_step of a small warm batch as one hipGraph launch (see pg_step)
+ *     "hji_cell_dims" 3/5/7 (3)  corners per cell record of the HJI table = 2^value (256 B / 1 KiB / 4 KiB records)
+ *   lateral solve kernel (decoupled formulation):
+ *     "lateral_solver" 0/1/2 (0) 0 = k_solve_lat beyond 20 intervals or with the polish off, else the embedding in k_solve; 1 = k_solve_lat; 2 = the embedding
+ *     "lat_workspace" 0/1        k_solve_lat keeps its row state in the per-wavefront workspace at every horizon (default: beyond 32 intervals, or with walls beyond 16)
+ *     "lat_split" 0/1 (1)        a step in which every instance is warm runs as two launches (warm attempts, then the cold solves of what they left)
+ *     "lat_rho_scale" (1e3 in fp64, 1 in fp32)  penalty of held rows = polish_rho x this;   "lat_mu0_cost" (10), "lat_far_cost" (3e4), "lat_polish2" 0/1 (1),
+ *     "lat_polish_rounds" (3), "lat_settle" 0..2 (0), "lat_warm_rounds" (2), "lat_wipm" 0/1 (0), "lat_wmu" (1e-2), "lat_wtau" (1e-4)   see pg_solve_lat.hip
+ *   read-only (pg_get_option): "stat_pipelined_launches", "stat_split_solve_launches", "stat_single_solve_launches", "stat_lat_two_launch_solves" -- how many launches of
+ *     this handle took the path named (tests assert that the path they mean to cover is the one that ran); "lateral_solver_in_use" (1 = k_solve_lat, 2 = embedding).
+ * The diagnostic build (libpigeon_hip_diag.so, -DPG_DIAG; never shipped) adds "diag_pipe_fault" (fault injection for the pipelined launch), "diag_instance",
+ * "diag_lin_groups", "diag_timeline". */
+int pg_set_option(pg_handle* h, const char* name, double value);
+int pg_get_option(pg_handle* h, const char* name, double* value);
 
 /* ---- read-backs for parity tests and logging (host pointers, any may be NULL) ---------------------------------- */
 /* ts [B][N+1], dt [B][N], prev_ts [B][N+1] */

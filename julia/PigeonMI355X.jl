@@ -223,6 +223,18 @@ function set_pipeline!(mpc::BatchedTrajectoryTrackingMPC, mode::Integer)
     check(mpc, ccall(sym(mpc, :pg_set_pipeline), Cint, (Ptr{Cvoid}, Int32), mpc.handle, Int32(mode)), "pg_set_pipeline")
 end
 
+"build-defined option of the handle by name (pg_set_option: solver rules, launch shape, lateral-solver tuning; the library reads nothing from ENV), e.g. set_option!(mpc, \"graph\", 1)"
+function set_option!(mpc::BatchedTrajectoryTrackingMPC, name::AbstractString, value::Real)
+    check(mpc, ccall(sym(mpc, :pg_set_option), Cint, (Ptr{Cvoid}, Cstring, Cdouble), mpc.handle, name, Float64(value)), "pg_set_option($name)")
+end
+
+"current value of an option, or a read-only launch statistic such as \"stat_pipelined_launches\" (pg_get_option)"
+function get_option(mpc::BatchedTrajectoryTrackingMPC, name::AbstractString)
+    v = Ref{Cdouble}(0.0)
+    check(mpc, ccall(sym(mpc, :pg_get_option), Cint, (Ptr{Cvoid}, Cstring, Ptr{Cdouble}), mpc.handle, name, v), "pg_get_option($name)")
+    v[]
+end
+
 "number of waiting wavefronts of the pipelined launch that gave up so far (each such step was redone launch per phase: late, not wrong; pg_get_pipeline_fallbacks)"
 function pipeline_fallbacks(mpc::BatchedTrajectoryTrackingMPC)
     n = Ref{Int64}(0)

@@ -5,6 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpigeon_hip.so")             # fp64 (the reference's arithmetic type)
 LIB_PATH_F32 = os.path.join(_HERE, "csrc", "libpigeon_hip_f32.so")     # fp32 build of the same sources (BASELINE configs 3/4)
+LIB_PATH_DIAG = os.path.join(_HERE, "csrc", "libpigeon_hip_diag.so")   # fp64, -DPG_DIAG: fault injection and traces for tests / tools (precision "f64-diag"); never the product
 _libs = {}
 
 
@@ -35,18 +36,20 @@ class pg_config(C.Structure):
 SYMBOLS = ["pg_precision_bits", "pg_abi_layout", "pg_default_config", "pg_default_config_decoupled", "pg_create", "pg_destroy", "pg_last_error", "pg_get_config", "pg_get_u_normalization", "pg_set_trajectory", "pg_set_trajectories", "pg_set_trajectory_index",
            "pg_set_hji_grid", "pg_clear_hji_grid", "pg_reset", "pg_set_inputs", "pg_set_inputs_dev", "pg_compute_time_steps",
            "pg_compute_linearization_nodes", "pg_update_qp", "pg_solve", "pg_get_next_control", "pg_get_next_control_dev", "pg_get_next_control_hji", "pg_get_next_control_hji_dev", "pg_step", "pg_step_dev", "pg_simulate_dev", "pg_get_state",
-           "pg_set_stream", "pg_set_fusion", "pg_set_pipeline", "pg_get_pipeline_fallbacks", "pg_synchronize", "pg_get_time_steps", "pg_get_nodes", "pg_get_path_coordinates", "pg_qp_len", "pg_get_qp", "pg_set_qp", "pg_get_solution",
+           "pg_set_stream", "pg_set_fusion", "pg_set_pipeline", "pg_set_option", "pg_get_option", "pg_get_pipeline_fallbacks", "pg_synchronize", "pg_get_time_steps", "pg_get_nodes", "pg_get_path_coordinates", "pg_qp_len", "pg_get_qp", "pg_set_qp", "pg_get_solution",
            "pg_get_solve_info", "pg_get_polish_info", "pg_get_multipliers", "pg_get_phase_ms", "pg_hji_lookup", "pg_hji_lookup_dev", "pg_hji_lookup8_dev", "pg_hji_grid_dims", "pg_hji_slice", "pg_get_hji_constraint", "pg_get_walls"]
 
 
 def load_library(precision="f64"):
     """Loads the HIP library of the requested arithmetic type.  PyTorch-ROCm is imported first so that both share ONE HIP runtime in this process."""
-    assert precision in ("f64", "f32")
+    assert precision in ("f64", "f32", "f64-diag")
     if precision in _libs:
         return _libs[precision]
-    path = LIB_PATH if precision == "f64" else LIB_PATH_F32
+    path = {"f64": LIB_PATH, "f32": LIB_PATH_F32, "f64-diag": LIB_PATH_DIAG}[precision]
     # A/B runs of an experimental build select it here (PIGEON_HIP_LIB / PIGEON_HIP_LIB_F32 = path of the .so) instead of copying it over the shipped library
-    path = os.environ.get("PIGEON_HIP_LIB" if precision == "f64" else "PIGEON_HIP_LIB_F32", path)
+    # (read by this Python mirror only: the C library itself reads nothing from the environment)
+    if precision != "f64-diag":
+        path = os.environ.get("PIGEON_HIP_LIB" if precision == "f64" else "PIGEON_HIP_LIB_F32", path)
     if not os.path.exists(path):
         raise PigeonError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)")
     try:
@@ -58,7 +61,7 @@ def load_library(precision="f64"):
     lib.pg_last_error.argtypes = [C.c_void_p]
     for s in SYMBOLS:
         getattr(lib, s)
-    assert lib.pg_precision_bits() == (64 if precision == "f64" else 32)
+    assert lib.pg_precision_bits() == (32 if precision == "f32" else 64)
     check_layout(lib)
     _libs[precision] = lib
     return lib

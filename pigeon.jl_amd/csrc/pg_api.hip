@@ -19,7 +19,14 @@ struct pg_handle {
     int warm_B = 0;                  // instances [0, warm_B) are known to carry a previous solution (solved = true): set by pg_solve, cleared by pg_reset
     hipStream_t stream = nullptr;
     int pipeline = 1;                                         // pg_set_pipeline: 1 = nodes + update_QP of a large batch with cold instances as one pipelined launch (k_nodes_linearize), 0 = never
-    bool pipe_fault = false;                                  // PG_PIPE_FAULT=1: fault injection for the pipelined launch (its nodes blocks never publish)
+    bool pipe_fault = false;                                  // -DPG_DIAG builds only (option "diag_pipe_fault"): fault injection for the pipelined launch (its nodes blocks never publish)
+    int lin_groups = 0;                                       // -DPG_DIAG builds only (option "diag_lin_groups"): force the lane arrangement of launch_linearize (1, 2, 4, 8 lanes per interval)
+    int debug_timeline = 0;                                   // -DPG_DIAG builds only (option "diag_timeline"): pg_debug_solve_cycles records the timeline of the product's kernel
+    int lateral_solver = 0;                                   // option "lateral_solver": 0 = by horizon (k_solve_lat beyond 20 intervals or with the polish off), 1 = k_solve_lat, 2 = the embedding in k_solve
+    int hji_cell_dims = 3;                                    // option "hji_cell_dims": corners per cell record of the next pg_set_hji_grid = 2^3 (256 B, default), 2^5, 2^7
+    int64_t stat_pipelined = 0, stat_split = 0, stat_single = 0, stat_lat_two = 0;      // read-only options "stat_*": launches that took the pipelined nodes + update_QP path / the split solve / the single solve kernel / the two-launch lateral solve
+    int solve_parity = 0;                                     // which of the two to-do counters the next solve launch counts into (the other one holds the previous launch's count: see launch_solve)
+    bool cnt_cleared = false;                                 // this step's projection kernel has zeroed the counter launch_solve is about to use
     bool lin_done = false;                                    // this step's launch_nodes already linearised (update_and_solve skips update_QP)
     int* d_progress = nullptr;                                // [cap / 64 + 1] nodes completed per nodes wavefront (k_nodes_linearize)
     int64_t fallback_total = 0; int fallback_seen = 0;        // pg_get_pipeline_fallbacks: 64-bit total kept on the host, last value of the device's 32-bit word
@@ -36,11 +43,10 @@ struct pg_handle {
     real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     real* d_lam = nullptr;                                      // [cap][N][16] multipliers of the last solve (warm start of the polish)
     int* d_wfail = nullptr;                                     // [cap] back-off of k_solve_lat's warm attempts
-    int pipe_min = 2304, pipe_max = 16384;                    // batch sizes the pipelined launch serves (PG_PIPE_MIN / PG_PIPE_MAX; its nodes blocks must be resident at once: <= 16384)
+    int pipe_min = 2304, pipe_max = 16384;                    // batch sizes the pipelined launch serves (options "pipe_min" / "pipe_max"; its nodes blocks must be resident at once: <= 16384)
     int lin_lpi = 1;                                          // lanes per (instance, interval) of the large-batch linearisation (k_linearize_split / k_nodes_linearize): one lane with all eight
-                                                              // directions (PG_LIN_LPI=2: the lane pair of rounds 1-3, for A/B runs; same bits in fp64, rounding-level differences in fp32)
-    int* d_todo = nullptr; int split_solve = 1, split_lat = 1; volatile int* h_todo = nullptr;      // h_todo: pinned copy of the previous launch's count (queued behind it, read -- never waited for -- by the next)
-    int* d_todo_unused = nullptr;                 // [cap + 1] instances the rounds-only k_solve leaves to the full kernel + their count; PG_SOLVE_SPLIT=0: one kernel as before
+                                                              // directions (option "lin_lanes" = 2: the lane pair of rounds 1-3, for A/B runs; same bits in fp64, rounding-level differences in fp32)
+    int* d_todo = nullptr; int split_solve = 1, split_lat = 1;      // d_todo [cap + 2]: instances the rounds-only k_solve leaves to the full kernel, then TWO counters used alternately (this launch's count / the previous launch's)
     int* d_order = nullptr; int order_B = 0;  // [cap] + 2 counters: launch order filed by the nodes kernels of the current step (likely slow instances first); order_B = batch it is valid for
     real *d_pol_u2 = nullptr, *d_pol_u = nullptr; int* d_pol_src = nullptr;   // HJI fallback policy (HJI_computation.jl:133-158)
     int *d_status = nullptr, *d_iters = nullptr, *d_polish = nullptr; uint16_t* d_active = nullptr;
@@ -49,19 +55,19 @@ struct pg_handle {
     hipEvent_t ev[4]; bool ev_ok = false; float phase_ms[3] = {0, 0, 0}; bool timing_valid = false;
     size_t solve_lds = 0; bool solve_ring = false;
     real* d_walls = nullptr;                                    // [cap][N][2] wall extension
-    char* d_lat_ws = nullptr; bool lat_mem = false;            // k_solve_lat's workspace for horizons beyond 32 intervals (PG_LAT_MEM=1: at every horizon)
+    char* d_lat_ws = nullptr; bool lat_mem = false, lat_mem_forced = false;            // k_solve_lat's workspace for horizons beyond 32 intervals (option "lat_workspace" = 1: at every horizon)
     real* d_lat = nullptr;                                      // [cap][N][LATP] packed stage records of the lateral formulation (k_qp_dec -> k_solve_lat)
     // hipGraph of a whole host-to-host warm step (pg_step of a small batch is launch-bound: one copy in, four kernels, one copy out; captured once, replayed while
     // nothing that the launches depend on has changed -- `sig` is compared field by field before every replay)
     struct StepGraph { hipGraph_t g = nullptr; hipGraphExec_t x = nullptr; hipStream_t own = nullptr; bool disabled = false; bool capturing = false;
                        DevCfg dc; HjiView hv; int B = 0, fuse = 0, pipeline = 0, has_hji = 0, traj_L = 0; hipStream_t user = nullptr; } sg;
-    int graph_mode = 0;                                       // PG_GRAPH=1 at pg_create turns it on.  OFF by default: capturing costs ~7 ms once and again whenever a launch parameter changes (a re-installed
+    int graph_mode = 0;                                       // option "graph" = 1 turns it on.  OFF by default: capturing costs ~7 ms once and again whenever a launch parameter changes (a re-installed
                                                               // path: every `path` message of the ROS loop), a jitter that a 100 Hz loop minds more than the 4-20 us per step the replay saves
     char* d_in = nullptr; char* d_out = nullptr;             // the five input arrays / (u, status, iters) as ONE allocation each: a batch that fills the handle travels in one copy per direction
     size_t in_bytes = 0, out_bytes = 0, in_dbl_off = 0;        // (layout by capacity: [state 6][control 3][other 4] real, then at in_dbl_off [t0][time_offset] double; [u 3] real, [status][iters] int)
     char* h_stage = nullptr; size_t stage_bytes = 0;            // pinned host staging of pg_set_inputs / pg_step (one stream synchronisation per call instead of one per array)
     real* d_ws4 = nullptr; bool solve_quad = false; size_t solve4_lds = 0;   // k_solve4 (four instances per wavefront)
-    bool solve_lat = false; size_t lat_lds = 0;               // lateral formulation: its own kernel k_solve_lat (PG_SOLVE_LAT=0 keeps the embedding in k_solve)
+    bool solve_lat = false; size_t lat_lds = 0;               // lateral formulation: its own kernel k_solve_lat (option "lateral_solver" = 2 keeps the embedding in k_solve)
 };
 
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return PG_ERR_HIP; } } while (0)
@@ -112,6 +118,24 @@ static void fill_dev_params(DevCfg& C, const pg_config* cfg) {
     U.V_min = (real)u.V_min; U.V_max = (real)u.V_max; U.k_V = (real)u.k_V; U.k_s = (real)u.k_s; U.deltadot_max = (real)u.deltadot_max;
     U.Q_ds = (real)u.Q_ds; U.Q_dpsi = (real)u.Q_dpsi; U.Q_e = (real)u.Q_e; U.W_beta = (real)u.W_beta; U.W_r = (real)u.W_r; U.W_HJI = (real)u.W_HJI;
     U.R_delta = (real)u.R_delta; U.R_ddelta = (real)u.R_ddelta; U.R_Fx = (real)u.R_Fx; U.R_dFx = (real)u.R_dFx; U.N_HJI = u.N_HJI;
+}
+
+// Lateral formulation: which kernel solves it, and the buffers that kernel needs.  Called by pg_create and by pg_set_option("lateral_solver" / "lat_workspace").
+static int configure_lateral(pg_handle* h, std::string* why) {
+    DevCfg& C = h->dc; const pg_config* cfg = &h->cfg; const int N = C.N; const size_t cap = (size_t)cfg->batch_capacity;
+    const bool want = h->lateral_solver == 1 || (h->lateral_solver != 2 && !(cfg->polish && N <= 20));
+    h->solve_lat = cfg->formulation == PG_DECOUPLED && want && !h->solve_quad;
+    if (!h->solve_lat) { C.lat_pack = nullptr; return PG_OK; }
+    if (!h->d_lat && hipMalloc((void**)&h->d_lat, cap * N * LATP * sizeof(real)) != hipSuccess) { *why = "hipMalloc failed for the packed lateral stage records"; return PG_ERR_HIP; }
+    C.lat_pack = h->d_lat;
+    // (round 4: with the wall rows the two-slot register variant spills 720 B per lane since the warm start was added -- 1.57 ms at N = 30 against 1.36 ms through the
+    // workspace; without them the registers still win, 0.94 against 1.01 ms)
+    h->lat_mem = N > 32 || (cfg->walls && N > 16) || h->lat_mem_forced;
+    if (h->lat_mem) {
+        if (!h->d_lat_ws && hipMalloc((void**)&h->d_lat_ws, lat_ws_bytes(cap)) != hipSuccess) { *why = "hipMalloc failed for k_solve_lat's workspace"; return PG_ERR_HIP; }
+        C.lat_ws = h->d_lat_ws;
+    } else C.lat_ws = nullptr;
+    return PG_OK;
 }
 
 extern "C" {
@@ -168,7 +192,6 @@ static void free_all(pg_handle* h) {
                     h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_wfail, h->d_todo, h->d_order, h->d_naux, h->d_progress, h->d_lat, h->d_lat_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
-    if (h->h_todo) (void)hipHostFree((void*)h->h_todo);
     if (h->sg.x) (void)hipGraphExecDestroy(h->sg.x);
     if (h->sg.g) (void)hipGraphDestroy(h->sg.g);
     if (h->sg.own) (void)hipStreamDestroy(h->sg.own);
@@ -200,7 +223,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     C.un0 = (real)cfg->vehicle.delta_max; C.un1 = (real)fmax(-cfg->vehicle.Fx_min, cfg->vehicle.Fx_max);      // coupled_lat_long.jl:199
     C.fxmin_n = (real)(cfg->vehicle.Fx_min / fmax(-cfg->vehicle.Fx_min, cfg->vehicle.Fx_max));
     C.formulation = cfg->formulation; C.ux_dummy = (real)(0.5 * (cfg->control.V_min + cfg->control.V_max));
-    C.dbg_instance = -1; if (const char* e = getenv("PG_DEBUG_INSTANCE")) C.dbg_instance = atoi(e);
+    C.dbg_instance = -1;                              // (-DPG_DIAG builds: option "diag_instance")
     if (cfg->formulation == PG_DECOUPLED) {          // no u normalisation in the lateral QP (decoupled_lat_long.jl:134-226); inert slots pinned
         C.un0 = 1.0; C.un1 = 1.0; C.fxmin_n = -1.0;
         C.cp.Q_ds = 0.0; C.cp.R_Fx = 0.0; C.cp.R_dFx = 1.0; C.cp.N_HJI = 0; C.cp.W_HJI = 0.0;
@@ -218,44 +241,27 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_sep, cap * 4, real); ALLOC(h->d_nodes, cap * NN * 10, real); ALLOC(h->d_qp, cap * C.qp_len, real);
     ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
     ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_mu, cap, real);
-    ALLOC(h->d_polish, cap, int); ALLOC(h->d_wfail, cap, int); ALLOC(h->d_todo, cap + 1, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_naux, cap * NN * 4, real); ALLOC(h->d_progress, cap / 64 + 6, int); ALLOC(h->d_active, cap * N, uint16_t);
+    ALLOC(h->d_polish, cap, int); ALLOC(h->d_wfail, cap, int); ALLOC(h->d_todo, cap + 2, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_naux, cap * NN * 4, real); ALLOC(h->d_progress, cap / 64 + 6, int); ALLOC(h->d_active, cap * N, uint16_t);
 #ifdef PG_EXPERIMENTAL_SOLVE4
     { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (experimental/pg_solve4.hip)
     if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), real);
 #endif
-    if (cfg->walls) { ALLOC(h->d_walls, cap * N * 2, real); C.walls = 1; C.wall_weight = (real)cfg->wall_weight; C.wall_edges = h->d_walls; if (h->solve_quad) { g_create_error = "PG_SOLVER=quad does not carry the wall rows"; free_all(h); delete h; return PG_ERR_INVALID; } }
+    if (cfg->walls) { ALLOC(h->d_walls, cap * N * 2, real); C.walls = 1; C.wall_weight = (real)cfg->wall_weight; C.wall_edges = h->d_walls; if (h->solve_quad) { g_create_error = "the experimental quad solver does not carry the wall rows"; free_all(h); delete h; return PG_ERR_INVALID; } }
     ALLOC(h->d_pol_u2, cap * 2, real); ALLOC(h->d_pol_u, cap * 3, real); ALLOC(h->d_pol_src, cap, int);
     // The lateral formulation has a solve kernel of its own (k_solve_lat, pg_solve_lat.hip) for horizons beyond 20 intervals.  Shorter ones -- the reference's on-vehicle
     // N_short = 5, N_long = 10 among them -- stay with the embedding in k_solve when the polish is on: its active-set rounds from the empty set serve a short lateral QP
     // without any interior-point iteration (N = 15, 4096 instances: 0.12 ms against 0.37), an advantage that is gone at N = 30 (2.4 against 1.5 ms) and reversed at
-    // N = 50 (12.6 against 5.9).  PG_SOLVE_LAT=0 / 1 forces the choice.
-    {
-        const char* e = getenv("PG_SOLVE_LAT");
-        const bool want = (e && e[0] == '1') || (!(e && e[0] == '0') && !(cfg->polish && N <= 20));
-        h->solve_lat = cfg->formulation == PG_DECOUPLED && want && !h->solve_quad;
-    }
-    if (h->solve_lat) {
-        ALLOC(h->d_lat, cap * N * LATP, real); C.lat_pack = h->d_lat;
-        // tuning knobs of k_solve_lat (diagnostics; a value that is not a positive finite number keeps the default)
-        auto env_pos = [](const char* name, double dflt) { const char* k = getenv(name); if (!k) return dflt; const double v = atof(k); return (v > 0.0 && v < 1e300) ? v : dflt; };
-        C.lat_mu0_cost = (real)env_pos("PG_LAT_MU0_COST", 10.0);
-        { const char* k = getenv("PG_LAT_POLISH2"); C.lat_polish2 = k ? (atoi(k) != 0) : 1; }
-        C.lat_far_cost = (real)env_pos("PG_LAT_FAR_COST", 3e4);
-        { const char* k = getenv("PG_LAT_RHO_SCALE"); const double v = k ? atof(k) : (sizeof(real) == 8 ? 1e3 : 1.0); C.lat_rho_scale = (real)((v > 0.0 && v < 1e12) ? v : 1.0); }
-        { const char* k = getenv("PG_LAT_POLISH_ROUNDS"); C.lat_polish_rounds = k ? atoi(k) : 3; if (C.lat_polish_rounds < 2) C.lat_polish_rounds = 2; }
-        { const char* k = getenv("PG_LAT_SETTLE"); C.lat_settle = k ? atoi(k) : 0; }
-        { const char* k = getenv("PG_LAT_WARM_ROUNDS"); C.lat_warm_rounds = k ? atoi(k) : 2;      /* (2 since the two-launch warm step: an attempt that needs a third working set is cheaper to hand to the cold list: 2.03 -> 1.95 ms, 2.9 -> 2.7 with walls) */ if (C.lat_warm_rounds < 0) C.lat_warm_rounds = 0; }
-        { const char* k = getenv("PG_LAT_WIPM"); C.lat_wipm = k ? atoi(k) : 0; }
-        C.lat_wmu = (real)env_pos("PG_LAT_WMU", 1e-2); C.lat_wtau = (real)env_pos("PG_LAT_WTAU", 1e-4);
-        const char* e = getenv("PG_LAT_MEM");
-        // (round 4: with the wall rows the two-slot register variant spills 720 B per lane since the warm start was added -- 1.57 ms at N = 30 against 1.36 ms through the
-        // workspace; without them the registers still win, 0.94 against 1.01 ms)
-        h->lat_mem = N > 32 || (cfg->walls && N > 16) || (e && e[0] == '1');
-        if (h->lat_mem) { ALLOC(h->d_lat_ws, lat_ws_bytes(cap), char); C.lat_ws = h->d_lat_ws; }
+    // N = 50 (12.6 against 5.9).  Option "lateral_solver" = 1 / 2 forces the choice (configure_lateral below).
+    if (cfg->formulation == PG_DECOUPLED) {
+        // defaults of k_solve_lat's tuning options (pg_set_option)
+        C.lat_mu0_cost = real(10.0); C.lat_polish2 = 1; C.lat_far_cost = real(3e4); C.lat_rho_scale = sizeof(real) == 8 ? real(1e3) : real(1.0); C.lat_polish_rounds = 3; C.lat_settle = 0;
+        C.lat_warm_rounds = 2;      /* (2 since the two-launch warm step: an attempt that needs a third working set is cheaper to hand to the cold list: 2.03 -> 1.95 ms, 2.9 -> 2.7 with walls) */
+        C.lat_wipm = 0; C.lat_wmu = real(1e-2); C.lat_wtau = real(1e-4);
+        std::string why;
+        if (configure_lateral(h, &why) != PG_OK) { g_create_error = why; free_all(h); delete h; return PG_ERR_HIP; }
     }
 #undef ALLOC
     h->stage_bytes = h->in_bytes > h->out_bytes ? h->in_bytes : h->out_bytes;          // inputs: state 6 + control 3 + other 4 (real) + t0 + time_offset (double); outputs reuse the front of it
-    { int* p_ = nullptr; if (hipHostMalloc((void**)&p_, sizeof(int), hipHostMallocDefault) != hipSuccess) { g_create_error = "hipHostMalloc failed for the to-do count"; free_all(h); delete h; return PG_ERR_HIP; } *p_ = 0; h->h_todo = p_; }
     if (hipHostMalloc((void**)&h->h_stage, h->stage_bytes, hipHostMallocDefault) != hipSuccess) { g_create_error = "hipHostMalloc failed for the staging buffer"; free_all(h); delete h; return PG_ERR_HIP; }
     // initial ts = 1..NN (model_predictive_control.jl:13), solved = false
     {
@@ -270,24 +276,15 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         (void)hipMemset(h->d_wfail, 0, cap * sizeof(int));
         (void)hipMemset(h->d_other, 0, cap * 4 * sizeof(real));
         (void)hipMemset(h->d_solx, 0, cap * NN * 8 * sizeof(real));
+        (void)hipMemset(h->d_lam, 0, cap * N * 16 * sizeof(real));          // pg_get_multipliers promises 0 off the working set: the kernels write only the rows they own
+        (void)hipMemset(h->d_active, 0, cap * N * sizeof(uint16_t));
+        (void)hipMemset(h->d_todo + cap, 0, 2 * sizeof(int));
         if (hipDeviceSynchronize() != hipSuccess) { g_create_error = "initial fills failed"; free_all(h); delete h; return PG_ERR_HIP; }   // hipMemset may return before the fill has run
     }
     for (int i = 0; i < 4; i++) if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_create_error = "hipEventCreate failed"; free_all(h); delete h; return PG_ERR_HIP; }
     h->ev_ok = true;
-    { const char* e = getenv("PG_HJI_SEED"); C.hji_seed = e ? atoi(e) : 0; }
-    { const char* e = getenv("PG_CLIP_GUESS"); C.clip_guess = e ? atoi(e) : 1; }
-    { const char* e = getenv("PG_CK_RICCATI"); C.ck_riccati = e ? atoi(e) : 1; }
-    { const char* e = getenv("PG_WARM_TRIVIAL_COLD"); C.warm_trivial_cold = e ? atoi(e) : 1; }
-    { const char* e = getenv("PG_HJI_ROUNDS"); C.hji_rounds = e ? atoi(e) : 0; }
-    { const char* e = getenv("PG_PIPE_MIN"); if (e && e[0] >= '0' && e[0] <= '9') h->pipe_min = atoi(e); }
-    { const char* e = getenv("PG_PIPE_MAX"); if (e && e[0] >= '0' && e[0] <= '9') { h->pipe_max = atoi(e); if (h->pipe_max > 16384) h->pipe_max = 16384; } }
-    { const char* e = getenv("PG_LIN_LPI"); if (e && (e[0] == '1' || e[0] == '2') && !e[1]) h->lin_lpi = e[0] - '0'; }
-    { const char* e = getenv("PG_LAT_SPLIT"); if (e && (e[0] == '0' || e[0] == '1')) h->split_lat = e[0] - '0'; }
-    { const char* e = getenv("PG_SOLVE_SPLIT"); if (e && (e[0] == '0' || e[0] == '1')) h->split_solve = e[0] - '0'; }
-    { const char* e = getenv("PG_FUSE"); if (e && e[0] >= '0' && e[0] <= '2') h->fuse = e[0] - '0'; }
-    { const char* e = getenv("PG_PIPELINE"); if (e && e[0] >= '0' && e[0] <= '1') h->pipeline = e[0] - '0'; }
-    { const char* e = getenv("PG_PIPE_FAULT"); h->pipe_fault = e && e[0] == '1'; }
-    { const char* e = getenv("PG_GRAPH"); if (e && (e[0] == '0' || e[0] == '1')) h->graph_mode = e[0] - '0'; }
+    // defaults of the build-defined options (pg_set_option changes them per handle; nothing here reads the process environment)
+    C.hji_seed = 0; C.clip_guess = 1; C.ck_riccati = 1; C.warm_trivial_cold = 1; C.hji_rounds = 0;
     // horizons up to 32 intervals keep their dynamics blocks resident in LDS (one pass over the QP data); longer ones stream them through a 4-slot ring
     h->solve_ring = N > 32;
 #ifdef PG_EXPERIMENTAL_SOLVE4
@@ -349,6 +346,91 @@ int pg_set_stream(pg_handle* h, void* s) {
 }
 int pg_set_pipeline(pg_handle* h, int32_t mode) { if (!h || mode < 0 || mode > 1) return PG_ERR_INVALID; h->pipeline = mode; return PG_OK; }
 int pg_set_fusion(pg_handle* h, int32_t mode) { if (!h || mode < 0 || mode > 2) return PG_ERR_INVALID; h->fuse = mode; return PG_OK; }
+// ---- build-defined options by name (include/pigeon_mpc.h lists them).  One table serves pg_set_option and pg_get_option. ----
+namespace {
+struct OptRef { int* i; real* r; int64_t* stat; double lo, hi; bool integer; };
+static bool find_option(pg_handle* h, const char* name, OptRef* o) {
+    DevCfg& C = h->dc;
+    *o = OptRef{nullptr, nullptr, nullptr, 0.0, 0.0, true};
+    auto I = [&](int* p, double lo, double hi) { o->i = p; o->lo = lo; o->hi = hi; o->integer = true; return true; };
+    auto R = [&](real* p, double lo, double hi) { o->r = p; o->lo = lo; o->hi = hi; o->integer = false; return true; };
+    auto S = [&](int64_t* p) { o->stat = p; return true; };
+    const std::string n(name);
+    // k_solve (coupled QP)
+    if (n == "clip_guess") return I(&C.clip_guess, 0, 1);
+    if (n == "ck_riccati") return I(&C.ck_riccati, 0, 1);
+    if (n == "warm_trivial_cold") return I(&C.warm_trivial_cold, 0, 1);
+    if (n == "hji_seed") return I(&C.hji_seed, 0, 4);
+    if (n == "hji_rounds") return I(&C.hji_rounds, 0, 64);
+    if (n == "solve_split") return I(&h->split_solve, 0, 1);
+    // launch shape
+    if (n == "pipe_min") return I(&h->pipe_min, 0, 1 << 30);
+    if (n == "pipe_max") return I(&h->pipe_max, 0, 16384);
+    if (n == "lin_lanes") return I(&h->lin_lpi, 1, 2);
+    if (n == "graph") return I(&h->graph_mode, 0, 1);
+    if (n == "hji_cell_dims") return I(&h->hji_cell_dims, 3, 7);
+    // k_solve_lat (lateral QP)
+    if (n == "lateral_solver") return I(&h->lateral_solver, 0, 2);
+    if (n == "lat_split") return I(&h->split_lat, 0, 1);
+    if (n == "lat_polish2") return I(&C.lat_polish2, 0, 1);
+    if (n == "lat_polish_rounds") return I(&C.lat_polish_rounds, 2, 64);
+    if (n == "lat_settle") return I(&C.lat_settle, 0, 2);
+    if (n == "lat_warm_rounds") return I(&C.lat_warm_rounds, 0, 64);
+    if (n == "lat_wipm") return I(&C.lat_wipm, 0, 1);
+    if (n == "lat_mu0_cost") return R(&C.lat_mu0_cost, 1e-300, 1e300);
+    if (n == "lat_far_cost") return R(&C.lat_far_cost, 1e-300, 1e300);
+    if (n == "lat_rho_scale") return R(&C.lat_rho_scale, 1e-300, 1e12);
+    if (n == "lat_wmu") return R(&C.lat_wmu, 1e-300, 1e300);
+    if (n == "lat_wtau") return R(&C.lat_wtau, 1e-300, 1e300);
+    // read-only launch statistics of this handle
+    if (n == "stat_pipelined_launches") return S(&h->stat_pipelined);
+    if (n == "stat_split_solve_launches") return S(&h->stat_split);
+    if (n == "stat_single_solve_launches") return S(&h->stat_single);
+    if (n == "stat_lat_two_launch_solves") return S(&h->stat_lat_two);
+#ifdef PG_DIAG      // diagnostic build only (libpigeon_hip_diag.so): fault injection and traces have no place in the shipped libraries
+    if (n == "diag_instance") return I(&C.dbg_instance, -1, 1 << 30);
+    if (n == "diag_lin_groups") return I(&h->lin_groups, 0, 8);
+    if (n == "diag_timeline") return I(&h->debug_timeline, 0, 1);
+#endif
+    return false;
+}
+}  // namespace
+int pg_set_option(pg_handle* h, const char* name, double value) {
+    if (!h || !name) return PG_ERR_INVALID;
+#ifdef PG_DIAG
+    if (strcmp(name, "diag_pipe_fault") == 0) { h->pipe_fault = value != 0.0; return PG_OK; }
+#endif
+    if (strcmp(name, "lat_workspace") == 0 || strcmp(name, "lateral_solver") == 0) {      // these two decide buffers: applied through configure_lateral, with the stream drained
+        REQUIRE(h, h->cfg.formulation == PG_DECOUPLED, "pg_set_option: an option of the decoupled formulation");
+        const bool which_solver = strcmp(name, "lateral_solver") == 0;
+        REQUIRE(h, value == 0.0 || value == 1.0 || (value == 2.0 && which_solver), "pg_set_option: value out of range");
+        HIPCHK(h, hipSetDevice(h->cfg.device)); HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (which_solver) h->lateral_solver = (int)value; else h->lat_mem_forced = value != 0.0;
+        if (which_solver && value == 1.0 && lat_lds_doubles(h->dc.N) * sizeof(real) > 64 * 1024) { h->err = "horizon too long for k_solve_lat's LDS staging"; return PG_ERR_INVALID; }
+        std::string why;
+        if (configure_lateral(h, &why) != PG_OK) { h->err = why; return PG_ERR_HIP; }
+        return PG_OK;
+    }
+    OptRef o;
+    if (!find_option(h, name, &o)) { h->err = std::string("pg_set_option: unknown option '") + name + "'"; return PG_ERR_INVALID; }
+    if (o.stat) { h->err = std::string("pg_set_option: '") + name + "' is read-only"; return PG_ERR_INVALID; }
+    if (!(value >= o.lo && value <= o.hi) || (o.integer && value != (double)(long long)value)) { h->err = std::string("pg_set_option: value out of range for '") + name + "'"; return PG_ERR_INVALID; }
+    if (strcmp(name, "hji_cell_dims") == 0 && !(value == 3 || value == 5 || value == 7)) { h->err = "pg_set_option: hji_cell_dims is 3, 5 or 7"; return PG_ERR_INVALID; }
+    if (o.i) *o.i = (int)value; else *o.r = (real)value;
+    return PG_OK;
+}
+int pg_get_option(pg_handle* h, const char* name, double* value) {
+    if (!h || !name || !value) return PG_ERR_INVALID;
+#ifdef PG_DIAG
+    if (strcmp(name, "diag_pipe_fault") == 0) { *value = h->pipe_fault ? 1.0 : 0.0; return PG_OK; }
+#endif
+    if (strcmp(name, "lat_workspace") == 0) { *value = h->lat_mem ? 1.0 : 0.0; return PG_OK; }
+    if (strcmp(name, "lateral_solver_in_use") == 0) { *value = h->solve_lat ? 1.0 : (h->cfg.formulation == PG_DECOUPLED ? 2.0 : 0.0); return PG_OK; }
+    OptRef o;
+    if (!find_option(h, name, &o)) { h->err = std::string("pg_get_option: unknown option '") + name + "'"; return PG_ERR_INVALID; }
+    *value = o.stat ? (double)*o.stat : (o.i ? (double)*o.i : (double)*o.r);
+    return PG_OK;
+}
 int pg_get_pipeline_fallbacks(pg_handle* h, int64_t* count) {
     if (!h || !count) return PG_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->cfg.device));                 // (a multi-GPU process: the copy below must not depend on whichever device happens to be current)
@@ -451,9 +533,8 @@ int pg_set_hji_grid(pg_handle* h, const int32_t dims[7], const float* knots_conc
     HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
     // Device layout: 256 B cell records (cdims = 3: sixteen per lookup; 6 x the node table -- 1.9 GB for the 13 x 13 x 9^5 grid).  Since the lookup reads every record 256
     // contiguous bytes per instruction and lane group (round 4), the three layouts stream at the same rate -- 0.77 / 0.76 / 0.69-0.74 of the HBM peak for 256 B / 1 KiB /
-    // 4 KiB records -- so the smallest table is the default (rounds 1-3: 4 KiB records, 19.3 GB).  PG_HJI_CELL_DIMS = 5 / 7 selects the larger records (bench, tests).
-    int cd = 3; long ncell = 0;
-    if (const char* e = getenv("PG_HJI_CELL_DIMS")) { int v = atoi(e); if (v == 3 || v == 5 || v == 7) cd = v; }
+    // 4 KiB records -- so the smallest table is the default (rounds 1-3: 4 KiB records, 19.3 GB).  Option "hji_cell_dims" = 5 / 7 selects the larger records (bench, tests).
+    int cd = h->hji_cell_dims; long ncell = 0;
     for (;; cd -= 2) {        // (a larger record asked for must fit a quarter of the free HBM)
         long cs = 1; ncell = 1;
         for (int d = 0; d < 7; d++) { int ext = d < cd ? dims[d] - 1 : dims[d]; h->hv.cstride[d] = cs; cs *= ext; ncell *= ext; }
@@ -584,10 +665,12 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
     const size_t cap = (size_t)h->cfg.batch_capacity;
     const bool file = h->dc.formulation != PG_DECOUPLED && h->dc.polish;
     int* const order_cnt = file ? h->d_order + cap : (int*)nullptr;            // the two counters of the launch order start from zero: the projection kernel clears them (no memset of its own)
+    int* const todo_cnt = h->d_todo + cap + h->solve_parity;                   // ... and the to-do counter this step's solve launch counts into (launch_solve)
+    h->cnt_cleared = !h->sg.capturing;
     if (with_time_grid) hipLaunchKernelGGL(k_project<true>, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep, h->d_t0, h->d_ts, h->d_dt, h->d_prev_ts,
-                                           pipelined ? h->d_progress : (int*)nullptr, (B + 63) / 64 + 1, order_cnt);      // (+ 1: the fault word of the pipelined launch)
+                                           pipelined ? h->d_progress : (int*)nullptr, (B + 63) / 64 + 1, order_cnt, todo_cnt);      // (+ 1: the fault word of the pipelined launch)
     else hipLaunchKernelGGL(k_project<false>, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep, (const double*)nullptr, (double*)nullptr, (double*)nullptr,
-                            (double*)nullptr, (int*)nullptr, 0, order_cnt);
+                            (double*)nullptr, (int*)nullptr, 0, order_cnt, todo_cnt);
     LAUNCH_CHECK(h);
     const bool staged = h->dc.n_traj == 1 && h->traj_L <= 2048;
     const size_t traj_lds = staged ? (size_t)2 * h->traj_L * sizeof(real) : 0;
@@ -637,7 +720,7 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
                 auto ksplit = lpi == 1 ? k_linearize_split<1> : k_linearize_split<2>;
                 hipLaunchKernelGGL(ksplit, dim3(512), dim3(64), 0, h->stream, h->dc, B, nbz, h->d_nodes, h->d_dt, h->d_Mb, h->d_qp, flt, nbz + nbr);
             }
-            h->lin_done = true;
+            h->lin_done = true; h->stat_pipelined++;
         } else {
             auto kern = staged ? k_nodes<true> : k_nodes<false>;
             hipLaunchKernelGGL(kern, grid, block, traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
@@ -693,7 +776,7 @@ static int launch_linearize(pg_handle* h, int n) {
     // spread the eight directions over four or eight lanes instead (same arithmetic per direction)
     // Large batches (several rounds of wavefronts): ONE lane per interval with all eight directions (k_linearize_split<1>) -- the fewest instructions per interval.
     // While every lane pair is resident at once (n <= 1024: 2 x 29 x 1024 / 64 = 928 wavefronts on 1024 SIMDs) the pair is the shorter chain.
-    static const int g_env = getenv("PG_LIN_G") ? atoi(getenv("PG_LIN_G")) : 0;       // (diagnostic: force the lane arrangement)
+    const int g_env = h->lin_groups;       // (-DPG_DIAG builds: option "diag_lin_groups" forces the lane arrangement; 0 otherwise)
 #ifdef PG_F32
     const int G_small = 2;   // (fp32: the instantiations differ at rounding level -- the compiler contracts them differently --, so only the two classes n <= 1024 / above exist:
                              //  shards and whole batch agree bit for bit when they fall in the same class)
@@ -733,7 +816,7 @@ int pg_update_qp(pg_handle* h) {
 }
 // k_solve over `n` instances on stream `st`: the whole batch in index order (order == nullptr) or the sub-range order[0..n) of the launch order
 static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, unsigned long long* lat_prof = nullptr) {
-    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, order, h->d_wfail, nullptr, nullptr, nullptr, nullptr};
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, order, h->d_wfail, nullptr, nullptr, nullptr, nullptr, nullptr};
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) { hipLaunchKernelGGL((k_solve4<2, false>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, (unsigned long long*)nullptr); LAUNCH_CHECK(h); return PG_OK; }
 #endif
@@ -745,11 +828,11 @@ static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, u
         if (h->dc.walls) { if (h->lat_mem) PG_LAT_LAUNCH(1, true, true); else if (slots == 1) PG_LAT_LAUNCH(1, true, false); else PG_LAT_LAUNCH(2, true, false); } \
         else { if (h->lat_mem) PG_LAT_LAUNCH(1, false, true); else if (slots == 1) PG_LAT_LAUNCH(1, false, false); else PG_LAT_LAUNCH(2, false, false); } } while (0)
         // A batch in which every instance carries a previous solution (a closed loop after its first step) is solved in TWO launches: the warm attempts, then -- over the
-        // list the first launch leaves -- the cold solves of what they did not serve, packed four per wavefront again (see k_solve_lat).  PG_LAT_SPLIT=0: one launch.
+        // list the first launch leaves -- the cold solves of what they did not serve, packed four per wavefront again (see k_solve_lat).  Option "lat_split" = 0: one launch.
         const bool two = h->split_lat && h->dc.polish && h->dc.warm_polish && h->dc.lat_warm_rounds > 0 && h->warm_B >= h->B && !lat_prof && !h->sg.capturing;
         if (two) {
             const size_t cap = (size_t)h->cfg.batch_capacity;
-            HIPCHK(h, hipMemsetAsync(h->d_todo + cap, 0, sizeof(int), st));
+            HIPCHK(h, hipMemsetAsync(h->d_todo + cap, 0, sizeof(int), st)); h->stat_lat_two++;
             O.todo = h->d_todo; O.n_todo = h->d_todo + cap;
             PG_LAT_LAUNCH_ANY();
             LAUNCH_CHECK(h);
@@ -762,29 +845,31 @@ static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, u
         return PG_OK;
     }
     if (h->solve_ring) hipLaunchKernelGGL((k_solve<false, true, false>), dim3(n), dim3(64), h->solve_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
-    else if (h->split_solve && h->dc.polish && (h->dc.cold_guess > 0 || h->dc.warm_polish) && !h->has_hji && *h->h_todo == 0 && !h->sg.capturing) {
-        // Two launches: the rounds-only instantiation (334 registers, no scratch: the interior point's state and code are not in it) serves the instances an active-set
-        // attempt verifies -- all of them on the tracking batches --; what it leaves (SolveOut::todo) goes through the full kernel in list mode, its 4096 blocks
-        // returning at once when the list is empty.  Not with a safety row installed: there the instances whose row is violated NEED the interior point (9-17 % of config
-        // 3), and in one kernel they start first (launch order) instead of after everyone else.  For the same reason the split is dropped as soon as a launch of this
-        // handle has left something on the list (its count travels to pinned memory behind the launch; the next launch reads whatever has arrived, without waiting): an
-        // instance that needs the interior point then runs it right behind its rounds, under the rest of the batch, instead of after it (`vail`, two such instances of 4096:
-        // 1.38 ms per cold step split, 1.07 ms in one kernel).  The single launch counts its interior-point instances the same way, so the split returns when they are gone.
+    else if (h->split_solve && h->dc.polish && (h->dc.cold_guess > 0 || h->dc.warm_polish) && !h->has_hji && !h->sg.capturing) {
+        // Two launches: the rounds-only instantiation (no scratch: the interior point's state and code are not in it) serves the instances an active-set attempt
+        // verifies -- all of them on the tracking batches --; what it leaves (SolveOut::todo) goes through the full kernel in list mode, its blocks returning at once
+        // when the list is empty.  Not with a safety row installed: there the instances whose row is violated NEED the interior point (9-17 % of config 3), and in one
+        // kernel they start first (launch order) instead of after everyone else.  For the same reason a launch of this handle that has left something for the interior
+        // point changes the NEXT launch: the full kernel then takes the whole batch in its launch order and the rounds-only kernel returns at once -- an instance that needs
+        // the interior point runs it right behind its rounds, under the rest of the batch, instead of after it (`vail`, two such instances of 4096: 1.38 ms per cold step
+        // split, 1.07 ms in one kernel).  The full kernel counts its interior-point instances the same way, so the split returns when they are gone.
+        // The decision is taken ON THE DEVICE from the previous launch's count (SolveOut::mode), i.e. from stream-ordered state only: the same sequence of calls gives the
+        // same launches whatever the host's timing (round 4 read a pinned copy of the count that an asynchronous copy filled "whenever it arrived").  Two counters are used
+        // alternately -- this launch counts into one while the other still holds the previous launch's count --; the projection kernel of the step zeroes the one about to be
+        // used (a solve without a nodes phase in front -- replayed QPs -- zeroes it here).
         const size_t cap = (size_t)h->cfg.batch_capacity;
-        HIPCHK(h, hipMemsetAsync(h->d_todo + cap, 0, sizeof(int), st));
-        O.todo = h->d_todo; O.n_todo = h->d_todo + cap;
+        int* const cnt = h->d_todo + cap + h->solve_parity; const int* const prev = h->d_todo + cap + (h->solve_parity ^ 1);
+        if (!h->cnt_cleared) HIPCHK(h, hipMemsetAsync(cnt, 0, sizeof(int), st));
+        h->cnt_cleared = false; h->solve_parity ^= 1; h->stat_split++;
+        O.todo = h->d_todo; O.n_todo = cnt; O.mode = prev;
         hipLaunchKernelGGL((k_solve<false, false, false, false>), dim3(n), dim3(64), h->solve_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
         LAUNCH_CHECK(h);
-        SolveOut O2 = O; O2.order_in = nullptr; O2.todo = nullptr; O2.n_todo = nullptr; O2.list = h->d_todo; O2.n_list = h->d_todo + cap;
+        SolveOut O2 = O; O2.todo = nullptr; O2.list = h->d_todo; O2.n_list = cnt;      // (order_in stays: the whole-batch mode uses the launch order)
         hipLaunchKernelGGL((k_solve<false, false, false, true>), dim3(n), dim3(64), h->solve_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O2, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
-        HIPCHK(h, hipMemcpyAsync((void*)h->h_todo, h->d_todo + cap, sizeof(int), hipMemcpyDeviceToHost, st));
     }
     else {
-        const bool count = h->split_solve && !h->has_hji && !h->sg.capturing;      // (the count decides whether the NEXT launch may split again)
-        const size_t cap = (size_t)h->cfg.batch_capacity;
-        if (count) { HIPCHK(h, hipMemsetAsync(h->d_todo + cap, 0, sizeof(int), st)); O.n_todo = h->d_todo + cap; }
+        h->stat_single++;
         hipLaunchKernelGGL((k_solve<false, false, false>), dim3(n), dim3(64), h->solve_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
-        if (count) HIPCHK(h, hipMemcpyAsync((void*)h->h_todo, h->d_todo + cap, sizeof(int), hipMemcpyDeviceToHost, st));
     }
     LAUNCH_CHECK(h);
     return PG_OK;
@@ -805,7 +890,7 @@ int pg_solve(pg_handle* h) {
 // skidpadoval, but 1.52 vs 1.40 on vail and 1.13 vs 1.05 on EastPaddock -- the linearisation runs ~15 % slower inside the big kernel (the waves of a CU are then
 // spread over 85 KB of code instead of sharing one loop in the 64 KB instruction cache), and where no straggler tail exists there is nothing to win.  Closed
 // loops were 5-8 % faster fused as long as a few instances per step fell back to the interior point; with those stragglers gone (the polish rules of k_solve)
-// the two-kernel sequence wins there too (0.91 vs 0.99, 1.06 vs 1.11, 0.87 vs 0.98 ms per closed-loop step).  Hence OFF by default (pg_set_fusion / PG_FUSE:
+// the two-kernel sequence wins there too (0.91 vs 0.99, 1.06 vs 1.11, 0.87 vs 0.98 ms per closed-loop step).  Hence OFF by default (pg_set_fusion:
 // 0 never, 1 always, 2 for all-warm batches of >= 1024 instances).
 static int update_and_solve(pg_handle* h, hipEvent_t after_update) {
     int rc;
@@ -825,7 +910,7 @@ static int update_and_solve(pg_handle* h, hipEvent_t after_update) {
     if ((rc = launch_hji_rows(h))) return rc;
     if (after_update) HIPCHK(h, hipEventRecord(after_update, h->stream));
     const bool use_order = h->dc.polish && h->order_B == h->B;
-    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, use_order ? h->d_order : nullptr, h->d_wfail, nullptr, nullptr, nullptr, nullptr};
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, use_order ? h->d_order : nullptr, h->d_wfail, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL((k_solve<false, false, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
     LAUNCH_CHECK(h);
     if (h->B > h->warm_B) h->warm_B = h->B;
@@ -839,17 +924,17 @@ int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     HIPCHK(h, hipMalloc((void**)&d, ((size_t)h->B * 9 + 1024) * 8));
     HIPCHK(h, hipMemset(d, 0, ((size_t)h->B * 9 + 1024) * 8));
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam,
-               (h->dc.polish && h->order_B == h->B) ? h->d_order : nullptr, h->d_wfail, nullptr, nullptr, nullptr, nullptr};            // (the launch order pg_solve would use: the timeline is the product's)
+               (h->dc.polish && h->order_B == h->B) ? h->d_order : nullptr, h->d_wfail, nullptr, nullptr, nullptr, nullptr, nullptr};            // (the launch order pg_solve would use: the timeline is the product's)
     if (h->solve_lat) { if ((rc = launch_solve(h, h->stream, nullptr, h->B, d))) { (void)hipFree(d); return rc; } } else
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) hipLaunchKernelGGL((k_solve4<2, true>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, d);
     else
 #endif
     if (h->solve_ring) hipLaunchKernelGGL((k_solve<true, true, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, d, h->d_dt, h->d_Mb);
-    else if (getenv("PG_DEBUG_TIMELINE")) hipLaunchKernelGGL((k_solve<false, false, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, d, h->d_dt, h->d_Mb);      // the product's kernel: timeline only
+    else if (h->debug_timeline) hipLaunchKernelGGL((k_solve<false, false, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, d, h->d_dt, h->d_Mb);      // the product's kernel: timeline only
     else hipLaunchKernelGGL((k_solve<true, false, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, d, h->d_dt, h->d_Mb);
     LAUNCH_CHECK(h);
-    HIPCHK(h, hipMemcpy(out, d, ((size_t)h->B * 9 + 1024) * 8, hipMemcpyDeviceToHost));      // out: [B][6] cycles + 1024-double trace of PG_DEBUG_INSTANCE + [B][3] timeline (k_solve: entry, exit on the 100 MHz wall clock, HW_ID | XCC_ID << 32)
+    HIPCHK(h, hipMemcpy(out, d, ((size_t)h->B * 9 + 1024) * 8, hipMemcpyDeviceToHost));      // out: [B][6] cycles + 1024-double trace of the "diag_instance" instance + [B][3] timeline (k_solve: entry, exit on the 100 MHz wall clock, HW_ID | XCC_ID << 32)
     (void)hipFree(d);
     return PG_OK;
 }

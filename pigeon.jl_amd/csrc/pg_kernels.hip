@@ -21,7 +21,7 @@ struct DevCfg {
     tdouble dt_short, dt_long;
     int use_correction_step, nsub;
     int formulation;              // PG_COUPLED / PG_DECOUPLED
-    int dbg_instance;             // diagnostic kernel build only: instance whose interior-point trace is printed (-1 = none; env PG_DEBUG_INSTANCE)
+    int dbg_instance;             // diagnostic kernel build only: instance whose interior-point trace is printed (-1 = none; option "diag_instance" of the -DPG_DIAG build)
     real ux_dummy;              // decoupled: value of the inert Ux slot of the embedded 8-state problem (strictly inside [V_min, V_max])
     int alias_prev_ts;            // the reference's MPCTimeSteps passes `ts` as prev_ts too (model_predictive_control.jl:15): same array
     int has_hji;
@@ -34,9 +34,9 @@ struct DevCfg {
     int polish;                   // active-set polish after the interior point (k_solve): 0 off, 1 on
     real polish_rho, polish_tol;  // penalty of the active rows in the polish solves; feasibility tolerance of its verification
     int hji_rounds;               // k_solve: working sets such a seeded attempt may try (0: the cold-guess cap and its extension)
-    int warm_trivial_cold;        // k_solve: a warm instance whose previous working set was empty starts like a cold one (PG_WARM_TRIVIAL_COLD, default 1)
-    int ck_riccati;               // k_solve (rounds-only instantiation): restart the matrix recursion of a round at its checkpoint when the working set allows (PG_CK_RICCATI, default 1)
-    int clip_guess;               // k_solve, cold instances: the first roll-out clips the steering rate at its limits and the clipped transitions are the first working set (PG_CLIP_GUESS, default 1)
+    int warm_trivial_cold;        // k_solve: a warm instance whose previous working set was empty starts like a cold one (option "warm_trivial_cold", default 1)
+    int ck_riccati;               // k_solve (rounds-only instantiation): restart the matrix recursion of a round at its checkpoint when the working set allows (option "ck_riccati", default 1)
+    int clip_guess;               // k_solve, cold instances: the first roll-out clips the steering rate at its limits and the clipped transitions are the first working set (option "clip_guess", default 1)
     int hji_seed;                 // k_solve: rounds of an instance whose safety row is violated at the current control start from a seeded working set (0: interior point, as before)
     int cold_guess;               // > 0: a COLD instance first tries the polish from the empty active set (unconstrained LQ optimum + add/drop rounds), at most this many rounds
     int warm_polish;              // instances with a previous solution first try the polish from its active set and multipliers (no interior point if it verifies)
@@ -134,10 +134,12 @@ PG_DEV void time_grid_lane(const DevCfg& C, int i, double t, double* T, double* 
 // writes the instance's time grid (lane = node): pg_step_dev launches time grid + projection as one kernel (TG = true; the fp32 purity check allows fp64
 // arithmetic in that instantiation only).
 template <bool TG> __global__ __launch_bounds__(256) void k_project(DevCfg C, int B, const real* __restrict__ state, real* __restrict__ sep, const double* __restrict__ t0, double* __restrict__ ts,
-                                                 double* __restrict__ dt, double* __restrict__ prev_ts, int* __restrict__ progress = nullptr, int n_progress = 0, int* __restrict__ order_cnt = nullptr) {
+                                                 double* __restrict__ dt, double* __restrict__ prev_ts, int* __restrict__ progress = nullptr, int n_progress = 0, int* __restrict__ order_cnt = nullptr,
+                                                 int* __restrict__ todo_cnt = nullptr) {
     int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (progress && blockIdx.x == 0) { for (int i = threadIdx.x; i < n_progress; i += blockDim.x) progress[i] = 0; }      // (k_nodes_linearize of this step counts from 0)
     if (order_cnt && blockIdx.x == 0 && threadIdx.x < 2) order_cnt[threadIdx.x] = 0;                                       // (the launch order the nodes kernel files: both counters from 0)
+    if (todo_cnt && blockIdx.x == 0 && threadIdx.x == 2) *todo_cnt = 0;                                                     // (the to-do counter of this step's solve launch)
     if (wave >= B) return;
     if constexpr (TG) time_grid_lane(C, lane, t0[wave], ts + (size_t)wave * C.NN, dt + (size_t)wave * C.N, prev_ts + (size_t)wave * C.NN);
     const TrajView T = traj_of(C, wave);
@@ -621,7 +623,7 @@ template <bool STAGED, int LPI> __global__ __launch_bounds__(64) void k_nodes_li
     if ((int)blockIdx.x < nb_nodes) {
         nodes_body<STAGED, true>(C, B, (int)blockIdx.x, state, control, toff, solved, sep, ts, dt, prev_ts, prev_x, nodes, F, naux, progress, pub_mask);
         __threadfence();                                                  // (warm or mixed wavefronts publish once, here; every lane is back from the body)
-        // (bit 63 of pub_mask = fault injection, PG_PIPE_FAULT=1 at pg_create: the recurrence never publishes, so that a test can watch every waiting wavefront give up)
+        // (bit 63 of pub_mask = fault injection, option "diag_pipe_fault" of the -DPG_DIAG build: the recurrence never publishes, so that a test can watch every waiting wavefront give up)
         if (threadIdx.x == 0 && !(pub_mask >> 63)) __hip_atomic_store(progress + blockIdx.x, C.NN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
@@ -1167,7 +1169,9 @@ __global__ __launch_bounds__(64) void k_hji_policy(DevCfg C, int B, int use_poli
 struct SolveOut { real* sol_x; real* sol_sigma; real* u_out; int* status; int* iters; uint16_t* active; real* mu; int* solved; int* polish; real* lam;
                   const int* order_in; int* wfail;         // wfail: k_solve_lat's back-off word per instance (nullptr: none)
                   int* todo; int* n_todo;                  // rounds-only k_solve: instances left for the full kernel, and how many
-                  const int* list; const int* n_list; };   // full k_solve in list mode: the instances to solve (interior point at once), and how many
+                  const int* list; const int* n_list;      // full k_solve in list mode: the instances to solve (interior point at once), and how many
+                  const int* mode; };                      // split launch of k_solve: the PREVIOUS launch's count of instances that needed the interior point (a stream-ordered device word).
+                                                           // Non-zero: the rounds-only kernel returns at once and the full kernel takes the whole batch in its launch order instead of the list
 
 #define NROW 16
 #define PG_POLISH_ROUNDS 6      // active-set rounds of the polish before it gives up
@@ -1254,8 +1258,11 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     if (PROF) tprev = clock64();
     const unsigned long long t_entry = (PG_TL && prof) ? wall_clock64() : 0ull;
     // Launch order: workgroup i solves instance order_in[i] when an order is supplied (filed by the nodes kernels, likely stragglers first: see OrderOut)
-    if (O.n_list && (int)blockIdx.x >= *O.n_list) return;      // list mode: nothing left for this block
-    const int b = O.n_list ? O.list[blockIdx.x] : (O.order_in ? O.order_in[blockIdx.x] : (int)blockIdx.x), lane = threadIdx.x;
+    const bool whole = O.mode && *O.mode != 0;                  // (wave-uniform: a scalar load)
+    if constexpr (!IPM) { if (whole) return; }                 // the full kernel behind this launch serves the whole batch
+    const bool listm = O.n_list && !whole;
+    if (listm && (int)blockIdx.x >= *O.n_list) return;         // list mode: nothing left for this block
+    const int b = listm ? O.list[blockIdx.x] : (O.order_in ? O.order_in[blockIdx.x] : (int)blockIdx.x), lane = threadIdx.x;
     const int N = C.N, NN = C.NN;
     // FUSE: update_QP! of this instance first, by the wave that is about to solve it -- lane pair (2t, 2t+1) linearises interval t (2N <= 64; lanes beyond 2N mirror
     // the last interval and store nothing).  The QP data go to memory exactly as k_linearize writes them (pg_get_qp reads them; the solve below reads them back
@@ -1414,7 +1421,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     // the gains and the later transitions saturate as they will in the optimum.  Nothing clipped: the point is the unconstrained optimum and verifies as before (half of the
     // batch).  Otherwise the point is not a KKT candidate; its clipped transitions are the first working set (no multiplier update, no drops in that check).
     // Headline batch: rounds 1 / 2 / 3 / 4+ 2105 / 714 / 928 / 349 -> 2105 / 1552 / 372 / 67 instances (mean 1.97 -> 1.62), k_solve 0.386 -> 0.334 ms.  Measured and dropped:
-    // clipping in every round (11 instances end in the interior point), clipping at the steering stops as well (fp64: 3-round instances 372 -> 418, 4+ 67 -> 21, same time; fp32: more 9-12 round instances, 0.34 -> 0.43 ms; and the code alone costs 4 % in the roll-out).  PG_CLIP_GUESS=0: off.
+    // clipping in every round (11 instances end in the interior point), clipping at the steering stops as well (fp64: 3-round instances 372 -> 418, 4+ 67 -> 21, same time; fp32: more 9-12 round instances, 0.34 -> 0.43 ms; and the code alone costs 4 % in the roll-out).  Option "clip_guess" = 0: off.
     bool clip_now = false, clip_used = false, clip_off = false; unsigned clip_mask = 0u;
     auto forward = [&](auto use_gain_t, bool delta = false) {      // delta: the roll-out of a CORRECTION (starts at 0, no affine term: see the polish refinement)
         constexpr bool use_gain = decltype(use_gain_t)::value;
@@ -1811,14 +1818,14 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     // current control: its weight (W_HJI) then overrides the tracking cost, the optimum is close to bang-bang (rate rows of both signs, force bounds, soft rows all
     // change together) and the add / drop iteration turns over dozens of rows per round -- the interior point needs its usual 8 iterations there
     const bool hji_hot = C.has_hji && M0 * sx0[6] + M1 * sx0[7] + hji_b < real(0.0);
-    // hji_seed (PG_HJI_SEED, experiment of round 4): a violated safety row does NOT send the instance to the interior point; its rounds start from a SEEDED working set
+    // hji_seed (option "hji_seed", experiment of round 4): a violated safety row does NOT send the instance to the interior point; its rounds start from a SEEDED working set
     // instead of the empty one -- the row held at its two stages with its slack free (an exact penalty: the multiplier of such a row IS the linear cost W_HJI of its slack)
     // and, with hji_seed = 2, the steering-rate row of those stages in the direction that relieves it
     const bool guess = C.polish && C.cold_guess > 0 && (!hji_hot || C.hji_seed > 0);
     int last_nchg = 0, good_steps = 0; real last_tmax = real(0.0); bool refine_only = false;
     int dbg_stage = -1, dbg_bit = -1, dbg_nadd = 0, dbg_ndrop = 0;      // diagnostic build: first stage / row that joined the set in the last check, rows added / dropped
     bool warm_attempt = false, from_prev = false;          // warm_attempt: a polish without an interior point in front (attempts -2, -1); from_prev: attempt -2
-    for (int attempt = O.n_list ? 0 : (warm ? -2 : (guess ? -1 : 0)); attempt < (IPM ? 2 : 0); attempt++) {
+    for (int attempt = listm ? 0 : (warm ? -2 : (guess ? -1 : 0)); attempt < (IPM ? 2 : 0); attempt++) {
     if (attempt == -1 && !guess) continue;
     rp0 = real(0.0); phi = real(1.0); pmode = 0; pstat = 0; polish_gave_up = false; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu; cycle_broken = false; settle_used = false; settle_left = 0; good_steps = 0;
     warm_attempt = attempt < 0; from_prev = attempt == -2;
@@ -1847,7 +1854,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
         }
         pmode = 1; mu = real(0.0);
     } else if (attempt == 0) {
-        if (!O.n_list && O.n_todo && lane == 0) atomicAdd(O.n_todo, 1);      // (one-kernel launch: count the instances that need the interior point -- the host's choice between the split and the single launch)
+        if (!listm && O.n_todo && lane == 0) atomicAdd(O.n_todo, 1);      // (one-kernel launch: count the instances that need the interior point -- the host's choice between the split and the single launch)
         // ---- first attempt: v = 0 roll-out (dynamics- and rate-feasible), sigma just feasible; t = max(slack, tau); lambda = mu0 / t ----
         forward(std::false_type{});
         real xs[8];
@@ -2250,7 +2257,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     }   // attempts
     it = it_total;
     stamp(0);
-    if (PG_TL && prof && lane == 0) {      // (the timeline also from the product's kernel in a -DPG_TIMELINE build: pg_debug_solve_cycles with PG_DEBUG_TIMELINE=1)
+    if (PG_TL && prof && lane == 0) {      // (the timeline also from the product's kernel in a -DPG_TIMELINE build: pg_debug_solve_cycles with the option "diag_timeline")
         if constexpr (PROF) for (int i = 0; i < 6; i++) prof[(size_t)b * 6 + i] = pc[i];
         // timeline record behind the trace region: wall clock (100 MHz) at entry and here, and where the wavefront ran (HW_ID | XCC_ID << 32)
         unsigned long long* tl = prof + (size_t)B * 6 + 1024 + (size_t)b * 3;

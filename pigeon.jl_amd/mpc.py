@@ -42,9 +42,12 @@ class BatchedTrajectoryTrackingMPC:
 
     def __init__(self, trajectory, batch_capacity, vehicle=None, control_params=None, N_short=10, N_long=20, dt_short=0.01, dt_long=0.2,
                  use_correction_step=True, rk4_substeps=10, device=0, ipm_max_iter=40, ipm_tol=None, ipm_mu0=100.0, hji_eps=0.05, formulation="coupled",
-                 precision="f64", walls=False, wall_weight=1000.0, polish=None, polish_rho=None, polish_tol=None, polish_ipm_tol=None, warm_polish=None, cold_guess=None):
+                 precision="f64", walls=False, wall_weight=1000.0, polish=None, polish_rho=None, polish_tol=None, polish_ipm_tol=None, warm_polish=None, cold_guess=None,
+                 options=None):
+        """options: {name: value} of build-defined options applied right after pg_create (pg_set_option, include/pigeon_mpc.h); precision "f64-diag" loads the
+        diagnostic build of the fp64 library (tests / tools only)."""
         self.precision = precision
-        self.real = np.float64 if precision == "f64" else np.float32      # element type of DEVICE arrays handed to the *_dev entry points
+        self.real = np.float32 if precision == "f32" else np.float64      # element type of DEVICE arrays handed to the *_dev entry points
         self.lib = _lib.load_library(precision)
         cfg = _lib.pg_config()
         assert formulation in ("coupled", "decoupled")
@@ -95,6 +98,8 @@ class BatchedTrajectoryTrackingMPC:
         self.u_normalization = un
         self.qp_len = self.lib.pg_qp_len(self.h)
         self.trajectory = None
+        for name, value in (options or {}).items():
+            self.set_option(name, value)
         if trajectory is not None:
             self.set_trajectory(trajectory)
 
@@ -228,7 +233,7 @@ class BatchedTrajectoryTrackingMPC:
         qh = uh = None; dq = du = None
         if record:
             import torch
-            tdt = torch.float64 if self.precision == "f64" else torch.float32         # device records have the library's own element type
+            tdt = torch.float32 if self.precision == "f32" else torch.float64         # device records have the library's own element type
             dq = torch.empty(steps, self.B, 6, dtype=tdt, device=f"cuda:{self.cfg.device}"); du = torch.empty(steps, self.B, 3, dtype=tdt, device=f"cuda:{self.cfg.device}")
         self._chk(self.lib.pg_simulate_dev(self.h, steps, C_.c_double(dt), C_.c_void_p(dq.data_ptr()) if record else None, C_.c_void_p(du.data_ptr()) if record else None), "pg_simulate_dev")
         s = np.zeros((self.B, 6)); c = np.zeros((self.B, 3)); t = np.zeros(self.B)
@@ -250,6 +255,16 @@ class BatchedTrajectoryTrackingMPC:
     def set_pipeline(self, mode):
         """Pipelined nodes + update_QP launch for large batches with cold instances (include/pigeon_mpc.h pg_set_pipeline): True / 1 where it applies (default), False / 0 never."""
         self._chk(self.lib.pg_set_pipeline(self.h, int(mode)), "pg_set_pipeline")
+
+    def set_option(self, name, value):
+        """Build-defined option of this handle by name (include/pigeon_mpc.h pg_set_option: solver rules, launch shape, lateral-solver tuning)."""
+        self._chk(self.lib.pg_set_option(self.h, name.encode(), C.c_double(float(value))), f"pg_set_option({name})")
+
+    def get_option(self, name):
+        """Current value of an option, or a read-only launch statistic ("stat_pipelined_launches", ...)."""
+        v = C.c_double(0.0)
+        self._chk(self.lib.pg_get_option(self.h, name.encode(), C.byref(v)), f"pg_get_option({name})")
+        return v.value
 
     def pipeline_fallbacks(self):
         """Cumulative number of waiting wavefronts of the pipelined nodes + update_QP launch that gave up (the step was then redone launch per phase)."""

@@ -119,3 +119,82 @@ def test_fp32_instantiation_has_no_stray_fp64_arithmetic():
     # and the check itself bites: the fp64 build of the same sources is full of fp64 arithmetic
     per = check_f32_purity.scan(os.path.join(csrc, "pg_api_f32.s"))
     assert any(check_f32_purity.kernel_name(k) == "k_time_steps" for k in per)
+
+
+def _strict(txt):
+    """json.loads that refuses NaN / Infinity (the driver's parser is strict)."""
+    import json
+
+    def bad(c):
+        raise ValueError(f"non-strict JSON constant {c}")
+    return json.loads(txt, parse_constant=bad)
+
+
+@pytest.mark.parametrize("n_gpus", [1, 8])
+def test_bench_last_line_is_compact_strict_json(n_gpus):
+    """Round 4's bench printed ONE 20.6 KB line and the driver's 8 KB stdout tail could not hold it (`BENCH_r04.parsed = null`).  The last stdout line is now built by
+    bench.compact_line from the full record (which goes to bench_full.json): contract keys only, strict JSON, <= 4 KB -- checked here on the committed round-4 record
+    (the largest one there is) for the single-GPU line and for a scaling line."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_final", "bench_line.json")))
+    full["roofline"]["kernels"] = [{"kernel": k, "avg_launch_ms": 0.3212345678, "hbm_frac": 1.71234e-4, "valu_flop_frac": 0.02812345, "traffic": 113932320.0, "valu_issue_frac": 0.3123234,
+                                    "mfma_busy_frac": 0.0659718, "mfma_flop_frac": 0.06600807, "avg_launch_ms_rocprof": 0.318834} for k in ("k_solve", "k_nodes_linearize")]
+    full["roofline"]["hji_lookup"] = {"bound": "hbm", "achieved": 6012.345678, "peak": 8000.0, "unit": "GB/s", "frac": 0.7515432, "avg_launch_ms": 0.7143, "min_launch_ms": 0.68, "max_launch_ms": 0.77,
+                                      "traffic": 4410866604.5, "algorithmic_bytes_per_launch": 4294967296}
+    full["phase_ms_short"] = {"nodes+update_qp": 0.3347, "update_qp": 0.0031, "solve": 0.3282}
+    full["pipeline_fallbacks"] = 0
+    full["env"] = ["PG_EXAMPLE=1", "PIGEON_HIP_LIB=/some/where/libpigeon_hip.so"]
+    full["secondary"] = {f"number_{i}": 1234567.891 * (i + 1) for i in range(10)}
+    full["cpu_baseline"]["cpu_model"] = "AMD EPYC 9575F 64-Core Processor"; full["cpu_baseline"]["flags"] = "g++ -O2 -march=x86-64-v3 -std=c++17 -fPIC -ffp-contract=off -pthread"
+    full["cpu_baseline"]["value_nan_example"] = float("nan")
+    if n_gpus > 1:
+        full.update(n_gpus=n_gpus, ranks=n_gpus, collective="rccl", per_rank_ms_per_step={"min": 0.66, "max": 0.69}, gather_ok=True)
+        full.pop("cpu_baseline")
+    txt = bench.compact_line(bench._json_safe(full))
+    assert "\n" not in txt and len(txt) <= 4096, len(txt)
+    line = _strict(txt)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "solved", "roofline"):
+        assert k in line, k
+    assert set(line["config"]) == {"workload", "batch_per_gpu", "parallelism"}
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    assert [e["kernel"] for e in line["roofline"]["kernels"]] == ["k_solve", "k_nodes_linearize"] and "mfma_busy_frac" in line["roofline"]["kernels"][0]
+    assert line["n_gpus"] == n_gpus and line["value"] > 0 and line["higher_is_better"] is True
+    if n_gpus == 1:
+        for k in ("value", "unit", "cores", "kind", "sample", "value_1thread", "cpu_model", "flags"):
+            assert k in line["cpu_baseline"], k
+    else:
+        assert line["collective"] == "rccl" and line["ranks"] == n_gpus and "per_rank_ms_per_step" in line
+    # a record stuffed far beyond anything the bench produces still fits: the optional keys go first, the contract keys stay
+    full["secondary"] = {f"number_{i}": float(i) for i in range(400)}
+    txt = bench.compact_line(bench._json_safe(full))
+    assert len(txt) <= 4096 and "roofline" in _strict(txt) and "secondary" not in _strict(txt)
+
+
+def test_bench_emit_writes_the_full_record_and_prints_the_compact_line_last(tmp_path, capsys, monkeypatch):
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_final", "bench_line.json")))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench.emit(full)
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(out) == 1 and len(out[0]) <= 4096
+    assert _strict(out[0])["full_record"] == "bench_full.json"
+    rec = _strict(open(tmp_path / "bench_full.json").read())
+    assert rec["value"] == full["value"] and "decoupled_n50" in rec
+
+
+@pytest.mark.parametrize("name", ["libpigeon_hip.so", "libpigeon_hip_f32.so"])
+def test_release_libraries_read_nothing_from_the_environment(name):
+    """Round 4 shipped 28 getenv switches (solver penalties, algorithm toggles, launch shape, a fault-injection hook): what a process computed depended on its
+    environment.  They are pg_set_option names now (or live in the -DPG_DIAG build only): the shipped libraries import no getenv and carry no PG_* string."""
+    import subprocess
+    path = os.path.join(ROOT, "pigeon.jl_amd", "csrc", name)
+    und = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+    strs = subprocess.run(["strings", path], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert [s for s in strs if s.startswith("PG_")] == []
+    assert not any("diag_pipe_fault" in s for s in strs)              # fault injection exists in libpigeon_hip_diag.so only
+    diag = subprocess.run(["strings", os.path.join(ROOT, "pigeon.jl_amd", "csrc", "libpigeon_hip_diag.so")], capture_output=True, text=True, check=True).stdout
+    assert "diag_pipe_fault" in diag

@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the multi-GPU host logic: contiguous batch shards, gather of controls, max-over-ranks time."""
+"""world_size-2 and world_size-8 gloo tests of the multi-GPU host logic: contiguous batch shards, gather of controls, max-over-ranks time."""
 import os
 import sys
 
@@ -33,10 +33,12 @@ def _worker(rank, world, port, B, ret):
     dist.barrier(); dist.destroy_process_group()
 
 
-def _run(B):
+def _run(B, world=2):
+    import socket
     mgr = mp.Manager(); ret = mgr.dict()
-    port = 29500 + (os.getpid() % 1000)
-    mp.spawn(_worker, args=(2, port, B, ret), nprocs=2, join=True)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    mp.spawn(_worker, args=(world, port, B, ret), nprocs=world, join=True)
     assert ret.get("ok") is True
 
 
@@ -46,3 +48,9 @@ def test_gather_even():
 
 def test_gather_ragged():
     _run(37)
+
+
+def test_gather_eight_ranks_even_and_ragged():
+    """The world size of BASELINE configs[3] (8 ranks, one per GPU of the node): shard ranges, the padded gather of a batch that does not divide by eight, max-over-ranks."""
+    _run(4096, world=8)
+    _run(1001, world=8)

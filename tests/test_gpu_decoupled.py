@@ -204,18 +204,15 @@ def test_config5_as_shipped_every_instance_against_the_oracle(pkg, oracle_mod, s
 @pytest.mark.parametrize("B,walls,path", [(1, False, "skidpadoval"), (5, True, "skidpadoval"), (1021, True, "EastPaddock"), (130, False, "vail")])
 def test_lateral_kernel_on_ragged_batches_matches_the_embedding(pkg, B, walls, path):
     """k_solve_lat (four instances per wavefront, the per-row state of N = 50 in its global workspace) against the embedding of the same QP in k_solve
-    (PG_SOLVE_LAT=0, one wavefront per instance) on batch sizes that leave the last wavefront ragged and on other paths than the benchmark's: two
+    (option "lateral_solver" = 2, one wavefront per instance) on batch sizes that leave the last wavefront ragged and on other paths than the benchmark's: two
     different kernels, the same verified KKT point wherever both verify."""
     import os
     traj = pkg.load_path_fixture(path)
     state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=3)
     out = {}
     for lat in ("1", "0"):
-        os.environ["PG_SOLVE_LAT"] = lat
-        try:
-            mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, walls=walls)
-        finally:
-            os.environ.pop("PG_SOLVE_LAT", None)
+        mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, walls=walls, options={"lateral_solver": 1 if lat == "1" else 2})
+        assert mpc.get_option("lateral_solver_in_use") == (1 if lat == "1" else 2)
         u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
         x, sg = mpc.solution()
         out[lat] = (u.copy(), status.copy(), x.copy(), mpc.polish_info().copy())

@@ -246,11 +246,11 @@ def test_fused_step_is_bit_identical(pkg, skidpad):
 
 
 def test_pipelined_nodes_and_update_qp_are_bit_identical(pkg, skidpad):
-    """pg_set_pipeline (default on, 2048 <= B <= 8192 with cold instances): compute_linearization_nodes! and update_QP! run as one launch in which interval t is
+    """pg_set_pipeline (default on, 2304 <= B <= 16384 with cold instances): compute_linearization_nodes! and update_QP! run as one launch in which interval t is
     linearised as soon as nodes t, t + 1 are seeded.  Same device functions on the same arguments: nodes, QP data, solution and controls are bit-identical to the
     launch-per-phase sequence -- on a cold batch, on a MIXED batch (half the instances reset after a step: their wavefronts publish once, at the end) and with a
     ragged last wavefront (B not a multiple of 64)."""
-    for Bn in (4096, 2048 + 37):
+    for Bn in (4096, 2304 + 37):
         state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, Bn, seed=5)
         out = {}
         for piped in (False, True):
@@ -264,6 +264,8 @@ def test_pipelined_nodes_and_update_qp_are_bit_identical(pkg, skidpad):
             mpc.step_dev(); mpc.synchronize()
             r += [np.concatenate([a.reshape(Bn, -1) for a in mpc.nodes()], axis=1), mpc.qp_data().copy(), mpc.get_next_control().copy(), mpc.solve_info()[0].copy()]
             out[piped] = r
+            # the path the test means to cover is the one that ran: both steps of the pipelined handle (cold, mixed) took the pipelined launch, none of the other handle's
+            assert mpc.get_option("stat_pipelined_launches") == (2 if piped else 0) and mpc.pipeline_fallbacks() == 0
             mpc.close()
         assert np.all(out[True][4] == pkg.SOLVED)
         for a, b in zip(out[False], out[True]):
@@ -272,10 +274,10 @@ def test_pipelined_nodes_and_update_qp_are_bit_identical(pkg, skidpad):
 
 def test_pipelined_launch_with_a_trajectory_library(pkg):
     """The pipelined launch with a LIBRARY of tubes and a per-instance selection (the un-staged instantiation: the searched channels stay in memory): bit-identical to
-    the launch-per-phase sequence, at the smallest batch the pipeline serves."""
+    the launch-per-phase sequence, at the smallest batch the pipeline serves (option "pipe_min", 2304 by default)."""
     paths = ["skidpadoval", "vail", "EastPaddock", "variable_speed"]
     tubes = [pkg.load_path_fixture(p) for p in paths]
-    Bn = 2048
+    Bn = 2304
     idx = ((np.arange(Bn) * 7 + 3) % len(tubes)).astype(np.int32)
     state = np.zeros((Bn, 6)); control = np.zeros((Bn, 3)); t0 = np.zeros(Bn); toff = np.zeros(Bn)
     for k, t in enumerate(tubes):
@@ -290,6 +292,7 @@ def test_pipelined_launch_with_a_trajectory_library(pkg):
         mpc.set_inputs(state, control, t0, time_offset=toff)
         mpc.step_dev(); mpc.synchronize()
         out[piped] = [np.concatenate([a.reshape(Bn, -1) for a in mpc.nodes()], axis=1), mpc.qp_data().copy(), mpc.get_next_control().copy(), mpc.solve_info()[0].copy()]
+        assert mpc.get_option("stat_pipelined_launches") == (1 if piped else 0) and mpc.pipeline_fallbacks() == 0
         mpc.close()
     assert np.mean(out[True][3] == pkg.SOLVED) > 0.99
     for a, b in zip(out[False], out[True]):
@@ -298,8 +301,10 @@ def test_pipelined_launch_with_a_trajectory_library(pkg):
 
 def test_split_solve_launch_gives_the_same_answers(pkg, skidpad, monkeypatch):
     """k_solve as two launches (the rounds-only instantiation, then the full kernel in list mode over what it left: the default without a safety row) against the single
-    kernel (PG_SOLVE_SPLIT=0), on the benchmark batch and on `vail` (two of whose 4096 cold instances need the interior point: the list-mode launch does real work there,
-    and the next launch of that handle drops the split by itself): same status, same interior-point iteration counts, controls of two verified KKT points of the same QP."""
+    kernel (option "solve_split" = 0), on the benchmark batch and on `vail` (two of whose 4096 cold instances need the interior point: the list-mode launch does real work there,
+    and the next launch of that handle hands the whole batch to the full kernel -- decided on the device from the previous launch's count): same status, same interior-point
+    iteration counts, controls of two verified KKT points of the same QP.  Instances served by their active-set rounds get the SAME BITS both ways (the checkpoint restart of
+    the rounds-only instantiation does not change a bit), so an instance's answer does not depend on which launch shape its batch-mates caused."""
     B = 4096
     un = np.array([0.314159, 16793.7, 16793.7])
     for path in ("skidpadoval", "vail"):
@@ -308,18 +313,20 @@ def test_split_solve_launch_gives_the_same_answers(pkg, skidpad, monkeypatch):
         state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345, **kw)
         out = {}
         for split in ("1", "0"):
-            monkeypatch.setenv("PG_SOLVE_SPLIT", split)
-            mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B)
+            mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, options={"solve_split": int(split)})
             u1, st1, it1 = mpc.step_(state, control, t0, time_offset=toff)
             mpc.reset()
             u2, st2, it2 = mpc.step_(state, control, t0, time_offset=toff)          # (after a launch that left work: the split handle has switched to the single kernel)
             out[split] = (u1, st1, it1, u2, st2, it2, mpc.polish_info().copy())
+            assert mpc.get_option("stat_split_solve_launches") == (2 if split == "1" else 0) and mpc.get_option("stat_single_solve_launches") == (0 if split == "1" else 2)
             mpc.close()
         a, b = out["1"], out["0"]
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5]), path
         assert np.all(pkg.is_solved(a[1]))
         both = (a[6] >= 1) & (b[6] >= 1)
         assert np.max(np.abs(a[0][both] - b[0][both]) / un) < 1e-8 and np.max(np.abs(a[3][both] - b[3][both]) / un) < 1e-8, path
+        rounds_only = (a[2] == 0) & (b[2] == 0)                  # served by active-set rounds in both launch shapes: bit for bit
+        assert rounds_only.sum() >= B - 8 and np.array_equal(a[0][rounds_only], b[0][rounds_only]) and np.array_equal(a[3][rounds_only], b[3][rounds_only]), path
         if path == "vail":
             assert (a[2] > 0).sum() >= 1          # the list-mode launch had something to do
 
@@ -327,31 +334,29 @@ def test_split_solve_launch_gives_the_same_answers(pkg, skidpad, monkeypatch):
 @pytest.mark.gpu
 def test_round4_guess_checkpoint_and_lane_arrangement_change_nothing(pkg, skidpad, monkeypatch):
     """Round 4's three changes to the headline path, each against its switch, on the benchmark batch (B = 4096, cold):
-    (i) PG_LIN_LPI: one lane per (instance, interval) with all eight tangent directions against the lane pair -- the QP data bit for bit (fp64);
-    (ii) PG_CK_RICCATI: the matrix recursion of a round restarted at its checkpoint -- controls, primal solution and statuses bit for bit;
-    (iii) PG_CLIP_GUESS: the rounds of a cold instance started from the clipped roll-out's working set against the plain empty set -- two routes to verified KKT
+    (i) option "lin_lanes": one lane per (instance, interval) with all eight tangent directions against the lane pair -- the QP data bit for bit (fp64);
+    (ii) option "ck_riccati": the matrix recursion of a round restarted at its checkpoint -- controls, primal solution and statuses bit for bit;
+    (iii) option "clip_guess": the rounds of a cold instance started from the clipped roll-out's working set against the plain empty set -- two routes to verified KKT
     points of the same QP: every instance solved without an interior-point iteration both ways, controls within 1e-8, the canonical active sets identical."""
     B = 4096
     un = np.array([0.314159, 16793.7, 16793.7])
     state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B, seed=12345, traj_mode=True)
 
-    def run(**env):
-        for k, v in env.items(): monkeypatch.setenv(k, v)
-        m = pkg.BatchedTrajectoryTrackingMPC(skidpad, B)
+    def run(**opts):
+        m = pkg.BatchedTrajectoryTrackingMPC(skidpad, B, options=opts)
         u, st, it = m.step_(state, control, t0, time_offset=toff)
         _, _, act, _ = m.solve_info()
         r = dict(u=u, st=st, it=it, x=m.solution()[0], qp=m.qp_data(), act=act, lam=m.multipliers(), pol=m.polish_info().copy())
         m.close()
-        for k in env: monkeypatch.delenv(k)
         return r
 
     ref = run()
     assert np.all(ref["st"] == pkg.SOLVED) and np.all(ref["it"] == 0) and np.all(ref["pol"] >= 1)
-    pair = run(PG_LIN_LPI="2")
+    pair = run(lin_lanes=2)
     assert np.array_equal(pair["qp"], ref["qp"]) and np.array_equal(pair["u"], ref["u"])
-    nock = run(PG_CK_RICCATI="0")
+    nock = run(ck_riccati=0)
     assert np.array_equal(nock["u"], ref["u"]) and np.array_equal(nock["x"], ref["x"]) and np.array_equal(nock["st"], ref["st"]) and np.array_equal(nock["pol"], ref["pol"])
-    plain = run(PG_CLIP_GUESS="0")
+    plain = run(clip_guess=0)
     assert np.all(plain["st"] == pkg.SOLVED) and np.all(plain["it"] == 0)
     assert np.max(np.abs(plain["u"] - ref["u"]) / un) < 1e-8
     can = lambda r: ((r["act"][:, :, None].astype(np.uint32) >> np.arange(16)[None, None, :]) & 1).astype(bool) & (r["lam"] > 1e-6)

@@ -16,10 +16,9 @@ def grid(pkg):
 
 @pytest.mark.parametrize("cell_dims", [7, 5, 3])
 def test_lookup_matches_oracle(pkg, oracle_mod, skidpad, grid, cell_dims, monkeypatch):
-    """All three device layouts (256 B cell records = the default, 1 KiB, 4 KiB: PG_HJI_CELL_DIMS) against the oracle."""
-    monkeypatch.setenv("PG_HJI_CELL_DIMS", str(cell_dims))
+    """All three device layouts (256 B cell records = the default, 1 KiB, 4 KiB: option "hji_cell_dims") against the oracle."""
     knots, V, g = grid
-    mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, 8)
+    mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, 8, options={"hji_cell_dims": cell_dims})
     mpc.set_hji_cache(knots, V, g)
     orc = make_oracle(oracle_mod, skidpad); orc.set_hji_grid(knots, V, g)
     rng = np.random.default_rng(0)

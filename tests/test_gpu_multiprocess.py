@@ -58,7 +58,7 @@ def test_bench_launches_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["solved"] == "512/512"
     assert d["gather_ok"] is True
-    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 512) < 1e-6 * 2 * 512          # value = all ranks' solves / max-over-ranks time
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 512) < 1e-3 * 2 * 512          # value = all ranks' solves / max-over-ranks time
 
 
 def test_config4_workload_line_over_two_ranks():
@@ -74,8 +74,8 @@ def test_config4_workload_line_over_two_ranks():
     assert d["n_gpus"] == 2 and d["dtype"] == "f32" and d["ranks"] == 2 and d["collective"] == "gloo" and d["gather_ok"] is True
     assert d["config"]["workload"].startswith("configs[3]: Batch=16384 coupled MPC, N=30, fp32, sharded 8192/GPU x2")
     assert d["solved"] == "8192/8192"
-    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 8192) < 1e-6 * 2 * 8192
-    assert d["per_rank_ms_per_step"]["min"] <= d["per_rank_ms_per_step"]["max"] == pytest.approx(d["ms_per_step"])
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 8192) < 1e-3 * 2 * 8192
+    assert d["per_rank_ms_per_step"]["min"] <= d["per_rank_ms_per_step"]["max"] == pytest.approx(d["ms_per_step"], rel=1e-4)
     for k in ("closed_loop_rollout", "hji_lookup", "decoupled_n50", "fp32", "cpu_baseline", "interior_point_only", "two_half_batches_on_two_streams"):
         assert k not in d, k
 
@@ -90,3 +90,24 @@ def test_rccl_gather_when_two_gpus_are_present():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["collective"] == "rccl" and d["ranks"] == 2 and d["gather_ok"] is True and d["solved"] == "1024/1024"
+
+
+def test_bench_scaling_line_over_four_ranks_is_compact():
+    """The scaling run the driver does at round end (`bench.py --gpus N`), rehearsed through the bench's own launcher with as many ranks as the GPU box lets one card
+    carry (its process guard allows 6 GPU processes: this test process + 4 ranks; the 8-rank shard / gather logic runs in tests/test_distributed_gloo.py on the CPU).
+    The LAST stdout line is the compact record: strict JSON within 4 KB with the contract keys, `ranks`, `collective` and `per_rank_ms_per_step`."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--batch", "512",
+                        "--precision", "f32"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) <= 4096
+
+    def bad(c):
+        raise ValueError(c)
+    d = json.loads(last, parse_constant=bad)
+    assert d["n_gpus"] == 4 and d["ranks"] == 4 and d["collective"] == "gloo" and d["gather_ok"] is True and d["solved"] == "512/512" and d["dtype"] == "f32"
+    assert d["per_rank_ms_per_step"]["min"] <= d["per_rank_ms_per_step"]["max"] == pytest.approx(d["ms_per_step"], rel=1e-4)
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 4 * 512) < 1e-3 * 4 * 512
+    for k in ("metric", "unit", "config", "roofline", "scaling", "vs_baseline", "data", "higher_is_better"):
+        assert k in d, k
+    assert "cpu_baseline" not in d
