@@ -203,15 +203,16 @@ def _json_safe(x):
     return x
 
 
-def emit(full):
-    """Write the whole record to bench_full.json (+ gpurun_out/ when that scratch directory exists, so that a gpurun call brings it home) and print the compact line LAST on stdout."""
+def emit(full, path=None):
+    """Write the whole record to bench_full.json (+ gpurun_out/ when that scratch directory exists, so that a gpurun call brings it home; `path`: there and nowhere else) and
+    print the compact line LAST on stdout."""
     full = _json_safe(full)
     blob = json.dumps(full, allow_nan=False)
-    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+    targets = [path] if path else [os.path.join(d, "bench_full.json") for d in (ROOT, os.path.join(ROOT, "gpurun_out")) if os.path.isdir(d)]
+    for t in targets:
         try:
-            if os.path.isdir(d):
-                with open(os.path.join(d, "bench_full.json"), "w") as f:
-                    f.write(blob + "\n")
+            with open(t, "w") as f:
+                f.write(blob + "\n")
         except OSError:
             pass
     print(compact_line(full), flush=True)
@@ -328,6 +329,7 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend for --gpus > 1: nccl = RCCL over xGMI (the product path); gloo = host-staged gather with the ranks sharing whatever GPUs exist "
                          "(test mode: exercises launch -> shard -> step -> gather end to end on a 1-GPU box)")
+    ap.add_argument("--full-record", default=None, help="where the whole record goes (default: bench_full.json beside bench.py, and in gpurun_out/ when that exists); the last stdout line is the compact one either way")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64",
                     help="arithmetic type of the headline run: f64 = BASELINE configs[1] (default, the metric's config); f32 with --batch 8192 --gpus 8 = configs[3]")
     args = ap.parse_args()
@@ -715,7 +717,7 @@ def main():
             rounds32 = np.where(p_ > 0, p_, np.where(p_ < 0, 6, 0))
             return {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": ph32,
                     "solved": f"{int(pkg.is_solved(st_).sum())}/{B}", "ipm_iters_mean": float(np.mean(it_)), "ipm_iters_hist": hist(it_), "verified_by_polish": f"{int((p_ >= 1).sum())}/{B}",
-                    "roofline": roofline_of(TR32, "k_solve<false, false, false, true>" if with_hji else "k_solve<false, false, false, false>", ph32[2], B, 68 + (16 + 4096 if with_hji else 0), float(np.sum(solve_flops(m32.N, it_.astype(np.float64), rounds32.astype(np.float64)))), "f32",
+                    "roofline": roofline_of(TR32, "k_solve<false, false, false, true" if with_hji else "k_solve<false, false, false, false", ph32[2], B, 68 + (16 + 4096 if with_hji else 0), float(np.sum(solve_flops(m32.N, it_.astype(np.float64), rounds32.astype(np.float64)))), "f32",
                                             note="solve phase of the fp32 library (k_solve, two waves per SIMD); bytes per solve: 68 (SURVEY 8d, fp32) + other car 16 B + 4096 B of corner records with the safety row")}
 
         plain = run32(False)
@@ -803,7 +805,7 @@ def main():
                     e["mfma_busy_frac"] = m_.get("busy_frac_of_simd_time"); e["mfma_flop_frac"] = m_.get("frac_of_peak")
             return e
         lin_match = ("k_nodes_linearize" if pipelined else "k_linearize")
-        kernels = [kernel_entry("k_solve", "k_solve<false, false, false, false>", float(ph[2]), valu), kernel_entry(lin_match, lin_match, lin_ms, valu_lin)]
+        kernels = [kernel_entry("k_solve", "k_solve<false, false, false, false", float(ph[2]), valu), kernel_entry(lin_match, lin_match, lin_ms, valu_lin)]
         kernels.sort(key=lambda e: -e["avg_launch_ms"])
         try:
             fallbacks = int(mpc.pipeline_fallbacks())
@@ -867,7 +869,7 @@ def main():
         if variants is not None:
             sec["config2_vail_solves_per_s"] = variants["vail"]["value"]; sec["config2_path_mode_solves_per_s"] = variants["path_mode"]["value"]
         line["secondary"] = {k: v for k, v in sec.items() if v is not None}
-        emit(line)
+        emit(line, args.full_record)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -48,8 +48,7 @@ def load_library(precision="f64"):
     path = {"f64": LIB_PATH, "f32": LIB_PATH_F32, "f64-diag": LIB_PATH_DIAG}[precision]
     # A/B runs of an experimental build select it here (PIGEON_HIP_LIB / PIGEON_HIP_LIB_F32 = path of the .so) instead of copying it over the shipped library
     # (read by this Python mirror only: the C library itself reads nothing from the environment)
-    if precision != "f64-diag":
-        path = os.environ.get("PIGEON_HIP_LIB" if precision == "f64" else "PIGEON_HIP_LIB_F32", path)
+    path = os.environ.get({"f64": "PIGEON_HIP_LIB", "f32": "PIGEON_HIP_LIB_F32", "f64-diag": "PIGEON_HIP_LIB_DIAG"}[precision], path)
     if not os.path.exists(path):
         raise PigeonError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)")
     try:

@@ -42,11 +42,13 @@ struct pg_handle {
     real *d_x7 = nullptr, *d_vg8 = nullptr, *d_Mb = nullptr;
     real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     real* d_lam = nullptr;                                      // [cap][N][16] multipliers of the last solve (warm start of the polish)
-    int* d_wfail = nullptr;                                     // [cap] back-off of k_solve_lat's warm attempts
+    int* d_wfail = nullptr;                                     // [cap] back-off of k_solve_lat's warm attempts (the second half of the d_solved allocation: pg_reset clears both with one fill)
     int pipe_min = 2304, pipe_max = 16384;                    // batch sizes the pipelined launch serves (options "pipe_min" / "pipe_max"; its nodes blocks must be resident at once: <= 16384)
     int lin_lpi = 1;                                          // lanes per (instance, interval) of the large-batch linearisation (k_linearize_split / k_nodes_linearize): one lane with all eight
                                                               // directions (option "lin_lanes" = 2: the lane pair of rounds 1-3, for A/B runs; same bits in fp64, rounding-level differences in fp32)
-    int* d_todo = nullptr; int split_solve = 1, split_lat = 1;      // d_todo [cap + 2]: instances the rounds-only k_solve leaves to the full kernel, then TWO counters used alternately (this launch's count / the previous launch's)
+    int* d_todo = nullptr; int split_solve = 1, split_lat = 1;      // d_todo [cap + 8]: instances the rounds-only k_solve leaves to the full kernel; behind them the control words of the solve launches:
+                                                                    // [0], [1] two to-do counters used alternately (this launch's count / the previous launch's)
+    real* u_direct = nullptr; bool u_written = false;               // pg_step_dev: the caller's control array for k_solve to write (SolveOut::u_out2), and whether the launch did
     int* d_order = nullptr; int order_B = 0;  // [cap] + 2 counters: launch order filed by the nodes kernels of the current step (likely slow instances first); order_B = batch it is valid for
     real *d_pol_u2 = nullptr, *d_pol_u = nullptr; int* d_pol_src = nullptr;   // HJI fallback policy (HJI_computation.jl:133-158)
     int *d_status = nullptr, *d_iters = nullptr, *d_polish = nullptr; uint16_t* d_active = nullptr;
@@ -189,7 +191,7 @@ int pg_default_config_decoupled(pg_config* c) {
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_in, h->d_out, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_wfail, h->d_todo, h->d_order, h->d_naux, h->d_progress, h->d_lat, h->d_lat_ws};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_todo, h->d_order, h->d_naux, h->d_progress, h->d_lat, h->d_lat_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->sg.x) (void)hipGraphExecDestroy(h->sg.x);
@@ -237,11 +239,11 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_in, h->in_bytes, char); ALLOC(h->d_out, h->out_bytes, char);
     h->d_state = (real*)h->d_in; h->d_control = h->d_state + cap * 6; h->d_other = h->d_control + cap * 3; h->d_t0 = (double*)(h->d_in + h->in_dbl_off); h->d_toff = h->d_t0 + cap;
     h->d_u = (real*)h->d_out; h->d_status = (int*)(h->d_u + cap * 3); h->d_iters = h->d_status + cap;
-    ALLOC(h->d_solved, cap, int); ALLOC(h->d_mask, cap, uint8_t); ALLOC(h->d_ts, cap * NN, double); ALLOC(h->d_dt, cap * N, double); ALLOC(h->d_prev_ts, cap * NN, double);
+    ALLOC(h->d_solved, 2 * cap, int); h->d_wfail = h->d_solved + cap; ALLOC(h->d_mask, cap, uint8_t); ALLOC(h->d_ts, cap * NN, double); ALLOC(h->d_dt, cap * N, double); ALLOC(h->d_prev_ts, cap * NN, double);
     ALLOC(h->d_sep, cap * 4, real); ALLOC(h->d_nodes, cap * NN * 10, real); ALLOC(h->d_qp, cap * C.qp_len, real);
     ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
     ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_mu, cap, real);
-    ALLOC(h->d_polish, cap, int); ALLOC(h->d_wfail, cap, int); ALLOC(h->d_todo, cap + 2, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_naux, cap * NN * 4, real); ALLOC(h->d_progress, cap / 64 + 6, int); ALLOC(h->d_active, cap * N, uint16_t);
+    ALLOC(h->d_polish, cap, int); ALLOC(h->d_todo, cap + 8, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_naux, cap * NN * 4, real); ALLOC(h->d_progress, cap / 64 + 6, int); ALLOC(h->d_active, cap * N, uint16_t);
 #ifdef PG_EXPERIMENTAL_SOLVE4
     { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (experimental/pg_solve4.hip)
     if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), real);
@@ -270,27 +272,26 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         (void)hipMemcpy(h->d_ts, ts.data(), ts.size() * 8, hipMemcpyHostToDevice);
         (void)hipMemcpy(h->d_prev_ts, ts.data(), ts.size() * 8, hipMemcpyHostToDevice);
         (void)hipMemcpy(h->d_dt, dt.data(), dt.size() * 8, hipMemcpyHostToDevice);
-        (void)hipMemset(h->d_solved, 0, cap * sizeof(int));
+        (void)hipMemset(h->d_solved, 0, 2 * cap * sizeof(int));
         (void)hipMemset(h->d_progress, 0, (cap / 64 + 6) * sizeof(int));
         (void)hipMemset(h->d_status, 0, cap * sizeof(int));
-        (void)hipMemset(h->d_wfail, 0, cap * sizeof(int));
         (void)hipMemset(h->d_other, 0, cap * 4 * sizeof(real));
         (void)hipMemset(h->d_solx, 0, cap * NN * 8 * sizeof(real));
         (void)hipMemset(h->d_lam, 0, cap * N * 16 * sizeof(real));          // pg_get_multipliers promises 0 off the working set: the kernels write only the rows they own
         (void)hipMemset(h->d_active, 0, cap * N * sizeof(uint16_t));
-        (void)hipMemset(h->d_todo + cap, 0, 2 * sizeof(int));
+        (void)hipMemset(h->d_todo + cap, 0, 8 * sizeof(int));
         if (hipDeviceSynchronize() != hipSuccess) { g_create_error = "initial fills failed"; free_all(h); delete h; return PG_ERR_HIP; }   // hipMemset may return before the fill has run
     }
     for (int i = 0; i < 4; i++) if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_create_error = "hipEventCreate failed"; free_all(h); delete h; return PG_ERR_HIP; }
     h->ev_ok = true;
     // defaults of the build-defined options (pg_set_option changes them per handle; nothing here reads the process environment)
-    C.hji_seed = 0; C.clip_guess = 1; C.ck_riccati = 1; C.warm_trivial_cold = 1; C.hji_rounds = 0;
+    C.hji_seed = 0; C.clip_guess = 1; C.clip_stops = 0; C.ck_riccati = 1; C.warm_trivial_cold = 1; C.hji_rounds = 0;
     // horizons up to 32 intervals keep their dynamics blocks resident in LDS (one pass over the QP data); longer ones stream them through a 4-slot ring
     h->solve_ring = N > 32;
 #ifdef PG_EXPERIMENTAL_SOLVE4
     h->solve4_lds = lds4_bytes(N);
 #endif
-    h->solve_lds = (size_t)((h->solve_ring ? 4 : N) * SB + 10 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 72 + 100 + 8 + 64 + 2 + 2 * N) * sizeof(real);
+    h->solve_lds = (size_t)((h->solve_ring ? 4 : N) * SB + 10 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 72 + 100 + 8 + 64 + 2 + 2 * N + N) * sizeof(real);
     if (h->solve_lds > 160 * 1024) { g_create_error = "horizon too long for LDS staging"; free_all(h); delete h; return PG_ERR_INVALID; }
     // hipFuncSetAttribute applies to the CURRENT DEVICE's copy of a kernel, and a later handle with a shorter horizon must not lower the limit an earlier handle of the same
     // device relies on: the largest size asked for so far is kept per device ordinal
@@ -358,6 +359,7 @@ static bool find_option(pg_handle* h, const char* name, OptRef* o) {
     const std::string n(name);
     // k_solve (coupled QP)
     if (n == "clip_guess") return I(&C.clip_guess, 0, 1);
+    if (n == "clip_stops") return I(&C.clip_stops, 0, 1);
     if (n == "ck_riccati") return I(&C.ck_riccati, 0, 1);
     if (n == "warm_trivial_cold") return I(&C.warm_trivial_cold, 0, 1);
     if (n == "hji_seed") return I(&C.hji_seed, 0, 4);
@@ -561,7 +563,7 @@ int pg_reset(pg_handle* h, const uint8_t* mask) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int cap = h->cfg.batch_capacity;
     h->warm_B = 0; h->order_B = 0;
-    if (!mask) { HIPCHK(h, hipMemsetAsync(h->d_solved, 0, (size_t)cap * sizeof(int), h->stream)); HIPCHK(h, hipMemsetAsync(h->d_wfail, 0, (size_t)cap * sizeof(int), h->stream)); return PG_OK; }
+    if (!mask) { HIPCHK(h, hipMemsetAsync(h->d_solved, 0, (size_t)2 * cap * sizeof(int), h->stream)); return PG_OK; }      // (solved flags and the back-off words behind them: one fill)
     REQUIRE(h, h->B > 0, "pg_reset with a mask needs inputs installed (B known)");
     HIPCHK(h, hipMemcpyAsync(h->d_mask, mask, h->B, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_reset, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, h->B, h->d_mask, h->d_solved, h->d_wfail);
@@ -665,12 +667,12 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
     const size_t cap = (size_t)h->cfg.batch_capacity;
     const bool file = h->dc.formulation != PG_DECOUPLED && h->dc.polish;
     int* const order_cnt = file ? h->d_order + cap : (int*)nullptr;            // the two counters of the launch order start from zero: the projection kernel clears them (no memset of its own)
-    int* const todo_cnt = h->d_todo + cap + h->solve_parity;                   // ... and the to-do counter this step's solve launch counts into (launch_solve)
+    int* const solve_ctl = h->d_todo + cap;                                    // ... and the control words of this step's solve launches (launch_solve): the to-do counter it counts into
     h->cnt_cleared = !h->sg.capturing;
     if (with_time_grid) hipLaunchKernelGGL(k_project<true>, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep, h->d_t0, h->d_ts, h->d_dt, h->d_prev_ts,
-                                           pipelined ? h->d_progress : (int*)nullptr, (B + 63) / 64 + 1, order_cnt, todo_cnt);      // (+ 1: the fault word of the pipelined launch)
+                                           pipelined ? h->d_progress : (int*)nullptr, (B + 63) / 64 + 1, order_cnt, solve_ctl, h->solve_parity);      // (+ 1: the fault word of the pipelined launch)
     else hipLaunchKernelGGL(k_project<false>, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep, (const double*)nullptr, (double*)nullptr, (double*)nullptr,
-                            (double*)nullptr, (int*)nullptr, 0, order_cnt, todo_cnt);
+                            (double*)nullptr, (int*)nullptr, 0, order_cnt, solve_ctl, h->solve_parity);
     LAUNCH_CHECK(h);
     const bool staged = h->dc.n_traj == 1 && h->traj_L <= 2048;
     const size_t traj_lds = staged ? (size_t)2 * h->traj_L * sizeof(real) : 0;
@@ -816,7 +818,7 @@ int pg_update_qp(pg_handle* h) {
 }
 // k_solve over `n` instances on stream `st`: the whole batch in index order (order == nullptr) or the sub-range order[0..n) of the launch order
 static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, unsigned long long* lat_prof = nullptr) {
-    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, order, h->d_wfail, nullptr, nullptr, nullptr, nullptr, nullptr};
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, order, h->d_wfail, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) { hipLaunchKernelGGL((k_solve4<2, false>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, (unsigned long long*)nullptr); LAUNCH_CHECK(h); return PG_OK; }
 #endif
@@ -844,6 +846,7 @@ static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, u
         LAUNCH_CHECK(h);
         return PG_OK;
     }
+    if (h->u_direct) { O.u_out2 = h->u_direct; h->u_written = true; }      // (every k_solve instantiation below writes the caller's array itself)
     if (h->solve_ring) hipLaunchKernelGGL((k_solve<false, true, false>), dim3(n), dim3(64), h->solve_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
     else if (h->split_solve && h->dc.polish && (h->dc.cold_guess > 0 || h->dc.warm_polish) && !h->has_hji && !h->sg.capturing) {
         // Two launches: the rounds-only instantiation (no scratch: the interior point's state and code are not in it) serves the instances an active-set attempt
@@ -858,7 +861,7 @@ static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, u
         // alternately -- this launch counts into one while the other still holds the previous launch's count --; the projection kernel of the step zeroes the one about to be
         // used (a solve without a nodes phase in front -- replayed QPs -- zeroes it here).
         const size_t cap = (size_t)h->cfg.batch_capacity;
-        int* const cnt = h->d_todo + cap + h->solve_parity; const int* const prev = h->d_todo + cap + (h->solve_parity ^ 1);
+        int* const ctl = h->d_todo + cap; int* const cnt = ctl + h->solve_parity; const int* const prev = ctl + (h->solve_parity ^ 1);
         if (!h->cnt_cleared) HIPCHK(h, hipMemsetAsync(cnt, 0, sizeof(int), st));
         h->cnt_cleared = false; h->solve_parity ^= 1; h->stat_split++;
         O.todo = h->d_todo; O.n_todo = cnt; O.mode = prev;
@@ -910,7 +913,8 @@ static int update_and_solve(pg_handle* h, hipEvent_t after_update) {
     if ((rc = launch_hji_rows(h))) return rc;
     if (after_update) HIPCHK(h, hipEventRecord(after_update, h->stream));
     const bool use_order = h->dc.polish && h->order_B == h->B;
-    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, use_order ? h->d_order : nullptr, h->d_wfail, nullptr, nullptr, nullptr, nullptr, nullptr};
+    SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam, use_order ? h->d_order : nullptr, h->d_wfail, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (h->u_direct) { O.u_out2 = h->u_direct; h->u_written = true; }
     hipLaunchKernelGGL((k_solve<false, false, true>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
     LAUNCH_CHECK(h);
     if (h->B > h->warm_B) h->warm_B = h->B;
@@ -924,14 +928,19 @@ int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     HIPCHK(h, hipMalloc((void**)&d, ((size_t)h->B * 9 + 1024) * 8));
     HIPCHK(h, hipMemset(d, 0, ((size_t)h->B * 9 + 1024) * 8));
     SolveOut O{h->d_solx, h->d_sigma, h->d_u, h->d_status, h->d_iters, h->d_active, h->d_mu, h->d_solved, h->d_polish, h->d_lam,
-               (h->dc.polish && h->order_B == h->B) ? h->d_order : nullptr, h->d_wfail, nullptr, nullptr, nullptr, nullptr, nullptr};            // (the launch order pg_solve would use: the timeline is the product's)
+               (h->dc.polish && h->order_B == h->B) ? h->d_order : nullptr, h->d_wfail, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};            // (the launch order pg_solve would use: the timeline is the product's)
     if (h->solve_lat) { if ((rc = launch_solve(h, h->stream, nullptr, h->B, d))) { (void)hipFree(d); return rc; } } else
 #ifdef PG_EXPERIMENTAL_SOLVE4
     if (h->solve_quad) hipLaunchKernelGGL((k_solve4<2, true>), dim3((h->B + 3) / 4), dim3(64), h->solve4_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, h->d_ws4, O, d);
     else
 #endif
     if (h->solve_ring) hipLaunchKernelGGL((k_solve<true, true, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, d, h->d_dt, h->d_Mb);
-    else if (h->debug_timeline) hipLaunchKernelGGL((k_solve<false, false, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, d, h->d_dt, h->d_Mb);      // the product's kernel: timeline only
+    else if (h->debug_timeline) {      // the product's kernel (the rounds-only instantiation of the split launch): timeline only
+        int* const cnt = h->d_todo + (size_t)h->cfg.batch_capacity + 4;
+        HIPCHK(h, hipMemsetAsync(cnt, 0, sizeof(int), h->stream));
+        O.todo = h->d_todo; O.n_todo = cnt;
+        hipLaunchKernelGGL((k_solve<false, false, false, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, d, h->d_dt, h->d_Mb);
+    }
     else hipLaunchKernelGGL((k_solve<true, false, false>), dim3(h->B), dim3(64), h->solve_lds, h->stream, h->dc, h->B, h->d_qp, h->d_nodes, O, d, h->d_dt, h->d_Mb);
     LAUNCH_CHECK(h);
     HIPCHK(h, hipMemcpy(out, d, ((size_t)h->B * 9 + 1024) * 8, hipMemcpyDeviceToHost));      // out: [B][6] cycles + 1024-double trace of the "diag_instance" instance + [B][3] timeline (k_solve: entry, exit on the 100 MHz wall clock, HW_ID | XCC_ID << 32)
@@ -983,8 +992,11 @@ int pg_step_dev(pg_handle* h, void* u_out_dev) {
     if (ev) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     if ((rc = launch_nodes(h, true))) return rc;
     if (ev) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-    if ((rc = update_and_solve(h, ev ? h->ev[2] : nullptr))) return rc;       // (chunked: ev[2] marks the end of the LAST update_QP chunk; earlier solve chunks run under it)
-    if ((rc = pg_get_next_control_dev(h, u_out_dev))) return rc;
+    h->u_direct = (real*)u_out_dev; h->u_written = false;
+    rc = update_and_solve(h, ev ? h->ev[2] : nullptr);       // (chunked: ev[2] marks the end of the LAST update_QP chunk; earlier solve chunks run under it)
+    h->u_direct = nullptr;
+    if (rc) return rc;
+    if (!h->u_written && (rc = pg_get_next_control_dev(h, u_out_dev))) return rc;      // (k_solve writes the caller's array itself; the lateral kernel's controls are copied)
     if (ev) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
     h->timing_valid = ev;
     return PG_OK;

@@ -36,6 +36,7 @@ struct DevCfg {
     int hji_rounds;               // k_solve: working sets such a seeded attempt may try (0: the cold-guess cap and its extension)
     int warm_trivial_cold;        // k_solve: a warm instance whose previous working set was empty starts like a cold one (option "warm_trivial_cold", default 1)
     int ck_riccati;               // k_solve (rounds-only instantiation): restart the matrix recursion of a round at its checkpoint when the working set allows (option "ck_riccati", default 1)
+    int clip_stops;               // k_solve: ... and the steering angle at its stops (option "clip_stops")
     int clip_guess;               // k_solve, cold instances: the first roll-out clips the steering rate at its limits and the clipped transitions are the first working set (option "clip_guess", default 1)
     int hji_seed;                 // k_solve: rounds of an instance whose safety row is violated at the current control start from a seeded working set (0: interior point, as before)
     int cold_guess;               // > 0: a COLD instance first tries the polish from the empty active set (unconstrained LQ optimum + add/drop rounds), at most this many rounds
@@ -135,11 +136,11 @@ PG_DEV void time_grid_lane(const DevCfg& C, int i, double t, double* T, double* 
 // arithmetic in that instantiation only).
 template <bool TG> __global__ __launch_bounds__(256) void k_project(DevCfg C, int B, const real* __restrict__ state, real* __restrict__ sep, const double* __restrict__ t0, double* __restrict__ ts,
                                                  double* __restrict__ dt, double* __restrict__ prev_ts, int* __restrict__ progress = nullptr, int n_progress = 0, int* __restrict__ order_cnt = nullptr,
-                                                 int* __restrict__ todo_cnt = nullptr) {
+                                                 int* __restrict__ solve_ctl = nullptr, int ctl_parity = 0) {
     int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (progress && blockIdx.x == 0) { for (int i = threadIdx.x; i < n_progress; i += blockDim.x) progress[i] = 0; }      // (k_nodes_linearize of this step counts from 0)
     if (order_cnt && blockIdx.x == 0 && threadIdx.x < 2) order_cnt[threadIdx.x] = 0;                                       // (the launch order the nodes kernel files: both counters from 0)
-    if (todo_cnt && blockIdx.x == 0 && threadIdx.x == 2) *todo_cnt = 0;                                                     // (the to-do counter of this step's solve launch)
+    if (solve_ctl && blockIdx.x == 0 && threadIdx.x == 2) solve_ctl[ctl_parity] = 0;                                        // (the to-do counter of this step's solve launch)
     if (wave >= B) return;
     if constexpr (TG) time_grid_lane(C, lane, t0[wave], ts + (size_t)wave * C.NN, dt + (size_t)wave * C.N, prev_ts + (size_t)wave * C.NN);
     const TrajView T = traj_of(C, wave);
@@ -1170,8 +1171,9 @@ struct SolveOut { real* sol_x; real* sol_sigma; real* u_out; int* status; int* i
                   const int* order_in; int* wfail;         // wfail: k_solve_lat's back-off word per instance (nullptr: none)
                   int* todo; int* n_todo;                  // rounds-only k_solve: instances left for the full kernel, and how many
                   const int* list; const int* n_list;      // full k_solve in list mode: the instances to solve (interior point at once), and how many
-                  const int* mode; };                      // split launch of k_solve: the PREVIOUS launch's count of instances that needed the interior point (a stream-ordered device word).
+                  const int* mode;                         // split launch of k_solve: the PREVIOUS launch's count of instances that needed the interior point (a stream-ordered device word).
                                                            // Non-zero: the rounds-only kernel returns at once and the full kernel takes the whole batch in its launch order instead of the list
+                  real* u_out2; };                         // pg_step_dev: the caller's control array, written next to u_out (saves the device-to-device copy behind the launch); may be nullptr
 
 #define NROW 16
 #define PG_POLISH_ROUNDS 6      // active-set rounds of the polish before it gives up
@@ -1253,15 +1255,18 @@ PG_DEV void wave_sync() {
 template <bool PROF, bool RING, bool FUSE, bool IPM = true>
 __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg C, int B, real* qp, const real* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof,
                                                                           const tdouble* __restrict__ dt_grid, const real* __restrict__ hji_Mb) {
-    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
-    auto stamp = [&](int slot) { if (PROF) { unsigned long long now = clock64(); pc[slot] += now - tprev; tprev = now; } };
-    if (PROF) tprev = clock64();
-    const unsigned long long t_entry = (PG_TL && prof) ? wall_clock64() : 0ull;
-    // Launch order: workgroup i solves instance order_in[i] when an order is supplied (filed by the nodes kernels, likely stragglers first: see OrderOut)
+    // Launch order: slot i of the launch is instance order_in[i] when an order is supplied (filed by the nodes kernels, likely stragglers first: see OrderOut)
     const bool whole = O.mode && *O.mode != 0;                  // (wave-uniform: a scalar load)
     if constexpr (!IPM) { if (whole) return; }                 // the full kernel behind this launch serves the whole batch
     const bool listm = O.n_list && !whole;
     if (listm && (int)blockIdx.x >= *O.n_list) return;         // list mode: nothing left for this block
+    // (Round 5, measured and removed: a PERSISTENT grid -- one block per wavefront slot, further instances pulled from a counter -- to save the 4.4 us between the exit of a
+    //  wavefront and the entry of the next one on its SIMD.  Same launch time with and without (0.319 / 0.319 ms at 4096 instances): the gap is the prologue's first round trip to
+    //  memory, not the dispatch; and the loop-carried register pressure cost the kernel 4 % and the full instantiation 80 B of scratch.  EXPERIMENTS.md 11.)
+    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int slot_) { if (PROF) { unsigned long long now = clock64(); pc[slot_] += now - tprev; tprev = now; } };
+    if (PROF) tprev = clock64();
+    const unsigned long long t_entry = (PG_TL && prof) ? wall_clock64() : 0ull;
     const int b = listm ? O.list[blockIdx.x] : (O.order_in ? O.order_in[blockIdx.x] : (int)blockIdx.x), lane = threadIdx.x;
     const int N = C.N, NN = C.NN;
     // FUSE: update_QP! of this instance first, by the wave that is about to solve it -- lane pair (2t, 2t+1) linearises interval t (2N <= 64; lanes beyond 2N mirror
@@ -1294,6 +1299,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     real* sDum = sx0 + 8;              // [64] sink for predicated-off stores (keeps the pass loops branch-free)
     real* sZero = sDum + 64;           // [2]  a stored 0.0 (off-pattern entries of Qhat)
     real* skf_ck = sZero + 2;          // [N][2] the predictor's feed-forward terms as the matrix pass left them (skf itself is rewritten by every vector pass): restored when the recursion restarts at its checkpoint
+    real* sG = skf_ck + 2 * N;         // [N]    held steering-rate rows (eliminated exactly, see `hmask`): gradient of the Lagrangian in the pinned input = -/+ the row's multiplier
 
     const QpOff o = qp_offsets(N);
     const real* Q = qp + (size_t)b * C.qp_len;
@@ -1423,6 +1429,18 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     // Headline batch: rounds 1 / 2 / 3 / 4+ 2105 / 714 / 928 / 349 -> 2105 / 1552 / 372 / 67 instances (mean 1.97 -> 1.62), k_solve 0.386 -> 0.334 ms.  Measured and dropped:
     // clipping in every round (11 instances end in the interior point), clipping at the steering stops as well (fp64: 3-round instances 372 -> 418, 4+ 67 -> 21, same time; fp32: more 9-12 round instances, 0.34 -> 0.43 ms; and the code alone costs 4 % in the roll-out).  Option "clip_guess" = 0: off.
     bool clip_now = false, clip_used = false, clip_off = false; unsigned clip_mask = 0u;
+    // Held steering-RATE rows (12, 13) are eliminated EXACTLY (round 5): such a row pins the first input of its stage, v0 = +ddmax / -ddmin, so the stage is solved for the
+    // second input alone -- K0 = 0, kff0 = the pinned value, (K1, kff1) from the 1 x 1 pivot S11 with the cross term S01 v0 in its right-hand side -- and the row's
+    // multiplier is read off the stationarity condition in v0 after the roll-out: lambda = -/+ (F0 x + f0 + S00 v0 + S01 v1).  No penalty, no multiplier iteration: a working set
+    // of rate rows and slack pivots (every two- and three-round instance of a cold tracking batch) verifies at its first check, without the refinement pass the augmented
+    // Lagrangian needed to bring |t| of its held rows below the tolerance (vector pass + roll-out: 13 of the ~37 us of such an instance's last round).
+    // hmask: stages with a held rate row (wave-uniform, bit = stage lane); vfix: the pinned value in the stage's lane.
+    unsigned long long hmask = 0ull; real vfix = real(0.0);
+#if !defined(PG_NO_MFMA)
+    constexpr bool EXR = true;
+#else
+    constexpr bool EXR = false;        // (the VALU fall-back of the matrix pass keeps the penalty form)
+#endif
     auto forward = [&](auto use_gain_t, bool delta = false) {      // delta: the roll-out of a CORRECTION (starts at 0, no affine term: see the polish refinement)
         constexpr bool use_gain = decltype(use_gain_t)::value;
         const int f16 = lane & 15;
@@ -1451,10 +1469,24 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             real d = d0 + d1;
             if (!use_gain) d = isK ? real(0.0) : d;            // v = 0 roll-out of the first start
             real v0 = rl(d, 8); const real v1 = rl(d, 9);
+            if constexpr (EXR && use_gain) {      // held rate row of this stage: lane 8 has evaluated F0 x + f0 (its slots of sK / skf hold F0 / f0 there), the input is the pinned value
+                const bool hk = (hmask >> k) & 1ull;
+                const real vf = delta ? real(0.0) : rl(vfix, k);
+                const real g = v0 + (sSi[4 * k] * vf + sSi[4 * k + 1] * v1);
+                *((lane == 2 && hk) ? sG + k : sDum + lane) = g;
+                v0 = hk ? vf : v0;
+            }
             if (clip_now) {        // (wave-uniform; first round of a cold instance) saturated roll-out: the gain of the unconstrained problem, the steering rate held inside its limits
                 const real hi = rl(bb[12], k), lo = -rl(bb[13], k);
-                if (v0 > hi) { v0 = hi; if (lane == k) clip_mask |= 1u << 12; }
-                else if (v0 < lo) { v0 = lo; if (lane == k) clip_mask |= 1u << 13; }
+                unsigned cm = 0u;
+                if (v0 > hi) { v0 = hi; cm = 1u << 12; }
+                else if (v0 < lo) { v0 = lo; cm = 1u << 13; }
+                if (C.clip_stops != 0) {      // ... and the steering angle inside its stops: a ramp that reaches the stop ends there, and the stop's rows are part of the guess
+                    const real dn = xm[6] + v0, smax = rl(bb[3], k), smin = -rl(bb[4], k);
+                    if (dn > smax) { v0 = smax - xm[6]; cm = (v0 < hi ? 0u : cm) | (1u << 3); }
+                    else if (dn < smin) { v0 = smin - xm[6]; cm = (v0 > lo ? 0u : cm) | (1u << 4); }
+                }
+                if (lane == k) clip_mask |= cm;
             }
             const real xr = d + (bf0 * v0 + bf1 * v1);
             // arithmetic blend instead of ?: so that the compiler keeps the LDS reads above unconditional (a branch here serialises them)
@@ -1488,7 +1520,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             // Same shape as the barrier terms: W = rho, constant part of the multiplier = y - rho b.
 #pragma unroll
             for (int j = 0; j < NROW; j++) {
-                const bool a = j < nrows && ((amask >> j) & 1u);
+                const bool a = j < nrows && ((amask >> j) & 1u) && !(EXR && (j == 12 || j == 13));      // (held rate rows: eliminated exactly in the recursion, not penalised)
                 W[j] = a ? rho : real(0.0);
                 ell[j] = a ? R.lam[j] - rho * bb[j] : real(0.0);
             }
@@ -1642,14 +1674,17 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             // rows 8, 9 of C: F = Bbar' M_A (c < 8), S - Rhat (c = 8, 9), Bbar' y (c = 10)
             real F0c, F1c; rows89(Cc, F0c, F1c);
             const real S00 = R0 + rl(F0c, 8), S01 = rl(F0c, 9), S11 = R1 + rl(F1c, 9);
-            const real idet = frcp(S00 * S11 - S01 * S01);
-            const real I00 = S11 * idet, I01 = -S01 * idet, I11 = S00 * idet;
+            const bool hk = EXR && ((hmask >> k) & 1ull);                           // the stage's rate row is held: its first input is pinned at vfk (wave-uniform)
+            const real vfk = EXR ? rl(vfix, k) : real(0.0);
+            const real idet = frcp(hk ? S11 : S00 * S11 - S01 * S01);
+            const real I00 = hk ? real(0.0) : S11 * idet, I01 = hk ? real(0.0) : -S01 * idet, I11 = hk ? idet : S00 * idet;
             const real K0 = -(I00 * F0c + I01 * F1c), K1 = -(I01 * F0c + I11 * F1c);
             const real f0 = r0v + F0c, f1 = r1v + F1c;                              // (meaningful in column 10)
-            const real kf0 = -(I00 * f0 + I01 * f1), kf1 = -(I01 * f0 + I11 * f1);
-            *((mg < 2 && mc < 8) ? sK + 16 * k + 8 * mg + mc : sDum + lane) = mg == 0 ? K0 : K1;
-            *(lane < 3 ? sSi + 4 * k + lane : sDum + lane) = lane == 0 ? I00 : (lane == 1 ? I01 : I11);
-            *((mc == 10 && mg < 2) ? skf + 2 * k + mg : sDum + lane) = mg == 0 ? kf0 : kf1;
+            const real kf0 = hk ? vfk : -(I00 * f0 + I01 * f1), kf1 = -(I01 * f0 + I11 * (hk ? f1 + S01 * vfk : f1));
+            // (a pinned stage leaves F0, f0, S00, S01 where the roll-out finds them -- in the slots of the absent gain row -- for the row's multiplier)
+            *((mg < 2 && mc < 8) ? sK + 16 * k + 8 * mg + mc : sDum + lane) = mg == 0 ? (hk ? F0c : K0) : K1;
+            *(lane < 3 ? sSi + 4 * k + lane : sDum + lane) = lane == 0 ? (hk ? S00 : I00) : (lane == 1 ? (hk ? S01 : I01) : I11);
+            *((mc == 10 && mg < 2) ? skf + 2 * k + mg : sDum + lane) = mg == 0 ? (hk ? f0 : kf0) : kf1;
             // C += F' [K | kff]
             const real a3 = mg == 0 ? F0c : (mg == 1 ? F1c : real(0.0));
             const real b3 = mg == 0 ? (mc == 10 ? kf0 : K0) : (mg == 1 ? (mc == 10 ? kf1 : K1) : real(0.0));
@@ -1767,6 +1802,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             for (int m = 0; m < 6; m++) { a6[m] = Ak[SB_ROW * m + r8]; b0[m] = Bk[2 * m]; b1[m] = Bk[2 * m + 1]; }
             real mc = delta ? real(0.0) : sMc[8 * k + r8], qk = sq[8 * k + r8], k0 = sK[16 * k + r8], k1 = sK[16 * k + 8 + r8], r0 = sr[2 * k], r1 = sr[2 * k + 1];
             real I00 = sSi[4 * k], I01 = sSi[4 * k + 1], I11 = sSi[4 * k + 2];
+            const bool hk = EXR && ((hmask >> k) & 1ull);      // pinned first input (held rate row; only ever in a correction pass, where the pinned value is 0): no gain row, 1 x 1 pivot
+            if (hk) { k0 = real(0.0); I00 = real(0.0); I01 = real(0.0); }
             real yi = mc + pi;
             real y[8];
 #pragma unroll
@@ -1780,7 +1817,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             }
             f0 += f0b; f1 += f1b;
             pi = (acc + accb) + (k0 * f0 + k1 * f1);          // (k == 0: never used)
-            *(lane < 2 ? skf + 2 * k + lane : sDum + lane) = lane == 0 ? -(I00 * f0 + I01 * f1) : -(I01 * f0 + I11 * f1);
+            *(lane < 2 ? skf + 2 * k + lane : sDum + lane) = lane == 0 ? (hk ? f0 : -(I00 * f0 + I01 * f1)) : -(I01 * f0 + I11 * f1);
         }
         __syncthreads();
     };
@@ -1828,7 +1865,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     for (int attempt = listm ? 0 : (warm ? -2 : (guess ? -1 : 0)); attempt < (IPM ? 2 : 0); attempt++) {
     if (attempt == -1 && !guess) continue;
     rp0 = real(0.0); phi = real(1.0); pmode = 0; pstat = 0; polish_gave_up = false; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu; cycle_broken = false; settle_used = false; settle_left = 0; good_steps = 0;
-    warm_attempt = attempt < 0; from_prev = attempt == -2;
+    warm_attempt = attempt < 0; from_prev = attempt == -2; hmask = 0ull;
     if (!IPM || attempt < 0) {
         amask = (act && from_prev) ? (unsigned)O.active[(size_t)b * N + s] : 0u; mask_ipm = amask;
 #pragma unroll
@@ -1942,10 +1979,15 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
         // (a roll-out that clipped the steering rate is not the optimum of its working set: no multiplier update, no drops -- its clipped transitions join the set)
         const bool clipped = __any(clip_mask != 0u);
         if (clipped) { add = act ? (clip_mask & ~amask) : 0u; settled = false; clip_used = true; }
+        if constexpr (EXR) {      // held rate rows: the multiplier IS minus / plus the gradient in the pinned input the roll-out left in sG (t = 0 exactly)
+            const real g = sG[s];
+            const bool h12 = act && (amask & (1u << 12)) != 0u, h13 = act && !h12 && (amask & (1u << 13)) != 0u;
+            R.lam[12] = h12 ? -g : R.lam[12]; R.lam[13] = h13 ? g : R.lam[13];      // (selects: a conditional store to either slot sends both to scratch)
+        }
 #pragma unroll
         for (int j = 0; j < NROW; j++) {
             const bool on = act && j < nrows, a = (amask >> j) & 1u;
-            if (a && !clipped) R.lam[j] -= rho * tp[j];
+            if (a && !clipped && !(EXR && (j == 12 || j == 13))) R.lam[j] -= rho * tp[j];
             if (on && a && !clipped && R.lam[j] < real(0.0)) drop |= 1u << j;
             if (on && a && !(fabs(tp[j]) <= ttol)) settled = false;            // written so that a NaN never verifies
             if (on && !a && !(tp[j] >= -ptol)) add |= 1u << j;
@@ -2099,7 +2141,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             const int end_up = __ffsll((long long)~run_up) - 1, end_dn = __ffsll((long long)~run_dn) - 1;      // first stage outside the run (lanes >= N are never in it)
             if (s < end_up) amask &= ~(overshoot & (1u << 12));
             if (s < end_dn) amask &= ~(overshoot & (1u << 13));
-        }
+            if constexpr (EXR) { hmask = __ballot(act && (amask & 0x3000u) != 0u); vfix = (amask & (1u << 12)) ? bb[12] : -bb[13]; }
+        } else hmask = 0ull;
 
         // ---- predictor (sigma = 0, no correction) / first polish solve ----
 #pragma unroll
@@ -2296,6 +2339,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
         if (C.formulation == PG_DECOUPLED) Fx = nodes[((size_t)b * NN + 1) * 10 + 7];      // decoupled_lat_long.jl:275-278: Fx of the seeded node 2
         real* U = O.u_out + (size_t)b * 3;
         U[0] = d; U[1] = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac; U[2] = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
+        if (O.u_out2) { real* U2 = O.u_out2 + (size_t)b * 3; U2[0] = U[0]; U2[1] = U[1]; U2[2] = U[2]; }
         O.status[b] = status; O.iters[b] = it; O.mu[b] = mu; O.polish[b] = pstat;
         O.solved[b] = 1;      // model_predictive_control.jl:76: solved = true
     }

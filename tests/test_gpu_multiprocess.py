@@ -51,7 +51,7 @@ def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` started as a plain process spawns its two ranks itself (before touching the GPU) and rank 0 prints ONE JSON line with
     n_gpus = 2 and the whole-job rate (here in the gloo test mode, ranks sharing the GPU)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--batch", "512",
-                        "--no-cpu-baseline", "--no-hji", "--no-decoupled", "--no-f32"], capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--no-hji", "--no-decoupled", "--no-f32", "--full-record", os.devnull], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -66,7 +66,7 @@ def test_config4_workload_line_over_two_ranks():
     that configuration, carries the whole-job rate over the max-over-ranks time and the per-rank times, and -- a scaling run being the timed loop, the gather check and
     one JSON line -- none of the secondary objects rank 0 would otherwise build while the other ranks wait."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--batch", "8192",
-                        "--precision", "f32"], capture_output=True, text=True, timeout=900)
+                        "--precision", "f32", "--full-record", os.devnull], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -97,7 +97,7 @@ def test_bench_scaling_line_over_four_ranks_is_compact():
     carry (its process guard allows 6 GPU processes: this test process + 4 ranks; the 8-rank shard / gather logic runs in tests/test_distributed_gloo.py on the CPU).
     The LAST stdout line is the compact record: strict JSON within 4 KB with the contract keys, `ranks`, `collective` and `per_rank_ms_per_step`."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--batch", "512",
-                        "--precision", "f32"], capture_output=True, text=True, timeout=900)
+                        "--precision", "f32", "--full-record", os.devnull], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
     assert len(last) <= 4096

@@ -1,7 +1,7 @@
 """Diagnostic: per-phase shader cycles inside k_solve (diagnostic kernel build with s_memtime stamps; shares, not run time), then the per-SIMD timeline of a COLD
 launch in the product's launch order: wavefront lifetimes by rounds, gaps between consecutive wavefronts of a SIMD, when the SIMDs run out of work, when the long
-instances start.  The timeline of the diagnostic kernel is stretched by its stamps (575 against 403 us); for the product's own kernel build the library with
-`make EXTRA=-DPG_TIMELINE`, point PIGEON_HIP_LIB at it and set PG_DEBUG_TIMELINE=1."""
+instances start.  The timeline of the diagnostic kernel is stretched by its stamps (575 against 403 us); for the product's own kernel build
+`make -C pigeon.jl_amd/csrc libpigeon_hip_tl.so` and run with PIGEON_HIP_LIB_DIAG=<that library> TL=1 (option "diag_timeline")."""
 import ctypes as C, sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,9 @@ from __graft_entry__ import _load_pkg
 pkg = _load_pkg()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 traj = pkg.load_path_fixture("skidpadoval")
-mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B)
+TL = os.environ.get("TL") == "1"
+KW = dict(precision="f64-diag", options={"diag_timeline": 1} if TL else {})
+mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, **KW)
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345)
 mpc.step_(state, control, t0, time_offset=toff)
 out = np.zeros(B * 9 + 1024, dtype=np.uint64)
@@ -26,7 +28,7 @@ for i, n in enumerate(names):
 
 # ---- timeline of the launch (k_solve only): per SIMD the wavefronts it ran, their entry / exit on the 100 MHz wall clock, the gaps between them
 # (a fresh handle, phases called one by one, the diagnostic solve in place of solve!: a COLD launch, in index order -- the figures above are those of the warm re-solve)
-mpc2 = pkg.BatchedTrajectoryTrackingMPC(traj, B)
+mpc2 = pkg.BatchedTrajectoryTrackingMPC(traj, B, **KW)
 mpc2.set_inputs(state, control, t0, time_offset=toff)
 mpc2.compute_time_steps_(); mpc2.compute_linearization_nodes_(); mpc2.update_QP_()
 raw = np.zeros(B * 9 + 1024, dtype=np.uint64)
