@@ -251,6 +251,8 @@ int pg_synchronize(pg_handle* h);
  *   lateral solve kernel (decoupled formulation):
  *     "lateral_solver" 0/1/2 (0) 0 = k_solve_lat beyond 20 intervals or with the polish off, else the embedding in k_solve; 1 = k_solve_lat; 2 = the embedding
  *     "lat_workspace" 0/1        k_solve_lat keeps its row state in the per-wavefront workspace at every horizon (default: beyond 32 intervals, or with walls beyond 16)
+ *     "lat_pin" 0/1 (1)          a held steering-rate row pins the input of its stage exactly in the polish (0: held through the augmented Lagrangian like every other row)
+ *     "lat_pack_only" 0/1 (1)    update_QP! of a handle solved by k_solve_lat writes the packed stage records only (the embedded block pg_get_qp returns is built on demand)
  *     "lat_split" 0/1 (1)        a step in which every instance is warm runs as two launches (warm attempts, then the cold solves of what they left)
  *     "lat_rho_scale" (1e3 in fp64, 1 in fp32)  penalty of held rows = polish_rho x this;   "lat_mu0_cost" (10), "lat_far_cost" (3e4), "lat_polish2" 0/1 (1),
  *     "lat_polish_rounds" (3), "lat_settle" 0..2 (0), "lat_warm_rounds" (2), "lat_wipm" 0/1 (0), "lat_wmu" (1e-2), "lat_wtau" (1e-4)   see pg_solve_lat.hip

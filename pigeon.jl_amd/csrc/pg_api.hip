@@ -69,6 +69,7 @@ struct pg_handle {
     size_t in_bytes = 0, out_bytes = 0, in_dbl_off = 0;        // (layout by capacity: [state 6][control 3][other 4] real, then at in_dbl_off [t0][time_offset] double; [u 3] real, [status][iters] int)
     char* h_stage = nullptr; size_t stage_bytes = 0;            // pinned host staging of pg_set_inputs / pg_step (one stream synchronisation per call instead of one per array)
     real* d_ws4 = nullptr; bool solve_quad = false; size_t solve4_lds = 0;   // k_solve4 (four instances per wavefront)
+    bool qp_embedded = true; int lat_pack_only = 1;            // lateral formulation: the embedded QP block is current (k_qp_dec wrote it) / option "lat_pack_only": steps write the packed records only
     bool solve_lat = false; size_t lat_lds = 0;               // lateral formulation: its own kernel k_solve_lat (option "lateral_solver" = 2 keeps the embedding in k_solve)
 };
 
@@ -256,7 +257,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     // N = 50 (12.6 against 5.9).  Option "lateral_solver" = 1 / 2 forces the choice (configure_lateral below).
     if (cfg->formulation == PG_DECOUPLED) {
         // defaults of k_solve_lat's tuning options (pg_set_option)
-        C.lat_mu0_cost = real(10.0); C.lat_polish2 = 1; C.lat_far_cost = real(3e4); C.lat_rho_scale = sizeof(real) == 8 ? real(1e3) : real(1.0); C.lat_polish_rounds = 3; C.lat_settle = 0;
+        C.lat_mu0_cost = real(10.0); C.lat_pin = 1; C.lat_polish2 = 1; C.lat_far_cost = real(3e4); C.lat_rho_scale = sizeof(real) == 8 ? real(1e3) : real(1.0); C.lat_polish_rounds = 3; C.lat_settle = 0;
         C.lat_warm_rounds = 2;      /* (2 since the two-launch warm step: an attempt that needs a third working set is cheaper to hand to the cold list: 2.03 -> 1.95 ms, 2.9 -> 2.7 with walls) */
         C.lat_wipm = 0; C.lat_wmu = real(1e-2); C.lat_wtau = real(1e-4);
         std::string why;
@@ -374,7 +375,9 @@ static bool find_option(pg_handle* h, const char* name, OptRef* o) {
     // k_solve_lat (lateral QP)
     if (n == "lateral_solver") return I(&h->lateral_solver, 0, 2);
     if (n == "lat_split") return I(&h->split_lat, 0, 1);
+    if (n == "lat_pack_only") return I(&h->lat_pack_only, 0, 1);
     if (n == "lat_polish2") return I(&C.lat_polish2, 0, 1);
+    if (n == "lat_pin") return I(&C.lat_pin, 0, 1);
     if (n == "lat_polish_rounds") return I(&C.lat_polish_rounds, 2, 64);
     if (n == "lat_settle") return I(&C.lat_settle, 0, 2);
     if (n == "lat_warm_rounds") return I(&C.lat_warm_rounds, 0, 64);
@@ -809,8 +812,11 @@ int pg_update_qp(pg_handle* h) {
     const int B = h->B; const DevCfg& C = h->dc;
     if (C.formulation == PG_DECOUPLED) {
         long nt = (long)B * C.N;
-        hipLaunchKernelGGL(k_qp_dec, dim3((unsigned)((nt + 127) / 128)), dim3(128), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_qp);
+        // (a handle whose solver is k_solve_lat needs the packed stage records only: the embedded block is built when pg_get_qp asks for it)
+        const int embed = (h->solve_lat && h->lat_pack_only) ? 0 : 1;
+        hipLaunchKernelGGL(k_qp_dec, dim3((unsigned)((nt + 127) / 128)), dim3(128), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_qp, embed);
         LAUNCH_CHECK(h);
+        h->qp_embedded = embed != 0;
         return PG_OK;
     }
     if ((rc = launch_hji_rows(h))) return rc;
@@ -1148,11 +1154,23 @@ int pg_get_path_coordinates(pg_handle* h, double* sep) {
 int pg_get_qp(pg_handle* h, int32_t b0, int32_t n, double* out) {
     int rc = check_ready(h); if (rc) return rc;
     REQUIRE(h, out && b0 >= 0 && n >= 1 && b0 + n <= h->B, "pg_get_qp: range outside the batch");
+    if (h->dc.formulation == PG_DECOUPLED && !h->qp_embedded) {      // the last update_QP! of this lateral handle wrote the packed records only: the embedded block now, from the same nodes
+        const long nt = (long)h->B * h->dc.N;
+        hipLaunchKernelGGL(k_qp_dec, dim3((unsigned)((nt + 127) / 128)), dim3(128), 0, h->stream, h->dc, h->B, h->d_nodes, h->d_dt, h->d_qp, 1);
+        LAUNCH_CHECK(h);
+        h->qp_embedded = true;
+    }
     return down(h, out, h->d_qp + (size_t)b0 * h->dc.qp_len, (size_t)n * h->dc.qp_len);
 }
 int pg_set_qp(pg_handle* h, int32_t b0, int32_t n, const double* in) {
     int rc = check_ready(h); if (rc) return rc;
     REQUIRE(h, in && b0 >= 0 && n >= 1 && b0 + n <= h->B, "pg_set_qp: range outside the batch");
+    if (h->dc.formulation == PG_DECOUPLED && !h->qp_embedded) {      // (a partial install on top of a step that wrote the packed records only: complete the embedded block first)
+        const long nt_ = (long)h->B * h->dc.N;
+        hipLaunchKernelGGL(k_qp_dec, dim3((unsigned)((nt_ + 127) / 128)), dim3(128), 0, h->stream, h->dc, h->B, h->d_nodes, h->d_dt, h->d_qp, 1);
+        LAUNCH_CHECK(h);
+        h->qp_embedded = true;
+    }
     if ((rc = up(h, h->d_qp + (size_t)b0 * h->dc.qp_len, in, (size_t)n * h->dc.qp_len))) return rc;
     if (h->solve_lat) {      // k_solve_lat reads the packed stage records: refresh them from the installed block
         const long nt = (long)n * h->dc.N;

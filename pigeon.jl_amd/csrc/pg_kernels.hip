@@ -50,6 +50,7 @@ struct DevCfg {
     int walls;                    // build-defined extension: soft rows edge_R - sw <= e <= edge_L + sw, sw >= 0 at nodes 2..N+1 (decoupled formulation only)
     real wall_weight;           // linear penalty on sw (per second, like W_beta)
     real* wall_edges;           // [B][N][2] (edge_L, edge_R) at node k+1, written by k_nodes_dec, read by k_solve
+    int lat_pin;                // k_solve_lat: a held steering-rate row pins the input of its stage exactly (1; 0 = every held row through the augmented Lagrangian, as in round 4)
     int lat_polish2;            // k_solve_lat: the polish gets a second chance behind the resumed interior point
     real lat_far_cost;          // k_solve_lat: starting cost per row beyond which the early hand-over to the polish is not tried
     real lat_mu0_cost;          // k_solve_lat: first barrier parameter = max(ipm_mu0, lat_mu0_cost x cost of the starting point per row)
@@ -809,7 +810,9 @@ PG_DEV M4d m4mul(const M4d& x, const M4d& y) { M4d r;
 // continuous Jacobians by forward mode (8 tangent directions: Uy, r, dpsi, e, delta, Fx, Ux, kappa), exact ZOH / FOH discretisation
 // (Ad = exp(A dt), G0 = int exp(A s) ds, G1 = (1/dt) int exp(A (dt - s)) s ds by Taylor series + scaling and squaring), envelope and bounds;
 // the result is written in the embedded coupled layout (QP block + the packed per-stage block k_solve streams).
-__global__ __launch_bounds__(128) void k_qp_dec(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, real* __restrict__ qp) {
+// embed = 0 (round 5; the steps of a handle whose solver is k_solve_lat): only the packed stage records and the fixed first node are written -- 92 MB instead of 283 MB per
+// 4096-instance launch of a kernel that is bound by its writes; pg_get_qp re-runs the kernel with embed = 1 when somebody asks for the embedded block.
+__global__ __launch_bounds__(128) void k_qp_dec(DevCfg C, int B, const real* __restrict__ nodes, const tdouble* __restrict__ dt, real* __restrict__ qp, int embed) {
     long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)B * C.N) return;
     int b = (int)(gid / C.N), t = (int)(gid - (long)b * C.N);
@@ -870,26 +873,29 @@ __global__ __launch_bounds__(128) void k_qp_dec(DevCfg C, int B, const real* __r
         }
         b0[i] = s0; bf[i] = sf; cd[i] = sc;
     }
-    // ---- embedded coupled layout ----
-    QpOff o = qp_offsets(C.N);
-    real* Q = qp + (size_t)b * C.qp_len;
-    real* A6 = Q + o.A + 36 * t; real* B06 = Q + o.B0 + 12 * t; real* Bf6 = Q + o.Bf + 12 * t; real* c6 = Q + o.c + 6 * t;
-    for (int i = 0; i < 36; i++) A6[i] = real(0.0);
-    for (int i = 0; i < 12; i++) { B06[i] = real(0.0); Bf6[i] = real(0.0); }
-    A6[0] = real(1.0); A6[7] = real(1.0); c6[0] = real(0.0); c6[1] = real(0.0);
-    for (int i = 0; i < 4; i++) {
-        for (int j = 0; j < 4; j++) A6[6 * (2 + i) + 2 + j] = Ad.a[4 * i + j];
-        B06[2 * (2 + i)] = b0[i]; Bf6[2 * (2 + i)] = bf[i]; c6[2 + i] = cd[i];
-    }
     // envelope and bounds (:262-272): Ux from the NEXT node's parameter, Fx from its seeded control; nothing is normalised here
     real Uxt = n1[1], Fx = n1[7];
     real Fxf = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac, Fxr = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
     Envelope e = stable_limits(C.veh, Uxt, Fxf, Fxr);
-    for (int i = 0; i < 4; i++) { Q[o.H + 8 * t + 2 * i] = e.H[i][0]; Q[o.H + 8 * t + 2 * i + 1] = e.H[i][1]; Q[o.G + 4 * t + i] = e.G[i]; }
-    Q[o.dmin + t] = jmax(e.dmin, -C.veh.delta_max); Q[o.dmax + t] = jmin(e.dmax, C.veh.delta_max);
-    Q[o.fxmax + t] = real(1.0);                                           // inert Fx slot: 0 <= 1 is never active
-    Q[o.ddmin + t] = -C.cp.deltadot_max * T; Q[o.ddmax + t] = C.cp.deltadot_max * T;
-    Q[o.dt + t] = T;
+    const real dmin_t = jmax(e.dmin, -C.veh.delta_max), dmax_t = jmin(e.dmax, C.veh.delta_max), ddmin_t = -C.cp.deltadot_max * T, ddmax_t = C.cp.deltadot_max * T;
+    // ---- embedded coupled layout ----
+    QpOff o = qp_offsets(C.N);
+    real* Q = qp + (size_t)b * C.qp_len;
+    if (embed) {
+        real* A6 = Q + o.A + 36 * t; real* B06 = Q + o.B0 + 12 * t; real* Bf6 = Q + o.Bf + 12 * t; real* c6 = Q + o.c + 6 * t;
+        for (int i = 0; i < 36; i++) A6[i] = real(0.0);
+        for (int i = 0; i < 12; i++) { B06[i] = real(0.0); Bf6[i] = real(0.0); }
+        A6[0] = real(1.0); A6[7] = real(1.0); c6[0] = real(0.0); c6[1] = real(0.0);
+        for (int i = 0; i < 4; i++) {
+            for (int j = 0; j < 4; j++) A6[6 * (2 + i) + 2 + j] = Ad.a[4 * i + j];
+            B06[2 * (2 + i)] = b0[i]; Bf6[2 * (2 + i)] = bf[i]; c6[2 + i] = cd[i];
+        }
+        for (int i = 0; i < 4; i++) { Q[o.H + 8 * t + 2 * i] = e.H[i][0]; Q[o.H + 8 * t + 2 * i + 1] = e.H[i][1]; Q[o.G + 4 * t + i] = e.G[i]; }
+        Q[o.dmin + t] = dmin_t; Q[o.dmax + t] = dmax_t;
+        Q[o.fxmax + t] = real(1.0);                                           // inert Fx slot: 0 <= 1 is never active
+        Q[o.ddmin + t] = ddmin_t; Q[o.ddmax + t] = ddmax_t;
+        Q[o.dt + t] = T;
+    }
     if (C.lat_pack) {      // the same numbers once more, packed for k_solve_lat
         real* Lp = C.lat_pack + ((size_t)b * C.N + t) * LATP;
         for (int i = 0; i < 4; i++) {
@@ -897,7 +903,7 @@ __global__ __launch_bounds__(128) void k_qp_dec(DevCfg C, int B, const real* __r
             Lp[8 * i + 4] = b0[i] + bf[i]; Lp[8 * i + 5] = bf[i]; Lp[8 * i + 6] = cd[i]; Lp[8 * i + 7] = real(0.0);
             Lp[32 + 2 * i] = e.H[i][0]; Lp[33 + 2 * i] = e.H[i][1]; Lp[40 + i] = e.G[i];
         }
-        Lp[44] = Q[o.dmax + t]; Lp[45] = Q[o.dmin + t]; Lp[46] = Q[o.ddmax + t]; Lp[47] = Q[o.ddmin + t]; Lp[48] = T;
+        Lp[44] = dmax_t; Lp[45] = dmin_t; Lp[46] = ddmax_t; Lp[47] = ddmin_t; Lp[48] = T;
         for (int i = 49; i < LATP; i++) Lp[i] = real(0.0);
     }
     if (t == 0) {

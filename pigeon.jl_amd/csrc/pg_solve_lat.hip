@@ -21,6 +21,14 @@
 //  * The roll-out holds ROW i of [Abar | Bbar | cbar] in lane i and the gain row in lane 5: x_{k+1} = six fused multiply-adds per stage.
 //  * LDS per instance: 24 doubles per stage (stage cost terms that the roll-out result overwrites, gains, S^-1, P cbar) = 9.6 KB at N = 50: four wavefronts per CU.
 //
+//  * Round 5 -- PINNED INPUTS.  The stage has ONE input, and a held steering-rate row fixes it (v = +ddmax / -ddmin).  The polish eliminates such a row exactly instead of
+//    penalising it: the stage has no gain (K = 0, kff = the pinned value), the recursion is  P_k = Q + A'PA,  p_k = q + A'y + F'kff,  and the row's multiplier is read off
+//    stationarity in v behind the roll-out: lambda = -/+ (F x + f + S v).  Nothing iterates: round 4's augmented Lagrangian contracted by S / (S + rho) per pass with
+//    S = Rhat + Bbar'P Bbar up to 1e12 on the open-loop unstable 8 s horizon, and such multipliers stalled (54 of 4096 config-5 answers ended unverified; now 0-1).
+//    Encoding for the serial passes, all in existing slots: rec[5] = -Rhat0 (negative: pinned), rec[11] = kff; table slots K[0..4] = F, kff = f, Sinv = -S.
+//    (Measured and removed: pinning a held steering-BOUND row the same way, v = -delta_k + bound, i.e. the fixed feedback K = -e_4' with the general recursion
+//    P_k = Q + A'PA + F'K + K'F + K'SK -- the same 4095 / 4096 verify, but 24 answers move by 1e-7 .. 8e-7 and delta by up to 6e-4 in the far horizon: those rows stay penalised.)
+//
 // The DPP forms are inline assembly: hipcc does not pad their hazards (VALU write -> DPP read of the same register: 2 wait states; EXEC write -> DPP: 5), so every block opens
 // with s_nop 4 and the pass loops carry no divergent branch (predicated stores go to a dummy LDS slot).
 
@@ -140,7 +148,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // ---------------- Riccati matrix pass (+ the predictor's vector recursion in column 6) ----------------
     // Software-pipelined by hand: the operands of stage k - 1 (global: the matrix column and dt; LDS: the stage-cost column, Rhat / rhat) are requested at the top of
     // stage k and first touched at the top of stage k - 1, a whole stage of arithmetic (~900 cycles) later.
-    auto matrix_pass = [&]() __attribute__((always_inline)) {
+    // (every serial pass exists twice: PIN = the form that honours pinned inputs, taken by a wavefront while any of its four instances is in a polish; the plain form -- an
+    //  LDS read, two broadcasts and a handful of selects per stage shorter -- serves the interior-point iterations, which are most of a cold launch)
+    auto matrix_pass = [&](auto pin_t) __attribute__((always_inline)) {
+        constexpr bool PIN = decltype(pin_t)::value;
         real P[5], X[4], Xn[4], Qc[5], Qn[5], dtk, dtn, radd, raddn;
         {   // P_N = Qhat_{N-1} (cost on node N), p_N = qhat_{N-1}
             const real dtl = Lb[(size_t)(N - 1) * LATP + 48];
@@ -177,15 +188,21 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
 #pragma unroll
             for (int i = 0; i < 5; i++) { *(c == 6 ? sTab + LAT_TAB * k + 7 + i : sDum + lane) = M[i]; M[i] = fma(m6, P[i], M[i]); }
             // G[c] = sum_i Bbar[i] M[i][c]: lanes 0..4 F, lane 5 Bbar' P Bbar, lane 6 Bbar' y   (Bbar = column 5; its row 4 is 1)
-            real G0 = radd, G1 = M[4];
+            // pinned input (see the header): lane 5's Rhat slot is negative, lane 6's rhat slot carries kff
+            const bool held = PIN && lat_bc<5>(radd) < real(0.0);
+            const real kffp = PIN ? lat_bc<6>(radd) : real(0.0);
+            real G0 = held ? (c == 5 ? -radd : real(0.0)) : radd, G1 = M[4];
             asm volatile("s_nop 4\n\t"
                          LAT_DPP(0, 2, 6, 5) LAT_DPP(1, 3, 7, 5) LAT_DPP(0, 4, 8, 5) LAT_DPP(1, 5, 9, 5)
                          : "+v"(G0), "+v"(G1)
                          : "v"(X[0]), "v"(X[1]), "v"(X[2]), "v"(X[3]), "v"(M[0]), "v"(M[1]), "v"(M[2]), "v"(M[3]));
             const real G = G0 + G1;                       // lane 5: S = Rhat + Bbar' P Bbar; lane 6: f = rhat + Bbar' y
-            const real Sinv = frcp(lat_bc<5>(G));
-            const real Kc = -G * Sinv;                    // lanes 0..4: K[c]; lane 6: kff
-            *(wslot >= 0 ? sTab + LAT_TAB * k + wslot : sDum + lane) = c == 5 ? Sinv : Kc;
+            const real Sb = lat_bc<5>(G);
+            const real Sinv = held ? real(0.0) : frcp(Sb);
+            const real Kfree = -G * Sinv;                 // lanes 0..4: K[c]; lane 6: kff
+            const real Kc = held ? (c == 6 ? kffp : real(0.0)) : Kfree;
+            // (a pinned stage leaves F, f and -S in the slots of the gain row, kff and S^-1: the roll-out and the vector pass find them there)
+            *(wslot >= 0 ? sTab + LAT_TAB * k + wslot : sDum + lane) = held ? (c == 5 ? -Sb : G) : (c == 5 ? Sinv : Kc);
             // P_k[i][c] = Qhat[i][c] + sum_k Abar[k][i] M[k][c] + F[i] K[c]   (lane 6: p_k = qhat + Abar' y + F kff);  Abar[4][i] = (i == 4)
             real Pn[5];
 #pragma unroll
@@ -207,7 +224,8 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
 
     // ---------------- Riccati vector pass (corrector): p_k = qhat + Abar' y + K f,  y = P cbar + p,  f = rhat + Bbar' y,  kff = -Sinv f ----------------
     // A stage is ~25 instructions here: the matrix columns are requested THREE stages ahead (L2 latency ~ several stages of this pass), the LDS operands one.
-    auto vector_pass = [&]() __attribute__((always_inline)) {
+    auto vector_pass = [&](auto pin_t) __attribute__((always_inline)) {
+        constexpr bool PIN = decltype(pin_t)::value;
         constexpr int D = LAT_PREFETCH_V;
         real buf[D][4];
         const int mcoff = c < 5 ? (int)(sTab - sZero) + 7 + c : 0, mcmul = c < 5 ? LAT_TAB : 0;       // P cbar [c]
@@ -237,9 +255,12 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
                              LAT_DPP(0, 1, 2, 0) LAT_DPP(0, 1, 3, 1) LAT_DPP(0, 1, 4, 2) LAT_DPP(0, 1, 5, 3)
                              : "+v"(acc) : "v"(y), "v"(buf[u][0]), "v"(buf[u][1]), "v"(buf[u][2]), "v"(buf[u][3]));
                 request(k - D, buf[u]);
-                const real f = lo[3] + lat_bc<5>(acc); // lane 5's column is Bbar
-                *((c == 0 && k >= 0) ? sTab + LAT_TAB * (k < 0 ? 0 : k) + 5 : sDum + lane) = -lo[4] * f;
-                p = m5lt * (lo[2] + acc + lo[1] * f);
+                // (pinned stage: slot S^-1 holds -S, the K slots hold F, the rhat slot holds kff; f goes where kff would -- the roll-out needs it for the row's multiplier)
+                const bool held = PIN && lo[4] < real(0.0);
+                const real f = (held ? real(0.0) : lo[3]) + lat_bc<5>(acc); // lane 5's column is Bbar
+                *((c == 0 && k >= 0) ? sTab + LAT_TAB * (k < 0 ? 0 : k) + 5 : sDum + lane) = held ? f : -lo[4] * f;
+                const real pin = lo[1] * (held ? lo[3] : f);      // F kff  |  K f
+                p = m5lt * (lo[2] + acc + pin);
 #pragma unroll
                 for (int i = 0; i < 5; i++) lo[i] = ln[i];
             }
@@ -250,43 +271,62 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     const int ri = c < 4 ? c : 0;
     const real wA = c < 4 ? real(1.0) : real(0.0), wD = c == 4 ? real(1.0) : real(0.0);
     const real x0c = c < 4 ? Q[o.qcurr + 2 + c] : (c == 4 ? Q[o.ucurr] : real(0.0));
-    auto forward_pass = [&](bool use_gain) __attribute__((always_inline)) {
+    auto forward_pass = [&](bool use_gain, auto pin_t) __attribute__((always_inline)) {
+        constexpr bool PIN = decltype(pin_t)::value;
         constexpr int D = LAT_PREFETCH_F;
         const bool isK = c == 5 && use_gain;          // (a select, not a multiplication by 0: the gain table holds nothing before the first matrix pass)
         real xr = x0c;
         const real2* const rowp = reinterpret_cast<const real2*>(Lb + 8 * ri);
         const real2* const tabp = reinterpret_cast<const real2*>(sTab);
-        real2 buf[D][4], kt[3], ktn[3];
+        real2 buf[D][4], kt[4], ktn[4]; real pk, pkn;
         auto request = [&](int k, real2* o4) __attribute__((always_inline)) { const real2* rp = rowp + (size_t)(k < N ? k : N - 1) * (LATP / 2);
 #pragma unroll
             for (int q = 0; q < 4; q++) o4[q] = rp[q]; };
-        auto request_lds = [&](int k, real2* o3) __attribute__((always_inline)) { const real2* tp = tabp + (LAT_TAB / 2) * (k < N ? k : N - 1);
+        auto request_lds = [&](int k, real2* o3, real& p2) __attribute__((always_inline)) { const int kk = k < N ? k : N - 1; const real2* tp = tabp + (LAT_TAB / 2) * kk;
 #pragma unroll
-            for (int q = 0; q < 3; q++) o3[q] = tp[q]; };
+            for (int q = 0; q < (PIN ? 4 : 3); q++) o3[q] = tp[q];            // K[0..4], kff, S^-1 (a pinned stage: F, f, -S)
+            if constexpr (PIN) p2 = sRec[LAT_REC * kk + 11]; };                // kff of a pinned stage
 #pragma unroll
         for (int u = 0; u < D; u++) request(u, buf[u]);
-        request_lds(0, kt);
+        request_lds(0, kt, pk);
 #pragma unroll 1
         for (int k0 = 0; k0 < N; k0 += D) {
             // (one basic block per D stages, as in the vector pass; stages >= N of the last group run on the last stage's operands and store nothing)
 #pragma unroll
             for (int u = 0; u < D; u++) {
                 const int k = k0 + u;
-                request_lds(k + 1, ktn);
+                request_lds(k + 1, ktn, pkn);
                 real R[7];
                 R[0] = isK ? kt[0].x : wA * buf[u][0].x; R[1] = isK ? kt[0].y : wA * buf[u][0].y; R[2] = isK ? kt[1].x : wA * buf[u][1].x; R[3] = isK ? kt[1].y : wA * buf[u][1].y;
                 R[4] = isK ? kt[2].x : wA * buf[u][2].x + wD; R[5] = wA * buf[u][2].y + wD; R[6] = isK ? kt[2].y : wA * buf[u][3].x;
                 asm volatile("" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]), "+v"(R[5]), "+v"(R[6]));      // the row is formed BEFORE its buffer is re-requested
                 request(k + D, buf[u]);
                 real acc = R[6], xn;
-                asm volatile("s_nop 4\n\t"
-                             LAT_DPP(1, 2, 3, 0) LAT_DPP(1, 2, 4, 1) LAT_DPP(1, 2, 5, 2) LAT_DPP(1, 2, 6, 3) LAT_DPP(1, 2, 7, 4)
-                             "s_nop 1\n\t" LAT_MOV " %0, %1\n\t" LAT_DPP(0, 1, 8, 5)
-                             : "=&v"(xn), "+v"(acc) : "v"(xr), "v"(R[0]), "v"(R[1]), "v"(R[2]), "v"(R[3]), "v"(R[4]), "v"(R[5]));
+                // pinned input (use_gain only: the tables hold nothing before the first matrix pass): lane 5 has evaluated F x + f; the input is the pinned value kff, and what goes
+                // into the record in its place is the gradient of the Lagrangian in it, F x + f + S v (the stage's lane knows v: it owns the row)
+                real outv;
+                if constexpr (PIN) {
+                    const bool held = use_gain && kt[3].x < real(0.0);
+                    const real vpin = pk;
+                    asm volatile("s_nop 4\n\t"
+                                 LAT_DPP(0, 1, 2, 0) LAT_DPP(0, 1, 3, 1) LAT_DPP(0, 1, 4, 2) LAT_DPP(0, 1, 5, 3) LAT_DPP(0, 1, 6, 4)
+                                 : "+v"(acc) : "v"(xr), "v"(R[0]), "v"(R[1]), "v"(R[2]), "v"(R[3]), "v"(R[4]));
+                    const real vsel = held ? vpin : acc;   // (lane 5: the input of this stage)
+                    asm volatile("s_nop 4\n\t" LAT_MOV " %0, %1\n\t" LAT_DPP(0, 3, 2, 5)
+                                 : "=&v"(xn) : "v"(acc), "v"(R[5]), "v"(vsel));
+                    outv = (held && c == 5) ? fma(-kt[3].x, vpin, acc) : xn;
+                } else {
+                    asm volatile("s_nop 4\n\t"
+                                 LAT_DPP(1, 2, 3, 0) LAT_DPP(1, 2, 4, 1) LAT_DPP(1, 2, 5, 2) LAT_DPP(1, 2, 6, 3) LAT_DPP(1, 2, 7, 4)
+                                 "s_nop 1\n\t" LAT_MOV " %0, %1\n\t" LAT_DPP(0, 1, 8, 5)
+                                 : "=&v"(xn), "+v"(acc) : "v"(xr), "v"(R[0]), "v"(R[1]), "v"(R[2]), "v"(R[3]), "v"(R[4]), "v"(R[5]));
+                    outv = xn;
+                }
                 xr = xn;                              // lanes 0..4: x_{k+1}; lane 5: v_k (its Bbar entry is 0)
-                *((c < 6 && k < N) ? sRec + LAT_REC * (k < N ? k : 0) + c : sDum + lane) = xn;
+                *((c < 6 && k < N) ? sRec + LAT_REC * (k < N ? k : 0) + c : sDum + lane) = outv;
 #pragma unroll
-                for (int q = 0; q < 3; q++) kt[q] = ktn[q];
+                for (int q = 0; q < (PIN ? 4 : 3); q++) kt[q] = ktn[q];
+                if constexpr (PIN) pk = pkn;
             }
         }
     };
@@ -471,12 +511,22 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // unverified for that reason alone (PG_RHO sweep, EXPERIMENTS 10.1: unverified 248 / 111 / 53 / 11 of 4096 at 1e7 / 1e9 / 1e10 / 1e11; accuracy against the oracle
     // unchanged up to 1e10, 3x worse with walls at 1e11).  The embedding in k_solve keeps polish_rho as it is (its refinement solves for a correction; tuned at 1e7).
     const real rho = C.polish_rho * C.lat_rho_scale, ptol = C.polish_tol;
+    // pinned input of a stage under working set `am` (see the header): kind 1 = a held rate row (rows 8, 9 leave the penalty form), kff = the pinned value
+    struct Pin { int kind; real kff; };
+    auto pin_of = [&](unsigned am, const StageC& S) __attribute__((always_inline)) -> Pin {
+        Pin p; p.kind = 0; p.kff = real(0.0);
+        if (!pmode || C.lat_pin == 0) return p;
+        if (am & (1u << 8)) { p.kind = 1; p.kff = S.b[8]; }
+        else if (am & (1u << 9)) { p.kind = 1; p.kff = -S.b[9]; }
+        return p;
+    };
     // barrier weights of a slot at the current iterate: it = 1/t, W = lambda/t, ell = (sigma mu - corr)/t + lambda - W b
     auto weights = [&](unsigned am, const real* Tl, const real* Ll, const real* Cl, const StageC& S, real sgmu, bool with_corr, real* it_, real* W, real* ell) __attribute__((always_inline)) {
         if (pmode) {
+            const Pin pn = pin_of(am, S);
 #pragma unroll
             for (int r = 0; r < NR; r++) {
-                const bool a = (am >> r) & 1u;
+                const bool a = ((am >> r) & 1u) && !(pn.kind == 1 && (r == 8 || r == 9));
                 it_[r] = real(1.0); W[r] = a ? rho : real(0.0); ell[r] = a ? Ll[r] - rho * S.b[r] : real(0.0);
             }
             return;
@@ -496,12 +546,16 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         return touched;
     };
     // after a polish solve (tp = slacks at the new point): multiplier update of the held rows and the add / drop decisions of this slot.  Returns the next working set.
-    auto polish_rows = [&](bool actj, unsigned am, real* Ll, const real* tp, real ttol, bool& unsettled) __attribute__((always_inline)) -> unsigned {
+    auto polish_rows = [&](bool actj, unsigned am, real* Ll, const real* tp, real ttol, bool& unsettled, const Pin& pn, real gpin) __attribute__((always_inline)) -> unsigned {
         unsigned add = 0u, drop = 0u;
+        // the pinned row: its multiplier is minus / plus the gradient of the Lagrangian in the input (rows "bound - (.)" take the minus sign)
+        const int rpin = pn.kind == 1 ? ((am & (1u << 8)) ? 8 : 9) : -1;
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             const bool a = (am >> r) & 1u;
-            if (a) Ll[r] -= rho * tp[r];
+            const bool excl = pn.kind == 1 && (r == 8 || r == 9);      // rows out of the penalty form
+            if (r == rpin) Ll[r] = r == 8 ? -gpin : gpin;
+            else if (a && !excl) Ll[r] -= rho * tp[r];
             if (actj && a && Ll[r] < real(0.0)) drop |= 1u << r;
             if (actj && a && !(fabs(tp[r]) <= ttol)) unsettled = true;             // written so that a NaN never verifies
             if (actj && !a && !(tp[r] >= -ptol)) add |= 1u << r;
@@ -526,10 +580,11 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             real* rec = sRec + LAT_REC * (c + 16 * j);
             rec[6] = g0 - E.c10 * E.g1 * E.d1 - E.c20 * E.g2 * E.d2;
             rec[7] = g1 - E.c11 * E.g1 * E.d1 - E.c21 * E.g2 * E.d2;
+            const Pin pn = pin_of(mt.am, S);
             rec[8] = real(0.0);
             if constexpr (WALLS) rec[9] = (ell[10] - ell[11]) - E.ch * E.gh * E.dh; else rec[9] = real(0.0);
             rec[10] = ell[0] - ell[1];
-            rec[11] = ell[8] - ell[9];
+            rec[11] = pn.kind ? pn.kff : ell[8] - ell[9];
             if (matrices) {
                 real yy = real(0.0), yr = real(0.0), rr = real(0.0);
 #pragma unroll
@@ -540,7 +595,8 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
                 rec[3] = real(2.0) * C.cp.Q_e * S.dts;
                 if constexpr (WALLS) rec[3] += W[10] + W[11] - E.ch * E.ch * E.dh;
                 rec[4] = real(2.0) * C.cp.R_delta * S.dts + W[0] + W[1];
-                rec[5] = real(2.0) * C.cp.R_ddelta * frcp(S.dts) + W[8] + W[9];
+                const real Rh = real(2.0) * C.cp.R_ddelta * frcp(S.dts) + W[8] + W[9];
+                rec[5] = pn.kind ? -Rh : Rh;             // (negative: the input of this stage is pinned)
             }
         }
     };
@@ -562,10 +618,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         out[3] = ell[0] - ell[1];
         out[4] = ell[8] - ell[9];
     };
-    auto put_vec = [&](int j, const real* qa, const real* qb) __attribute__((always_inline)) {
+    auto put_vec = [&](int j, const real* qa, const real* qb, const Pin& pn) __attribute__((always_inline)) {
         if (is_act(j)) {
             real* rec = sRec + LAT_REC * (c + 16 * j);
-            rec[6] = qa[0]; rec[7] = qa[1]; rec[8] = real(0.0); rec[9] = qa[2]; rec[10] = qa[3]; rec[11] = qa[4];
+            rec[6] = qa[0]; rec[7] = qa[1]; rec[8] = real(0.0); rec[9] = qa[2]; rec[10] = qa[3]; rec[11] = pn.kind ? pn.kff : qa[4];
             if (!pmode) {       // (a polish has no sigma mu part, and its verdict may still want the point in rec[0..4]: polish_decide stores it as the answer)
 #pragma unroll
                 for (int i = 0; i < 5; i++) rec[i] = qb[i];
@@ -573,11 +629,13 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         }
     };
     // Newton point of slot j from the roll-out (x+ of node s+1, v+ of transition s) -> eliminated slacks and the slack of every row
-    auto newton = [&](int j, const StageC& S, const Elim& E, real* xn, real& vn, real* sg3, real* tp) __attribute__((always_inline)) {
-        const real* rec = sRec + LAT_REC * (is_act(j) ? c + 16 * j : N - 1);
+    auto newton = [&](int j, const StageC& S, const Elim& E, real* xn, real& vn, real* sg3, real* tp, const Pin& pn, real& gpin) __attribute__((always_inline)) {
+        const int sj = is_act(j) ? c + 16 * j : N - 1;
+        const real* rec = sRec + LAT_REC * sj;
 #pragma unroll
         for (int m = 0; m < 5; m++) xn[m] = rec[m];
-        vn = rec[5];
+        vn = rec[5]; gpin = real(0.0);
+        if (pn.kind) { gpin = vn; vn = pn.kff; }      // the record carries the gradient in the pinned input instead of the input itself
         sg3[0] = -(E.c10 * xn[0] + E.c11 * xn[1] + E.g1) * E.d1;
         sg3[1] = -(E.c20 * xn[0] + E.c21 * xn[1] + E.g2) * E.d2;
         sg3[2] = WALLS ? -(E.ch * xn[3] + E.gh) * E.dh : real(0.0);
@@ -586,7 +644,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
 
     // ---------------- start: v = 0 roll-out (dynamics- and rate-feasible), soft-row slacks just feasible + 1, t = max(slack, tau), lambda = mu0 / t ----------------
     __syncthreads();
-    forward_pass(false);
+    forward_pass(false, std::false_type{});
     wave_sync();
     stamp(3);
     real rp0 = real(0.0), j0 = real(0.0);
@@ -800,10 +858,11 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         need_a1 = false;
         wave_sync();
         stamp(0);
-        matrix_pass();
+        const bool wave_pin = __any(pmode != 0) != 0;      // (wave-uniform: some instance of this wavefront is in a polish)
+        if (wave_pin) matrix_pass(std::true_type{}); else matrix_pass(std::false_type{});
         wave_sync();
         stamp(1);
-        forward_pass(true);
+        if (wave_pin) forward_pass(true, std::true_type{}); else forward_pass(true, std::false_type{});
         wave_sync();
         stamp(3);
         real rmax = real(0.0), S2 = real(0.0); bool unsettled = false;
@@ -812,10 +871,11 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             real it_[NR], W[NR], ell[NR], tp[NR], xn[5], vn, sg3[3]; Elim E;
             weights(mt.am, Tl, Ll, Cl, S, real(0.0), false, it_, W, ell);
             eliminate(S, W, ell, E);
-            newton(j, S, E, xn, vn, sg3, tp);
+            const Pin pn = pin_of(mt.am, S); real gpin;
+            newton(j, S, E, xn, vn, sg3, tp, pn, gpin);
             real qa[5], qb[5];
             if (pmode) {
-                put_sn(j, sg3); mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, real(0.01) * ptol, unsettled); put_meta(j, mt); put_tl(j, Tl, Ll);
+                put_sn(j, sg3); mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, real(0.01) * ptol, unsettled, pn, gpin); put_meta(j, mt); put_tl(j, Tl, Ll);
                 if constexpr (SPLIT_CORR) {      // the refinement solve behind this one: same set, the multipliers just updated (no sigma mu in a polish)
                     weights(mt.am, Tl, Ll, Cl, S, real(0.0), false, it_, W, ell);
                     vec_terms(S, E, ell, true, qa);
@@ -843,7 +903,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
                     vec_terms(S, E, it_, false, qb);
                 }
             }
-            if constexpr (SPLIT_CORR) put_vec(j, qa, qb);
+            if constexpr (SPLIT_CORR) put_vec(j, qa, qb, pn);
         });
         skip_second = false;
         if (pmode && !done) skip_second = polish_decide(unsettled, false);
@@ -868,10 +928,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         });
         wave_sync();
         stamp(0);
-        vector_pass();
+        if (wave_pin) vector_pass(std::true_type{}); else vector_pass(std::false_type{});
         wave_sync();
         stamp(2);
-        forward_pass(true);
+        if (wave_pin) forward_pass(true, std::true_type{}); else forward_pass(true, std::false_type{});
         wave_sync();
         stamp(3);
         real T1 = real(0.0), T2 = real(0.0);
@@ -881,9 +941,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             real it_[NR], W[NR], ell[NR], tp[NR], xn[5], vn, sg3[3]; Elim E;
             weights(mt.am, Tl, Ll, Cl, S, sgmu, true, it_, W, ell);
             eliminate(S, W, ell, E);
-            newton(j, S, E, xn, vn, sg3, tp);
+            const Pin pn = pin_of(mt.am, S); real gpin;
+            newton(j, S, E, xn, vn, sg3, tp, pn, gpin);
             put_sn(j, sg3);
-            if (pmode) { if (!skip_second && !resume_ipm) { mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, ptol, unsettled); put_meta(j, mt); put_tl(j, Tl, Ll); } }
+            if (pmode) { if (!skip_second && !resume_ipm) { mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, ptol, unsettled, pn, gpin); put_meta(j, mt); put_tl(j, Tl, Ll); } }
             else {
                 real rm = real(0.0), t1 = real(0.0), t2 = real(0.0);
 #pragma unroll

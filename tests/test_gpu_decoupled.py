@@ -188,7 +188,7 @@ def test_config5_as_shipped_every_instance_against_the_oracle(pkg, oracle_mod, s
     assert np.all(res[:, 4] == 1) and np.all(res[:, 5] >= 1)                      # the oracle's side: a verified KKT point for every instance
     assert res[:, 0].max() <= 1e-6, (res[:, 0].max(), int(np.argmax(res[:, 0])))
     assert res[:, 1].max() <= 1e-5 and res[:, 2].max() <= 1e-9, (res[:, 1].max(), res[:, 2].max())
-    assert (pol >= 1).sum() >= 0.9 * B
+    assert (pol >= 1).sum() >= B - 8, int((pol < 0).sum())         # (round 4: 53 / 54 unverified -- multipliers of held steering-rate rows stalled under the penalty; round 5 pins them exactly: 0 / 4)
     mpc.close()
     # the interior point alone: accurate for all but a handful -- which is why it is not the default
     ipm = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, B, N_short=Ns, N_long=Nl, walls=walls, polish=False)
