@@ -218,6 +218,20 @@ def emit(full, path=None):
     print(compact_line(full), flush=True)
 
 
+def phases_of(m, n=3, cold=True, u_ptr=None):
+    """Per-phase device time of a step of handle `m` (median over n steps, HIP events on the launch stream): the library's instrumentation (option "phase_timing": four event
+    records per step, 13-25 us of stream time) is switched on for these steps only -- the timed loops of this file run without it, as the library does by default."""
+    import torch
+    m.set_option("phase_timing", 1)
+    ph = []
+    for _ in range(n):
+        if cold:
+            m.reset()
+        m.step_dev(u_ptr); torch.cuda.synchronize(); ph.append(m.phase_ms())
+    m.set_option("phase_timing", 0)
+    return [float(v) for v in np.median(np.array(ph), axis=0)]
+
+
 def cpu_baseline(pkg, traj, mpc, state, control, t0, toff, precision, local):
     """The reference ALGORITHM (OSQP-form ADMM with sparse LDL', default settings) on the host cores: oracle 'port'.
     Only this leg may touch oracle/: as the timed CPU baseline, and as the CHECKER of the GPU numbers (accuracy sample, config 1)."""
@@ -291,7 +305,7 @@ def cpu_baseline(pkg, traj, mpc, state, control, t0, toff, precision, local):
         E, Nn, psi, kappa, V, t = pkg.synthetic.path_pose(tj, 20.0)
         q0 = np.array([E - 0.3 * np.cos(psi), Nn - 0.3 * np.sin(psi), psi + 0.05, V, 0.0, 0.0]); u0 = np.zeros(3)
         o1 = orc_mod.Oracle(); o1.set_trajectory(tj.data)
-        g = pkg.BatchedTrajectoryTrackingMPC(tj, 1, device=local, precision=precision)
+        g = pkg.BatchedTrajectoryTrackingMPC(tj, 1, device=local, precision=precision, phase_timing=False)
         res = {}
         for who in ("gpu", "cpu"):
             q, u, tt = q0.copy(), u0.copy(), float(t)
@@ -371,7 +385,7 @@ def main():
     except Exception:
         TR = None
     traj = pkg.load_path_fixture("skidpadoval")
-    mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision=args.precision)
+    mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision=args.precision, phase_timing=False)      # (the library's default: no per-phase events on the stream)
     npdt = np.float64 if args.precision == "f64" else np.float32; tdt = torch.float64 if args.precision == "f64" else torch.float32
     state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345 + rank, traj_mode=True)
     dev = torch.device("cuda", local)
@@ -441,9 +455,11 @@ def main():
         rank_ms = {"min": 1e3 * min(per_rank) / args.steps, "max": 1e3 * max(per_rank) / args.steps}
 
     # per-phase device time (HIP events recorded by pg_step_dev on the launch stream): mean over a few extra steps outside the timed region
+    mpc.set_option("phase_timing", 1)
     ph = []
     for _ in range(5):
         one_step(); torch.cuda.synchronize(); ph.append(mpc.phase_ms())
+    mpc.set_option("phase_timing", 0)
     ph = np.mean(np.array(ph), axis=0)
     st, it, act, mu = mpc.solve_info(); pol = mpc.polish_info()
     ok = int(pkg.is_solved(st).sum())
@@ -455,7 +471,7 @@ def main():
     # the same cold workload with the active-set guess OFF (every instance through the interior point; round-2-mid behaviour), as a reference for what the guess buys
     ipm_only = None; fused_line = None; per_phase_line = None
     if rank == 0 and world == 1 and not args.no_warm:
-        m0 = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision=args.precision, cold_guess=0)
+        m0 = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision=args.precision, cold_guess=0, phase_timing=False)
         m0.set_stream(torch.cuda.current_stream().cuda_stream)
         m0.set_inputs_dev(B, d_state.data_ptr(), d_control.data_ptr(), d_t0.data_ptr(), None, d_toff.data_ptr())
         for _ in range(2):
@@ -465,7 +481,7 @@ def main():
             m0.reset(); m0.step_dev(u_out.data_ptr())
         torch.cuda.synchronize(); t_ = time.perf_counter() - t_
         st0_, it0_, _, _ = m0.solve_info(); p0_ = m0.polish_info()
-        ipm_only = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": [float(v) for v in m0.phase_ms()],
+        ipm_only = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": phases_of(m0, u_ptr=u_out.data_ptr()),
                     "solved": f"{int(pkg.is_solved(st0_).sum())}/{B}", "ipm_iters_mean": float(np.mean(it0_)), "polish_rounds_hist": hist(p0_),
                     "config": "pg_config.cold_guess = 0: Mehrotra interior point to mu <= 3e-6 + active-set polish for every instance"}
         m0.close()
@@ -477,7 +493,7 @@ def main():
         for _ in range(args.steps):
             mpc.reset(); mpc.step_dev(u_out.data_ptr())
         torch.cuda.synchronize(); t_ = time.perf_counter() - t_
-        fused_line = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": [float(v) for v in mpc.phase_ms()],
+        fused_line = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": phases_of(mpc, u_ptr=u_out.data_ptr()),
                       "config": "pg_set_fusion(1): the wave that solves an instance linearises it first (one kernel for update_QP! + solve!); off by default"}
         mpc.set_fusion(0)
         # ... and with one launch per phase (pg_set_pipeline(0): nodes, update_QP!, solve as three kernels; the default pipelines the first two, bit-identical in fp64)
@@ -488,7 +504,7 @@ def main():
         for _ in range(args.steps):
             mpc.reset(); mpc.step_dev(u_out.data_ptr())
         torch.cuda.synchronize(); t_ = time.perf_counter() - t_
-        per_phase_line = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": [float(v) for v in mpc.phase_ms()],
+        per_phase_line = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": phases_of(mpc, u_ptr=u_out.data_ptr()),
                           "config": "pg_set_pipeline(0): nodes (k_nodes), update_QP! (k_linearize_split) and solve as one launch each; the default runs the first two as one pipelined launch"}
         mpc.set_pipeline(1)
         mpc.reset(); mpc.step_dev(u_out.data_ptr()); torch.cuda.synchronize()         # (leave the headline controller's outputs as the last thing in u_out)
@@ -499,7 +515,7 @@ def main():
         hs = []
         for k in range(2):
             sl = slice(k * B // 2, (k + 1) * B // 2)
-            m2 = pkg.BatchedTrajectoryTrackingMPC(traj, B // 2, device=local, precision=args.precision)
+            m2 = pkg.BatchedTrajectoryTrackingMPC(traj, B // 2, device=local, precision=args.precision, phase_timing=False)
             st2 = torch.cuda.Stream(device=dev)
             m2.set_stream(st2.cuda_stream)
             m2.set_inputs(state[sl], control[sl], t0[sl], time_offset=toff[sl])
@@ -520,7 +536,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_warm and B >= 2048:
         hs = []
         for k in range(2):
-            m2 = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision=args.precision)
+            m2 = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision=args.precision, phase_timing=False)
             st2 = torch.cuda.Stream(device=dev)
             m2.set_stream(st2.cuda_stream)
             s2, c2, t2, o2 = pkg.synthetic.config2_inputs(traj, B, seed=777 + k, traj_mode=True)
@@ -544,7 +560,7 @@ def main():
         variants = {}
         for key, path, tmode in (("vail", "vail", True), ("path_mode", "skidpadoval", False)):
             tj = pkg.load_path_fixture(path)
-            mv = pkg.BatchedTrajectoryTrackingMPC(tj, B, device=local, precision=args.precision)
+            mv = pkg.BatchedTrajectoryTrackingMPC(tj, B, device=local, precision=args.precision, phase_timing=False)
             mv.set_stream(torch.cuda.current_stream().cuda_stream)
             sv, cv, tv, ov = pkg.synthetic.config2_inputs(tj, B, seed=12345, traj_mode=tmode)
             mv.set_inputs(sv, cv, tv, time_offset=ov)
@@ -555,7 +571,7 @@ def main():
                 mv.reset(); mv.step_dev()
             torch.cuda.synchronize(); t_ = time.perf_counter() - t_
             stv, itv, _, _ = mv.solve_info(); pv = mv.polish_info()
-            variants[key] = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": [float(v) for v in mv.phase_ms()],
+            variants[key] = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": phases_of(mv),
                              "solved": f"{int(pkg.is_solved(stv).sum())}/{B}", "interior_point_instances": int((itv > 0).sum()), "polish_rounds_hist": hist(pv),
                              "workload": f"configs[1] on {path}, " + ("trajectory mode (time_offset = 0)" if tmode else "PATH mode (time_offset = NaN: V, A from the speed profile at s; coupled_lat_long.jl:115)")}
             mv.close()
@@ -568,7 +584,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_rollout:
         roll = {"workload": f"{B} controllers in closed loop on the device, 40 steps of 10 ms after 4 warm-up steps (skidpadoval, config-2 initial states), {args.precision}"}
         for warm in (True, False):
-            mr = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision=args.precision, warm_polish=warm)
+            mr = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision=args.precision, warm_polish=warm, phase_timing=False)
             mr.set_stream(torch.cuda.current_stream().cuda_stream)
             mr.set_inputs_dev(B, d_state.data_ptr(), d_control.data_ptr(), d_t0.data_ptr(), None, d_toff.data_ptr())
             mr.simulate_(4); torch.cuda.synchronize(); tr_ = time.perf_counter()
@@ -582,7 +598,7 @@ def main():
     dec = None
     if rank == 0 and world == 1 and not args.no_decoupled:
         def run_dec(walls, polish=None):
-            mpc_d = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, device=local, precision=args.precision, walls=walls, polish=polish)
+            mpc_d = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, device=local, precision=args.precision, walls=walls, polish=polish, phase_timing=False)
             mpc_d.set_stream(torch.cuda.current_stream().cuda_stream)
             mpc_d.set_inputs_dev(B, d_state.data_ptr(), d_control.data_ptr(), d_t0.data_ptr(), None, d_toff.data_ptr())
             for _ in range(2):
@@ -592,7 +608,7 @@ def main():
                 mpc_d.reset(); mpc_d.step_dev(u_out.data_ptr())          # (reset: solved = false -- every timed step is a COLD step; k_solve_lat warm-starts otherwise)
             torch.cuda.synchronize(); td = time.perf_counter() - td
             std, itd, _, _ = mpc_d.solve_info(); pd_ = mpc_d.polish_info()
-            phd = [float(v) for v in mpc_d.phase_ms()]
+            phd = phases_of(mpc_d, u_ptr=u_out.data_ptr())
             r = {"value": B * args.steps / td, "unit": "solves/s", "ms_per_step": 1e3 * td / args.steps, "phase_ms": phd,
                  "solved": f"{int(pkg.is_solved(std).sum())}/{B}", "ipm_iters_mean": float(np.mean(itd)), "ipm_iters_max": int(np.max(itd)), "verified_by_polish": f"{int((pd_ >= 1).sum())}/{B}"}
             # roofline of the dominant kernel (k_solve_lat): the launch runs as long as its slowest instance -- passes through the loop = interior-point iterations + polish rounds
@@ -617,13 +633,12 @@ def main():
         def run_loop(path, walls, burn, warm):
             tj = pkg.load_path_fixture(path)
             s_, c_, t_, o_ = pkg.synthetic.config2_inputs(tj, B, seed=12345)
-            ml = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), tj, B, N_short=10, N_long=40, device=local, precision=args.precision, walls=walls, warm_polish=warm)
+            ml = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), tj, B, N_short=10, N_long=40, device=local, precision=args.precision, walls=walls, warm_polish=warm, phase_timing=False)
             ml.set_stream(torch.cuda.current_stream().cuda_stream)
             ml.set_inputs(s_, c_, t_, time_offset=o_)
             ml.simulate_(burn); torch.cuda.synchronize(); tl = time.perf_counter()
             ml.simulate_(40); torch.cuda.synchronize(); tl = time.perf_counter() - tl
             stl, itl, _, _ = ml.solve_info(); pl = ml.polish_info()
-            ml.step_dev(); torch.cuda.synchronize(); phl = ml.phase_ms()           # (one more step on the last inputs, for its phase times)
             r = {"value": B * 40 / tl, "unit": "solves/s", "ms_per_step": 1e3 * tl / 40, "solved_last_step": f"{int(pkg.is_solved(stl).sum())}/{B}",
                  "verified_last_step": f"{int((pl >= 1).sum())}/{B}", "served_by_warm_attempt_alone_last_step": int((itl == 0).sum()), "ipm_iters_mean_last_step": float(np.mean(itl))}
             ml.close()
@@ -697,7 +712,7 @@ def main():
     # BASELINE config 3: coupled MPC + HJI safety constraint on the precomputed 7-D grid, fp32 (libpigeon_hip_f32.so: same translation unit, real = float)
     f32 = None
     if rank == 0 and world == 1 and not args.no_f32 and args.precision == "f64":
-        m32 = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision="f32")
+        m32 = pkg.BatchedTrajectoryTrackingMPC(traj, B, device=local, precision="f32", phase_timing=False)
         m32.set_stream(torch.cuda.current_stream().cuda_stream)
         TR32 = {"kernels": (TR or {}).get("kernels_f32", {})}
         other = pkg.synthetic.other_cars(state, seed=777)
@@ -713,7 +728,7 @@ def main():
             for _ in range(args.steps):
                 m32.reset(); m32.step_dev(u32.data_ptr())
             torch.cuda.synchronize(); t_ = time.perf_counter() - t_
-            st_, it_, _, _ = m32.solve_info(); p_ = m32.polish_info(); ph32 = [float(v) for v in m32.phase_ms()]
+            st_, it_, _, _ = m32.solve_info(); p_ = m32.polish_info(); ph32 = phases_of(m32, u_ptr=u32.data_ptr())
             rounds32 = np.where(p_ > 0, p_, np.where(p_ < 0, 6, 0))
             return {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": ph32,
                     "solved": f"{int(pkg.is_solved(st_).sum())}/{B}", "ipm_iters_mean": float(np.mean(it_)), "ipm_iters_hist": hist(it_), "verified_by_polish": f"{int((p_ >= 1).sum())}/{B}",
@@ -733,7 +748,7 @@ def main():
         # BASELINE config 5 in fp32 (SURVEY 8d lists it in both precisions): the same lateral batch through libpigeon_hip_f32.so, cold
         if dec is not None:
             def run_dec32(walls):
-                md = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, device=local, precision="f32", walls=walls)
+                md = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, device=local, precision="f32", walls=walls, phase_timing=False)
                 md.set_stream(torch.cuda.current_stream().cuda_stream)
                 md.set_inputs_dev(B, s32.data_ptr(), c32.data_ptr(), d_t0.data_ptr(), None, d_toff.data_ptr())
                 for _ in range(2):
@@ -743,7 +758,7 @@ def main():
                     md.reset(); md.step_dev(u32.data_ptr())
                 torch.cuda.synchronize(); t_ = time.perf_counter() - t_
                 st_, it_, _, _ = md.solve_info(); p_ = md.polish_info()
-                r = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": [float(v) for v in md.phase_ms()],
+                r = {"value": B * args.steps / t_, "unit": "solves/s", "ms_per_step": 1e3 * t_ / args.steps, "phase_ms": phases_of(md, u_ptr=u32.data_ptr()),
                      "solved": f"{int(pkg.is_solved(st_).sum())}/{B}", "status_hist": hist(st_), "ipm_iters_mean": float(np.mean(it_)), "verified_by_polish": f"{int((p_ >= 1).sum())}/{B}"}
                 md.close()
                 return r
@@ -820,7 +835,9 @@ def main():
                        "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}, all_gather of controls ({args.backend})" if world > 1 else "single GPU",
                        "solver": "active-set rounds from the empty set on the stage-structured QP (Riccati; pg_config.cold_guess = 8 + structural rules for the steering rows), verified KKT point; instances the rounds do not serve: "
                                  "Mehrotra interior point to mu <= " + ("3e-6" if args.precision == "f64" else "1e-4") + ", then active-set polish (verified KKT point)",
-                       "accuracy": "measured in this run: cpu_baseline.accuracy (sample of 256); every one of the 4096 instances <= 1e-6 is asserted by tests/test_gpu_full_size.py (measured max 5e-11)"},
+                       "accuracy": "measured in this run: cpu_baseline.accuracy (sample of 256); every one of the 4096 instances <= 1e-6 is asserted by tests/test_gpu_full_size.py (measured max 5e-11)",
+                       "instrumentation": "the library's default (option phase_timing = 0: no per-phase HIP events on the stream) in every timed loop; phase_ms / roofline launch times come from "
+                                          "separate steps with the events on (they cost 13-25 us of stream time per step)"},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale, "avg_launch_ms": dom_ms, **dom_extra, "mfma": mfma_util(tr, 2, pipelined), "valu": valu, "valu_linearize": valu_lin,
                          "kernels": kernels,

@@ -246,6 +246,8 @@ int pg_synchronize(pg_handle* h);
  *   launch shape:
  *     "pipe_min" (2304), "pipe_max" (16384, at most)  batch sizes the pipelined nodes + update_QP launch serves (pg_set_pipeline)
  *     "lin_lanes" 1/2 (1)        lanes per (instance, interval) of the large-batch linearisation
+ *     "phase_timing" 0/1 (0)     1 = pg_step_dev records the HIP events pg_get_phase_ms reads (four event records per step on the handle's stream: measured 13-25 us per step, 2-4 % of a
+ *                                4096-instance step); 0 = no instrumentation, pg_get_phase_ms returns PG_ERR_STATE
  *     "graph" 0/1 (0)            pg_step of a small warm batch as one hipGraph launch (see pg_step)
  *     "hji_cell_dims" 3/5/7 (3)  corners per cell record of the HJI table = 2^value (256 B / 1 KiB / 4 KiB records)
  *   lateral solve kernel (decoupled formulation):
@@ -291,7 +293,8 @@ int pg_get_polish_info(pg_handle* h, int32_t* polish);
  * which side of "active" it is on), the same rule the oracle applies to its own multipliers.  An unverified instance: the interior point's multipliers at the hand-over
  * (k_solve_lat) or the estimates of the last working set tried (k_solve) -- not a certificate. */
 int pg_get_multipliers(pg_handle* h, double* lam);
-/* milliseconds of the last pg_step_dev per phase: time_steps+nodes, update_qp (linearize, limits, HJI), solve (+extract); HIP events */
+/* milliseconds of the last pg_step_dev per phase: time_steps+nodes, update_qp (linearize, limits, HJI), solve (+extract); HIP events, recorded when the option
+ * "phase_timing" is 1 (off by default: PG_ERR_STATE) */
 int pg_get_phase_ms(pg_handle* h, float out3[3]);
 
 /* cache[x] for a batch of relative states: HJI_computation.jl:66-72.  x7 [B][7] host; V [B], gradV [B][7] host.  Out of bounds => V=+Inf, gradV=0 */

@@ -48,6 +48,7 @@ struct pg_handle {
                                                               // directions (option "lin_lanes" = 2: the lane pair of rounds 1-3, for A/B runs; same bits in fp64, rounding-level differences in fp32)
     int* d_todo = nullptr; int split_solve = 1, split_lat = 1;      // d_todo [cap + 8]: instances the rounds-only k_solve leaves to the full kernel; behind them the control words of the solve launches:
                                                                     // [0], [1] two to-do counters used alternately (this launch's count / the previous launch's)
+    int phase_timing = 0;                                           // option "phase_timing": 1 = pg_step_dev records the four HIP events pg_get_phase_ms reads (13-25 us of stream time per step at B = 4096: 2-4 %); 0 (default) = no instrumentation on the stream
     real* u_direct = nullptr; bool u_written = false;               // pg_step_dev: the caller's control array for k_solve to write (SolveOut::u_out2), and whether the launch did
     int* d_order = nullptr; int order_B = 0;  // [cap] + 2 counters: launch order filed by the nodes kernels of the current step (likely slow instances first); order_B = batch it is valid for
     real *d_pol_u2 = nullptr, *d_pol_u = nullptr; int* d_pol_src = nullptr;   // HJI fallback policy (HJI_computation.jl:133-158)
@@ -371,6 +372,7 @@ static bool find_option(pg_handle* h, const char* name, OptRef* o) {
     if (n == "pipe_max") return I(&h->pipe_max, 0, 16384);
     if (n == "lin_lanes") return I(&h->lin_lpi, 1, 2);
     if (n == "graph") return I(&h->graph_mode, 0, 1);
+    if (n == "phase_timing") return I(&h->phase_timing, 0, 1);
     if (n == "hji_cell_dims") return I(&h->hji_cell_dims, 3, 7);
     // k_solve_lat (lateral QP)
     if (n == "lateral_solver") return I(&h->lateral_solver, 0, 2);
@@ -994,7 +996,7 @@ int pg_get_next_control_hji(pg_handle* h, int32_t use_hji_policy, double* u_out,
 }
 int pg_step_dev(pg_handle* h, void* u_out_dev) {
     int rc = check_ready(h); if (rc) return rc;
-    const bool ev = !h->sg.capturing;                             // (a step that is being captured into a graph carries no timing events)
+    const bool ev = !h->sg.capturing && h->phase_timing != 0;     // (a step that is being captured into a graph carries no timing events; option "phase_timing" = 0: none at all)
     if (ev) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     if ((rc = launch_nodes(h, true))) return rc;
     if (ev) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));

@@ -43,9 +43,10 @@ class BatchedTrajectoryTrackingMPC:
     def __init__(self, trajectory, batch_capacity, vehicle=None, control_params=None, N_short=10, N_long=20, dt_short=0.01, dt_long=0.2,
                  use_correction_step=True, rk4_substeps=10, device=0, ipm_max_iter=40, ipm_tol=None, ipm_mu0=100.0, hji_eps=0.05, formulation="coupled",
                  precision="f64", walls=False, wall_weight=1000.0, polish=None, polish_rho=None, polish_tol=None, polish_ipm_tol=None, warm_polish=None, cold_guess=None,
-                 options=None):
+                 options=None, phase_timing=True):
         """options: {name: value} of build-defined options applied right after pg_create (pg_set_option, include/pigeon_mpc.h); precision "f64-diag" loads the
-        diagnostic build of the fp64 library (tests / tools only)."""
+        diagnostic build of the fp64 library (tests / tools only).  phase_timing: this mirror is the test / bench harness and switches the library's per-phase HIP events ON
+        by default (phase_ms(); the library's own default is off -- 2-4 % of a step: bench.py times its loops with phase_timing=False)."""
         self.precision = precision
         self.real = np.float32 if precision == "f32" else np.float64      # element type of DEVICE arrays handed to the *_dev entry points
         self.lib = _lib.load_library(precision)
@@ -98,6 +99,7 @@ class BatchedTrajectoryTrackingMPC:
         self.u_normalization = un
         self.qp_len = self.lib.pg_qp_len(self.h)
         self.trajectory = None
+        self.set_option("phase_timing", 1 if phase_timing else 0)
         for name, value in (options or {}).items():
             self.set_option(name, value)
         if trajectory is not None:

@@ -1,6 +1,6 @@
-"""Config 3 (B = 4096 coupled + HJI safety row, fp32) cold step under the PG_HJI_SEED knob: solve-phase time, interior-point iteration histogram, polish rounds of the
+"""Config 3 (B = 4096 coupled + HJI safety row, fp32) cold step under the option "hji_seed" (HJI_SEED=n in the environment of THIS tool; "hji_rounds" likewise): solve-phase time, interior-point iteration histogram, polish rounds of the
 instances whose row is violated at the current control, and the distance of the applied controls from a reference run (PG_KNOB_REF=1 stores it).
-Usage (GPU box): PG_HJI_SEED=1 python tools/gpu_config3_probe.py [f32|f64]"""
+Usage (GPU box): HJI_SEED=1 python tools/gpu_config3_probe.py [f32|f64]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,8 @@ if prec == "f32": state, control = state.astype(np.float32).astype(np.float64), 
 other = pkg.synthetic.other_cars(state, seed=777)
 if prec == "f32": other = other.astype(np.float32).astype(np.float64)
 knots, V, g = pkg.synthetic.hji_grid_large()
-mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, precision=prec)
+kw = {} if "PIT" not in os.environ else dict(polish_ipm_tol=float(os.environ["PIT"]))
+mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, precision=prec, **kw, options={"hji_seed": int(os.environ.get("HJI_SEED", "0")), "hji_rounds": int(os.environ.get("HJI_ROUNDS", "0"))})
 mpc.set_hji_cache(knots, V, g)
 ms = []
 for _ in range(5):
@@ -27,7 +28,7 @@ hot = (M[:, 0] * control[:, 0] / un[0] + M[:, 1] * (control[:, 1] + control[:, 2
 ref = os.path.join(ROOT, "gpurun_out", f"c3_ref_{prec}.npy")
 if os.environ.get("PG_KNOB_REF") == "1": np.save(ref, u)
 d = np.max(np.abs(u - np.load(ref)) / un, axis=1) if os.path.exists(ref) else np.zeros(B)
-print(f"{prec} seed={os.environ.get('PG_HJI_SEED', '0')}: phases {np.round(ms, 3)} | status {np.bincount(st, minlength=6)} | hot {int(hot.sum())}: served by rounds {int((it[hot] == 0).sum())}, rounds hist {np.bincount(np.clip(pol[hot & (it == 0)], 0, 30))[1:]} "
+print(f"{prec} seed={os.environ.get('HJI_SEED', '0')} rounds={os.environ.get('HJI_ROUNDS', '0')} pit={os.environ.get('PIT', '-')}: phases {np.round(ms, 3)} | status {np.bincount(st, minlength=6)} | hot {int(hot.sum())}: served by rounds {int((it[hot] == 0).sum())}, rounds hist {np.bincount(np.clip(pol[hot & (it == 0)], 0, 30))[1:]} "
       f"| ipm iters hist {np.bincount(it)} | |u - ref| max {d.max():.1e} (hot {d[hot].max():.1e})", flush=True)
 if os.environ.get("PG_C3_DUMP") == "1":            # the verified working sets of the instances with a violated safety row: stage by stage, which rows are held
     names = {0: "Ux>", 1: "Ux<", 2: "Fx>", 3: "d<", 4: "d>", 5: "Fx<", 6: "e0", 7: "e1", 8: "e2", 9: "e3", 10: "s1", 11: "s2", 12: "dd<", 13: "dd>", 14: "HJI", 15: "sH"}

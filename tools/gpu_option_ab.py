@@ -44,7 +44,9 @@ def main():
                 ph = []
                 for _ in range(a.reps):
                     if not a.warm: m.reset()
-                    m.step_dev(); torch.cuda.synchronize(); ph.append(m.phase_ms())
+                    m.step_dev(); torch.cuda.synchronize()
+                    try: ph.append(m.phase_ms())
+                    except Exception: ph.append([0.0, 0.0, 0.0])
                 ph = np.median(np.array(ph), axis=0)
                 t = time.perf_counter()
                 for _ in range(a.reps):
