@@ -1441,7 +1441,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     // of rate rows and slack pivots (every two- and three-round instance of a cold tracking batch) verifies at its first check, without the refinement pass the augmented
     // Lagrangian needed to bring |t| of its held rows below the tolerance (vector pass + roll-out: 13 of the ~37 us of such an instance's last round).
     // hmask: stages with a held rate row (wave-uniform, bit = stage lane); vfix: the pinned value in the stage's lane.
-    unsigned long long hmask = 0ull; real vfix = real(0.0);
+    unsigned long long hmask = 0ull; unsigned amask = 0;      // (amask: this stage's rows currently held active -- the polish state further down)
+    auto vfix_of = [&]() { return (amask & (1u << 12)) ? bb[12] : -bb[13]; };      // (formed where it is read: a register pair less to keep across the passes)
 #if !defined(PG_NO_MFMA)
     constexpr bool EXR = true;
 #else
@@ -1475,9 +1476,10 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             real d = d0 + d1;
             if (!use_gain) d = isK ? real(0.0) : d;            // v = 0 roll-out of the first start
             real v0 = rl(d, 8); const real v1 = rl(d, 9);
-            if constexpr (EXR && use_gain) {      // held rate row of this stage: lane 8 has evaluated F0 x + f0 (its slots of sK / skf hold F0 / f0 there), the input is the pinned value
+            if (EXR && use_gain && hmask != 0ull) {      // (wave-uniform branch: nothing is pinned while the interior point runs, and its iterations -- all of config 3's launch -- skip this)
+                // held rate row of this stage: lane 8 has evaluated F0 x + f0 (its slots of sK / skf hold F0 / f0 there), the input is the pinned value
                 const bool hk = (hmask >> k) & 1ull;
-                const real vf = delta ? real(0.0) : rl(vfix, k);
+                const real vf = delta ? real(0.0) : rl(vfix_of(), k);
                 const real g = v0 + (sSi[4 * k] * vf + sSi[4 * k + 1] * v1);
                 *((lane == 2 && hk) ? sG + k : sDum + lane) = g;
                 v0 = hk ? vf : v0;
@@ -1517,7 +1519,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     real it_[NROW];                    // 1 / t_j, refreshed once per interior-point iteration
     // Polish state (see the loop below): pmode = 0 while the interior point runs, then the round number of the active-set polish;
     // amask = this stage's rows currently held active.
-    int pmode = 0, pstat = 0; unsigned amask = 0, mask_ipm = 0, amask_1ago = 0xFFFFFFFFu, amask_2ago = 0xFFFFFFFFu; bool polish_gave_up = false, cycle_broken = false, settle_used = false; int settle_left = 0;
+    int pmode = 0, pstat = 0; unsigned mask_ipm = 0, amask_1ago = 0xFFFFFFFFu, amask_2ago = 0xFFFFFFFFu; bool polish_gave_up = false, cycle_broken = false, settle_used = false; int settle_left = 0;
     const real rho = C.polish_rho, ptol = C.polish_tol, dtol = real(1000.0) * C.polish_tol;      // dtol: largest correction of the last refinement pass a verified point may have had
     auto assemble = [&](real sigmu, bool matrices) {
         real W[NROW], ell[NROW];
@@ -1681,7 +1683,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             real F0c, F1c; rows89(Cc, F0c, F1c);
             const real S00 = R0 + rl(F0c, 8), S01 = rl(F0c, 9), S11 = R1 + rl(F1c, 9);
             const bool hk = EXR && ((hmask >> k) & 1ull);                           // the stage's rate row is held: its first input is pinned at vfk (wave-uniform)
-            const real vfk = EXR ? rl(vfix, k) : real(0.0);
+            const real vfk = (EXR && hmask != 0ull) ? rl(vfix_of(), k) : real(0.0);
             const real idet = frcp(hk ? S11 : S00 * S11 - S01 * S01);
             const real I00 = hk ? real(0.0) : S11 * idet, I01 = hk ? real(0.0) : -S01 * idet, I11 = hk ? idet : S00 * idet;
             const real K0 = -(I00 * F0c + I01 * F1c), K1 = -(I01 * F0c + I11 * F1c);
@@ -2147,7 +2149,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             const int end_up = __ffsll((long long)~run_up) - 1, end_dn = __ffsll((long long)~run_dn) - 1;      // first stage outside the run (lanes >= N are never in it)
             if (s < end_up) amask &= ~(overshoot & (1u << 12));
             if (s < end_dn) amask &= ~(overshoot & (1u << 13));
-            if constexpr (EXR) { hmask = __ballot(act && (amask & 0x3000u) != 0u); vfix = (amask & (1u << 12)) ? bb[12] : -bb[13]; }
+            if constexpr (EXR) hmask = __ballot(act && (amask & 0x3000u) != 0u);
         } else hmask = 0ull;
 
         // ---- predictor (sigma = 0, no correction) / first polish solve ----
