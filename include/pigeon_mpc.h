@@ -220,7 +220,7 @@ int pg_set_stream(pg_handle* h, void* hip_stream);
  * Measured on MI355X: +7 % on the cold benchmark batch (skidpadoval), -5..-8 % on the other paths and in closed loop (EXPERIMENTS.md 4.1) -- it pays only where a few
  * slow instances dominate the solve kernel.  The four compute calls invoked one by one are never fused. */
 int pg_set_fusion(pg_handle* h, int32_t mode);
-/* Pipelined nodes + update_QP (build-defined; no counterpart in the reference): for batches of 2304..16384 instances with cold instances, coupled formulation,
+/* Pipelined nodes + update_QP (build-defined; no counterpart in the reference): for batches of 2304..8192 instances with cold instances, coupled formulation,
  * pg_step / pg_step_dev / pg_simulate_dev run compute_linearization_nodes! and update_QP! as ONE launch in which the linearisation of
  * interval t starts as soon as nodes t, t + 1 of its instances are seeded (the cold seeding is a serial recurrence over the nodes: 0.18 ms of latency on 6 % of the
  * chip that the linearisation of the early intervals now runs under).  With a safety row installed its (M, b) are computed before that launch.  Same device
@@ -244,7 +244,7 @@ int pg_synchronize(pg_handle* h);
  *     "warm_trivial_cold" 0/1 (1)  a warm instance whose previous working set was empty starts like a cold one
  *     "hji_seed" 0..4 (0), "hji_rounds" 0..64 (0)   seeded working sets for instances whose safety row is violated at the current control (experiment, off)
  *   launch shape:
- *     "pipe_min" (2304), "pipe_max" (16384, at most)  batch sizes the pipelined nodes + update_QP launch serves (pg_set_pipeline)
+ *     "pipe_min" (2304), "pipe_max" (8192, at most: 256 nodes wavefronts of 32 instances)  batch sizes the pipelined nodes + update_QP launch serves (pg_set_pipeline)
  *     "lin_lanes" 1/2 (1)        lanes per (instance, interval) of the large-batch linearisation
  *     "phase_timing" 0/1 (0)     1 = pg_step_dev records the HIP events pg_get_phase_ms reads (four event records per step on the handle's stream: measured 13-25 us per step, 2-4 % of a
  *                                4096-instance step); 0 = no instrumentation, pg_get_phase_ms returns PG_ERR_STATE

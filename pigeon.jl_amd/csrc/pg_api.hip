@@ -28,7 +28,7 @@ struct pg_handle {
     int solve_parity = 0;                                     // which of the two to-do counters the next solve launch counts into (the other one holds the previous launch's count: see launch_solve)
     bool cnt_cleared = false;                                 // this step's projection kernel has zeroed the counter launch_solve is about to use
     bool lin_done = false;                                    // this step's launch_nodes already linearised (update_and_solve skips update_QP)
-    int* d_progress = nullptr;                                // [cap / 64 + 1] nodes completed per nodes wavefront (k_nodes_linearize)
+    int* d_progress = nullptr;                                // [cap / NODES_IPB + 8] nodes completed per nodes wavefront (k_nodes_linearize), then the fault word of the launch; last entry: fall-backs so far
     int64_t fallback_total = 0; int fallback_seen = 0;        // pg_get_pipeline_fallbacks: 64-bit total kept on the host, last value of the device's 32-bit word
     int fuse = 0;                                             // pg_step_dev / pg_simulate_dev: linearisation fused into the solve kernel (pg_set_fusion): 0 never (default), 1 always, 2 for all-warm batches
     std::string err;
@@ -43,7 +43,7 @@ struct pg_handle {
     real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     real* d_lam = nullptr;                                      // [cap][N][16] multipliers of the last solve (warm start of the polish)
     int* d_wfail = nullptr;                                     // [cap] back-off of k_solve_lat's warm attempts (the second half of the d_solved allocation: pg_reset clears both with one fill)
-    int pipe_min = 2304, pipe_max = 16384;                    // batch sizes the pipelined launch serves (options "pipe_min" / "pipe_max"; its nodes blocks must be resident at once: <= 16384)
+    int pipe_min = 2304, pipe_max = 256 * NODES_IPB;                    // batch sizes the pipelined launch serves (options "pipe_min" / "pipe_max"; its nodes blocks must be resident at once: <= 16384)
     int lin_lpi = 1;                                          // lanes per (instance, interval) of the large-batch linearisation (k_linearize_split / k_nodes_linearize): one lane with all eight
                                                               // directions (option "lin_lanes" = 2: the lane pair of rounds 1-3, for A/B runs; same bits in fp64, rounding-level differences in fp32)
     int* d_todo = nullptr; int split_solve = 1, split_lat = 1;      // d_todo [cap + 8]: instances the rounds-only k_solve leaves to the full kernel; behind them the control words of the solve launches:
@@ -245,7 +245,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_sep, cap * 4, real); ALLOC(h->d_nodes, cap * NN * 10, real); ALLOC(h->d_qp, cap * C.qp_len, real);
     ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
     ALLOC(h->d_solx, cap * NN * 8, real); ALLOC(h->d_sigma, cap * N * 3, real); ALLOC(h->d_mu, cap, real);
-    ALLOC(h->d_polish, cap, int); ALLOC(h->d_todo, cap + 8, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_naux, cap * NN * 4, real); ALLOC(h->d_progress, cap / 64 + 6, int); ALLOC(h->d_active, cap * N, uint16_t);
+    ALLOC(h->d_polish, cap, int); ALLOC(h->d_todo, cap + 8, int); ALLOC(h->d_lam, cap * N * 16, real); ALLOC(h->d_order, 2 * cap + 2, int); ALLOC(h->d_naux, cap * NN * 4, real); ALLOC(h->d_progress, cap / NODES_IPB + 8, int); ALLOC(h->d_active, cap * N, uint16_t);
 #ifdef PG_EXPERIMENTAL_SOLVE4
     { const char* e = getenv("PG_SOLVER"); h->solve_quad = N <= 32 && e && strcmp(e, "quad") == 0; }   // experimental four-instances-per-wavefront kernel (experimental/pg_solve4.hip)
     if (h->solve_quad) ALLOC(h->d_ws4, cap * ws4_len(N), real);
@@ -275,7 +275,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         (void)hipMemcpy(h->d_prev_ts, ts.data(), ts.size() * 8, hipMemcpyHostToDevice);
         (void)hipMemcpy(h->d_dt, dt.data(), dt.size() * 8, hipMemcpyHostToDevice);
         (void)hipMemset(h->d_solved, 0, 2 * cap * sizeof(int));
-        (void)hipMemset(h->d_progress, 0, (cap / 64 + 6) * sizeof(int));
+        (void)hipMemset(h->d_progress, 0, (cap / NODES_IPB + 8) * sizeof(int));
         (void)hipMemset(h->d_status, 0, cap * sizeof(int));
         (void)hipMemset(h->d_other, 0, cap * 4 * sizeof(real));
         (void)hipMemset(h->d_solx, 0, cap * NN * 8 * sizeof(real));
@@ -369,7 +369,7 @@ static bool find_option(pg_handle* h, const char* name, OptRef* o) {
     if (n == "solve_split") return I(&h->split_solve, 0, 1);
     // launch shape
     if (n == "pipe_min") return I(&h->pipe_min, 0, 1 << 30);
-    if (n == "pipe_max") return I(&h->pipe_max, 0, 16384);
+    if (n == "pipe_max") return I(&h->pipe_max, 0, 256 * NODES_IPB);
     if (n == "lin_lanes") return I(&h->lin_lpi, 1, 2);
     if (n == "graph") return I(&h->graph_mode, 0, 1);
     if (n == "phase_timing") return I(&h->phase_timing, 0, 1);
@@ -443,7 +443,7 @@ int pg_get_pipeline_fallbacks(pg_handle* h, int64_t* count) {
     HIPCHK(h, hipSetDevice(h->cfg.device));                 // (a multi-GPU process: the copy below must not depend on whichever device happens to be current)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     int v = 0;
-    HIPCHK(h, hipMemcpy(&v, h->d_progress + (size_t)h->cfg.batch_capacity / 64 + 5, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(&v, h->d_progress + (size_t)h->cfg.batch_capacity / NODES_IPB + 7, sizeof(int), hipMemcpyDeviceToHost));
     // the device word is a 32-bit counter of waiting wavefronts that gave up: the host keeps the 64-bit total and folds the device word into it (a wrap of the 32-bit
     // word between two calls would need 2^31 fall-backs -- at one per 20 ms wait, more than a year of nothing but fall-backs)
     h->fallback_total += (int64_t)(uint32_t)((uint32_t)v - (uint32_t)h->fallback_seen);
@@ -675,7 +675,7 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
     int* const solve_ctl = h->d_todo + cap;                                    // ... and the control words of this step's solve launches (launch_solve): the to-do counter it counts into
     h->cnt_cleared = !h->sg.capturing;
     if (with_time_grid) hipLaunchKernelGGL(k_project<true>, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep, h->d_t0, h->d_ts, h->d_dt, h->d_prev_ts,
-                                           pipelined ? h->d_progress : (int*)nullptr, (B + 63) / 64 + 1, order_cnt, solve_ctl, h->solve_parity);      // (+ 1: the fault word of the pipelined launch)
+                                           pipelined ? h->d_progress : (int*)nullptr, (B + NODES_IPB - 1) / NODES_IPB + 1, order_cnt, solve_ctl, h->solve_parity);      // (+ 1: the fault word of the pipelined launch)
     else hipLaunchKernelGGL(k_project<false>, dim3((B * 64 + 255) / 256), dim3(256), 0, h->stream, h->dc, B, h->d_state, h->d_sep, (const double*)nullptr, (double*)nullptr, (double*)nullptr,
                             (double*)nullptr, (int*)nullptr, 0, order_cnt, solve_ctl, h->solve_parity);
     LAUNCH_CHECK(h);
@@ -699,7 +699,7 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
         } else if (pipelined) {
             { int rc = launch_hji_rows_compute(h); if (rc) return rc; }      // (M, b) of the safety row: read by the lanes that linearise interval 0
             const int lpi = h->lin_lpi, ipb = 64 / lpi;
-            const int nbn = (B + 63) / 64, nbt = (B + ipb - 1) / ipb;
+            const int nbn = (B + NODES_IPB - 1) / NODES_IPB, nbt = (B + ipb - 1) / ipb;
             const size_t lds = traj_lds > 64 * 20 * sizeof(real) ? traj_lds : 64 * 20 * sizeof(real);
             auto kern = lpi == 1 ? (staged ? k_nodes_linearize<true, 1> : k_nodes_linearize<false, 1>) : (staged ? k_nodes_linearize<true, 2> : k_nodes_linearize<false, 2>);
             int nzf = (1024 - nbn + nbt - 1) / nbt;               // short-horizon intervals that go first: one wavefront for every SIMD the recurrence leaves free
@@ -712,7 +712,7 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
                 if (i <= h->dc.Ns ? i % 3 == 0 : (i - h->dc.Ns) % 5 == 4) pub |= 1ull << i;
             if (h->pipe_fault) pub = 1ull << 63;                  // test hook: nothing is ever published (tests/test_gpu_api_contract.py)
             hipLaunchKernelGGL(kern, dim3((unsigned)(nbn + nbt * h->dc.N)), block, lds, h->stream, h->dc, B, nbn, nzf, pub, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
-                               h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes, F, h->d_naux, h->d_progress, h->d_Mb, h->d_qp, h->d_progress + nbn, h->d_progress + cap / 64 + 5);
+                               h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes, F, h->d_naux, h->d_progress, h->d_Mb, h->d_qp, h->d_progress + nbn, h->d_progress + cap / NODES_IPB + 7);
             LAUNCH_CHECK(h);
             // repair, queued unconditionally and predicated on the device: if any waiting wavefront of the launch above gave up (its fault word, zeroed by the
             // projection kernel of the step), the deferred angles and update_QP! of the WHOLE batch run launch per phase -- the same kernels on the same nodes, so the QP
@@ -730,7 +730,7 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
             h->lin_done = true; h->stat_pipelined++;
         } else {
             auto kern = staged ? k_nodes<true> : k_nodes<false>;
-            hipLaunchKernelGGL(kern, grid, block, traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
+            hipLaunchKernelGGL(kern, dim3((B + NODES_IPB - 1) / NODES_IPB), block, traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
                                h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes, F, h->d_naux);
             LAUNCH_CHECK(h);
             const long nn = (long)B * h->dc.NN;

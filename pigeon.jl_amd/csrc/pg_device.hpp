@@ -459,15 +459,22 @@ PG_DEV Envelope stable_limits(const DevVehicle& B, real Ux, real Fxf, real Fxr) 
 // (defer = true: the three inverse tangents of the exit are left to the caller -- ang_y, ang_x, ang_t, tb carry their arguments: delta = atan2(ang_y, ang_x) - atan(ang_t),
 // beta = atan(tb) when beta_is_tan.  The cold node seeding is one serial chain per instance; the angles feed nothing in it and cost a fifth of its instructions)
 struct Steady { real beta, Ux, Uy, r, A, delta, Fx, ang_y, ang_x, ang_t, tb; bool beta_is_tan; };
-PG_DEV Steady steady_state(const DevVehicle& P, real V, real A_tan, real kappa, int num_iters, real r, real beta, real sb, real cb, real delta, real sd, real cd, real Fyf, bool defer = false) {
+// the friction-circle limit at the top of steady_state_estimates (vehicle_dynamics.jl:325-333): (A_tan, A_rad = V^2 kappa) pulled back onto |A| <= mu G.
+// A function of its own since round 5: the cold node seeding runs (V, s) ahead on this value -- the acceleration the solve below returns unless a limit binds inside it.
+PG_DEV void limit_accel(const DevVehicle& P, real V, real kappa, real& A_tan, real& A_rad) {
 #pragma clang fp contract(off)
-    real ang_y = real(0.0), ang_x = real(1.0), ang_t = real(0.0);
-    real A_rad = V * V * kappa;
-    real A_max = P.mu * P.G;
+    A_rad = V * V * kappa;
+    const real A_max = P.mu * P.G;
     if (hypot(A_tan, A_rad) > A_max) {
         if (fabs(A_rad) > A_max) { A_rad = A_max * sgn(A_rad); A_tan = real(0.0); }
         else A_tan = sqrt_diff_sq(A_max, A_rad) * sgn(A_tan);
     }
+}
+PG_DEV Steady steady_state(const DevVehicle& P, real V, real A_tan, real kappa, int num_iters, real r, real beta, real sb, real cb, real delta, real sd, real cd, real Fyf, bool defer = false) {
+#pragma clang fp contract(off)
+    real ang_y = real(0.0), ang_x = real(1.0), ang_t = real(0.0);
+    real A_rad;
+    limit_accel(P, V, kappa, A_tan, A_rad);
     real rdot = A_tan * kappa;
     real Fxr = real(0.0), Fxf = real(0.0), A_out = A_tan, tb = real(0.0);
     bool beta_is_tan = false;

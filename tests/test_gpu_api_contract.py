@@ -119,7 +119,7 @@ def test_options_by_name(pkg, skidpad):
     """pg_set_option / pg_get_option: the build-defined switches of a handle (round 4 read them from the environment).  Defaults as documented in the header, range and
     name checks, read-only statistics, options of the other formulation refused."""
     m = pkg.BatchedTrajectoryTrackingMPC(skidpad, 8)
-    for name, dflt in [("clip_guess", 1), ("ck_riccati", 1), ("warm_trivial_cold", 1), ("hji_seed", 0), ("solve_split", 1), ("pipe_min", 2304), ("pipe_max", 16384), ("lin_lanes", 1),
+    for name, dflt in [("clip_guess", 1), ("ck_riccati", 1), ("warm_trivial_cold", 1), ("hji_seed", 0), ("solve_split", 1), ("pipe_min", 2304), ("pipe_max", 8192), ("lin_lanes", 1),
                        ("graph", 0), ("hji_cell_dims", 3), ("stat_pipelined_launches", 0), ("stat_split_solve_launches", 0)]:
         assert m.get_option(name) == dflt, name
     m.set_option("pipe_min", 1024); assert m.get_option("pipe_min") == 1024
