@@ -1409,7 +1409,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     real* sDum = sx0 + 8;              // [64] sink for predicated-off stores (keeps the pass loops branch-free)
     real* sZero = sDum + 64;           // [2]  a stored 0.0 (off-pattern entries of Qhat)
     real* skf_ck = sZero + 2;          // [N][2] the predictor's feed-forward terms as the matrix pass left them (skf itself is rewritten by every vector pass): restored when the recursion restarts at its checkpoint
-    real* sG = skf_ck + 2 * N;         // [N]    held steering-rate rows (eliminated exactly, see `hmask`): gradient of the Lagrangian in the pinned input = -/+ the row's multiplier
+    real* sF0 = skf_ck + 2 * N;        // [N][8] F0 = Bbar0' P Abar of the matrix pass: the stationarity condition in the first input, for the multiplier of a pinned rate row
+    real* sAux = sF0 + 8 * N;          // [N][3] Bbar0' P Bbar0, S01, Bbar0' y (the last rewritten by a vector pass)
 
     const QpOff o = qp_offsets(N);
     const real* Q = qp + (size_t)b * C.qp_len;
@@ -1539,14 +1540,18 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     // Headline batch: rounds 1 / 2 / 3 / 4+ 2105 / 714 / 928 / 349 -> 2105 / 1552 / 372 / 67 instances (mean 1.97 -> 1.62), k_solve 0.386 -> 0.334 ms.  Measured and dropped:
     // clipping in every round (11 instances end in the interior point), clipping at the steering stops as well (fp64: 3-round instances 372 -> 418, 4+ 67 -> 21, same time; fp32: more 9-12 round instances, 0.34 -> 0.43 ms; and the code alone costs 4 % in the roll-out).  Option "clip_guess" = 0: off.
     bool clip_now = false, clip_used = false, clip_off = false; unsigned clip_mask = 0u;
-    // Held steering-RATE rows (12, 13) are eliminated EXACTLY (round 5): such a row pins the first input of its stage, v0 = +ddmax / -ddmin, so the stage is solved for the
-    // second input alone -- K0 = 0, kff0 = the pinned value, (K1, kff1) from the 1 x 1 pivot S11 with the cross term S01 v0 in its right-hand side -- and the row's
-    // multiplier is read off the stationarity condition in v0 after the roll-out: lambda = -/+ (F0 x + f0 + S00 v0 + S01 v1).  No penalty, no multiplier iteration: a working set
-    // of rate rows and slack pivots (every two- and three-round instance of a cold tracking batch) verifies at its first check, without the refinement pass the augmented
-    // Lagrangian needed to bring |t| of its held rows below the tolerance (vector pass + roll-out: 13 of the ~37 us of such an instance's last round).
-    // hmask: stages with a held rate row (wave-uniform, bit = stage lane); vfix: the pinned value in the stage's lane.
-    unsigned long long hmask = 0ull; unsigned amask = 0;      // (amask: this stage's rows currently held active -- the polish state further down)
-    auto vfix_of = [&]() { return (amask & (1u << 12)) ? bb[12] : -bb[13]; };      // (formed where it is read: a register pair less to keep across the passes)
+    // Held steering-RATE rows (12, 13) are eliminated EXACTLY (round 5): such a row pins the first input of its stage, v0 = +ddmax / -ddmin.  The stage cost of a pinned stage
+    // carries  Rhat0 = BIGP, rhat0 = -BIGP v0  -- a penalty so large that 1 / BIGP vanishes against everything else in the arithmetic (1e200; 1e22 in fp32): the UNCHANGED
+    // recursion then returns K0 = 0, kff0 = v0 and (K1, kff1) from the 1 x 1 pivot S11 with the cross term S01 v0 in its right-hand side to the last bit -- no select on the
+    // serial chain, nothing added to the roll-out.  The row's multiplier is read off the stationarity condition in v0 by the stage's own lane behind the roll-out:
+    //   lambda = -/+ (F0 x + Bbar0'y + S00 v0 + S01 v1),  F0, Bbar0'P Bbar0, S01, Bbar0'y left in LDS by the matrix (vector) pass; in a correction pass x, v are the corrections
+    //   and the first input's own gradient is Rhat0 v0 (the re-centred problem's multiplier is the multiplier).
+    // No penalty iteration, t = 0 exactly: a working set of rate rows and slack pivots (every two- and three-round instance of a cold tracking batch) verifies at its first
+    // check, without the refinement pass the augmented Lagrangian needed (vector pass + roll-out: 13 of the ~37 us of such an instance's last round).
+    // (First version of this round: K0 = 0 / kff0 = v0 / 1 x 1 pivot through selects in the matrix pass and the multiplier formed inside the roll-out -- +150 cycles per stage
+    //  of the matrix pass, +10 % per round, and the warm steps of a closed loop, one round each with nothing to save, went from 0.59 to 0.62 ms.)
+    unsigned amask = 0;                // (this stage's rows currently held active -- the polish state further down)
+    const real BIGP = sizeof(real) == 8 ? real(1e200) : real(1e22);
 #if !defined(PG_NO_MFMA)
     constexpr bool EXR = true;
 #else
@@ -1581,14 +1586,6 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             real d = d0 + d1;
             if (!use_gain) d = isK ? real(0.0) : d;            // v = 0 roll-out of the first start
             real v0 = rl(d, 8); const real v1 = rl(d, 9);
-            if (EXR && use_gain && hmask != 0ull) {      // (wave-uniform branch: nothing is pinned while the interior point runs, and its iterations -- all of config 3's launch -- skip this)
-                // held rate row of this stage: lane 8 has evaluated F0 x + f0 (its slots of sK / skf hold F0 / f0 there), the input is the pinned value
-                const bool hk = (hmask >> k) & 1ull;
-                const real vf = delta ? real(0.0) : rl(vfix_of(), k);
-                const real g = v0 + (sSi[4 * k] * vf + sSi[4 * k + 1] * v1);
-                *((lane == 2 && hk) ? sG + k : sDum + lane) = g;
-                v0 = hk ? vf : v0;
-            }
             if (clip_now) {        // (wave-uniform; first round of a cold instance) saturated roll-out: the gain of the unconstrained problem, the steering rate held inside its limits
                 const real hi = rl(bb[12], k), lo = -rl(bb[13], k);
                 unsigned cm = 0u;
@@ -1663,7 +1660,9 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             qo[3] = g3 - e_c11 * e_g1 * e_d1 - e_c21 * e_g2 * e_d2;
             qo[6] = g6 - (wall_on ? real(0.0) : e_ch0 * e_gh * e_dh); qo[7] = g7 - e_ch1 * e_gh * e_dh;
             if (wall_on) qo[5] = (ell[0] - ell[1]) - e_ch0 * e_gh * e_dh;
-            sr[2 * s] = gv0;
+            const bool pinned = exr && (pmode != 0 || !IPM) && (amask & 0x3000u) != 0u;
+            const real vpin = (amask & (1u << 12)) ? bb[12] : -bb[13];
+            sr[2 * s] = pinned ? -BIGP * vpin : gv0;
             if (matrices) {
                 real* Qo = sQ + 10 * (s + 1);
                 if (wall_on) Qo[5] = Qd5 + W[0] + W[1] - e_ch0 * e_ch0 * e_dh;
@@ -1677,7 +1676,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
                 Qo[8] = yr - e_c10 * e_c11 * e_d1 - e_c20 * e_c21 * e_d2;
                 Qo[3] = rr - e_c11 * e_c11 * e_d1 - e_c21 * e_c21 * e_d2;
                 Qo[9] = M0 * M1 * W[14] - e_ch0 * e_ch1 * e_dh;
-                sR[2 * s] = Rd0 + W[12] + W[13];
+                sR[2 * s] = pinned ? BIGP : Rd0 + W[12] + W[13];
             }
         }
     };
@@ -1786,18 +1785,19 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             Cc = PG_MFMA(mc < 10 ? b11 : real(0.0), mc == 10 ? M1 + V1 : M1, Cc);
             // rows 8, 9 of C: F = Bbar' M_A (c < 8), S - Rhat (c = 8, 9), Bbar' y (c = 10)
             real F0c, F1c; rows89(Cc, F0c, F1c);
-            const real S00 = R0 + rl(F0c, 8), S01 = rl(F0c, 9), S11 = R1 + rl(F1c, 9);
-            const bool hk = EXR && ((hmask >> k) & 1ull);                           // the stage's rate row is held: its first input is pinned at vfk (wave-uniform)
-            const real vfk = (EXR && hmask != 0ull) ? rl(vfix_of(), k) : real(0.0);
-            const real idet = frcp(hk ? S11 : S00 * S11 - S01 * S01);
-            const real I00 = hk ? real(0.0) : S11 * idet, I01 = hk ? real(0.0) : -S01 * idet, I11 = hk ? idet : S00 * idet;
+            const real bpb0 = rl(F0c, 8), S00 = R0 + bpb0, S01 = rl(F0c, 9), S11 = R1 + rl(F1c, 9);
+            const real idet = frcp(S00 * S11 - S01 * S01);
+            const real I00 = S11 * idet, I01 = -S01 * idet, I11 = S00 * idet;
             const real K0 = -(I00 * F0c + I01 * F1c), K1 = -(I01 * F0c + I11 * F1c);
             const real f0 = r0v + F0c, f1 = r1v + F1c;                              // (meaningful in column 10)
-            const real kf0 = hk ? vfk : -(I00 * f0 + I01 * f1), kf1 = -(I01 * f0 + I11 * (hk ? f1 + S01 * vfk : f1));
-            // (a pinned stage leaves F0, f0, S00, S01 where the roll-out finds them -- in the slots of the absent gain row -- for the row's multiplier)
-            *((mg < 2 && mc < 8) ? sK + 16 * k + 8 * mg + mc : sDum + lane) = mg == 0 ? (hk ? F0c : K0) : K1;
-            *(lane < 3 ? sSi + 4 * k + lane : sDum + lane) = lane == 0 ? (hk ? S00 : I00) : (lane == 1 ? (hk ? S01 : I01) : I11);
-            *((mc == 10 && mg < 2) ? skf + 2 * k + mg : sDum + lane) = mg == 0 ? (hk ? f0 : kf0) : kf1;
+            const real kf0 = -(I00 * f0 + I01 * f1), kf1 = -(I01 * f0 + I11 * f1);
+            *((mg < 2 && mc < 8) ? sK + 16 * k + 8 * mg + mc : sDum + lane) = mg == 0 ? K0 : K1;
+            *(lane < 3 ? sSi + 4 * k + lane : sDum + lane) = lane == 0 ? I00 : (lane == 1 ? I01 : I11);
+            *((mc == 10 && mg < 2) ? skf + 2 * k + mg : sDum + lane) = mg == 0 ? kf0 : kf1;
+            if constexpr (EXR) {      // (off the chain: what the multiplier of a pinned rate row is read from -- F0, Bbar0'P Bbar0, S01, Bbar0'y)
+                *((mg == 0 && mc < 8) ? sF0 + 8 * k + mc : sDum + lane) = F0c;
+                *(lane < 3 ? sAux + 3 * k + lane : sDum + lane) = lane == 0 ? bpb0 : (lane == 1 ? S01 : rl(F0c, 10));
+            }
             // C += F' [K | kff]
             const real a3 = mg == 0 ? F0c : (mg == 1 ? F1c : real(0.0));
             const real b3 = mg == 0 ? (mc == 10 ? kf0 : K0) : (mg == 1 ? (mc == 10 ? kf1 : K1) : real(0.0));
@@ -1915,22 +1915,23 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             for (int m = 0; m < 6; m++) { a6[m] = Ak[SB_ROW * m + r8]; b0[m] = Bk[2 * m]; b1[m] = Bk[2 * m + 1]; }
             real mc = delta ? real(0.0) : sMc[8 * k + r8], qk = sq[8 * k + r8], k0 = sK[16 * k + r8], k1 = sK[16 * k + 8 + r8], r0 = sr[2 * k], r1 = sr[2 * k + 1];
             real I00 = sSi[4 * k], I01 = sSi[4 * k + 1], I11 = sSi[4 * k + 2];
-            const bool hk = EXR && ((hmask >> k) & 1ull);      // pinned first input (held rate row; only ever in a correction pass, where the pinned value is 0): no gain row, 1 x 1 pivot
-            if (hk) { k0 = real(0.0); I00 = real(0.0); I01 = real(0.0); }
             real yi = mc + pi;
             real y[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) y[m] = rl(yi, m);
-            real f0 = r0 + y[6], f1 = r1 + y[7], f0b = real(0.0), f1b = real(0.0);
+            // (Bbar0'y is summed on its own and rhat0 added last: on a pinned stage rhat0 is BIGP x a rounding error and would swallow the sum the multiplier needs)
+            real by0 = y[6], f1 = r1 + y[7], f0b = real(0.0), f1b = real(0.0);
             real acc = qk + (r8 == 6 ? y[6] : (r8 == 7 ? y[7] : real(0.0))), accb = real(0.0);
 #pragma unroll
             for (int m = 0; m < 6; m += 2) {
-                f0 += b0[m] * y[m]; f0b += b0[m + 1] * y[m + 1]; f1 += b1[m] * y[m]; f1b += b1[m + 1] * y[m + 1];
+                by0 += b0[m] * y[m]; f0b += b0[m + 1] * y[m + 1]; f1 += b1[m] * y[m]; f1b += b1[m + 1] * y[m + 1];
                 acc += a6[m] * y[m]; accb += a6[m + 1] * y[m + 1];
             }
-            f0 += f0b; f1 += f1b;
+            by0 += f0b; f1 += f1b;
+            const real f0 = r0 + by0;
             pi = (acc + accb) + (k0 * f0 + k1 * f1);          // (k == 0: never used)
-            *(lane < 2 ? skf + 2 * k + lane : sDum + lane) = lane == 0 ? (hk ? f0 : -(I00 * f0 + I01 * f1)) : -(I01 * f0 + I11 * f1);
+            *(lane < 2 ? skf + 2 * k + lane : sDum + lane) = lane == 0 ? -(I00 * f0 + I01 * f1) : -(I01 * f0 + I11 * f1);
+            if constexpr (EXR) *(lane == 2 ? sAux + 3 * k + 2 : sDum + lane) = by0;      // Bbar0'y of this pass
         }
         __syncthreads();
     };
@@ -1981,7 +1982,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     for (int attempt = listm ? 0 : (warm ? -2 : (guess ? -1 : 0)); attempt < (IPM ? 2 : 0); attempt++) {
     if (attempt == -1 && !guess) continue;
     rp0 = real(0.0); phi = real(1.0); pmode = 0; pstat = 0; polish_gave_up = false; amask_1ago = 0xFFFFFFFFu; amask_2ago = 0xFFFFFFFFu; cycle_broken = false; settle_used = false; settle_left = 0; good_steps = 0;
-    warm_attempt = attempt < 0; from_prev = attempt == -2; hmask = 0ull;
+    warm_attempt = attempt < 0; from_prev = attempt == -2;
     if (!IPM || attempt < 0) {
         amask = (act && from_prev) ? (unsigned)O.active[(size_t)b * N + s] : 0u; mask_ipm = amask;
 #pragma unroll
@@ -2090,15 +2091,22 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     };
     // after a polish solve (tp = slacks at the new point): multiplier update of the active rows, then the verification.  Returns 0 = verified (solution
     // stored, pstat set), 1 = same set but the active rows are not yet at t = 0 within `ttol` (refine), 2 = the active set changed, 3 = the sets cycle.
-    auto polish_check = [&](const real* tp, real ttol, real dmax = real(0.0)) -> int {
+    auto polish_check = [&](const real* tp, real ttol, real dmax = real(0.0), bool delta = false) -> int {
         unsigned add = 0, drop = 0; bool settled = !(dmax > dtol);
         // (a roll-out that clipped the steering rate is not the optimum of its working set: no multiplier update, no drops -- its clipped transitions join the set)
         const bool clipped = __any(clip_mask != 0u);
         if (clipped) { add = act ? (clip_mask & ~amask) : 0u; settled = false; clip_used = true; }
-        if (exr) {      // held rate rows: the multiplier IS minus / plus the gradient in the pinned input the roll-out left in sG (t = 0 exactly)
-            const real g = sG[s];
+        if (exr && !clipped) {      // pinned rate row: the multiplier IS minus / plus the gradient of the Lagrangian in the pinned input at the roll-out's point (t = 0 exactly)
             const bool h12 = act && (amask & (1u << 12)) != 0u, h13 = act && !h12 && (amask & (1u << 13)) != 0u;
-            R.lam[12] = h12 ? -g : R.lam[12]; R.lam[13] = h13 ? g : R.lam[13];      // (selects: a conditional store to either slot sends both to scratch)
+            if (__any(h12 || h13)) {
+                const real* F = sF0 + 8 * s; const real* xs = sx + 8 * s; const real* ax = sAux + 3 * s;
+                real g = ax[2], g2 = real(0.0);
+#pragma unroll
+                for (int m = 0; m < 8; m += 2) { g += F[m] * xs[m]; g2 += F[m + 1] * xs[m + 1]; }
+                const real v0s = sv[2 * s], v1s = sv[2 * s + 1], vpin = h12 ? bb[12] : -bb[13];
+                g = (g + g2) + ((delta ? Rd0 * vpin : (Rd0 + ax[0]) * v0s) + ax[1] * v1s);
+                R.lam[12] = h12 ? -g : R.lam[12]; R.lam[13] = h13 ? g : R.lam[13];      // (selects: a conditional store to either slot sends both to scratch)
+            }
         }
 #pragma unroll
         for (int j = 0; j < NROW; j++) {
@@ -2257,8 +2265,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             const int end_up = __ffsll((long long)~run_up) - 1, end_dn = __ffsll((long long)~run_dn) - 1;      // first stage outside the run (lanes >= N are never in it)
             if (s < end_up) amask &= ~(overshoot & (1u << 12));
             if (s < end_dn) amask &= ~(overshoot & (1u << 13));
-            hmask = exr ? __ballot(act && (amask & 0x3000u) != 0u) : 0ull;
-        } else hmask = 0ull;
+        }
 
         // ---- predictor (sigma = 0, no correction) / first polish solve ----
 #pragma unroll
@@ -2400,7 +2407,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             if (mu > real(1e8) * C.ipm_mu0) break;          // diverging: give up on this start
             it++;
         } else {
-            const int pc = polish_check(tp, ptol, last_dmax);
+            const int pc = polish_check(tp, ptol, last_dmax, true);
             ptrace(pc + 10, tp);
             if (pc == 0) break;
             // same set, but the rows are not at t = 0 yet or the correction was not small: another refinement pass on the same matrices (no predictor)

@@ -99,7 +99,10 @@ class BatchedTrajectoryTrackingMPC:
         self.u_normalization = un
         self.qp_len = self.lib.pg_qp_len(self.h)
         self.trajectory = None
-        self.set_option("phase_timing", 1 if phase_timing else 0)
+        try:
+            self.set_option("phase_timing", 1 if phase_timing else 0)
+        except _lib.PigeonError:          # (an older build selected through PIGEON_HIP_LIB for an A/B run: its events are always on)
+            pass
         for name, value in (options or {}).items():
             self.set_option(name, value)
         if trajectory is not None:
