@@ -59,6 +59,7 @@ struct pg_handle {
     size_t solve_lds = 0; bool solve_ring = false;
     real* d_walls = nullptr;                                    // [cap][N][2] wall extension
     char* d_lat_ws = nullptr; bool lat_mem = false, lat_mem_forced = false;            // k_solve_lat's workspace for horizons beyond 32 intervals (option "lat_workspace" = 1: at every horizon)
+    real* d_lat_aux = nullptr;                                  // [cap][64][8] F, Bbar'P Bbar, Bbar'y per stage: what k_solve_lat reads the multiplier of a pinned rate row from
     real* d_lat = nullptr;                                      // [cap][N][LATP] packed stage records of the lateral formulation (k_qp_dec -> k_solve_lat)
     // hipGraph of a whole host-to-host warm step (pg_step of a small batch is launch-bound: one copy in, four kernels, one copy out; captured once, replayed while
     // nothing that the launches depend on has changed -- `sig` is compared field by field before every replay)
@@ -132,6 +133,8 @@ static int configure_lateral(pg_handle* h, std::string* why) {
     if (!h->solve_lat) { C.lat_pack = nullptr; return PG_OK; }
     if (!h->d_lat && hipMalloc((void**)&h->d_lat, cap * N * LATP * sizeof(real)) != hipSuccess) { *why = "hipMalloc failed for the packed lateral stage records"; return PG_ERR_HIP; }
     C.lat_pack = h->d_lat;
+    if (!h->d_lat_aux && hipMalloc((void**)&h->d_lat_aux, cap * 64 * LAT_AUX * sizeof(real)) != hipSuccess) { *why = "hipMalloc failed for k_solve_lat's multiplier block"; return PG_ERR_HIP; }
+    C.lat_aux = h->d_lat_aux;
     // (round 4: with the wall rows the two-slot register variant spills 720 B per lane since the warm start was added -- 1.57 ms at N = 30 against 1.36 ms through the
     // workspace; without them the registers still win, 0.94 against 1.01 ms)
     h->lat_mem = N > 32 || (cfg->walls && N > 16) || h->lat_mem_forced;
@@ -193,7 +196,7 @@ int pg_default_config_decoupled(pg_config* c) {
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_in, h->d_out, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_todo, h->d_order, h->d_naux, h->d_progress, h->d_lat, h->d_lat_ws};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_todo, h->d_order, h->d_naux, h->d_progress, h->d_lat, h->d_lat_aux, h->d_lat_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->sg.x) (void)hipGraphExecDestroy(h->sg.x);

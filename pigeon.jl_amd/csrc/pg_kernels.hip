@@ -59,6 +59,7 @@ struct DevCfg {
     int lat_settle;             // k_solve_lat: working-set decisions wait for settled multipliers (0 never, 1 warm attempts, 2 every polish)
     int lat_wipm; real lat_wmu, lat_wtau;      // k_solve_lat: interior point of a warm instance starts from the previous solution (floors of t lambda and of t)
     int lat_warm_rounds;        // k_solve_lat: working sets a warm attempt (previous step's set and multipliers) may try before the cold start takes over
+    real* lat_aux;              // lateral formulation: [B][64][8] what the multiplier of a pinned rate row is read from (k_solve_lat, see its header)
     char* lat_ws;               // lateral formulation, horizons beyond 32 intervals: k_solve_lat's per-wavefront workspace (lat_ws_bytes(B); nullptr: not wanted)
     real* lat_pack;             // lateral formulation: [B][N][LATP] packed stage records for k_solve_lat, written by k_qp_dec next to the QP block (nullptr: not wanted)
 };

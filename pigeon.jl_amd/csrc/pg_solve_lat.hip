@@ -22,12 +22,14 @@
 //  * LDS per instance: 24 doubles per stage (stage cost terms that the roll-out result overwrites, gains, S^-1, P cbar) = 9.6 KB at N = 50: four wavefronts per CU.
 //
 //  * Round 5 -- PINNED INPUTS.  The stage has ONE input, and a held steering-rate row fixes it (v = +ddmax / -ddmin).  The polish eliminates such a row exactly instead of
-//    penalising it: the stage has no gain (K = 0, kff = the pinned value), the recursion is  P_k = Q + A'PA,  p_k = q + A'y + F'kff,  and the row's multiplier is read off
-//    stationarity in v behind the roll-out: lambda = -/+ (F x + f + S v).  Nothing iterates: round 4's augmented Lagrangian contracted by S / (S + rho) per pass with
-//    S = Rhat + Bbar'P Bbar up to 1e12 on the open-loop unstable 8 s horizon, and such multipliers stalled (54 of 4096 config-5 answers ended unverified; now 0-1).
-//    Encoding for the serial passes, all in existing slots: rec[5] = -Rhat0 (negative: pinned), rec[11] = kff; table slots K[0..4] = F, kff = f, Sinv = -S.
-//    (Measured and removed: pinning a held steering-BOUND row the same way, v = -delta_k + bound, i.e. the fixed feedback K = -e_4' with the general recursion
-//    P_k = Q + A'PA + F'K + K'F + K'SK -- the same 4095 / 4096 verify, but 24 answers move by 1e-7 .. 8e-7 and delta by up to 6e-4 in the far horizon: those rows stay penalised.)
+//    iterating on its multiplier: the stage cost of a pinned stage carries Rhat = BIGP, rhat = -BIGP v -- a penalty so large that 1 / BIGP vanishes against everything else
+//    in the arithmetic (1e200; 1e22 in fp32) -- and the UNCHANGED serial passes return K = 0, kff = v to the last bit.  The row's multiplier is read off stationarity in v by
+//    the stage's own lane behind the roll-out: lambda = -/+ (F x + Bbar'y + S v), with F = Bbar'P Abar, Bbar'P Bbar and Bbar'y left in a small per-wavefront block of the
+//    workspace by the matrix (vector) pass.  Round 4's augmented Lagrangian contracted by S / (S + rho) per pass with S up to 1e12 on the open-loop unstable 8 s horizon, and such
+//    multipliers stalled: 53 / 54 of 4096 config-5 answers ended unverified; now 0 / 4.
+//    (First version of this round: K = 0 / kff = v through flags in every serial pass, each pass compiled twice -- +3.5 % on the launch.  Measured and removed: pinning a held
+//    steering-BOUND row the same way, v = -delta_k + bound, i.e. the fixed feedback K = -e_4' with the general recursion P_k = Q + A'PA + F'K + K'F + K'SK -- the same 4095 /
+//    4096 verify, but 24 answers move by 1e-7 .. 8e-7 and delta by up to 6e-4 in the far horizon: those rows stay penalised.)
 //
 // The DPP forms are inline assembly: hipcc does not pad their hazards (VALU write -> DPP read of the same register: 2 wait states; EXEC write -> DPP: 5), so every block opens
 // with s_nop 4 and the pass loops carry no divergent branch (predicated stores go to a dummy LDS slot).
@@ -55,6 +57,8 @@ __host__ __device__ inline size_t lat_lds_doubles(int N) { return (size_t)4 * N 
 // (13 rows x 64 lanes x (t, lambda) + 7 x 64 x 2 second-order terms + 64 x 4 eliminated slacks + 64 x 16 B of working-set words, fp64), four slots per wavefront
 constexpr size_t LAT_WS_SLOT_BYTES = 23552;
 __host__ __device__ inline size_t lat_ws_bytes(int B) { return (size_t)((B + 3) / 4) * 4 * LAT_WS_SLOT_BYTES; }
+// what the multiplier of a pinned rate row is read from (C.lat_aux, per instance and stage): F[0..4] = Bbar'P Abar, Bbar'P Bbar, Bbar'y, -   (L2-resident, written by every matrix pass)
+constexpr int LAT_AUX = 8;
 
 // broadcast of lane K of each 16-lane row (compiler builtin: hazards padded by hipcc; v_mov_b64_dpp row_newbcast)
 template <int K> PG_DEV real lat_bc(real v) {
@@ -124,6 +128,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // ---------------- addressing of the serial passes ----------------
     // The stage matrices come from the packed records k_qp_dec wrote (LATP doubles per stage, L2-resident): [8 i + m] = row i of [A | B0+Bf | Bf | c], m = 7 a stored 0.
     const real* const Lb = C.lat_pack + (size_t)b * N * LATP;
+    real* const aux = C.lat_aux + (size_t)b * 64 * LAT_AUX;      // (an invalid lane group of a ragged last wavefront writes the last instance's block again: same values)
     // column distribution (matrix + vector pass): lane c holds X[0..3][c] of [Abar | Bbar | cbar]; row 4 is the constant x4; lanes 7..15 read the zero column
     const real* const colp = Lb + (c < 7 ? c : 7);
     const real cx4 = (c == 4 || c == 5) ? real(1.0) : real(0.0);
@@ -148,10 +153,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // ---------------- Riccati matrix pass (+ the predictor's vector recursion in column 6) ----------------
     // Software-pipelined by hand: the operands of stage k - 1 (global: the matrix column and dt; LDS: the stage-cost column, Rhat / rhat) are requested at the top of
     // stage k and first touched at the top of stage k - 1, a whole stage of arithmetic (~900 cycles) later.
-    // (every serial pass exists twice: PIN = the form that honours pinned inputs, taken by a wavefront while any of its four instances is in a polish; the plain form -- an
-    //  LDS read, two broadcasts and a handful of selects per stage shorter -- serves the interior-point iterations, which are most of a cold launch)
-    auto matrix_pass = [&](auto pin_t) __attribute__((always_inline)) {
-        constexpr bool PIN = decltype(pin_t)::value;
+    auto matrix_pass = [&]() __attribute__((always_inline)) {
         real P[5], X[4], Xn[4], Qc[5], Qn[5], dtk, dtn, radd, raddn;
         {   // P_N = Qhat_{N-1} (cost on node N), p_N = qhat_{N-1}
             const real dtl = Lb[(size_t)(N - 1) * LATP + 48];
@@ -188,21 +190,18 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
 #pragma unroll
             for (int i = 0; i < 5; i++) { *(c == 6 ? sTab + LAT_TAB * k + 7 + i : sDum + lane) = M[i]; M[i] = fma(m6, P[i], M[i]); }
             // G[c] = sum_i Bbar[i] M[i][c]: lanes 0..4 F, lane 5 Bbar' P Bbar, lane 6 Bbar' y   (Bbar = column 5; its row 4 is 1)
-            // pinned input (see the header): lane 5's Rhat slot is negative, lane 6's rhat slot carries kff
-            const bool held = PIN && lat_bc<5>(radd) < real(0.0);
-            const real kffp = PIN ? lat_bc<6>(radd) : real(0.0);
-            real G0 = held ? (c == 5 ? -radd : real(0.0)) : radd, G1 = M[4];
+            real G0 = real(0.0), G1 = M[4];
             asm volatile("s_nop 4\n\t"
                          LAT_DPP(0, 2, 6, 5) LAT_DPP(1, 3, 7, 5) LAT_DPP(0, 4, 8, 5) LAT_DPP(1, 5, 9, 5)
                          : "+v"(G0), "+v"(G1)
                          : "v"(X[0]), "v"(X[1]), "v"(X[2]), "v"(X[3]), "v"(M[0]), "v"(M[1]), "v"(M[2]), "v"(M[3]));
-            const real G = G0 + G1;                       // lane 5: S = Rhat + Bbar' P Bbar; lane 6: f = rhat + Bbar' y
-            const real Sb = lat_bc<5>(G);
-            const real Sinv = held ? real(0.0) : frcp(Sb);
-            const real Kfree = -G * Sinv;                 // lanes 0..4: K[c]; lane 6: kff
-            const real Kc = held ? (c == 6 ? kffp : real(0.0)) : Kfree;
-            // (a pinned stage leaves F, f and -S in the slots of the gain row, kff and S^-1: the roll-out and the vector pass find them there)
-            *(wslot >= 0 ? sTab + LAT_TAB * k + wslot : sDum + lane) = held ? (c == 5 ? -Sb : G) : (c == 5 ? Sinv : Kc);
+            // (the stage-cost term is added LAST: on a pinned stage it is BIGP (x the pinned value) and would swallow Bbar'P Bbar / Bbar'y, which the row's multiplier needs)
+            const real Gb = G0 + G1;                      // lanes 0..4: F; lane 5: Bbar' P Bbar; lane 6: Bbar' y
+            aux[(size_t)k * LAT_AUX + (c < 7 ? c : 7)] = Gb;      // (no branch in a pass loop: lanes 7..15 write the unused eighth slot; a wave-uniform "some instance is in a polish" test around the store measured SLOWER, 3.096 against 3.026 ms)
+            const real G = Gb + radd;                     // lane 5: S = Rhat + Bbar' P Bbar; lane 6: f = rhat + Bbar' y
+            const real Sinv = frcp(lat_bc<5>(G));
+            const real Kc = -G * Sinv;                    // lanes 0..4: K[c]; lane 6: kff
+            *(wslot >= 0 ? sTab + LAT_TAB * k + wslot : sDum + lane) = c == 5 ? Sinv : Kc;
             // P_k[i][c] = Qhat[i][c] + sum_k Abar[k][i] M[k][c] + F[i] K[c]   (lane 6: p_k = qhat + Abar' y + F kff);  Abar[4][i] = (i == 4)
             real Pn[5];
 #pragma unroll
@@ -224,8 +223,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
 
     // ---------------- Riccati vector pass (corrector): p_k = qhat + Abar' y + K f,  y = P cbar + p,  f = rhat + Bbar' y,  kff = -Sinv f ----------------
     // A stage is ~25 instructions here: the matrix columns are requested THREE stages ahead (L2 latency ~ several stages of this pass), the LDS operands one.
-    auto vector_pass = [&](auto pin_t) __attribute__((always_inline)) {
-        constexpr bool PIN = decltype(pin_t)::value;
+    auto vector_pass = [&]() __attribute__((always_inline)) {
         constexpr int D = LAT_PREFETCH_V;
         real buf[D][4];
         const int mcoff = c < 5 ? (int)(sTab - sZero) + 7 + c : 0, mcmul = c < 5 ? LAT_TAB : 0;       // P cbar [c]
@@ -255,12 +253,11 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
                              LAT_DPP(0, 1, 2, 0) LAT_DPP(0, 1, 3, 1) LAT_DPP(0, 1, 4, 2) LAT_DPP(0, 1, 5, 3)
                              : "+v"(acc) : "v"(y), "v"(buf[u][0]), "v"(buf[u][1]), "v"(buf[u][2]), "v"(buf[u][3]));
                 request(k - D, buf[u]);
-                // (pinned stage: slot S^-1 holds -S, the K slots hold F, the rhat slot holds kff; f goes where kff would -- the roll-out needs it for the row's multiplier)
-                const bool held = PIN && lo[4] < real(0.0);
-                const real f = (held ? real(0.0) : lo[3]) + lat_bc<5>(acc); // lane 5's column is Bbar
-                *((c == 0 && k >= 0) ? sTab + LAT_TAB * (k < 0 ? 0 : k) + 5 : sDum + lane) = held ? f : -lo[4] * f;
-                const real pin = lo[1] * (held ? lo[3] : f);      // F kff  |  K f
-                p = m5lt * (lo[2] + acc + pin);
+                const real by = lat_bc<5>(acc);        // lane 5's column is Bbar: Bbar'y
+                aux[(size_t)(k < 0 ? 0 : k) * LAT_AUX + ((c == 0 && k >= 0) ? 6 : 7)] = by;
+                const real f = lo[3] + by;
+                *((c == 0 && k >= 0) ? sTab + LAT_TAB * (k < 0 ? 0 : k) + 5 : sDum + lane) = -lo[4] * f;
+                p = m5lt * (lo[2] + acc + lo[1] * f);
 #pragma unroll
                 for (int i = 0; i < 5; i++) lo[i] = ln[i];
             }
@@ -271,62 +268,43 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     const int ri = c < 4 ? c : 0;
     const real wA = c < 4 ? real(1.0) : real(0.0), wD = c == 4 ? real(1.0) : real(0.0);
     const real x0c = c < 4 ? Q[o.qcurr + 2 + c] : (c == 4 ? Q[o.ucurr] : real(0.0));
-    auto forward_pass = [&](bool use_gain, auto pin_t) __attribute__((always_inline)) {
-        constexpr bool PIN = decltype(pin_t)::value;
+    auto forward_pass = [&](bool use_gain) __attribute__((always_inline)) {
         constexpr int D = LAT_PREFETCH_F;
         const bool isK = c == 5 && use_gain;          // (a select, not a multiplication by 0: the gain table holds nothing before the first matrix pass)
         real xr = x0c;
         const real2* const rowp = reinterpret_cast<const real2*>(Lb + 8 * ri);
         const real2* const tabp = reinterpret_cast<const real2*>(sTab);
-        real2 buf[D][4], kt[4], ktn[4]; real pk, pkn;
+        real2 buf[D][4], kt[3], ktn[3];
         auto request = [&](int k, real2* o4) __attribute__((always_inline)) { const real2* rp = rowp + (size_t)(k < N ? k : N - 1) * (LATP / 2);
 #pragma unroll
             for (int q = 0; q < 4; q++) o4[q] = rp[q]; };
-        auto request_lds = [&](int k, real2* o3, real& p2) __attribute__((always_inline)) { const int kk = k < N ? k : N - 1; const real2* tp = tabp + (LAT_TAB / 2) * kk;
+        auto request_lds = [&](int k, real2* o3) __attribute__((always_inline)) { const real2* tp = tabp + (LAT_TAB / 2) * (k < N ? k : N - 1);
 #pragma unroll
-            for (int q = 0; q < (PIN ? 4 : 3); q++) o3[q] = tp[q];            // K[0..4], kff, S^-1 (a pinned stage: F, f, -S)
-            if constexpr (PIN) p2 = sRec[LAT_REC * kk + 11]; };                // kff of a pinned stage
+            for (int q = 0; q < 3; q++) o3[q] = tp[q]; };
 #pragma unroll
         for (int u = 0; u < D; u++) request(u, buf[u]);
-        request_lds(0, kt, pk);
+        request_lds(0, kt);
 #pragma unroll 1
         for (int k0 = 0; k0 < N; k0 += D) {
             // (one basic block per D stages, as in the vector pass; stages >= N of the last group run on the last stage's operands and store nothing)
 #pragma unroll
             for (int u = 0; u < D; u++) {
                 const int k = k0 + u;
-                request_lds(k + 1, ktn, pkn);
+                request_lds(k + 1, ktn);
                 real R[7];
                 R[0] = isK ? kt[0].x : wA * buf[u][0].x; R[1] = isK ? kt[0].y : wA * buf[u][0].y; R[2] = isK ? kt[1].x : wA * buf[u][1].x; R[3] = isK ? kt[1].y : wA * buf[u][1].y;
                 R[4] = isK ? kt[2].x : wA * buf[u][2].x + wD; R[5] = wA * buf[u][2].y + wD; R[6] = isK ? kt[2].y : wA * buf[u][3].x;
                 asm volatile("" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]), "+v"(R[5]), "+v"(R[6]));      // the row is formed BEFORE its buffer is re-requested
                 request(k + D, buf[u]);
                 real acc = R[6], xn;
-                // pinned input (use_gain only: the tables hold nothing before the first matrix pass): lane 5 has evaluated F x + f; the input is the pinned value kff, and what goes
-                // into the record in its place is the gradient of the Lagrangian in it, F x + f + S v (the stage's lane knows v: it owns the row)
-                real outv;
-                if constexpr (PIN) {
-                    const bool held = use_gain && kt[3].x < real(0.0);
-                    const real vpin = pk;
-                    asm volatile("s_nop 4\n\t"
-                                 LAT_DPP(0, 1, 2, 0) LAT_DPP(0, 1, 3, 1) LAT_DPP(0, 1, 4, 2) LAT_DPP(0, 1, 5, 3) LAT_DPP(0, 1, 6, 4)
-                                 : "+v"(acc) : "v"(xr), "v"(R[0]), "v"(R[1]), "v"(R[2]), "v"(R[3]), "v"(R[4]));
-                    const real vsel = held ? vpin : acc;   // (lane 5: the input of this stage)
-                    asm volatile("s_nop 4\n\t" LAT_MOV " %0, %1\n\t" LAT_DPP(0, 3, 2, 5)
-                                 : "=&v"(xn) : "v"(acc), "v"(R[5]), "v"(vsel));
-                    outv = (held && c == 5) ? fma(-kt[3].x, vpin, acc) : xn;
-                } else {
-                    asm volatile("s_nop 4\n\t"
-                                 LAT_DPP(1, 2, 3, 0) LAT_DPP(1, 2, 4, 1) LAT_DPP(1, 2, 5, 2) LAT_DPP(1, 2, 6, 3) LAT_DPP(1, 2, 7, 4)
-                                 "s_nop 1\n\t" LAT_MOV " %0, %1\n\t" LAT_DPP(0, 1, 8, 5)
-                                 : "=&v"(xn), "+v"(acc) : "v"(xr), "v"(R[0]), "v"(R[1]), "v"(R[2]), "v"(R[3]), "v"(R[4]), "v"(R[5]));
-                    outv = xn;
-                }
+                asm volatile("s_nop 4\n\t"
+                             LAT_DPP(1, 2, 3, 0) LAT_DPP(1, 2, 4, 1) LAT_DPP(1, 2, 5, 2) LAT_DPP(1, 2, 6, 3) LAT_DPP(1, 2, 7, 4)
+                             "s_nop 1\n\t" LAT_MOV " %0, %1\n\t" LAT_DPP(0, 1, 8, 5)
+                             : "=&v"(xn), "+v"(acc) : "v"(xr), "v"(R[0]), "v"(R[1]), "v"(R[2]), "v"(R[3]), "v"(R[4]), "v"(R[5]));
                 xr = xn;                              // lanes 0..4: x_{k+1}; lane 5: v_k (its Bbar entry is 0)
-                *((c < 6 && k < N) ? sRec + LAT_REC * (k < N ? k : 0) + c : sDum + lane) = outv;
+                *((c < 6 && k < N) ? sRec + LAT_REC * (k < N ? k : 0) + c : sDum + lane) = xn;
 #pragma unroll
-                for (int q = 0; q < (PIN ? 4 : 3); q++) kt[q] = ktn[q];
-                if constexpr (PIN) pk = pkn;
+                for (int q = 0; q < 3; q++) kt[q] = ktn[q];
             }
         }
     };
@@ -511,13 +489,14 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // unverified for that reason alone (PG_RHO sweep, EXPERIMENTS 10.1: unverified 248 / 111 / 53 / 11 of 4096 at 1e7 / 1e9 / 1e10 / 1e11; accuracy against the oracle
     // unchanged up to 1e10, 3x worse with walls at 1e11).  The embedding in k_solve keeps polish_rho as it is (its refinement solves for a correction; tuned at 1e7).
     const real rho = C.polish_rho * C.lat_rho_scale, ptol = C.polish_tol;
-    // pinned input of a stage under working set `am` (see the header): kind 1 = a held rate row (rows 8, 9 leave the penalty form), kff = the pinned value
-    struct Pin { int kind; real kff; };
+    const real BIGP = sizeof(real) == 8 ? real(1e200) : real(1e22);
+    // pinned input of a stage under working set `am` (see the header): a held rate row (rows 8, 9 leave the penalty form); kff = the pinned value
+    struct Pin { bool on; real kff; };
     auto pin_of = [&](unsigned am, const StageC& S) __attribute__((always_inline)) -> Pin {
-        Pin p; p.kind = 0; p.kff = real(0.0);
+        Pin p; p.on = false; p.kff = real(0.0);
         if (!pmode || C.lat_pin == 0) return p;
-        if (am & (1u << 8)) { p.kind = 1; p.kff = S.b[8]; }
-        else if (am & (1u << 9)) { p.kind = 1; p.kff = -S.b[9]; }
+        if (am & (1u << 8)) { p.on = true; p.kff = S.b[8]; }
+        else if (am & (1u << 9)) { p.on = true; p.kff = -S.b[9]; }
         return p;
     };
     // barrier weights of a slot at the current iterate: it = 1/t, W = lambda/t, ell = (sigma mu - corr)/t + lambda - W b
@@ -526,7 +505,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             const Pin pn = pin_of(am, S);
 #pragma unroll
             for (int r = 0; r < NR; r++) {
-                const bool a = ((am >> r) & 1u) && !(pn.kind == 1 && (r == 8 || r == 9));
+                const bool a = ((am >> r) & 1u) && !(pn.on && (r == 8 || r == 9));
                 it_[r] = real(1.0); W[r] = a ? rho : real(0.0); ell[r] = a ? Ll[r] - rho * S.b[r] : real(0.0);
             }
             return;
@@ -548,12 +527,12 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // after a polish solve (tp = slacks at the new point): multiplier update of the held rows and the add / drop decisions of this slot.  Returns the next working set.
     auto polish_rows = [&](bool actj, unsigned am, real* Ll, const real* tp, real ttol, bool& unsettled, const Pin& pn, real gpin) __attribute__((always_inline)) -> unsigned {
         unsigned add = 0u, drop = 0u;
-        // the pinned row: its multiplier is minus / plus the gradient of the Lagrangian in the input (rows "bound - (.)" take the minus sign)
-        const int rpin = pn.kind == 1 ? ((am & (1u << 8)) ? 8 : 9) : -1;
+        // the pinned row: its multiplier is minus / plus the gradient of the Lagrangian in the input (the row "ddmax - v" takes the minus sign)
+        const int rpin = pn.on ? ((am & (1u << 8)) ? 8 : 9) : -1;
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             const bool a = (am >> r) & 1u;
-            const bool excl = pn.kind == 1 && (r == 8 || r == 9);      // rows out of the penalty form
+            const bool excl = pn.on && (r == 8 || r == 9);      // rows out of the penalty form
             if (r == rpin) Ll[r] = r == 8 ? -gpin : gpin;
             else if (a && !excl) Ll[r] -= rho * tp[r];
             if (actj && a && Ll[r] < real(0.0)) drop |= 1u << r;
@@ -565,6 +544,21 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         if ((add & 0x030u) == 0x030u) add &= ~(tp[4] <= tp[5] ? (1u << 5) : (1u << 4));
         if constexpr (WALLS) { if ((add & 0xC00u) == 0xC00u) add &= ~(tp[10] <= tp[11] ? (1u << 11) : (1u << 10)); }
         return (am & ~drop) | add;
+    };
+    // gradient of the Lagrangian in the pinned input of stage sj at the roll-out's point: F x_s + Bbar'y + S v  (x_s: the node the stage starts from; S = Rhat0 + Bbar'P Bbar)
+    auto pin_gradient = [&](int sj, const StageC& S, real v) __attribute__((always_inline)) -> real {
+        const real* ax = aux + (size_t)sj * LAT_AUX;
+        real g = ax[6] + (real(2.0) * C.cp.R_ddelta * frcp(S.dts) + ax[5]) * v;
+        if (sj > 0) {
+            const real* xp = sRec + LAT_REC * (sj - 1);
+#pragma unroll
+            for (int m = 0; m < 5; m++) g += ax[m] * xp[m];
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; m++) g += ax[m] * Q[o.qcurr + 2 + m];
+            g += ax[4] * Q[o.ucurr];
+        }
+        return g;
     };
     // barrier terms of slot j -> stage cost of the Riccati passes (rec[0..5] the matrices, rec[6..11] the vectors)
     auto assemble = [&](int j, In& in, real sgmu, bool matrices) __attribute__((always_inline)) {
@@ -580,11 +574,11 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             real* rec = sRec + LAT_REC * (c + 16 * j);
             rec[6] = g0 - E.c10 * E.g1 * E.d1 - E.c20 * E.g2 * E.d2;
             rec[7] = g1 - E.c11 * E.g1 * E.d1 - E.c21 * E.g2 * E.d2;
-            const Pin pn = pin_of(mt.am, S);
             rec[8] = real(0.0);
             if constexpr (WALLS) rec[9] = (ell[10] - ell[11]) - E.ch * E.gh * E.dh; else rec[9] = real(0.0);
+            const Pin pn = pin_of(mt.am, S);
             rec[10] = ell[0] - ell[1];
-            rec[11] = pn.kind ? pn.kff : ell[8] - ell[9];
+            rec[11] = pn.on ? -BIGP * pn.kff : ell[8] - ell[9];
             if (matrices) {
                 real yy = real(0.0), yr = real(0.0), rr = real(0.0);
 #pragma unroll
@@ -595,8 +589,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
                 rec[3] = real(2.0) * C.cp.Q_e * S.dts;
                 if constexpr (WALLS) rec[3] += W[10] + W[11] - E.ch * E.ch * E.dh;
                 rec[4] = real(2.0) * C.cp.R_delta * S.dts + W[0] + W[1];
-                const real Rh = real(2.0) * C.cp.R_ddelta * frcp(S.dts) + W[8] + W[9];
-                rec[5] = pn.kind ? -Rh : Rh;             // (negative: the input of this stage is pinned)
+                rec[5] = pn.on ? BIGP : real(2.0) * C.cp.R_ddelta * frcp(S.dts) + W[8] + W[9];
             }
         }
     };
@@ -621,7 +614,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     auto put_vec = [&](int j, const real* qa, const real* qb, const Pin& pn) __attribute__((always_inline)) {
         if (is_act(j)) {
             real* rec = sRec + LAT_REC * (c + 16 * j);
-            rec[6] = qa[0]; rec[7] = qa[1]; rec[8] = real(0.0); rec[9] = qa[2]; rec[10] = qa[3]; rec[11] = pn.kind ? pn.kff : qa[4];
+            rec[6] = qa[0]; rec[7] = qa[1]; rec[8] = real(0.0); rec[9] = qa[2]; rec[10] = qa[3]; rec[11] = pn.on ? -BIGP * pn.kff : qa[4];
             if (!pmode) {       // (a polish has no sigma mu part, and its verdict may still want the point in rec[0..4]: polish_decide stores it as the answer)
 #pragma unroll
                 for (int i = 0; i < 5; i++) rec[i] = qb[i];
@@ -629,13 +622,11 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         }
     };
     // Newton point of slot j from the roll-out (x+ of node s+1, v+ of transition s) -> eliminated slacks and the slack of every row
-    auto newton = [&](int j, const StageC& S, const Elim& E, real* xn, real& vn, real* sg3, real* tp, const Pin& pn, real& gpin) __attribute__((always_inline)) {
-        const int sj = is_act(j) ? c + 16 * j : N - 1;
-        const real* rec = sRec + LAT_REC * sj;
+    auto newton = [&](int j, const StageC& S, const Elim& E, real* xn, real& vn, real* sg3, real* tp) __attribute__((always_inline)) {
+        const real* rec = sRec + LAT_REC * (is_act(j) ? c + 16 * j : N - 1);
 #pragma unroll
         for (int m = 0; m < 5; m++) xn[m] = rec[m];
-        vn = rec[5]; gpin = real(0.0);
-        if (pn.kind) { gpin = vn; vn = pn.kff; }      // the record carries the gradient in the pinned input instead of the input itself
+        vn = rec[5];
         sg3[0] = -(E.c10 * xn[0] + E.c11 * xn[1] + E.g1) * E.d1;
         sg3[1] = -(E.c20 * xn[0] + E.c21 * xn[1] + E.g2) * E.d2;
         sg3[2] = WALLS ? -(E.ch * xn[3] + E.gh) * E.dh : real(0.0);
@@ -644,7 +635,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
 
     // ---------------- start: v = 0 roll-out (dynamics- and rate-feasible), soft-row slacks just feasible + 1, t = max(slack, tau), lambda = mu0 / t ----------------
     __syncthreads();
-    forward_pass(false, std::false_type{});
+    forward_pass(false);
     wave_sync();
     stamp(3);
     real rp0 = real(0.0), j0 = real(0.0);
@@ -858,11 +849,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         need_a1 = false;
         wave_sync();
         stamp(0);
-        const bool wave_pin = __any(pmode != 0) != 0;      // (wave-uniform: some instance of this wavefront is in a polish)
-        if (wave_pin) matrix_pass(std::true_type{}); else matrix_pass(std::false_type{});
+        matrix_pass();
         wave_sync();
         stamp(1);
-        if (wave_pin) forward_pass(true, std::true_type{}); else forward_pass(true, std::false_type{});
+        forward_pass(true);
         wave_sync();
         stamp(3);
         real rmax = real(0.0), S2 = real(0.0); bool unsettled = false;
@@ -871,10 +861,11 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             real it_[NR], W[NR], ell[NR], tp[NR], xn[5], vn, sg3[3]; Elim E;
             weights(mt.am, Tl, Ll, Cl, S, real(0.0), false, it_, W, ell);
             eliminate(S, W, ell, E);
-            const Pin pn = pin_of(mt.am, S); real gpin;
-            newton(j, S, E, xn, vn, sg3, tp, pn, gpin);
+            newton(j, S, E, xn, vn, sg3, tp);
+            const Pin pn = pin_of(mt.am, S);
             real qa[5], qb[5];
             if (pmode) {
+                const real gpin = (pn.on && is_act(j)) ? pin_gradient(c + 16 * j, S, vn) : real(0.0);
                 put_sn(j, sg3); mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, real(0.01) * ptol, unsettled, pn, gpin); put_meta(j, mt); put_tl(j, Tl, Ll);
                 if constexpr (SPLIT_CORR) {      // the refinement solve behind this one: same set, the multipliers just updated (no sigma mu in a polish)
                     weights(mt.am, Tl, Ll, Cl, S, real(0.0), false, it_, W, ell);
@@ -928,10 +919,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         });
         wave_sync();
         stamp(0);
-        if (wave_pin) vector_pass(std::true_type{}); else vector_pass(std::false_type{});
+        vector_pass();
         wave_sync();
         stamp(2);
-        if (wave_pin) forward_pass(true, std::true_type{}); else forward_pass(true, std::false_type{});
+        forward_pass(true);
         wave_sync();
         stamp(3);
         real T1 = real(0.0), T2 = real(0.0);
@@ -941,10 +932,12 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             real it_[NR], W[NR], ell[NR], tp[NR], xn[5], vn, sg3[3]; Elim E;
             weights(mt.am, Tl, Ll, Cl, S, sgmu, true, it_, W, ell);
             eliminate(S, W, ell, E);
-            const Pin pn = pin_of(mt.am, S); real gpin;
-            newton(j, S, E, xn, vn, sg3, tp, pn, gpin);
+            newton(j, S, E, xn, vn, sg3, tp);
             put_sn(j, sg3);
-            if (pmode) { if (!skip_second && !resume_ipm) { mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, ptol, unsettled, pn, gpin); put_meta(j, mt); put_tl(j, Tl, Ll); } }
+            if (pmode) { if (!skip_second && !resume_ipm) {
+                const Pin pn = pin_of(mt.am, S);
+                const real gpin = (pn.on && is_act(j)) ? pin_gradient(c + 16 * j, S, vn) : real(0.0);
+                mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, ptol, unsettled, pn, gpin); put_meta(j, mt); put_tl(j, Tl, Ll); } }
             else {
                 real rm = real(0.0), t1 = real(0.0), t2 = real(0.0);
 #pragma unroll
