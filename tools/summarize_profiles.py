@@ -33,6 +33,8 @@ stats = {}
 for d, out in (("stats", "kernel_stats.csv"), ("stats_dec", "kernel_stats_dec.csv"), ("stats_roll", "kernel_stats_roll.csv"), ("stats_c3", "kernel_stats_c3.csv"),
                ("stats_f32", "kernel_stats_f32.csv"), ("stats_decloop", "kernel_stats_decloop.csv"), ("stats_hji", "kernel_stats_hji.csv")):
     ks = glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv"))
+    # (gpurun MERGES a call's files into gpurun_out/: two campaigns leave two files per directory and their counters would be averaged together -- delete gpurun_out/prof first)
+    assert len(ks) <= 1, f"{d}: files of more than one campaign in gpurun_out/prof -- delete it and run tools/gpu_profile.sh again"
     if len(ks) == 1:
         shutil.copy(ks[0], os.path.join(dst, out))
         stats[d] = list(csv.DictReader(open(ks[0])))
@@ -45,7 +47,9 @@ summary = {}
 for g, dirs in groups.items():
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     for d in dirs:
-        for f in glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")):
+        fs = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+        assert len(fs) <= 1, f"{d}: files of more than one campaign in gpurun_out/prof"
+        for f in fs:
             for row in csv.DictReader(open(f)):
                 k = short(row["Kernel_Name"])
                 if not k.startswith("pg::"):
