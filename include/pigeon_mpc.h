@@ -240,6 +240,7 @@ int pg_synchronize(pg_handle* h);
  *   coupled solve kernel (k_solve):
  *     "solve_split" 0/1 (1)      rounds-only kernel + list-mode full kernel instead of one kernel (never with a safety row installed)
  *     "clip_guess" 0/1 (1)       first roll-out of a cold instance clips the steering rate; the clipped transitions are its first working set
+ *     "clip_stops" 0/1 (0)       ... and at the steering stops too (measured: fewer rounds, a longer launch; EXPERIMENTS.md 11.3)
  *     "ck_riccati" 0/1 (1)       the matrix recursion of a later round restarts at a checkpoint behind the rows that changed (fp64)
  *     "warm_trivial_cold" 0/1 (1)  a warm instance whose previous working set was empty starts like a cold one
  *     "hji_seed" 0..4 (0), "hji_rounds" 0..64 (0)   seeded working sets for instances whose safety row is violated at the current control (experiment, off)

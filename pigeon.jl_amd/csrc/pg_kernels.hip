@@ -1941,7 +1941,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
 #pragma unroll
         for (int m = 0; m < 8; m++) xn[m] = (delta ? xn[m] : real(0.0)) + sx[8 * (s + 1) + m];
         vn0 = (delta ? vn0 : real(0.0)) + sv[2 * s]; vn1 = (delta ? vn1 : real(0.0)) + sv[2 * s + 1];
-        if (delta) {      // size of the correction (largest component of any stage): the refinement has converged when it is small
+        if (__builtin_amdgcn_readfirstlane((int)delta)) {      // size of the correction (largest component of any stage): the refinement has converged when it is small
             real dm = real(0.0);
 #pragma unroll
             for (int m = 0; m < 8; m++) dm = fmax(dm, act ? fabs(sx[8 * (s + 1) + m]) : real(0.0));
