@@ -1410,8 +1410,9 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     real* sDum = sx0 + 8;              // [64] sink for predicated-off stores (keeps the pass loops branch-free)
     real* sZero = sDum + 64;           // [2]  a stored 0.0 (off-pattern entries of Qhat)
     real* skf_ck = sZero + 2;          // [N][2] the predictor's feed-forward terms as the matrix pass left them (skf itself is rewritten by every vector pass): restored when the recursion restarts at its checkpoint
-    real* sF0 = skf_ck + 2 * N;        // [N][8] F0 = Bbar0' P Abar of the matrix pass: the stationarity condition in the first input, for the multiplier of a pinned rate row
-    real* sAux = sF0 + 8 * N;          // [N][3] Bbar0' P Bbar0, S01, Bbar0' y (the last rewritten by a vector pass)
+    real* sF0 = skf_ck + 2 * N;        // [N][11] row 8 of the matrix pass's product C = [Abar Bbar]'[M_A | M_B | y]: F0 = Bbar0' P Abar (8), Bbar0' P Bbar0, S01, Bbar0' y (the last rewritten by a
+                                       // vector pass) -- the stationarity condition in the first input, for the multiplier of a pinned rate row; written only while a stage is pinned
+    bool any_pin = false;              // (wave-uniform: some stage of this instance is pinned in the round being assembled)
 
     const QpOff o = qp_offsets(N);
     const real* Q = qp + (size_t)b * C.qp_len;
@@ -1654,6 +1655,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
         e_c20 = -(W[8] * h0[2] + W[9] * h0[3]); e_c21 = -(W[8] * h1[2] + W[9] * h1[3]);
         e_ch0 = wall_on ? -(W[0] - W[1]) : W[14] * M0; e_ch1 = wall_on ? real(0.0) : W[14] * M1;      // wall rows: t = b -/+ e + sw, i.e. the envelope-row pattern with h = +1, -1 on e
         if (!hji_on && !wall_on) e_gh = real(0.0);
+        any_pin = __any(act && exr && (pmode != 0 || !IPM) && (amask & 0x3000u) != 0u);
         if (act) {
             real* qo = sq + 8 * (s + 1);
             qo[1] = g1;
@@ -1795,10 +1797,9 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             *((mg < 2 && mc < 8) ? sK + 16 * k + 8 * mg + mc : sDum + lane) = mg == 0 ? K0 : K1;
             *(lane < 3 ? sSi + 4 * k + lane : sDum + lane) = lane == 0 ? I00 : (lane == 1 ? I01 : I11);
             *((mc == 10 && mg < 2) ? skf + 2 * k + mg : sDum + lane) = mg == 0 ? kf0 : kf1;
-            if constexpr (EXR) {      // (off the chain: what the multiplier of a pinned rate row is read from -- F0, Bbar0'P Bbar0, S01, Bbar0'y)
-                *((mg == 0 && mc < 8) ? sF0 + 8 * k + mc : sDum + lane) = F0c;
-                *(lane < 3 ? sAux + 3 * k + lane : sDum + lane) = lane == 0 ? bpb0 : (lane == 1 ? S01 : rl(F0c, 10));
-            }
+            // (off the chain: what the multiplier of a pinned rate row is read from -- row 8 of C as it stands: F0, Bbar0'P Bbar0, S01, Bbar0'y in columns 0..10.  ONE store, and
+            //  only in rounds that pin a stage: two stores with a three-way select and a lane read in every pass cost the interior point's matrix pass 15-19 %)
+            if constexpr (EXR) { if (any_pin) *((mg == 0 && mc < 11) ? sF0 + 11 * k + mc : sDum + lane) = F0c; }
             // C += F' [K | kff]
             const real a3 = mg == 0 ? F0c : (mg == 1 ? F1c : real(0.0));
             const real b3 = mg == 0 ? (mc == 10 ? kf0 : K0) : (mg == 1 ? (mc == 10 ? kf1 : K1) : real(0.0));
@@ -1932,7 +1933,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             const real f0 = r0 + by0;
             pi = (acc + accb) + (k0 * f0 + k1 * f1);          // (k == 0: never used)
             *(lane < 2 ? skf + 2 * k + lane : sDum + lane) = lane == 0 ? -(I00 * f0 + I01 * f1) : -(I01 * f0 + I11 * f1);
-            if constexpr (EXR) *(lane == 2 ? sAux + 3 * k + 2 : sDum + lane) = by0;      // Bbar0'y of this pass
+            if constexpr (EXR) { if (any_pin) *(lane == 2 ? sF0 + 11 * k + 10 : sDum + lane) = by0; }      // Bbar0'y of this pass
         }
         __syncthreads();
     };
@@ -2100,7 +2101,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
         if (exr && !clipped) {      // pinned rate row: the multiplier IS minus / plus the gradient of the Lagrangian in the pinned input at the roll-out's point (t = 0 exactly)
             const bool h12 = act && (amask & (1u << 12)) != 0u, h13 = act && !h12 && (amask & (1u << 13)) != 0u;
             if (__any(h12 || h13)) {
-                const real* F = sF0 + 8 * s; const real* xs = sx + 8 * s; const real* ax = sAux + 3 * s;
+                const real* F = sF0 + 11 * s; const real* xs = sx + 8 * s; const real* ax = F + 8;
                 real g = ax[2], g2 = real(0.0);
 #pragma unroll
                 for (int m = 0; m < 8; m += 2) { g += F[m] * xs[m]; g2 += F[m + 1] * xs[m + 1]; }
