@@ -1777,33 +1777,44 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             const real b10 = xlds[0] ? x0l : xcst[0], b11 = xlds[1] ? x1l : xcst[1];
             // M = P X
             mfma_acc Ma = {real(0.0), real(0.0), real(0.0), real(0.0)};
-            Ma = PG_MFMA(mc < 8 ? V0 : real(0.0), b10, Ma);
-            Ma = PG_MFMA(mc < 8 ? V1 : real(0.0), b11, Ma);
+            // (A operand = P through its own result: lane (g, c) supplies row c of the product.  Columns 8 .. 15 of V hold other things -- S, the vector recursion -- and
+            //  give rows 8 .. 15 of M, which nothing reads: no masking.  The same holds for row 10 of C below, the cbar column of X.)
+            Ma = PG_MFMA(V0, b10, Ma);
+            Ma = PG_MFMA(V1, b11, Ma);
             real M0, M1; to_operands(Ma, M0, M1);
             *(mc == 10 ? sMc + 8 * k + mg : sDum + lane) = M0;                     // Mc_k = P_{k+1} cbar_k for the corrector's vector pass
             *(mc == 10 ? sMc + 8 * k + 4 + mg : sDum + lane) = M1;
             // C = [Abar Bbar]' [M_A | M_B | y]
             mfma_acc Cc = {real(0.0), real(0.0), real(0.0), real(0.0)};
-            Cc = PG_MFMA(mc < 10 ? b10 : real(0.0), mc == 10 ? M0 + V0 : M0, Cc);
-            Cc = PG_MFMA(mc < 10 ? b11 : real(0.0), mc == 10 ? M1 + V1 : M1, Cc);
-            // rows 8, 9 of C: F = Bbar' M_A (c < 8), S - Rhat (c = 8, 9), Bbar' y (c = 10)
+            Cc = PG_MFMA(b10, mc == 10 ? M0 + V0 : M0, Cc);
+            Cc = PG_MFMA(b11, mc == 10 ? M1 + V1 : M1, Cc);
+            // rows 8, 9 of C: F = Bbar' M_A (c < 8), S - Rhat (c = 8, 9), Bbar' y (c = 10).
+            // The pivot's three numbers are read straight from the result registers (fp64: D[8][c] = register 2 of lane c, D[9][c] = register 2 of lane 16 + c; fp32: D[8 + j][c]
+            // = register j of lane 32 + c), so the determinant and its reciprocal run NEXT TO the broadcast of the two rows (rows89), not behind it; and the third product takes
+            // F' (-1 / det) as one operand and adj(S) [F | f] as the other: behind the reciprocal the chain is one multiplication, then the MFMA (it was I = adj / det,
+            // K = -(I F): three dependent operations).  K, kff and S^-1 for the other passes are formed off the chain.
+#ifdef PG_F32
+            const real bpb0 = rl(Cc[0], 40), S01 = rl(Cc[0], 41), bpb1 = rl(Cc[1], 41);
+#else
+            const real bpb0 = rl(Cc[2], 8), S01 = rl(Cc[2], 9), bpb1 = rl(Cc[2], 25);
+#endif
+            const real S00 = R0 + bpb0, S11 = R1 + bpb1;
+            const real idet = frcp(S00 * S11 - S01 * S01), nid = -idet;      // (a reciprocal with ONE Newton step instead of two measured the same: 0.270 ms)
             real F0c, F1c; rows89(Cc, F0c, F1c);
-            const real bpb0 = rl(F0c, 8), S00 = R0 + bpb0, S01 = rl(F0c, 9), S11 = R1 + rl(F1c, 9);
-            const real idet = frcp(S00 * S11 - S01 * S01);
-            const real I00 = S11 * idet, I01 = -S01 * idet, I11 = S00 * idet;
-            const real K0 = -(I00 * F0c + I01 * F1c), K1 = -(I01 * F0c + I11 * F1c);
             const real f0 = r0v + F0c, f1 = r1v + F1c;                              // (meaningful in column 10)
-            const real kf0 = -(I00 * f0 + I01 * f1), kf1 = -(I01 * f0 + I11 * f1);
-            *((mg < 2 && mc < 8) ? sK + 16 * k + 8 * mg + mc : sDum + lane) = mg == 0 ? K0 : K1;
+            const real aK0 = S11 * F0c - S01 * F1c, aK1 = S00 * F1c - S01 * F0c;    // adj(S) F
+            const real ak0 = S11 * f0 - S01 * f1, ak1 = S00 * f1 - S01 * f0;        // adj(S) f
+            // C += F' [K | kff]
+            const real a3 = (mg == 0 ? F0c : (mg == 1 ? F1c : real(0.0))) * nid;
+            const real b3 = mg == 0 ? (mc == 10 ? ak0 : aK0) : (mg == 1 ? (mc == 10 ? ak1 : aK1) : real(0.0));
+            Cc = PG_MFMA(a3, b3, Cc);
+            const real I00 = S11 * idet, I01 = -S01 * idet, I11 = S00 * idet;
+            *((mg < 2 && mc < 8) ? sK + 16 * k + 8 * mg + mc : sDum + lane) = (mg == 0 ? aK0 : aK1) * nid;
             *(lane < 3 ? sSi + 4 * k + lane : sDum + lane) = lane == 0 ? I00 : (lane == 1 ? I01 : I11);
-            *((mc == 10 && mg < 2) ? skf + 2 * k + mg : sDum + lane) = mg == 0 ? kf0 : kf1;
+            *((mc == 10 && mg < 2) ? skf + 2 * k + mg : sDum + lane) = (mg == 0 ? ak0 : ak1) * nid;
             // (off the chain: what the multiplier of a pinned rate row is read from -- row 8 of C as it stands: F0, Bbar0'P Bbar0, S01, Bbar0'y in columns 0..10.  ONE store, and
             //  only in rounds that pin a stage: two stores with a three-way select and a lane read in every pass cost the interior point's matrix pass 15-19 %)
             if constexpr (EXR) { if (any_pin) *((mg == 0 && mc < 11) ? sF0 + 11 * k + mc : sDum + lane) = F0c; }
-            // C += F' [K | kff]
-            const real a3 = mg == 0 ? F0c : (mg == 1 ? F1c : real(0.0));
-            const real b3 = mg == 0 ? (mc == 10 ? kf0 : K0) : (mg == 1 ? (mc == 10 ? kf1 : K1) : real(0.0));
-            Cc = PG_MFMA(a3, b3, Cc);
             real C0, C1; to_operands(Cc, C0, C1);
             V0 = C0 + add0; V1 = C1 + add1;
             // symmetrise P (see the note in the VALU version below) by a transpose through LDS -- every fourth stage: the A operand above reads P through its
