@@ -1407,9 +1407,10 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     real* sP = sv + 2 * N;             // [8][9]   (row stride 9: conflict-free row reads)
     real* sMT = sP + 72;               // [11][9]  (P [Abar | Bbar | cbar]) stored column-major, column stride 9
     real* sx0 = sMT + 99 + 1;              // [8]
-    real* sDum = sx0 + 8;              // [64] sink for predicated-off stores (keeps the pass loops branch-free)
-    real* sZero = sDum + 64;           // [2]  a stored 0.0 (off-pattern entries of Qhat)
-    real* skf_ck = sZero + 2;          // [N][2] the predictor's feed-forward terms as the matrix pass left them (skf itself is rewritten by every vector pass): restored when the recursion restarts at its checkpoint
+    real* sDum = sx0 + 8;              // [72] sink for predicated-off stores (keeps the pass loops branch-free; a lane's slot and the one four further on)
+    real* sZero = sDum + 72;           // [2]  a stored 0.0 (off-pattern entries of Qhat)
+    real* sOne = sZero + 2;            // [2]  a stored 1.0 (the identity entries of the operand [Abar | Bbar | cbar])
+    real* skf_ck = sOne + 2;          // [N][2] the predictor's feed-forward terms as the matrix pass left them (skf itself is rewritten by every vector pass): restored when the recursion restarts at its checkpoint
     real* sF0 = skf_ck + 2 * N;        // [N][11] row 8 of the matrix pass's product C = [Abar Bbar]'[M_A | M_B | y]: F0 = Bbar0' P Abar (8), Bbar0' P Bbar0, S01, Bbar0' y (the last rewritten by a
                                        // vector pass) -- the stationarity condition in the first input, for the multiplier of a pinned rate row; written only while a stage is pinned
     bool any_pin = false;              // (wave-uniform: some stage of this instance is pinned in the round being assembled)
@@ -1448,7 +1449,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     const real x0_fill = lane < 6 ? Q[o.qcurr + lane] : Q[o.ucurr + (lane < 8 ? lane - 6 : 0)];
     const int prev_solved = O.solved[b], prev_status = O.status[b];      // (the warm-start test further down: loaded with the batch, not in a round trip of its own)
     const real hji_b = Q[o.b];
-    if (lane < 2) sZero[lane] = real(0.0);
+    if (lane < 4) sZero[lane] = lane < 2 ? real(0.0) : real(1.0);
 
     // ---- per-stage constants in the registers of lane s (stage s = transition s, node s+1) ----
     const bool act = lane < N;
@@ -1701,14 +1702,24 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     // that column, and the third adds F' kff, so that column 10 of the result is A'y + K'f = p_k - q.
     // Round 1 ran this pass on the VALU with two LDS exchanges per stage (46 % of the kernel: 2450 cycles per stage, co-limited by LDS bandwidth and issue).
     const int mg = lane >> 4, mc = lane & 15;
-    int xoff[2]; bool xlds[2]; real xcst[2];
+    // Every per-lane choice of the stage loop below is made ONCE, here, as an address and a stride per stage (LDS addresses are one dword: a select on an address is one
+    // instruction, a select on an fp64 value two; the loop is bound by instruction issue -- EXPERIMENTS.md 11.8): operands that are constants for some lanes come from a stored
+    // 0.0 / 1.0 with stride 0, predicated-off stores go to the lane's dummy slot with stride 0, one-hot lane weights replace value selects.
+    int xoff[2]; bool xlds[2]; const real* xsrc[2]; int xstr[2];
 #pragma unroll
     for (int sgi = 0; sgi < 2; sgi++) {            // operand X[4 s + g][c] of X = [Abar | Bbar | cbar] (8 x 11): rows 0..5 live in the LDS stage block, rows 6, 7 are [0 I | I | 0]
         const int row = 4 * sgi + mg;
         xlds[sgi] = row < 6 && mc < 11;
         xoff[sgi] = !xlds[sgi] ? 0 : (mc < 8 ? SB_ROW * row + mc : (mc < 10 ? SB_B + 2 * row + (mc - 8) : SB_C + row));
-        xcst[sgi] = (row == 6 && (mc == 6 || mc == 8)) || (row == 7 && (mc == 7 || mc == 9)) ? real(1.0) : real(0.0);
+        const bool one = (row == 6 && (mc == 6 || mc == 8)) || (row == 7 && (mc == 7 || mc == 9));
+        xsrc[sgi] = xlds[sgi] ? sRing + xoff[sgi] : (one ? sOne : sZero);
+        xstr[sgi] = xlds[sgi] ? SB : 0;
     }
+    const real m10 = mc == 10 ? real(1.0) : real(0.0), w0 = mg == 0 ? real(1.0) : real(0.0), w1 = mg == 1 ? real(1.0) : real(0.0);
+    real* const dMc = mc == 10 ? sMc + mg : sDum + lane;                       const int tMc = mc == 10 ? 8 : 0;       // Mc_k: rows mg and mg + 4
+    real* const dKf = mg < 2 ? (mc < 8 ? sK + 8 * mg + mc : (mc == 10 ? skf + mg : sDum + lane)) : sDum + lane;
+    const int tKf = mg < 2 ? (mc < 8 ? 16 : (mc == 10 ? 2 : 0)) : 0;                                                    // gains (columns 0..7) and feed-forward (column 10): one store
+    real* const dSi = lane < 3 ? sSi + lane : sDum + lane;                     const int tSi = lane < 3 ? 4 : 0;
     const real* abase[2]; int amul[2];             // what is added to the operand-layout value s: Qhat_k[4s + g][c] (c < 8), qhat_k[4s + g] (c == 10), nothing elsewhere
 #pragma unroll
     for (int r = 0; r < 2; r++) {
@@ -1771,10 +1782,9 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             ring_step(k, -1);
             const real* Xk = ring_slot(k);
             // stage constants: none of these reads depends on the recursion
-            const real x0l = Xk[xoff[0]], x1l = Xk[xoff[1]];
+            const real b10 = RING ? *(xlds[0] ? Xk + xoff[0] : xsrc[0]) : xsrc[0][xstr[0] * k], b11 = RING ? *(xlds[1] ? Xk + xoff[1] : xsrc[1]) : xsrc[1][xstr[1] * k];
             const real add0 = abase[0][amul[0] * k], add1 = abase[1][amul[1] * k];
             const real R0 = sR[2 * k], R1 = sR[2 * k + 1], r0v = sr[2 * k], r1v = sr[2 * k + 1];
-            const real b10 = xlds[0] ? x0l : xcst[0], b11 = xlds[1] ? x1l : xcst[1];
             // M = P X
             mfma_acc Ma = {real(0.0), real(0.0), real(0.0), real(0.0)};
             // (A operand = P through its own result: lane (g, c) supplies row c of the product.  Columns 8 .. 15 of V hold other things -- S, the vector recursion -- and
@@ -1782,12 +1792,11 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             Ma = PG_MFMA(V0, b10, Ma);
             Ma = PG_MFMA(V1, b11, Ma);
             real M0, M1; to_operands(Ma, M0, M1);
-            *(mc == 10 ? sMc + 8 * k + mg : sDum + lane) = M0;                     // Mc_k = P_{k+1} cbar_k for the corrector's vector pass
-            *(mc == 10 ? sMc + 8 * k + 4 + mg : sDum + lane) = M1;
-            // C = [Abar Bbar]' [M_A | M_B | y]
+            { real* d = dMc + tMc * k; d[0] = M0; d[4] = M1; }                       // Mc_k = P_{k+1} cbar_k for the corrector's vector pass
+            // C = [Abar Bbar]' [M_A | M_B | y]   (y = P c + p in column 10)
             mfma_acc Cc = {real(0.0), real(0.0), real(0.0), real(0.0)};
-            Cc = PG_MFMA(b10, mc == 10 ? M0 + V0 : M0, Cc);
-            Cc = PG_MFMA(b11, mc == 10 ? M1 + V1 : M1, Cc);
+            Cc = PG_MFMA(b10, fma(V0, m10, M0), Cc);
+            Cc = PG_MFMA(b11, fma(V1, m10, M1), Cc);
             // rows 8, 9 of C: F = Bbar' M_A (c < 8), S - Rhat (c = 8, 9), Bbar' y (c = 10).
             // The pivot's three numbers are read straight from the result registers (fp64: D[8][c] = register 2 of lane c, D[9][c] = register 2 of lane 16 + c; fp32: D[8 + j][c]
             // = register j of lane 32 + c), so the determinant and its reciprocal run NEXT TO the broadcast of the two rows (rows89), not behind it; and the third product takes
@@ -1801,17 +1810,15 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             const real S00 = R0 + bpb0, S11 = R1 + bpb1;
             const real idet = frcp(S00 * S11 - S01 * S01), nid = -idet;      // (a reciprocal with ONE Newton step instead of two measured the same: 0.270 ms)
             real F0c, F1c; rows89(Cc, F0c, F1c);
-            const real f0 = r0v + F0c, f1 = r1v + F1c;                              // (meaningful in column 10)
-            const real aK0 = S11 * F0c - S01 * F1c, aK1 = S00 * F1c - S01 * F0c;    // adj(S) F
-            const real ak0 = S11 * f0 - S01 * f1, ak1 = S00 * f1 - S01 * f0;        // adj(S) f
-            // C += F' [K | kff]
-            const real a3 = (mg == 0 ? F0c : (mg == 1 ? F1c : real(0.0))) * nid;
-            const real b3 = mg == 0 ? (mc == 10 ? ak0 : aK0) : (mg == 1 ? (mc == 10 ? ak1 : aK1) : real(0.0));
+            // [F | f]: column 10 carries f = rhat + Bbar'y, so ONE pair of products gives adj(S) F in columns 0..7 and adj(S) f in column 10
+            const real Fx0 = fma(r0v, m10, F0c), Fx1 = fma(r1v, m10, F1c);
+            const real X0 = S11 * Fx0 - S01 * Fx1, X1 = S00 * Fx1 - S01 * Fx0;
+            // C += F' [K | kff]: the k = 2, 3 terms of the contraction vanish through the B operand (w0, w1 are zero there); lane c = 10 of the A operand feeds row 10, unread
+            const real a3 = ((mg & 1) ? F1c : F0c) * nid;
+            const real b3 = fma(X1, w1, X0 * w0);
             Cc = PG_MFMA(a3, b3, Cc);
-            const real I00 = S11 * idet, I01 = -S01 * idet, I11 = S00 * idet;
-            *((mg < 2 && mc < 8) ? sK + 16 * k + 8 * mg + mc : sDum + lane) = (mg == 0 ? aK0 : aK1) * nid;
-            *(lane < 3 ? sSi + 4 * k + lane : sDum + lane) = lane == 0 ? I00 : (lane == 1 ? I01 : I11);
-            *((mc == 10 && mg < 2) ? skf + 2 * k + mg : sDum + lane) = (mg == 0 ? ak0 : ak1) * nid;
+            dKf[tKf * k] = ((mg & 1) ? X1 : X0) * nid;                              // K_k (columns 0..7), kff_k (column 10)
+            dSi[tSi * k] = (lane == 0 ? S11 : (lane == 1 ? -S01 : S00)) * idet;     // S^-1: (I00, I01, I11)
             // (off the chain: what the multiplier of a pinned rate row is read from -- row 8 of C as it stands: F0, Bbar0'P Bbar0, S01, Bbar0'y in columns 0..10.  ONE store, and
             //  only in rounds that pin a stage: two stores with a three-way select and a lane read in every pass cost the interior point's matrix pass 15-19 %)
             if constexpr (EXR) { if (any_pin) *((mg == 0 && mc < 11) ? sF0 + 11 * k + mc : sDum + lane) = F0c; }
