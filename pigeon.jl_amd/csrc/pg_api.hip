@@ -296,7 +296,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
 #ifdef PG_EXPERIMENTAL_SOLVE4
     h->solve4_lds = lds4_bytes(N);
 #endif
-    h->solve_lds = (size_t)((h->solve_ring ? 4 : N) * SB + 10 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 72 + 100 + 8 + 72 + 4 + 2 * N + 11 * N) * sizeof(real);
+    h->solve_lds = (size_t)((h->solve_ring ? 4 : N) * SB + 10 * NN + 8 * NN + 2 * N + 2 * N + 16 * N + 4 * N + 8 * N + 2 * N + 8 * NN + 2 * N + 72 + 100 + 8 + 72 + 4 + 32 + 2 * N + 11 * N) * sizeof(real);
     if (h->solve_lds > 160 * 1024) { g_create_error = "horizon too long for LDS staging"; free_all(h); delete h; return PG_ERR_INVALID; }
     // hipFuncSetAttribute applies to the CURRENT DEVICE's copy of a kernel, and a later handle with a shorter horizon must not lower the limit an earlier handle of the same
     // device relies on: the largest size asked for so far is kept per device ordinal

@@ -1410,7 +1410,8 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     real* sDum = sx0 + 8;              // [72] sink for predicated-off stores (keeps the pass loops branch-free; a lane's slot and the one four further on)
     real* sZero = sDum + 72;           // [2]  a stored 0.0 (off-pattern entries of Qhat)
     real* sOne = sZero + 2;            // [2]  a stored 1.0 (the identity entries of the operand [Abar | Bbar | cbar])
-    real* skf_ck = sOne + 2;          // [N][2] the predictor's feed-forward terms as the matrix pass left them (skf itself is rewritten by every vector pass): restored when the recursion restarts at its checkpoint
+    real* sCst = sOne + 2;             // [32] constant rows of the roll-out: e6 (0..7), e7 (8..15), (1, 0), (0, 1) (16..19), zeros (20..31)
+    real* skf_ck = sCst + 32;          // [N][2] the predictor's feed-forward terms as the matrix pass left them (skf itself is rewritten by every vector pass): restored when the recursion restarts at its checkpoint
     real* sF0 = skf_ck + 2 * N;        // [N][11] row 8 of the matrix pass's product C = [Abar Bbar]'[M_A | M_B | y]: F0 = Bbar0' P Abar (8), Bbar0' P Bbar0, S01, Bbar0' y (the last rewritten by a
                                        // vector pass) -- the stationarity condition in the first input, for the multiplier of a pinned rate row; written only while a stage is pinned
     bool any_pin = false;              // (wave-uniform: some stage of this instance is pinned in the round being assembled)
@@ -1450,6 +1451,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     const int prev_solved = O.solved[b], prev_status = O.status[b];      // (the warm-start test further down: loaded with the batch, not in a round trip of its own)
     const real hji_b = Q[o.b];
     if (lane < 4) sZero[lane] = lane < 2 ? real(0.0) : real(1.0);
+    if (lane < 32) sCst[lane] = (lane == 6 || lane == 15 || lane == 16 || lane == 19) ? real(1.0) : real(0.0);
 
     // ---- per-stage constants in the registers of lane s (stage s = transition s, node s+1) ----
     const bool act = lane < N;
@@ -1563,31 +1565,42 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     bool exr = EXR;                    // (per instance, i.e. wave-uniform: see where the safety row is examined)
     auto forward = [&](auto use_gain_t, bool delta = false) {      // delta: the roll-out of a CORRECTION (starts at 0, no affine term: see the polish refinement)
         constexpr bool use_gain = decltype(use_gain_t)::value;
+        // Every lane evaluates x+ = row . x + addc + bf . v with ITS row, constant and input column, each an LDS address and a stride per stage fixed here (the loop is bound by
+        // instruction issue: no value selects, no blend): lanes 0..5 the six dynamics rows of [Abar | cbar | Bbar]; lanes 6, 7 the input states as the rows e6, e7 with the
+        // input columns (1, 0), (0, 1) from a stored table; lanes 8, 9 the gain rows with kff (v = 0 roll-out: zeros); the rest zeros.  Rows of 16 lanes mirror each other.
         const int f16 = lane & 15;
-        const bool isA = f16 < 6, isK = f16 == 8 || f16 == 9;
-        const int rrA = isA ? f16 : 5, kro = 8 * (isK ? f16 - 8 : 0);
+        const bool isA = f16 < 6, isK = use_gain && (f16 == 8 || f16 == 9), isU = f16 == 6 || f16 == 7;
+        const real* const zrow = sCst + 20;
+        const real* const prow = isA ? sRing + SB_ROW * f16 : (isU ? sCst + 8 * (f16 - 6) : (isK ? sK + 8 * (f16 - 8) : zrow));
+        const int trow = isA ? SB : (isK ? 16 : 0);
+        const real* const padd = (isA && !delta) ? sRing + SB_C + f16 : (isK ? skf + (f16 - 8) : zrow);
+        const int tadd = (isA && !delta) ? SB : (isK ? 2 : 0);
+        const real* const pbf = isA ? sRing + SB_B + 2 * f16 : (isU ? sCst + 16 + 2 * (f16 - 6) : zrow);
+        const int tbf = isA ? SB : 0;
+        real* const dX = lane < 8 ? sx + 8 + lane : sDum + lane;   const int tX = lane < 8 ? 8 : 0;
+        real* const dV = lane < 2 ? sv + lane : sDum + lane;       const int tV = lane < 2 ? 2 : 0;
         real xi = delta ? real(0.0) : sx0[r8];
         *(lane < 8 ? sx + lane : sDum + lane) = xi;
         ring_prime(0, +1);
-        const real w_lo = isA ? real(1.0) : real(0.0), w_6 = f16 == 6 ? real(1.0) : real(0.0), w_7 = f16 == 7 ? real(1.0) : real(0.0);
 #pragma unroll 1
         for (int k = 0; k < N; k++) {
             ring_step(k, +1);
             const real* Rk = ring_slot(k);
-            const real* rowp = (use_gain && isK) ? sK + 16 * k + kro : Rk + SB_ROW * rrA;
+            // (RING: the stage block sits in slot k & 3 of the ring -- the lanes that read it form their address per stage)
+            const real* rowp = RING ? (isA ? Rk + SB_ROW * f16 : prow + trow * k) : prow + trow * k;
             real rw[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) rw[m] = rowp[m];
-            const real addc = isK ? (use_gain ? skf[2 * k + (f16 - 8)] : real(0.0)) : (delta ? real(0.0) : Rk[SB_C + rrA]);
-            const real bf0 = Rk[SB_B + 2 * rrA], bf1 = Rk[SB_B + 2 * rrA + 1];
+            const real addc = RING ? *((isA && !delta) ? Rk + SB_C + f16 : padd + tadd * k) : padd[tadd * k];
+            const real* bfp = RING ? (isA ? Rk + SB_B + 2 * f16 : pbf) : pbf + tbf * k;
+            const real bf0 = bfp[0], bf1 = bfp[1];
             real xm[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) xm[m] = rl(xi, m);
             real d0 = addc, d1 = real(0.0);
 #pragma unroll
             for (int m = 0; m < 8; m += 2) { d0 += rw[m] * xm[m]; d1 += rw[m + 1] * xm[m + 1]; }
-            real d = d0 + d1;
-            if (!use_gain) d = isK ? real(0.0) : d;            // v = 0 roll-out of the first start
+            const real d = d0 + d1;
             real v0 = rl(d, 8); const real v1 = rl(d, 9);
             if (clip_now) {        // (wave-uniform; first round of a cold instance) saturated roll-out: the gain of the unconstrained problem, the steering rate held inside its limits
                 const real hi = rl(bb[12], k), lo = -rl(bb[13], k);
@@ -1601,12 +1614,10 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
                 }
                 if (lane == k) clip_mask |= cm;
             }
-            const real xr = d + (bf0 * v0 + bf1 * v1);
-            // arithmetic blend instead of ?: so that the compiler keeps the LDS reads above unconditional (a branch here serialises them)
-            const real xn = w_lo * xr + w_6 * (xm[6] + v0) + w_7 * (xm[7] + v1);
+            const real xn = d + (bf0 * v0 + bf1 * v1);        // (lanes 8..15 of a row: not a state, never read)
             xi = xn;
-            *(lane < 8 ? sx + 8 * (k + 1) + lane : sDum + lane) = xn;
-            *(lane < 2 ? sv + 2 * k + lane : sDum + lane) = lane == 0 ? v0 : v1;
+            dX[tX * k] = xn;
+            dV[tV * k] = lane == 0 ? v0 : v1;
         }
         __syncthreads();
     };
