@@ -1594,7 +1594,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             const real addc = RING ? *((isA && !delta) ? Rk + SB_C + f16 : padd + tadd * k) : padd[tadd * k];
             const real* bfp = RING ? (isA ? Rk + SB_B + 2 * f16 : pbf) : pbf + tbf * k;
             const real bf0 = bfp[0], bf1 = bfp[1];
-            real xm[8];
+            real xm[8];      // (measured and dropped: x_k[m] broadcast inside the multiply-add, v_fmac_f64_dpp row_newbcast -- 8 instructions for 24 --: 0.2305 against 0.232 ms, in the noise)
 #pragma unroll
             for (int m = 0; m < 8; m++) xm[m] = rl(xi, m);
             real d0 = addc, d1 = real(0.0);
