@@ -1380,6 +1380,12 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     const unsigned long long t_entry = (PG_TL && prof) ? wall_clock64() : 0ull;
     const int b = listm ? O.list[blockIdx.x] : (O.order_in ? O.order_in[blockIdx.x] : (int)blockIdx.x), lane = threadIdx.x;
     const int N = C.N, NN = C.NN;
+    // -DPG_TIMELINE build, product instantiation: wall-clock marks (10 ns units since entry) of the FIRST time each point is passed, in the slots the cycle counters of the
+    // diagnostic instantiation use: 0 prologue done, 1 first stage assembly done, 2 first matrix pass done, 3 first roll-out done, 4 first check done, 5 epilogue starts
+    unsigned tl_seen = 0u;
+    auto tl_mark = [&](int slot) __attribute__((always_inline)) {
+        if constexpr (PG_TL && !PROF) { if (prof && lane == 0 && !((tl_seen >> slot) & 1u)) { prof[(size_t)b * 6 + slot] = wall_clock64() - t_entry; tl_seen |= 1u << slot; } }
+    };
     // FUSE: update_QP! of this instance first, by the wave that is about to solve it -- lane pair (2t, 2t+1) linearises interval t (2N <= 64; lanes beyond 2N mirror
     // the last interval and store nothing).  The QP data go to memory exactly as k_linearize writes them (pg_get_qp reads them; the solve below reads them back
     // through L2: fence + barrier in between).  Why fuse: k_solve ends with its slowest wave, and as a kernel of its own it idles most of the machine during that
@@ -1582,6 +1588,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
         real xi = delta ? real(0.0) : sx0[r8];
         *(lane < 8 ? sx + lane : sDum + lane) = xi;
         ring_prime(0, +1);
+        // (measured and dropped: the row, constant and input column of stage k + 1 loaded while stage k computes -- eleven more live values: 0.2305 -> 0.232 ms)
 #pragma unroll 1
         for (int k = 0; k < N; k++) {
             ring_step(k, +1);
@@ -1788,20 +1795,33 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
 #pragma unroll 1
         for (int seg = restart ? 1 : 0; seg < nseg; seg++) {
         const int k_hi = (nseg == 2 && seg == 1) ? ck_k - 1 : N - 1, k_lo = (nseg == 2 && seg == 0) ? ck_k : 0;
+        // stage constants (none of these reads depends on the recursion).  PREF: those of stage k - 1 are loaded while the first product of stage k runs -- eight more live
+        // values: the fp32 full kernel has the registers (config 3's solve launch 0.595 -> 0.551 ms); the fp64 rounds-only kernel does not (0.233 -> 0.240 ms: more moves
+        // through the accumulation registers), and the fp32 rounds-only kernel would leave its two waves per SIMD or spill
+        constexpr bool PREF = !RING && IPM && sizeof(real) == 4;
+        real nb10 = real(0.0), nb11 = real(0.0), nadd0 = real(0.0), nadd1 = real(0.0), nR0 = real(0.0), nR1 = real(0.0), nr0 = real(0.0), nr1 = real(0.0);
+        auto stage_constants = [&](int kk) __attribute__((always_inline)) {
+            nb10 = xsrc[0][xstr[0] * kk]; nb11 = xsrc[1][xstr[1] * kk]; nadd0 = abase[0][amul[0] * kk]; nadd1 = abase[1][amul[1] * kk];
+            nR0 = sR[2 * kk]; nR1 = sR[2 * kk + 1]; nr0 = sr[2 * kk]; nr1 = sr[2 * kk + 1];
+        };
+        if (PREF) stage_constants(k_hi);
 #pragma unroll 1
         for (int k = k_hi; k >= k_lo; k--) {
             ring_step(k, -1);
             const real* Xk = ring_slot(k);
-            // stage constants: none of these reads depends on the recursion
-            const real b10 = RING ? *(xlds[0] ? Xk + xoff[0] : xsrc[0]) : xsrc[0][xstr[0] * k], b11 = RING ? *(xlds[1] ? Xk + xoff[1] : xsrc[1]) : xsrc[1][xstr[1] * k];
-            const real add0 = abase[0][amul[0] * k], add1 = abase[1][amul[1] * k];
-            const real R0 = sR[2 * k], R1 = sR[2 * k + 1], r0v = sr[2 * k], r1v = sr[2 * k + 1];
+            real b10, b11, add0, add1, R0, R1, r0v, r1v;
+            if (!PREF) {
+                b10 = RING ? *(xlds[0] ? Xk + xoff[0] : xsrc[0]) : xsrc[0][xstr[0] * k]; b11 = RING ? *(xlds[1] ? Xk + xoff[1] : xsrc[1]) : xsrc[1][xstr[1] * k];
+                add0 = abase[0][amul[0] * k]; add1 = abase[1][amul[1] * k];
+                R0 = sR[2 * k]; R1 = sR[2 * k + 1]; r0v = sr[2 * k]; r1v = sr[2 * k + 1];
+            } else { b10 = nb10; b11 = nb11; add0 = nadd0; add1 = nadd1; R0 = nR0; R1 = nR1; r0v = nr0; r1v = nr1; }
             // M = P X
             mfma_acc Ma = {real(0.0), real(0.0), real(0.0), real(0.0)};
             // (A operand = P through its own result: lane (g, c) supplies row c of the product.  Columns 8 .. 15 of V hold other things -- S, the vector recursion -- and
             //  give rows 8 .. 15 of M, which nothing reads: no masking.  The same holds for row 10 of C below, the cbar column of X.)
             Ma = PG_MFMA(V0, b10, Ma);
             Ma = PG_MFMA(V1, b11, Ma);
+            if (PREF) stage_constants(k > 0 ? k - 1 : 0);      // (in the shadow of the two products)
             real M0, M1; to_operands(Ma, M0, M1);
             { real* d = dMc + tMc * k; d[0] = M0; d[4] = M1; }                       // Mc_k = P_{k+1} cbar_k for the corrector's vector pass
             // C = [Abar Bbar]' [M_A | M_B | y]   (y = P c + p in column 10)
@@ -2302,9 +2322,11 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
 #pragma unroll
         for (int j = 0; j < NROW; j++) R.corr[j] = real(0.0);
         stamp(0);
+        tl_mark(0);
         assemble(real(0.0), true);
         __syncthreads();
         stamp(1);
+        tl_mark(1);
         {
             bool restart = false;
             if constexpr (CKPT) {
@@ -2321,10 +2343,12 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
             ck_restart = false;
         }
         stamp(2);
+        tl_mark(2);
         clip_mask = 0u; clip_now = C.clip_guess != 0 && !clip_off && attempt == -1 && pmode == 1 && !hji_hot;
         forward(std::true_type{});
         clip_now = false;
         stamp(4);
+        tl_mark(3);
         newton_point(tp);
         if (IPM && !pmode) {
             // step to the boundary: alpha_max = 1 / max_j( -dt_j / t_j, -dl_j / lam_j )  (only rows that move towards the boundary are positive)
@@ -2359,6 +2383,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
         } else {
             // first polish solve done: with multiplier estimates as good as the interior point's, it usually verifies at once (no refinement needed)
             const int pc = polish_check(tp, real(0.01) * ptol);
+            tl_mark(4);
             ptrace(pc, tp);
             if (pc == 0) break;
             if (pc == 3) { if (polish_failed()) break; continue; }
@@ -2454,6 +2479,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     }   // attempts
     it = it_total;
     stamp(0);
+    tl_mark(5);
     if (PG_TL && prof && lane == 0) {      // (the timeline also from the product's kernel in a -DPG_TIMELINE build: pg_debug_solve_cycles with the option "diag_timeline")
         if constexpr (PROF) for (int i = 0; i < 6; i++) prof[(size_t)b * 6 + i] = pc[i];
         // timeline record behind the trace region: wall clock (100 MHz) at entry and here, and where the wavefront ran (HW_ID | XCC_ID << 32)

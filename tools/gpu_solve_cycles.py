@@ -43,6 +43,13 @@ if tl[:, 1].any():
     simd = (hw >> np.uint64(4)) & np.uint64(3); cu = (hw >> np.uint64(8)) & np.uint64(15); sh = (hw >> np.uint64(12)) & np.uint64(1); se = (hw >> np.uint64(13)) & np.uint64(7)
     slot = (((xcc * np.uint64(8) + se) * np.uint64(2) + sh) * np.uint64(16) + cu) * np.uint64(4) + simd
     pol = mpc.polish_info()
+    if TL and cyc[:, 5].any():      # -DPG_TIMELINE build, product kernel: wall-clock marks of the first pass through each point (10 ns units since the wavefront's entry)
+        mk = cyc / 100.0; life = ext - ent
+        for r in (1, 2):
+            m = pol == r
+            if m.any():
+                print(f"instances with {r} round(s) ({int(m.sum())}): prologue done {mk[m, 0].mean():.1f} us, first assembly {mk[m, 1].mean():.1f}, first matrix pass {mk[m, 2].mean():.1f}, "
+                      f"first roll-out {mk[m, 3].mean():.1f}, first check {mk[m, 4].mean():.1f}, epilogue starts {mk[m, 5].mean():.1f}, exit {life[m].mean():.1f}")
     print(f"launch: first entry 0, last entry {ent.max():.1f} us, last exit {ext.max():.1f} us; wavefront lifetime mean {np.mean(ext - ent):.1f} us (min {np.min(ext - ent):.1f}, max {np.max(ext - ent):.1f}); distinct SIMDs seen {len(np.unique(slot))}")
     busy = []; gaps = []; nper = []
     for sl_ in np.unique(slot):
