@@ -43,6 +43,7 @@ struct pg_handle {
     real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     real* d_lam = nullptr;                                      // [cap][N][16] multipliers of the last solve (warm start of the polish)
     int* d_wfail = nullptr;                                     // [cap] back-off of k_solve_lat's warm attempts (the second half of the d_solved allocation: pg_reset clears both with one fill)
+    int pipe_first = 0;                                               // option "pipe_first": short-horizon intervals that go first in the pipelined launch (0 = as many as fill the SIMDs the recurrence leaves free)
     int pipe_min = 2304, pipe_max = 256 * NODES_IPB;                    // batch sizes the pipelined launch serves (options "pipe_min" / "pipe_max"; its nodes blocks must be resident at once: <= 16384)
     int lin_lpi = 1;                                          // lanes per (instance, interval) of the large-batch linearisation (k_linearize_split / k_nodes_linearize): one lane with all eight
                                                               // directions (option "lin_lanes" = 2: the lane pair of rounds 1-3, for A/B runs; same bits in fp64, rounding-level differences in fp32)
@@ -372,6 +373,7 @@ static bool find_option(pg_handle* h, const char* name, OptRef* o) {
     if (n == "solve_split") return I(&h->split_solve, 0, 1);
     // launch shape
     if (n == "pipe_min") return I(&h->pipe_min, 0, 1 << 30);
+    if (n == "pipe_first") return I(&h->pipe_first, 0, 64);
     if (n == "pipe_max") return I(&h->pipe_max, 0, 256 * NODES_IPB);
     if (n == "lin_lanes") return I(&h->lin_lpi, 1, 2);
     if (n == "graph") return I(&h->graph_mode, 0, 1);
@@ -706,6 +708,7 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
             const size_t lds = traj_lds > 64 * 20 * sizeof(real) ? traj_lds : 64 * 20 * sizeof(real);
             auto kern = lpi == 1 ? (staged ? k_nodes_linearize<true, 1> : k_nodes_linearize<false, 1>) : (staged ? k_nodes_linearize<true, 2> : k_nodes_linearize<false, 2>);
             int nzf = (1024 - nbn + nbt - 1) / nbt;               // short-horizon intervals that go first: one wavefront for every SIMD the recurrence leaves free
+            if (h->pipe_first > 0) nzf = h->pipe_first;
             if (nzf > h->dc.Ns) nzf = h->dc.Ns;
             if (nzf < 1) nzf = 1;
             // nodes after which the recurrence publishes its progress (each publication is a device-scope release, i.e. an L2 write-back): every third node of the

@@ -530,6 +530,7 @@ PG_DEV void linearize_lanes_at(const DevCfg& C, int b, int t, int g, bool live, 
     }
     const real pV0 = n0[8], pK0 = n0[9], pV1 = ramp ? n1[8] : n0[8], pK1 = ramp ? n1[9] : n0[9];
     const int nsub = C.nsub; const real h = h_total / nsub;
+    const real h6 = h / real(6.0);
 #pragma unroll 1
     for (int i = 0; i < nsub; i++) {
         const real t0 = i * h;
@@ -562,20 +563,33 @@ PG_DEV void linearize_lanes_at(const DevCfg& C, int b, int t, int g, bool live, 
                 const real da = s0a[d] + (sfa[d] - s0a[d]) * w, db = s0b[d] + (sfb[d] - s0b[d]) * w;
                 real kd[6];
                 kd[0] = J.a0[0] * tU + J.a0[1] * tY + J.a0[2] * tP;
+                // One lane per interval (K == ND): the direction index is a compile-time number once this loop is unrolled, and the input terms exist for two directions each
+                // (da for j = 4, 6; db for j = 5, 7) -- the others would add 0 x J: the same value without them (36 of 288 multiply-adds per stage)
+                const int j = g * K + d;
+                const bool has_a = K != ND || j == 4 || j == 6, has_b = K != ND || j == 5 || j == 7;
 #pragma unroll
-                for (int m = 0; m < 3; m++) kd[1 + m] = J.b[m][0] * tU + J.b[m][1] * tY + J.b[m][2] * tR + J.b[m][3] * da + J.b[m][4] * db;
+                for (int m = 0; m < 3; m++) {
+                    real v = J.b[m][0] * tU + J.b[m][1] * tY + J.b[m][2] * tR;
+                    if (has_a) v = v + J.b[m][3] * da;
+                    if (has_b) v = v + J.b[m][4] * db;
+                    kd[1 + m] = v;
+                }
                 kd[4] = tR + J.a4[0] * tU + J.a4[1] * tY + J.a4[2] * tP;
                 kd[5] = J.a5[0] * tU + J.a5[1] * tY + J.a5[2] * tP;
+                // (the tangents of ds and e feed nothing back -- the model reads neither --: pure quadratures, summed into the state as they come instead of through an
+                //  accumulator of their own: 2 K fewer live values)
+                x[0].d[d] = x[0].d[d] + kd[0] * (wgt * h6); x[5].d[d] = x[5].d[d] + kd[5] * (wgt * h6);
 #pragma unroll
-                for (int k = 0; k < 6; k++) { acc[k].d[d] = acc[k].d[d] + kd[k] * wgt; xx[k].d[d] = x[k].d[d] + kd[k] * nxt; }
+                for (int k = 1; k < 5; k++) { acc[k].d[d] = acc[k].d[d] + kd[k] * wgt; xx[k].d[d] = x[k].d[d] + kd[k] * nxt; }
             }
         }
-        const real h6 = h / real(6.0);
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             x[k].v = x[k].v + acc[k].v * h6;
+            if (k >= 1 && k <= 4) {
 #pragma unroll
-            for (int d = 0; d < K; d++) x[k].d[d] = x[k].d[d] + acc[k].d[d] * h6;
+                for (int d = 0; d < K; d++) x[k].d[d] = x[k].d[d] + acc[k].d[d] * h6;
+            }
         }
     }
     // this lane's share of c_i = Phi_i - A_i. q - B0_i. u0 - Bf_i. uf   (raw, un-normalised Jacobians: coupled_lat_long.jl:336-353)
