@@ -451,6 +451,9 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // one pass over the slots (MEM: rolled; the loads of a visit are issued back to back at its top.  Requesting slot j + 1 while slot j computes was measured:
     // barrier terms 48 k -> 40 k cycles per iteration, Newton point unchanged, and the 62-double copy of the prefetched operands per visit ate the gain:
     // 2.46 / 3.42 ms with it, 2.36 / 3.45 ms without)
+    // (Round 5, measured and removed: pulling the NEXT slot towards the L2 while this one computes -- three loads of one dword per lane, 128 B apart, touch the 184 cache
+    // lines of a slot, nothing copied: 3.05 -> 3.47 ms with walls, 2.19 -> 2.40 without.  A load instruction that touches 64 cache lines costs the memory pipeline more than
+    // the round trip it was meant to hide.)
     auto piped = [&](int what, auto&& compute) __attribute__((always_inline)) {
         if constexpr (MEM) {
 #pragma unroll 1
