@@ -17,7 +17,7 @@ def test_decoupled_matches_oracle(pkg, oracle_mod, skidpad, Ns, Nl):
     u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
     assert np.all(pkg.is_solved(status)), status      # (PG_SOLVED_UNVERIFIED: instances whose polish did not verify keep the interior-point iterate; compared below like the rest)
     qs, us, ps = mpc.nodes(); qp = mpc.qp_data(); x, sg = mpc.solution(); st, it, act, mu = mpc.solve_info(); lam = mpc.multipliers()
-    worst = 0.0
+    worst = 0.0; lam_err = 0.0; n_lam = 0
     for b in range(B):
         ts, dt = orc.time_steps(t0[b])
         oq, ou, op = orc.nodes(state[b], control[b], ts, dt, time_offset=toff[b])
@@ -44,7 +44,17 @@ def test_decoupled_matches_oracle(pkg, oracle_mod, skidpad, Ns, Nl):
         uo = orc.next_control(X["delta"][1], ou[1, 1])                       # decoupled_lat_long.jl:275-278
         assert abs(u[b, 0] - uo[0]) < 1e-6 and np.max(np.abs(u[b, 1:] - uo[1:])) <= 1e-9 * max(1.0, np.max(np.abs(uo)))
         assert pkg.decoupled_canonical_active_set(orc.N, Ns, act[b], lam=lam[b]) == oracle_mod.active_set(qpc, xe, ye, tol=1e-6), b
+        # multipliers of the held steering rows of a VERIFIED instance against the oracle's duals: the rate rows (bits 12 / 13) are eliminated exactly in k_solve_lat's polish
+        # and their multipliers read off stationarity (round 5), the steering-bound rows (3 / 4) go through the augmented Lagrangian
+        if st[b] == pkg.SOLVED:
+            r_7 = 2 * orc.N + orc.N + 4 + 1 + 4 * Ns + 4 * (orc.N - Ns)
+            for k in range(orc.N):
+                for j, row in ((3, r_7 + 8 * k), (4, r_7 + 8 * k + 1), (12, r_7 + 8 * k + 6), (13, r_7 + 8 * k + 7)):
+                    if (int(act[b, k]) >> j) & 1 and lam[b, k, j] > 1e-6:
+                        lam_err = max(lam_err, abs(lam[b, k, j] - abs(ye[row])) / max(1.0, abs(ye[row]))); n_lam += j >= 12
     assert worst < 1e-6, worst
+    assert n_lam >= 20 and lam_err <= 1e-5, (n_lam, lam_err)      # (measured: see the printed line)
+    print(f"N = {orc.N}: {n_lam} held rate rows compared, worst |lambda - lambda*| / max(1, lambda*) over the steering rows {lam_err:.1e}")
 
 
 def test_decoupled_refuses_hji(pkg, skidpad):

@@ -114,6 +114,40 @@ def test_accuracy_of_every_instance_of_the_batch(run, oracle_mod, skidpad, pkg):
     assert res[:, 3].sum() == 0, (int(res[:, 3].sum()), np.flatnonzero(res[:, 3])[:8])          # the signed index lists are IDENTICAL for every one of the 4096 instances
 
 
+def test_multipliers_of_held_rows_are_the_oracle_duals(run, oracle_mod, skidpad):
+    """pg_get_multipliers against the oracle's dual solution, row by row, for 160 instances that needed more than one round (they hold steering-rate rows).  Since round 5 a
+    held rate row is eliminated exactly in the recursion and its multiplier is READ OFF the stationarity condition in the pinned input (k_solve: polish_check) -- nothing
+    iterates on it --, so this is the direct check of that expression: rows 12 / 13; next to them the bound rows held through the augmented Lagrangian (3, 4, 5) and the
+    pivots of the eliminated slacks (10, 11), whose multipliers are the linear cost coefficients of their slacks.  Measured: rate rows 2.6e-8 at worst (median 6e-13)."""
+    from concurrent.futures import ThreadPoolExecutor
+    mpc, state, control, t0, toff, u, status, iters = run
+    qp = mpc.qp_data(); _, _, act, _ = mpc.solve_info(); lam = mpc.multipliers(); pol = mpc.polish_info()
+    N, Ns, Nl = mpc.N, mpc.N_short, mpc.N_long
+    r_C1 = 0; r_C13 = 2 * N + Ns + 2 * N + 3 * (N + 1) + 6 + 2 + 6 * Ns + Ns + 6 * Nl      # (the row blocks of the canonical QP: mpc.canonical_active_set)
+    pick = np.flatnonzero(pol >= 2)[:160]
+    assert len(pick) == 160
+    nthr = min(16, len(os.sched_getaffinity(0)))
+    orcs = [make_oracle(oracle_mod, skidpad) for _ in range(nthr)]
+
+    def work(w):
+        out = []
+        for b in pick[w::nthr]:
+            xe, ye, info = orcs[w].solve_exact(qp[b])
+            assert info["status"] == 1
+            for k in range(N):
+                base = r_C13 + 9 * k
+                for j, row in ((3, base), (4, base + 1), (5, base + 2), (12, base + 7), (13, base + 8), (10, r_C1 + 2 * k), (11, r_C1 + 2 * k + 1)):
+                    if (int(act[b, k]) >> j) & 1 and lam[b, k, j] > 1e-6:
+                        out.append((j, abs(lam[b, k, j] - abs(ye[row])) / max(1.0, abs(ye[row]))))
+        return out
+    with ThreadPoolExecutor(nthr) as ex:
+        res = np.array(sum(ex.map(work, range(nthr)), []))
+    rate = res[(res[:, 0] == 12) | (res[:, 0] == 13)]
+    assert len(rate) >= 300                                            # the sample does hold rate rows
+    print(f"held rows compared: {len(res)} ({len(rate)} rate rows); worst |lambda - lambda*| / max(1, lambda*): rate rows {rate[:, 1].max():.1e}, all {res[:, 1].max():.1e}")
+    assert res[:, 1].max() <= 1e-6, res[np.argmax(res[:, 1])]
+
+
 def test_golden_cases_on_gpu(pkg):
     """The committed vectors (tools/make_golden_cases.py): cold step and warm second step on two of the reference's test paths."""
     G = np.load(os.path.join(ROOT, "tests", "golden", "coupled_cases.npz"))
