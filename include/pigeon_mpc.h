@@ -248,6 +248,8 @@ int pg_synchronize(pg_handle* h);
  *     "pipe_min" (2304), "pipe_max" (8192, at most: 256 nodes wavefronts of 32 instances)  batch sizes the pipelined nodes + update_QP launch serves (pg_set_pipeline)
  *     "pipe_first" 0..64 (0)     short-horizon intervals whose wavefronts go first in that launch (0: as many as fill the SIMDs the recurrence leaves free -- all ten at B = 4096;
  *                                measured: fewer is slower, 0.317 / 0.323 / 0.328 / 0.344 ms for 10 / 8 / 6 / 2)
+ *     "pipe_pub_short" (3), "pipe_pub_long" (5)   the recurrence of that launch publishes its progress after every n-th node of the short / long horizon (a publication is a
+ *                                device-scope release, ~3 us on the serial chain: every node of the short horizon 0.317 -> 0.345 ms)
  *     "lin_lanes" 1/2 (1)        lanes per (instance, interval) of the large-batch linearisation
  *     "phase_timing" 0/1 (0)     1 = pg_step_dev records the HIP events pg_get_phase_ms reads (four event records per step on the handle's stream: measured 13-25 us per step, 2-4 % of a
  *                                4096-instance step); 0 = no instrumentation, pg_get_phase_ms returns PG_ERR_STATE

@@ -43,6 +43,7 @@ struct pg_handle {
     real *d_solx = nullptr, *d_sigma = nullptr, *d_u = nullptr, *d_mu = nullptr;
     real* d_lam = nullptr;                                      // [cap][N][16] multipliers of the last solve (warm start of the polish)
     int* d_wfail = nullptr;                                     // [cap] back-off of k_solve_lat's warm attempts (the second half of the d_solved allocation: pg_reset clears both with one fill)
+    int pipe_pub_short = 3, pipe_pub_long = 5;                        // options: the recurrence of the pipelined launch publishes every n-th node of the short / long horizon
     int pipe_first = 0;                                               // option "pipe_first": short-horizon intervals that go first in the pipelined launch (0 = as many as fill the SIMDs the recurrence leaves free)
     int pipe_min = 2304, pipe_max = 256 * NODES_IPB;                    // batch sizes the pipelined launch serves (options "pipe_min" / "pipe_max"; its nodes blocks must be resident at once: <= 16384)
     int lin_lpi = 1;                                          // lanes per (instance, interval) of the large-batch linearisation (k_linearize_split / k_nodes_linearize): one lane with all eight
@@ -374,6 +375,8 @@ static bool find_option(pg_handle* h, const char* name, OptRef* o) {
     // launch shape
     if (n == "pipe_min") return I(&h->pipe_min, 0, 1 << 30);
     if (n == "pipe_first") return I(&h->pipe_first, 0, 64);
+    if (n == "pipe_pub_short") return I(&h->pipe_pub_short, 1, 64);
+    if (n == "pipe_pub_long") return I(&h->pipe_pub_long, 1, 64);
     if (n == "pipe_max") return I(&h->pipe_max, 0, 256 * NODES_IPB);
     if (n == "lin_lanes") return I(&h->lin_lpi, 1, 2);
     if (n == "graph") return I(&h->graph_mode, 0, 1);
@@ -715,7 +718,7 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
             // short horizon, every fifth of the long one (N = 30, Ns = 10: nodes 3, 6, 9, 14, 19, 24); the end of the recurrence always publishes
             unsigned long long pub = 0ull;
             for (int i = 1; i < h->dc.N - 2 && i < 63; i++)
-                if (i <= h->dc.Ns ? i % 3 == 0 : (i - h->dc.Ns) % 5 == 4) pub |= 1ull << i;
+                if (i <= h->dc.Ns ? i % h->pipe_pub_short == 0 : (i - h->dc.Ns) % h->pipe_pub_long == h->pipe_pub_long - 1) pub |= 1ull << i;
             if (h->pipe_fault) pub = 1ull << 63;                  // test hook: nothing is ever published (tests/test_gpu_api_contract.py)
             hipLaunchKernelGGL(kern, dim3((unsigned)(nbn + nbt * h->dc.N)), block, lds, h->stream, h->dc, B, nbn, nzf, pub, h->d_state, h->d_control, h->d_toff, h->d_solved, h->d_sep, h->d_ts,
                                h->d_dt, h->d_prev_ts, h->d_solx, h->d_nodes, F, h->d_naux, h->d_progress, h->d_Mb, h->d_qp, h->d_progress + nbn, h->d_progress + cap / NODES_IPB + 7);
@@ -961,6 +964,15 @@ int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     (void)hipFree(d);
     return PG_OK;
 }
+#ifdef PG_TIMELINE
+// debug (timeline build only, not part of the public header): per block of the last pipelined launch (entry, end of the wait, exit on the 100 MHz wall clock; interval, 1000 = a nodes block)
+extern "C" int pg_debug_pipeline_timeline(pg_handle* h, unsigned long long* out, int n_blocks) {
+    int rc = check_ready(h); if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nl_timeline), (size_t)(n_blocks < 8192 ? n_blocks : 8192) * 4 * sizeof(unsigned long long)));
+    return PG_OK;
+}
+#endif
 int pg_get_next_control_dev(pg_handle* h, void* u_out_dev) {
     int rc = check_ready(h); if (rc) return rc;
     if (u_out_dev) HIPCHK(h, hipMemcpyAsync(u_out_dev, h->d_u, (size_t)h->B * 3 * sizeof(real), hipMemcpyDeviceToDevice, h->stream));

@@ -345,7 +345,7 @@ template <bool STAGED, bool PUB> PG_DEV void nodes_body(const DevCfg& C, int B, 
         if (i == 1) { d1 = atan2(est.ang_y, est.ang_x) - atan(est.ang_t); Fx1 = est.Fx; }          // (the launch-order hint needs this one angle now)
         if constexpr (PUB) {
             if (publish && ((pub_mask >> i) & 1ull)) {                 // nodes 0..i of all 64 instances are in memory: release, then the count
-                __threadfence();
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // (a RELEASE: write-back only -- __threadfence() also invalidates this wavefront's caches, which hold the trajectory it keeps searching)
                 if (threadIdx.x == 0) __hip_atomic_store(progress + blk, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -407,7 +407,7 @@ template <bool STAGED, bool PUB> PG_DEV void nodes_body(const DevCfg& C, int B, 
                 if (publish && done > prev) {      // nodes prev .. done - 1 of every instance of the wavefront are in memory: publish when one of them is a publication point
                     const unsigned long long lo_new = done >= 64 ? ~0ull : ((1ull << done) - 1ull), lo_old = (1ull << prev) - 1ull;
                     if (pub_mask & 0x7FFFFFFFFFFFFFFFull & lo_new & ~lo_old) {
-                        __threadfence();
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                         if (threadIdx.x == 0) __hip_atomic_store(progress + blk, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
@@ -730,11 +730,19 @@ __global__ __launch_bounds__(64, PG_LIN_WAVES) void k_linearize(DevCfg C, int B,
 //    writes the dirty lines of the XCD's L2 back -- including the QP data the linearisation wavefronts of that XCD are in the middle of writing -- so the recurrence
 //    publishes after a few chosen nodes (`pub_mask`), not after every node: measured, B = 16384: 1.595 ms with 30 publications per wavefront, 1.434 with 6 (two launches:
 //    1.45); fp32 at 8192: 0.572 / 0.483 (0.555); B = 4096: 0.41 / 0.40 (0.53).
+#ifdef PG_TIMELINE        // (diagnostic build: wall-clock marks per block of the pipelined launch -- entry, end of the wait for the nodes, exit, interval -- read by pg_debug_pipeline_timeline)
+__device__ unsigned long long g_nl_timeline[4 * 8192];
+#define PG_NL_MARK(slot, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_nl_timeline[4 * blockIdx.x + (slot)] = (v); } while (0)
+#else
+#define PG_NL_MARK(slot, v) do { } while (0)
+#endif
 template <bool STAGED, int LPI> __global__ __launch_bounds__(64) void k_nodes_linearize(DevCfg C, int B, int nb_nodes, int nz_first, unsigned long long pub_mask, const real* __restrict__ state, const real* __restrict__ control,
                         const tdouble* __restrict__ toff, const int* __restrict__ solved, const real* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt,
                         const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* nodes, OrderOut F, real* naux, int* progress, const real* __restrict__ hji_Mb, real* __restrict__ qp, int* fault, int* fault_total) {
+    PG_NL_MARK(0, wall_clock64());
     if ((int)blockIdx.x < nb_nodes) {
         nodes_body<STAGED, true>(C, B, (int)blockIdx.x, state, control, toff, solved, sep, ts, dt, prev_ts, prev_x, nodes, F, naux, progress, pub_mask);
+        PG_NL_MARK(2, wall_clock64()); PG_NL_MARK(3, 1000ull);
         __threadfence();                                                  // (warm or mixed wavefronts publish once, here; every lane is back from the body)
         // (bit 63 of pub_mask = fault injection, option "diag_pipe_fault" of the -DPG_DIAG build: the recurrence never publishes, so that a test can watch every waiting wavefront give up)
         if (threadIdx.x == 0 && !(pub_mask >> 63)) __hip_atomic_store(progress + blockIdx.x, C.NN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -781,6 +789,7 @@ template <bool STAGED, int LPI> __global__ __launch_bounds__(64) void k_nodes_li
             return;
         }
     }
+    PG_NL_MARK(1, wall_clock64()); PG_NL_MARK(3, (unsigned long long)t);
     const real* n0g = nodes + ((size_t)b * C.NN + t) * 10;
     const real* a0 = naux + ((size_t)b * C.NN + t) * 4;
     real* rec = sh_rec + lane * 20;
@@ -803,6 +812,7 @@ template <bool STAGED, int LPI> __global__ __launch_bounds__(64) void k_nodes_li
     }
     if (t < C.Ns) linearize_lanes_at<6 / LPI, 6>(C, b, t, g, live, rec, rec + 10, dt, hji_Mb, qp);
     else linearize_lanes_at<8 / LPI, 8>(C, b, t, g, live, rec, rec + 10, dt, hji_Mb, qp);
+    PG_NL_MARK(2, wall_clock64());
 }
 
 // ------------------------------------------------------------------------------------------------------------------
