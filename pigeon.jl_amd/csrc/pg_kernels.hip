@@ -210,6 +210,18 @@ PG_DEV void put_node(real* __restrict__ ND, int i, const NodeRec& r) {
     real* o = ND + i * 10;
     o[0] = r.q0; o[1] = r.q1; o[2] = r.q2; o[3] = r.q3; o[4] = r.q4; o[5] = r.q5; o[6] = r.u0; o[7] = r.u1; o[8] = r.pV; o[9] = r.pK;
 }
+// the two searched channels (t, s) of the shared trajectory into LDS.  Eight strides per trip, every load of a trip issued before the first store: rolled one stride per
+// trip, each of the 16 trips at L = 1000 was a round trip to the L2 -- and this copy is the first thing on the serial chain of the seeding recurrence.
+PG_DEV void stage_trajectory(const TrajView& T, real* __restrict__ sh) {
+    const int Lt = T.L, bd = (int)blockDim.x;
+    for (int i0 = (int)threadIdx.x; i0 < Lt; i0 += 8 * bd) {
+        real vt[8], vs[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + u * bd; const int ic = i < Lt ? i : Lt - 1; vt[u] = T.t[ic]; vs[u] = T.s[ic]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + u * bd; if (i < Lt) { sh[i] = vt[u]; sh[Lt + i] = vs[u]; } }
+    }
+}
 // PUB (k_nodes_linearize, the pipelined nodes + update_QP launch): a wavefront whose 64 instances are all cold publishes, after every node of the seeding
 // recurrence, how many nodes of its instances are complete (`progress[blk]`, release at device scope) -- the linearisation of interval t only needs nodes t, t + 1.
 // The two scalar recurrences of the cold seeding (coupled_lat_long.jl:117-141), in functions of their own with contraction off: they are evaluated in several places (the serial
@@ -267,7 +279,7 @@ template <bool STAGED, bool PUB> PG_DEV void nodes_body(const DevCfg& C, int B, 
     extern __shared__ real sh_traj[];
     TrajView T = C.traj;
     if constexpr (STAGED) {                                 // single shared trajectory; compile-time so the searches compile to ds_read, not flat loads
-        for (int i = threadIdx.x; i < T.L; i += blockDim.x) { sh_traj[i] = C.traj.t[i]; sh_traj[T.L + i] = C.traj.s[i]; }
+        stage_trajectory(C.traj, sh_traj);
         __syncthreads();
         T.t = sh_traj; T.s = sh_traj + T.L;
     }
@@ -452,7 +464,7 @@ template <bool STAGED> __global__ __launch_bounds__(256) void k_nodes_warm(DevCf
     extern __shared__ real sh_traj[];
     TrajView T = C.traj;
     if constexpr (STAGED) {
-        for (int i = threadIdx.x; i < T.L; i += blockDim.x) { sh_traj[i] = C.traj.t[i]; sh_traj[T.L + i] = C.traj.s[i]; }
+        stage_trajectory(C.traj, sh_traj);
         __syncthreads();
         T.t = sh_traj; T.s = sh_traj + T.L;
     }
@@ -865,7 +877,7 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg 
     extern __shared__ real sh_traj[];
     TrajView T = C.traj;
     if constexpr (STAGED) {                                 // single shared trajectory; compile-time so the searches compile to ds_read, not flat loads
-        for (int i = threadIdx.x; i < T.L; i += blockDim.x) { sh_traj[i] = C.traj.t[i]; sh_traj[T.L + i] = C.traj.s[i]; }
+        stage_trajectory(C.traj, sh_traj);
         __syncthreads();
         T.t = sh_traj; T.s = sh_traj + T.L;
     }
