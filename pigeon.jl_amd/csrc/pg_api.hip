@@ -969,7 +969,7 @@ int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
 extern "C" int pg_debug_pipeline_timeline(pg_handle* h, unsigned long long* out, int n_blocks) {
     int rc = check_ready(h); if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nl_timeline), (size_t)(n_blocks < 8192 ? n_blocks : 8192) * 4 * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nl_timeline), (size_t)(n_blocks < 8192 ? n_blocks : 8192) * 8 * sizeof(unsigned long long)));
     return PG_OK;
 }
 #endif

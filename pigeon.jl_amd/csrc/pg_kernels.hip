@@ -210,6 +210,12 @@ PG_DEV void put_node(real* __restrict__ ND, int i, const NodeRec& r) {
     real* o = ND + i * 10;
     o[0] = r.q0; o[1] = r.q1; o[2] = r.q2; o[3] = r.q3; o[4] = r.q4; o[5] = r.q5; o[6] = r.u0; o[7] = r.u1; o[8] = r.pV; o[9] = r.pK;
 }
+#ifdef PG_TIMELINE        // (diagnostic build: wall-clock marks per block of the pipelined launch -- slots 0 entry, 1 end of the wait for the nodes, 2 exit, 3 interval (1000: a nodes block, whose slots 4..7 are: trajectory staged, measured state seeded, node 1, node 3) -- read by pg_debug_pipeline_timeline)
+__device__ unsigned long long g_nl_timeline[8 * 8192];
+#define PG_NL_MARK(slot, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_nl_timeline[8 * blockIdx.x + (slot)] = (v); } while (0)
+#else
+#define PG_NL_MARK(slot, v) do { } while (0)
+#endif
 // the two searched channels (t, s) of the shared trajectory into LDS.  Eight strides per trip, every load of a trip issued before the first store: rolled one stride per
 // trip, each of the 16 trips at L = 1000 was a round trip to the L2 -- and this copy is the first thing on the serial chain of the seeding recurrence.
 PG_DEV void stage_trajectory(const TrajView& T, real* __restrict__ sh) {
@@ -283,6 +289,7 @@ template <bool STAGED, bool PUB> PG_DEV void nodes_body(const DevCfg& C, int B, 
         __syncthreads();
         T.t = sh_traj; T.s = sh_traj + T.L;
     }
+    if constexpr (PUB) PG_NL_MARK(4, wall_clock64());
     const int b = blk * NODES_IPB + (int)threadIdx.x / NODES_LPN, lp = (int)threadIdx.x % NODES_LPN;      // lp: this lane's place among the lanes of its instance
     if (b >= B) return;
     const bool lead = lp == 0;                            // (the lane that writes what all lanes of the instance compute alike)
@@ -333,6 +340,7 @@ template <bool STAGED, bool PUB> PG_DEV void nodes_body(const DevCfg& C, int B, 
     // i == 1 of the reference loop: acceleration from the full nonlinear model (:117-119); its node record is already written above
     real s = s0, d1 = d0, Fx1 = real(0.0);
     advance_vs(V, s, ms.A1, DT[0]);
+    if constexpr (PUB) PG_NL_MARK(5, wall_clock64());
     const bool ahead = NODES_LPN > 1 && C.Ns + 1 < C.NN;     // the long nodes NODES_LPN at a time (below); the loop here then ends with the short horizon
     const int i_serial_end = ahead ? C.Ns + 1 : C.NN;
 #pragma unroll 1
@@ -355,6 +363,7 @@ template <bool STAGED, bool PUB> PG_DEV void nodes_body(const DevCfg& C, int B, 
             ax[0] = est.ang_y; ax[1] = est.ang_x; ax[2] = est.ang_t; ax[3] = (!shortp && est.beta_is_tan) ? est.tb : NAN;      // (NaN: q4 stands as written)
         }
         if (i == 1) { d1 = atan2(est.ang_y, est.ang_x) - atan(est.ang_t); Fx1 = est.Fx; }          // (the launch-order hint needs this one angle now)
+        if constexpr (PUB) { if (i == 1) PG_NL_MARK(6, wall_clock64()); if (i == 3) PG_NL_MARK(7, wall_clock64()); }
         if constexpr (PUB) {
             if (publish && ((pub_mask >> i) & 1ull)) {                 // nodes 0..i of all 64 instances are in memory: release, then the count
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // (a RELEASE: write-back only -- __threadfence() also invalidates this wavefront's caches, which hold the trajectory it keeps searching)
@@ -742,12 +751,6 @@ __global__ __launch_bounds__(64, PG_LIN_WAVES) void k_linearize(DevCfg C, int B,
 //    writes the dirty lines of the XCD's L2 back -- including the QP data the linearisation wavefronts of that XCD are in the middle of writing -- so the recurrence
 //    publishes after a few chosen nodes (`pub_mask`), not after every node: measured, B = 16384: 1.595 ms with 30 publications per wavefront, 1.434 with 6 (two launches:
 //    1.45); fp32 at 8192: 0.572 / 0.483 (0.555); B = 4096: 0.41 / 0.40 (0.53).
-#ifdef PG_TIMELINE        // (diagnostic build: wall-clock marks per block of the pipelined launch -- entry, end of the wait for the nodes, exit, interval -- read by pg_debug_pipeline_timeline)
-__device__ unsigned long long g_nl_timeline[4 * 8192];
-#define PG_NL_MARK(slot, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_nl_timeline[4 * blockIdx.x + (slot)] = (v); } while (0)
-#else
-#define PG_NL_MARK(slot, v) do { } while (0)
-#endif
 template <bool STAGED, int LPI> __global__ __launch_bounds__(64) void k_nodes_linearize(DevCfg C, int B, int nb_nodes, int nz_first, unsigned long long pub_mask, const real* __restrict__ state, const real* __restrict__ control,
                         const tdouble* __restrict__ toff, const int* __restrict__ solved, const real* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt,
                         const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* nodes, OrderOut F, real* naux, int* progress, const real* __restrict__ hji_Mb, real* __restrict__ qp, int* fault, int* fault_total) {

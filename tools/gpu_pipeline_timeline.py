@@ -14,12 +14,14 @@ state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345)
 for _ in range(3):
     m.reset(); m.set_inputs(state, control, t0, time_offset=toff); m.step_dev(); m.synchronize()
 nb = B // 32 + (B // 64) * m.N
-raw = np.zeros(4 * nb, dtype=np.uint64)
+raw = np.zeros(8 * nb, dtype=np.uint64)
 rc = m.lib.pg_debug_pipeline_timeline(m.h, raw.ctypes.data_as(C.c_void_p), C.c_int(nb)); assert rc == 0
-tl = raw.reshape(nb, 4); t0_ = tl[:, 0].min()
+tl = raw.reshape(nb, 8); t0_ = tl[:, 0].min()
 ent = (tl[:, 0] - t0_) / 100.0; rdy = (np.maximum(tl[:, 1], tl[:, 0]) - t0_) / 100.0; ext = (tl[:, 2] - t0_) / 100.0; kind = tl[:, 3].astype(int)
 nodes = kind == 1000
 print(f"launch {ext.max():.1f} us; nodes blocks {int(nodes.sum())}: exit mean {ext[nodes].mean():.1f} max {ext[nodes].max():.1f}")
+mk = (tl[nodes, 4:8].astype(float) - float(t0_)) / 100.0
+print(f"  recurrence, mean over its blocks: trajectory staged {mk[:, 0].mean():.1f} us, measured state seeded {mk[:, 1].mean():.1f}, node 1 done {mk[:, 2].mean():.1f}, node 3 done {mk[:, 3].mean():.1f}")
 print("interval: blocks, entry (mean), waited (mean / max), computed (mean), exit (mean / max)")
 for t in sorted(set(kind[~nodes])):
     k = kind == t
