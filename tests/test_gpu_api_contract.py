@@ -162,3 +162,23 @@ def test_closed_loop_on_the_device_is_reproducible_bit_for_bit(pkg, path):
     for a, b in zip(runs[0], runs[1]):
         assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
     assert runs[0][8] == 30
+
+
+def test_launch_shape_options_change_no_result(pkg, skidpad):
+    """The options that only shape the pipelined nodes + update_QP launch -- which short-horizon intervals go first (`pipe_first`), after which nodes the recurrence publishes its
+    progress (`pipe_pub_short`, `pipe_pub_long`) -- move wavefronts in time, nothing else: nodes, QP data, controls and statuses of a cold 2400-instance step (the pipelined
+    launch serves it: the counter says so) are the same bits under every setting."""
+    B = 2400
+    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B, seed=77)
+    ref = None
+    for opts in ({}, {"pipe_first": 3}, {"pipe_pub_short": 1, "pipe_pub_long": 1}, {"pipe_pub_short": 5, "pipe_pub_long": 9, "pipe_first": 7}):
+        m = pkg.BatchedTrajectoryTrackingMPC(skidpad, B, options=opts)
+        u, st, it = m.step_(state, control, t0, time_offset=toff)
+        assert m.get_option("stat_pipelined_launches") == 1
+        got = (u, st, it, m.qp_data(), m.nodes()[0], m.nodes()[1])
+        if ref is None:
+            ref = got
+        else:
+            for a, b in zip(ref, got):
+                assert np.array_equal(a, b, equal_nan=True), opts
+        m.close()
