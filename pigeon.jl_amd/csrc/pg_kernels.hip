@@ -701,8 +701,13 @@ PG_DEV void linearize_pair(const DevCfg& C, int b, int t, int g, bool live, cons
 //     update_QP! of 4096 instances 0.343 -> 0.251 ms, the same bits (EXPERIMENTS.md 10.4 -- the paper argument against it, "two AGPR moves per access", was wrong).
 //     fp32: 0.281 -> 0.160 ms.
 //   2: the lane pair of rounds 1-3 (three / four directions per lane); batches of <= 1024 instances, where every pair is resident at once and the pair is the shorter chain.
+#ifdef PG_F32
+#define PG_SPLIT_WAVES 2        // fp32: the one-lane linearisation is 20 registers over two waves per SIMD; held to 256
+#else
+#define PG_SPLIT_WAVES 1
+#endif
 template <int LPI>
-__global__ __launch_bounds__(64) void k_linearize_split(DevCfg C, int B, int nb_zoh, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb,
+__global__ __launch_bounds__(64, PG_SPLIT_WAVES) void k_linearize_split(DevCfg C, int B, int nb_zoh, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb,
                                                         real* __restrict__ qp, const int* __restrict__ only_if = nullptr, int nb_total = 0) {
     if (only_if && *only_if == 0) return;                         // (repair launch behind k_nodes_linearize, see there)
     // (block-stride over the nb_total blocks of work when launched as a small repair grid; the ordinary launch -- nb_total = 0 -- has one block per block of work)
