@@ -710,6 +710,9 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
             const int nbn = (B + NODES_IPB - 1) / NODES_IPB, nbt = (B + ipb - 1) / ipb;
             const size_t lds = traj_lds > 64 * 20 * sizeof(real) ? traj_lds : 64 * 20 * sizeof(real);
             auto kern = lpi == 1 ? (staged ? k_nodes_linearize<true, 1> : k_nodes_linearize<false, 1>) : (staged ? k_nodes_linearize<true, 2> : k_nodes_linearize<false, 2>);
+#ifdef PG_F32
+            if (lpi == 1 && B >= 6144) kern = staged ? k_nodes_linearize<true, 1, 2> : k_nodes_linearize<false, 1, 2>;      // (two waves per SIMD once the linearisation is more than one round of them)
+#endif
             int nzf = (1024 - nbn + nbt - 1) / nbt;               // short-horizon intervals that go first: one wavefront for every SIMD the recurrence leaves free
             if (h->pipe_first > 0) nzf = h->pipe_first;
             if (nzf > h->dc.Ns) nzf = h->dc.Ns;

@@ -694,6 +694,11 @@ PG_DEV void linearize_pair(const DevCfg& C, int b, int t, int g, bool live, cons
                            real* __restrict__ qp) {
     linearize_lanes<4>(C, b, t, g, live, nodes, dt, hji_Mb, qp);
 }
+#ifdef PG_F32
+#define PG_SPLIT_WAVES 2        // fp32: the one-lane linearisation is 20 registers over two waves per SIMD; held to 256
+#else
+#define PG_SPLIT_WAVES 1
+#endif
 // the large-batch form: the Ns zero-order-hold intervals of every instance with six directions (ND = 6), the N - Ns ramp intervals with eight (ND = 8);
 // blocks [0, nb_zoh) take the first group -- a wavefront runs one of the two instruction streams.  LPI = lanes per (instance, interval):
 //   1 (round 4): ONE lane carries all the directions.  The scalar part of a lane (value, local Jacobian, RK4 of the state) costs as much as six directions, and a
@@ -701,11 +706,6 @@ PG_DEV void linearize_pair(const DevCfg& C, int b, int t, int g, bool live, cons
 //     update_QP! of 4096 instances 0.343 -> 0.251 ms, the same bits (EXPERIMENTS.md 10.4 -- the paper argument against it, "two AGPR moves per access", was wrong).
 //     fp32: 0.281 -> 0.160 ms.
 //   2: the lane pair of rounds 1-3 (three / four directions per lane); batches of <= 1024 instances, where every pair is resident at once and the pair is the shorter chain.
-#ifdef PG_F32
-#define PG_SPLIT_WAVES 2        // fp32: the one-lane linearisation is 20 registers over two waves per SIMD; held to 256
-#else
-#define PG_SPLIT_WAVES 1
-#endif
 template <int LPI>
 __global__ __launch_bounds__(64, PG_SPLIT_WAVES) void k_linearize_split(DevCfg C, int B, int nb_zoh, const real* __restrict__ nodes, const tdouble* __restrict__ dt, const real* __restrict__ hji_Mb,
                                                         real* __restrict__ qp, const int* __restrict__ only_if = nullptr, int nb_total = 0) {
@@ -756,7 +756,9 @@ __global__ __launch_bounds__(64, PG_LIN_WAVES) void k_linearize(DevCfg C, int B,
 //    writes the dirty lines of the XCD's L2 back -- including the QP data the linearisation wavefronts of that XCD are in the middle of writing -- so the recurrence
 //    publishes after a few chosen nodes (`pub_mask`), not after every node: measured, B = 16384: 1.595 ms with 30 publications per wavefront, 1.434 with 6 (two launches:
 //    1.45); fp32 at 8192: 0.572 / 0.483 (0.555); B = 4096: 0.41 / 0.40 (0.53).
-template <bool STAGED, int LPI> __global__ __launch_bounds__(64) void k_nodes_linearize(DevCfg C, int B, int nb_nodes, int nz_first, unsigned long long pub_mask, const real* __restrict__ state, const real* __restrict__ control,
+// WAVES (fp32 only): 2 = held to two waves per SIMD.  The fp32 kernel sits within a register or two of 256 and falls to one wave with any small change; with two, 8192
+// instances per GPU run 0.342 against 0.383 ms, 4096 -- one round of wavefronts either way, each slower next to a neighbour -- 0.258 against 0.249: the host picks by batch size.
+template <bool STAGED, int LPI, int WAVES = 1> __global__ __launch_bounds__(64, WAVES) void k_nodes_linearize(DevCfg C, int B, int nb_nodes, int nz_first, unsigned long long pub_mask, const real* __restrict__ state, const real* __restrict__ control,
                         const tdouble* __restrict__ toff, const int* __restrict__ solved, const real* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt,
                         const tdouble* __restrict__ prev_ts, const real* __restrict__ prev_x, real* nodes, OrderOut F, real* naux, int* progress, const real* __restrict__ hji_Mb, real* __restrict__ qp, int* fault, int* fault_total) {
     PG_NL_MARK(0, wall_clock64());
