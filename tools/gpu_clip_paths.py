@@ -1,4 +1,4 @@
-"""Robustness of the clipped working-set guess (PG_CLIP_GUESS) across the reference's test paths: cold step of 4096 instances per path, with and without it --
+"""Robustness of the clipped working-set guess (option "clip_guess") across the reference's test paths: cold step of 4096 instances per path, with and without it --
 instances that end in the interior point, active-set rounds per instance, solve-phase time.  Usage (GPU box): python tools/gpu_clip_paths.py"""
 import os, sys
 import numpy as np
@@ -14,8 +14,7 @@ for name in sorted(f[:-4] for f in os.listdir(root) if f.endswith(".npz")):
     state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=4242, **kw)
     res = {}
     for clip in ("0", "1"):
-        os.environ["PG_CLIP_GUESS"] = clip
-        m = pkg.BatchedTrajectoryTrackingMPC(traj, B)
+        m = pkg.BatchedTrajectoryTrackingMPC(traj, B, options={"clip_guess": float(clip)})
         ms = []
         for _ in range(4):
             m.reset(); m.set_inputs(state, control, t0, time_offset=toff); m.step_dev(); m.synchronize(); ms.append(m.phase_ms())

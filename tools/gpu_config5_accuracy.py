@@ -12,11 +12,14 @@ from oracle import oracle as om
 walls = len(sys.argv) > 1 and sys.argv[1] == "1"
 polish = None if len(sys.argv) <= 2 else sys.argv[2] == "1"
 pkg = load_pkg(); om.build()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _legacy_env import options_from_env, precision_for      # (the PG_* variables of this tool's usage line become pg_set_option names: the library reads no environment)
+OPTS = options_from_env()
 traj = pkg.load_path_fixture("skidpadoval")
 B, Ns, Nl = 4096, 10, 40
 rho = float(os.environ['PG_RHO']) if 'PG_RHO' in os.environ else None          # PG_RHO: polish penalty (default: the library's)
 prec = os.environ.get('PG_PREC', 'f64')                                         # PG_PREC=f32: the fp32 library against the oracle's exact optimum of ITS OWN (fp32-rounded) QP data
-mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=Ns, N_long=Nl, walls=walls, polish=polish, polish_rho=rho, precision=prec, polish_ipm_tol=float(os.environ['PG_PIT']) if 'PG_PIT' in os.environ else None)
+mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=Ns, N_long=Nl, walls=walls, polish=polish, polish_rho=rho, precision=prec, options=OPTS, polish_ipm_tol=float(os.environ['PG_PIT']) if 'PG_PIT' in os.environ else None)
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B)
 if prec == 'f32': state, control = state.astype(np.float32).astype(np.float64), control.astype(np.float32).astype(np.float64)
 u, status, iters = mpc.step_(state, control, t0, time_offset=toff)

@@ -1,4 +1,4 @@
-"""k_solve_lat (the lateral formulation's own solve kernel) against the embedding in k_solve (PG_SOLVE_LAT=0) on the same batches: status, iterations, applied steering,
+"""k_solve_lat (the lateral formulation's own solve kernel) against the embedding in k_solve (option "lateral_solver" = 2) on the same batches: status, iterations, applied steering,
 whole solution, solve-phase time.  Usage (GPU box): python tools/gpu_lat_check.py [B]"""
 import os, sys, time
 import numpy as np
@@ -11,8 +11,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 
 
 def run(Ns, Nl, walls, lat, reps=5, polish=None):
-    os.environ["PG_SOLVE_LAT"] = "1" if lat else "0"
-    mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=Ns, N_long=Nl, walls=walls, polish=polish)
+    mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=Ns, N_long=Nl, walls=walls, polish=polish, options={"lateral_solver": 1.0 if lat else 2.0})
     state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B)
     u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
     ms = []

@@ -7,12 +7,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_pkg
 pkg = load_pkg()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _legacy_env import options_from_env, precision_for      # (the PG_* variables of this tool's usage line become pg_set_option names: the library reads no environment)
+OPTS = options_from_env()
 traj = pkg.load_path_fixture("skidpadoval")
 walls = len(sys.argv) > 1 and sys.argv[1] == "1"
 Nl = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 B = 4096
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B)
-mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=Nl, walls=walls)
+mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=Nl, walls=walls, options=OPTS)
 ms = []
 for _ in range(5):
     mpc.reset(); mpc.set_inputs(state, control, t0, time_offset=toff); mpc.step_dev(); mpc.synchronize(); ms.append(mpc.phase_ms()[2])

@@ -6,10 +6,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_pkg
 pkg = load_pkg()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _legacy_env import options_from_env, precision_for      # (the PG_* variables of this tool's usage line become pg_set_option names: the library reads no environment)
+OPTS = options_from_env()
 traj = pkg.load_path_fixture("skidpadoval")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 for walls in (False, True):
-    mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, walls=walls)
+    mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, walls=walls, options=OPTS)
     state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B)
     mpc.step_(state, control, t0, time_offset=toff)
     ms = []

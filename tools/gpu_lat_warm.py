@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_pkg
 pkg = load_pkg()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _legacy_env import options_from_env, precision_for      # (the PG_* variables of this tool's usage line become pg_set_option names: the library reads no environment)
+OPTS = options_from_env()
 traj = pkg.load_path_fixture(os.environ.get("PG_PATH", "skidpadoval"))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
@@ -15,7 +18,7 @@ walls = bool(int(sys.argv[4])) if len(sys.argv) > 4 else False
 Ns = 10
 
 rho = float(os.environ["PG_RHO"]) if "PG_RHO" in os.environ else None
-warm = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=Ns, N_long=Nl, walls=walls, polish_rho=rho)
+warm = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=Ns, N_long=Nl, walls=walls, polish_rho=rho, options=OPTS)
 cold = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=Ns, N_long=Nl, walls=walls, warm_polish=False)
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B)
 q, u, t = state.copy(), control.copy(), t0.copy()

@@ -6,10 +6,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from __graft_entry__ import _load_pkg
 pkg = _load_pkg()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _legacy_env import options_from_env, precision_for      # (the PG_* variables of this tool's usage line become pg_set_option names: the library reads no environment)
+OPTS = options_from_env()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 traj = pkg.load_path_fixture("skidpadoval")
 prec = os.environ.get("PREC", "f64")
-mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, precision=prec)
+mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, precision=precision_for(OPTS, prec), options=OPTS)      # (PG_LIN_G -> "diag_lin_groups": fp64 diagnostic library)
 mpc.set_stream(torch.cuda.current_stream().cuda_stream)
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345, traj_mode=True)
 mpc.set_inputs(state, control, t0, time_offset=toff)
