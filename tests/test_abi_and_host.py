@@ -207,3 +207,15 @@ def test_design_md_numbers_are_the_generated_ones():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "doc_numbers.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_tools_option_names_exist_in_the_header():
+    """tools/_legacy_env.py turns the PG_* variables the older diagnostic tools document into pg_set_option names: every name it produces must be one the header lists
+    (the diag_* ones in its paragraph on the diagnostic build)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_legacy_env", os.path.join(ROOT, "tools", "_legacy_env.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    header = open(os.path.join(ROOT, "include", "pigeon_mpc.h")).read()
+    listed = set(re.findall(r'"([a-z0-9_]+)"', header))
+    missing = sorted(n for n in set(mod._MAP.values()) | {"lateral_solver"} if n not in listed)
+    assert not missing, missing
