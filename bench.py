@@ -748,7 +748,7 @@ def main():
         # BASELINE config 5 in fp32 (SURVEY 8d lists it in both precisions): the same lateral batch through libpigeon_hip_f32.so, cold
         if dec is not None:
             def run_dec32(walls):
-                md = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, device=local, precision="f32", walls=walls, phase_timing=False)
+                md = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, device=local, precision="f32", walls=walls, phase_timing=False, allow_f32_long_lateral=True)
                 md.set_stream(torch.cuda.current_stream().cuda_stream)
                 md.set_inputs_dev(B, s32.data_ptr(), c32.data_ptr(), d_t0.data_ptr(), None, d_toff.data_ptr())
                 for _ in range(2):

@@ -96,7 +96,10 @@ typedef struct pg_config {
                                      * TrajectoryTube, src/trajectories.jl:19-20,33, but no constraint reads them, README.md:54): 1 adds to the DECOUPLED
                                      * formulation, at nodes t = 2..N+1, the rows  e_t <= edge_L(s_t) + sw_t,  e_t >= edge_R(s_t) - sw_t,  sw_t >= 0  and the
                                      * cost  wall_weight * dt_t * sw_t  (soft, like the stability-envelope rows of :193-211); 0 (default) = the reference's QP */
-    int32_t _pad2;
+    int32_t allow_f32_long_lateral; /* (occupies what was explicit padding up to round 5: the layout is unchanged, pg_default_config* zero it)  The fp32 library REFUSES the decoupled
+                                     * formulation with more than 32 intervals at pg_create unless this is 1: single precision on the open-loop unstable 8 s lateral horizon solves
+                                     * 99.7 % of the N = 50 benchmark batch with the applied steering up to 6e-3 rad off the exact optimum -- fp64 is the precision
+                                     * for that configuration, and a caller has to ask for the other one explicitly.  Ignored by the fp64 library */
     double wall_weight;             /* linear penalty on the wall slack per second (default 1000) */
     int32_t polish;                 /* 1 (default, both formulations): after the interior point has converged, an active-set polish (OSQP's `polish`, off in the reference's settings,
                                      * src/coupled_lat_long.jl:201-203) solves the equality-constrained problem on the detected active set with the same Riccati passes
@@ -264,7 +267,9 @@ int pg_synchronize(pg_handle* h);
  *     "lat_rho_scale" (1e3 in fp64, 1 in fp32)  penalty of held rows = polish_rho x this;   "lat_mu0_cost" (10), "lat_far_cost" (3e4), "lat_polish2" 0/1 (1),
  *     "lat_polish_rounds" (3), "lat_settle" 0..2 (0), "lat_warm_rounds" (2), "lat_wipm" 0/1 (0), "lat_wmu" (1e-2), "lat_wtau" (1e-4)   see pg_solve_lat.hip
  *   read-only (pg_get_option): "stat_pipelined_launches", "stat_split_solve_launches", "stat_single_solve_launches", "stat_lat_two_launch_solves" -- how many launches of
- *     this handle took the path named (tests assert that the path they mean to cover is the one that ran); "lateral_solver_in_use" (1 = k_solve_lat, 2 = embedding).
+ *     this handle took the path named (tests assert that the path they mean to cover is the one that ran); "stat_whole_batch_solves" -- counted ON THE DEVICE: launches in
+ *     which the full k_solve took the whole batch because the previous launch had left instances for the interior point (reading it drains the stream);
+ *     "lateral_solver_in_use" (1 = k_solve_lat, 2 = embedding).
  * The diagnostic build (libpigeon_hip_diag.so, -DPG_DIAG; never shipped) adds "diag_pipe_fault" (fault injection for the pipelined launch), "diag_instance",
  * "diag_lin_groups", "diag_timeline". */
 int pg_set_option(pg_handle* h, const char* name, double value);

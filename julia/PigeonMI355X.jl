@@ -55,7 +55,7 @@ struct PgConfig
     ipm_tol::Float64
     ipm_mu0::Float64
     walls::Int32                # build-defined soft wall rows (decoupled only)
-    _pad2::Int32
+    allow_f32_long_lateral::Int32   # fp32 library only: 1 = accept the decoupled formulation beyond 32 intervals (refused otherwise: steering up to 6e-3 rad off at N = 50)
     wall_weight::Float64
     polish::Int32               # active-set polish after the interior point
     _pad3::Int32
@@ -126,7 +126,8 @@ end
 edge_R - sw <= e <= edge_L + sw from the tube's edge channels (the reference snapshot carries the edges but no constraint reads them, README.md:54)."
 function BatchedDecoupledTrajectoryTrackingMPC(vehicle::Dict{Symbol,Float64}, trajectory::TrajectoryTube{Float64}, B::Integer;
                                                control_params=Pigeon.DecoupledControlParams(), N_short=10, N_long=20, dt_short=0.01, dt_long=0.2,
-                                               use_correction_step=true, device=0, precision::Symbol=:f64, walls=false, wall_weight=1000.0, polish=nothing, warm_polish=nothing)
+                                               use_correction_step=true, device=0, precision::Symbol=:f64, walls=false, wall_weight=1000.0, polish=nothing, warm_polish=nothing,
+                                               allow_f32_long_lateral=false)
     L = lib(precision)
     cfg = Ref{PgConfig}()
     ccall(Libdl.dlsym(L, :pg_default_config_decoupled), Cint, (Ref{PgConfig},), cfg)
@@ -134,7 +135,7 @@ function BatchedDecoupledTrajectoryTrackingMPC(vehicle::Dict{Symbol,Float64}, tr
     U = control_params                                # the lateral formulation has no Q_Δs / R_Fx / R_ΔFx / W_HJI / N_HJI: those slots keep the library's defaults
     cp = PgControlParams(U.V_min, U.V_max, U.k_V, U.k_s, U.δ̇_max, d.Q_ds, U.Q_Δψ, U.Q_e, U.W_β, U.W_r, d.W_HJI, U.R_δ, U.R_Δδ, d.R_Fx, d.R_dFx, d.N_HJI, 0)
     _create(PgConfig(_vehicle(vehicle), cp, N_short, N_long, dt_short, dt_long, use_correction_step, c.rk4_substeps, c.hji_eps, B, device,
-                     c.ipm_max_iter, 1, c.ipm_tol, c.ipm_mu0, walls, 0, wall_weight, polish === nothing ? c.polish : Int32(polish), 0, c.polish_rho, c.polish_tol, c.polish_ipm_tol,
+                     c.ipm_max_iter, 1, c.ipm_tol, c.ipm_mu0, walls, Int32(allow_f32_long_lateral), wall_weight, polish === nothing ? c.polish : Int32(polish), 0, c.polish_rho, c.polish_tol, c.polish_ipm_tol,
                      warm_polish === nothing ? c.warm_polish : Int32(warm_polish), c.cold_guess), L, trajectory, B)
 end
 
@@ -240,6 +241,15 @@ function pipeline_fallbacks(mpc::BatchedTrajectoryTrackingMPC)
     n = Ref{Int64}(0)
     check(mpc, ccall(sym(mpc, :pg_get_pipeline_fallbacks), Cint, (Ptr{Cvoid}, Ptr{Int64}), mpc.handle, n), "pg_get_pipeline_fallbacks")
     n[]
+end
+
+"milliseconds of the last `pg_step_dev` per phase -- (time grid + nodes, update_QP!, solve! + get_next_control) -- the figure `ros_integration.jl:94-109` logs as one number.
+The HIP events behind it are OFF by default (four event records cost 13-25 us of stream time per step): call `set_option!(mpc, \"phase_timing\", 1)` first, otherwise
+pg_get_phase_ms returns PG_ERR_STATE and its message says that the option is off (pg_get_phase_ms)"
+function phase_ms(mpc::BatchedTrajectoryTrackingMPC)
+    out = Vector{Float32}(undef, 3)
+    check(mpc, ccall(sym(mpc, :pg_get_phase_ms), Cint, (Ptr{Cvoid}, Ptr{Float32}), mpc.handle, out), "pg_get_phase_ms")
+    out
 end
 
 # per-instance solver status words (include/pigeon_mpc.h: pg_solve_status).  With the polish on, PG_SOLVED is a VERIFIED KKT point of the QP; PG_SOLVED_UNVERIFIED is the

@@ -27,7 +27,7 @@ class pg_config(C.Structure):
     _fields_ = [("vehicle", pg_vehicle), ("control", pg_control_params), ("N_short", C.c_int32), ("N_long", C.c_int32), ("dt_short", C.c_double),
                 ("dt_long", C.c_double), ("use_correction_step", C.c_int32), ("rk4_substeps", C.c_int32), ("hji_eps", C.c_double),
                 ("batch_capacity", C.c_int32), ("device", C.c_int32), ("ipm_max_iter", C.c_int32), ("formulation", C.c_int32), ("ipm_tol", C.c_double),
-                ("ipm_mu0", C.c_double), ("walls", C.c_int32), ("_pad2", C.c_int32), ("wall_weight", C.c_double),
+                ("ipm_mu0", C.c_double), ("walls", C.c_int32), ("allow_f32_long_lateral", C.c_int32), ("wall_weight", C.c_double),
                 ("polish", C.c_int32), ("_pad3", C.c_int32), ("polish_rho", C.c_double), ("polish_tol", C.c_double), ("polish_ipm_tol", C.c_double),
                 ("warm_polish", C.c_int32), ("cold_guess", C.c_int32)]
 

@@ -74,6 +74,7 @@ struct pg_handle {
     char* h_stage = nullptr; size_t stage_bytes = 0;            // pinned host staging of pg_set_inputs / pg_step (one stream synchronisation per call instead of one per array)
     real* d_ws4 = nullptr; bool solve_quad = false; size_t solve4_lds = 0;   // k_solve4 (four instances per wavefront)
     bool qp_embedded = true; int lat_pack_only = 1;            // lateral formulation: the embedded QP block is current (k_qp_dec wrote it) / option "lat_pack_only": steps write the packed records only
+    bool qp_stale = false;                                    // the lateral solver was switched (option "lateral_solver") after the last update_QP!: pg_solve returns PG_ERR_STATE until the QP data are rebuilt
     bool solve_lat = false; size_t lat_lds = 0;               // lateral formulation: its own kernel k_solve_lat (option "lateral_solver" = 2 keeps the embedding in k_solve)
 };
 
@@ -222,6 +223,13 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     if (cfg->N_short < 1 || cfg->N_long < 0 || cfg->N_short + cfg->N_long + 1 > 64 || cfg->batch_capacity < 1 || cfg->rk4_substeps < 1) {
         g_create_error = "invalid horizon / capacity (need 1 <= N_short, N_short+N_long+1 <= 64)"; return PG_ERR_INVALID;
     }
+#ifdef PG_F32
+    if (cfg->formulation == PG_DECOUPLED && cfg->N_short + cfg->N_long > 32 && cfg->allow_f32_long_lateral != 1) {
+        g_create_error = "the fp32 library refuses the decoupled formulation beyond 32 intervals (applied steering up to 6e-3 rad off on the N = 50 benchmark batch: use libpigeon_hip.so, "
+                         "or set pg_config.allow_f32_long_lateral = 1 to run it anyway)";
+        return PG_ERR_INVALID;
+    }
+#endif
     if (hipSetDevice(cfg->device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return PG_ERR_HIP; }
     pg_handle* h = new pg_handle();
     h->cfg = *cfg;
@@ -312,8 +320,10 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         (void)hipFuncSetAttribute((const void*)k_solve<false, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
         (void)hipFuncSetAttribute((const void*)k_solve<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
         (void)hipFuncSetAttribute((const void*)k_solve<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+#ifdef PG_DIAG      // (the PROF instantiations exist in the diagnostic library only: pg_debug_solve_cycles)
         (void)hipFuncSetAttribute((const void*)k_solve<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
         (void)hipFuncSetAttribute((const void*)k_solve<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+#endif
     }
     h->lat_lds = lat_lds_doubles(N) * sizeof(real);
     // (N + 1 <= 64 nodes: at most 4 x 63 x 24 doubles + 72 = 48,960 B, below the 64 KB a launch may ask for without raising the function attribute)
@@ -420,10 +430,18 @@ int pg_set_option(pg_handle* h, const char* name, double value) {
         const bool which_solver = strcmp(name, "lateral_solver") == 0;
         REQUIRE(h, value == 0.0 || value == 1.0 || (value == 2.0 && which_solver), "pg_set_option: value out of range");
         HIPCHK(h, hipSetDevice(h->cfg.device)); HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (which_solver) h->lateral_solver = (int)value; else h->lat_mem_forced = value != 0.0;
+        // (validated BEFORE anything changes, and a configure_lateral that fails -- an allocation -- leaves the handle as it was: ADVICE r5)
         if (which_solver && value == 1.0 && lat_lds_doubles(h->dc.N) * sizeof(real) > 64 * 1024) { h->err = "horizon too long for k_solve_lat's LDS staging"; return PG_ERR_INVALID; }
+        const int old_solver = h->lateral_solver; const bool old_forced = h->lat_mem_forced, old_lat = h->solve_lat;
+        if (which_solver) h->lateral_solver = (int)value; else h->lat_mem_forced = value != 0.0;
         std::string why;
-        if (configure_lateral(h, &why) != PG_OK) { h->err = why; return PG_ERR_HIP; }
+        if (configure_lateral(h, &why) != PG_OK) {
+            h->lateral_solver = old_solver; h->lat_mem_forced = old_forced; std::string why2; (void)configure_lateral(h, &why2);
+            h->err = why; return PG_ERR_HIP;
+        }
+        // the two solve kernels read different QP records (k_solve: the embedded block, k_solve_lat: the packed stage records) and the last update_QP! wrote what the OLD
+        // choice needed: pg_solve refuses until pg_update_qp (or a whole-batch pg_set_qp) has run again
+        if (h->solve_lat != old_lat) h->qp_stale = true;
         return PG_OK;
     }
     OptRef o;
@@ -440,6 +458,11 @@ int pg_get_option(pg_handle* h, const char* name, double* value) {
     if (strcmp(name, "diag_pipe_fault") == 0) { *value = h->pipe_fault ? 1.0 : 0.0; return PG_OK; }
 #endif
     if (strcmp(name, "lat_workspace") == 0) { *value = h->lat_mem ? 1.0 : 0.0; return PG_OK; }
+    if (strcmp(name, "stat_whole_batch_solves") == 0) {      // counted ON THE DEVICE by the full k_solve whenever it takes the whole batch (SolveOut::mode): drains the stream
+        HIPCHK(h, hipSetDevice(h->cfg.device)); HIPCHK(h, hipStreamSynchronize(h->stream));
+        int v = 0; HIPCHK(h, hipMemcpy(&v, h->d_todo + (size_t)h->cfg.batch_capacity + 5, sizeof(int), hipMemcpyDeviceToHost));
+        *value = (double)v; return PG_OK;
+    }
     if (strcmp(name, "lateral_solver_in_use") == 0) { *value = h->solve_lat ? 1.0 : (h->cfg.formulation == PG_DECOUPLED ? 2.0 : 0.0); return PG_OK; }
     OptRef o;
     if (!find_option(h, name, &o)) { h->err = std::string("pg_get_option: unknown option '") + name + "'"; return PG_ERR_INVALID; }
@@ -830,7 +853,7 @@ int pg_update_qp(pg_handle* h) {
         const int embed = (h->solve_lat && h->lat_pack_only) ? 0 : 1;
         hipLaunchKernelGGL(k_qp_dec, dim3((unsigned)((nt + 127) / 128)), dim3(128), 0, h->stream, h->dc, B, h->d_nodes, h->d_dt, h->d_qp, embed);
         LAUNCH_CHECK(h);
-        h->qp_embedded = embed != 0;
+        h->qp_embedded = embed != 0; h->qp_stale = false;
         return PG_OK;
     }
     if ((rc = launch_hji_rows(h))) return rc;
@@ -884,7 +907,7 @@ static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, u
         int* const ctl = h->d_todo + cap; int* const cnt = ctl + h->solve_parity; const int* const prev = ctl + (h->solve_parity ^ 1);
         if (!h->cnt_cleared) HIPCHK(h, hipMemsetAsync(cnt, 0, sizeof(int), st));
         h->cnt_cleared = false; h->solve_parity ^= 1; h->stat_split++;
-        O.todo = h->d_todo; O.n_todo = cnt; O.mode = prev;
+        O.todo = h->d_todo; O.n_todo = cnt; O.mode = prev; O.n_whole = ctl + 5;
         hipLaunchKernelGGL((k_solve<false, false, false, false>), dim3(n), dim3(64), h->solve_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, (unsigned long long*)nullptr, h->d_dt, h->d_Mb);
         LAUNCH_CHECK(h);
         SolveOut O2 = O; O2.todo = nullptr; O2.list = h->d_todo; O2.n_list = cnt;      // (order_in stays: the whole-batch mode uses the launch order)
@@ -899,6 +922,7 @@ static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, u
 }
 int pg_solve(pg_handle* h) {
     int rc = check_ready(h); if (rc) return rc;
+    if (h->qp_stale) { h->err = "pg_solve: the lateral solver was switched (pg_set_option \"lateral_solver\") after the last update_QP!: call pg_update_qp first"; return PG_ERR_STATE; }
     // launch order: the one the nodes kernels of this step filed (likely slow instances first)
     const bool use_order = h->dc.polish && h->order_B == h->B;
     if ((rc = launch_solve(h, h->stream, use_order ? h->d_order : nullptr, h->B))) return rc;
@@ -940,8 +964,9 @@ static int update_and_solve(pg_handle* h, hipEvent_t after_update) {
     if (h->B > h->warm_B) h->warm_B = h->B;
     return PG_OK;
 }
-// debug (not part of the public header): per-phase shader-clock cycles of one solve launch, out [B][6] =
-// (stage assembly+step, sync, matrix pass, vector passes, forward passes, prologue); diagnostic build of the kernel, never timed
+#ifdef PG_DIAG
+// debug (-DPG_DIAG library only; not part of the public header, not in the shipped libraries -- nor are the PROF instantiations of k_solve it launches): per-phase shader-clock
+// cycles of one solve launch, out [B][6] = (stage assembly+step, sync, matrix pass, vector passes, forward passes, prologue); diagnostic build of the kernel, never timed
 int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     int rc = check_ready(h); if (rc) return rc;
     unsigned long long* d = nullptr;
@@ -967,6 +992,7 @@ int pg_debug_solve_cycles(pg_handle* h, unsigned long long* out) {
     (void)hipFree(d);
     return PG_OK;
 }
+#endif
 #ifdef PG_TIMELINE
 // debug (timeline build only, not part of the public header): per block of the last pipelined launch (entry, end of the wait, exit on the 100 MHz wall clock; interval, 1000 = a nodes block)
 extern "C" int pg_debug_pipeline_timeline(pg_handle* h, unsigned long long* out, int n_blocks) {
@@ -1052,7 +1078,10 @@ int pg_get_state(pg_handle* h, double* state, double* control, double* t0) {
 }
 int pg_get_phase_ms(pg_handle* h, float out3[3]) {
     if (!h || !out3) return PG_ERR_INVALID;
-    if (!h->timing_valid) { h->err = "no pg_step_dev recorded yet"; return PG_ERR_STATE; }
+    if (!h->timing_valid) {
+        h->err = h->phase_timing == 0 ? "phase timing is off (the default since round 5): pg_set_option(h, \"phase_timing\", 1), then pg_step_dev" : "no pg_step_dev recorded yet";
+        return PG_ERR_STATE;
+    }
     HIPCHK(h, hipEventSynchronize(h->ev[3]));
     for (int i = 0; i < 3; i++) HIPCHK(h, hipEventElapsedTime(&out3[i], h->ev[i], h->ev[i + 1]));
     return PG_OK;
@@ -1200,6 +1229,7 @@ int pg_set_qp(pg_handle* h, int32_t b0, int32_t n, const double* in) {
         hipLaunchKernelGGL(k_lat_pack, dim3((unsigned)((nt + 127) / 128)), dim3(128), 0, h->stream, h->dc, b0, n, h->d_qp);
         LAUNCH_CHECK(h);
     }
+    if (b0 == 0 && n == h->B) h->qp_stale = false;      // (both record forms of the whole batch are current now)
     return PG_OK;
 }
 int pg_get_solution(pg_handle* h, double* x, double* sigma) {

@@ -1330,7 +1330,8 @@ struct SolveOut { real* sol_x; real* sol_sigma; real* u_out; int* status; int* i
                   const int* list; const int* n_list;      // full k_solve in list mode: the instances to solve (interior point at once), and how many
                   const int* mode;                         // split launch of k_solve: the PREVIOUS launch's count of instances that needed the interior point (a stream-ordered device word).
                                                            // Non-zero: the rounds-only kernel returns at once and the full kernel takes the whole batch in its launch order instead of the list
-                  real* u_out2; };                         // pg_step_dev: the caller's control array, written next to u_out (saves the device-to-device copy behind the launch); may be nullptr
+                  real* u_out2;                            // pg_step_dev: the caller's control array, written next to u_out (saves the device-to-device copy behind the launch); may be nullptr
+                  int* n_whole; };                         // split launch: counts the launches in which the full kernel took the WHOLE batch (`mode` non-zero) -- read-only option "stat_whole_batch_solves"; may be nullptr
 
 #define NROW 16
 #define PG_POLISH_ROUNDS 6      // active-set rounds of the polish before it gives up
@@ -1416,6 +1417,7 @@ __global__ __launch_bounds__(64, PG_SOLVE_WAVES(RING, IPM)) void k_solve(DevCfg 
     const bool whole = O.mode && *O.mode != 0;                  // (wave-uniform: a scalar load)
     if constexpr (!IPM) { if (whole) return; }                 // the full kernel behind this launch serves the whole batch
     const bool listm = O.n_list && !whole;
+    if constexpr (IPM) { if (whole && O.n_whole && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(O.n_whole, 1); }      // (one word per launch: the test of the device-side switch reads it)
     if (listm && (int)blockIdx.x >= *O.n_list) return;         // list mode: nothing left for this block
     // (Round 5, measured and removed: a PERSISTENT grid -- one block per wavefront slot, further instances pulled from a counter -- to save the 4.4 us between the exit of a
     //  wavefront and the entry of the next one on its SIMD.  Same launch time with and without (0.319 / 0.319 ms at 4096 instances): the gap is the prologue's first round trip to

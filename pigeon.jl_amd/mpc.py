@@ -43,7 +43,7 @@ class BatchedTrajectoryTrackingMPC:
     def __init__(self, trajectory, batch_capacity, vehicle=None, control_params=None, N_short=10, N_long=20, dt_short=0.01, dt_long=0.2,
                  use_correction_step=True, rk4_substeps=10, device=0, ipm_max_iter=40, ipm_tol=None, ipm_mu0=100.0, hji_eps=0.05, formulation="coupled",
                  precision="f64", walls=False, wall_weight=1000.0, polish=None, polish_rho=None, polish_tol=None, polish_ipm_tol=None, warm_polish=None, cold_guess=None,
-                 options=None, phase_timing=True):
+                 options=None, phase_timing=True, allow_f32_long_lateral=False):
         """options: {name: value} of build-defined options applied right after pg_create (pg_set_option, include/pigeon_mpc.h); precision "f64-diag" loads the
         diagnostic build of the fp64 library (tests / tools only).  phase_timing: this mirror is the test / bench harness and switches the library's per-phase HIP events ON
         by default (phase_ms(); the library's own default is off -- 2-4 % of a step: bench.py times its loops with phase_timing=False)."""
@@ -82,6 +82,7 @@ class BatchedTrajectoryTrackingMPC:
         cfg.ipm_max_iter, cfg.ipm_tol, cfg.ipm_mu0, cfg.hji_eps = ipm_max_iter, ipm_tol, ipm_mu0, hji_eps
         cfg.walls = int(bool(walls))          # build-defined extension: soft rows edge_R - sw <= e <= edge_L + sw (decoupled formulation)
         cfg.wall_weight = float(wall_weight)
+        cfg.allow_f32_long_lateral = int(bool(allow_f32_long_lateral))      # (the fp32 library refuses the decoupled formulation beyond 32 intervals without it: pigeon_mpc.h)
         self.wall_weight = float(wall_weight)
         self.walls = bool(walls)
         self.cfg = cfg

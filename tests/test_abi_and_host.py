@@ -27,6 +27,22 @@ def test_library_exports_every_header_symbol(pkg, precision, bits):
     assert lib.pg_precision_bits() == bits
 
 
+@pytest.mark.parametrize("name", ["libpigeon_hip.so", "libpigeon_hip_f32.so"])
+def test_release_libraries_export_exactly_the_header(name):
+    """the shipped libraries exported `pg_debug_solve_cycles` (55 names against the header's 54) and carried the diagnostic instantiations of k_solve.
+    The dynamic symbol table of a release library is the header's declarations, no more and no less; the debug entry point and the `k_solve<true, ...>` (PROF)
+    kernels exist in the -DPG_DIAG library only."""
+    import subprocess
+    csrc = os.path.join(ROOT, "pigeon.jl_amd", "csrc")
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(csrc, name)], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines())
+    assert exported == header_symbols()           # (pg_exports.map: kernel stubs and handles are local; nothing but the C ABI is visible)
+    # device side: the PROF = true instantiations of k_solve (its first template argument) are not in the release code object
+    assert "k_solveILb1E" not in out and "k_solveILb1E" not in subprocess.run(["strings", os.path.join(csrc, name)], capture_output=True, text=True, check=True).stdout
+    diag = subprocess.run(["nm", "-D", "--defined-only", os.path.join(csrc, "libpigeon_hip_diag.so")], capture_output=True, text=True, check=True).stdout
+    assert "pg_debug_solve_cycles" in diag
+
+
 def test_default_config_matches_x1(pkg):
     from pigeon_jl_amd import _lib
     lib = pkg.load_library()

@@ -106,16 +106,17 @@ def test_two_consecutive_lateral_steps_match_the_oracle(pkg, oracle_mod, skidpad
     assert worst < 1e-6, worst
 
 
-@pytest.mark.parametrize("path,walls,burn,min_served,max_ratio", [("skidpadoval", False, 3, 0.6, 1.6), ("skidpadoval", True, 3, 0.5, 1.6), ("EastPaddock", False, 100, 0.999, 0.6)])
-def test_warm_lateral_step_of_the_full_batch_every_instance_against_the_oracle(pkg, oracle_mod, path, walls, burn, min_served, max_ratio):
+@pytest.mark.parametrize("path,walls,burn,min_served", [("skidpadoval", False, 3, 0.6), ("skidpadoval", True, 3, 0.5), ("EastPaddock", False, 100, 0.999)])
+def test_warm_lateral_step_of_the_full_batch_every_instance_against_the_oracle(pkg, oracle_mod, path, walls, burn, min_served):
     """BASELINE configs[4] in closed loop: B = 4096, N = 50 (+ walls), `burn` steps on the device, then one more step -- warm for every instance -- checked like the cold
     one (test_config5_as_shipped_every_instance_against_the_oracle): the applied steering of EVERY instance within 1e-6 of the exact optimum of its own QP data (a
     verified KKT point of the canonical QP by the oracle), however the instance was served (warm attempt, or the interior point behind a failed / skipped attempt).
     What the warm start buys depends on the loop (EXPERIMENTS 10.1): k_solve_lat ends with its slowest instance, so ONE instance that falls back to the interior point
     costs the launch the cold time.  On the benchmark batch (random starts on the skidpad, far horizons whose working sets turn over by a dozen rows per 10 ms) 75-85 %
     of the instances are served warm and the solve phase is that of a cold step; in a settled loop (EastPaddock after 1 s) every instance is served by ONE polish round and
-    the solve phase is >= 3x shorter than the cold one.  The timing bars here are deliberately loose (single un-repeated launches on a possibly shared GPU: 1.6x and 0.6x);
-    the measured ratios are bench.py's business (`decoupled_n50.closed_loop`)."""
+    the solve phase is >= 3x shorter than the cold one.  No wall-clock bar here (round 6: a correctness test does not time single un-warmed launches): the ratios are
+    measured by bench.py (`decoupled_n50.closed_loop`: both loops, with and without the warm start); what this test asserts of the warm start is the SHARE of instances it
+    serves without an interior-point iteration."""
     B, Ns, Nl = 4096, 10, 40
     traj = pkg.load_path_fixture(path)
     mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=Ns, N_long=Nl, walls=walls)
@@ -146,4 +147,3 @@ def test_warm_lateral_step_of_the_full_batch_every_instance_against_the_oracle(p
     assert (pol >= 1).sum() >= B - 8, int((pol < 0).sum())          # round 4: 37-60 unverified answers per step (stalled multipliers of held rate rows); pinned: 0-4
     assert np.max(np.abs(uw[both, 0] - uc[both, 0])) <= 3e-7                  # two verified KKT points of the same QP (each within 2e-7 of the oracle's: measured 1.3e-7 apart)
     assert np.mean(it == 0) >= min_served, np.mean(it == 0)
-    assert warm_ms[2] <= max_ratio * cold_ms[2], (warm_ms, cold_ms)

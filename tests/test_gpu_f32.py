@@ -112,7 +112,11 @@ def test_f32_decoupled_n50(pkg, skidpad):
     state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, n, seed=8)
     state, control = f32_round(state), f32_round(control)
     d64 = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, n, N_short=10, N_long=40)
-    d32 = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, n, N_short=10, N_long=40, precision="f32")
+    with pytest.raises(pkg.PigeonError) as refused:      # (round 6: the fp32 library refuses this configuration unless asked for explicitly -- DESIGN 4.4: steering up to 6e-3 rad off)
+        pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, n, N_short=10, N_long=40, precision="f32")
+    assert "allow_f32_long_lateral" in str(refused.value)
+    pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, 8, N_short=10, N_long=20, precision="f32").close()      # (32 intervals and fewer are accepted as before)
+    d32 = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, n, N_short=10, N_long=40, precision="f32", allow_f32_long_lateral=True)
     u64, st64, _ = d64.step_(state, control, t0, time_offset=toff)
     u32, st32, _ = d32.step_(state, control, t0, time_offset=toff)
     assert np.mean(pkg.is_solved(st32)) >= 0.995, np.bincount(st32)            # (default fp32 tolerance of this formulation: 1e-4)
@@ -134,7 +138,7 @@ def test_f32_config5_full_size_every_instance_against_the_oracle(pkg, oracle_mod
     B, Ns, Nl = 4096, 10, 40
     state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B)
     state, control = f32_round(state), f32_round(control)
-    d32 = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, B, N_short=Ns, N_long=Nl, precision="f32", walls=walls)
+    d32 = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, B, N_short=Ns, N_long=Nl, precision="f32", walls=walls, allow_f32_long_lateral=True)
     u, status, iters = d32.step_(state, control, t0, time_offset=toff)
     ok = pkg.is_solved(status)
     assert np.mean(ok) >= 0.995 and np.sum(status == pkg.NUMERICAL) <= 4, np.bincount(status)

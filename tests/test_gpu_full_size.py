@@ -280,7 +280,7 @@ def test_fused_step_is_bit_identical(pkg, skidpad):
 
 
 def test_pipelined_nodes_and_update_qp_are_bit_identical(pkg, skidpad):
-    """pg_set_pipeline (default on, 2304 <= B <= 16384 with cold instances): compute_linearization_nodes! and update_QP! run as one launch in which interval t is
+    """pg_set_pipeline (default on, 2304 <= B <= 8192 with cold instances): compute_linearization_nodes! and update_QP! run as one launch in which interval t is
     linearised as soon as nodes t, t + 1 are seeded.  Same device functions on the same arguments: nodes, QP data, solution and controls are bit-identical to the
     launch-per-phase sequence -- on a cold batch, on a MIXED batch (half the instances reset after a step: their wavefronts publish once, at the end) and with a
     ragged last wavefront (B not a multiple of 64)."""

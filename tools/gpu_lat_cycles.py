@@ -9,7 +9,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 Nl = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 walls = len(sys.argv) > 3 and sys.argv[3] == "1"
 traj = pkg.load_path_fixture("skidpadoval")
-mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=Nl, walls=walls)
+mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=Nl, walls=walls, precision="f64-diag")      # (pg_debug_solve_cycles lives in the diagnostic library)
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B)
 mpc.set_inputs(state, control, t0, time_offset=toff)
 mpc.compute_time_steps_(); mpc.compute_linearization_nodes_(); mpc.update_QP_()      # (no solve yet: the diagnostic launch below is the COLD solve; k_solve_lat warm-starts otherwise)

@@ -11,7 +11,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 warmup = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 Nl = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 walls = bool(int(sys.argv[4])) if len(sys.argv) > 4 else False
-mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=Nl, walls=walls, polish_rho=float(os.environ['PG_RHO']) if 'PG_RHO' in os.environ else None)
+mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=Nl, walls=walls, precision="f64-diag", polish_rho=float(os.environ['PG_RHO']) if 'PG_RHO' in os.environ else None)
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B)
 mpc.set_inputs(state, control, t0, time_offset=toff)
 s, c, t, _, _ = mpc.simulate_(warmup)

@@ -13,9 +13,9 @@ traj = pkg.load_path_fixture(path)
 B = 4096
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345)
 if int(os.environ.get("PG_DEC", "0")):                     # PG_DEC=1: the decoupled N = 50 formulation (BASELINE config 5) with the polish and the empty-set rounds switched on
-    mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, walls=bool(int(os.environ.get("PG_WALLS", "0"))), precision=precision_for(OPTS), options=OPTS, **(dict(polish=True, cold_guess=8) if int(os.environ.get("PG_DEC_POLISH", "1")) else {}))
+    mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, walls=bool(int(os.environ.get("PG_WALLS", "0"))), precision="f64-diag", options=OPTS, **(dict(polish=True, cold_guess=8) if int(os.environ.get("PG_DEC_POLISH", "1")) else {}))
 else:
-    mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, precision=precision_for(OPTS, os.environ.get("PG_PREC", "f64")), options=OPTS)      # (the trace exists in the fp64 diagnostic library)
+    mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, precision="f64-diag" if os.environ.get("PG_PREC", "f64") == "f64" else os.environ["PG_PREC"], options=OPTS)      # (the trace exists in the fp64 diagnostic library)
 other = None
 if int(os.environ.get("PG_HJI", "0")):                     # PG_HJI=1 (+ PG_PREC=f32): BASELINE config 3
     mpc.set_hji_cache(*pkg.synthetic.hji_grid_large()); other = pkg.synthetic.other_cars(state, seed=777)

@@ -9,7 +9,7 @@ pkg = load_pkg()
 prec = sys.argv[1] if len(sys.argv) > 1 else "f64"
 B = 4096
 traj = pkg.load_path_fixture("skidpadoval")
-mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, precision=prec, cold_guess=0)
+mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B, precision="f64-diag" if prec == "f64" else prec, cold_guess=0)      # (round 6: pg_debug_solve_cycles lives in the -DPG_DIAG library only; an fp32 run needs `make EXTRA=-DPG_DIAG libpigeon_hip_f32.so` selected through PIGEON_HIP_LIB_F32)
 state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345)
 mpc.reset(); mpc.step_(state, control, t0, time_offset=toff)
 mpc.reset()
