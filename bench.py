@@ -53,6 +53,32 @@ def lat_flops(N, NR, passes):
     return passes * N * (800.0 + 90.0 + 170.0 + 3 * 70.0 * NR)
 
 
+def linearize_flops_from_isa(B, Ns, Nl, precision):
+    """(flops of one linearisation launch, its instruction totals) from profiles/isa_mix.json (tools/isa_mix.py: static counts of the kernel's loop nests x trip counts; per lane =
+    per (instance, interval)).  Falls back to the hand count of the same algorithm (832 / 699 flops per ramp / zero-order-hold stage, 40 stages per interval) without the file."""
+    try:
+        mix = json.load(open(os.path.join(ROOT, "profiles", "isa_mix.json")))
+        m = mix["kernels"]["k_nodes_linearize<true, 1, 1>" + ("" if precision == "f64" else " [f32]")]
+        tot = {k: B * (Ns * m["zoh"]["per_interval"][k] + Nl * m["ramp"]["per_interval"][k]) for k in ("valu", "agpr_moves", "arith", "flops")}
+        isa = {"valu_wave_insts": tot["valu"] / 64.0, "agpr_move_wave_insts": tot["agpr_moves"] / 64.0, "arith_wave_insts": tot["arith"] / 64.0,
+               "flops_per_stage": {"ramp": m["ramp"]["per_stage"]["flops"], "zoh": m["zoh"]["per_stage"]["flops"]}, "stale": mix.get("kernel_source_sha16") != kernel_source_sha16()}
+        return float(tot["flops"]), isa
+    except Exception:
+        return float(B) * 40.0 * (Ns * 699.0 + Nl * 832.0), None
+
+
+def roofline_consistency(line):
+    """What must hold between the fractions of a bench record whatever the numbers are: a kernel cannot execute more arithmetic than it issues instructions for.  Returns the
+    list of violations (empty = consistent); bench.py attaches it to the record, tests/test_abi_and_host.py asserts it empty on the committed record of this round."""
+    bad = []
+    for e in ((line.get("roofline") or {}).get("kernels") or []):
+        issue = e.get("valu_issue_frac")
+        for k in ("valu_flop_frac", "executed_fp64_frac", "hw_valu_flop_frac"):
+            if issue is not None and e.get(k) is not None and e[k] > issue:
+                bad.append(f"{e.get('kernel')}: {k} {e[k]:.3f} > valu_issue_frac {issue:.3f}")
+    return bad
+
+
 def roofline_of(tr, kernel_match, ms, units, bytes_per_unit, flops, precision, note=None):
     """`roofline` object of a secondary benchmark line: HBM fraction from the algorithmic bytes and the live duration; counter traffic, VALU issue fraction (SQ_INSTS_VALU x 4
     cycles over the SIMD time of the launch) and the rocprof duration spread from the committed PMC / stats passes (profiles/traffic.json); flop-model fraction of the vector peak."""
@@ -82,6 +108,31 @@ def mfma_util(tr, dom, pipelined):
     kern = {0: "k_nodes_linearize" if pipelined else "k_nodes", 1: "k_linearize", 2: "k_solve"}[dom]
     hit = [v for k, v in tr.get("kernels", {}).items() if kern in k and "mfma" in v]
     return hit[0]["mfma"] if hit else None
+
+
+def detect_xgmi():
+    """Link type between the GPUs of this node from `rocm-smi --showtopotype` (a child process: nothing here touches the GPU): True when every GPU pair is XGMI,
+    False when some pair is not (PCIe), "unknown" when the tool is missing or there is one GPU."""
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "--showtopotype"], capture_output=True, text=True, timeout=30).stdout
+    except Exception:
+        return "unknown"
+    kinds = [w for ln in out.splitlines() if ln.startswith("GPU") for w in ln.split()[1:] if w in ("XGMI", "PCIE")]
+    if not kinds:
+        return "unknown"
+    return all(k == "XGMI" for k in kinds)
+
+
+XGMI = "unknown"
+
+
+def rccl_version(torch):
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:
+        return None
 
 
 def usable_cores():
@@ -170,7 +221,10 @@ def compact_line(full):
             "solved": g("solved"), "roofline": roof}
     if cpu is not None:
         line["cpu_baseline"] = cpu
-    for k in ("phase_ms_short", "pipeline_fallbacks", "env", "kernel_source_sha16", "ranks", "collective", "per_rank_ms_per_step", "gather_ok", "secondary"):
+    if full.get("timing"):
+        tm = full["timing"]
+        line["timing"] = {k: tm.get(k) for k in ("repeats", "ms_per_step_min", "ms_per_step_median", "ms_per_step_max")}
+    for k in ("phase_ms_short", "pipeline_fallbacks", "env", "kernel_source_sha16", "ranks", "collective", "per_rank_ms_per_step", "gather_ms", "rccl_version", "xgmi", "gather_ok", "roofline_consistency", "secondary"):
         if full.get(k) is not None:
             line[k] = full[k]
     line["full_record"] = "bench_full.json"
@@ -337,6 +391,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hji", action="store_true")
     ap.add_argument("--no-decoupled", action="store_true")
+    ap.add_argument("--repeats", type=int, default=5, help="the timed region is repeated this many times (each: --steps steps between two barrier + synchronize brackets); "
+                                                            "`value` is the MEDIAN block, min / max / every block go to bench_full.json (VERDICT r5: one 10 ms shot is thin as a measurement)")
     ap.add_argument("--no-f32", action="store_true")
     ap.add_argument("--no-rollout", action="store_true", help="skip the closed-loop rollout object")
     ap.add_argument("--no-warm", action="store_true", help="skip the warm-step loop (the profile campaign uses it so that every k_solve launch of the trace is a cold headline launch)")
@@ -361,6 +417,9 @@ def main():
         env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         raise SystemExit(subprocess.call(cmd, env=env))
 
+    global XGMI
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) == 0:
+        XGMI = detect_xgmi()          # (before this process initialises the GPU)
     import torch
     import torch.distributed as dist
     from __graft_entry__ import _load_pkg
@@ -436,23 +495,49 @@ def main():
     for _ in range(args.warmup):
         one_step()
     sync()
-    t_begin = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-        # no host sync inside the loop: events are read after the region
-    torch.cuda.synchronize()
-    sync()
-    elapsed = time.perf_counter() - t_begin
-    rank_ms = None
+    # the timed region: EXACTLY --steps steps between two (barrier + synchronize) brackets, taken --repeats times back to back; `value` is the median block
+    # (N > 1: a block counts with the time of its slowest rank)
+    blocks = []
+    for _ in range(max(1, args.repeats)):
+        sync()
+        t_begin = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+            # no host sync inside the loop: events are read after the region
+        torch.cuda.synchronize()
+        sync()
+        blocks.append(time.perf_counter() - t_begin)
+    rank_ms = None; gather_ms = None
     if world > 1:
         # a scaling run is the timed loop, the gather check and ONE JSON line: every secondary object below is skipped when world > 1 (rank 0 would otherwise build
         # HJI tables, decoupled and fp32 handles while the other ranks wait in the barrier)
-        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        mine = torch.tensor(blocks, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
-        per_rank = [float(t.item()) for t in every]
-        elapsed = max(per_rank)
-        rank_ms = {"min": 1e3 * min(per_rank) / args.steps, "max": 1e3 * max(per_rank) / args.steps}
+        per_rank = np.array([[float(v) for v in t.tolist()] for t in every])            # [rank][block]
+        blocks = [float(v) for v in per_rank.max(axis=0)]
+        mid = int(np.argsort(blocks)[len(blocks) // 2])
+        rank_ms = {"min": 1e3 * float(per_rank[:, mid].min()) / args.steps, "max": 1e3 * float(per_rank[:, mid].max()) / args.steps}
+        # how long the collective itself takes (so that a weak-scaling efficiency below 0.9 can be attributed: launch overhead or the gather): a few more steps with an
+        # event pair around each all_gather on the communication stream, outside the timed region
+        if comm_stream is not None:
+            g_ev = []
+            for _ in range(6):
+                one_step()
+                k_ = (step_no[0] - 1) & 1
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                with torch.cuda.stream(comm_stream):
+                    e0.record(comm_stream); dist.all_gather_into_tensor(g_bufs[k_], u_bufs[k_]); e1.record(comm_stream)
+                g_ev.append((e0, e1))
+            sync()
+            mine_g = torch.tensor([float(np.median([a.elapsed_time(b) for a, b in g_ev[1:]]))], dtype=torch.float64, device=dev)
+            every_g = [torch.zeros_like(mine_g) for _ in range(world)]
+            dist.all_gather(every_g, mine_g)
+            gather_ms = {"per_rank_median": [float(t.item()) for t in every_g], "bytes_per_rank": int(u_out.numel() * u_out.element_size()),
+                         "how": "HIP events on the communication stream around an all_gather_into_tensor of one step's controls, 5 launches outside the timed region"}
+    elapsed = float(np.median(blocks))
+    timing = {"repeats": len(blocks), "steps_per_block": args.steps, "block_s": blocks, "value_is": "median block", "ms_per_step_min": 1e3 * min(blocks) / args.steps,
+              "ms_per_step_median": 1e3 * elapsed / args.steps, "ms_per_step_max": 1e3 * max(blocks) / args.steps}
 
     # per-phase device time (HIP events recorded by pg_step_dev on the launch stream): mean over a few extra steps outside the timed region
     mpc.set_option("phase_timing", 1)
@@ -792,13 +877,18 @@ def main():
             dom_extra = {k: hit[0][k] for k in ("valu_issue_frac", "valu_insts_per_launch", "avg_launch_ns_rocprof", "min_launch_ns_rocprof", "max_launch_ns_rocprof", "stddev_launch_ns_rocprof") if hit and k in hit[0]}
         except Exception:
             pass
-        # k_linearize is throughput-bound on the fp64 vector unit: 40 dynamics evaluations per interval x (130 value + 260 per tangent direction) flops -- eight
-        # directions on the ramp intervals, six on the zero-order-hold intervals of the short horizon (uf is not a variable there)
-        lin_fl = float(B) * 40 * (mpc.N_short * (130 + 6 * 260) + (mpc.N - mpc.N_short) * (130 + 8 * 260))
+        # The linearisation's flops are COUNTED, not modelled (round 6; rounds 1-5 priced the launch with the forward-mode count of an algorithm it no longer runs: 130 + 260 per
+        # direction and evaluation, 1.0e10 per launch, i.e. "0.42 of the vector peak" -- above anything the 80.6 M counted VALU instructions could deliver).  What runs: the
+        # right-hand side with its local Jacobian once per RK4 stage (tracking_jac: 356 flops by hand with every reciprocal / square root / sincos counted as one), then
+        # ~51 flops per tangent direction (+ 6 for a control direction) -- 832 per ramp stage, 699 per zero-order-hold stage by hand; the ISA of the stage loops (software
+        # sincos, refined reciprocals and square roots included) holds 1204 / 912: tools/isa_mix.py -> profiles/isa_mix.json, per interval x (N_short, N_long) x B.
+        lin_fl, isa_lin = linearize_flops_from_isa(B, mpc.N_short, mpc.N - mpc.N_short, args.precision)
         peak_lin = FP64_VALU_PEAK_TF if args.precision == "f64" else 2 * FP64_VALU_PEAK_TF
         valu_lin = {"bound": "valu-" + args.precision, "kernel": "k_nodes_linearize" if pipelined else "k_linearize", "algorithmic_flops_per_launch": lin_fl, "achieved": lin_fl / (lin_ms * 1e-3) / 1e12, "peak": peak_lin,
-                    "unit": "TFLOP/s", "frac": lin_fl / (lin_ms * 1e-3) / 1e12 / peak_lin, "avg_launch_ms": lin_ms,
-                    "source": "flop model of the forward-mode RK4 linearisation (EXPERIMENTS.md 6); time live (HIP events: " + ("the nodes + update_qp phase -- projection, the nodes recurrence and the linearisation running under it" if pipelined else "the update_qp phase") + ", no HJI row in the headline run)"}
+                    "unit": "TFLOP/s", "frac": lin_fl / (lin_ms * 1e-3) / 1e12 / peak_lin, "avg_launch_ms": lin_ms, "isa": isa_lin,
+                    # an UPPER bound on executed arithmetic: every fp64 arithmetic instruction of the launch (ISA count) taken as a 64-lane multiply-add
+                    "executed_fp64_frac": None if not isa_lin else isa_lin["arith_wave_insts"] * 128.0 / (lin_ms * 1e-3) / 1e12 / peak_lin,
+                    "source": "flops counted from the ISA of the kernel's loop nests x trip counts (tools/isa_mix.py, profiles/isa_mix.json; the nodes recurrence -- 2 % of the instructions -- is not in it); time live (HIP events: " + ("the nodes + update_qp phase -- projection, the nodes recurrence and the linearisation running under it" if pipelined else "the update_qp phase") + ", no HJI row in the headline run)"}
         # secondary roofline of the dominant kernel: ALGORITHMIC flops (model above x the iteration counts of THIS run) against the fp64 / fp32 vector peak --
         # the resource class that binds (the step moves 112 B per solve through HBM, so its HBM fraction is ~1e-5 by construction)
         rounds = np.where(pol > 0, pol, np.where(pol < 0, 6, 0))
@@ -811,10 +901,16 @@ def main():
         # names the longer one and lists BOTH (their phases are within a few per cent of each other and swap places from run to run)
         def kernel_entry(name, match, ms, flop_obj):
             e = {"kernel": name, "avg_launch_ms": ms, "hbm_frac": B * bytes_per_solve / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "valu_flop_frac": flop_obj["frac"]}
+            if flop_obj.get("executed_fp64_frac") is not None:
+                e["executed_fp64_frac"] = flop_obj["executed_fp64_frac"]
             hit_ = [v for k, v in (tr or {}).get("kernels" if args.precision == "f64" else "kernels_f32", {}).items() if match in k]
             if hit_:
                 h_ = hit_[0]
                 e["traffic"] = h_.get("hbm_bytes_per_launch"); e["valu_issue_frac"] = h_.get("valu_issue_frac"); e["avg_launch_ms_rocprof"] = (h_.get("avg_launch_ns_rocprof") or 0) * 1e-6 or None
+                hw_ = h_.get("hw_flops")
+                if isinstance(hw_, dict) and hw_.get("valu_flops_per_launch"):
+                    # the hardware's own count of executed arithmetic (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 of the committed PMC pass) over the LIVE duration
+                    e["hw_valu_flop_frac"] = hw_["valu_flops_per_launch"] / (ms * 1e-3) / 1e12 / hw_["peak_tflops"]; e["hw_arith_share_of_valu_insts"] = hw_.get("arith_share_of_valu_insts")
                 m_ = h_.get("mfma")
                 if isinstance(m_, dict):
                     e["mfma_busy_frac"] = m_.get("busy_frac_of_simd_time"); e["mfma_flop_frac"] = m_.get("frac_of_peak")
@@ -828,7 +924,7 @@ def main():
             fallbacks = None
         line = {
             "metric": "MPC QP solves/sec (N=30 coupled, X1 model)", "kernel_source_sha16": kernel_source_sha16(), "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "timing": timing, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": (f"configs[1]: Batch={B}/GPU coupled MPC, N=30 (N_short=10, N_long=20), X1, randomised x0 along skidpadoval, cold start, HJI inactive, fp64" if args.precision == "f64"
                                     else f"configs[3]: Batch={world * B} coupled MPC, N=30, fp32, sharded {B}/GPU x{world}, RCCL all_gather of controls, cold start"),
@@ -847,7 +943,7 @@ def main():
             "pipeline_fallbacks": fallbacks, "env": pg_environment(),
             "warm_value": None if args.no_warm else world * B * args.steps / warm_elapsed,
             "solved": f"{ok}/{B}", "gather_ok": gather_ok, "ranks": world if world == 1 else dist.get_world_size(), "collective": None if world == 1 else ("rccl" if args.backend == "nccl" else "gloo"),
-            "per_rank_ms_per_step": rank_ms, "ipm_iters_mean": float(np.mean(it)), "ipm_iters_max": int(np.max(it)), "ipm_iters_hist": hist(it),
+            "per_rank_ms_per_step": rank_ms, "gather_ms": gather_ms, "rccl_version": rccl_version(torch) if world > 1 else None, "xgmi": XGMI if world > 1 else None, "ipm_iters_mean": float(np.mean(it)), "ipm_iters_max": int(np.max(it)), "ipm_iters_hist": hist(it),
             "polish_rounds_hist": hist(pol), "polish_note": "k >= 1: verified in round k; 0: not run; -1: not verified (interior-point iterate at 1e-12 kept)",
             "served_by_active_set_guess_alone": int((it == 0).sum()),
         }
@@ -886,6 +982,7 @@ def main():
         if variants is not None:
             sec["config2_vail_solves_per_s"] = variants["vail"]["value"]; sec["config2_path_mode_solves_per_s"] = variants["path_mode"]["value"]
         line["secondary"] = {k: v for k, v in sec.items() if v is not None}
+        line["roofline_consistency"] = roofline_consistency(line)
         emit(line, args.full_record)
     if world > 1:
         dist.barrier()

@@ -208,9 +208,16 @@ int pg_step_dev(pg_handle* h, pg_real_dev* u_out_dev);
 
 /* simulate(mpc, q0, u0, dt)  src/model_predictive_control.jl:80-100 for every instance, entirely on the device (no host round trip between
  * steps): per step  record -> the four compute calls -> state = propagate(dynamics, state, StepControl(dt, old control)) -> control = get_next_control
- * -> t += dt.  Starts from the inputs last installed (pg_set_inputs*: state, control, t0, time_offset) and leaves the final ones there
+ * -> t = the next element of the loop's range (see pg_simulate_clock below).  Starts from the inputs last installed (pg_set_inputs*: state, control, t0, time_offset) and leaves the final ones there
  * (pg_get_state reads them).  state_hist_dev [steps][B][6] / control_hist_dev [steps][B][3] may be NULL.  Asynchronous on the handle's stream. */
 int pg_simulate_dev(pg_handle* h, int32_t steps, double dt, pg_real_dev* state_hist_dev, pg_real_dev* control_hist_dev);
+/* The loop variable of that rollout: `for t in 0:dt:mpc.trajectory.t[end]` (src/model_predictive_control.jl:87) is a Julia RANGE -- element k is ONE rounding of k dt with dt lifted
+ * to its exact rational (0.01 = 1/100) when dt and the path's end time have one, `fl(k dt)` otherwise -- not the accumulation t += dt (which is 0.2900000000000001 at step 29 and
+ * then puts the long horizon of :23 a whole dt_long later).  pg_simulate_dev forms each instance's time as (t_start .+ (0:dt:t_end))[k + 1] with t_start the time installed by
+ * pg_set_inputs* and t_end the last time of the installed trajectory (trajectory 0 of a library); consecutive calls with the same dt continue the clock, pg_set_inputs* restarts it.
+ * This entry point returns those times on the host, out[k * B + b] for k < steps, so that a host-driven loop (pg_step per step) can feed the same t0 the device loop uses.
+ * Option "time_grid_naive" = 1: t_start + accumulated dt, as in rounds 1-5.  (A restatement of Julia 1.0's Base range arithmetic that could not be executed here.) */
+int pg_simulate_clock(pg_handle* h, double dt, int32_t steps, int32_t B, const double* t_start, double* out);
 /* current device-resident inputs: state [B][6], control [B][3], t0 [B] (host pointers, any may be NULL) */
 int pg_get_state(pg_handle* h, double* state, double* control, double* t0);
 
@@ -257,6 +264,11 @@ int pg_synchronize(pg_handle* h);
  *     "phase_timing" 0/1 (0)     1 = pg_step_dev records the HIP events pg_get_phase_ms reads (four event records per step on the handle's stream: measured 13-25 us per step, 2-4 % of a
  *                                4096-instance step); 0 = no instrumentation, pg_get_phase_ms returns PG_ERR_STATE
  *     "graph" 0/1 (0)            pg_step of a small warm batch as one hipGraph launch (see pg_step)
+ *     "time_grid_naive" 0/1 (0)  0 = the time axes as Julia's RANGES give them (src/model_predictive_control.jl:25-26: `t0 .+ dt_short*(0:N_short)`, `t0_long .+ dt_long*(1:N_long)`,
+ *                                and :87, `for t in 0:dt:trajectory.t[end]` in pg_simulate_dev): reference value and step in twice the working precision, dt lifted to its exact
+ *                                rational (0.01 = 1/100, 0.2 = 1/5), every element ONE rounding -- a restatement of Julia 1.0's Base that could not be executed here;
+ *                                1 = `t0 + dt*i` with two roundings and `t += dt` in the closed loop (the form of rounds 1-5: differs by an ulp of ts now and then, which the
+ *                                discontinuous `ceil` of :23 can turn into a different lattice point)
  *     "hji_cell_dims" 3/5/7 (3)  corners per cell record of the HJI table = 2^value (256 B / 1 KiB / 4 KiB records)
  *   lateral solve kernel (decoupled formulation):
  *     "lateral_solver" 0/1/2 (0) 0 = k_solve_lat beyond 20 intervals or with the polish off, else the embedding in k_solve; 1 = k_solve_lat; 2 = the embedding

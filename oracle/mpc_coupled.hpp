@@ -13,6 +13,7 @@
 //     THROUGH the integrator (ForwardDiff 0.10.3).
 //   The number of RK4 sub-steps is a configuration value of this build (rk4_substeps).
 #pragma once
+#include "julia_range.hpp"
 #include <cmath>
 #include <vector>
 #include "dual.hpp"
@@ -40,6 +41,9 @@ struct MPCTimeSteps {
     // CURRENT grid: the warm branch (coupled_lat_long.jl:82-102) therefore re-uses the previous solution node-for-node.
     // alias_prev_ts = true reproduces that behaviour; false gives the (apparently intended) time-shifted interpolation.
     bool alias_prev_ts = true;
+    // :25-26 build the grid out of Julia RANGES (`t0 .+ dt_short*(0:N_short)`): julia_range.hpp restates their twice-precision arithmetic (one rounding per element, dt
+    // lifted to its rational).  naive_time_grid = true: `t0 + dt*i` with two roundings, the form of rounds 1-5 (kept for A/B and for the knife-edge test)
+    bool naive_time_grid = false;
     std::vector<double> ts, dt, prev_ts;
     void init() {
         int N = 1 + N_short + N_long;
@@ -52,8 +56,15 @@ struct MPCTimeSteps {
         prev_ts = ts;
         double t0_long = t0 + N_short * dt_short;
         if (use_correction_step) t0_long = dt_long * std::ceil((t0_long + dt_short) / dt_long - 1);
-        for (int i = 0; i <= N_short; i++) ts[i] = t0 + dt_short * i;
-        for (int i = 1; i <= N_long; i++) ts[N_short + i] = t0_long + dt_long * i;
+        if (naive_time_grid) {
+            for (int i = 0; i <= N_short; i++) ts[i] = t0 + dt_short * i;
+            for (int i = 1; i <= N_long; i++) ts[N_short + i] = t0_long + dt_long * i;
+        } else {
+            const jlrange::Range rs = jlrange::shifted(jlrange::scalar_times_unitrange(dt_short, 0, N_short), t0);            // t0 .+ dt_short*(0:N_short)       :25
+            const jlrange::Range rl = jlrange::shifted(jlrange::scalar_times_unitrange(dt_long, 1, N_long), t0_long);         // t0_long .+ dt_long*(1:N_long)    :26
+            for (int i = 0; i <= N_short; i++) ts[i] = jlrange::elem(rs, i + 1);
+            for (int i = 1; i <= N_long; i++) ts[N_short + i] = jlrange::elem(rl, i);
+        }
         for (int i = 0; i < N_short + N_long; i++) dt[i] = ts[i + 1] - ts[i];
         if (alias_prev_ts) prev_ts = ts;
     }

@@ -114,6 +114,16 @@ class Oracle:
         self.L.po_time_steps(self.h, C.c_double(t0), _d(ts), _d(dt))
         return ts, dt
 
+    def set_time_grid_naive(self, naive):
+        """True: `t0 + dt*i` with two roundings (rounds 1-5); False (default): Julia's range arithmetic (oracle/julia_range.hpp; model_predictive_control.jl:25-26)."""
+        self.L.po_set_time_grid_naive(self.h, int(bool(naive)))
+
+    def simulate_times(self, dt, t_end, steps, t_start=0.0):
+        """(t_start .+ (0:dt:t_end))[1:steps] -- the loop variable of `simulate` (model_predictive_control.jl:87) as Julia's range gives it."""
+        out = np.zeros(steps); self.L.po_simulate_times.restype = C.c_int
+        self.L.po_simulate_times(C.c_double(dt), C.c_double(t_end), C.c_double(t_start), int(steps), _d(out))
+        return out
+
     def path_coordinates(self, E, N):
         out = np.zeros(3); im = C.c_int()
         self.L.po_path_coordinates(self.h, C.c_double(E), C.c_double(N), _d(out), C.byref(im))
@@ -375,6 +385,14 @@ class OracleDecoupled:
     def time_steps(self, t0):
         ts = np.zeros(self.Nn); dt = np.zeros(self.N)
         self.L.pd_time_steps(self.h, C.c_double(t0), _d(ts), _d(dt)); return ts, dt
+
+    def set_time_grid_naive(self, naive):
+        self.L.pd_set_time_grid_naive(self.h, int(bool(naive)))
+
+    def simulate_times(self, dt, t_end, steps, t_start=0.0):
+        out = np.zeros(steps); self.L.po_simulate_times.restype = C.c_int
+        self.L.po_simulate_times(C.c_double(dt), C.c_double(t_end), C.c_double(t_start), int(steps), _d(out))
+        return out
 
     def nodes(self, state6, control3, ts, dt, time_offset=float("nan")):
         qs = np.zeros((self.Nn, 4)); us = np.zeros((self.Nn, 2)); ps = np.zeros((self.Nn, 4))

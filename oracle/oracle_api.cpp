@@ -91,6 +91,13 @@ void po_time_steps(void* hv, double t0, double* ts, double* dt) {
     Handle* h = (Handle*)hv; MPCTimeSteps T = h->mpc.TS; T.compute(t0);
     std::memcpy(ts, T.ts.data(), T.ts.size() * 8); std::memcpy(dt, T.dt.data(), T.dt.size() * 8);
 }
+void po_set_time_grid_naive(void* hv, int naive) { ((Handle*)hv)->mpc.TS.naive_time_grid = naive != 0; }      // A/B: the two-rounding grid of rounds 1-5
+// the values `t` takes in `for t in 0:dt:t_end` (model_predictive_control.jl:87), shifted by t_start: out[k] = (t_start .+ (0:dt:t_end))[k + 1]; returns the range's length
+int po_simulate_times(double dt, double t_end, double t_start, int steps, double* out) {
+    const jlrange::Range r = jlrange::shifted(jlrange::colon(0.0, dt, t_end), t_start);
+    for (int k = 0; k < steps; k++) out[k] = jlrange::elem(r, k + 1);
+    return (int)r.len;
+}
 void po_path_coordinates(void* hv, double E, double N, double* out3, int* imin) {
     ((Handle*)hv)->mpc.traj.path_coordinates(E, N, out3[0], out3[1], out3[2], imin);
 }
@@ -288,6 +295,7 @@ void pd_time_steps(void* hv, double t0, double* ts, double* dt) {
     MPCTimeSteps T = ((HandleDec*)hv)->mpc.TS; T.compute(t0);
     std::memcpy(ts, T.ts.data(), T.ts.size() * 8); std::memcpy(dt, T.dt.data(), T.dt.size() * 8);
 }
+void pd_set_time_grid_naive(void* hv, int naive) { ((HandleDec*)hv)->mpc.TS.naive_time_grid = naive != 0; }
 void pd_nodes(void* hv, const double* state6, const double* control3, double time_offset, const double* ts, const double* dt, double* qs, double* us, double* ps) {
     DecoupledMPC m = ((HandleDec*)hv)->mpc; int Nn = m.N() + 1;
     m.TS.ts.assign(ts, ts + Nn); m.TS.dt.assign(dt, dt + Nn - 1);

@@ -345,13 +345,169 @@ class Trajectory:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def compute_time_steps(t0, N_short=10, N_long=20, dt_short=0.01, dt_long=0.2, use_correction_step=True):
-    """model_predictive_control.jl:17-30"""
+# Julia's floating-point RANGES (Base twiceprecision.jl / range.jl / broadcast.jl of Julia 1.0, restated from memory: no Julia here, Base is not under /root/reference --
+# a reading that could not be executed).  `x*(a:b)` is range(x*a, step=x, length=...): a StepRangeLen whose reference and step are TwicePrecision numbers, lifted to the
+# exact rational where start and step have one (0.01 = 1/100, 0.2 = 1/5); `t .+ range` adds t to the reference in twice precision and stays a range; element i is ONE
+# rounding of ref + (i - offset) step.  Written independently of oracle/julia_range.hpp: the error-free product is taken from exact rationals here, from fma there.
+from fractions import Fraction as _Fr
+
+
+def _canon2(big, little):
+    h = big + little
+    return h, (big - h) + little
+
+
+def _add12(x, y):
+    if abs(y) > abs(x):
+        x, y = y, x
+    return _canon2(x, y)
+
+
+def _mul12(x, y):
+    h = x * y
+    if h == 0.0 or not math.isfinite(h):
+        return h, h
+    return _canon2(h, float(_Fr(x) * _Fr(y) - _Fr(h)))          # (the residual of a product is exactly representable)
+
+
+def _truncbits(x, nb):
+    if nb <= 0:
+        return x
+    u = np.float64(x).view(np.uint64)
+    return float((u & np.uint64((0xFFFFFFFFFFFFFFFF << nb) & 0xFFFFFFFFFFFFFFFF)).view(np.float64))
+
+
+def _tp_int(i):
+    hi = _truncbits(float(i), 27)
+    return _canon2(hi, float(i - int(hi)))
+
+
+def _tp_div(x, y):
+    hi = x[0] / y[0]
+    uh, ul = _mul12(hi, y[0])
+    lo = ((((x[0] - uh) - ul) + x[1]) - hi * y[1]) / y[0]
+    return _canon2(hi, lo)
+
+
+def _tp_trunc(v, nb):
+    hi = _truncbits(v[0], nb)
+    return hi, (v[0] - hi) + v[1]
+
+
+def _tp_add(x, y):
+    s_hi, s_lo = _add12(x[0], y)
+    return _canon2(s_hi, s_lo + x[1])
+
+
+def _rat(x):
+    y = x; a = d = 1; b = c = 0; m = 16777216
+    while abs(y) <= m:
+        f = int(math.trunc(y)); y -= f
+        a, c = f * a + c, a
+        b, d = f * b + d, b
+        if not max(abs(a), abs(b)) <= m:
+            return c, d
+        if b != 0 and float(a) / float(b) == x:
+            break
+        y = 1.0 / y if y != 0.0 else math.inf
+    return a, b
+
+
+def _nbitslen(length, offset):
+    return 0 if length < 2 else min(27, int(math.ceil(math.log2(max(offset - 1, length - offset)))) + 1)
+
+
+class JuliaRange:
+    """StepRangeLen{Float64, TwicePrecision, TwicePrecision}: ref, step = (hi, lo) pairs; 1-based getindex."""
+
+    def __init__(self, ref, step, length, offset):
+        self.ref, self.step, self.len, self.offset = ref, step, length, offset
+
+    def __getitem__(self, i):
+        u = float(i - self.offset)
+        shift_hi, shift_lo = u * self.step[0], u * self.step[1]
+        x_hi, x_lo = _add12(self.ref[0], shift_hi)
+        return x_hi + (x_lo + (shift_lo + self.ref[1]))
+
+    def plus(self, x):
+        """x .+ r (broadcast.jl: the result is again a range)"""
+        return JuliaRange(_tp_add(self.ref, x), self.step, self.len, self.offset)
+
+    def values(self):
+        return np.array([self[i] for i in range(1, self.len + 1)])
+
+
+def _floatrange(start_n, step_n, length, den):
+    if length < 2 or step_n == 0:
+        return JuliaRange(_tp_div(_tp_int(start_n), _tp_int(den)), _tp_div(_tp_int(step_n), _tp_int(den)), length, 1)
+    imin = min(max(round(-start_n / step_n + 1), 1), length)
+    ref_n = start_n + (imin - 1) * step_n
+    return JuliaRange(_tp_div(_tp_int(ref_n), _tp_int(den)), _tp_trunc(_tp_div(_tp_int(step_n), _tp_int(den)), _nbitslen(length, imin)), length, imin)
+
+
+def julia_range(a, st, length):
+    """range(a, step = st, length = length) for Float64"""
+    sn, sd = _rat(a); tn, td = _rat(st)
+    if sd != 0 and td != 0 and sn / sd == a and tn / td == st:
+        den = sd * td // math.gcd(sd, td)
+        if abs(den * a) <= 2.0 ** 53 and abs(den * st) <= 2.0 ** 53 and den % sd == 0 and den % td == 0:
+            return _floatrange(round(den * a), round(den * st), length, den)
+    return JuliaRange((a, 0.0), (st, 0.0), length, 1)
+
+
+def julia_scalar_times_unitrange(x, first, last):
+    """x*(first:last)"""
+    return julia_range(x * float(first), x * 1.0, max(last - first + 1, 0))
+
+
+def julia_colon(start, step, stop):
+    """start:step:stop for Float64"""
+    between = lambda a, x, b: a <= x <= b or b <= x <= a
+    tn, td = _rat(step)
+    if td != 0 and tn / td == step:
+        sn, sd = _rat(start); en, ed = _rat(stop)
+        if sd != 0 and ed != 0 and sn / sd == start and en / ed == stop:
+            den = sd * td // math.gcd(sd, td)
+            if den != 0 and abs(start * den) <= 2.0 ** 53 and abs(step * den) <= 2.0 ** 53 and den % sd == 0 and den % td == 0:
+                start_n, step_n = round(start * den), round(step * den)
+                num, dd = den * en - ed * start_n + step_n * ed, step_n * ed
+                length = max(0, abs(num) // abs(dd) * (1 if (num >= 0) == (dd >= 0) else -1))          # Julia's div truncates
+                if between(start, start + (length - 1) * step, stop + step / 2) and not between(start, start + length * step, stop):
+                    return _floatrange(start_n, step_n, length, den)
+    lf = (stop - start) / step
+    if lf < 0:
+        length = 0
+    elif lf == 0:
+        length = 1
+    else:
+        length = round(lf) + 1
+        stop2 = start + (length - 1) * step
+        length -= int(start < stop < stop2) + int(start > stop > stop2)
+    return JuliaRange((start, 0.0), (step, 0.0), length, 1)
+
+
+def compute_time_steps(t0, N_short=10, N_long=20, dt_short=0.01, dt_long=0.2, use_correction_step=True, naive=False):
+    """model_predictive_control.jl:17-30.  naive = True: the two-rounding form `t0 + dt*i` of rounds 1-5 (kept for A/B); default: Julia's range arithmetic (:25-26)."""
     t0_long = t0 + N_short * dt_short
     if use_correction_step:
         t0_long = dt_long * math.ceil((t0_long + dt_short) / dt_long - 1)
-    ts = np.concatenate([t0 + dt_short * np.arange(N_short + 1), t0_long + dt_long * np.arange(1, N_long + 1)])
+    if naive:
+        ts = np.concatenate([t0 + dt_short * np.arange(N_short + 1), t0_long + dt_long * np.arange(1, N_long + 1)])
+    else:
+        ts = np.concatenate([julia_scalar_times_unitrange(dt_short, 0, N_short).plus(t0).values(), julia_scalar_times_unitrange(dt_long, 1, N_long).plus(t0_long).values()])
     return ts, np.diff(ts)
+
+
+def simulate_times(dt, t_end, steps, t_start=0.0, naive=False):
+    """The values `t` takes in `for t in 0:dt:trajectory.t[end]` (model_predictive_control.jl:87), shifted by t_start (the batch generalisation: t_start .+ (0:dt:t_end));
+    naive = True: the accumulation t += dt of rounds 1-5."""
+    if naive:
+        out = [t_start]
+        for _ in range(steps - 1):
+            out.append(out[-1] + dt)
+        return np.array(out)
+    r = julia_colon(0.0, dt, t_end).plus(t_start)
+    return np.array([r[k + 1] for k in range(steps)])
 
 
 def compute_linearization_nodes(P, U, traj, state6, control3, ts, dt, N_short, N_long, time_offset=float("nan"), prev=None):

@@ -35,7 +35,7 @@ class pg_config(C.Structure):
 # every symbol include/pigeon_mpc.h declares (tests check that the built library exports each one)
 SYMBOLS = ["pg_precision_bits", "pg_abi_layout", "pg_default_config", "pg_default_config_decoupled", "pg_create", "pg_destroy", "pg_last_error", "pg_get_config", "pg_get_u_normalization", "pg_set_trajectory", "pg_set_trajectories", "pg_set_trajectory_index",
            "pg_set_hji_grid", "pg_clear_hji_grid", "pg_reset", "pg_set_inputs", "pg_set_inputs_dev", "pg_compute_time_steps",
-           "pg_compute_linearization_nodes", "pg_update_qp", "pg_solve", "pg_get_next_control", "pg_get_next_control_dev", "pg_get_next_control_hji", "pg_get_next_control_hji_dev", "pg_step", "pg_step_dev", "pg_simulate_dev", "pg_get_state",
+           "pg_compute_linearization_nodes", "pg_update_qp", "pg_solve", "pg_get_next_control", "pg_get_next_control_dev", "pg_get_next_control_hji", "pg_get_next_control_hji_dev", "pg_step", "pg_step_dev", "pg_simulate_dev", "pg_simulate_clock", "pg_get_state",
            "pg_set_stream", "pg_set_fusion", "pg_set_pipeline", "pg_set_option", "pg_get_option", "pg_get_pipeline_fallbacks", "pg_synchronize", "pg_get_time_steps", "pg_get_nodes", "pg_get_path_coordinates", "pg_qp_len", "pg_get_qp", "pg_set_qp", "pg_get_solution",
            "pg_get_solve_info", "pg_get_polish_info", "pg_get_multipliers", "pg_get_phase_ms", "pg_hji_lookup", "pg_hji_lookup_dev", "pg_hji_lookup8_dev", "pg_hji_grid_dims", "pg_hji_slice", "pg_get_hji_constraint", "pg_get_walls"]
 

@@ -36,6 +36,9 @@ struct pg_handle {
     real *d_traj = nullptr; int traj_L = 0; int *d_traj_len = nullptr, *d_traj_idx = nullptr; int traj_idx_B = 0;
     real *d_state = nullptr, *d_control = nullptr, *d_other = nullptr;
     double *d_t0 = nullptr, *d_toff = nullptr;            // absolute time stays fp64 in both builds (tdouble)
+    // clock of pg_simulate_dev (model_predictive_control.jl:87, `for t in 0:dt:trajectory.t[end]`): start time per instance, the range, and the index of the element t0 holds.
+    // pg_set_inputs* restarts it (sim_idx = 0); consecutive pg_simulate_dev calls with the same dt continue it, so 4 + 40 steps see the times of 44
+    double* d_tstart = nullptr; JlRange sim_clk{}; int sim_idx = 0; double sim_dt = 0.0, sim_tend = 0.0; double traj_t_end = 0.0;
     int* d_solved = nullptr; uint8_t* d_mask = nullptr;     // d_mask: staging of pg_reset's per-instance mask
     double *d_ts = nullptr, *d_dt = nullptr, *d_prev_ts = nullptr;
     real *d_sep = nullptr, *d_nodes = nullptr, *d_qp = nullptr, *d_naux = nullptr;      // d_naux [cap][NN][4]: arguments of the angles k_nodes leaves to k_nodes_angles
@@ -199,7 +202,7 @@ int pg_default_config_decoupled(pg_config* c) {
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_in, h->d_out, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_todo, h->d_order, h->d_naux, h->d_progress, h->d_lat, h->d_lat_aux, h->d_lat_ws};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_todo, h->d_order, h->d_naux, h->d_progress, h->d_lat, h->d_lat_aux, h->d_lat_ws, h->d_tstart};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->sg.x) (void)hipGraphExecDestroy(h->sg.x);
@@ -237,6 +240,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     fill_dev_params(C, cfg); C.Ns = cfg->N_short; C.Nl = cfg->N_long; C.N = C.Ns + C.Nl; C.NN = C.N + 1;
     C.dt_short = cfg->dt_short; C.dt_long = cfg->dt_long; C.use_correction_step = cfg->use_correction_step; C.nsub = cfg->rk4_substeps;
     C.alias_prev_ts = 1; C.has_hji = 0; C.hji_eps = (real)cfg->hji_eps;
+    C.tg_short = jl_scalar_times_unitrange(cfg->dt_short, 0, cfg->N_short); C.tg_long = jl_scalar_times_unitrange(cfg->dt_long, 1, cfg->N_long); C.time_grid_naive = 0;
     C.un0 = (real)cfg->vehicle.delta_max; C.un1 = (real)fmax(-cfg->vehicle.Fx_min, cfg->vehicle.Fx_max);      // coupled_lat_long.jl:199
     C.fxmin_n = (real)(cfg->vehicle.Fx_min / fmax(-cfg->vehicle.Fx_min, cfg->vehicle.Fx_max));
     C.formulation = cfg->formulation; C.ux_dummy = (real)(0.5 * (cfg->control.V_min + cfg->control.V_max));
@@ -254,6 +258,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     ALLOC(h->d_in, h->in_bytes, char); ALLOC(h->d_out, h->out_bytes, char);
     h->d_state = (real*)h->d_in; h->d_control = h->d_state + cap * 6; h->d_other = h->d_control + cap * 3; h->d_t0 = (double*)(h->d_in + h->in_dbl_off); h->d_toff = h->d_t0 + cap;
     h->d_u = (real*)h->d_out; h->d_status = (int*)(h->d_u + cap * 3); h->d_iters = h->d_status + cap;
+    ALLOC(h->d_tstart, cap, double);
     ALLOC(h->d_solved, 2 * cap, int); h->d_wfail = h->d_solved + cap; ALLOC(h->d_mask, cap, uint8_t); ALLOC(h->d_ts, cap * NN, double); ALLOC(h->d_dt, cap * N, double); ALLOC(h->d_prev_ts, cap * NN, double);
     ALLOC(h->d_sep, cap * 4, real); ALLOC(h->d_nodes, cap * NN * 10, real); ALLOC(h->d_qp, cap * C.qp_len, real);
     ALLOC(h->d_x7, cap * 7, real); ALLOC(h->d_vg8, cap * 8, real); ALLOC(h->d_Mb, cap * 4, real);
@@ -392,6 +397,7 @@ static bool find_option(pg_handle* h, const char* name, OptRef* o) {
     if (n == "graph") return I(&h->graph_mode, 0, 1);
     if (n == "phase_timing") return I(&h->phase_timing, 0, 1);
     if (n == "hji_cell_dims") return I(&h->hji_cell_dims, 3, 7);
+    if (n == "time_grid_naive") return I(&C.time_grid_naive, 0, 1);
     // k_solve_lat (lateral QP)
     if (n == "lateral_solver") return I(&h->lateral_solver, 0, 2);
     if (n == "lat_split") return I(&h->split_lat, 0, 1);
@@ -497,6 +503,7 @@ static int install_trajectories(pg_handle* h, int n_traj, int Lmax, const int32_
     { int rc = up(h, h->d_traj, channels, (size_t)n_traj * stride); if (rc) return rc; }
     HIPCHK(h, hipMalloc((void**)&h->d_traj_len, (size_t)n_traj * sizeof(int)));
     HIPCHK(h, hipMemcpy(h->d_traj_len, L, (size_t)n_traj * sizeof(int), hipMemcpyHostToDevice));
+    h->traj_t_end = channels[(size_t)L[0] - 1];          // trajectory.t[end] of trajectory 0 (channel 0 = t): the stop of pg_simulate_dev's clock range
     TrajView& T = h->dc.traj; T.L = L[0];
     const real* p = h->d_traj; const size_t c = (size_t)Lmax;
     T.t = p; T.s = p + c; T.V = p + 2 * c; T.A = p + 3 * c; T.E = p + 4 * c; T.N = p + 5 * c; T.psi = p + 6 * c; T.kappa = p + 7 * c; T.edge_L = p + 8 * c; T.edge_R = p + 9 * c;
@@ -614,7 +621,7 @@ static int set_inputs(pg_handle* h, int32_t B, const void* state, const void* co
     REQUIRE(h, B >= 1 && B <= h->cfg.batch_capacity, "batch size outside [1, batch_capacity]");
     REQUIRE(h, state && control && t0, "state, control and t0 are required");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    h->B = B;
+    h->B = B; h->sim_idx = 0;      // (new times: the clock of pg_simulate_dev restarts from them)
     const hipMemcpyKind kind = host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     int rc;
     if (host) {
@@ -1061,12 +1068,31 @@ int pg_simulate_dev(pg_handle* h, int32_t steps, double dt, void* state_hist_dev
     REQUIRE(h, steps >= 1 && dt > 0.0, "pg_simulate_dev: steps >= 1 and dt > 0 required");
     const int B = h->B;
     real* state_hist_dev = (real*)state_hist_dev_; real* control_hist_dev = (real*)control_hist_dev_;
+    // the loop's clock (:87): t takes the elements of 0:dt:trajectory.t[end], here shifted by each instance's start time.  A call continues the clock of the previous one
+    // (same dt, same path end, no pg_set_inputs in between); otherwise it restarts from the times the inputs carry
+    if (h->sim_idx == 0 || h->sim_dt != dt || h->sim_tend != h->traj_t_end) {
+        HIPCHK(h, hipMemcpyAsync(h->d_tstart, h->d_t0, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        h->sim_clk = jl_colon(0.0, dt, h->traj_t_end); h->sim_idx = 1; h->sim_dt = dt; h->sim_tend = h->traj_t_end;
+    }
     for (int k = 0; k < steps; k++) {
         if (state_hist_dev) HIPCHK(h, hipMemcpyAsync(state_hist_dev + (size_t)k * B * 6, h->d_state, (size_t)B * 6 * sizeof(real), hipMemcpyDeviceToDevice, h->stream));      // push!(qs, state) :88
         if (control_hist_dev) HIPCHK(h, hipMemcpyAsync(control_hist_dev + (size_t)k * B * 3, h->d_control, (size_t)B * 3 * sizeof(real), hipMemcpyDeviceToDevice, h->stream)); // push!(us, control) :89
         if ((rc = launch_nodes(h, true)) || (rc = update_and_solve(h, nullptr))) return rc;          // :90-93 (time grid fused into the projection launch)
-        hipLaunchKernelGGL(k_advance, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, dt, h->d_state, h->d_control, h->d_u, h->d_t0);                  // :94-95
+        h->sim_idx++;                                                                                                                                         // (t0 now holds element sim_idx of the clock)
+        hipLaunchKernelGGL(k_advance, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->dc, B, dt, h->d_state, h->d_control, h->d_u, h->d_t0, h->d_tstart, h->sim_clk, h->sim_idx);      // :94-95
         LAUNCH_CHECK(h);
+    }
+    return PG_OK;
+}
+int pg_simulate_clock(pg_handle* h, double dt, int32_t steps, int32_t B, const double* t_start, double* out) {
+#pragma clang fp contract(off)
+    if (!h) return PG_ERR_INVALID;
+    REQUIRE(h, steps >= 1 && dt > 0.0 && B >= 1 && t_start && out, "pg_simulate_clock: steps >= 1, dt > 0, B >= 1 and both arrays required");
+    REQUIRE(h, h->d_traj, "pg_simulate_clock: no trajectory installed (its last time is the stop of the range)");
+    const JlRange clk = jl_colon(0.0, dt, h->traj_t_end);
+    for (int b = 0; b < B; b++) {
+        double acc = t_start[b];
+        for (int k = 0; k < steps; k++) { out[(size_t)k * B + b] = h->dc.time_grid_naive ? acc : jl_shifted_elem(clk, t_start[b], k + 1); acc = acc + dt; }
     }
     return PG_OK;
 }

@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include <type_traits>
 #include "pg_device.hpp"
+#include "pg_julia_range.hpp"
 
 namespace pg {
 
@@ -24,6 +25,8 @@ struct DevCfg {
     int dbg_instance;             // diagnostic kernel build only: instance whose interior-point trace is printed (-1 = none; option "diag_instance" of the -DPG_DIAG build)
     real ux_dummy;              // decoupled: value of the inert Ux slot of the embedded 8-state problem (strictly inside [V_min, V_max])
     int alias_prev_ts;            // the reference's MPCTimeSteps passes `ts` as prev_ts too (model_predictive_control.jl:15): same array
+    JlRange tg_short, tg_long;    // dt_short*(0:Ns), dt_long*(1:Nl) as Julia builds them (model_predictive_control.jl:25-26; pg_julia_range.hpp), made by pg_create
+    int time_grid_naive;          // option "time_grid_naive": 1 = t0 + dt*i with two roundings (rounds 1-5) instead of the range arithmetic; also t += dt in the closed loop
     int has_hji;
     real hji_eps;
     real un0, un1;              // u_normalization (coupled_lat_long.jl:199)
@@ -104,8 +107,8 @@ __global__ __launch_bounds__(64) void k_time_steps(DevCfg C, int B, const double
     double t = t0[b];
     double t0_long = t + C.Ns * C.dt_short;                                        // :21
     if (C.use_correction_step) t0_long = C.dt_long * ceil((t0_long + C.dt_short) / C.dt_long - 1.0);   // :23
-    for (int i = 0; i <= C.Ns; i++) T[i] = t + C.dt_short * i;                     // :25
-    for (int i = 1; i <= C.Nl; i++) T[C.Ns + i] = t0_long + C.dt_long * i;         // :26
+    for (int i = 0; i <= C.Ns; i++) T[i] = C.time_grid_naive ? t + C.dt_short * i : jl_shifted_elem(C.tg_short, t, i + 1);                     // :25  t0 .+ dt_short*(0:N_short)
+    for (int i = 1; i <= C.Nl; i++) T[C.Ns + i] = C.time_grid_naive ? t0_long + C.dt_long * i : jl_shifted_elem(C.tg_long, t0_long, i);       // :26  t0_long .+ dt_long*(1:N_long)
     for (int i = 0; i < C.N; i++) D[i] = T[i + 1] - T[i];                          // :27-29
     if (C.alias_prev_ts) for (int i = 0; i < C.NN; i++) PT[i] = T[i];              // prev_ts IS ts in the reference (:15)
 }
@@ -126,9 +129,13 @@ PG_DEV void time_grid_lane(const DevCfg& C, int i, double t, double* T, double* 
     PT[i] = T[i];                                                                   // :20
     double t0_long = t + C.Ns * C.dt_short;                                         // :21
     if (C.use_correction_step) t0_long = C.dt_long * ceil((t0_long + C.dt_short) / C.dt_long - 1.0);   // :23
-    const double Ti = i <= C.Ns ? t + C.dt_short * i : t0_long + C.dt_long * (i - C.Ns);            // :25-26
+    auto node_time = [&](int k) __attribute__((always_inline)) -> double {                         // :25-26 (Julia's range elements: pg_julia_range.hpp)
+        if (C.time_grid_naive) return k <= C.Ns ? t + C.dt_short * k : t0_long + C.dt_long * (k - C.Ns);
+        return k <= C.Ns ? jl_shifted_elem(C.tg_short, t, k + 1) : jl_shifted_elem(C.tg_long, t0_long, k - C.Ns);
+    };
+    const double Ti = node_time(i);
     const int n = i + 1;
-    const double Tn = n <= C.Ns ? t + C.dt_short * n : t0_long + C.dt_long * (n - C.Ns);
+    const double Tn = node_time(n);
     T[i] = Ti;
     if (i < C.N) D[i] = Tn - Ti;                                                    // :27-29
     if (C.alias_prev_ts) PT[i] = Ti;                                                // prev_ts IS ts in the reference (:15)
@@ -842,9 +849,10 @@ template <bool STAGED, int LPI, int WAVES = 1> __global__ __launch_bounds__(64, 
 //   state   <- propagate(dynamics, state, StepControl(dt, BicycleControl2(current_control)))   (RK4, nsub sub-steps, world-frame BicycleModel
 //              through the actuator limits: vehicle_dynamics.jl:111-135,293-314)
 //   control <- get_next_control(mpc)     (one-step actuation delay: the state moves with the OLD control)
-//   t       <- t + dt
+//   t       <- the next element of the loop's range `0:dt:trajectory.t[end]` (:87), shifted by the instance's start time: (t_start .+ clk)[idx] -- ONE rounding of
+//              t_start + (idx - 1) dt with dt lifted to its rational, as Julia's range gives it (rounds 1-5 accumulated t += dt: option "time_grid_naive")
 __global__ __launch_bounds__(64) void k_advance(DevCfg C, int B, tdouble dtp, real* __restrict__ state, real* __restrict__ control, const real* __restrict__ u_next,
-                                                tdouble* __restrict__ t0) {
+                                                tdouble* __restrict__ t0, const tdouble* __restrict__ t_start, JlRange clk, int idx) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     real* q = state + (size_t)b * 6; real* u = control + (size_t)b * 3;
@@ -870,7 +878,7 @@ __global__ __launch_bounds__(64) void k_advance(DevCfg C, int B, tdouble dtp, re
     }
     for (int k = 0; k < 6; k++) q[k] = x[k];
     u[0] = u_next[(size_t)b * 3]; u[1] = u_next[(size_t)b * 3 + 1]; u[2] = u_next[(size_t)b * 3 + 2];
-    t0[b] += dtp;
+    t0[b] = C.time_grid_naive ? t0[b] + dtp : jl_shifted_elem(clk, t_start[b], idx);
 }
 
 // ==================================================================================================================

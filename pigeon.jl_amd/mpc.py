@@ -248,6 +248,14 @@ class BatchedTrajectoryTrackingMPC:
             qh = dq.cpu().numpy().astype(np.float64); uh = du.cpu().numpy().astype(np.float64)
         return s, c, t, qh, uh
 
+    def simulate_clock(self, steps, t_start, dt=0.01):
+        """The times the rollout's loop variable takes, per instance: (t_start .+ (0:dt:trajectory.t[end]))[1:steps] as Julia's range arithmetic gives them
+        (model_predictive_control.jl:87; pg_simulate_clock) -- [steps][B]."""
+        import ctypes as C_
+        ts = _f64(t_start).reshape(-1).copy(); out = np.zeros((steps, len(ts)))
+        self._chk(self.lib.pg_simulate_clock(self.h, C_.c_double(dt), int(steps), len(ts), _p(ts), _p(out)), "pg_simulate_clock")
+        return out
+
     def synchronize(self):
         self._chk(self.lib.pg_synchronize(self.h), "pg_synchronize")
 
@@ -447,11 +455,11 @@ def simulate(mpc: BatchedTrajectoryTrackingMPC, plant_step, q0, u0, steps, dt=0.
     q = _f64(q0).reshape(-1, 6).copy(); u = _f64(u0, q.shape[:1] + (3,)).copy()
     t = np.zeros(q.shape[0]) if t_start is None else _f64(t_start, (q.shape[0],)).copy()
     hist = []
-    for _ in range(steps):
+    clock = mpc.simulate_clock(steps, t, dt)          # `for t in 0:dt:trajectory.t[end]` (:87) is a Julia range, not an accumulation
+    for k in range(steps):
         hist.append((q.copy(), u.copy()))
-        mpc.set_inputs(q, u, t, time_offset=time_offset)
+        mpc.set_inputs(q, u, clock[k], time_offset=time_offset)
         mpc.compute_time_steps_(); mpc.compute_linearization_nodes_(); mpc.update_QP_(); mpc.solve_()
         q = plant_step(q, u, dt)
         u = mpc.get_next_control()
-        t = t + dt
     return hist

@@ -164,8 +164,10 @@ def test_bench_last_line_is_compact_strict_json(n_gpus):
     full["secondary"] = {f"number_{i}": 1234567.891 * (i + 1) for i in range(10)}
     full["cpu_baseline"]["cpu_model"] = "AMD EPYC 9575F 64-Core Processor"; full["cpu_baseline"]["flags"] = "g++ -O2 -march=x86-64-v3 -std=c++17 -fPIC -ffp-contract=off -pthread"
     full["cpu_baseline"]["value_nan_example"] = float("nan")
+    full["timing"] = {"repeats": 5, "steps_per_block": 20, "block_s": [0.0107, 0.0106, 0.0108, 0.0107, 0.0109], "value_is": "median block", "ms_per_step_min": 0.53, "ms_per_step_median": 0.535, "ms_per_step_max": 0.545}
     if n_gpus > 1:
-        full.update(n_gpus=n_gpus, ranks=n_gpus, collective="rccl", per_rank_ms_per_step={"min": 0.66, "max": 0.69}, gather_ok=True)
+        full.update(n_gpus=n_gpus, ranks=n_gpus, collective="rccl", per_rank_ms_per_step={"min": 0.66, "max": 0.69}, gather_ok=True, rccl_version="2.26.6", xgmi=True,
+                    gather_ms={"per_rank_median": [0.021] * n_gpus, "bytes_per_rank": 98304, "how": "HIP events on the communication stream"})
         full.pop("cpu_baseline")
     txt = bench.compact_line(bench._json_safe(full))
     assert "\n" not in txt and len(txt) <= 4096, len(txt)
@@ -182,10 +184,37 @@ def test_bench_last_line_is_compact_strict_json(n_gpus):
             assert k in line["cpu_baseline"], k
     else:
         assert line["collective"] == "rccl" and line["ranks"] == n_gpus and "per_rank_ms_per_step" in line
+        # (a weak-scaling efficiency below 0.9 must be attributable from the one record -- launch overhead or the collective)
+        assert line["rccl_version"] == "2.26.6" and line["xgmi"] is True and len(line["gather_ms"]["per_rank_median"]) == n_gpus
+    assert line["timing"]["repeats"] == 5 and line["timing"]["ms_per_step_min"] <= line["timing"]["ms_per_step_median"] <= line["timing"]["ms_per_step_max"]
     # a record stuffed far beyond anything the bench produces still fits: the optional keys go first, the contract keys stay
     full["secondary"] = {f"number_{i}": float(i) for i in range(400)}
     txt = bench.compact_line(bench._json_safe(full))
     assert len(txt) <= 4096 and "roofline" in _strict(txt) and "secondary" not in _strict(txt)
+
+
+def test_roofline_fractions_are_consistent_with_the_counters():
+    """the bench line priced the linearisation launch at 0.42 of the fp64 vector peak with the flop count of an algorithm it no longer runs, above what its
+    counted instructions can deliver.  Now (i) the flops of that launch are counted from the ISA (tools/isa_mix.py -> profiles/isa_mix.json, taken at the device sources of
+    this tree), (ii) bench.roofline_consistency lists every kernel whose flop fraction exceeds its VALU issue fraction, and (iii) the committed records of this round
+    (profiles/r06_*/bench_line.json) carry an empty list."""
+    import glob
+    import json
+    import subprocess
+    import sys
+    import bench
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_mix.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    fl, isa = bench.linearize_flops_from_isa(4096, 10, 20, "f64")
+    assert isa is not None and not isa["stale"] and 3e9 < fl < 8e9                      # (the forward-mode count of rounds 1-5 was 1.0e10)
+    assert isa["arith_wave_insts"] <= isa["valu_wave_insts"] - isa["agpr_move_wave_insts"]
+    bad = bench.roofline_consistency({"roofline": {"kernels": [{"kernel": "a", "valu_flop_frac": 0.42, "valu_issue_frac": 0.27}, {"kernel": "b", "valu_flop_frac": 0.1, "executed_fp64_frac": 0.2, "valu_issue_frac": 0.3}]}})
+    assert len(bad) == 1 and bad[0].startswith("a:")
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r06_*", "bench_line.json"))):
+        rec = json.load(open(f))
+        assert bench.roofline_consistency(rec) == [] and rec.get("roofline_consistency") == [], f
+        for e in rec["roofline"]["kernels"]:
+            assert e["valu_flop_frac"] <= e["valu_issue_frac"], (f, e)
 
 
 def test_bench_emit_writes_the_full_record_and_prints_the_compact_line_last(tmp_path, capsys, monkeypatch):

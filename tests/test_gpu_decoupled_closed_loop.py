@@ -30,6 +30,7 @@ def oracle_lateral_loop(oracle_mod, tube, Ns, Nl, walls, Ww, state, control, t0,
         od, oc = ods[w], ocs[w]
         for b in range(w, B, nthr):
             q, u, t = state[b].copy(), control[b].copy(), float(t0[b])
+            clock = od.simulate_times(dt, float(tube.t[-1]), steps + 1, t_start=float(t0[b]))               # `for t in 0:dt:trajectory.t[end]` (:87) as Julia's range gives it
             for k in range(steps):
                 qh[k, b] = q; uh[k, b] = u
                 ts, dts = od.time_steps(t)                                                                   # compute_time_steps! :90
@@ -45,7 +46,7 @@ def oracle_lateral_loop(oracle_mod, tube, Ns, Nl, walls, Ww, state, control, t0,
                 X = od.split_x(xe[:od.n])
                 q = oc.plant_step(q, u, dt)                                                                  # propagate with the OLD control :94
                 u = od.next_control(X["delta"][1], ou[1, 1])                                                 # get_next_control :95 (decoupled_lat_long.jl:275-278)
-                t += dt
+                t = float(clock[k + 1])
             qf[b] = q; uf[b] = u
     with ThreadPoolExecutor(nthr) as ex:
         list(ex.map(work, range(nthr)))

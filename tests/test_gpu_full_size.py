@@ -190,14 +190,16 @@ def test_closed_loop_on_device_matches_oracle(pkg, oracle_mod, skidpad):
     orc = make_oracle(oracle_mod, skidpad)
     q = state.copy(); u = control.copy(); tt = t0.copy()
     un = np.array([orc.u_norm[0], orc.u_norm[1], orc.u_norm[1]])
+    # the loop's clock: `for t in 0:dt:trajectory.t[end]` (:87) shifted by each instance's start time, as Julia's range arithmetic gives it (oracle/julia_range.hpp)
+    clock = np.stack([orc.simulate_times(0.01, float(skidpad.t[-1]), steps + 1, t_start=float(t0[b])) for b in range(Bc)], axis=1)
     for k in range(steps):
         assert np.max(np.abs(qh[k] - q) / np.maximum(1.0, np.abs(q))) < 1e-5, k
         assert np.max(np.abs(uh[k] - u) / un) < 1e-5, k
         unext, _, it, st, _ = orc.step_batch(q, u, tt, time_offsets=toff, solver=0)
         assert np.all(st == pkg.SOLVED)
         q = np.stack([orc.plant_step(q[b], u[b], 0.01) for b in range(Bc)])
-        u = unext; tt = tt + 0.01
-    assert np.max(np.abs(s - q) / np.maximum(1.0, np.abs(q))) < 1e-5 and np.max(np.abs(c - u) / un) < 1e-5 and np.allclose(t, tt)
+        u = unext; tt = clock[k + 1]
+    assert np.max(np.abs(s - q) / np.maximum(1.0, np.abs(q))) < 1e-5 and np.max(np.abs(c - u) / un) < 1e-5 and np.array_equal(t, tt)      # (times: bit for bit)
     st, it, act, mu = mpc.solve_info()
     assert np.all(st == pkg.SOLVED)
 

@@ -49,6 +49,54 @@ def test_time_steps_and_projection(setup):
         assert abs(sep[b, 0] - s) <= 1e-9 * max(1, abs(s)) and abs(sep[b, 1] - e) <= 1e-9 and abs(sep[b, 2] - t) <= 1e-9 * max(1, abs(t))
 
 
+def test_time_grid_is_julias_range_arithmetic_bit_for_bit(pkg, oracle_mod, skidpad):
+    """model_predictive_control.jl:25-26 build the grid out of Julia ranges (`t0 .+ dt_short*(0:N_short)`, `t0_long .+ dt_long*(1:N_long)`: TwicePrecision reference and step,
+    one rounding per element).  Kernel (k_time_steps and the fused time grid of k_project), C++ oracle and the independent Python restatement agree BIT FOR BIT on the knife
+    edges of the correction step and on random times; option "time_grid_naive" gives the two-rounding grid of rounds 1-5, which differs.  And the clock of pg_simulate_dev
+    (`for t in 0:dt:trajectory.t[end]`, :87) is the range's elements, continued across calls -- not an accumulation.  (A reading of Julia 1.0's Base that could not be
+    executed: tests/test_time_grid_ranges.py.)"""
+    from oracle import spec_numpy as sp
+    rng = np.random.default_rng(3)
+    t0 = np.concatenate([[0.0, 0.09, 0.29, 0.49, 0.69, 1.29, 16.09, 12.29, 1e-9, 1234.5678], 0.01 * np.arange(0, 400, 7), rng.uniform(0.0, 150.0, 189)])
+    B = len(t0)
+    state, control, _, toff = pkg.synthetic.config2_inputs(skidpad, B, seed=5)
+    orc = make_oracle(oracle_mod, skidpad)
+    mpc = pkg.BatchedTrajectoryTrackingMPC(skidpad, B)
+    mpc.set_inputs(state, control, t0, time_offset=toff)
+    mpc.compute_time_steps_()
+    ts, dt, _ = mpc.time_steps()
+    mpc.compute_linearization_nodes_()          # (the step path writes the grid from inside the projection kernel: same bits)
+    ts_b, dt_b, _ = mpc.time_steps()
+    differ = 0
+    for b in range(B):
+        ots, odt = orc.time_steps(t0[b]); sts, sdt = sp.compute_time_steps(t0[b])
+        assert np.array_equal(ts[b], ots) and np.array_equal(dt[b], odt) and np.array_equal(ots, sts) and np.array_equal(odt, sdt), (b, t0[b])
+        differ += not np.array_equal(ots, sp.compute_time_steps(t0[b], naive=True)[0])
+    assert np.array_equal(ts, ts_b) and np.array_equal(dt, dt_b) and differ >= 20
+    mpc.step_dev(); mpc.synchronize()
+    assert np.array_equal(mpc.time_steps()[0], ts)
+    nv = pkg.BatchedTrajectoryTrackingMPC(skidpad, B, options={"time_grid_naive": 1})
+    nv.set_inputs(state, control, t0, time_offset=toff); nv.compute_time_steps_()
+    tsn = nv.time_steps()[0]
+    assert all(np.array_equal(tsn[b], sp.compute_time_steps(t0[b], naive=True)[0]) for b in range(B)) and not np.array_equal(tsn, ts)
+    # the closed loop's clock: 4 + 40 steps see the times of 44 (k / 100 rounded once for the instance that starts at 0), the host-side helper returns the same numbers
+    t_end = float(skidpad.t[-1])
+    clock = mpc.simulate_clock(45, t0)
+    assert all(np.array_equal(clock[:, b], orc.simulate_times(0.01, t_end, 45, t_start=float(t0[b]))) and np.array_equal(clock[:, b], sp.simulate_times(0.01, t_end, 45, t_start=float(t0[b]))) for b in range(B))
+    mpc.set_inputs(state, control, t0, time_offset=toff)
+    _, _, t4, _, _ = mpc.simulate_(4)
+    assert np.array_equal(t4, clock[4])
+    _, _, t44, _, _ = mpc.simulate_(40)
+    assert np.array_equal(t44, clock[44]) and t44[0] == sp.simulate_times(0.01, t_end, 45)[44]
+    nv.set_inputs(state, control, t0, time_offset=toff)
+    _, _, tn, _, _ = nv.simulate_(44)
+    acc = t0.copy()
+    for _ in range(44):
+        acc = acc + 0.01
+    assert np.array_equal(tn, acc) and not np.array_equal(tn, t44)
+    mpc.close(); nv.close()
+
+
 def test_cold_nodes(setup):
     mpc, orc, state, control, t0, toff = setup
     mpc.reset()

@@ -40,9 +40,9 @@ for d, out in (("stats", "kernel_stats.csv"), ("stats_dec", "kernel_stats_dec.cs
         stats[d] = list(csv.DictReader(open(ks[0])))
 assert "stats" in stats, "PART=1 of tools/gpu_profile.sh has not run"
 
-groups = {"headline": ["pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_mfma", "pmc_tcc", "pmc_wr", "pmc_wb"], "hji": ["pmc_fetch_hji", "pmc_write_hji"],
-          "dec": ["pmc_fetch_dec", "pmc_write_dec", "pmc_sq_dec", "pmc_sq2_dec"], "f32": ["pmc_fetch_f32", "pmc_write_f32", "pmc_sq_f32", "pmc_mfma_f32"],
-          "c3": ["pmc_fetch_c3", "pmc_write_c3", "pmc_sq_c3"]}
+groups = {"headline": ["pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_mfma", "pmc_flops", "pmc_tcc", "pmc_wr", "pmc_wb"], "hji": ["pmc_fetch_hji", "pmc_write_hji"],
+          "dec": ["pmc_fetch_dec", "pmc_write_dec", "pmc_sq_dec", "pmc_sq2_dec", "pmc_flops_dec"], "f32": ["pmc_fetch_f32", "pmc_write_f32", "pmc_sq_f32", "pmc_mfma_f32", "pmc_flops_f32"],
+          "c3": ["pmc_fetch_c3", "pmc_write_c3", "pmc_sq_c3", "pmc_flops_c3"]}
 summary = {}
 for g, dirs in groups.items():
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
@@ -96,6 +96,17 @@ def entry(group, stats_key, match):
                        ("SQ_ACTIVE_INST_VALU", "active_inst_valu"), ("SQ_WAVE_CYCLES", "wave_cycles"), ("SQ_WAVES", "waves")):
             if k_ in c:
                 e[n_] = c[k_]
+    for prec, peak in (("F64", 78.6), ("F32", 157.3)):
+        if f"SQ_INSTS_VALU_FMA_{prec}" in c:
+            # the hardware's own count of executed arithmetic (round 6): wave-level instruction counts by type; one instruction = 64 lanes whatever EXEC holds, FMA = 2 flops.
+            # Against the vector peak of that precision over the launch's average duration; also as a share of ALL counted VALU instructions
+            ar = c.get(f"SQ_INSTS_VALU_ADD_{prec}", 0.0) + c.get(f"SQ_INSTS_VALU_MUL_{prec}", 0.0) + c.get(f"SQ_INSTS_VALU_TRANS_{prec}", 0.0) + c[f"SQ_INSTS_VALU_FMA_{prec}"]
+            fl = 64.0 * (ar + c[f"SQ_INSTS_VALU_FMA_{prec}"])
+            secs = float(dom["AverageNs"]) * 1e-9
+            e["hw_flops"] = {"precision": prec.lower(), "add": c.get(f"SQ_INSTS_VALU_ADD_{prec}"), "mul": c.get(f"SQ_INSTS_VALU_MUL_{prec}"), "fma": c[f"SQ_INSTS_VALU_FMA_{prec}"], "trans": c.get(f"SQ_INSTS_VALU_TRANS_{prec}"),
+                             "int32": c.get("SQ_INSTS_VALU_INT32"), "int64": c.get("SQ_INSTS_VALU_INT64"), "cvt": c.get("SQ_INSTS_VALU_CVT"),
+                             "arith_insts_per_launch": ar, "valu_flops_per_launch": fl, "frac_of_vector_peak": fl / secs / 1e12 / peak, "peak_tflops": peak,
+                             "arith_share_of_valu_insts": (ar / c["SQ_INSTS_VALU"]) if c.get("SQ_INSTS_VALU") else None, "source": f"profiles/{tag}/pmc_summary.json [{group}]"}
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
         # busy cycles of the matrix pipe (summed over SIMDs) over 1024 SIMDs x the launch at 2.4 GHz; fp64 MFMA flops (512 per MOPS unit: MI355X_MICROARCH.md) against the dense fp64 peak
         secs = float(dom["AverageNs"]) * 1e-9
