@@ -64,6 +64,9 @@ struct pg_handle {
     size_t solve_lds = 0; bool solve_ring = false;
     real* d_walls = nullptr;                                    // [cap][N][2] wall extension
     char* d_lat_ws = nullptr; bool lat_mem = false, lat_mem_forced = false;            // k_solve_lat's workspace for horizons beyond 32 intervals (option "lat_workspace" = 1: at every horizon)
+    real* d_hand_r = nullptr; int* d_hand_i = nullptr;          // [cap][8] / [cap][16] hand-over records of k_solve_lat's unfinished instances (round 6: SolveOut::hand_mode)
+    int lat_handover = 1, lat_hand_target = 1024, lat_hand_min = 8, lat_hand_cap = 0, lat_hand_batch = 2048;      // options "lat_handover" (0 off, 1 = on), "lat_hand_target", "lat_hand_min", "lat_hand_cap", "lat_hand_batch" (smallest batch that hands over)
+    int64_t stat_lat_hand = 0;                                  // read-only option "stat_lat_handover_solves"
     real* d_lat_aux = nullptr;                                  // [cap][64][8] F, Bbar'P Bbar, Bbar'y per stage: what k_solve_lat reads the multiplier of a pinned rate row from
     real* d_lat = nullptr;                                      // [cap][N][LATP] packed stage records of the lateral formulation (k_qp_dec -> k_solve_lat)
     // hipGraph of a whole host-to-host warm step (pg_step of a small batch is launch-bound: one copy in, four kernels, one copy out; captured once, replayed while
@@ -139,14 +142,20 @@ static int configure_lateral(pg_handle* h, std::string* why) {
     if (!h->solve_lat) { C.lat_pack = nullptr; return PG_OK; }
     if (!h->d_lat && hipMalloc((void**)&h->d_lat, cap * N * LATP * sizeof(real)) != hipSuccess) { *why = "hipMalloc failed for the packed lateral stage records"; return PG_ERR_HIP; }
     C.lat_pack = h->d_lat;
-    if (!h->d_lat_aux && hipMalloc((void**)&h->d_lat_aux, cap * 64 * LAT_AUX * sizeof(real)) != hipSuccess) { *why = "hipMalloc failed for k_solve_lat's multiplier block"; return PG_ERR_HIP; }
+    if (!h->d_lat_aux && hipMalloc((void**)&h->d_lat_aux, (cap + 1) * 64 * LAT_AUX * sizeof(real)) != hipSuccess)      /* (+ 1: the spare block idle lane groups of a resumed launch write) */ { *why = "hipMalloc failed for k_solve_lat's multiplier block"; return PG_ERR_HIP; }
     C.lat_aux = h->d_lat_aux;
     // (round 4: with the wall rows the two-slot register variant spills 720 B per lane since the warm start was added -- 1.57 ms at N = 30 against 1.36 ms through the
     // workspace; without them the registers still win, 0.94 against 1.01 ms)
-    h->lat_mem = N > 32 || (cfg->walls && N > 16) || h->lat_mem_forced;
+    // (round 6: horizons of 17..32 intervals WITHOUT the wall rows used the two-slot register instantiation, k_solve_lat<2, .., false> -- 512 registers + 300 B of scratch, the
+    // largest code of the kernel.  With this round's edits hipcc 7.2 allocated one accumulation register to two live values there (rocgdb, precise memory violations on: the
+    // stage index of a slot visit read back from a76 was the high word of a double; memory access fault at the first launch).  Not a source bug that could be found: the
+    // instantiation is retired, those horizons take the workspace variant like the longer ones -- and its straggler hand-over with it)
+    h->lat_mem = N > 16 || h->lat_mem_forced;
     if (h->lat_mem) {
         if (!h->d_lat_ws && hipMalloc((void**)&h->d_lat_ws, lat_ws_bytes(cap)) != hipSuccess) { *why = "hipMalloc failed for k_solve_lat's workspace"; return PG_ERR_HIP; }
         C.lat_ws = h->d_lat_ws;
+        if (!h->d_hand_r && hipMalloc((void**)&h->d_hand_r, cap * LAT_HAND_R * sizeof(real)) != hipSuccess) { *why = "hipMalloc failed for k_solve_lat's hand-over records"; return PG_ERR_HIP; }
+        if (!h->d_hand_i && hipMalloc((void**)&h->d_hand_i, cap * LAT_HAND_I * sizeof(int)) != hipSuccess) { *why = "hipMalloc failed for k_solve_lat's hand-over records"; return PG_ERR_HIP; }
     } else C.lat_ws = nullptr;
     return PG_OK;
 }
@@ -202,7 +211,7 @@ int pg_default_config_decoupled(pg_config* c) {
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_in, h->d_out, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_todo, h->d_order, h->d_naux, h->d_progress, h->d_lat, h->d_lat_aux, h->d_lat_ws, h->d_tstart};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_todo, h->d_order, h->d_naux, h->d_progress, h->d_lat, h->d_lat_aux, h->d_lat_ws, h->d_tstart, h->d_hand_r, h->d_hand_i};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->sg.x) (void)hipGraphExecDestroy(h->sg.x);
@@ -278,7 +287,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         // defaults of k_solve_lat's tuning options (pg_set_option)
         C.lat_mu0_cost = real(10.0); C.lat_pin = 1; C.lat_polish2 = 1; C.lat_far_cost = real(3e4); C.lat_rho_scale = sizeof(real) == 8 ? real(1e3) : real(1.0); C.lat_polish_rounds = 3; C.lat_settle = 0;
         C.lat_warm_rounds = 2;      /* (2 since the two-launch warm step: an attempt that needs a third working set is cheaper to hand to the cold list: 2.03 -> 1.95 ms, 2.9 -> 2.7 with walls) */
-        C.lat_wipm = 0; C.lat_wmu = real(1e-2); C.lat_wtau = real(1e-4);
+        C.lat_wipm = 0; C.lat_wmu = real(1e-2); C.lat_wtau = real(1e-4); C.lat_aux_gate = 1; C.lat_stagger_us = 0;
         std::string why;
         if (configure_lateral(h, &why) != PG_OK) { g_create_error = why; free_all(h); delete h; return PG_ERR_HIP; }
     }
@@ -401,6 +410,14 @@ static bool find_option(pg_handle* h, const char* name, OptRef* o) {
     // k_solve_lat (lateral QP)
     if (n == "lateral_solver") return I(&h->lateral_solver, 0, 2);
     if (n == "lat_split") return I(&h->split_lat, 0, 1);
+    if (n == "lat_handover") return I(&h->lat_handover, 0, 1);
+    if (n == "nodes_serial") return I(&C.nodes_serial, 0, 1);
+    if (n == "lat_stagger_us") return I(&C.lat_stagger_us, 0, 1000);
+    if (n == "lat_aux_gate") return I(&C.lat_aux_gate, 0, 1);
+    if (n == "lat_hand_target") return I(&h->lat_hand_target, 0, 1 << 30);
+    if (n == "lat_hand_min") return I(&h->lat_hand_min, 1, 1 << 20);
+    if (n == "lat_hand_cap") return I(&h->lat_hand_cap, 0, 1 << 20);
+    if (n == "lat_hand_batch") return I(&h->lat_hand_batch, 1, 1 << 30);
     if (n == "lat_pack_only") return I(&h->lat_pack_only, 0, 1);
     if (n == "lat_polish2") return I(&C.lat_polish2, 0, 1);
     if (n == "lat_pin") return I(&C.lat_pin, 0, 1);
@@ -418,6 +435,7 @@ static bool find_option(pg_handle* h, const char* name, OptRef* o) {
     if (n == "stat_split_solve_launches") return S(&h->stat_split);
     if (n == "stat_single_solve_launches") return S(&h->stat_single);
     if (n == "stat_lat_two_launch_solves") return S(&h->stat_lat_two);
+    if (n == "stat_lat_handover_solves") return S(&h->stat_lat_hand);
 #ifdef PG_DIAG      // diagnostic build only (libpigeon_hip_diag.so): fault injection and traces have no place in the shipped libraries
     if (n == "diag_instance") return I(&C.dbg_instance, -1, 1 << 30);
     if (n == "diag_lin_groups") return I(&h->lin_groups, 0, 8);
@@ -724,7 +742,7 @@ static int launch_nodes(pg_handle* h, bool with_time_grid) {
     h->order_B = file ? B : 0;
     if (h->dc.formulation == PG_DECOUPLED) {
         auto kern = staged ? k_nodes_dec<true> : k_nodes_dec<false>;
-        hipLaunchKernelGGL(kern, grid, block, traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_sep, h->d_ts, h->d_dt, h->d_nodes, h->d_naux);
+        hipLaunchKernelGGL(kern, dim3((unsigned)((B + NODES_DEC_IPB - 1) / NODES_DEC_IPB)), block, traj_lds, h->stream, h->dc, B, h->d_state, h->d_control, h->d_toff, h->d_sep, h->d_ts, h->d_dt, h->d_nodes, h->d_naux);      // (NODES_DEC_LPN lanes per instance)
         LAUNCH_CHECK(h);
         const long nn = (long)B * h->dc.NN;
         hipLaunchKernelGGL(k_nodes_angles, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, h->dc, B, h->d_naux, h->d_nodes, (const int*)nullptr);
@@ -877,8 +895,8 @@ static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, u
         const int slots = (h->dc.N + 15) / 16;
 #define PG_LAT_LAUNCH(NS, W, M) hipLaunchKernelGGL((k_solve_lat<NS, W, M>), grid, dim3(64), h->lat_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, lat_prof)
 #define PG_LAT_LAUNCH_ANY() do { \
-        if (h->dc.walls) { if (h->lat_mem) PG_LAT_LAUNCH(1, true, true); else if (slots == 1) PG_LAT_LAUNCH(1, true, false); else PG_LAT_LAUNCH(2, true, false); } \
-        else { if (h->lat_mem) PG_LAT_LAUNCH(1, false, true); else if (slots == 1) PG_LAT_LAUNCH(1, false, false); else PG_LAT_LAUNCH(2, false, false); } } while (0)
+        if (h->dc.walls) { if (h->lat_mem) PG_LAT_LAUNCH(1, true, true); else PG_LAT_LAUNCH(1, true, false); } \
+        else { if (h->lat_mem) PG_LAT_LAUNCH(1, false, true); else PG_LAT_LAUNCH(1, false, false); } } while (0)
         // A batch in which every instance carries a previous solution (a closed loop after its first step) is solved in TWO launches: the warm attempts, then -- over the
         // list the first launch leaves -- the cold solves of what they did not serve, packed four per wavefront again (see k_solve_lat).  Option "lat_split" = 0: one launch.
         const bool two = h->split_lat && h->dc.polish && h->dc.warm_polish && h->dc.lat_warm_rounds > 0 && h->warm_B >= h->B && !lat_prof && !h->sg.capturing;
@@ -889,6 +907,27 @@ static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, u
             PG_LAT_LAUNCH_ANY();
             LAUNCH_CHECK(h);
             O.todo = nullptr; O.n_todo = nullptr; O.list = h->d_todo; O.n_list = h->d_todo + cap;
+        }
+        // Straggler hand-over (round 6, see k_solve_lat): a batch that starts cold interior points runs as TWO launches -- the first stops at a trip boundary once at most
+        // `lat_hand_target` instances of the batch are unfinished and files them, the second resumes those, ONE instance per wavefront (option "lat_handover" = 0: one launch
+        // as in round 5.  Measured and removed: resuming four per wavefront again, i.e. compaction only -- 3.34 against 3.25 ms for the single launch).  Only where the row
+        // state lives in the workspace (N > 32, or the wall rows), and not behind the warm attempts' own two launches.
+        const bool hand = h->lat_handover != 0 && h->lat_mem && !two && !h->sg.capturing && h->B >= h->lat_hand_batch && (h->lat_hand_target > 0 || h->lat_hand_cap > 0);
+        if (hand) {
+            const size_t cap = (size_t)h->cfg.batch_capacity;
+            int* const ctl = h->d_todo + cap;
+            HIPCHK(h, hipMemsetAsync(ctl, 0, 2 * sizeof(int), st)); h->stat_lat_hand++;
+            O.todo = h->d_todo; O.n_todo = ctl; O.hand_mode = 1; O.hand_cap = h->lat_hand_cap; O.hand_target = h->lat_hand_target; O.hand_min = h->lat_hand_min; O.hand_done = ctl + 1;
+            O.hand_r = h->d_hand_r; O.hand_i = h->d_hand_i;
+            if (h->dc.walls) hipLaunchKernelGGL((k_solve_lat<1, true, true, 16, 1>), grid, dim3(64), h->lat_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, lat_prof);
+            else hipLaunchKernelGGL((k_solve_lat<1, false, true, 16, 1>), grid, dim3(64), h->lat_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, lat_prof);
+            LAUNCH_CHECK(h);
+            O.todo = nullptr; O.n_todo = nullptr; O.list = h->d_todo; O.n_list = ctl; O.hand_mode = 2;
+            const size_t lds1 = lat_lds_doubles(h->dc.N, 1) * sizeof(real);          // one wavefront per listed instance; blocks beyond the list return at once
+            if (h->dc.walls) hipLaunchKernelGGL((k_solve_lat<1, true, false, 64, 2>), dim3((unsigned)h->B), dim3(64), lds1, st, h->dc, h->B, h->d_qp, h->d_nodes, O, lat_prof);
+            else hipLaunchKernelGGL((k_solve_lat<1, false, false, 64, 2>), dim3((unsigned)h->B), dim3(64), lds1, st, h->dc, h->B, h->d_qp, h->d_nodes, O, lat_prof);
+            LAUNCH_CHECK(h);
+            return PG_OK;
         }
         PG_LAT_LAUNCH_ANY();
 #undef PG_LAT_LAUNCH_ANY

@@ -62,6 +62,9 @@ struct DevCfg {
     int lat_settle;             // k_solve_lat: working-set decisions wait for settled multipliers (0 never, 1 warm attempts, 2 every polish)
     int lat_wipm; real lat_wmu, lat_wtau;      // k_solve_lat: interior point of a warm instance starts from the previous solution (floors of t lambda and of t)
     int lat_warm_rounds;        // k_solve_lat: working sets a warm attempt (previous step's set and multipliers) may try before the cold start takes over
+    int nodes_serial;           // option "nodes_serial" (A/B and parity tests): 1 = the cold seeding commits ONE node per pass -- the serial recurrence of the reference to the last bit
+    int lat_stagger_us;         // k_solve_lat (experiment, option "lat_stagger_us"): the wavefronts that share a CU start this many microseconds apart
+    int lat_aux_gate;           // k_solve_lat (option "lat_aux_gate"): the serial passes leave F / B'PB / B'y in lat_aux only while an instance of the wavefront is in a polish
     real* lat_aux;              // lateral formulation: [B][64][8] what the multiplier of a pinned rate row is read from (k_solve_lat, see its header)
     char* lat_ws;               // lateral formulation, horizons beyond 32 intervals: k_solve_lat's per-wavefront workspace (lat_ws_bytes(B); nullptr: not wanted)
     real* lat_pack;             // lateral formulation: [B][N][LATP] packed stage records for k_solve_lat, written by k_qp_dec next to the QP block (nullptr: not wanted)
@@ -380,14 +383,14 @@ template <bool STAGED, bool PUB> PG_DEV void nodes_body(const DevCfg& C, int B, 
         advance_vs(V, s, est.A, tau);
     }
     if (ahead) {
-        const real tolA = sizeof(real) == 8 ? real(1e-12) : real(4e-6);
+        const real tolA = sizeof(real) == 8 ? real(1e-12) : real(4e-6);      // (fp32: the limit and the solve's own value differ by a few ulp as a rule; tests/test_gpu_f32.py holds the nodes against the serial form, option "nodes_serial")
         const int base = (int)(threadIdx.x & 63u) - lp;        // first lane of this instance in the wavefront
         int i = C.Ns + 1, done = C.Ns + 1;                     // i: next node of this instance = its number of complete nodes; done: the wavefront's (min over its instances)
 #pragma unroll 1
         while (__any(i < C.NN)) {
             // (V, s) ahead on the commanded acceleration: every lane of the instance runs the same cheap chain and keeps the arguments of ITS node
             real Vs = V, ss = s, Vm = V, sm = s, Adm = real(0.0), kpm = real(0.0), taum = real(1.0), dsm = real(0.0), pVm = real(0.0), Agm = real(0.0);
-            real Vend[NODES_LPN], send[NODES_LPN], Agj[NODES_LPN], Vst[NODES_LPN], sst[NODES_LPN], tauj[NODES_LPN];
+            real Agj[NODES_LPN], Vst[NODES_LPN], sst[NODES_LPN], tauj[NODES_LPN];
 #pragma unroll
             for (int j = 0; j < NODES_LPN; j++) {
                 const int ii = i + j < C.NN ? i + j : C.NN - 1;
@@ -399,7 +402,6 @@ template <bool STAGED, bool PUB> PG_DEV void nodes_body(const DevCfg& C, int B, 
                 if (j == lp) { Vm = Vs; sm = ss; Adm = A_des; kpm = tjj.kappa; taum = tau; dsm = ds; pVm = tjj.V; Agm = At; }
                 Vst[j] = Vs; sst[j] = ss; tauj[j] = tau; Agj[j] = At;
                 advance_vs(Vs, ss, At, tau);
-                Vend[j] = Vs; send[j] = ss;
             }
             // this lane's node: the four-iteration solve from (V kappa, 0, 0, 0) (:128), exactly as the serial form evaluates it
             const Steady est = steady_state(P, Vm, Adm, kpm, 4, Vm * kpm, real(0.0), real(0.0), real(1.0), real(0.0), real(0.0), real(1.0), real(0.0), true);
@@ -408,7 +410,7 @@ template <bool STAGED, bool PUB> PG_DEV void nodes_body(const DevCfg& C, int B, 
             // nodes i .. i + c - 1 are valid: node i always, node i + j while every node before it returned the acceleration assumed
             int c = 1;
 #pragma unroll
-            for (int j = 1; j < NODES_LPN; j++) c += (c == j && ((mb >> (base + j - 1)) & 1ull) && i + j < C.NN) ? 1 : 0;
+            for (int j = 1; j < NODES_LPN; j++) c += (c == j && ((mb >> (base + j - 1)) & 1ull) && i + j < C.NN && !C.nodes_serial) ? 1 : 0;
             if (i < C.NN && lp < c) {
                 NodeRec rr;
                 rr.q0 = dsm; rr.q1 = est.Ux; rr.q2 = est.Uy; rr.q3 = est.r; rr.q4 = real(0.0); rr.q5 = real(0.0);      // q4 = -beta and u0 = delta are finished by k_nodes_angles
@@ -417,16 +419,16 @@ template <bool STAGED, bool PUB> PG_DEV void nodes_body(const DevCfg& C, int B, 
                 real* ax = naux + ((size_t)b * C.NN + i + lp) * 4;
                 ax[0] = est.ang_y; ax[1] = est.ang_x; ax[2] = est.ang_t; ax[3] = est.beta_is_tan ? est.tb : NAN;
             }
-            // state behind the last valid node: the chain's own value where that node matched, else from the acceleration ITS solve returned (every lane of the instance alike)
+            // state behind the last valid node: ALWAYS from the acceleration its own solve returned (every lane of the instance alike), as the serial form advances -- round 5
+            // kept the chain's value where that node had matched, i.e. the ASSUMED acceleration, up to 1e-12 (4e-6 in fp32) away per pass
             if (i < C.NN) {
                 const int jl = c - 1;
                 const real A_last = __shfl(est.A, base + jl);
-                const bool m_last = (mb >> (base + jl)) & 1ull;
-                real Vn = Vend[0], sn = send[0], Vs0 = Vst[0], ss0 = sst[0], tl = tauj[0];
+                real Vs0 = Vst[0], ss0 = sst[0], tl = tauj[0];
 #pragma unroll
-                for (int j = 1; j < NODES_LPN; j++) if (j == jl) { Vn = Vend[j]; sn = send[j]; Vs0 = Vst[j]; ss0 = sst[j]; tl = tauj[j]; }
+                for (int j = 1; j < NODES_LPN; j++) if (j == jl) { Vs0 = Vst[j]; ss0 = sst[j]; tl = tauj[j]; }
                 real Vx = Vs0, sx = ss0; advance_vs(Vx, sx, A_last, tl);
-                V = m_last ? Vn : Vx; s = m_last ? sn : sx;
+                V = Vx; s = sx;
                 i += c;
             }
             if constexpr (PUB) {
@@ -887,11 +889,21 @@ __global__ __launch_bounds__(64) void k_advance(DevCfg C, int B, tdouble dtp, re
 // never-active bounds on the three inert slots, so the same solve kernel serves both formulations (the inert slots are exactly
 // decoupled from the rest, the optimum of the embedded problem restricted to the live slots IS the lateral optimum).
 // Node record (10 doubles): (0, Ux parameter, Uy, r, dpsi, e, delta, Fx, 0, kappa).
+// Lanes per instance in k_nodes_dec (round 6).  The seeding of the lateral formulation is the same recurrence as the coupled one's cold branch, run at EVERY step (there is no warm
+// branch: decoupled_lat_long.jl:52-104) over 51 nodes at N = 50: one lane per instance took 0.31-0.33 ms -- half of a settled closed-loop step.  As in nodes_body: the long
+// nodes (four-iteration solves from (V kappa, 0, 0, 0)) are coupled through ONE number, the acceleration the solve returns, and that is the commanded acceleration pulled back
+// onto the friction circle unless a limit binds inside the solve.  LPN lanes run the cheap (V, s) chain LPN nodes ahead on that value, each solves ITS node, a ballot commits the
+// leading run of nodes whose solve returned the value assumed (to 1e-12), and the state behind the last committed node advances with that node's own solve value, as the serial
+// form does.  Option "nodes_serial": one node per pass -- the serial form exactly.
+#ifndef PG_NODES_DEC_LPN
+#define PG_NODES_DEC_LPN 4
+#endif
+constexpr int NODES_DEC_LPN = PG_NODES_DEC_LPN, NODES_DEC_IPB = 64 / NODES_DEC_LPN;
 template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg C, int B, const real* __restrict__ state, const real* __restrict__ control, const tdouble* __restrict__ toff,
                                                   const real* __restrict__ sep, const tdouble* __restrict__ ts, const tdouble* __restrict__ dt, real* __restrict__ nodes, real* __restrict__ naux) {
-    // One serial chain per instance (lane = instance), 51 nodes at N = 50: latency is its whole cost.  As in k_nodes: the arclength and time channels are searched in ONE
-    // lockstep loop per node (traj_lookup2; the wall edges reuse its knot), and the three inverse tangents of a seeded node -- they feed nothing in the chain -- are left to
-    // k_nodes_angles (lane = (instance, node)), launched behind this kernel: the same expressions on the same arguments, bit-identical nodes (round 4: 0.36 -> see DESIGN.md).
+    // As in k_nodes: the arclength and time channels are searched in ONE lockstep loop per node (traj_lookup2; the wall edges reuse its knot), and the three inverse tangents of a
+    // seeded node -- they feed nothing in the chain -- are left to k_nodes_angles (lane = (instance, node)), launched behind this kernel.
+    constexpr int LPN = NODES_DEC_LPN;
     extern __shared__ real sh_traj[];
     TrajView T = C.traj;
     if constexpr (STAGED) {                                 // single shared trajectory; compile-time so the searches compile to ds_read, not flat loads
@@ -899,8 +911,9 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg 
         __syncthreads();
         T.t = sh_traj; T.s = sh_traj + T.L;
     }
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.x * NODES_DEC_IPB + (int)threadIdx.x / LPN, lp = (int)threadIdx.x % LPN;
     if (b >= B) return;
+    const bool lead = lp == 0;                              // (the lane that stores what all lanes of the instance compute alike)
     if constexpr (!STAGED) T = traj_of(C, b);
     const DevVehicle& P = C.veh;
     const real* q0 = state + (size_t)b * 6; const real* u0 = control + (size_t)b * 3;
@@ -918,22 +931,28 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg 
         lateral_forces<real>(P, af, ar, Fxf0, Fxr0, sd, cd, Fyf0, Fyr0);               // :71
     }
     const bool traj_mode = !(toff[b] != toff[b]);
+    auto put_walls = [&](int i, int jk, real wk) __attribute__((always_inline)) {      // traj_edges_at_s(T, s): the knot and weight of the node's lookup
+        real* w = C.wall_edges + ((size_t)b * C.N + i - 1) * 2;
+        w[0] = T.edge_L[jk] + wk * (T.edge_L[jk + 1] - T.edge_L[jk]); w[1] = T.edge_R[jk] + wk * (T.edge_R[jk + 1] - T.edge_R[jk]);
+    };
+    // the measured node and the short horizon (one iteration from the measured state: not a fixed point -- serial, every lane of the instance alike, the lead lane stores)
+    const bool ahead = LPN > 1 && C.Ns + 1 < C.NN;
+    const int i_serial_end = ahead ? C.Ns + 1 : C.NN;
 #pragma unroll 1
-    for (int i = 0; i < C.NN; i++) {
-        real tau = (i == C.NN - 1) ? DT[i - 1] : DT[i];
+    for (int i = 0; i < i_serial_end; i++) {
+        const real tau = (i == C.NN - 1) ? DT[i - 1] : DT[i];
         TrajS tj; real s_ref; int jk; real wk;
         traj_lookup2(T, s, TS[i], tj, s_ref, &jk, &wk);
-        real A_des = tj.A + C.cp.k_V * (tj.V - V) / tau + (traj_mode ? C.cp.k_s * (s_ref - s) / tau / tau : real(0.0));   // :76
-        A_des = jmin(jmax(A_des, (C.cp.V_min - V) / tau), (C.cp.V_max - V) / tau);
+        const real A_des = commanded_accel(C.cp, tj.A, tj.V, V, s - s_ref, tau, traj_mode);                                   // :76-77
         NodeRec r; real A;
         real* ax = naux + ((size_t)b * C.NN + i) * 4;
         r.q0 = real(0.0); r.pV = real(0.0); r.pK = tj.kappa;
+        real a0 = NAN, a1 = real(0.0), a2 = real(0.0), a3 = NAN;
         if (i == 0) {
             r.q1 = Ux0; r.q2 = Uy0; r.q3 = r0; r.q4 = adiff(psi0, tj.psi); r.q5 = e0; r.u0 = d0; r.u1 = Fxf0 + Fxr0;      // :79-81
             real dUx, dUy, dr;
             world_body_rhs<real>(P, Ux0, Uy0, r0, d0, Fxf0 + Fxr0, dUx, dUy, dr);                                          // :82
-            A = (dUx - r0 * Uy0) * cb0 + (dUy + r0 * Ux0) * sb0;                                                             // :83
-            ax[0] = NAN;                                                                                                     // the measured state: nothing deferred
+            A = (dUx - r0 * Uy0) * cb0 + (dUy + r0 * Ux0) * sb0;                                                             // :83   (a0 = NaN: the measured state, nothing deferred)
         } else {
             const bool shortp = i <= C.Ns;
             Steady est = steady_state(P, V, A_des, tj.kappa, shortp ? 1 : 4, shortp ? r0 : V * tj.kappa, shortp ? beta0 : real(0.0), shortp ? sb0 : real(0.0), shortp ? cb0 : real(1.0),
@@ -941,15 +960,62 @@ template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg 
             r.q1 = est.Ux;
             r.q2 = shortp ? Uy0 : est.Uy; r.q3 = shortp ? r0 : est.r; r.q4 = shortp ? adiff(psi0, tj.psi) : -est.beta; r.q5 = shortp ? e0 : real(0.0);   // :85,92 (long nodes: q4 = -beta by k_nodes_angles)
             r.u0 = real(0.0); r.u1 = est.Fx; A = est.A;                                                                      // (u0 = delta by k_nodes_angles)
-            ax[0] = est.ang_y; ax[1] = est.ang_x; ax[2] = est.ang_t; ax[3] = (!shortp && est.beta_is_tan) ? est.tb : NAN;
+            a0 = est.ang_y; a1 = est.ang_x; a2 = est.ang_t; a3 = (!shortp && est.beta_is_tan) ? est.tb : NAN;
         }
-        put_node(ND, i, r);
-        if (C.walls && i >= 1) {                                                        // traj_edges_at_s(T, s): the knot and weight of the lookup above
-            real* w = C.wall_edges + ((size_t)b * C.N + i - 1) * 2;
-            w[0] = T.edge_L[jk] + wk * (T.edge_L[jk + 1] - T.edge_L[jk]); w[1] = T.edge_R[jk] + wk * (T.edge_R[jk + 1] - T.edge_R[jk]);
+        if (lead) {
+            put_node(ND, i, r);
+            ax[0] = a0; ax[1] = a1; ax[2] = a2; ax[3] = a3;
+            if (C.walls && i >= 1) put_walls(i, jk, wk);
         }
-        V = V + A * tau;
-        s = s + V * tau + A * tau * tau * real(0.5);
+        advance_vs(V, s, A, tau);                                                                                           // :100-101
+    }
+    if (ahead) {
+        const real tolA = sizeof(real) == 8 ? real(1e-12) : real(4e-6);
+        const int base = (int)(threadIdx.x & 63u) - lp;        // first lane of this instance in the wavefront
+        int i = C.Ns + 1;
+#pragma unroll 1
+        while (__any(i < C.NN)) {
+            // (V, s) ahead on the commanded acceleration pulled onto the friction circle: every lane of the instance runs the same cheap chain and keeps the arguments of ITS node
+            real Vs = V, ss = s, Vm = V, Adm = real(0.0), kpm = real(0.0), Agm = real(0.0), wkm = real(0.0); int jkm = 0;
+            real Vst[LPN], sst[LPN], tauj[LPN];
+#pragma unroll
+            for (int j = 0; j < LPN; j++) {
+                const int ii = i + j < C.NN ? i + j : C.NN - 1;
+                const real tau = (ii == C.NN - 1) ? DT[ii - 1] : DT[ii];
+                TrajS tjj; real s_ref; int jk; real wk;
+                traj_lookup2(T, ss, TS[ii], tjj, s_ref, &jk, &wk);
+                const real A_des = commanded_accel(C.cp, tjj.A, tjj.V, Vs, ss - s_ref, tau, traj_mode);
+                real At = A_des, Ar; limit_accel(P, Vs, tjj.kappa, At, Ar);
+                if (j == lp) { Vm = Vs; Adm = A_des; kpm = tjj.kappa; Agm = At; jkm = jk; wkm = wk; }
+                Vst[j] = Vs; sst[j] = ss; tauj[j] = tau;
+                advance_vs(Vs, ss, At, tau);
+            }
+            // this lane's node: the four-iteration solve from (V kappa, 0, 0, 0) (:91), exactly as the serial form evaluates it
+            const Steady est = steady_state(P, Vm, Adm, kpm, 4, Vm * kpm, real(0.0), real(0.0), real(1.0), real(0.0), real(0.0), real(1.0), real(0.0), true);
+            const bool match = fabs(est.A - Agm) <= tolA * (real(1.0) + fabs(Agm));       // (a NaN never matches: the solve's own value goes on, as in the serial form)
+            const unsigned long long mb = __ballot(match);
+            int c = 1;      // nodes i .. i + c - 1 are valid: node i always, node i + j while every node before it returned the acceleration assumed
+#pragma unroll
+            for (int j = 1; j < LPN; j++) c += (c == j && ((mb >> (base + j - 1)) & 1ull) && i + j < C.NN && !C.nodes_serial) ? 1 : 0;
+            if (i < C.NN && lp < c) {
+                NodeRec rr;
+                rr.q0 = real(0.0); rr.q1 = est.Ux; rr.q2 = est.Uy; rr.q3 = est.r; rr.q4 = -est.beta; rr.q5 = real(0.0);      // (q4 = -beta and u0 = delta are finished by k_nodes_angles)
+                rr.u0 = real(0.0); rr.u1 = est.Fx; rr.pV = real(0.0); rr.pK = kpm;
+                put_node(ND, i + lp, rr);
+                real* ax = naux + ((size_t)b * C.NN + i + lp) * 4;
+                ax[0] = est.ang_y; ax[1] = est.ang_x; ax[2] = est.ang_t; ax[3] = est.beta_is_tan ? est.tb : NAN;
+                if (C.walls) put_walls(i + lp, jkm, wkm);
+            }
+            if (i < C.NN) {      // the state behind the last valid node, from the acceleration ITS solve returned (every lane of the instance alike)
+                const int jl = c - 1;
+                const real A_last = __shfl(est.A, base + jl);
+                real Vs0 = Vst[0], ss0 = sst[0], tl = tauj[0];
+#pragma unroll
+                for (int j = 1; j < LPN; j++) if (j == jl) { Vs0 = Vst[j]; ss0 = sst[j]; tl = tauj[j]; }
+                V = Vs0; s = ss0; advance_vs(V, s, A_last, tl);
+                i += c;
+            }
+        }
     }
 }
 
@@ -1339,7 +1405,9 @@ struct SolveOut { real* sol_x; real* sol_sigma; real* u_out; int* status; int* i
                   const int* mode;                         // split launch of k_solve: the PREVIOUS launch's count of instances that needed the interior point (a stream-ordered device word).
                                                            // Non-zero: the rounds-only kernel returns at once and the full kernel takes the whole batch in its launch order instead of the list
                   real* u_out2;                            // pg_step_dev: the caller's control array, written next to u_out (saves the device-to-device copy behind the launch); may be nullptr
-                  int* n_whole; };                         // split launch: counts the launches in which the full kernel took the WHOLE batch (`mode` non-zero) -- read-only option "stat_whole_batch_solves"; may be nullptr
+                  int* n_whole;                            // split launch: counts the launches in which the full kernel took the WHOLE batch (`mode` non-zero) -- read-only option "stat_whole_batch_solves"; may be nullptr
+                  // k_solve_lat's straggler hand-over (round 6; pg_solve_lat.hip): 0 off, 1 = this launch hands its unfinished instances over (to `todo`), 2 = this launch resumes them (`list`)
+                  int hand_mode, hand_cap, hand_target, hand_min; int* hand_done; real* hand_r; int* hand_i; };
 
 #define NROW 16
 #define PG_POLISH_ROUNDS 6      // active-set rounds of the polish before it gives up

@@ -52,7 +52,7 @@
 constexpr int LAT_REC = 12;     // stage -> serial: (yy, yr, rr, ee, dd, Rhat) [overwritten by the roll-out: x+_{k+1}[0..4], v+_k], qhat[5], rhat
 constexpr int LAT_TAB = 12;     // serial tables: K[5], kff, Sinv, P cbar [5]
 constexpr int LAT_STRIDE = LAT_REC + LAT_TAB;
-__host__ __device__ inline size_t lat_lds_doubles(int N) { return (size_t)4 * N * LAT_STRIDE + 64 + 8; }
+__host__ __device__ inline size_t lat_lds_doubles(int N, int instances_per_wavefront = 4) { return (size_t)instances_per_wavefront * N * LAT_STRIDE + 64 + 8; }
 // horizons beyond 32 intervals keep the per-row interior-point state in a global workspace (see "stage-parallel part"): bytes per 16-stage slot of one wavefront
 // (13 rows x 64 lanes x (t, lambda) + 7 x 64 x 2 second-order terms + 64 x 4 eliminated slacks + 64 x 16 B of working-set words, fp64), four slots per wavefront
 constexpr size_t LAT_WS_SLOT_BYTES = 23552;
@@ -71,6 +71,9 @@ template <int K> PG_DEV real lat_bc(real v) {
 // all-reduce over the 16 lanes of a row (DPP butterflies: no LDS)
 PG_DEV real row_sum(real v) { v += dpp_move<0xB1>(v); v += dpp_move<0x4E>(v); v += dpp_move<0x124>(v); v += dpp_move<0x128>(v); return v; }
 PG_DEV real row_max(real v) { v = fmax(v, dpp_move<0xB1>(v)); v = fmax(v, dpp_move<0x4E>(v)); v = fmax(v, dpp_move<0x124>(v)); v = fmax(v, dpp_move<0x128>(v)); return v; }
+// all-reduce over the LPI lanes that serve one instance in the stage-parallel passes: a DPP row (16), or the whole wavefront (64: one instance per wavefront, round 6)
+template <int LPI> PG_DEV real grp_sum(real v) { v = row_sum(v); if constexpr (LPI == 64) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); } return v; }
+template <int LPI> PG_DEV real grp_max(real v) { v = row_max(v); if constexpr (LPI == 64) { v = fmax(v, __shfl_xor(v, 16)); v = fmax(v, __shfl_xor(v, 32)); } return v; }
 // reciprocal of the interior-point weights: hardware seed + ONE Newton step (~1e-14 relative in fp64; the Newton system only has to be consistent, see assemble)
 PG_DEV real lat_rcp(real x) {
 #ifdef PG_F32
@@ -98,28 +101,54 @@ __global__ __launch_bounds__(128) void k_lat_pack(DevCfg C, int b0, int n, const
     for (int i = 49; i < LATP; i++) Lp[i] = real(0.0);
 }
 
-template <int NSLOT, bool WALLS, bool MEM>
+// Round 6 -- STRAGGLER HAND-OVER (SolveOut::hand_mode).  A cold N = 50 batch needs 14 trips through the loop on average and 29 for its slowest instance, four instances
+// share a wavefront, and every wavefront is resident from the first cycle: after trip 17 a quarter of the instances but two thirds of the wavefronts are still alive, each at
+// the full price of a trip.  hand_mode = 1: a wavefront stops at a trip boundary once the batch has few enough unfinished instances (hand_target, counted on the device;
+// or after hand_cap trips), files the scalars of its unfinished instances in a small record (their row state already lives in the workspace) and appends them to the to-do
+// list.  hand_mode = 2: the launch behind it RESUMES the listed instances -- with LPI = 64 ONE instance per wavefront: the stage-parallel passes see one stage per lane (one
+// slot visit instead of four, the row state in registers), the serial passes run as before in the first DPP row.  A trip then costs a wavefront about half of what it costs
+// four instances sharing one, and the tail of the batch runs on a few hundred wavefronts instead of two thirds of the chip.
+constexpr int LAT_HAND_R = 8, LAT_HAND_I = 16;      // per-instance hand-over record: reals (mu, phi, rp0, mu0i, tol_cur, tol_cold), ints (see the save below)
+template <int NSLOT, bool WALLS, bool MEM, int LPI = 16, int HAND = 0>
 __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real* __restrict__ qp, const real* __restrict__ nodes, SolveOut O, unsigned long long* __restrict__ prof) {
+    static_assert(LPI == 16 || (LPI == 64 && NSLOT == 1 && !MEM), "one instance per wavefront keeps its single slot in registers");
+    static_assert(NSLOT == 1, "the two-slot register instantiation (horizons of 17..32 intervals) is retired: hipcc 7.2 allocated one accumulation register to two live values in it (see configure_lateral)");
+    static_assert(HAND == 0 || (HAND == 1 && MEM && LPI == 16) || (HAND == 2 && LPI == 64), "hand-over: out of a launch whose row state lives in the workspace, into one instance per wavefront");
+    // (HAND is a template argument, not a launch argument: the plain kernel carries none of the hand-over's code -- as a run-time flag it cost the round-5 launch 9 %)
     constexpr int NR = WALLS ? 13 : 10;
+    constexpr int NI = 64 / LPI;                          // instances per wavefront
     // diagnostic cycle counters (pg_debug_solve_cycles): 0 barrier terms, 1 matrix pass, 2 vector pass, 3 roll-outs, 4 Newton point / step rules, 5 everything else
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = prof ? clock64() : 0;
     auto stamp = [&](int slot) __attribute__((always_inline)) { if (prof) { const unsigned long long now = clock64(); pc[slot] += now - tprev; tprev = now; } };
-    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    // c: the lane's role in the serial passes (column / row of the stage matrices inside its DPP row); cs: its role in the stage-parallel passes (stage cs, cs + LPI, ...);
+    // frow: the lanes that run the serial passes (LPI = 64: ONE DPP row serves the wavefront's one instance; the other three rows sit the pass out under EXEC -- their loads
+    // would cost the CU's address unit what the first row's do)
+    const int lane = threadIdx.x, g = LPI == 16 ? lane >> 4 : 0, c = lane & 15, cs = LPI == 16 ? c : lane;
+    const bool frow = LPI == 16 || lane < 16;
     const int N = C.N, NN = C.NN;
+    constexpr bool resume = HAND == 2;
     // Two launches per WARM step (round 4, SolveOut::todo / list): the first runs the warm attempts only and appends what they do not serve (and the instances that are
     // cold or backing off) to a list; the second solves that list cold, four instances per wavefront again -- 150 wavefronts instead of the 600 that would otherwise
     // stay alive for one unserved instance each, i.e. one per CU instead of two or three: a pass through the loop costs 61-80 us there against 110 us with four per CU.
-    const bool listm = O.n_list != nullptr, defer = O.todo != nullptr;
+    const bool listm = O.n_list != nullptr, defer = O.todo != nullptr && O.hand_mode == 0;
     const int n_list = listm ? *O.n_list : B;
-    if (listm && 4 * (int)blockIdx.x >= n_list) return;          // (uniform over the block; nothing has been touched yet)
-    const int idx_raw = 4 * (int)blockIdx.x + g;
+    if (listm && NI * (int)blockIdx.x >= n_list) return;          // (uniform over the block; nothing has been touched yet)
+    const int idx_raw = NI * (int)blockIdx.x + g;
     const int b_raw = listm ? (idx_raw < n_list ? O.list[idx_raw] : B) : idx_raw;
     const bool valid = b_raw < B;
     const int b = valid ? b_raw : B - 1;                 // (a ragged last wavefront solves the last instance again and stores nothing)
+    if constexpr (LPI == 16) {
+        // (experiment, option "lat_stagger_us": the four wavefronts of a CU run their phases in lockstep and meet at the address unit in the load-heavy ones -- start them apart.
+        //  Blocks go round the XCDs, then round an XCD's 32 CUs: block b is wavefront (b / 256) % 4 of its CU)
+        if (C.lat_stagger_us > 0) {
+            const unsigned long long t_go = wall_clock64() + (unsigned long long)(((blockIdx.x >> 8) & 3u) * (unsigned)C.lat_stagger_us) * 100ull;
+            while (wall_clock64() < t_go) __builtin_amdgcn_s_sleep(64);
+        }
+    }
     extern __shared__ real lds[];
     real* const sI = lds + (size_t)g * N * LAT_STRIDE;   // this instance's region: rec[N][12] then tab[N][12]
     real* const sRec = sI; real* const sTab = sI + (size_t)N * LAT_REC;
-    real* const sDum = lds + (size_t)4 * N * LAT_STRIDE; // [64] sink for predicated-off stores
+    real* const sDum = lds + (size_t)NI * N * LAT_STRIDE; // [64] sink for predicated-off stores
     real* const sZero = sDum + 64;                       // a stored 0
     if (lane < 8) sZero[lane] = real(0.0);
     const QpOff o = qp_offsets(N);
@@ -128,7 +157,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // ---------------- addressing of the serial passes ----------------
     // The stage matrices come from the packed records k_qp_dec wrote (LATP doubles per stage, L2-resident): [8 i + m] = row i of [A | B0+Bf | Bf | c], m = 7 a stored 0.
     const real* const Lb = C.lat_pack + (size_t)b * N * LATP;
-    real* const aux = C.lat_aux + (size_t)b * 64 * LAT_AUX;      // (an invalid lane group of a ragged last wavefront writes the last instance's block again: same values)
+    real* const aux = C.lat_aux + (size_t)b * 64 * LAT_AUX;      // (an invalid lane group of a ragged last wavefront writes the last instance's block again: same values; a resumed launch has one instance per wavefront and no such group)
     // column distribution (matrix + vector pass): lane c holds X[0..3][c] of [Abar | Bbar | cbar]; row 4 is the constant x4; lanes 7..15 read the zero column
     const real* const colp = Lb + (c < 7 ? c : 7);
     const real cx4 = (c == 4 || c == 5) ? real(1.0) : real(0.0);
@@ -153,7 +182,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // ---------------- Riccati matrix pass (+ the predictor's vector recursion in column 6) ----------------
     // Software-pipelined by hand: the operands of stage k - 1 (global: the matrix column and dt; LDS: the stage-cost column, Rhat / rhat) are requested at the top of
     // stage k and first touched at the top of stage k - 1, a whole stage of arithmetic (~900 cycles) later.
-    auto matrix_pass = [&]() __attribute__((always_inline)) {
+    auto matrix_pass = [&](auto aux_on) __attribute__((always_inline)) {      // aux_on: leave F / B'PB / B'y of every stage in lat_aux (what a pinned row's multiplier is read from)
         real P[5], X[4], Xn[4], Qc[5], Qn[5], dtk, dtn, radd, raddn;
         {   // P_N = Qhat_{N-1} (cost on node N), p_N = qhat_{N-1}
             const real dtl = Lb[(size_t)(N - 1) * LATP + 48];
@@ -197,7 +226,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
                          : "v"(X[0]), "v"(X[1]), "v"(X[2]), "v"(X[3]), "v"(M[0]), "v"(M[1]), "v"(M[2]), "v"(M[3]));
             // (the stage-cost term is added LAST: on a pinned stage it is BIGP (x the pinned value) and would swallow Bbar'P Bbar / Bbar'y, which the row's multiplier needs)
             const real Gb = G0 + G1;                      // lanes 0..4: F; lane 5: Bbar' P Bbar; lane 6: Bbar' y
-            aux[(size_t)k * LAT_AUX + (c < 7 ? c : 7)] = Gb;      // (no branch in a pass loop: lanes 7..15 write the unused eighth slot; a wave-uniform "some instance is in a polish" test around the store measured SLOWER, 3.096 against 3.026 ms)
+            if constexpr (decltype(aux_on)::value) aux[(size_t)k * LAT_AUX + (c < 7 ? c : 7)] = Gb;      // (no branch in a pass loop: lanes 7..15 write the unused eighth slot; a wave-uniform "some instance is in a polish" test around the store measured SLOWER, 3.096 against 3.026 ms)
             const real G = Gb + radd;                     // lane 5: S = Rhat + Bbar' P Bbar; lane 6: f = rhat + Bbar' y
             const real Sinv = frcp(lat_bc<5>(G));
             const real Kc = -G * Sinv;                    // lanes 0..4: K[c]; lane 6: kff
@@ -223,7 +252,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
 
     // ---------------- Riccati vector pass (corrector): p_k = qhat + Abar' y + K f,  y = P cbar + p,  f = rhat + Bbar' y,  kff = -Sinv f ----------------
     // A stage is ~25 instructions here: the matrix columns are requested THREE stages ahead (L2 latency ~ several stages of this pass), the LDS operands one.
-    auto vector_pass = [&]() __attribute__((always_inline)) {
+    auto vector_pass = [&](auto aux_on) __attribute__((always_inline)) {
         constexpr int D = LAT_PREFETCH_V;
         real buf[D][4];
         const int mcoff = c < 5 ? (int)(sTab - sZero) + 7 + c : 0, mcmul = c < 5 ? LAT_TAB : 0;       // P cbar [c]
@@ -254,7 +283,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
                              : "+v"(acc) : "v"(y), "v"(buf[u][0]), "v"(buf[u][1]), "v"(buf[u][2]), "v"(buf[u][3]));
                 request(k - D, buf[u]);
                 const real by = lat_bc<5>(acc);        // lane 5's column is Bbar: Bbar'y
-                aux[(size_t)(k < 0 ? 0 : k) * LAT_AUX + ((c == 0 && k >= 0) ? 6 : 7)] = by;
+                if constexpr (decltype(aux_on)::value) aux[(size_t)(k < 0 ? 0 : k) * LAT_AUX + ((c == 0 && k >= 0) ? 6 : 7)] = by;
                 const real f = lo[3] + by;
                 *((c == 0 && k >= 0) ? sTab + LAT_TAB * (k < 0 ? 0 : k) + 5 : sDum + lane) = -lo[4] * f;
                 p = m5lt * (lo[2] + acc + lo[1] * f);
@@ -324,8 +353,15 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     constexpr int NREG = MEM ? 1 : NSLOT;
     real T[NREG][NR], L[NREG][NR], CR[NREG][NR];
     unsigned amask[NREG], mask_ipm[NREG], nmask[NREG]; real SN[NREG][3];
-    char* const wsw = MEM ? C.lat_ws + (size_t)blockIdx.x * 4 * LAT_WS_SLOT_BYTES : nullptr;
-    auto is_act = [&](int j) __attribute__((always_inline)) { return c + 16 * j < N; };
+    // HOME of an instance's row state: the workspace block of the wavefront that STARTED it and its lane group there.  A launch that starts instances is its own home; a
+    // resumed instance (hand_mode 2) names its home in the hand-over record
+    const int* const hrec_i = O.hand_i ? O.hand_i + (size_t)(valid ? b : 0) * LAT_HAND_I : nullptr;
+    const real* const hrec_r = O.hand_r ? O.hand_r + (size_t)(valid ? b : 0) * LAT_HAND_R : nullptr;
+    const int hb = resume ? hrec_i[12] : (int)blockIdx.x, hg = resume ? hrec_i[13] : g;
+    const int hl = 16 * hg + c;                              // (LPI = 16: this lane's position in the home wavefront)
+    char* const wsw = MEM ? C.lat_ws + (size_t)hb * 4 * LAT_WS_SLOT_BYTES : nullptr;
+    auto sidx = [&](int j) __attribute__((always_inline)) { return cs + LPI * j; };      // the stage this lane owns in slot j
+    auto is_act = [&](int j) __attribute__((always_inline)) { return cs + LPI * j < N; };
     auto for_slots = [&](auto&& body) __attribute__((always_inline)) {
         if constexpr (MEM) {
 #pragma unroll 1
@@ -339,7 +375,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         if constexpr (MEM) {
             // (lanes whose stage lies beyond the horizon -- 14 of the 16 lanes of the last slot at N = 50 -- carry t = lambda = 1 and touch no memory: a fifth of the
             // workspace traffic of the kernel was theirs)
-            const real2* p = reinterpret_cast<const real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES) + lane;
+            const real2* p = reinterpret_cast<const real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES) + hl;
             if (is_act(j)) {
 #pragma unroll
                 for (int r = 0; r < NR; r++) { const real2 v = p[64 * r]; Tl[r] = v.x; Ll[r] = v.y; }
@@ -354,7 +390,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     };
     auto put_tl = [&](int j, const real* Tl, const real* Ll) __attribute__((always_inline)) {
         if constexpr (MEM) {
-            real2* p = reinterpret_cast<real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES) + lane;
+            real2* p = reinterpret_cast<real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES) + hl;
             if (is_act(j)) {
 #pragma unroll
                 for (int r = 0; r < NR; r++) { real2 v; v.x = Tl[r]; v.y = Ll[r]; p[64 * r] = v; }
@@ -366,7 +402,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     };
     auto get_cr = [&](int j, real* Cl) __attribute__((always_inline)) {
         if constexpr (MEM) {
-            const real2* p = reinterpret_cast<const real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL) + lane;
+            const real2* p = reinterpret_cast<const real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL) + hl;
             if (is_act(j)) {
 #pragma unroll
                 for (int q = 0; q < NP; q++) { const real2 v = p[64 * q]; Cl[2 * q] = v.x; if (2 * q + 1 < NR) Cl[2 * q + 1] = v.y; }
@@ -381,7 +417,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     };
     auto put_cr = [&](int j, const real* Cl) __attribute__((always_inline)) {
         if constexpr (MEM) {
-            real2* p = reinterpret_cast<real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL) + lane;
+            real2* p = reinterpret_cast<real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL) + hl;
             if (is_act(j)) {
 #pragma unroll
                 for (int q = 0; q < NP; q++) { real2 v; v.x = Cl[2 * q]; v.y = 2 * q + 1 < NR ? Cl[2 * q + 1] : real(0.0); p[64 * q] = v; }
@@ -393,14 +429,14 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     };
     auto get_sn = [&](int j, real* s3) __attribute__((always_inline)) {
         if constexpr (MEM) {
-            const real2* p = reinterpret_cast<const real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL + WS_CR) + 2 * lane;
+            const real2* p = reinterpret_cast<const real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL + WS_CR) + 2 * hl;
             if (is_act(j)) { const real2 a = p[0], b_ = p[1]; s3[0] = a.x; s3[1] = a.y; s3[2] = b_.x; }
             else { s3[0] = real(0.0); s3[1] = real(0.0); s3[2] = real(0.0); }
         } else { s3[0] = SN[j][0]; s3[1] = SN[j][1]; s3[2] = SN[j][2]; }
     };
     auto put_sn = [&](int j, const real* s3) __attribute__((always_inline)) {
         if constexpr (MEM) {
-            real2* p = reinterpret_cast<real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL + WS_CR) + 2 * lane;
+            real2* p = reinterpret_cast<real2*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL + WS_CR) + 2 * hl;
             if (is_act(j)) { real2 a, b_; a.x = s3[0]; a.y = s3[1]; b_.x = s3[2]; b_.y = real(0.0); p[0] = a; p[1] = b_; }
         } else { SN[j][0] = s3[0]; SN[j][1] = s3[1]; SN[j][2] = s3[2]; }
     };
@@ -408,7 +444,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     struct Meta { unsigned am, mi, nm; };
     auto get_meta = [&](int j) __attribute__((always_inline)) -> Meta {
         Meta m;
-        if constexpr (MEM) { m.am = 0u; m.mi = 0u; m.nm = 0u; if (is_act(j)) { const uint4 v = *(reinterpret_cast<const uint4*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL + WS_CR + WS_SN) + lane); m.am = v.x; m.mi = v.y; m.nm = v.z; } }
+        if constexpr (MEM) { m.am = 0u; m.mi = 0u; m.nm = 0u; if (is_act(j)) { const uint4 v = *(reinterpret_cast<const uint4*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL + WS_CR + WS_SN) + hl); m.am = v.x; m.mi = v.y; m.nm = v.z; } }
         else { m.am = amask[j]; m.mi = mask_ipm[j]; m.nm = nmask[j]; }
         return m;
     };
@@ -418,15 +454,15 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         return m;
     };
     auto put_meta = [&](int j, const Meta& m) __attribute__((always_inline)) {
-        if constexpr (MEM) { if (is_act(j)) { uint4 v; v.x = m.am; v.y = m.mi; v.z = m.nm; v.w = 0u; *(reinterpret_cast<uint4*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL + WS_CR + WS_SN) + lane) = v; } }
+        if constexpr (MEM) { if (is_act(j)) { uint4 v; v.x = m.am; v.y = m.mi; v.z = m.nm; v.w = 0u; *(reinterpret_cast<uint4*>(wsw + (size_t)j * LAT_WS_SLOT_BYTES + WS_TL + WS_CR + WS_SN) + hl) = v; } }
         else { amask[j] = m.am; mask_ipm[j] = m.mi; nmask[j] = m.nm; }
     };
-    auto sx_of = [&](int j) __attribute__((always_inline)) { const int s = is_act(j) ? c + 16 * j : N - 1; return O.sol_x + (size_t)b * NN * 8 + 8 * (s + 1); };
-    auto sg_of = [&](int j) __attribute__((always_inline)) { const int s = is_act(j) ? c + 16 * j : N - 1; return O.sol_sigma + ((size_t)b * N + s) * 3; };
+    auto sx_of = [&](int j) __attribute__((always_inline)) { const int s = is_act(j) ? sidx(j) : N - 1; return O.sol_x + (size_t)b * NN * 8 + 8 * (s + 1); };
+    auto sg_of = [&](int j) __attribute__((always_inline)) { const int s = is_act(j) ? sidx(j) : N - 1; return O.sol_sigma + ((size_t)b * N + s) * 3; };
 
     struct StageC { real b[NR], h0[4], h1[4], dts; };
     auto load_consts = [&](int j, StageC& S) __attribute__((always_inline)) {
-        int s = is_act(j) ? c + 16 * j : N - 1;
+        int s = is_act(j) ? sidx(j) : N - 1;
         asm volatile("" : "+v"(s));        // opaque per call: these loads are invariant across the interior-point loop, and hoisted out of it they would sit in ~45 registers per slot
         const real2* cp = reinterpret_cast<const real2*>(Lb + (size_t)s * LATP + 32);
 #pragma unroll
@@ -574,7 +610,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
 #pragma unroll
         for (int i = 0; i < 4; i++) { g0 += S.h0[i] * ell[2 + i]; g1 += S.h1[i] * ell[2 + i]; }
         if (is_act(j)) {
-            real* rec = sRec + LAT_REC * (c + 16 * j);
+            real* rec = sRec + LAT_REC * (sidx(j));
             rec[6] = g0 - E.c10 * E.g1 * E.d1 - E.c20 * E.g2 * E.d2;
             rec[7] = g1 - E.c11 * E.g1 * E.d1 - E.c21 * E.g2 * E.d2;
             rec[8] = real(0.0);
@@ -616,7 +652,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     };
     auto put_vec = [&](int j, const real* qa, const real* qb, const Pin& pn) __attribute__((always_inline)) {
         if (is_act(j)) {
-            real* rec = sRec + LAT_REC * (c + 16 * j);
+            real* rec = sRec + LAT_REC * (sidx(j));
             rec[6] = qa[0]; rec[7] = qa[1]; rec[8] = real(0.0); rec[9] = qa[2]; rec[10] = qa[3]; rec[11] = pn.on ? -BIGP * pn.kff : qa[4];
             if (!pmode) {       // (a polish has no sigma mu part, and its verdict may still want the point in rec[0..4]: polish_decide stores it as the answer)
 #pragma unroll
@@ -626,7 +662,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     };
     // Newton point of slot j from the roll-out (x+ of node s+1, v+ of transition s) -> eliminated slacks and the slack of every row
     auto newton = [&](int j, const StageC& S, const Elim& E, real* xn, real& vn, real* sg3, real* tp) __attribute__((always_inline)) {
-        const real* rec = sRec + LAT_REC * (is_act(j) ? c + 16 * j : N - 1);
+        const real* rec = sRec + LAT_REC * (is_act(j) ? sidx(j) : N - 1);
 #pragma unroll
         for (int m = 0; m < 5; m++) xn[m] = rec[m];
         vn = rec[5];
@@ -636,23 +672,29 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         slacks(S, xn, vn, sg3[0], sg3[1], sg3[2], tp);
     };
 
-    // ---------------- start: v = 0 roll-out (dynamics- and rate-feasible), soft-row slacks just feasible + 1, t = max(slack, tau), lambda = mu0 / t ----------------
+    // state of the solve that a hand-over carries from one launch to the next (per instance, the same value in every lane that serves it)
+    constexpr int lat_bit[13] = {3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 0, 1, 2};      // local row -> bit of the 16-bit active mask (the numbering of the embedded stage: pigeon_mpc.h)
+    const real ntot = (real)(N * NR), intot = real(1.0) / ntot, tol = C.ipm_tol;
+    real rp0 = real(0.0), j0 = real(0.0), ms_next = real(0.0), mu0i = C.ipm_mu0, tol_cur = tol, tol_cold = tol, mu = real(0.0), phi = real(1.0);
+    int status = PG_MAX_ITER, it = 0, good = 0, wf = 0, trips = 0, trips0 = 0;      // (trips0: trips an instance had behind it when this launch took it over)
+    bool done = false, warm = false, warm_try = false, warm_failed = false, deferred = false, warm_tried = false, counted = false;
+    const int cap = C.ipm_max_iter;
     __syncthreads();
-    forward_pass(false);
+    if constexpr (!resume) {
+    // ---------------- start: v = 0 roll-out (dynamics- and rate-feasible), soft-row slacks just feasible + 1, t = max(slack, tau), lambda = mu0 / t ----------------
+    if (frow) forward_pass(false);
     wave_sync();
     stamp(3);
-    real rp0 = real(0.0), j0 = real(0.0);
-    constexpr int lat_bit[13] = {3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 0, 1, 2};      // local row -> bit of the 16-bit active mask (the numbering of the embedded stage: pigeon_mpc.h)
     // an instance whose previous step ended in a solved QP (see "warm start" below)
-    const bool warm = C.polish && C.warm_polish && O.solved[b] != 0 && (O.status[b] == PG_SOLVED || O.status[b] == PG_SOLVED_UNVERIFIED);
+    warm = C.polish && C.warm_polish && O.solved[b] != 0 && (O.status[b] == PG_SOLVED || O.status[b] == PG_SOLVED_UNVERIFIED);
     // ... whose interior point, should it be needed, starts from the PREVIOUS solution instead of the v = 0 roll-out: slacks of the previous primal point against the new
     // rows, floored at lat_wtau; multipliers the previous ones, floored at lat_wmu / t (every product t lambda >= lat_wmu: a centred neighbourhood of the old optimum)
     const bool wipm = warm && C.lat_wipm != 0 && O.n_list == nullptr;
-    real ms_next = real(0.0);       // sum t lambda over this lane's rows at the iterate just stored (the complementarity gap of the next loop top)
+    // (ms_next: sum t lambda over this lane's rows at the iterate just stored -- the complementarity gap of the next loop top)
     // the damped iterate (x_{s+1}, sigma) of a stage is kept in the output buffers (read-modify-write once per iteration), not in registers
     for_slots([&](int j) __attribute__((always_inline)) {
         const bool actj = is_act(j);
-        const int s = actj ? c + 16 * j : N - 1;
+        const int s = actj ? sidx(j) : N - 1;
         real* const SXj = sx_of(j); real* const SGj = sg_of(j);
         StageC S; load_consts(j, S);
         const real* rec = sRec + LAT_REC * s;
@@ -687,16 +729,15 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         put_tl(j, Tl, Ll); put_cr(j, Cl);
         Meta m0; m0.am = 0u; m0.mi = 0u; m0.nm = 0u; put_meta(j, m0);
     });
-    rp0 = row_max(rp0);
-    const real ntot = (real)(N * NR), intot = real(1.0) / ntot, tol = C.ipm_tol;
+    rp0 = grp_max<LPI>(rp0);
     // First barrier parameter: ipm_mu0, raised to lat_mu0_cost (10) x (cost of the starting point per row).  The v = 0 roll-out of an open-loop unstable 8 s horizon can start
     // kilometres off the path; from mu = 100 such an instance spends ~12 iterations with step lengths of a few per cent while mu climbs by itself to ~1e5, and it is these
     // instances (one in twenty) that set the kernel's time.  With the scaled start the slowest of the N = 50 batch needs 16 iterations to the hand-over instead of 27
     // and the mean drops from 9.8 to 9.0 (oracle/lat_ipm_numpy.py carries the same rule).
-    real mu0i = fmax(C.ipm_mu0, C.lat_mu0_cost * row_sum(j0) * intot);
+    mu0i = fmax(C.ipm_mu0, C.lat_mu0_cost * grp_sum<LPI>(j0) * intot);
     for_slots([&](int j) __attribute__((always_inline)) {
         real Tl[NR], Ll[NR]; get_tl(j, Tl, Ll);
-        const real* Lp = O.lam + ((size_t)b * N + (is_act(j) ? c + 16 * j : N - 1)) * 16;
+        const real* Lp = O.lam + ((size_t)b * N + (is_act(j) ? sidx(j) : N - 1)) * 16;
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             const real lw = wipm ? fmax(fmax(Lp[lat_bit[r]], real(0.0)), C.lat_wmu * lat_rcp(Tl[r])) : mu0i * lat_rcp(Tl[r]);
@@ -704,17 +745,13 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         }
         put_tl(j, Tl, Ll);
     });
-    if (wipm) mu0i = row_sum(ms_next) * intot;
+    if (wipm) mu0i = grp_sum<LPI>(ms_next) * intot;
     // with the polish on, the interior point only has to get close enough for the active set to show (polish_ipm_tol); if the polish does not verify from there, the
     // interior point resumes from the centred point (t, mu / t) and runs down to ipm_tol before the polish gets its second and last chance
     // (an instance that starts further than lat_far_cost per row from its optimum's neighbourhood -- the open-loop roll-out of an unstable horizon, kilometres off the
     // path -- almost never verifies at the hand-over tolerance: of the N = 50 batch 107 of 140 such instances do not, against 17 of 3956 of the rest.  It goes straight
     // down to ipm_tol and has the one polish behind it.)
-    real tol_cur = (C.polish && C.polish_ipm_tol > tol && !(row_sum(j0) * intot > C.lat_far_cost)) ? C.polish_ipm_tol : tol;
-    real mu = real(0.0), phi = real(1.0);
-    int status = PG_MAX_ITER, it = 0, good = 0;
-    bool done = false;
-    const int cap = C.ipm_max_iter;
+    tol_cur = (C.polish && C.polish_ipm_tol > tol && !(grp_sum<LPI>(j0) * intot > C.lat_far_cost)) ? C.polish_ipm_tol : tol;
     // Warm start of the ACTIVE SET (the reference runs the lateral QP with OSQP's WarmStart = true, decoupled_lat_long.jl:139, inside the same 100 Hz loop as the coupled
     // one, Pigeon.jl:34 / model_predictive_control.jl:80-100).  An instance whose previous step ended in a solved QP first tries the polish from that step's working set
     // and multipliers on the NEW QP data: a verified round IS the exact optimum of the new QP whatever the guess was.  The cold start above has been prepared anyway (its
@@ -723,16 +760,15 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // Back-off: the instances a warm attempt does not serve are mostly the same ones from step to step (far horizons whose working set turns over by a dozen rows per
     // 10 ms), and a failed attempt costs its rounds ON TOP of the cold solve -- in a kernel that ends with its slowest instance.  An instance whose attempt failed skips the
     // next 1, 3, 7, 15, 31 attempts (level in bits 8.., remaining skips in bits 0..7 of wfail[b]); a verified attempt clears the word.
-    const int wf = O.wfail ? O.wfail[b] : 0;
-    bool warm_try = warm && C.lat_warm_rounds > 0 && (wf & 0xFF) == 0 && !listm;
-    bool warm_failed = false, deferred = false;
-    const bool warm_tried = warm_try;
-    const real tol_cold = tol_cur;
+    wf = O.wfail ? O.wfail[b] : 0;
+    warm_try = warm && C.lat_warm_rounds > 0 && (wf & 0xFF) == 0 && !listm;
+    warm_tried = warm_try;
+    tol_cold = tol_cur;
     if (warm_try) {
         for_slots([&](int j) __attribute__((always_inline)) {
             real Tl[NR], Ll[NR]; get_tl(j, Tl, Ll);
             put_cr(j, Ll);
-            const int s = is_act(j) ? c + 16 * j : N - 1;
+            const int s = is_act(j) ? sidx(j) : N - 1;
             const unsigned pm = is_act(j) ? (unsigned)O.active[(size_t)b * N + s] : 0u;
             const real* Lp = O.lam + ((size_t)b * N + s) * 16;
             unsigned mk = 0u;
@@ -744,6 +780,44 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         pmode = 1; pchecks = 0; status = PG_SOLVED;
     }
     if (defer && !warm_try) { deferred = true; done = true; }      // (first of two launches: this instance has no warm attempt to make -- cold, or backing off: the second launch solves it)
+    } else {
+        // ---------------- resume (hand_mode 2): the scalars of the solve from the hand-over record, its row state from (or in) its home ----------------
+        {
+            mu = hrec_r[0]; phi = hrec_r[1]; rp0 = hrec_r[2]; mu0i = hrec_r[3]; tol_cur = hrec_r[4]; tol_cold = hrec_r[5];
+            it = hrec_i[0]; good = hrec_i[1]; status = hrec_i[2]; pmode = hrec_i[3]; pstat = hrec_i[4]; pchecks = hrec_i[5];
+            const int fl = hrec_i[6];
+            want_polish = (fl & 1) != 0; resume_ipm = (fl & 2) != 0; warm_try = (fl & 4) != 0; warm_failed = (fl & 8) != 0; warm_tried = (fl & 16) != 0; warm = (fl & 32) != 0;
+            wf = hrec_i[7]; trips = hrec_i[8]; trips0 = trips;
+        }
+        if constexpr (LPI == 64) {
+            // one instance per wavefront: lane cs takes stage cs of the home layout (slot cs / 16, lane 16 hg + cs % 16 of the home wavefront) into its registers, for good
+            const char* hw = C.lat_ws + ((size_t)hb * 4 + (size_t)(cs >> 4)) * LAT_WS_SLOT_BYTES;
+            const int hl64 = 16 * hg + (cs & 15);
+            if (is_act(0)) {
+                const real2* pt = reinterpret_cast<const real2*>(hw) + hl64;
+#pragma unroll
+                for (int r = 0; r < NR; r++) { const real2 v = pt[64 * r]; T[0][r] = v.x; L[0][r] = v.y; }
+                const real2* pc = reinterpret_cast<const real2*>(hw + WS_TL) + hl64;
+#pragma unroll
+                for (int q = 0; q < NP; q++) { const real2 v = pc[64 * q]; CR[0][2 * q] = v.x; if (2 * q + 1 < NR) CR[0][2 * q + 1] = v.y; }
+                const real2* ps = reinterpret_cast<const real2*>(hw + WS_TL + WS_CR) + 2 * hl64;
+                const real2 sa = ps[0], sb = ps[1]; SN[0][0] = sa.x; SN[0][1] = sa.y; SN[0][2] = sb.x;
+                const uint4 mv = *(reinterpret_cast<const uint4*>(hw + WS_TL + WS_CR + WS_SN) + hl64);
+                amask[0] = mv.x; mask_ipm[0] = mv.y; nmask[0] = mv.z;
+            } else {
+#pragma unroll
+                for (int r = 0; r < NR; r++) { T[0][r] = real(1.0); L[0][r] = real(1.0); CR[0][r] = real(0.0); }
+                SN[0][0] = real(0.0); SN[0][1] = real(0.0); SN[0][2] = real(0.0); amask[0] = 0u; mask_ipm[0] = 0u; nmask[0] = 0u;
+            }
+        }
+        for_slots([&](int j) __attribute__((always_inline)) {      // the complementarity gap of the iterate at hand (what the update pass of the last trip left in ms_next)
+            real Tl[NR], Ll[NR]; get_tl(j, Tl, Ll);
+            real ms = real(0.0);
+#pragma unroll
+            for (int r = 0; r < NR; r++) ms += Tl[r] * Ll[r];
+            ms_next += is_act(j) ? ms : real(0.0);
+        });
+    }
 
     // the verdict of a polish solve for this instance, from the per-slot results of polish_rows (the proposed sets are in the slots' meta words, the eliminated slacks
     // of the solve in their sn words): verified (the point is primal and dual feasible: a KKT point of the full QP, stored as the answer), refine (same set, held rows
@@ -753,11 +827,11 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     auto polish_decide = [&](bool unsettled_, bool second_half) __attribute__((always_inline)) -> bool {
         real chg = real(0.0), nch = real(0.0);
         for_slots([&](int j) __attribute__((always_inline)) { const Meta m = get_meta(j); chg = fmax(chg, (is_act(j) && m.nm != m.am) ? real(1.0) : real(0.0)); nch += is_act(j) ? (real)__popc(m.nm ^ m.am) : real(0.0); });
-        const real nchg = row_sum(nch);          // rows that enter or leave the working set in this verdict
-        const bool conv = !(row_max(unsettled_ ? real(1.0) : real(0.0)) > real(0.0));
+        const real nchg = grp_sum<LPI>(nch);          // rows that enter or leave the working set in this verdict
+        const bool conv = !(grp_max<LPI>(unsettled_ ? real(1.0) : real(0.0)) > real(0.0));
         // decisions wait for settled multipliers (lat_settle: 1 = warm attempts, 2 = every polish): on an open-loop unstable horizon a held row that is still 1e-5 off its
         // bound moves the far end of the trajectory by metres, and the rows that then LOOK violated send the working set off (traces: 1 -> 15 -> 90 rows changing per round)
-        const bool changed = row_max(chg) > real(0.0) && (conv || !(C.lat_settle == 2 || (C.lat_settle == 1 && warm_try)));
+        const bool changed = grp_max<LPI>(chg) > real(0.0) && (conv || !(C.lat_settle == 2 || (C.lat_settle == 1 && warm_try)));
         if (prof) {      // nibble: changed | settled << 1 | warm attempt << 2 | second half << 3; byte: rows that change
             const int nc = (int)fmin(nchg, real(255.0));
             if (dbg_n < 16) dbg_tr0 |= (unsigned long long)((changed ? 1 : 0) | (conv ? 2 : 0) | (warm_try ? 4 : 0) | (second_half ? 8 : 0)) << (4 * dbg_n);
@@ -768,7 +842,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         if (!changed && conv) {
             for_slots([&](int j) __attribute__((always_inline)) {
                 if (is_act(j) && valid) {
-                    const real* rec = sRec + LAT_REC * (c + 16 * j);
+                    const real* rec = sRec + LAT_REC * (sidx(j));
                     real* const SXj = sx_of(j); real* const SGj = sg_of(j);
                     real s3[3]; get_sn(j, s3);
 #pragma unroll
@@ -808,7 +882,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     bool need_a1 = true;
     while (true) {
         {   // complementarity gap and the stopping rules (per instance = per row of lanes)
-            const real mu_new = row_sum(ms_next) * intot;
+            const real mu_new = grp_sum<LPI>(ms_next) * intot;
             if (resume_ipm) {       // the polish at the hand-over tolerance did not verify: the interior point resumes where it stopped (t is untouched by the polish,
                                     // lambda was set aside) and goes all the way down before the polish gets its second and last chance
                 // (or the warm attempt did not verify: the cold start prepared before it takes over, at the tolerance a cold instance starts with)
@@ -820,7 +894,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
                     for (int r = 0; r < NR; r++) { Ll[r] = is_act(j) ? Cl[r] : real(1.0); msr += is_act(j) ? Tl[r] * Ll[r] : real(0.0); }
                     put_tl(j, Tl, Ll);
                 });
-                mu = row_sum(msr) * intot;
+                mu = grp_sum<LPI>(msr) * intot;
             } else if (!done && !pmode && !want_polish) {
                 mu = mu_new;
                 // (convergence is tested BEFORE the cap: an instance that meets its tolerances exactly at the cap is solved, not PG_MAX_ITER)
@@ -852,10 +926,13 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         need_a1 = false;
         wave_sync();
         stamp(0);
-        matrix_pass();
+        // (round 6: lat_aux is read by the polish check of a PINNED stage only -- a wavefront none of whose instances is in its polish runs the copy of the two passes
+        //  without those stores: one copy or the other per pass, no test per store (that was measured slower in round 5))
+        const bool aux_need = C.lat_aux_gate == 0 || __any(pmode != 0);
+        if (frow) { if (aux_need) matrix_pass(std::true_type{}); else matrix_pass(std::false_type{}); }
         wave_sync();
         stamp(1);
-        forward_pass(true);
+        if (frow) forward_pass(true);
         wave_sync();
         stamp(3);
         real rmax = real(0.0), S2 = real(0.0); bool unsettled = false;
@@ -868,7 +945,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             const Pin pn = pin_of(mt.am, S);
             real qa[5], qb[5];
             if (pmode) {
-                const real gpin = (pn.on && is_act(j)) ? pin_gradient(c + 16 * j, S, vn) : real(0.0);
+                const real gpin = (pn.on && is_act(j)) ? pin_gradient(sidx(j), S, vn) : real(0.0);
                 put_sn(j, sg3); mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, real(0.01) * ptol, unsettled, pn, gpin); put_meta(j, mt); put_tl(j, Tl, Ll);
                 if constexpr (SPLIT_CORR) {      // the refinement solve behind this one: same set, the multipliers just updated (no sigma mu in a polish)
                     weights(mt.am, Tl, Ll, Cl, S, real(0.0), false, it_, W, ell);
@@ -901,7 +978,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         });
         skip_second = false;
         if (pmode && !done) skip_second = polish_decide(unsettled, false);
-        rmax = row_max(rmax); S2 = row_sum(S2);
+        rmax = grp_max<LPI>(rmax); S2 = grp_sum<LPI>(S2);
         const real aaff = rmax > real(1.0) ? frcp(rmax) : real(1.0);
         // rounding floor: once mu is within 1e4 x of the tolerance and the affine direction can no longer move, further iterations only add noise
         if (!done && !pmode && mu <= real(1e4) * tol && aaff < real(0.3) && phi * fmax(rp0, real(1.0)) <= tol) { status = PG_SOLVED; if (C.polish && (tol_cur > tol || C.lat_polish2)) want_polish = true; else done = true; }
@@ -914,7 +991,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         if constexpr (!SPLIT_CORR) piped(F_TL | F_CR | F_META, [&](int j, In& in) __attribute__((always_inline)) { assemble(j, in, sgmu, false); });
         else for_slots([&](int j) __attribute__((always_inline)) {
             if (is_act(j)) {
-                real* rec = sRec + LAT_REC * (c + 16 * j);
+                real* rec = sRec + LAT_REC * (sidx(j));
                 constexpr int dst[5] = {6, 7, 9, 10, 11};
 #pragma unroll
                 for (int i = 0; i < 5; i++) { const real v = rec[dst[i]], w = rec[i]; rec[dst[i]] = pmode ? v : fma(sgmu, w, v); }      // (a select: sigma mu of an instance in its polish is not a number)
@@ -922,10 +999,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         });
         wave_sync();
         stamp(0);
-        vector_pass();
+        if (frow) { if (aux_need) vector_pass(std::true_type{}); else vector_pass(std::false_type{}); }
         wave_sync();
         stamp(2);
-        forward_pass(true);
+        if (frow) forward_pass(true);
         wave_sync();
         stamp(3);
         real T1 = real(0.0), T2 = real(0.0);
@@ -939,7 +1016,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             put_sn(j, sg3);
             if (pmode) { if (!skip_second && !resume_ipm) {
                 const Pin pn = pin_of(mt.am, S);
-                const real gpin = (pn.on && is_act(j)) ? pin_gradient(c + 16 * j, S, vn) : real(0.0);
+                const real gpin = (pn.on && is_act(j)) ? pin_gradient(sidx(j), S, vn) : real(0.0);
                 mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, ptol, unsettled, pn, gpin); put_meta(j, mt); put_tl(j, Tl, Ll); } }
             else {
                 real rm = real(0.0), t1 = real(0.0), t2 = real(0.0);
@@ -956,7 +1033,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             }
         });
         if (pmode && !done && !skip_second && !resume_ipm) (void)polish_decide(unsettled, true);
-        rmax = row_max(rmax); T1 = row_sum(T1); T2 = row_sum(T2);
+        rmax = grp_max<LPI>(rmax); T1 = grp_sum<LPI>(T1); T2 = grp_sum<LPI>(T2);
         const real alpha = rmax > real(0.995) ? real(0.995) * frcp(rmax) : real(1.0);
         // rounding floor, second form: a step that would MULTIPLY mu near the tolerance is a Newton direction computed at a conditioning the arithmetic no longer
         // carries -- the iterate at hand is as good as it gets
@@ -970,7 +1047,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         piped(F_TL | F_CR | F_SN | F_META, [&](int j, In& in) __attribute__((always_inline)) {
             const bool actj = is_act(j);
             StageC& S = in.S; real* const Tl = in.Tl; real* const Ll = in.Ll; real* const Cl = in.Cl; real* const s3 = in.s3;
-            const real* rec = sRec + LAT_REC * (actj ? c + 16 * j : N - 1);
+            const real* rec = sRec + LAT_REC * (actj ? sidx(j) : N - 1);
             real xn[5], tp[NR];
 #pragma unroll
             for (int m = 0; m < 5; m++) xn[m] = rec[m];
@@ -1001,13 +1078,35 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         }
         wave_sync();
         stamp(4);
+        trips++;
+        if constexpr (HAND == 1) {
+            // Hand-over (see the header of this kernel).  Every instance that finishes is counted once on the device; at a trip boundary a wavefront with unfinished
+            // instances stops when the batch has at most hand_target of them left (not before hand_min trips), or after hand_cap trips.
+            if (done && !counted && valid && cs == 0) atomicAdd(O.hand_done, 1);
+            counted = counted || done;
+            const int fin = __builtin_amdgcn_readfirstlane(__hip_atomic_load(O.hand_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const bool go = (O.hand_cap > 0 && trips >= O.hand_cap) || (O.hand_target > 0 && trips >= O.hand_min && B - fin <= O.hand_target);
+            if (go && !__all(done)) {
+                if (!done) {
+                    if (valid && cs == 0) {
+                        real* hr = O.hand_r + (size_t)b * LAT_HAND_R; int* hi = O.hand_i + (size_t)b * LAT_HAND_I;
+                        hr[0] = mu; hr[1] = phi; hr[2] = rp0; hr[3] = mu0i; hr[4] = tol_cur; hr[5] = tol_cold;
+                        hi[0] = it; hi[1] = good; hi[2] = status; hi[3] = pmode; hi[4] = pstat; hi[5] = pchecks;
+                        hi[6] = (want_polish ? 1 : 0) | (resume_ipm ? 2 : 0) | (warm_try ? 4 : 0) | (warm_failed ? 8 : 0) | (warm_tried ? 16 : 0) | (warm ? 32 : 0);
+                        hi[7] = wf; hi[8] = trips; hi[12] = hb; hi[13] = hg;
+                    }
+                    deferred = true;
+                }
+                break;
+            }
+        }
     }
     stamp(5);
-    if (prof && valid && c == 0) for (int i = 0; i < 6; i++) prof[(size_t)b * 6 + i] = pc[i];
-    if (prof && valid && c == 0) { unsigned long long* tl = prof + (size_t)B * 6 + 1024 + (size_t)b * 3; tl[0] = dbg_tr0; tl[1] = dbg_tr1; tl[2] = (unsigned long long)dbg_n; }      // (the [B][3] region k_solve uses for its timeline)
+    if (prof && valid && cs == 0) for (int i = 0; i < 6; i++) prof[(size_t)b * 6 + i] = pc[i];
+    if (prof && valid && cs == 0) { unsigned long long* tl = prof + (size_t)B * 6 + 1024 + (size_t)b * 3; tl[0] = dbg_tr0; tl[1] = dbg_tr1; tl[2] = (unsigned long long)dbg_n | ((unsigned long long)trips << 32) | ((unsigned long long)trips0 << 48); }      // (the [B][3] region k_solve uses for its timeline)
 
     // ---------------- outputs ----------------
-    if (valid && c == 0) {
+    if (valid && cs == 0) {
         if (deferred) O.todo[atomicAdd(O.n_todo, 1)] = b;
         if (O.wfail && !listm) {        // (the back-off word belongs to the launch that makes -- or skips -- the warm attempt)
             const int lvl = (wf >> 8) & 0xFF, nl = lvl < 5 ? lvl + 1 : 5;
@@ -1016,13 +1115,13 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     }
     if (valid && !deferred) {
         real* SX = O.sol_x + (size_t)b * NN * 8;
-        if (c < 8) SX[c] = c == 1 ? C.ux_dummy : (c >= 2 && c < 6 ? Q[o.qcurr + c] : (c == 6 ? Q[o.ucurr] : real(0.0)));
+        if (cs < 8) SX[cs] = cs == 1 ? C.ux_dummy : (cs >= 2 && cs < 6 ? Q[o.qcurr + cs] : (cs == 6 ? Q[o.ucurr] : real(0.0)));
         for_slots([&](int j) __attribute__((always_inline)) {
             if (is_act(j)) {
                 real Tl[NR], Ll[NR], Cl[NR]; get_tl(j, Tl, Ll); get_cr(j, Cl);
                 const Meta m = get_meta(j);
                 unsigned mask = 0;
-                real* const Lst = O.lam + ((size_t)b * N + c + 16 * j) * 16;
+                real* const Lst = O.lam + ((size_t)b * N + sidx(j)) * 16;
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
                     const bool on = pstat > 0 ? ((m.am >> r) & 1u) : (pmode ? ((m.mi >> r) & 1u) : (Ll[r] > Tl[r]));      // the polish's verified set / the interior point's at hand-over
@@ -1030,10 +1129,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
                     // multipliers for the next step's warm attempt: the verified set's, else the interior point's (set aside in the second-order slot at the hand-over)
                     Lst[lat_bit[r]] = pstat > 0 ? Ll[r] : (pmode ? Cl[r] : Ll[r]);      // (indexed like the mask bits: pg_get_multipliers)
                 }
-                O.active[(size_t)b * N + c + 16 * j] = (uint16_t)mask;
+                O.active[(size_t)b * N + sidx(j)] = (uint16_t)mask;
             }
         });
-        if (c == 0) {
+        if (cs == 0) {
             // get_next_control (decoupled_lat_long.jl:275-278): delta of node 2 from the QP, Fx of the seeded node 2
             const real d = (O.sol_x + (size_t)b * NN * 8 + 8)[6] * C.un0, Fx = nodes[((size_t)b * NN + 1) * 10 + 7];
             real* U = O.u_out + (size_t)b * 3;
