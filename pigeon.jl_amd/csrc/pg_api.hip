@@ -64,8 +64,9 @@ struct pg_handle {
     size_t solve_lds = 0; bool solve_ring = false;
     real* d_walls = nullptr;                                    // [cap][N][2] wall extension
     char* d_lat_ws = nullptr; bool lat_mem = false, lat_mem_forced = false;            // k_solve_lat's workspace for horizons beyond 32 intervals (option "lat_workspace" = 1: at every horizon)
+    real* d_lat_spc = nullptr;                                  // k_solve_lat's lane-contiguous stage constants (lat_spc_bytes)
     real* d_hand_r = nullptr; int* d_hand_i = nullptr;          // [cap][8] / [cap][16] hand-over records of k_solve_lat's unfinished instances (round 6: SolveOut::hand_mode)
-    int lat_handover = 1, lat_hand_target = 1024, lat_hand_min = 8, lat_hand_cap = 0, lat_hand_batch = 2048;      // options "lat_handover" (0 off, 1 = on), "lat_hand_target", "lat_hand_min", "lat_hand_cap", "lat_hand_batch" (smallest batch that hands over)
+    int lat_handover = 1, lat_hand_target = 1500, lat_hand_min = 8, lat_hand_cap = 0, lat_hand_batch = 2048;      // options "lat_handover" (0 off, 1 = on), "lat_hand_target", "lat_hand_min", "lat_hand_cap", "lat_hand_batch" (smallest batch that hands over)
     int64_t stat_lat_hand = 0;                                  // read-only option "stat_lat_handover_solves"
     real* d_lat_aux = nullptr;                                  // [cap][64][8] F, Bbar'P Bbar, Bbar'y per stage: what k_solve_lat reads the multiplier of a pinned rate row from
     real* d_lat = nullptr;                                      // [cap][N][LATP] packed stage records of the lateral formulation (k_qp_dec -> k_solve_lat)
@@ -154,6 +155,8 @@ static int configure_lateral(pg_handle* h, std::string* why) {
     if (h->lat_mem) {
         if (!h->d_lat_ws && hipMalloc((void**)&h->d_lat_ws, lat_ws_bytes(cap)) != hipSuccess) { *why = "hipMalloc failed for k_solve_lat's workspace"; return PG_ERR_HIP; }
         C.lat_ws = h->d_lat_ws;
+        if (!h->d_lat_spc && hipMalloc((void**)&h->d_lat_spc, lat_spc_bytes((int)cap, N)) != hipSuccess) { *why = "hipMalloc failed for k_solve_lat's stage constants"; return PG_ERR_HIP; }
+        C.lat_spc = h->d_lat_spc;
         if (!h->d_hand_r && hipMalloc((void**)&h->d_hand_r, cap * LAT_HAND_R * sizeof(real)) != hipSuccess) { *why = "hipMalloc failed for k_solve_lat's hand-over records"; return PG_ERR_HIP; }
         if (!h->d_hand_i && hipMalloc((void**)&h->d_hand_i, cap * LAT_HAND_I * sizeof(int)) != hipSuccess) { *why = "hipMalloc failed for k_solve_lat's hand-over records"; return PG_ERR_HIP; }
     } else C.lat_ws = nullptr;
@@ -211,7 +214,7 @@ int pg_default_config_decoupled(pg_config* c) {
 
 static void free_all(pg_handle* h) {
     void* ptrs[] = {h->d_traj, h->d_traj_len, h->d_traj_idx, h->d_in, h->d_out, h->d_solved, h->d_ts, h->d_dt, h->d_prev_ts, h->d_sep, h->d_nodes,
-                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_todo, h->d_order, h->d_naux, h->d_progress, h->d_lat, h->d_lat_aux, h->d_lat_ws, h->d_tstart, h->d_hand_r, h->d_hand_i};
+                    h->d_qp, h->d_x7, h->d_vg8, h->d_Mb, h->d_solx, h->d_sigma, h->d_mu, h->d_active, h->d_knots, h->d_hnodes, h->d_hcells, h->d_pol_u2, h->d_pol_u, h->d_pol_src, h->d_ws4, h->d_walls, h->d_mask, h->d_polish, h->d_lam, h->d_todo, h->d_order, h->d_naux, h->d_progress, h->d_lat, h->d_lat_aux, h->d_lat_ws, h->d_tstart, h->d_hand_r, h->d_hand_i, h->d_lat_spc};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->sg.x) (void)hipGraphExecDestroy(h->sg.x);
@@ -287,7 +290,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
         // defaults of k_solve_lat's tuning options (pg_set_option)
         C.lat_mu0_cost = real(10.0); C.lat_pin = 1; C.lat_polish2 = 1; C.lat_far_cost = real(3e4); C.lat_rho_scale = sizeof(real) == 8 ? real(1e3) : real(1.0); C.lat_polish_rounds = 3; C.lat_settle = 0;
         C.lat_warm_rounds = 2;      /* (2 since the two-launch warm step: an attempt that needs a third working set is cheaper to hand to the cold list: 2.03 -> 1.95 ms, 2.9 -> 2.7 with walls) */
-        C.lat_wipm = 0; C.lat_wmu = real(1e-2); C.lat_wtau = real(1e-4); C.lat_aux_gate = 1; C.lat_stagger_us = 0;
+        C.lat_wipm = 0; C.lat_wmu = real(1e-2); C.lat_wtau = real(1e-4); C.lat_aux_gate = 1;
         std::string why;
         if (configure_lateral(h, &why) != PG_OK) { g_create_error = why; free_all(h); delete h; return PG_ERR_HIP; }
     }
@@ -412,7 +415,6 @@ static bool find_option(pg_handle* h, const char* name, OptRef* o) {
     if (n == "lat_split") return I(&h->split_lat, 0, 1);
     if (n == "lat_handover") return I(&h->lat_handover, 0, 1);
     if (n == "nodes_serial") return I(&C.nodes_serial, 0, 1);
-    if (n == "lat_stagger_us") return I(&C.lat_stagger_us, 0, 1000);
     if (n == "lat_aux_gate") return I(&C.lat_aux_gate, 0, 1);
     if (n == "lat_hand_target") return I(&h->lat_hand_target, 0, 1 << 30);
     if (n == "lat_hand_min") return I(&h->lat_hand_min, 1, 1 << 20);
@@ -916,7 +918,7 @@ static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, u
         if (hand) {
             const size_t cap = (size_t)h->cfg.batch_capacity;
             int* const ctl = h->d_todo + cap;
-            HIPCHK(h, hipMemsetAsync(ctl, 0, 2 * sizeof(int), st)); h->stat_lat_hand++;
+            HIPCHK(h, hipMemsetAsync(ctl, 0, 3 * sizeof(int), st)); h->stat_lat_hand++;      // [0] listed from the front, [1] finished instances, [2] listed from the back
             O.todo = h->d_todo; O.n_todo = ctl; O.hand_mode = 1; O.hand_cap = h->lat_hand_cap; O.hand_target = h->lat_hand_target; O.hand_min = h->lat_hand_min; O.hand_done = ctl + 1;
             O.hand_r = h->d_hand_r; O.hand_i = h->d_hand_i;
             if (h->dc.walls) hipLaunchKernelGGL((k_solve_lat<1, true, true, 16, 1>), grid, dim3(64), h->lat_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, lat_prof);

@@ -63,8 +63,8 @@ struct DevCfg {
     int lat_wipm; real lat_wmu, lat_wtau;      // k_solve_lat: interior point of a warm instance starts from the previous solution (floors of t lambda and of t)
     int lat_warm_rounds;        // k_solve_lat: working sets a warm attempt (previous step's set and multipliers) may try before the cold start takes over
     int nodes_serial;           // option "nodes_serial" (A/B and parity tests): 1 = the cold seeding commits ONE node per pass -- the serial recurrence of the reference to the last bit
-    int lat_stagger_us;         // k_solve_lat (experiment, option "lat_stagger_us"): the wavefronts that share a CU start this many microseconds apart
     int lat_aux_gate;           // k_solve_lat (option "lat_aux_gate"): the serial passes leave F / B'PB / B'y in lat_aux only while an instance of the wavefront is in a polish
+    real* lat_spc;              // lateral formulation: k_solve_lat's lane-contiguous copy of the stage constants of its stage-parallel passes (LAT_SPC_Q; nullptr: not wanted)
     real* lat_aux;              // lateral formulation: [B][64][8] what the multiplier of a pinned rate row is read from (k_solve_lat, see its header)
     char* lat_ws;               // lateral formulation, horizons beyond 32 intervals: k_solve_lat's per-wavefront workspace (lat_ws_bytes(B); nullptr: not wanted)
     real* lat_pack;             // lateral formulation: [B][N][LATP] packed stage records for k_solve_lat, written by k_qp_dec next to the QP block (nullptr: not wanted)
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(64) void k_advance(DevCfg C, int B, tdouble dtp, re
 // leading run of nodes whose solve returned the value assumed (to 1e-12), and the state behind the last committed node advances with that node's own solve value, as the serial
 // form does.  Option "nodes_serial": one node per pass -- the serial form exactly.
 #ifndef PG_NODES_DEC_LPN
-#define PG_NODES_DEC_LPN 4
+#define PG_NODES_DEC_LPN 8
 #endif
 constexpr int NODES_DEC_LPN = PG_NODES_DEC_LPN, NODES_DEC_IPB = 64 / NODES_DEC_LPN;
 template <bool STAGED> __global__ __launch_bounds__(64) void k_nodes_dec(DevCfg C, int B, const real* __restrict__ state, const real* __restrict__ control, const tdouble* __restrict__ toff,

@@ -59,6 +59,12 @@ constexpr size_t LAT_WS_SLOT_BYTES = 23552;
 __host__ __device__ inline size_t lat_ws_bytes(int B) { return (size_t)((B + 3) / 4) * 4 * LAT_WS_SLOT_BYTES; }
 // what the multiplier of a pinned rate row is read from (C.lat_aux, per instance and stage): F[0..4] = Bbar'P Abar, Bbar'P Bbar, Bbar'y, -   (L2-resident, written by every matrix pass)
 constexpr int LAT_AUX = 8;
+// Stage constants of the STAGE-PARALLEL passes in the order the wavefront reads them (round 6): C.lat_spc [home wavefront][slot][LAT_SPC_Q][64 lanes] real2 -- H (4), G (2), the
+// steering bounds, the rate bounds, (dt, 0) of the stage a lane owns in that slot.  Every slot visit of every pass used to read these 136 B per lane from the packed records,
+// lane = stage: each of the nine load instructions touched 64-128 cache lines, twelve visits per trip, four wavefronts per CU -- the address unit, not the bytes, was what the
+// visits queued for.  The wavefront that starts an instance files the constants once, lane-contiguous: the same nine loads now touch eight lines each.
+constexpr int LAT_SPC_Q = 9;
+__host__ __device__ inline size_t lat_spc_bytes(int B, int N) { return (size_t)((B + 3) / 4) * ((N + 15) / 16) * LAT_SPC_Q * 64 * 2 * sizeof(real); }
 
 // broadcast of lane K of each 16-lane row (compiler builtin: hazards padded by hipcc; v_mov_b64_dpp row_newbcast)
 template <int K> PG_DEV real lat_bc(real v) {
@@ -131,20 +137,15 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // cold or backing off) to a list; the second solves that list cold, four instances per wavefront again -- 150 wavefronts instead of the 600 that would otherwise
     // stay alive for one unserved instance each, i.e. one per CU instead of two or three: a pass through the loop costs 61-80 us there against 110 us with four per CU.
     const bool listm = O.n_list != nullptr, defer = O.todo != nullptr && O.hand_mode == 0;
-    const int n_list = listm ? *O.n_list : B;
+    // (a resumed launch, HAND = 2: the list has two ends -- the instances that were still in their interior point at the hand-over, which have the most trips ahead of them,
+    //  are filed from the front and start first; the ones already in their polish, one to three trips from done, from the back of the same array, counted in n_list[2])
+    const int n_front = listm ? *O.n_list : B;
+    const int n_list = (listm && HAND == 2) ? n_front + O.n_list[2] : n_front;
     if (listm && NI * (int)blockIdx.x >= n_list) return;          // (uniform over the block; nothing has been touched yet)
     const int idx_raw = NI * (int)blockIdx.x + g;
-    const int b_raw = listm ? (idx_raw < n_list ? O.list[idx_raw] : B) : idx_raw;
+    const int b_raw = listm ? (idx_raw < n_list ? (HAND == 2 && idx_raw >= n_front ? O.list[B - 1 - (idx_raw - n_front)] : O.list[idx_raw]) : B) : idx_raw;
     const bool valid = b_raw < B;
     const int b = valid ? b_raw : B - 1;                 // (a ragged last wavefront solves the last instance again and stores nothing)
-    if constexpr (LPI == 16) {
-        // (experiment, option "lat_stagger_us": the four wavefronts of a CU run their phases in lockstep and meet at the address unit in the load-heavy ones -- start them apart.
-        //  Blocks go round the XCDs, then round an XCD's 32 CUs: block b is wavefront (b / 256) % 4 of its CU)
-        if (C.lat_stagger_us > 0) {
-            const unsigned long long t_go = wall_clock64() + (unsigned long long)(((blockIdx.x >> 8) & 3u) * (unsigned)C.lat_stagger_us) * 100ull;
-            while (wall_clock64() < t_go) __builtin_amdgcn_s_sleep(64);
-        }
-    }
     extern __shared__ real lds[];
     real* const sI = lds + (size_t)g * N * LAT_STRIDE;   // this instance's region: rec[N][12] then tab[N][12]
     real* const sRec = sI; real* const sTab = sI + (size_t)N * LAT_REC;
@@ -461,17 +462,33 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     auto sg_of = [&](int j) __attribute__((always_inline)) { const int s = is_act(j) ? sidx(j) : N - 1; return O.sol_sigma + ((size_t)b * N + s) * 3; };
 
     struct StageC { real b[NR], h0[4], h1[4], dts; };
+    constexpr bool USE_SPC = MEM || HAND == 2;          // (the lane-contiguous copy of the stage constants: wherever an instance has a home in the workspace)
+    const int nslot_h = (N + 15) >> 4;
+    auto spc_of = [&](int s) __attribute__((always_inline)) {      // stage s of this instance in its home wavefront's block: slot s / 16, lane 16 hg + s % 16
+        return reinterpret_cast<real2*>(C.lat_spc) + ((size_t)hb * nslot_h + (size_t)(s >> 4)) * LAT_SPC_Q * 64 + 16 * hg + (s & 15);
+    };
     auto load_consts = [&](int j, StageC& S) __attribute__((always_inline)) {
         int s = is_act(j) ? sidx(j) : N - 1;
         asm volatile("" : "+v"(s));        // opaque per call: these loads are invariant across the interior-point loop, and hoisted out of it they would sit in ~45 registers per slot
-        const real2* cp = reinterpret_cast<const real2*>(Lb + (size_t)s * LATP + 32);
+        real2 h4[4], g01, g23, dd, rr;
+        if constexpr (USE_SPC) {
+            const real2* sp = spc_of(s);
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const real2 h = cp[i]; S.h0[i] = h.x; S.h1[i] = h.y; }
-        const real2 g01 = cp[4], g23 = cp[5], dd = cp[6], rr = cp[7];
+            for (int i = 0; i < 4; i++) h4[i] = sp[64 * i];
+            g01 = sp[64 * 4]; g23 = sp[64 * 5]; dd = sp[64 * 6]; rr = sp[64 * 7];
+            S.dts = sp[64 * 8].x;
+        } else {
+            const real2* cp = reinterpret_cast<const real2*>(Lb + (size_t)s * LATP + 32);
+#pragma unroll
+            for (int i = 0; i < 4; i++) h4[i] = cp[i];
+            g01 = cp[4]; g23 = cp[5]; dd = cp[6]; rr = cp[7];
+            S.dts = Lb[(size_t)s * LATP + 48];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { S.h0[i] = h4[i].x; S.h1[i] = h4[i].y; }
         S.b[2] = g01.x; S.b[3] = g01.y; S.b[4] = g23.x; S.b[5] = g23.y;
         S.b[0] = dd.x; S.b[1] = -dd.y; S.b[6] = real(0.0); S.b[7] = real(0.0); S.b[8] = rr.x; S.b[9] = -rr.y;
         if constexpr (WALLS) { const real* w = C.wall_edges + ((size_t)b * N + s) * 2; S.b[10] = w[0]; S.b[11] = -w[1]; S.b[12] = real(0.0); }
-        S.dts = Lb[(size_t)s * LATP + 48];
     };
     int pmode = 0, pstat = 0, pchecks = 0; bool want_polish = false, skip_second = false, resume_ipm = false;
     // what a slot visit reads before it computes: stage constants, (t, lambda), second-order term / d-lambda, working-set words, eliminated slacks
@@ -681,6 +698,20 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     const int cap = C.ipm_max_iter;
     __syncthreads();
     if constexpr (!resume) {
+    if constexpr (USE_SPC) {      // file this wavefront's stage constants lane-contiguous (see LAT_SPC_Q): once per launch, read by every slot visit of every pass
+#pragma unroll 1
+        for (int j = 0; j < nslot_h; j++) {
+            if (cs + LPI * j < N) {
+                const int s = sidx(j);
+                const real2* cp = reinterpret_cast<const real2*>(Lb + (size_t)s * LATP + 32);
+                real2* sp = spc_of(s);
+#pragma unroll
+                for (int q = 0; q < 8; q++) sp[64 * q] = cp[q];
+                real2 dz; dz.x = Lb[(size_t)s * LATP + 48]; dz.y = real(0.0); sp[64 * 8] = dz;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // (a lane reads back what it wrote itself -- and, clamped to the last stage, what its neighbour wrote)
+    }
     // ---------------- start: v = 0 roll-out (dynamics- and rate-feasible), soft-row slacks just feasible + 1, t = max(slack, tau), lambda = mu0 / t ----------------
     if (frow) forward_pass(false);
     wave_sync();
@@ -1107,7 +1138,8 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
 
     // ---------------- outputs ----------------
     if (valid && cs == 0) {
-        if (deferred) O.todo[atomicAdd(O.n_todo, 1)] = b;
+        if constexpr (HAND == 1) { if (deferred) { if (pmode != 0) O.todo[B - 1 - atomicAdd(O.n_todo + 2, 1)] = b; else O.todo[atomicAdd(O.n_todo, 1)] = b; } }
+        else if (deferred) O.todo[atomicAdd(O.n_todo, 1)] = b;
         if (O.wfail && !listm) {        // (the back-off word belongs to the launch that makes -- or skips -- the warm attempt)
             const int lvl = (wf >> 8) & 0xFF, nl = lvl < 5 ? lvl + 1 : 5;
             O.wfail[b] = !warm ? 0 : (warm_tried ? (warm_failed ? ((nl << 8) | ((1 << nl) - 1)) : 0) : ((lvl << 8) | (((wf & 0xFF) > 0 ? (wf & 0xFF) - 1 : 0))));

@@ -199,6 +199,19 @@ def test_config5_as_shipped_every_instance_against_the_oracle(pkg, oracle_mod, s
     assert res[:, 0].max() <= 1e-6, (res[:, 0].max(), int(np.argmax(res[:, 0])))
     assert res[:, 1].max() <= 1e-5 and res[:, 2].max() <= 1e-9, (res[:, 1].max(), res[:, 2].max())
     assert (pol >= 1).sum() >= B - 8, int((pol < 0).sum())         # (round 4: 53 / 54 unverified -- multipliers of held steering-rate rows stalled under the penalty; round 5 pins them exactly: 0 / 4)
+    # round 6: the default cold launch of this batch is the two-launch straggler hand-over (k_solve_lat<.., 16, 1> -> k_solve_lat<.., 64, 2>): what has just been held
+    # against the oracle, every instance of it, IS that path -- the library's own counter says so
+    assert mpc.get_option("stat_lat_handover_solves") == 1 and mpc.get_option("lat_handover") == 1
+    # ... and the single launch of round 5 (option "lat_handover" = 0) gives the same answers: both end in verified KKT points of the same QP (or, for the handful that
+    # verify nowhere, in interior-point iterates at 1e-12).  Iteration counts agree except where the order of a sum decided a step rule (one instance per wavefront sums over
+    # 64 lanes, four per wavefront over 16)
+    one = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, B, N_short=Ns, N_long=Nl, walls=walls, options={"lat_handover": 0})
+    u1, status1, iters1 = one.step_(state, control, t0, time_offset=toff)
+    assert one.get_option("stat_lat_handover_solves") == 0 and np.all(pkg.is_solved(status1))
+    both = (status == pkg.SOLVED) & (status1 == pkg.SOLVED)
+    print(f"walls={walls}: hand-over vs single launch: status differs on {int((status != status1).sum())}, iterations on {int((iters != iters1).sum())}, max |d2 - d2'| {np.max(np.abs(u[:, 0] - u1[:, 0])):.1e}")
+    assert both.sum() >= B - 12 and np.max(np.abs(u[both, 0] - u1[both, 0])) <= 3e-7 and np.max(np.abs(u[:, 0] - u1[:, 0])) <= 1e-6 and (iters != iters1).sum() <= B // 20
+    one.close()
     mpc.close()
     # the interior point alone: accurate for all but a handful -- which is why it is not the default
     ipm = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, B, N_short=Ns, N_long=Nl, walls=walls, polish=False)
