@@ -911,6 +911,8 @@ def main():
                 if isinstance(hw_, dict) and hw_.get("valu_flops_per_launch"):
                     # the hardware's own count of executed arithmetic (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 of the committed PMC pass) over the LIVE duration
                     e["hw_valu_flop_frac"] = hw_["valu_flops_per_launch"] / (ms * 1e-3) / 1e12 / hw_["peak_tflops"]; e["hw_arith_share_of_valu_insts"] = hw_.get("arith_share_of_valu_insts")
+                    # ... which IS the flop fraction of this kernel: the model / ISA count stays beside it as `model_flop_frac`
+                    e["model_flop_frac"] = e["valu_flop_frac"]; e["valu_flop_frac"] = e["hw_valu_flop_frac"]; e["valu_flop_frac_source"] = "counters: 64 x (ADD + MUL + TRANS + 2 FMA) wave instructions of the committed PMC pass / live duration"
                 m_ = h_.get("mfma")
                 if isinstance(m_, dict):
                     e["mfma_busy_frac"] = m_.get("busy_frac_of_simd_time"); e["mfma_flop_frac"] = m_.get("frac_of_peak")

@@ -276,9 +276,18 @@ int pg_synchronize(pg_handle* h);
  *     "lat_pin" 0/1 (1)          a held steering-rate row pins the input of its stage exactly in the polish (0: held through the augmented Lagrangian like every other row)
  *     "lat_pack_only" 0/1 (1)    update_QP! of a handle solved by k_solve_lat writes the packed stage records only (the embedded block pg_get_qp returns is built on demand)
  *     "lat_split" 0/1 (1)        a step in which every instance is warm runs as two launches (warm attempts, then the cold solves of what they left)
+ *     "lat_handover" 0/1 (1)     STRAGGLER HAND-OVER of a cold launch (batches of >= "lat_hand_batch" (1025) instances whose row state lives in the workspace: N > 16): the launch stops at
+ *                                a trip boundary once at most "lat_hand_target" (1500) instances of the batch are unfinished (not before "lat_hand_min" (8) trips; "lat_hand_cap" > 0:
+ *                                after that many trips whatever the count), files them, and a second launch resumes them with ONE instance per wavefront.  Same verified KKT points
+ *                                (measured 4e-8 apart at most); 2.96-3.03 -> 2.60-2.69 ms on the N = 50 + walls batch of 4096.  0 = one launch, as in round 5
+ *     "lat_single_max" (1024)    cold lateral batches of at most this many instances (horizons beyond 16 intervals) run one instance per WAVEFRONT from the start: a trip through the
+ *                                solver's loop costs 57 us instead of 84 (0: never)
+ *     "lat_aux_gate" 0/1 (1)     the serial passes write what a pinned row's multiplier is read from only while an instance of the wavefront is in a polish
+ *     "nodes_serial" 0/1 (0)     1 = the cold node seeding (both formulations) commits ONE node per pass: the reference's serial recurrence exactly (the default runs 2 / 8 lanes per
+ *                                instance ahead on the commanded acceleration and commits the nodes whose solve returned it: identical to 1e-12, 4e-6 in fp32; parity tests use this)
  *     "lat_rho_scale" (1e3 in fp64, 1 in fp32)  penalty of held rows = polish_rho x this;   "lat_mu0_cost" (10), "lat_far_cost" (3e4), "lat_polish2" 0/1 (1),
  *     "lat_polish_rounds" (3), "lat_settle" 0..2 (0), "lat_warm_rounds" (2), "lat_wipm" 0/1 (0), "lat_wmu" (1e-2), "lat_wtau" (1e-4)   see pg_solve_lat.hip
- *   read-only (pg_get_option): "stat_pipelined_launches", "stat_split_solve_launches", "stat_single_solve_launches", "stat_lat_two_launch_solves" -- how many launches of
+ *   read-only (pg_get_option): "stat_pipelined_launches", "stat_split_solve_launches", "stat_single_solve_launches", "stat_lat_two_launch_solves", "stat_lat_handover_solves", "stat_lat_one_per_wavefront_solves" -- how many launches of
  *     this handle took the path named (tests assert that the path they mean to cover is the one that ran); "stat_whole_batch_solves" -- counted ON THE DEVICE: launches in
  *     which the full k_solve took the whole batch because the previous launch had left instances for the interior point (reading it drains the stream);
  *     "lateral_solver_in_use" (1 = k_solve_lat, 2 = embedding).

@@ -66,7 +66,9 @@ struct pg_handle {
     char* d_lat_ws = nullptr; bool lat_mem = false, lat_mem_forced = false;            // k_solve_lat's workspace for horizons beyond 32 intervals (option "lat_workspace" = 1: at every horizon)
     real* d_lat_spc = nullptr;                                  // k_solve_lat's lane-contiguous stage constants (lat_spc_bytes)
     real* d_hand_r = nullptr; int* d_hand_i = nullptr;          // [cap][8] / [cap][16] hand-over records of k_solve_lat's unfinished instances (round 6: SolveOut::hand_mode)
-    int lat_handover = 1, lat_hand_target = 1500, lat_hand_min = 8, lat_hand_cap = 0, lat_hand_batch = 2048;      // options "lat_handover" (0 off, 1 = on), "lat_hand_target", "lat_hand_min", "lat_hand_cap", "lat_hand_batch" (smallest batch that hands over)
+    int lat_single_max = 1024;                                  // option "lat_single_max": cold lateral batches up to this size run ONE instance per wavefront from the start (k_solve_lat<.., 64, 0>)
+    int lat_handover = 1, lat_hand_target = 1500, lat_hand_min = 8, lat_hand_cap = 0, lat_hand_batch = 1025;      // options "lat_handover" (0 off, 1 = on), "lat_hand_target", "lat_hand_min", "lat_hand_cap", "lat_hand_batch" (smallest batch that hands over)
+    int64_t stat_lat_single = 0;                                // read-only option "stat_lat_one_per_wavefront_solves"
     int64_t stat_lat_hand = 0;                                  // read-only option "stat_lat_handover_solves"
     real* d_lat_aux = nullptr;                                  // [cap][64][8] F, Bbar'P Bbar, Bbar'y per stage: what k_solve_lat reads the multiplier of a pinned rate row from
     real* d_lat = nullptr;                                      // [cap][N][LATP] packed stage records of the lateral formulation (k_qp_dec -> k_solve_lat)
@@ -420,6 +422,7 @@ static bool find_option(pg_handle* h, const char* name, OptRef* o) {
     if (n == "lat_hand_min") return I(&h->lat_hand_min, 1, 1 << 20);
     if (n == "lat_hand_cap") return I(&h->lat_hand_cap, 0, 1 << 20);
     if (n == "lat_hand_batch") return I(&h->lat_hand_batch, 1, 1 << 30);
+    if (n == "lat_single_max") return I(&h->lat_single_max, 0, 1 << 30);
     if (n == "lat_pack_only") return I(&h->lat_pack_only, 0, 1);
     if (n == "lat_polish2") return I(&C.lat_polish2, 0, 1);
     if (n == "lat_pin") return I(&C.lat_pin, 0, 1);
@@ -438,6 +441,7 @@ static bool find_option(pg_handle* h, const char* name, OptRef* o) {
     if (n == "stat_single_solve_launches") return S(&h->stat_single);
     if (n == "stat_lat_two_launch_solves") return S(&h->stat_lat_two);
     if (n == "stat_lat_handover_solves") return S(&h->stat_lat_hand);
+    if (n == "stat_lat_one_per_wavefront_solves") return S(&h->stat_lat_single);
 #ifdef PG_DIAG      // diagnostic build only (libpigeon_hip_diag.so): fault injection and traces have no place in the shipped libraries
     if (n == "diag_instance") return I(&C.dbg_instance, -1, 1 << 30);
     if (n == "diag_lin_groups") return I(&h->lin_groups, 0, 8);
@@ -914,6 +918,16 @@ static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, u
         // `lat_hand_target` instances of the batch are unfinished and files them, the second resumes those, ONE instance per wavefront (option "lat_handover" = 0: one launch
         // as in round 5.  Measured and removed: resuming four per wavefront again, i.e. compaction only -- 3.34 against 3.25 ms for the single launch).  Only where the row
         // state lives in the workspace (N > 32, or the wall rows), and not behind the warm attempts' own two launches.
+        // Small batches (round 6): with at most one wavefront per SIMD to fill anyway, every instance gets a wavefront of its own from the start -- the mapping of the resuming
+        // launch (lane = stage in the stage-parallel passes, one slot visit instead of four, the row state in registers): a trip costs 57 us instead of 84.  Not behind warm
+        // attempts (their launches are a round or two of the polish: four per wavefront is the cheaper shape there).
+        if (!two && !h->sg.capturing && h->warm_B < h->B && h->B <= h->lat_single_max && h->dc.N > 16) {
+            const size_t lds1 = lat_lds_doubles(h->dc.N, 1) * sizeof(real);
+            if (h->dc.walls) hipLaunchKernelGGL((k_solve_lat<1, true, false, 64, 0>), dim3((unsigned)h->B), dim3(64), lds1, st, h->dc, h->B, h->d_qp, h->d_nodes, O, lat_prof);
+            else hipLaunchKernelGGL((k_solve_lat<1, false, false, 64, 0>), dim3((unsigned)h->B), dim3(64), lds1, st, h->dc, h->B, h->d_qp, h->d_nodes, O, lat_prof);
+            LAUNCH_CHECK(h); h->stat_lat_single++;
+            return PG_OK;
+        }
         const bool hand = h->lat_handover != 0 && h->lat_mem && !two && !h->sg.capturing && h->B >= h->lat_hand_batch && (h->lat_hand_target > 0 || h->lat_hand_cap > 0);
         if (hand) {
             const size_t cap = (size_t)h->cfg.batch_capacity;

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     static_assert(LPI == 16 || (LPI == 64 && NSLOT == 1 && !MEM), "one instance per wavefront keeps its single slot in registers");
     static_assert(NSLOT == 1, "the two-slot register instantiation (horizons of 17..32 intervals) is retired: hipcc 7.2 allocated one accumulation register to two live values in it (see configure_lateral)");
     static_assert(HAND == 0 || (HAND == 1 && MEM && LPI == 16) || (HAND == 2 && LPI == 64), "hand-over: out of a launch whose row state lives in the workspace, into one instance per wavefront");
+    // (LPI = 64 with HAND = 0: a small batch, one instance per wavefront from the start)
     // (HAND is a template argument, not a launch argument: the plain kernel carries none of the hand-over's code -- as a run-time flag it cost the round-5 launch 9 %)
     constexpr int NR = WALLS ? 13 : 10;
     constexpr int NI = 64 / LPI;                          // instances per wavefront

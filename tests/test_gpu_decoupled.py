@@ -226,21 +226,26 @@ def test_config5_as_shipped_every_instance_against_the_oracle(pkg, oracle_mod, s
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,walls,path", [(1, False, "skidpadoval"), (5, True, "skidpadoval"), (1021, True, "EastPaddock"), (130, False, "vail")])
 def test_lateral_kernel_on_ragged_batches_matches_the_embedding(pkg, B, walls, path):
-    """k_solve_lat (four instances per wavefront, the per-row state of N = 50 in its global workspace) against the embedding of the same QP in k_solve
-    (option "lateral_solver" = 2, one wavefront per instance) on batch sizes that leave the last wavefront ragged and on other paths than the benchmark's: two
-    different kernels, the same verified KKT point wherever both verify."""
-    import os
+    """k_solve_lat against the embedding of the same QP in k_solve (option "lateral_solver" = 2, one wavefront per instance) on batch sizes that leave the last wavefront
+    ragged and on other paths than the benchmark's: two different kernels, the same verified KKT point wherever both verify.  Round 6: cold batches of up to 1024
+    instances take k_solve_lat's ONE-instance-per-wavefront instantiation (option "lat_single_max"; the library's counter says so); with the option at 0 the same batch runs
+    four per wavefront with the row state in the workspace, ragged last wavefront included -- both are held against the embedding, and against each other."""
     traj = pkg.load_path_fixture(path)
     state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=3)
     out = {}
-    for lat in ("1", "0"):
-        mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, walls=walls, options={"lateral_solver": 1 if lat == "1" else 2})
-        assert mpc.get_option("lateral_solver_in_use") == (1 if lat == "1" else 2)
+    for lat, opts in (("1", {"lateral_solver": 1}), ("4", {"lateral_solver": 1, "lat_single_max": 0}), ("0", {"lateral_solver": 2})):
+        mpc = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, walls=walls, options=opts)
+        assert mpc.get_option("lateral_solver_in_use") == (2 if lat == "0" else 1)
         u, status, iters = mpc.step_(state, control, t0, time_offset=toff)
+        assert mpc.get_option("stat_lat_one_per_wavefront_solves") == (1 if lat == "1" else 0)
         x, sg = mpc.solution()
         out[lat] = (u.copy(), status.copy(), x.copy(), mpc.polish_info().copy())
         mpc.close()
+    (u4, s4, x4, p4) = out["4"]
     (ua, sa, xa, pa), (ue, se, xe, pe) = out["1"], out["0"]
+    assert np.all(pkg.is_solved(s4))
+    b14 = (pa >= 1) & (p4 >= 1)
+    assert b14.sum() >= max(1, int(0.9 * B)) and np.max(np.abs(xa[b14, 1, 6] - x4[b14, 1, 6])) <= 3e-7      # one per wavefront against four per wavefront: two verified KKT points of the same QP
     assert np.all(pkg.is_solved(sa)), np.bincount(sa)
     both = (pa >= 1) & (pe >= 1)
     assert both.sum() >= max(1, int(0.8 * B)), (int(both.sum()), B)

@@ -47,7 +47,7 @@ def main():
         torch.cuda.synchronize(); t = time.perf_counter() - t
         st, it, act, mu = m.solve_info(); pol = m.polish_info(); u = m.get_next_control(); x, sg = m.solution()
         line = (f"walls={int(a.walls)} {setting:28s}: nodes {np.median(ph[:, 0]):.3f} qp {np.median(ph[:, 1]):.3f} solve {np.median(ph[:, 2]):.3f} ms (min {ph[:, 2].min():.3f}, max {ph[:, 2].max():.3f})  step {1e3 * t / a.reps:.3f} ms = {B * a.reps / t / 1e6:.3f} M solves/s  "
-                f"solved {int(pkg.is_solved(st).sum())}/{B} verified {int((pol >= 1).sum())} ipm iters mean {it.mean():.2f} max {it.max()} hand-over launches {m.get_option('stat_lat_handover_solves'):.0f}")
+                f"solved {int(pkg.is_solved(st).sum())}/{B} verified {int((pol >= 1).sum())} ipm iters mean {it.mean():.2f} max {it.max()} hand-over launches {m.get_option('stat_lat_handover_solves'):.0f} one-per-wavefront launches {m.get_option('stat_lat_one_per_wavefront_solves'):.0f}")
         if ref is None:
             ref = (st, it, act, u, pol, x)
         else:
