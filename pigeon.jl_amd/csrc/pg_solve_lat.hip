@@ -43,6 +43,9 @@
 #endif
 #define LAT_DPP(acc, bsrc, x, lane) LAT_FMAC " %" #acc ", %" #bsrc ", %" #x " row_newbcast:" #lane " row_mask:0xf bank_mask:0xf\n\t"
 
+#ifndef LAT_SYM
+#define LAT_SYM 1                 // the matrix pass multiplies by 1/2 (P + P'): experiment switch
+#endif
 #ifndef LAT_PREFETCH_V
 #define LAT_PREFETCH_V 3        // stages of matrix columns in flight in the vector pass
 #endif
@@ -52,7 +55,9 @@
 constexpr int LAT_REC = 12;     // stage -> serial: (yy, yr, rr, ee, dd, Rhat) [overwritten by the roll-out: x+_{k+1}[0..4], v+_k], qhat[5], rhat
 constexpr int LAT_TAB = 12;     // serial tables: K[5], kff, Sinv, P cbar [5]
 constexpr int LAT_STRIDE = LAT_REC + LAT_TAB;
-__host__ __device__ inline size_t lat_lds_doubles(int N, int instances_per_wavefront = 4) { return (size_t)instances_per_wavefront * N * LAT_STRIDE + 64 + 8; }
+constexpr int LAT_XS = 34;      // one instance per wavefront: the stage matrices (32 doubles: rows of [A | B0+Bf | Bf | c]) and dt of a stage are copied into the LDS once per launch, 34 doubles apart
+__host__ __device__ inline size_t lat_lds_doubles(int N, int instances_per_wavefront = 4) {
+    return (size_t)instances_per_wavefront * N * LAT_STRIDE + 64 + 8 + (instances_per_wavefront == 1 ? (size_t)N * LAT_XS : 0); }
 // horizons beyond 32 intervals keep the per-row interior-point state in a global workspace (see "stage-parallel part"): bytes per 16-stage slot of one wavefront
 // (13 rows x 64 lanes x (t, lambda) + 7 x 64 x 2 second-order terms + 64 x 4 eliminated slacks + 64 x 16 B of working-set words, fp64), four slots per wavefront
 constexpr size_t LAT_WS_SLOT_BYTES = 23552;
@@ -153,6 +158,8 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     real* const sDum = lds + (size_t)NI * N * LAT_STRIDE; // [64] sink for predicated-off stores
     real* const sZero = sDum + 64;                       // a stored 0
     if (lane < 8) sZero[lane] = real(0.0);
+    constexpr bool XLDS = LPI == 64;                     // the serial passes read the stage matrices from the LDS (a wavefront with ONE instance has the room: 13.6 KB at N = 50)
+    real* const sMat = sZero + 8;
     const QpOff o = qp_offsets(N);
     const real* const Q = qp + (size_t)b * C.qp_len;
 
@@ -161,7 +168,9 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     const real* const Lb = C.lat_pack + (size_t)b * N * LATP;
     real* const aux = C.lat_aux + (size_t)b * 64 * LAT_AUX;      // (an invalid lane group of a ragged last wavefront writes the last instance's block again: same values; a resumed launch has one instance per wavefront and no such group)
     // column distribution (matrix + vector pass): lane c holds X[0..3][c] of [Abar | Bbar | cbar]; row 4 is the constant x4; lanes 7..15 read the zero column
-    const real* const colp = Lb + (c < 7 ? c : 7);
+    constexpr int XSTR = XLDS ? LAT_XS : LATP, XDT = XLDS ? 32 : 48;
+    const real* const Xb = XLDS ? sMat : Lb;
+    const real* const colp = Xb + (c < 7 ? c : 7);
     const real cx4 = (c == 4 || c == 5) ? real(1.0) : real(0.0);
     // stage-cost column of lane c inside rec[k]: Qhat[i][c] for c < 5, qhat[i] for c == 6, else zero (a stored 0 with stride 0)
     int qoff[5], qmul[5];
@@ -187,17 +196,17 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     auto matrix_pass = [&](auto aux_on) __attribute__((always_inline)) {      // aux_on: leave F / B'PB / B'y of every stage in lat_aux (what a pinned row's multiplier is read from)
         real P[5], X[4], Xn[4], Qc[5], Qn[5], dtk, dtn, radd, raddn;
         {   // P_N = Qhat_{N-1} (cost on node N), p_N = qhat_{N-1}
-            const real dtl = Lb[(size_t)(N - 1) * LATP + 48];
+            const real dtl = Xb[(size_t)(N - 1) * XSTR + XDT];
 #pragma unroll
             for (int i = 0; i < 5; i++) P[i] = (sZero + qoff[i])[qmul[i] * (N - 1)];
             P[2] += cpsi * dtl;
         }
         auto request = [&](int k, real* Xo, real* Qo, real& dto, real& ro) __attribute__((always_inline)) {      // operands of stage k (k < 0: stage 0 again, unused)
             const int kk = k < 0 ? 0 : k, km = kk > 0 ? kk - 1 : 0;
-            const real* cp = colp + (size_t)kk * LATP;
+            const real* cp = colp + (size_t)kk * XSTR;
 #pragma unroll
             for (int i = 0; i < 4; i++) Xo[i] = cp[8 * i];
-            dto = Lb[(size_t)km * LATP + 48];                 // dt of stage k - 1: its cost sits on node k
+            dto = Xb[(size_t)km * XSTR + XDT];                 // dt of stage k - 1: its cost sits on node k
 #pragma unroll
             for (int i = 0; i < 5; i++) Qo[i] = (sZero + qoff[i])[qmul[i] * km];
             ro = (sZero + roff)[rmul * kk];
@@ -208,13 +217,17 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             request(k - 1, Xn, Qn, dtn, raddn);
             real Xh[5], M[5];
 #pragma unroll
-            for (int i = 0; i < 4; i++) { Xh[i] = real(0.5) * X[i]; M[i] = real(0.0); }
-            Xh[4] = real(0.5) * cx4; M[4] = real(0.0);
+            for (int i = 0; i < 4; i++) { Xh[i] = real(LAT_SYM ? 0.5 : 1.0) * X[i]; M[i] = real(0.0); }
+            Xh[4] = real(LAT_SYM ? 0.5 : 1.0) * cx4; M[4] = real(0.0);
             // M[i][c] = sum_k 1/2 (P[i][k] + P[k][i]) X[k][c]:  bc_k(P[i]) = P[i][k],  bc_i(P[k]) = P[k][i]
             asm volatile("s_nop 4\n\t"
 #define LAT_M1(k, xk) LAT_DPP(0, 5, xk, k) LAT_DPP(1, 6, xk, k) LAT_DPP(2, 7, xk, k) LAT_DPP(3, 8, xk, k) LAT_DPP(4, 9, xk, k)
 #define LAT_M2(pk, xk) LAT_DPP(0, pk, xk, 0) LAT_DPP(1, pk, xk, 1) LAT_DPP(2, pk, xk, 2) LAT_DPP(3, pk, xk, 3) LAT_DPP(4, pk, xk, 4)
+#if LAT_SYM
                          LAT_M1(0, 10) LAT_M2(5, 10) LAT_M1(1, 11) LAT_M2(6, 11) LAT_M1(2, 12) LAT_M2(7, 12) LAT_M1(3, 13) LAT_M2(8, 13) LAT_M1(4, 14) LAT_M2(9, 14)
+#else
+                         LAT_M1(0, 10) LAT_M1(1, 11) LAT_M1(2, 12) LAT_M1(3, 13) LAT_M1(4, 14)
+#endif
                          : "+v"(M[0]), "+v"(M[1]), "+v"(M[2]), "+v"(M[3]), "+v"(M[4])
                          : "v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]), "v"(P[4]), "v"(Xh[0]), "v"(Xh[1]), "v"(Xh[2]), "v"(Xh[3]), "v"(Xh[4]));
             // lane 6: M = P cbar (kept for the corrector's vector pass), then y = P cbar + p
@@ -261,7 +274,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         const int koff = c < 5 ? (int)(sTab - sZero) + c : 0;                                        // K[c]
         const int qvoff = c < 5 ? (int)(sRec - sZero) + 6 + c : 0, qvmul = c < 5 ? LAT_REC : 0;      // qhat[c]
         real p = (sZero + qvoff)[qvmul * (N - 1)];
-        auto request = [&](int k, real* Xo) __attribute__((always_inline)) { const real* cp = colp + (size_t)(k < 0 ? 0 : k) * LATP;
+        auto request = [&](int k, real* Xo) __attribute__((always_inline)) { const real* cp = colp + (size_t)(k < 0 ? 0 : k) * XSTR;
 #pragma unroll
             for (int i = 0; i < 4; i++) Xo[i] = cp[8 * i]; };
         auto request_lds = [&](int k, real* o5) __attribute__((always_inline)) { const int kk = k < 0 ? 0 : k, km = kk > 0 ? kk - 1 : 0;
@@ -303,10 +316,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         constexpr int D = LAT_PREFETCH_F;
         const bool isK = c == 5 && use_gain;          // (a select, not a multiplication by 0: the gain table holds nothing before the first matrix pass)
         real xr = x0c;
-        const real2* const rowp = reinterpret_cast<const real2*>(Lb + 8 * ri);
+        const real2* const rowp = reinterpret_cast<const real2*>(Xb + 8 * ri);
         const real2* const tabp = reinterpret_cast<const real2*>(sTab);
         real2 buf[D][4], kt[3], ktn[3];
-        auto request = [&](int k, real2* o4) __attribute__((always_inline)) { const real2* rp = rowp + (size_t)(k < N ? k : N - 1) * (LATP / 2);
+        auto request = [&](int k, real2* o4) __attribute__((always_inline)) { const real2* rp = rowp + (size_t)(k < N ? k : N - 1) * (XSTR / 2);
 #pragma unroll
             for (int q = 0; q < 4; q++) o4[q] = rp[q]; };
         auto request_lds = [&](int k, real2* o3) __attribute__((always_inline)) { const real2* tp = tabp + (LAT_TAB / 2) * (k < N ? k : N - 1);
@@ -698,6 +711,14 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     bool done = false, warm = false, warm_try = false, warm_failed = false, deferred = false, warm_tried = false, counted = false;
     const int cap = C.ipm_max_iter;
     __syncthreads();
+    if constexpr (XLDS) {      // the stage matrices of this wavefront's instance, once per launch
+        const real2* const src = reinterpret_cast<const real2*>(Lb);
+        real2* const dst = reinterpret_cast<real2*>(sMat);
+#pragma unroll 1
+        for (int idx = lane; idx < 16 * N; idx += 64) dst[(idx >> 4) * (LAT_XS / 2) + (idx & 15)] = src[(size_t)(idx >> 4) * (LATP / 2) + (idx & 15)];
+        for (int sq = lane; sq < N; sq += 64) { real2 dz; dz.x = Lb[(size_t)sq * LATP + 48]; dz.y = real(0.0); dst[sq * (LAT_XS / 2) + 16] = dz; }
+        wave_sync();
+    }
     if constexpr (!resume) {
     if constexpr (USE_SPC) {      // file this wavefront's stage constants lane-contiguous (see LAT_SPC_Q): once per launch, read by every slot visit of every pass
 #pragma unroll 1
