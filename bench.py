@@ -88,13 +88,23 @@ def roofline_of(tr, kernel_match, ms, units, bytes_per_unit, flops, precision, n
          "algorithmic_bytes_per_launch": units * bytes_per_unit, "traffic": None,
          "valu": {"bound": "valu-" + precision, "algorithmic_flops_per_launch": flops, "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
                   "frac": flops / (ms * 1e-3) / 1e12 / peak_tf}}
-    hit = [v for k, v in (tr or {}).get("kernels", {}).items() if kernel_match in k]
-    if hit:
-        e = hit[0]
-        r["traffic"] = e.get("hbm_bytes_per_launch"); r["traffic_source"] = e.get("source")
-        for k in ("valu_issue_frac", "valu_insts_per_launch", "avg_launch_ns_rocprof", "min_launch_ns_rocprof", "max_launch_ns_rocprof", "stddev_launch_ns_rocprof", "launches_rocprof"):
-            if k in e:
-                r[k] = e[k]
+    matches = [kernel_match] if isinstance(kernel_match, str) else list(kernel_match)      # (several: the launches a phase is made of -- k_solve_lat's first launch + the resuming one)
+    r["kernel"] = matches[0] if len(matches) == 1 else " + ".join(matches)
+    hits = [[v for k, v in (tr or {}).get("kernels", {}).items() if m in k] for m in matches]
+    if hits and all(hits):
+        es = [h[0] for h in hits]
+        r["traffic"] = sum(e.get("hbm_bytes_per_launch") or 0.0 for e in es); r["traffic_source"] = es[0].get("source")
+        for k in ("valu_insts_per_launch", "avg_launch_ns_rocprof"):
+            if all(k in e for e in es):
+                r[k] = sum(e[k] for e in es)
+        if len(es) == 1:
+            for k in ("valu_issue_frac", "min_launch_ns_rocprof", "max_launch_ns_rocprof", "stddev_launch_ns_rocprof", "launches_rocprof"):
+                if k in es[0]:
+                    r[k] = es[0][k]
+        else:
+            r["launches"] = [{"kernel": m, **{k: e.get(k) for k in ("hbm_bytes_per_launch", "avg_launch_ns_rocprof", "valu_issue_frac", "launches_rocprof")}} for m, e in zip(matches, es)]
+            if all("valu_issue_frac" in e and "avg_launch_ns_rocprof" in e for e in es):      # SIMD-time-weighted
+                r["valu_issue_frac"] = sum(e["valu_issue_frac"] * e["avg_launch_ns_rocprof"] for e in es) / sum(e["avg_launch_ns_rocprof"] for e in es)
     if note:
         r["note"] = note
     return r
@@ -698,7 +708,7 @@ def main():
                  "solved": f"{int(pkg.is_solved(std).sum())}/{B}", "ipm_iters_mean": float(np.mean(itd)), "ipm_iters_max": int(np.max(itd)), "verified_by_polish": f"{int((pd_ >= 1).sum())}/{B}"}
             # roofline of the dominant kernel (k_solve_lat): the launch runs as long as its slowest instance -- passes through the loop = interior-point iterations + polish rounds
             passes = itd.astype(np.float64) + np.where(pd_ > 0, pd_, 3) + 1.0
-            r["roofline"] = roofline_of(TR, "k_solve_lat<1, true, true>" if walls else "k_solve_lat<1, false, true>", phd[2], B, BYTES_PER_SOLVE_COLD_FP64 if args.precision == "f64" else 68,
+            r["roofline"] = roofline_of(TR, ("k_solve_lat<1, true, true, 16, 1>", "k_solve_lat<1, true, false, 64, 2>") if walls else ("k_solve_lat<1, false, true, 16, 1>", "k_solve_lat<1, false, false, 64, 2>"), phd[2], B, BYTES_PER_SOLVE_COLD_FP64 if args.precision == "f64" else 68,
                                         float(np.sum(lat_flops(50, 13 if walls else 10, passes))), args.precision,
                                         note="k_solve_lat is bound by the dependent fp64 chains of its slowest instance (one wavefront per SIMD, every wavefront resident): the HBM fraction is ~1e-5 by "
                                              "construction; `traffic` is what the per-wavefront workspace and the packed stage records move through the memory side (L2 / Infinity Cache, not HBM-served)")

@@ -913,6 +913,17 @@ static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, u
             PG_LAT_LAUNCH_ANY();
             LAUNCH_CHECK(h);
             O.todo = nullptr; O.n_todo = nullptr; O.list = h->d_todo; O.n_list = h->d_todo + cap;
+            // (round 6) a list of up to `lat_single_max` instances is solved ONE instance per wavefront (see "small batches" below: 871 unserved instances of the benchmark
+            // batch 1.5 instead of 2.1 ms); the host does not know the length, so both arrangements are queued and the device word picks one (an idle launch: ~4 us)
+            if (h->lat_single_max > 0 && h->dc.N > 16) {
+                const unsigned nb1 = (unsigned)(h->B < h->lat_single_max ? h->B : h->lat_single_max);
+                const size_t lds1 = lat_lds_doubles(h->dc.N, 1) * sizeof(real);
+                O.list_lo = 0; O.list_hi = h->lat_single_max;
+                if (h->dc.walls) hipLaunchKernelGGL((k_solve_lat<1, true, false, 64, 0>), dim3(nb1), dim3(64), lds1, st, h->dc, h->B, h->d_qp, h->d_nodes, O, lat_prof);
+                else hipLaunchKernelGGL((k_solve_lat<1, false, false, 64, 0>), dim3(nb1), dim3(64), lds1, st, h->dc, h->B, h->d_qp, h->d_nodes, O, lat_prof);
+                LAUNCH_CHECK(h);
+                O.list_lo = h->lat_single_max + 1; O.list_hi = 0;
+            }
         }
         // Straggler hand-over (round 6, see k_solve_lat): a batch that starts cold interior points runs as TWO launches -- the first stops at a trip boundary once at most
         // `lat_hand_target` instances of the batch are unfinished and files them, the second resumes those, ONE instance per wavefront (option "lat_handover" = 0: one launch

@@ -1407,7 +1407,9 @@ struct SolveOut { real* sol_x; real* sol_sigma; real* u_out; int* status; int* i
                   real* u_out2;                            // pg_step_dev: the caller's control array, written next to u_out (saves the device-to-device copy behind the launch); may be nullptr
                   int* n_whole;                            // split launch: counts the launches in which the full kernel took the WHOLE batch (`mode` non-zero) -- read-only option "stat_whole_batch_solves"; may be nullptr
                   // k_solve_lat's straggler hand-over (round 6; pg_solve_lat.hip): 0 off, 1 = this launch hands its unfinished instances over (to `todo`), 2 = this launch resumes them (`list`)
-                  int hand_mode, hand_cap, hand_target, hand_min; int* hand_done; real* hand_r; int* hand_i; };
+                  int hand_mode, hand_cap, hand_target, hand_min; int* hand_done; real* hand_r; int* hand_i;
+                  int list_lo, list_hi; };                 // k_solve_lat in list mode: this launch serves the list only when list_lo <= its length (<= list_hi, when that is set): the host queues one launch per
+                                                           // arrangement (one instance per wavefront / four) behind the warm attempts and the DEVICE word decides which of them runs
 
 #define NROW 16
 #define PG_POLISH_ROUNDS 6      // active-set rounds of the polish before it gives up

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     const int n_front = listm ? *O.n_list : B;
     const int n_list = (listm && HAND == 2) ? n_front + O.n_list[2] : n_front;
     if (listm && NI * (int)blockIdx.x >= n_list) return;          // (uniform over the block; nothing has been touched yet)
+    if (listm && HAND == 0 && (n_list < O.list_lo || (O.list_hi > 0 && n_list > O.list_hi))) return;      // (a list of this length belongs to the other arrangement's launch)
     const int idx_raw = NI * (int)blockIdx.x + g;
     const int b_raw = listm ? (idx_raw < n_list ? (HAND == 2 && idx_raw >= n_front ? O.list[B - 1 - (idx_raw - n_front)] : O.list[idx_raw]) : B) : idx_raw;
     const bool valid = b_raw < B;

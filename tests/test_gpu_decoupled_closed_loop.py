@@ -107,7 +107,7 @@ def test_two_consecutive_lateral_steps_match_the_oracle(pkg, oracle_mod, skidpad
     assert worst < 1e-6, worst
 
 
-@pytest.mark.parametrize("path,walls,burn,min_served", [("skidpadoval", False, 3, 0.6), ("skidpadoval", True, 3, 0.5), ("EastPaddock", False, 100, 0.999)])
+@pytest.mark.parametrize("path,walls,burn,min_served", [("skidpadoval", False, 3, 0.55), ("skidpadoval", True, 3, 0.5), ("EastPaddock", False, 100, 0.999)])
 def test_warm_lateral_step_of_the_full_batch_every_instance_against_the_oracle(pkg, oracle_mod, path, walls, burn, min_served):
     """BASELINE configs[4] in closed loop: B = 4096, N = 50 (+ walls), `burn` steps on the device, then one more step -- warm for every instance -- checked like the cold
     one (test_config5_as_shipped_every_instance_against_the_oracle): the applied steering of EVERY instance within 1e-6 of the exact optimum of its own QP data (a

@@ -123,7 +123,7 @@ out = {"formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correctio
        "kernel_source_sha16": kernel_source_sha16(), "kernels": {}}
 for group, sk, m in (("headline", "stats", "pg::k_solve<false, false, false, false"), ("headline", "stats", "pg::k_solve<false, false, false, true"), ("hji", "stats_hji", "pg::k_hji_lookup<3>"), ("hji", "stats_hji", "pg::k_hji_lookup<5>"), ("hji", "stats_hji", "pg::k_hji_lookup<7>"),
                      ("headline", "stats", "pg::k_linearize"), ("headline", "stats", "pg::k_nodes"),
-                     ("dec", "stats_dec", "pg::k_solve_lat<1, true, true>"), ("dec", "stats_dec", "pg::k_solve_lat<1, false, true>"), ("dec", "stats_dec", "pg::k_qp_dec"), ("dec", "stats_dec", "pg::k_nodes_dec")):
+                     ("dec", "stats_dec", "pg::k_solve_lat<1, true, true, 16, 1>"), ("dec", "stats_dec", "pg::k_solve_lat<1, true, false, 64, 2>"), ("dec", "stats_dec", "pg::k_solve_lat<1, false, true, 16, 1>"), ("dec", "stats_dec", "pg::k_solve_lat<1, false, false, 64, 2>"), ("dec", "stats_dec", "pg::k_qp_dec"), ("dec", "stats_dec", "pg::k_nodes_dec")):
     t = entry(group, sk, m)
     if t:
         out["kernels"][t[0]] = t[1]
