@@ -276,10 +276,13 @@ int pg_synchronize(pg_handle* h);
  *     "lat_pin" 0/1 (1)          a held steering-rate row pins the input of its stage exactly in the polish (0: held through the augmented Lagrangian like every other row)
  *     "lat_pack_only" 0/1 (1)    update_QP! of a handle solved by k_solve_lat writes the packed stage records only (the embedded block pg_get_qp returns is built on demand)
  *     "lat_split" 0/1 (1)        a step in which every instance is warm runs as two launches (warm attempts, then the cold solves of what they left)
- *     "lat_handover" 0/1 (1)     STRAGGLER HAND-OVER of a cold launch (batches of >= "lat_hand_batch" (1025) instances whose row state lives in the workspace: N > 16): the launch stops at
- *                                a trip boundary once at most "lat_hand_target" (1500) instances of the batch are unfinished (not before "lat_hand_min" (8) trips; "lat_hand_cap" > 0:
- *                                after that many trips whatever the count), files them, and a second launch resumes them with ONE instance per wavefront.  Same verified KKT points
- *                                (measured 4e-8 apart at most); 2.96-3.03 -> 2.60-2.69 ms on the N = 50 + walls batch of 4096.  0 = one launch, as in round 5
+ *     "lat_handover" 0/1 (1)     STRAGGLER HAND-OVER of a cold launch (batches of >= "lat_hand_batch" (1025) instances whose row state lives in the workspace: N > 16): the launch stops
+ *                                after "lat_hand_cap" trips through the solver's loop (0 = 16 with the wall rows, 11 without), files its unfinished instances, and a second launch
+ *                                resumes them with ONE instance per wavefront.  Same verified KKT points as the single launch (measured 4e-8 apart at most); 2.96-3.03 -> 2.61 ms on
+ *                                the N = 50 + walls batch of 4096.  0 = one launch, as in round 5.  The trip rule depends on the data only: the same call returns the same bits.
+ *     "lat_hand_target" (0)      > 0: stop the first launch once at most this many instances of the batch are unfinished instead (counted on the device, not before "lat_hand_min" (8)
+ *                                trips).  Adapts to the batch (1500: 2.58 ms on the batch above, vail + walls 2.09 against 2.19) -- but WHEN a wavefront sees the count is a matter of
+ *                                timing: answers then differ by ~1e-8 from run to run (two verified KKT points of the same QP, resumed a trip earlier or later)
  *     "lat_single_max" (1024)    cold lateral batches of at most this many instances (horizons beyond 16 intervals) run one instance per WAVEFRONT from the start: a trip through the
  *                                solver's loop costs 57 us instead of 84 (0: never)
  *     "lat_aux_gate" 0/1 (1)     the serial passes write what a pinned row's multiplier is read from only while an instance of the wavefront is in a polish

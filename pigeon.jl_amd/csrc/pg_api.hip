@@ -67,7 +67,7 @@ struct pg_handle {
     real* d_lat_spc = nullptr;                                  // k_solve_lat's lane-contiguous stage constants (lat_spc_bytes)
     real* d_hand_r = nullptr; int* d_hand_i = nullptr;          // [cap][8] / [cap][16] hand-over records of k_solve_lat's unfinished instances (round 6: SolveOut::hand_mode)
     int lat_single_max = 1024;                                  // option "lat_single_max": cold lateral batches up to this size run ONE instance per wavefront from the start (k_solve_lat<.., 64, 0>)
-    int lat_handover = 1, lat_hand_target = 1500, lat_hand_min = 8, lat_hand_cap = 0, lat_hand_batch = 1025;      // options "lat_handover" (0 off, 1 = on), "lat_hand_target", "lat_hand_min", "lat_hand_cap", "lat_hand_batch" (smallest batch that hands over)
+    int lat_handover = 1, lat_hand_target = 0, lat_hand_min = 8, lat_hand_cap = 0, lat_hand_batch = 1025, lat_hand_work = 0, lat_hand_w0 = 3;      // options "lat_handover" (0 off, 1 = on), "lat_hand_target", "lat_hand_min", "lat_hand_cap", "lat_hand_batch" (smallest batch that hands over)
     int64_t stat_lat_single = 0;                                // read-only option "stat_lat_one_per_wavefront_solves"
     int64_t stat_lat_hand = 0;                                  // read-only option "stat_lat_handover_solves"
     real* d_lat_aux = nullptr;                                  // [cap][64][8] F, Bbar'P Bbar, Bbar'y per stage: what k_solve_lat reads the multiplier of a pinned rate row from
@@ -258,7 +258,7 @@ int pg_create(const pg_config* cfg, pg_handle** out) {
     C.un0 = (real)cfg->vehicle.delta_max; C.un1 = (real)fmax(-cfg->vehicle.Fx_min, cfg->vehicle.Fx_max);      // coupled_lat_long.jl:199
     C.fxmin_n = (real)(cfg->vehicle.Fx_min / fmax(-cfg->vehicle.Fx_min, cfg->vehicle.Fx_max));
     C.formulation = cfg->formulation; C.ux_dummy = (real)(0.5 * (cfg->control.V_min + cfg->control.V_max));
-    C.dbg_instance = -1;                              // (-DPG_DIAG builds: option "diag_instance")
+    C.dbg_poison = 0; C.dbg_instance = -1;                              // (-DPG_DIAG builds: option "diag_instance")
     if (cfg->formulation == PG_DECOUPLED) {          // no u normalisation in the lateral QP (decoupled_lat_long.jl:134-226); inert slots pinned
         C.un0 = 1.0; C.un1 = 1.0; C.fxmin_n = -1.0;
         C.cp.Q_ds = 0.0; C.cp.R_Fx = 0.0; C.cp.R_dFx = 1.0; C.cp.N_HJI = 0; C.cp.W_HJI = 0.0;
@@ -421,6 +421,8 @@ static bool find_option(pg_handle* h, const char* name, OptRef* o) {
     if (n == "lat_hand_target") return I(&h->lat_hand_target, 0, 1 << 30);
     if (n == "lat_hand_min") return I(&h->lat_hand_min, 1, 1 << 20);
     if (n == "lat_hand_cap") return I(&h->lat_hand_cap, 0, 1 << 20);
+    if (n == "lat_hand_work") return I(&h->lat_hand_work, 0, 1 << 20);
+    if (n == "lat_hand_w0") return I(&h->lat_hand_w0, 0, 1 << 10);
     if (n == "lat_hand_batch") return I(&h->lat_hand_batch, 1, 1 << 30);
     if (n == "lat_single_max") return I(&h->lat_single_max, 0, 1 << 30);
     if (n == "lat_pack_only") return I(&h->lat_pack_only, 0, 1);
@@ -444,6 +446,7 @@ static bool find_option(pg_handle* h, const char* name, OptRef* o) {
     if (n == "stat_lat_one_per_wavefront_solves") return S(&h->stat_lat_single);
 #ifdef PG_DIAG      // diagnostic build only (libpigeon_hip_diag.so): fault injection and traces have no place in the shipped libraries
     if (n == "diag_instance") return I(&C.dbg_instance, -1, 1 << 30);
+    if (n == "diag_lat_poison") return I(&C.dbg_poison, 0, 1);
     if (n == "diag_lin_groups") return I(&h->lin_groups, 0, 8);
     if (n == "diag_timeline") return I(&h->debug_timeline, 0, 1);
 #endif
@@ -898,6 +901,14 @@ static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, u
 #endif
     if (h->solve_lat) {      // lateral formulation: four instances per wavefront, always the whole batch in index order
         const dim3 grid((unsigned)((h->B + 3) / 4));
+#ifdef PG_DIAG
+        if (h->dc.dbg_poison) {      // (every byte 0xFF: NaN in both precisions)
+            const size_t cap = (size_t)h->cfg.batch_capacity;
+            if (h->d_lat_ws) HIPCHK(h, hipMemsetAsync(h->d_lat_ws, 0xFF, lat_ws_bytes(cap), st));
+            if (h->d_lat_aux) HIPCHK(h, hipMemsetAsync(h->d_lat_aux, 0xFF, (cap + 1) * 64 * LAT_AUX * sizeof(real), st));
+            if (h->d_lat_spc) HIPCHK(h, hipMemsetAsync(h->d_lat_spc, 0xFF, lat_spc_bytes((int)cap, h->dc.N), st));
+        }
+#endif
         const int slots = (h->dc.N + 15) / 16;
 #define PG_LAT_LAUNCH(NS, W, M) hipLaunchKernelGGL((k_solve_lat<NS, W, M>), grid, dim3(64), h->lat_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, lat_prof)
 #define PG_LAT_LAUNCH_ANY() do { \
@@ -939,12 +950,17 @@ static int launch_solve(pg_handle* h, hipStream_t st, const int* order, int n, u
             LAUNCH_CHECK(h); h->stat_lat_single++;
             return PG_OK;
         }
-        const bool hand = h->lat_handover != 0 && h->lat_mem && !two && !h->sg.capturing && h->B >= h->lat_hand_batch && (h->lat_hand_target > 0 || h->lat_hand_cap > 0);
+        const bool hand = h->lat_handover != 0 && h->lat_mem && !two && !h->sg.capturing && h->B >= h->lat_hand_batch ;
         if (hand) {
             const size_t cap = (size_t)h->cfg.batch_capacity;
             int* const ctl = h->d_todo + cap;
             HIPCHK(h, hipMemsetAsync(ctl, 0, 3 * sizeof(int), st)); h->stat_lat_hand++;      // [0] listed from the front, [1] finished instances, [2] listed from the back
-            O.todo = h->d_todo; O.n_todo = ctl; O.hand_mode = 1; O.hand_cap = h->lat_hand_cap; O.hand_target = h->lat_hand_target; O.hand_min = h->lat_hand_min; O.hand_done = ctl + 1;
+            O.todo = h->d_todo; O.n_todo = ctl; O.hand_mode = 1;
+            // When to stop the first launch.  Default: after a fixed number of trips (16 with the wall rows, 11 without: mean interior-point iterations + 2..3 on the benchmark
+            // batches) -- a rule that depends on the data only, so that the same call gives the same bits.  Option "lat_hand_target" > 0 stops when that few instances of the
+            // batch are unfinished instead (counted on the device: adapts to the batch -- vail + walls 2.09 against 2.19 ms -- but WHEN a wavefront sees the count is a matter
+            // of timing, and an instance resumed one trip earlier or later ends 1e-8 away: two verified KKT points of the same QP, not the same bits).
+            O.hand_cap = h->lat_hand_cap > 0 ? h->lat_hand_cap : ((h->lat_hand_target > 0 || h->lat_hand_work > 0) ? 0 : (h->dc.walls ? 16 : 11)); O.hand_target = h->lat_hand_target; O.hand_min = h->lat_hand_min; O.hand_done = ctl + 1; O.hand_work = h->lat_hand_work; O.hand_w0 = h->lat_hand_w0;
             O.hand_r = h->d_hand_r; O.hand_i = h->d_hand_i;
             if (h->dc.walls) hipLaunchKernelGGL((k_solve_lat<1, true, true, 16, 1>), grid, dim3(64), h->lat_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, lat_prof);
             else hipLaunchKernelGGL((k_solve_lat<1, false, true, 16, 1>), grid, dim3(64), h->lat_lds, st, h->dc, h->B, h->d_qp, h->d_nodes, O, lat_prof);

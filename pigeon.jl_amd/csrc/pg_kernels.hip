@@ -22,6 +22,7 @@ struct DevCfg {
     tdouble dt_short, dt_long;
     int use_correction_step, nsub;
     int formulation;              // PG_COUPLED / PG_DECOUPLED
+    int dbg_poison;               // diagnostic kernel build only (option "diag_lat_poison"): k_solve_lat fills its LDS with NaN before it starts and the host its workspaces before every launch -- a read before the launch's own write shows
     int dbg_instance;             // diagnostic kernel build only: instance whose interior-point trace is printed (-1 = none; option "diag_instance" of the -DPG_DIAG build)
     real ux_dummy;              // decoupled: value of the inert Ux slot of the embedded 8-state problem (strictly inside [V_min, V_max])
     int alias_prev_ts;            // the reference's MPCTimeSteps passes `ts` as prev_ts too (model_predictive_control.jl:15): same array
@@ -1407,7 +1408,7 @@ struct SolveOut { real* sol_x; real* sol_sigma; real* u_out; int* status; int* i
                   real* u_out2;                            // pg_step_dev: the caller's control array, written next to u_out (saves the device-to-device copy behind the launch); may be nullptr
                   int* n_whole;                            // split launch: counts the launches in which the full kernel took the WHOLE batch (`mode` non-zero) -- read-only option "stat_whole_batch_solves"; may be nullptr
                   // k_solve_lat's straggler hand-over (round 6; pg_solve_lat.hip): 0 off, 1 = this launch hands its unfinished instances over (to `todo`), 2 = this launch resumes them (`list`)
-                  int hand_mode, hand_cap, hand_target, hand_min; int* hand_done; real* hand_r; int* hand_i;
+                  int hand_mode, hand_cap, hand_target, hand_min; int* hand_done; real* hand_r; int* hand_i; int hand_work, hand_w0;
                   int list_lo, list_hi; };                 // k_solve_lat in list mode: this launch serves the list only when list_lo <= its length (<= list_hi, when that is set): the host queues one launch per
                                                            // arrangement (one instance per wavefront / four) behind the warm attempts and the DEVICE word decides which of them runs
 

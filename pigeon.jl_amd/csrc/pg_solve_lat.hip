@@ -158,6 +158,9 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     real* const sRec = sI; real* const sTab = sI + (size_t)N * LAT_REC;
     real* const sDum = lds + (size_t)NI * N * LAT_STRIDE; // [64] sink for predicated-off stores
     real* const sZero = sDum + 64;                       // a stored 0
+#ifdef PG_DIAG
+    if (C.dbg_poison) { for (int i = lane; i < (int)lat_lds_doubles(N, NI == 1 ? 1 : 4); i += 64) lds[i] = real(NAN); __syncthreads(); }
+#endif
     if (lane < 8) sZero[lane] = real(0.0);
     constexpr bool XLDS = LPI == 64;                     // the serial passes read the stage matrices from the LDS (a wavefront with ONE instance has the room: 13.6 KB at N = 50)
     real* const sMat = sZero + 8;
@@ -167,7 +170,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     // ---------------- addressing of the serial passes ----------------
     // The stage matrices come from the packed records k_qp_dec wrote (LATP doubles per stage, L2-resident): [8 i + m] = row i of [A | B0+Bf | Bf | c], m = 7 a stored 0.
     const real* const Lb = C.lat_pack + (size_t)b * N * LATP;
-    real* const aux = C.lat_aux + (size_t)b * 64 * LAT_AUX;      // (an invalid lane group of a ragged last wavefront writes the last instance's block again: same values; a resumed launch has one instance per wavefront and no such group)
+    // (an idle lane group -- the tail of a ragged last wavefront, whose lanes run instance B - 1 again and store nothing else -- gets the spare block behind the batch: in a
+    //  list-mode launch the real instance B - 1 may be in ANOTHER wavefront, or long done in another launch, and a second writer of its block is a race: round 6, found by the
+    //  bit-for-bit test of the closed loop with walls -- the multipliers of instance 4095's pinned rows 3e-5 apart between two runs)
+    real* const aux = C.lat_aux + (size_t)(valid ? b : B) * 64 * LAT_AUX;
     // column distribution (matrix + vector pass): lane c holds X[0..3][c] of [Abar | Bbar | cbar]; row 4 is the constant x4; lanes 7..15 read the zero column
     constexpr int XSTR = XLDS ? LAT_XS : LATP, XDT = XLDS ? 32 : 48;
     const real* const Xb = XLDS ? sMat : Lb;
@@ -708,7 +714,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     constexpr int lat_bit[13] = {3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 0, 1, 2};      // local row -> bit of the 16-bit active mask (the numbering of the embedded stage: pigeon_mpc.h)
     const real ntot = (real)(N * NR), intot = real(1.0) / ntot, tol = C.ipm_tol;
     real rp0 = real(0.0), j0 = real(0.0), ms_next = real(0.0), mu0i = C.ipm_mu0, tol_cur = tol, tol_cold = tol, mu = real(0.0), phi = real(1.0);
-    int status = PG_MAX_ITER, it = 0, good = 0, wf = 0, trips = 0, trips0 = 0;      // (trips0: trips an instance had behind it when this launch took it over)
+    int status = PG_MAX_ITER, it = 0, good = 0, wf = 0, trips = 0, trips0 = 0, work = 0;      // (trips0: trips an instance had behind it when this launch took it over)
     bool done = false, warm = false, warm_try = false, warm_failed = false, deferred = false, warm_tried = false, counted = false;
     const int cap = C.ipm_max_iter;
     __syncthreads();
@@ -999,8 +1005,14 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             const Pin pn = pin_of(mt.am, S);
             real qa[5], qb[5];
             if (pmode) {
-                const real gpin = (pn.on && is_act(j)) ? pin_gradient(sidx(j), S, vn) : real(0.0);
-                put_sn(j, sg3); mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, real(0.01) * ptol, unsettled, pn, gpin); put_meta(j, mt); put_tl(j, Tl, Ll);
+                // (!done: an instance whose polish has verified keeps its lanes in the loop while the other instances of the wavefront go on -- its multipliers must not take
+                //  further steps of the multiplier iteration meanwhile: how many trips that is depends on WHO shares the wavefront, and in a list-mode launch that is the order
+                //  in which the to-do list was filled.  Round 6: found by the bit-for-bit test of the lateral closed loop -- the solutions were the same, the multipliers
+                //  handed to the next step's warm attempt 1e-14 apart, the loop 1e-7 apart after ten steps)
+                if (!done) {
+                    const real gpin = (pn.on && is_act(j)) ? pin_gradient(sidx(j), S, vn) : real(0.0);
+                    put_sn(j, sg3); mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, real(0.01) * ptol, unsettled, pn, gpin); put_meta(j, mt); put_tl(j, Tl, Ll);
+                }
                 if constexpr (SPLIT_CORR) {      // the refinement solve behind this one: same set, the multipliers just updated (no sigma mu in a polish)
                     weights(mt.am, Tl, Ll, Cl, S, real(0.0), false, it_, W, ell);
                     vec_terms(S, E, ell, true, qa);
@@ -1067,8 +1079,8 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             weights(mt.am, Tl, Ll, Cl, S, sgmu, true, it_, W, ell);
             eliminate(S, W, ell, E);
             newton(j, S, E, xn, vn, sg3, tp);
-            put_sn(j, sg3);
-            if (pmode) { if (!skip_second && !resume_ipm) {
+            if (!(pmode && done)) put_sn(j, sg3);
+            if (pmode) { if (!skip_second && !resume_ipm && !done) {
                 const Pin pn = pin_of(mt.am, S);
                 const real gpin = (pn.on && is_act(j)) ? pin_gradient(sidx(j), S, vn) : real(0.0);
                 mt.nm = polish_rows(is_act(j), mt.am, Ll, tp, ptol, unsettled, pn, gpin); put_meta(j, mt); put_tl(j, Tl, Ll); } }
@@ -1139,7 +1151,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             if (done && !counted && valid && cs == 0) atomicAdd(O.hand_done, 1);
             counted = counted || done;
             const int fin = __builtin_amdgcn_readfirstlane(__hip_atomic_load(O.hand_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            const bool go = (O.hand_cap > 0 && trips >= O.hand_cap) || (O.hand_target > 0 && trips >= O.hand_min && B - fin <= O.hand_target);
+            // (hand_work: a DETERMINISTIC stand-in for "at a fixed time" -- a trip costs a wavefront a fixed part (the serial passes serve its four instances at once) and a part
+            //  per unfinished instance (the stage-parallel visits): the wavefront stops when hand_w0 + #unfinished, summed over its trips, reaches hand_work)
+            work += O.hand_w0 + __popcll(__ballot(!done && valid && cs == 0));
+            const bool go = (O.hand_cap > 0 && trips >= O.hand_cap) || (O.hand_target > 0 && trips >= O.hand_min && B - fin <= O.hand_target) || (O.hand_work > 0 && work >= O.hand_work);
             if (go && !__all(done)) {
                 if (!done) {
                     if (valid && cs == 0) {
@@ -1164,6 +1179,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         if constexpr (HAND == 1) { if (deferred) { if (pmode != 0) O.todo[B - 1 - atomicAdd(O.n_todo + 2, 1)] = b; else O.todo[atomicAdd(O.n_todo, 1)] = b; } }
         else if (deferred) O.todo[atomicAdd(O.n_todo, 1)] = b;
         if (O.wfail && !listm) {        // (the back-off word belongs to the launch that makes -- or skips -- the warm attempt)
+            if constexpr (!resume) wf = O.wfail[b];      // (read AGAIN rather than kept in a register across the whole solve)
             const int lvl = (wf >> 8) & 0xFF, nl = lvl < 5 ? lvl + 1 : 5;
             O.wfail[b] = !warm ? 0 : (warm_tried ? (warm_failed ? ((nl << 8) | ((1 << nl) - 1)) : 0) : ((lvl << 8) | (((wf & 0xFF) > 0 ? (wf & 0xFF) - 1 : 0))));
         }
@@ -1193,6 +1209,9 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             real* U = O.u_out + (size_t)b * 3;
             U[0] = d; U[1] = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac; U[2] = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
             O.status[b] = (status == PG_SOLVED && C.polish && pstat < 0) ? PG_SOLVED_UNVERIFIED : status; O.iters[b] = it; O.mu[b] = mu; O.polish[b] = pstat;
+#ifdef LAT_DBG_WF
+            O.mu[b] = (real)(wf + 65536 * (warm_tried ? 1 : 0) + 131072 * (warm_failed ? 1 : 0) + 262144 * pchecks);
+#endif
             O.solved[b] = 1;      // model_predictive_control.jl:76: solved = true
         }
     }

@@ -165,6 +165,27 @@ def test_closed_loop_on_the_device_is_reproducible_bit_for_bit(pkg, path):
     assert (runs[0][9] > 0) == (path == "vail"), runs[0][9]
 
 
+@pytest.mark.parametrize("walls", [False, True])
+def test_lateral_closed_loop_on_the_device_is_reproducible_bit_for_bit(pkg, skidpad, walls):
+    """The same for the lateral formulation (round 6): its cold step is the two-launch straggler hand-over, whose first launch stops after a fixed number of TRIPS (a rule of the
+    data alone; the count rule of option "lat_hand_target" depends on when a wavefront sees the device counter and is not the default for that reason), its warm steps the warm
+    attempts + the list launches -- the to-do lists are filled through atomics in whatever order the wavefronts arrive, which decides the block that serves an instance and
+    nothing of its arithmetic.  Two handles, the same calls: the same bits over a 12-step loop of 4096 controllers with N = 50."""
+    B = 4096
+    state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B, seed=12345)
+    runs = []
+    for rep in range(2):
+        m = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, B, N_short=10, N_long=40, walls=walls)
+        m.set_inputs(state, control, t0, time_offset=toff)
+        s, c, t, sh, ch = m.simulate_(12, record=True)
+        st, it, act, mu = m.solve_info()
+        runs.append((s, c, t, sh, ch, st, it, act, m.get_option("stat_lat_handover_solves"), m.get_option("stat_lat_two_launch_solves")))
+        m.close()
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+    assert runs[0][8] == 1 and runs[0][9] == 11          # one cold step through the hand-over, eleven warm steps through the two-launch path
+
+
 def test_launch_shape_options_change_no_result(pkg, skidpad):
     """The options that only shape the pipelined nodes + update_QP launch -- which short-horizon intervals go first (`pipe_first`), after which nodes the recurrence publishes its
     progress (`pipe_pub_short`, `pipe_pub_long`) -- move wavefronts in time, nothing else: nodes, QP data, controls and statuses of a cold 2400-instance step (the pipelined
