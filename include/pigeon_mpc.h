@@ -283,8 +283,11 @@ int pg_synchronize(pg_handle* h);
  *     "lat_hand_target" (0)      > 0: stop the first launch once at most this many instances of the batch are unfinished instead (counted on the device, not before "lat_hand_min" (8)
  *                                trips).  Adapts to the batch (1500: 2.58 ms on the batch above, vail + walls 2.09 against 2.19) -- but WHEN a wavefront sees the count is a matter of
  *                                timing: answers then differ by ~1e-8 from run to run (two verified KKT points of the same QP, resumed a trip earlier or later)
+ *                                ("lat_hand_work" > 0 with "lat_hand_w0": a third, deterministic rule kept for A/B -- stop when w0 + #unfinished instances, summed over the wavefront's
+ *                                trips, reaches the budget: measured worse than the trip count at every weight, EXPERIMENTS 12.8)
  *     "lat_single_max" (1024)    cold lateral batches of at most this many instances (horizons beyond 16 intervals) run one instance per WAVEFRONT from the start: a trip through the
- *                                solver's loop costs 57 us instead of 84 (0: never)
+ *                                solver's loop costs 57 us instead of 84 (0: never).  The same arrangement serves the list a warm step's attempts leave, when it is that short (the length
+ *                                is a device word: both arrangements are queued, one of them returns at once)
  *     "lat_aux_gate" 0/1 (1)     the serial passes write what a pinned row's multiplier is read from only while an instance of the wavefront is in a polish
  *     "nodes_serial" 0/1 (0)     1 = the cold node seeding (both formulations) commits ONE node per pass: the reference's serial recurrence exactly (the default runs 2 / 8 lanes per
  *                                instance ahead on the commanded acceleration and commits the nodes whose solve returned it: identical to 1e-12, 4e-6 in fp32; parity tests use this)
