@@ -1,5 +1,6 @@
 """Diagnostic: long closed loop (PG_STEPS steps of 10 ms, default 3000 = 30 s of driving) of a 4096 batch on every reference path: status counts, instances that needed
-the interior point, step time and tracking error per block of 250 steps.  Looks for slow degradation (stragglers accumulating, instances that stop solving)."""
+the interior point, step time and tracking error per block of 250 steps.  Looks for slow degradation (stragglers accumulating, instances that stop solving).
+PG_FORM=dec | dec_walls: the lateral formulation instead (round 6)."""
 import os, sys, time, glob
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +14,9 @@ for path in names:
     s_end = float(traj.s[-1])
     kw = dict(s_range=(2.0, 0.4 * s_end)) if s_end <= 90 else {}
     state, control, t0, toff = pkg.synthetic.config2_inputs(traj, B, seed=12345, **kw)
-    mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B)
+    # PG_FORM=dec / dec_walls: the lateral formulation (N = 50: k_solve_lat -- cold hand-over at the first step, warm attempts + list-mode launches afterwards)
+    form = os.environ.get("PG_FORM", "coupled")
+    mpc = pkg.BatchedTrajectoryTrackingMPC(traj, B) if form == "coupled" else pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), traj, B, N_short=10, N_long=40, walls=form == "dec_walls")
     mpc.set_inputs(state, control, t0, time_offset=toff)
     print(f"{path}: path length {s_end:.0f} m", flush=True)
     near_end = np.zeros(B, dtype=bool)                       # instances whose horizon has reached the end of the path at some point (the reference extrapolates there)
