@@ -145,8 +145,10 @@ static int configure_lateral(pg_handle* h, std::string* why) {
     if (!h->solve_lat) { C.lat_pack = nullptr; return PG_OK; }
     if (!h->d_lat && hipMalloc((void**)&h->d_lat, cap * N * LATP * sizeof(real)) != hipSuccess) { *why = "hipMalloc failed for the packed lateral stage records"; return PG_ERR_HIP; }
     C.lat_pack = h->d_lat;
-    if (!h->d_lat_aux && hipMalloc((void**)&h->d_lat_aux, (cap + 1) * 64 * LAT_AUX * sizeof(real)) != hipSuccess)      /* (+ 1: the spare block idle lane groups of a resumed launch write) */ { *why = "hipMalloc failed for k_solve_lat's multiplier block"; return PG_ERR_HIP; }
+    if (!h->d_lat_aux && hipMalloc((void**)&h->d_lat_aux, ((cap + 1) * 64 * LAT_AUX + 8) * sizeof(real)) != hipSuccess)      /* (+ 1: the spare block idle lane groups of a resumed launch write) */ { *why = "hipMalloc failed for k_solve_lat's multiplier block"; return PG_ERR_HIP; }
     C.lat_aux = h->d_lat_aux;
+    C.lat_zero = h->d_lat_aux + (cap + 1) * 64 * LAT_AUX;      // (+ 8 stored zeros: DevCfg::lat_zero)
+    if (hipMemset((void*)C.lat_zero, 0, 8 * sizeof(real)) != hipSuccess) { *why = "hipMemset failed"; return PG_ERR_HIP; }
     // (round 4: with the wall rows the two-slot register variant spills 720 B per lane since the warm start was added -- 1.57 ms at N = 30 against 1.36 ms through the
     // workspace; without them the registers still win, 0.94 against 1.01 ms)
     // (round 6: horizons of 17..32 intervals WITHOUT the wall rows used the two-slot register instantiation, k_solve_lat<2, .., false> -- 512 registers + 300 B of scratch, the

@@ -66,6 +66,7 @@ struct DevCfg {
     int nodes_serial;           // option "nodes_serial" (A/B and parity tests): 1 = the cold seeding commits ONE node per pass -- the serial recurrence of the reference to the last bit
     int lat_aux_gate;           // k_solve_lat (option "lat_aux_gate"): the serial passes leave F / B'PB / B'y in lat_aux only while an instance of the wavefront is in a polish
     real* lat_spc;              // lateral formulation: k_solve_lat's lane-contiguous copy of the stage constants of its stage-parallel passes (LAT_SPC_Q; nullptr: not wanted)
+    const real* lat_zero;       // eight stored zeros behind lat_aux: the row a lane of k_solve_lat's roll-out reads when its side of the row is empty
     real* lat_aux;              // lateral formulation: [B][64][8] what the multiplier of a pinned rate row is read from (k_solve_lat, see its header)
     char* lat_ws;               // lateral formulation, horizons beyond 32 intervals: k_solve_lat's per-wavefront workspace (lat_ws_bytes(B); nullptr: not wanted)
     real* lat_pack;             // lateral formulation: [B][N][LATP] packed stage records for k_solve_lat, written by k_qp_dec next to the QP block (nullptr: not wanted)

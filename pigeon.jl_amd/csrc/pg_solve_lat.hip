@@ -57,7 +57,7 @@ constexpr int LAT_TAB = 12;     // serial tables: K[5], kff, Sinv, P cbar [5]
 constexpr int LAT_STRIDE = LAT_REC + LAT_TAB;
 constexpr int LAT_XS = 34;      // one instance per wavefront: the stage matrices (32 doubles: rows of [A | B0+Bf | Bf | c]) and dt of a stage are copied into the LDS once per launch, 34 doubles apart
 __host__ __device__ inline size_t lat_lds_doubles(int N, int instances_per_wavefront = 4) {
-    return (size_t)instances_per_wavefront * N * LAT_STRIDE + 64 + 8 + (instances_per_wavefront == 1 ? (size_t)N * LAT_XS : 0); }
+    return (size_t)instances_per_wavefront * N * LAT_STRIDE + 72 + 16 + (instances_per_wavefront == 1 ? (size_t)N * LAT_XS : 0); }
 // horizons beyond 32 intervals keep the per-row interior-point state in a global workspace (see "stage-parallel part"): bytes per 16-stage slot of one wavefront
 // (13 rows x 64 lanes x (t, lambda) + 7 x 64 x 2 second-order terms + 64 x 4 eliminated slacks + 64 x 16 B of working-set words, fp64), four slots per wavefront
 constexpr size_t LAT_WS_SLOT_BYTES = 23552;
@@ -131,6 +131,12 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     constexpr int NI = 64 / LPI;                          // instances per wavefront
     // diagnostic cycle counters (pg_debug_solve_cycles): 0 barrier terms, 1 matrix pass, 2 vector pass, 3 roll-outs, 4 Newton point / step rules, 5 everything else
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, tprev = prof ? clock64() : 0;
+#ifdef LAT_MP_TIMING
+    unsigned long long mp[4] = {0, 0, 0, 0};      // experiment: sub-phases of a matrix-pass stage (requests, M, G + reciprocal + K, P)
+#define LAT_MPT(i) do { if (prof) { const unsigned long long n_ = clock64(); mp[i] += n_ - mpt; mpt = n_; } } while (0)
+#else
+#define LAT_MPT(i) do { } while (0)
+#endif
     auto stamp = [&](int slot) __attribute__((always_inline)) { if (prof) { const unsigned long long now = clock64(); pc[slot] += now - tprev; tprev = now; } };
     // c: the lane's role in the serial passes (column / row of the stage matrices inside its DPP row); cs: its role in the stage-parallel passes (stage cs, cs + LPI, ...);
     // frow: the lanes that run the serial passes (LPI = 64: ONE DPP row serves the wavefront's one instance; the other three rows sit the pass out under EXEC -- their loads
@@ -156,14 +162,16 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     extern __shared__ real lds[];
     real* const sI = lds + (size_t)g * N * LAT_STRIDE;   // this instance's region: rec[N][12] then tab[N][12]
     real* const sRec = sI; real* const sTab = sI + (size_t)N * LAT_REC;
-    real* const sDum = lds + (size_t)NI * N * LAT_STRIDE; // [64] sink for predicated-off stores
-    real* const sZero = sDum + 64;                       // a stored 0
+    real* const sDum = lds + (size_t)NI * N * LAT_STRIDE; // [72] sink for predicated-off stores (lane + up to four slots)
+    real* const sZero = sDum + 72;                       // a stored 0
 #ifdef PG_DIAG
     if (C.dbg_poison) { for (int i = lane; i < (int)lat_lds_doubles(N, NI == 1 ? 1 : 4); i += 64) lds[i] = real(NAN); __syncthreads(); }
 #endif
     if (lane < 8) sZero[lane] = real(0.0);
     constexpr bool XLDS = LPI == 64;                     // the serial passes read the stage matrices from the LDS (a wavefront with ONE instance has the room: 13.6 KB at N = 50)
-    real* const sMat = sZero + 8;
+    real* const sDelta = sZero + 8;                       // [8] the roll-out's delta row: (0, 0, 0, 0, 1, 1, 0, 0)
+    if (lane < 8) sDelta[lane] = (lane == 4 || lane == 5) ? real(1.0) : real(0.0);
+    real* const sMat = sZero + 16;
     const QpOff o = qp_offsets(N);
     const real* const Q = qp + (size_t)b * C.qp_len;
 
@@ -180,7 +188,9 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     const real* const colp = Xb + (c < 7 ? c : 7);
     const real cx4 = (c == 4 || c == 5) ? real(1.0) : real(0.0);
     // stage-cost column of lane c inside rec[k]: Qhat[i][c] for c < 5, qhat[i] for c == 6, else zero (a stored 0 with stride 0)
-    int qoff[5], qmul[5];
+    // (a per-lane stride is either 0 or one constant: `uniform product & lane mask` -- one v_and with a scalar operand -- instead of a 32-bit multiplication per lane and
+    //  stage, which this hardware issues at a quarter of the rate: round 6)
+    int qoff[5], qmul[5];      // (qmul: the lane MASK, -1 where the lane's column entry is stored, 0 where it reads the stored zero)
 #pragma unroll
     for (int i = 0; i < 5; i++) {
         int e = -1;
@@ -189,39 +199,51 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         else if (c == 3) e = i == 3 ? 3 : -1;
         else if (c == 4) e = i == 4 ? 4 : -1;
         else if (c == 6) e = 6 + i;
-        qoff[i] = e >= 0 ? (int)(sRec - sZero) + e : 0; qmul[i] = e >= 0 ? LAT_REC : 0;
+        qoff[i] = e >= 0 ? (int)(sRec - sZero) + e : 0; qmul[i] = e >= 0 ? -1 : 0;
+        asm volatile("" : "+v"(qmul[i]));      // (opaque: the compiler turns a known 0 / -1 mask back into a condition held in scalar registers -- and spills those)
     }
     const real cpsi = c == 2 ? real(2.0) * C.cp.Q_dpsi : real(0.0);      // Qhat[2][2] = 2 Q_dpsi dt_k is not stored: lane 2 forms it from dt_k
-    const int roff = c == 5 ? (int)(sRec - sZero) + 5 : (c == 6 ? (int)(sRec - sZero) + 11 : 0), rmul = (c == 5 || c == 6) ? LAT_REC : 0;      // Rhat (lane 5) / rhat (lane 6)
+    const int roff = c == 5 ? (int)(sRec - sZero) + 5 : (c == 6 ? (int)(sRec - sZero) + 11 : 0), rmul_ = (c == 5 || c == 6) ? -1 : 0;      // Rhat (lane 5) / rhat (lane 6)
+    int rmul = rmul_; asm volatile("" : "+v"(rmul));
     // table slot lane c writes after a stage of the matrix pass: K[c] (c < 5), kff (lane 6 -> slot 5), Sinv (lane 5 -> slot 6)
     const int wslot = c < 5 ? c : (c == 6 ? 5 : (c == 5 ? 6 : -1));
     const real m6 = c == 6 ? real(1.0) : real(0.0), m5lt = c < 5 ? real(1.0) : real(0.0);
+    // (predicated-off stores go to the lane's sink slot: an offset and a lane mask chosen once, not a pointer select per store)
+    const int mstoff = c == 6 ? (int)(sTab - sZero) + 7 : (int)(sDum - sZero) + lane, wstoff = wslot >= 0 ? (int)(sTab - sZero) + wslot : (int)(sDum - sZero) + lane;
+    int mstmsk = c == 6 ? -1 : 0, wstmsk = wslot >= 0 ? -1 : 0; asm volatile("" : "+v"(mstmsk), "+v"(wstmsk));
 
     // ---------------- Riccati matrix pass (+ the predictor's vector recursion in column 6) ----------------
     // Software-pipelined by hand: the operands of stage k - 1 (global: the matrix column and dt; LDS: the stage-cost column, Rhat / rhat) are requested at the top of
     // stage k and first touched at the top of stage k - 1, a whole stage of arithmetic (~900 cycles) later.
     auto matrix_pass = [&](auto aux_on) __attribute__((always_inline)) {      // aux_on: leave F / B'PB / B'y of every stage in lat_aux (what a pinned row's multiplier is read from)
-        real P[5], X[4], Xn[4], Qc[5], Qn[5], dtk, dtn, radd, raddn;
+        // Three operand sets in rotation (round 6): a stage reads P from the Q slots of set `a` (where the stage before accumulated it), computes on the operands of set `b`
+        // -- whose Q slots it turns into the next P in place -- and requests the operands of the stage after into set `c`.  Rolled with two sets and P / Pn, the loop
+        // copied 23 doubles per stage from the "next" names to the "current" ones (v_mov_b64: a ninth of its instructions); written out three stages per trip, nothing moves.
+        struct MpSet { real X[4], Q[5], dt, r; };
+        MpSet s0, s1, s2;
         {   // P_N = Qhat_{N-1} (cost on node N), p_N = qhat_{N-1}
             const real dtl = Xb[(size_t)(N - 1) * XSTR + XDT];
 #pragma unroll
-            for (int i = 0; i < 5; i++) P[i] = (sZero + qoff[i])[qmul[i] * (N - 1)];
-            P[2] += cpsi * dtl;
+            for (int i = 0; i < 5; i++) s0.Q[i] = (sZero + qoff[i])[(LAT_REC * (N - 1)) & qmul[i]];
+            s0.Q[2] += cpsi * dtl;
         }
-        auto request = [&](int k, real* Xo, real* Qo, real& dto, real& ro) __attribute__((always_inline)) {      // operands of stage k (k < 0: stage 0 again, unused)
+        auto request = [&](int k, MpSet& o) __attribute__((always_inline)) {      // operands of stage k (k < 0: stage 0 again, unused)
             const int kk = k < 0 ? 0 : k, km = kk > 0 ? kk - 1 : 0;
             const real* cp = colp + (size_t)kk * XSTR;
 #pragma unroll
-            for (int i = 0; i < 4; i++) Xo[i] = cp[8 * i];
-            dto = Xb[(size_t)km * XSTR + XDT];                 // dt of stage k - 1: its cost sits on node k
+            for (int i = 0; i < 4; i++) o.X[i] = cp[8 * i];
+            o.dt = Xb[(size_t)km * XSTR + XDT];                // dt of stage k - 1: its cost sits on node k
 #pragma unroll
-            for (int i = 0; i < 5; i++) Qo[i] = (sZero + qoff[i])[qmul[i] * km];
-            ro = (sZero + roff)[rmul * kk];
+            for (int i = 0; i < 5; i++) o.Q[i] = (sZero + qoff[i])[(LAT_REC * km) & qmul[i]];
+            o.r = (sZero + roff)[(LAT_REC * kk) & rmul];
         };
-        request(N - 1, X, Qc, dtk, radd);
-#pragma unroll 1
-        for (int k = N - 1; k >= 0; k--) {
-            request(k - 1, Xn, Qn, dtn, raddn);
+        auto stage = [&](int k, const real* P, MpSet& cur, MpSet& nxt) __attribute__((always_inline)) {
+#ifdef LAT_MP_TIMING
+            unsigned long long mpt = prof ? clock64() : 0;
+#endif
+            request(k - 1, nxt);
+            LAT_MPT(0);
+            real* const X = cur.X; real* const Pn = cur.Q;
             real Xh[5], M[5];
 #pragma unroll
             for (int i = 0; i < 4; i++) { Xh[i] = real(LAT_SYM ? 0.5 : 1.0) * X[i]; M[i] = real(0.0); }
@@ -237,9 +259,11 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
 #endif
                          : "+v"(M[0]), "+v"(M[1]), "+v"(M[2]), "+v"(M[3]), "+v"(M[4])
                          : "v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]), "v"(P[4]), "v"(Xh[0]), "v"(Xh[1]), "v"(Xh[2]), "v"(Xh[3]), "v"(Xh[4]));
+            LAT_MPT(1);
             // lane 6: M = P cbar (kept for the corrector's vector pass), then y = P cbar + p
+            { real* const mp_ = sZero + mstoff + ((LAT_TAB * k) & mstmsk);      // lane 6: sTab[k][7..11]; the others: their five sink slots (sDum is 72 long for this)
 #pragma unroll
-            for (int i = 0; i < 5; i++) { *(c == 6 ? sTab + LAT_TAB * k + 7 + i : sDum + lane) = M[i]; M[i] = fma(m6, P[i], M[i]); }
+              for (int i = 0; i < 5; i++) { mp_[i] = M[i]; M[i] = fma(m6, P[i], M[i]); } }
             // G[c] = sum_i Bbar[i] M[i][c]: lanes 0..4 F, lane 5 Bbar' P Bbar, lane 6 Bbar' y   (Bbar = column 5; its row 4 is 1)
             real G0 = real(0.0), G1 = M[4];
             asm volatile("s_nop 4\n\t"
@@ -249,26 +273,28 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             // (the stage-cost term is added LAST: on a pinned stage it is BIGP (x the pinned value) and would swallow Bbar'P Bbar / Bbar'y, which the row's multiplier needs)
             const real Gb = G0 + G1;                      // lanes 0..4: F; lane 5: Bbar' P Bbar; lane 6: Bbar' y
             if constexpr (decltype(aux_on)::value) aux[(size_t)k * LAT_AUX + (c < 7 ? c : 7)] = Gb;      // (no branch in a pass loop: lanes 7..15 write the unused eighth slot; a wave-uniform "some instance is in a polish" test around the store measured SLOWER, 3.096 against 3.026 ms)
-            const real G = Gb + radd;                     // lane 5: S = Rhat + Bbar' P Bbar; lane 6: f = rhat + Bbar' y
+            const real G = Gb + cur.r;                    // lane 5: S = Rhat + Bbar' P Bbar; lane 6: f = rhat + Bbar' y
             const real Sinv = frcp(lat_bc<5>(G));
             const real Kc = -G * Sinv;                    // lanes 0..4: K[c]; lane 6: kff
-            *(wslot >= 0 ? sTab + LAT_TAB * k + wslot : sDum + lane) = c == 5 ? Sinv : Kc;
-            // P_k[i][c] = Qhat[i][c] + sum_k Abar[k][i] M[k][c] + F[i] K[c]   (lane 6: p_k = qhat + Abar' y + F kff);  Abar[4][i] = (i == 4)
-            real Pn[5];
-#pragma unroll
-            for (int i = 0; i < 5; i++) Pn[i] = Qc[i];
-            Pn[2] += cpsi * dtk;
+            (sZero + wstoff)[(LAT_TAB * k) & wstmsk] = c == 5 ? Sinv : Kc;
+            LAT_MPT(2);
+            // P_k[i][c] = Qhat[i][c] + sum_k Abar[k][i] M[k][c] + F[i] K[c]   (lane 6: p_k = qhat + Abar' y + F kff);  Abar[4][i] = (i == 4): accumulated IN the Q slots of this set
+            Pn[2] += cpsi * cur.dt;
             Pn[4] += M[4];                                // row 4 of Abar is e_4'
             asm volatile("s_nop 4\n\t"
 #define LAT_P1(xk, mk) LAT_DPP(0, xk, mk, 0) LAT_DPP(1, xk, mk, 1) LAT_DPP(2, xk, mk, 2) LAT_DPP(3, xk, mk, 3) LAT_DPP(4, xk, mk, 4)
                          LAT_P1(5, 9) LAT_P1(6, 10) LAT_P1(7, 11) LAT_P1(8, 12) LAT_P1(13, 14)
                          : "+v"(Pn[0]), "+v"(Pn[1]), "+v"(Pn[2]), "+v"(Pn[3]), "+v"(Pn[4])
                          : "v"(X[0]), "v"(X[1]), "v"(X[2]), "v"(X[3]), "v"(M[0]), "v"(M[1]), "v"(M[2]), "v"(M[3]), "v"(G), "v"(Kc));
-#pragma unroll
-            for (int i = 0; i < 5; i++) { P[i] = Pn[i]; Qc[i] = Qn[i]; }
-#pragma unroll
-            for (int i = 0; i < 4; i++) X[i] = Xn[i];
-            dtk = dtn; radd = raddn;
+            LAT_MPT(3);
+        };
+        request(N - 1, s1);
+        int k = N - 1;
+#pragma unroll 1
+        while (true) {
+            stage(k, s0.Q, s1, s2); if (--k < 0) break;
+            stage(k, s1.Q, s2, s0); if (--k < 0) break;
+            stage(k, s2.Q, s0, s1); if (--k < 0) break;
         }
     };
 
@@ -277,15 +303,17 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     auto vector_pass = [&](auto aux_on) __attribute__((always_inline)) {
         constexpr int D = LAT_PREFETCH_V;
         real buf[D][4];
-        const int mcoff = c < 5 ? (int)(sTab - sZero) + 7 + c : 0, mcmul = c < 5 ? LAT_TAB : 0;       // P cbar [c]
+        const int mcoff = c < 5 ? (int)(sTab - sZero) + 7 + c : 0, mcmul_ = c < 5 ? -1 : 0;       // P cbar [c]
+        int mcmul = mcmul_; asm volatile("" : "+v"(mcmul));
         const int koff = c < 5 ? (int)(sTab - sZero) + c : 0;                                        // K[c]
-        const int qvoff = c < 5 ? (int)(sRec - sZero) + 6 + c : 0, qvmul = c < 5 ? LAT_REC : 0;      // qhat[c]
-        real p = (sZero + qvoff)[qvmul * (N - 1)];
+        const int qvoff = c < 5 ? (int)(sRec - sZero) + 6 + c : 0, qvmul_ = c < 5 ? -1 : 0;      // qhat[c]
+        int qvmul = qvmul_; asm volatile("" : "+v"(qvmul));
+        real p = (sZero + qvoff)[(LAT_REC * (N - 1)) & qvmul];
         auto request = [&](int k, real* Xo) __attribute__((always_inline)) { const real* cp = colp + (size_t)(k < 0 ? 0 : k) * XSTR;
 #pragma unroll
             for (int i = 0; i < 4; i++) Xo[i] = cp[8 * i]; };
         auto request_lds = [&](int k, real* o5) __attribute__((always_inline)) { const int kk = k < 0 ? 0 : k, km = kk > 0 ? kk - 1 : 0;
-            o5[0] = (sZero + mcoff)[mcmul * kk]; o5[1] = (sZero + koff)[mcmul * kk]; o5[2] = (sZero + qvoff)[qvmul * km]; o5[3] = sRec[LAT_REC * kk + 11]; o5[4] = sTab[LAT_TAB * kk + 6]; };
+            o5[0] = (sZero + mcoff)[(LAT_TAB * kk) & mcmul]; o5[1] = (sZero + koff)[(LAT_TAB * kk) & mcmul]; o5[2] = (sZero + qvoff)[(LAT_REC * km) & qvmul]; o5[3] = sRec[LAT_REC * kk + 11]; o5[4] = sTab[LAT_TAB * kk + 6]; };
 #pragma unroll
         for (int u = 0; u < D; u++) request(N - 1 - u, buf[u]);
         real lo[5], ln[5];
@@ -316,35 +344,48 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     };
 
     // ---------------- roll-out: lane i < 4 holds row i of [A | B0+Bf | Bf | c], lane 4 the delta row, lane 5 the gain row (K | 0 | kff) ----------------
-    const int ri = c < 4 ? c : 0;
-    const real wA = c < 4 ? real(1.0) : real(0.0), wD = c == 4 ? real(1.0) : real(0.0);
     const real x0c = c < 4 ? Q[o.qcurr + 2 + c] : (c == 4 ? Q[o.ucurr] : real(0.0));
     auto forward_pass = [&](bool use_gain) __attribute__((always_inline)) {
         constexpr int D = LAT_PREFETCH_F;
-        const bool isK = c == 5 && use_gain;          // (a select, not a multiplication by 0: the gain table holds nothing before the first matrix pass)
+        // Row of lane c = (what it reads from the matrix side) + (what it reads from the LDS side), every lane through the same two loads with ITS OWN base and stride
+        // (round 6: the per-element selects "gain row or matrix row" and the multiplications by a 0 / 1 lane weight were 19 of a stage's 53 instructions):
+        //   lanes 0..3: row c of [A | B0+Bf | Bf | c]  +  a stored zero row         lane 4: zero row  +  the delta row (0, 0, 0, 0, 1, 1, 0)
+        //   lane 5: zero row  +  the gain row (K | . | kff) of the table, or a zero row before the first matrix pass (v = 0)        lanes 6..15: zero + zero
+        // (the table keeps kff in slot 5, where the row wants a 0 and the constant term one slot later: element 5 is taken with a lane weight, element 6 through its own address)
+        const bool isK = c == 5 && use_gain;
         real xr = x0c;
-        const real2* const rowp = reinterpret_cast<const real2*>(Xb + 8 * ri);
-        const real2* const tabp = reinterpret_cast<const real2*>(sTab);
-        real2 buf[D][4], kt[3], ktn[3];
-        auto request = [&](int k, real2* o4) __attribute__((always_inline)) { const real2* rp = rowp + (size_t)(k < N ? k : N - 1) * (XSTR / 2);
+        // (LDS addresses are INTEGER offsets from one LDS base: a pointer chosen per lane would lose its address space -- flat loads, and they were)
+        int gs = c < 4 ? -1 : 0; asm volatile("" : "+v"(gs));                                       // (lane masks, as above)
+        const int goff = c < 4 ? (int)(sMat - sZero) + 8 * c : 0;                                  // (matrices in the LDS: one instance per wavefront)
+        const real* const gsrc = c < 4 ? Lb + 8 * c : C.lat_zero;                                  // (matrices in the packed records: two global pointers)
+        const int loff = isK ? (int)(sTab - sZero) : (c == 4 ? (int)(sDelta - sZero) : 0);
+        const int loff6 = isK ? loff + 5 : loff + 6;
+        int ls = isK ? -1 : 0; asm volatile("" : "+v"(ls));
+        const real w5 = c == 5 ? real(0.0) : real(1.0);
+        real2 buf[D][4], kt[3], ktn[3]; real k6, k6n;
+        auto request = [&](int k, real2* o4) __attribute__((always_inline)) {
+            const int kc = k < N ? k : N - 1;
+            const real2* rp;
+            if constexpr (XLDS) rp = reinterpret_cast<const real2*>(sZero + goff + ((XSTR * kc) & gs)); else rp = reinterpret_cast<const real2*>(gsrc + (unsigned)((XSTR * kc) & gs));
 #pragma unroll
             for (int q = 0; q < 4; q++) o4[q] = rp[q]; };
-        auto request_lds = [&](int k, real2* o3) __attribute__((always_inline)) { const real2* tp = tabp + (LAT_TAB / 2) * (k < N ? k : N - 1);
+        auto request_lds = [&](int k, real2* o3, real& o6) __attribute__((always_inline)) { const int kc = k < N ? k : N - 1; const real2* tp = reinterpret_cast<const real2*>(sZero + loff + ((LAT_TAB * kc) & ls));
 #pragma unroll
-            for (int q = 0; q < 3; q++) o3[q] = tp[q]; };
+            for (int q = 0; q < 3; q++) o3[q] = tp[q];
+            o6 = (sZero + loff6)[(LAT_TAB * kc) & ls]; };
 #pragma unroll
         for (int u = 0; u < D; u++) request(u, buf[u]);
-        request_lds(0, kt);
+        request_lds(0, kt, k6);
 #pragma unroll 1
         for (int k0 = 0; k0 < N; k0 += D) {
             // (one basic block per D stages, as in the vector pass; stages >= N of the last group run on the last stage's operands and store nothing)
 #pragma unroll
             for (int u = 0; u < D; u++) {
                 const int k = k0 + u;
-                request_lds(k + 1, ktn);
+                request_lds(k + 1, ktn, k6n);
                 real R[7];
-                R[0] = isK ? kt[0].x : wA * buf[u][0].x; R[1] = isK ? kt[0].y : wA * buf[u][0].y; R[2] = isK ? kt[1].x : wA * buf[u][1].x; R[3] = isK ? kt[1].y : wA * buf[u][1].y;
-                R[4] = isK ? kt[2].x : wA * buf[u][2].x + wD; R[5] = wA * buf[u][2].y + wD; R[6] = isK ? kt[2].y : wA * buf[u][3].x;
+                R[0] = buf[u][0].x + kt[0].x; R[1] = buf[u][0].y + kt[0].y; R[2] = buf[u][1].x + kt[1].x; R[3] = buf[u][1].y + kt[1].y;
+                R[4] = buf[u][2].x + kt[2].x; R[5] = fma(w5, kt[2].y, buf[u][2].y); R[6] = buf[u][3].x + k6;
                 asm volatile("" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]), "+v"(R[5]), "+v"(R[6]));      // the row is formed BEFORE its buffer is re-requested
                 request(k + D, buf[u]);
                 real acc = R[6], xn;
@@ -356,6 +397,7 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
                 *((c < 6 && k < N) ? sRec + LAT_REC * (k < N ? k : 0) + c : sDum + lane) = xn;
 #pragma unroll
                 for (int q = 0; q < 3; q++) kt[q] = ktn[q];
+                k6 = k6n;
             }
         }
     };
@@ -1172,7 +1214,11 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     }
     stamp(5);
     if (prof && valid && cs == 0) for (int i = 0; i < 6; i++) prof[(size_t)b * 6 + i] = pc[i];
-    if (prof && valid && cs == 0) { unsigned long long* tl = prof + (size_t)B * 6 + 1024 + (size_t)b * 3; tl[0] = dbg_tr0; tl[1] = dbg_tr1; tl[2] = (unsigned long long)dbg_n | ((unsigned long long)trips << 32) | ((unsigned long long)trips0 << 48); }      // (the [B][3] region k_solve uses for its timeline)
+    if (prof && valid && cs == 0) { unsigned long long* tl = prof + (size_t)B * 6 + 1024 + (size_t)b * 3; tl[0] = dbg_tr0; tl[1] = dbg_tr1;
+#ifdef LAT_MP_TIMING
+        tl[0] = (mp[0] >> 4) | ((mp[1] >> 4) << 32); tl[1] = (mp[2] >> 4) | ((mp[3] >> 4) << 32);
+#endif
+        tl[2] = (unsigned long long)dbg_n | ((unsigned long long)trips << 32) | ((unsigned long long)trips0 << 48); }      // (the [B][3] region k_solve uses for its timeline)
 
     // ---------------- outputs ----------------
     if (valid && cs == 0) {
