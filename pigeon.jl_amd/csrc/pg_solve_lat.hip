@@ -83,6 +83,10 @@ template <int K> PG_DEV real lat_bc(real v) {
 PG_DEV real row_sum(real v) { v += dpp_move<0xB1>(v); v += dpp_move<0x4E>(v); v += dpp_move<0x124>(v); v += dpp_move<0x128>(v); return v; }
 PG_DEV real row_max(real v) { v = fmax(v, dpp_move<0xB1>(v)); v = fmax(v, dpp_move<0x4E>(v)); v = fmax(v, dpp_move<0x124>(v)); v = fmax(v, dpp_move<0x128>(v)); return v; }
 // all-reduce over the LPI lanes that serve one instance in the stage-parallel passes: a DPP row (16), or the whole wavefront (64: one instance per wavefront, round 6)
+// (round 6, tried and dropped: forming the sums of the two arrangements in ONE order -- per-slot subtotals, lanes l % 16, + 16, + 32, + 48 first, then the row butterfly -- so that
+//  an instance takes the same iterations to the same bits in either.  The sums then agree; the per-row arithmetic does not: the compiler contracts multiply-adds differently in the
+//  rolled slot loop of the workspace variant and in the single visit of the register variant -- multipliers one ulp apart after the FIRST iteration on all 256 instances of a
+//  test batch (tools/gpu_lat_arrangements.py).  The arrangements agree to 1e-7 in the answer, not bit for bit; which arrangement runs is a rule of the data alone.)
 template <int LPI> PG_DEV real grp_sum(real v) { v = row_sum(v); if constexpr (LPI == 64) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); } return v; }
 template <int LPI> PG_DEV real grp_max(real v) { v = row_max(v); if constexpr (LPI == 64) { v = fmax(v, __shfl_xor(v, 16)); v = fmax(v, __shfl_xor(v, 32)); } return v; }
 // reciprocal of the interior-point weights: hardware seed + ONE Newton step (~1e-14 relative in fp64; the Newton system only has to be consistent, see assemble)
@@ -187,35 +191,38 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     const real* const Xb = XLDS ? sMat : Lb;
     const real* const colp = Xb + (c < 7 ? c : 7);
     const real cx4 = (c == 4 || c == 5) ? real(1.0) : real(0.0);
-    // stage-cost column of lane c inside rec[k]: Qhat[i][c] for c < 5, qhat[i] for c == 6, else zero (a stored 0 with stride 0)
-    // (a per-lane stride is either 0 or one constant: `uniform product & lane mask` -- one v_and with a scalar operand -- instead of a 32-bit multiplication per lane and
-    //  stage, which this hardware issues at a quarter of the rate: round 6)
-    int qoff[5], qmul[5];      // (qmul: the lane MASK, -1 where the lane's column entry is stored, 0 where it reads the stored zero)
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-        int e = -1;
-        if (c == 0) e = i == 0 ? 0 : (i == 1 ? 1 : -1);
-        else if (c == 1) e = i == 0 ? 1 : (i == 1 ? 2 : -1);
-        else if (c == 3) e = i == 3 ? 3 : -1;
-        else if (c == 4) e = i == 4 ? 4 : -1;
-        else if (c == 6) e = 6 + i;
-        qoff[i] = e >= 0 ? (int)(sRec - sZero) + e : 0; qmul[i] = e >= 0 ? -1 : 0;
-        asm volatile("" : "+v"(qmul[i]));      // (opaque: the compiler turns a known 0 / -1 mask back into a condition held in scalar registers -- and spills those)
-    }
     const real cpsi = c == 2 ? real(2.0) * C.cp.Q_dpsi : real(0.0);      // Qhat[2][2] = 2 Q_dpsi dt_k is not stored: lane 2 forms it from dt_k
-    const int roff = c == 5 ? (int)(sRec - sZero) + 5 : (c == 6 ? (int)(sRec - sZero) + 11 : 0), rmul_ = (c == 5 || c == 6) ? -1 : 0;      // Rhat (lane 5) / rhat (lane 6)
-    int rmul = rmul_; asm volatile("" : "+v"(rmul));
     // table slot lane c writes after a stage of the matrix pass: K[c] (c < 5), kff (lane 6 -> slot 5), Sinv (lane 5 -> slot 6)
     const int wslot = c < 5 ? c : (c == 6 ? 5 : (c == 5 ? 6 : -1));
     const real m6 = c == 6 ? real(1.0) : real(0.0), m5lt = c < 5 ? real(1.0) : real(0.0);
-    // (predicated-off stores go to the lane's sink slot: an offset and a lane mask chosen once, not a pointer select per store)
-    const int mstoff = c == 6 ? (int)(sTab - sZero) + 7 : (int)(sDum - sZero) + lane, wstoff = wslot >= 0 ? (int)(sTab - sZero) + wslot : (int)(sDum - sZero) + lane;
-    int mstmsk = c == 6 ? -1 : 0, wstmsk = wslot >= 0 ? -1 : 0; asm volatile("" : "+v"(mstmsk), "+v"(wstmsk));
 
     // ---------------- Riccati matrix pass (+ the predictor's vector recursion in column 6) ----------------
     // Software-pipelined by hand: the operands of stage k - 1 (global: the matrix column and dt; LDS: the stage-cost column, Rhat / rhat) are requested at the top of
     // stage k and first touched at the top of stage k - 1, a whole stage of arithmetic (~900 cycles) later.
     auto matrix_pass = [&](auto aux_on) __attribute__((always_inline)) {      // aux_on: leave F / B'PB / B'y of every stage in lat_aux (what a pinned row's multiplier is read from)
+        // (the lane's offsets and masks are formed HERE, per call, not once per kernel: kept alive across the whole solve they are parked in accumulation registers and read back at
+        //  every use -- 22 reads per stage; the volatile asm keeps the compiler from hoisting them out again)
+        // stage-cost column of lane c inside rec[k]: Qhat[i][c] for c < 5, qhat[i] for c == 6, else zero (a stored 0 with stride 0)
+        // (a per-lane stride is either 0 or one constant: `uniform product & lane mask` -- one v_and with a scalar operand -- instead of a 32-bit multiplication per lane and
+        //  stage, which this hardware issues at a quarter of the rate: round 6)
+        int qoff[5], qmul[5];      // (qmul: the lane MASK, -1 where the lane's column entry is stored, 0 where it reads the stored zero)
+    #pragma unroll
+        for (int i = 0; i < 5; i++) {
+            int e = -1;
+            if (c == 0) e = i == 0 ? 0 : (i == 1 ? 1 : -1);
+            else if (c == 1) e = i == 0 ? 1 : (i == 1 ? 2 : -1);
+            else if (c == 3) e = i == 3 ? 3 : -1;
+            else if (c == 4) e = i == 4 ? 4 : -1;
+            else if (c == 6) e = 6 + i;
+            qoff[i] = e >= 0 ? (int)(sRec - sZero) + e : 0; qmul[i] = e >= 0 ? -1 : 0;
+            asm volatile("" : "+v"(qmul[i]));      // (opaque: the compiler turns a known 0 / -1 mask back into a condition held in scalar registers -- and spills those)
+        }
+        const int roff = c == 5 ? (int)(sRec - sZero) + 5 : (c == 6 ? (int)(sRec - sZero) + 11 : 0), rmul_ = (c == 5 || c == 6) ? -1 : 0;      // Rhat (lane 5) / rhat (lane 6)
+        int rmul = rmul_; asm volatile("" : "+v"(rmul));
+        // (predicated-off stores go to the lane's sink slot: an offset and a lane mask chosen once, not a pointer select per store)
+        const int mstoff = c == 6 ? (int)(sTab - sZero) + 7 : (int)(sDum - sZero) + lane, wstoff = wslot >= 0 ? (int)(sTab - sZero) + wslot : (int)(sDum - sZero) + lane;
+        int mstmsk = c == 6 ? -1 : 0, wstmsk = wslot >= 0 ? -1 : 0; asm volatile("" : "+v"(mstmsk), "+v"(wstmsk));
+
         // Three operand sets in rotation (round 6): a stage reads P from the Q slots of set `a` (where the stage before accumulated it), computes on the operands of set `b`
         // -- whose Q slots it turns into the next P in place -- and requests the operands of the stage after into set `c`.  Rolled with two sets and P / Pn, the loop
         // copied 23 doubles per stage from the "next" names to the "current" ones (v_mov_b64: a ninth of its instructions); written out three stages per trip, nothing moves.
@@ -818,8 +825,9 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         }
         // cost of the starting point (tracking terms on node s + 1, the linear penalties of the soft-row slacks): it sets the scale of the first barrier parameter below
         if (actj) {
-            j0 += real(0.5) * S.dts * (real(2.0) * C.cp.Q_dpsi * xs[2] * xs[2] + real(2.0) * C.cp.Q_e * xs[3] * xs[3] + real(2.0) * C.cp.R_delta * xs[4] * xs[4])
-                  + S.dts * (C.cp.W_beta * s1 + C.cp.W_r * s2 + (WALLS ? C.wall_weight * sw : real(0.0)));
+            real j0s = real(0.5) * S.dts * (real(2.0) * C.cp.Q_dpsi * xs[2] * xs[2] + real(2.0) * C.cp.Q_e * xs[3] * xs[3] + real(2.0) * C.cp.R_delta * xs[4] * xs[4])
+                       + S.dts * (C.cp.W_beta * s1 + C.cp.W_r * s2 + (WALLS ? C.wall_weight * sw : real(0.0)));
+            j0 += j0s;
         }
         real Tl[NR], Ll[NR], Cl[NR];
 #pragma unroll
@@ -840,11 +848,13 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     for_slots([&](int j) __attribute__((always_inline)) {
         real Tl[NR], Ll[NR]; get_tl(j, Tl, Ll);
         const real* Lp = O.lam + ((size_t)b * N + (is_act(j) ? sidx(j) : N - 1)) * 16;
+        real ms = real(0.0);
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             const real lw = wipm ? fmax(fmax(Lp[lat_bit[r]], real(0.0)), C.lat_wmu * lat_rcp(Tl[r])) : mu0i * lat_rcp(Tl[r]);
-            Ll[r] = is_act(j) ? lw : real(1.0); ms_next += is_act(j) ? Tl[r] * Ll[r] : real(0.0);
+            Ll[r] = is_act(j) ? lw : real(1.0); ms += Tl[r] * Ll[r];
         }
+        ms_next += is_act(j) ? ms : real(0.0);
         put_tl(j, Tl, Ll);
     });
     if (wipm) mu0i = grp_sum<LPI>(ms_next) * intot;
@@ -992,8 +1002,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
                 real msr = real(0.0);
                 for_slots([&](int j) __attribute__((always_inline)) {
                     real Tl[NR], Ll[NR], Cl[NR]; get_tl(j, Tl, Ll); get_cr(j, Cl);
+                    real ms = real(0.0);
 #pragma unroll
-                    for (int r = 0; r < NR; r++) { Ll[r] = is_act(j) ? Cl[r] : real(1.0); msr += is_act(j) ? Tl[r] * Ll[r] : real(0.0); }
+                    for (int r = 0; r < NR; r++) { Ll[r] = is_act(j) ? Cl[r] : real(1.0); ms += Tl[r] * Ll[r]; }
+                    msr += is_act(j) ? ms : real(0.0);
                     put_tl(j, Tl, Ll);
                 });
                 mu = grp_sum<LPI>(msr) * intot;
