@@ -763,7 +763,10 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
     constexpr int lat_bit[13] = {3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 0, 1, 2};      // local row -> bit of the 16-bit active mask (the numbering of the embedded stage: pigeon_mpc.h)
     const real ntot = (real)(N * NR), intot = real(1.0) / ntot, tol = C.ipm_tol;
     real rp0 = real(0.0), j0 = real(0.0), ms_next = real(0.0), mu0i = C.ipm_mu0, tol_cur = tol, tol_cold = tol, mu = real(0.0), phi = real(1.0);
-    int status = PG_MAX_ITER, it = 0, good = 0, wf = 0, trips = 0, trips0 = 0, work = 0;      // (trips0: trips an instance had behind it when this launch took it over)
+    int status = PG_MAX_ITER, it = 0, good = 0, wf = 0, trips = 0, trips0 = 0, work = 0;
+#ifdef LAT_TRIP_MIX
+    unsigned long long mixI = 0, mixP = 0, mixB = 0, mixA = 0;      // experiment: trips of this wavefront with an instance in its interior point / in a polish / both; unfinished instances summed over trips
+#endif      // (trips0: trips an instance had behind it when this launch took it over)
     bool done = false, warm = false, warm_try = false, warm_failed = false, deferred = false, warm_tried = false, counted = false;
     const int cap = C.ipm_max_iter;
     __syncthreads();
@@ -1043,6 +1046,9 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
         // (round 6: lat_aux is read by the polish check of a PINNED stage only -- a wavefront none of whose instances is in its polish runs the copy of the two passes
         //  without those stores: one copy or the other per pass, no test per store (that was measured slower in round 5))
         const bool aux_need = C.lat_aux_gate == 0 || __any(pmode != 0);
+#ifdef LAT_TRIP_MIX
+        { const bool ai = __any(!done && pmode == 0 && valid), ap_ = __any(!done && pmode != 0 && valid); mixI += ai ? 1 : 0; mixP += ap_ ? 1 : 0; mixB += (ai && ap_) ? 1 : 0; mixA += __popcll(__ballot(!done && valid && cs == 0)); }
+#endif
         if (frow) { if (aux_need) matrix_pass(std::true_type{}); else matrix_pass(std::false_type{}); }
         wave_sync();
         stamp(1);
@@ -1230,6 +1236,9 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
 #ifdef LAT_MP_TIMING
         tl[0] = (mp[0] >> 4) | ((mp[1] >> 4) << 32); tl[1] = (mp[2] >> 4) | ((mp[3] >> 4) << 32);
 #endif
+#ifdef LAT_TRIP_MIX
+        tl[0] = mixI | (mixP << 16) | (mixB << 32) | (mixA << 48);
+#endif
         tl[2] = (unsigned long long)dbg_n | ((unsigned long long)trips << 32) | ((unsigned long long)trips0 << 48); }      // (the [B][3] region k_solve uses for its timeline)
 
     // ---------------- outputs ----------------
@@ -1267,9 +1276,6 @@ __global__ __launch_bounds__(64, 1) void k_solve_lat(DevCfg C, int B, const real
             real* U = O.u_out + (size_t)b * 3;
             U[0] = d; U[1] = Fx > real(0.0) ? Fx * C.veh.fwd_frac : Fx * C.veh.fwb_frac; U[2] = Fx > real(0.0) ? Fx * C.veh.rwd_frac : Fx * C.veh.rwb_frac;
             O.status[b] = (status == PG_SOLVED && C.polish && pstat < 0) ? PG_SOLVED_UNVERIFIED : status; O.iters[b] = it; O.mu[b] = mu; O.polish[b] = pstat;
-#ifdef LAT_DBG_WF
-            O.mu[b] = (real)(wf + 65536 * (warm_tried ? 1 : 0) + 131072 * (warm_failed ? 1 : 0) + 262144 * pchecks);
-#endif
             O.solved[b] = 1;      // model_predictive_control.jl:76: solved = true
         }
     }
