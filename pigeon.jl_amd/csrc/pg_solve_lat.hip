@@ -10,16 +10,24 @@
 // iteration, vector pass for the corrector, dynamics and slacks exact at every Newton point), but mapped for a 5 x 5 stage instead of being embedded in the 8 x 8 one:
 //
 //  * SIXTEEN lanes = one instance, four instances per wavefront (one DPP row each): 4096 instances = 1024 wavefronts = one per SIMD of the chip, a single round.
-//  * Stage-parallel work (barrier terms, slack elimination, Newton point, step rules): lane c of a row owns stages c, c + 16, ... (NSLOT of them); t and lambda of its rows
-//    live in its registers for the whole solve.
+//    Round 6: or the WHOLE wavefront = one instance (template argument LPI = 64: lane = stage in the stage-parallel passes, the serial passes in the first DPP row) -- for cold
+//    batches of up to 1024 instances, for the list a warm step's attempts leave, and for the stragglers a cold launch of a large batch hands over (HAND = 1 -> HAND = 2, below).
+//  * Stage-parallel work (barrier terms, slack elimination, Newton point, step rules): lane c of a row owns stages c, c + 16, c + 32, c + 48 (one slot visit each per pass); t,
+//    lambda and the second-order term of its rows live in a per-wavefront workspace in global memory (template argument MEM: every horizon beyond 16 intervals; L2 / Infinity
+//    Cache resident, 6 TB/s through the memory side at B = 4096) -- or, with one instance per wavefront, in the lane's registers for the whole solve.
 //  * Serial passes: lane c holds COLUMN c of the stage matrices ([Abar | Bbar | cbar] = columns 0..6, P = columns 0..4, the vector recursion rides in column 6), loaded
-//    straight from the QP data in global memory (L2) one stage ahead -- no LDS copy of the dynamics.  Every product is a sequence of v_fmac_f64_dpp row_newbcast:k -- the
-//    broadcast of lane k's register to its row fused into the multiply-add (tools/probes/dpp_f64_probe.hip: 8.5 cycles against 22.5 for v_mov_b64_dpp + v_fma_f64, which is
-//    what the compiler emits for the builtin) -- so a stage's matrix recursion is ~90 instructions with NO LDS traffic and no cross-lane shuffles in the dependent chain.
+//    from the packed stage records in global memory (L2) one stage ahead (from an LDS copy where the wavefront has one instance and the room).  Every product is a sequence
+//    of v_fmac_f64_dpp row_newbcast:k -- the broadcast of lane k's register to its row fused into the multiply-add (tools/probes/dpp_f64_probe.hip: 8.5 cycles against 22.5
+//    for v_mov_b64_dpp + v_fma_f64, which is what the compiler emits for the builtin) -- no LDS traffic and no cross-lane shuffles in the dependent chain.  A stage of the
+//    matrix pass is 181 instructions (79 of them DPP multiply-adds; round 6 took it from 193: three operand sets in rotation instead of register copies, per-lane strides as
+//    lane masks, store addresses chosen once -- EXPERIMENTS 12.10), 1000-1100 cycles with one wavefront per SIMD.
 //    P is used from both orientations in M = P [Abar Bbar cbar] (M = (P + P')/2 X): the antisymmetric rounding error of the recursion never propagates (k_solve
 //    symmetrises through LDS every stage at N = 50).
-//  * The roll-out holds ROW i of [Abar | Bbar | cbar] in lane i and the gain row in lane 5: x_{k+1} = six fused multiply-adds per stage.
+//  * The roll-out holds ROW i of [Abar | Bbar | cbar] in lane i, the delta row in lane 4 and the gain row in lane 5 -- every lane forms its row as (matrix side) + (LDS
+//    side) through the same two loads with its own base and stride -- : x_{k+1} = six fused multiply-adds per stage, 47 instructions.
 //  * LDS per instance: 24 doubles per stage (stage cost terms that the roll-out result overwrites, gains, S^-1, P cbar) = 9.6 KB at N = 50: four wavefronts per CU.
+//  * STRAGGLER HAND-OVER (round 6, at the kernel itself): a cold batch needs 13 trips through the loop on average and 26-29 for its slowest instance.  The first launch
+//    (HAND = 1) stops after a fixed number of trips and files its unfinished instances; the second (HAND = 2) resumes them one per wavefront (2.96-3.03 -> 2.47-2.50 ms).
 //
 //  * Round 5 -- PINNED INPUTS.  The stage has ONE input, and a held steering-rate row fixes it (v = +ddmax / -ddmin).  The polish eliminates such a row exactly instead of
 //    iterating on its multiplier: the stage cost of a pinned stage carries Rhat = BIGP, rhat = -BIGP v -- a penalty so large that 1 / BIGP vanishes against everything else
