@@ -148,3 +148,35 @@ def test_warm_lateral_step_of_the_full_batch_every_instance_against_the_oracle(p
     assert (pol >= 1).sum() >= B - 8, int((pol < 0).sum())          # round 4: 37-60 unverified answers per step (stalled multipliers of held rate rows); pinned: 0-4
     assert np.max(np.abs(uw[both, 0] - uc[both, 0])) <= 3e-7                  # two verified KKT points of the same QP (each within 2e-7 of the oracle's: measured 1.3e-7 apart)
     assert np.mean(it == 0) >= min_served, np.mean(it == 0)
+
+
+def test_short_list_behind_the_warm_attempts_runs_one_instance_per_wavefront(pkg, skidpad):
+    """Round 6: behind the warm attempts of a lateral step the unserved instances are solved cold from a to-do list; a list of up to `lat_single_max` (1024) instances takes the
+    one-instance-per-wavefront arrangement, a longer one four per wavefront -- both launches are queued, the DEVICE word (the list's length) picks one.  The host cannot see the
+    choice; the answers can: the two arrangements end in the same verified KKT points (3e-7) but not in the same bits (their sums run over 64 and 16 lanes), so a warm step whose
+    list is short differs in bits from the same step with the option at 0 exactly on listed instances -- and a step whose list is long does not differ at all."""
+    Ns, Nl = 10, 40
+    res = {}
+    for B, walls, burn in ((2048, True, 4), (4096, False, 3)):           # a short list (a fifth of 2048 instances) and a long one (a quarter of 4096)
+        state, control, t0, toff = pkg.synthetic.config2_inputs(skidpad, B)
+        for name, opts in (("default", {}), ("four", {"lat_single_max": 0})):
+            m = pkg.DecoupledTrajectoryTrackingMPC(pkg.X1(), skidpad, B, N_short=Ns, N_long=Nl, walls=walls, options=dict(opts, lat_handover=0))      # (the same cold first step in both)
+            m.set_inputs(state, control, t0, time_offset=toff)
+            m.simulate_(1)                                                # cold step: the single four-per-wavefront launch in both handles
+            m.set_option("lat_single_max", 0); m.simulate_(burn - 1)      # identical warm steps up to the one under test ...
+            m.set_option("lat_single_max", 0 if name == "four" else 1024)
+            s, c, t = m.simulate_(1)[:3]                                  # ... which differs in the option only
+            st, it, _, _ = m.solve_info()
+            res[(walls, name)] = (np.asarray(c).copy(), st.copy(), it.copy(), m.polish_info().copy())
+            m.close()
+        (cd, sd, itd, pd_), (cf, sf, itf, pf) = res[(walls, "default")], res[(walls, "four")]
+        listed = itf > 0                                                  # went through the interior point: was on the to-do list
+        differ = (cd != cf).any(axis=1)
+        both = (pd_ >= 1) & (pf >= 1)
+        print(f"B={B} walls={walls}: listed {int(listed.sum())}, controls differ in bits on {int(differ.sum())}, max |du| {np.max(np.abs(cd[both] - cf[both]) / UN):.1e}")
+        assert np.all(pkg.is_solved(sd)) and np.all(pkg.is_solved(sf))
+        assert not np.any(differ & ~listed)                               # served by the warm attempt: the same launch, the same bits
+        assert np.max(np.abs(cd[both] - cf[both]) / UN) <= 3e-7
+        assert (listed.sum() <= 1024) == (B == 2048)                      # (the two cases are what the comment above says they are)
+        if listed.sum() <= 1024: assert differ.sum() > 0                  # a short list: the other arrangement ran
+        else: assert differ.sum() == 0                                    # a long list: the same four-per-wavefront launch
